@@ -1,0 +1,297 @@
+"""Host-side LP container mirroring the fields of HiGHS' HighsLp
+(highs/lp_data/HighsLp.h) that the PDLP path reads
+(CupdlpWrapper.cpp:280-308), plus the small amount of data-format code the
+tests and bench need on a box without the reference tree: an MPS reader, the
+reference's in-code test LPs (check/SpecialLps.h, check/TestPdlp.cpp) and the
+KKT measures HiGHS reports after a solve (lp_data/HighsSolution.cpp:1043+).
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+kHighsInf = float("inf")
+
+
+@dataclass
+class HighsLp:
+    num_col: int = 0
+    num_row: int = 0
+    col_cost: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    col_lower: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    col_upper: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    row_lower: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    row_upper: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    # a_matrix_ column-wise (MatrixFormat::kColwise)
+    a_start: np.ndarray = field(default_factory=lambda: np.zeros(1, np.int32))
+    a_index: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+    a_value: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    sense: int = 1  # ObjSense::kMinimize = 1, kMaximize = -1
+    offset: float = 0.0
+    model_name: str = ""
+
+    def normalise(self):
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        self.col_cost, self.col_lower, self.col_upper = f(self.col_cost), f(self.col_lower), f(self.col_upper)
+        self.row_lower, self.row_upper, self.a_value = f(self.row_lower), f(self.row_upper), f(self.a_value)
+        self.a_start = np.ascontiguousarray(self.a_start, dtype=np.int32)
+        self.a_index = np.ascontiguousarray(self.a_index, dtype=np.int32)
+        return self
+
+    @property
+    def num_nz(self):
+        return int(self.a_start[self.num_col])
+
+    def objective_value(self, col_value):
+        """HighsLp::objectiveValue: offset + c'x (no sense factor)."""
+        return float(self.offset + np.dot(self.col_cost, col_value))
+
+    def row_activity(self, col_value):
+        out = np.zeros(self.num_row)
+        cols = np.repeat(np.arange(self.num_col), np.diff(self.a_start))
+        np.add.at(out, self.a_index, self.a_value * np.asarray(col_value)[cols])
+        return out
+
+    def to_npz(self, path):
+        np.savez_compressed(path, num_col=self.num_col, num_row=self.num_row, col_cost=self.col_cost,
+                            col_lower=self.col_lower, col_upper=self.col_upper, row_lower=self.row_lower,
+                            row_upper=self.row_upper, a_start=self.a_start, a_index=self.a_index,
+                            a_value=self.a_value, sense=self.sense, offset=self.offset,
+                            model_name=np.array(self.model_name))
+
+    @staticmethod
+    def from_npz(path):
+        z = np.load(path, allow_pickle=False)
+        return HighsLp(int(z["num_col"]), int(z["num_row"]), z["col_cost"], z["col_lower"], z["col_upper"],
+                       z["row_lower"], z["row_upper"], z["a_start"], z["a_index"], z["a_value"],
+                       int(z["sense"]), float(z["offset"]), str(z["model_name"])).normalise()
+
+    @staticmethod
+    def from_rowwise(num_col, num_row, r_start, r_index, r_value, **kw):
+        """Row-wise (CSR) input -> column-wise storage, entries of a column in
+        ascending row order (what HighsSparseMatrix::ensureColwise produces)."""
+        r_start = np.asarray(r_start, dtype=np.int64)
+        r_index = np.asarray(r_index, dtype=np.int64)
+        r_value = np.asarray(r_value, dtype=np.float64)
+        rows = np.repeat(np.arange(num_row, dtype=np.int64), np.diff(r_start))
+        order = np.argsort(r_index, kind="stable")
+        a_index = rows[order].astype(np.int32)
+        a_value = r_value[order]
+        counts = np.bincount(r_index, minlength=num_col)
+        a_start = np.zeros(num_col + 1, dtype=np.int32)
+        a_start[1:] = np.cumsum(counts)
+        return HighsLp(num_col=num_col, num_row=num_row, a_start=a_start, a_index=a_index, a_value=a_value, **kw).normalise()
+
+
+def _dense_lp(name, cost, cl, cu, rl, ru, start, index, value, sense=1, offset=0.0):
+    return HighsLp(len(cost), len(rl), np.array(cost, float), np.array(cl, float), np.array(cu, float),
+                   np.array(rl, float), np.array(ru, float), np.array(start, np.int32), np.array(index, np.int32),
+                   np.array(value, float), sense, offset, name).normalise()
+
+
+def special_lps():
+    """The in-code LPs of the reference's PDLP unit tests."""
+    inf = kHighsInf
+    return {
+        # check/SpecialLps.h:278-296, objective 31.2
+        "distillation": _dense_lp("distillation", [8, 10], [0, 0], [inf, inf], [7, 12, 6], [inf, inf, inf],
+                                  [0, 3, 6], [0, 1, 2, 0, 1, 2], [2, 3, 2, 2, 4, 1]),
+        # check/SpecialLps.h:335-353, maximise, objective 7
+        "3d": _dense_lp("3-d LP", [1, 2, 3], [0, 0, 0], [inf, inf, inf], [-inf, -inf], [3, 2],
+                        [0, 1, 2, 4], [0, 1, 0, 1], [1, 1, 2, 2], sense=-1),
+        # check/TestPdlp.cpp:150-184, boxed rows, objective -16
+        "boxed_row": _dense_lp("boxed-row", [-1, -2], [0, 0], [inf, 6], [3, -4], [10, 2],
+                               [0, 2, 4], [0, 1, 0, 1], [1, 1, 1, -1]),
+        # check/TestPdlp.cpp:186-209 -> kUnboundedOrInfeasible
+        "infeasible": _dense_lp("infeasible", [-1, -2], [0, 0], [inf, inf], [-inf], [-1],
+                                [0, 1, 2], [0, 0], [1, 1]),
+        # check/TestPdlp.cpp:211-239 -> kUnbounded (after HiGHS' KKT check)
+        "unbounded": _dense_lp("unbounded", [-1, -2], [0, 0], [inf, inf], [1], [inf],
+                               [0, 1, 2], [0, 0], [1, 1]),
+        # check/TestPdlp.cpp:260-284: LB, EQ, BX, UB rows, maximise (hot-start test)
+        "restart_lp": _dense_lp("restart-lp", [1, 3, 5], [0, 0, 0], [inf, inf, inf], [1, 3, 2, -inf],
+                                [inf, 3, 10, 5], [0, 4, 8, 12], [0, 1, 2, 3] * 3,
+                                [1, 1, 1, 1, 2, 1, 2, 2, 4, 3, 2, 3], sense=-1),
+        # check/SpecialLps.h blendingLp, objective -2850
+        "blending": _dense_lp("blending", [-8, -10], [0, 0], [inf, inf], [-inf, -inf], [120, 210],
+                              [0, 2, 4], [0, 1, 0, 1], [0.3, 0.7, 0.5, 0.5]),
+    }
+
+
+def read_mps(path):
+    """Minimal MPS reader (fixed or free format, whitespace-separated fields):
+    ROWS / COLUMNS / RHS / RANGES / BOUNDS / OBJSENSE.  Semantics follow
+    HiGHS' reader (io/HMpsFF.cpp): first N row is the objective, RHS on the
+    objective row is minus the offset, a negative UP bound on a column whose
+    lower bound is still 0 makes the lower bound -inf."""
+    import gzip
+
+    op = gzip.open if str(path).endswith(".gz") else open
+    rows, row_type, row_idx = [], [], {}
+    obj_name = None
+    cols, col_idx = [], {}
+    entries = []  # (row, col, val)
+    cost = {}
+    rhs, ranges = {}, {}
+    bounds = []
+    sense, offset, name = 1, 0.0, ""
+    section = None
+    with op(path, "rt") as f:
+        for line in f:
+            if not line.strip() or line[0] == "*":
+                continue
+            if line[0] not in " \t":
+                t = line.split()
+                section = t[0].upper()
+                if section == "NAME":
+                    name = t[1] if len(t) > 1 else ""
+                elif section in ("OBJSENSE",) and len(t) > 1:
+                    sense = -1 if t[1].upper().startswith("MAX") else 1
+                elif section == "ENDATA":
+                    break
+                continue
+            t = line.split()
+            if section == "OBJSENSE":
+                sense = -1 if t[0].upper().startswith("MAX") else 1
+            elif section == "ROWS":
+                ty, rn = t[0].upper(), t[1]
+                if ty == "N":
+                    if obj_name is None:
+                        obj_name = rn
+                    continue
+                row_idx[rn] = len(rows)
+                rows.append(rn)
+                row_type.append(ty)
+            elif section == "COLUMNS":
+                if len(t) >= 3 and t[1] == "'MARKER'":
+                    continue
+                cn = t[0]
+                if cn not in col_idx:
+                    col_idx[cn] = len(cols)
+                    cols.append(cn)
+                j = col_idx[cn]
+                for k in range(1, len(t) - 1, 2):
+                    rn, v = t[k], float(t[k + 1])
+                    if rn == obj_name:
+                        cost[j] = v
+                    elif rn in row_idx:
+                        entries.append((row_idx[rn], j, v))
+            elif section in ("RHS", "RANGES"):
+                tt = t[1:] if len(t) % 2 == 1 else t
+                for k in range(0, len(tt) - 1, 2):
+                    rn, v = tt[k], float(tt[k + 1])
+                    if section == "RHS":
+                        if rn == obj_name:
+                            offset = -v
+                        elif rn in row_idx:
+                            rhs[row_idx[rn]] = v
+                    elif rn in row_idx:
+                        ranges[row_idx[rn]] = v
+            elif section == "BOUNDS":
+                ty = t[0].upper()
+                if ty in ("FR", "MI", "PL", "BV"):
+                    cn = t[2] if len(t) >= 3 else t[1]
+                    bounds.append((ty, col_idx[cn], 0.0))
+                else:
+                    cn, v = (t[2], float(t[3])) if len(t) >= 4 else (t[1], float(t[2]))
+                    bounds.append((ty, col_idx[cn], v))
+    n, m = len(cols), len(rows)
+    inf = kHighsInf
+    rl, ru = np.zeros(m), np.zeros(m)
+    for i, ty in enumerate(row_type):
+        b = rhs.get(i, 0.0)
+        if ty == "E":
+            rl[i] = ru[i] = b
+        elif ty == "L":
+            rl[i], ru[i] = -inf, b
+        elif ty == "G":
+            rl[i], ru[i] = b, inf
+    for i, r in ranges.items():
+        ty = row_type[i]
+        if ty == "L":
+            rl[i] = ru[i] - abs(r)
+        elif ty == "G":
+            ru[i] = rl[i] + abs(r)
+        elif ty == "E":
+            if r >= 0:
+                ru[i] = rl[i] + r
+            else:
+                rl[i] = ru[i] + r
+    cl, cu = np.zeros(n), np.full(n, inf)
+    for ty, j, v in bounds:
+        if ty == "UP":
+            cu[j] = v
+            if v < 0 and cl[j] == 0:
+                cl[j] = -inf
+        elif ty == "LO":
+            cl[j] = v
+        elif ty == "FX":
+            cl[j] = cu[j] = v
+        elif ty == "FR":
+            cl[j], cu[j] = -inf, inf
+        elif ty == "MI":
+            cl[j] = -inf
+        elif ty == "PL":
+            cu[j] = inf
+        elif ty == "BV":
+            cl[j], cu[j] = 0.0, 1.0
+    c = np.zeros(n)
+    for j, v in cost.items():
+        c[j] = v
+    # build CSC with each column's entries in file order (HiGHS keeps file order)
+    ent = np.array(entries, dtype=np.float64).reshape(-1, 3)
+    order = np.argsort(ent[:, 1], kind="stable")
+    a_index = ent[order, 0].astype(np.int32)
+    a_value = ent[order, 2]
+    a_start = np.zeros(n + 1, dtype=np.int32)
+    a_start[1:] = np.cumsum(np.bincount(ent[:, 1].astype(np.int64), minlength=n))
+    return HighsLp(n, m, c, cl, cu, rl, ru, a_start, a_index, a_value, sense, offset, name).normalise()
+
+
+def kkt_measures(lp, col_value, col_dual, row_value, row_dual):
+    """The HighsInfo quantities HiGHS derives from a returned LP solution
+    (getKktFailures / getLpKktFailures, lp_data/HighsSolution.cpp): objective,
+    max primal/dual infeasibility, max primal/dual residual error and the
+    relative primal-dual objective error.  Used for the parity columns."""
+    x = np.asarray(col_value)
+    ax = lp.row_activity(x)
+    obj = lp.objective_value(x)
+    pinf_c = np.maximum(np.maximum(lp.col_lower - x, x - lp.col_upper), 0.0)
+    pinf_r = np.maximum(np.maximum(lp.row_lower - row_value, row_value - lp.row_upper), 0.0)
+    pres = np.abs(ax - row_value)
+    # dual residual: c - A'y - z = 0  (HiGHS sign convention: col_dual = c - A' row_dual)
+    cols = np.repeat(np.arange(lp.num_col), np.diff(lp.a_start))
+    aty = np.zeros(lp.num_col)
+    np.add.at(aty, cols, lp.a_value * np.asarray(row_dual)[lp.a_index])
+    dres = np.abs(lp.col_cost - aty - col_dual)
+
+    def dual_infeas(lower, upper, value, dual, tol=1e-7):
+        d = lp.sense * np.asarray(dual)
+        at_lo = np.abs(value - lower) <= tol
+        at_up = np.abs(value - upper) <= tol
+        fixed = lower >= upper
+        out = np.abs(d)  # off bounds / free
+        out = np.where(at_lo & ~at_up, np.maximum(-d, 0.0), out)
+        out = np.where(at_up & ~at_lo, np.maximum(d, 0.0), out)
+        out = np.where(fixed, 0.0, out)
+        return out
+
+    dinf_c = dual_infeas(lp.col_lower, lp.col_upper, x, col_dual)
+    dinf_r = dual_infeas(lp.row_lower, lp.row_upper, np.asarray(row_value), row_dual)
+    # dual objective
+    def bound_term(lower, upper, dual):
+        d = np.asarray(dual)
+        lo = np.where(np.isfinite(lower), lower, 0.0)
+        up = np.where(np.isfinite(upper), upper, 0.0)
+        s = lp.sense
+        return float(np.sum(np.where(s * d > 0, lo * d, up * d)))
+
+    dobj = lp.offset + bound_term(lp.col_lower, lp.col_upper, col_dual) + bound_term(lp.row_lower, lp.row_upper, row_dual)
+    return {
+        "objective_function_value": obj,
+        "dual_objective_value": dobj,
+        "max_primal_infeasibility": float(max(pinf_c.max(initial=0.0), pinf_r.max(initial=0.0))),
+        "max_dual_infeasibility": float(max(dinf_c.max(initial=0.0), dinf_r.max(initial=0.0))),
+        "max_primal_residual_error": float(pres.max(initial=0.0)),
+        "max_dual_residual_error": float(dres.max(initial=0.0)),
+        "primal_dual_objective_error": abs(obj - dobj) / (1.0 + abs(obj) + abs(dobj)),
+    }

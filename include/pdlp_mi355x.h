@@ -1,0 +1,231 @@
+/*
+ * pdlp_mi355x.h — C ABI of the MI355X-native PDLP hot path for HiGHS.
+ *
+ * This is the drop-in boundary for ONE path of ERGO-Code/HiGHS: the PDLP
+ * first-order LP solver reached through Highs::run() with solver="pdlp".
+ * The entry points below are exactly what the reference wrapper
+ * (highs/pdlp/CupdlpWrapper.cpp) would bind instead of its calls into the
+ * vendored cuPDLP-C:
+ *
+ *   reference call (file:line)                               replaced by
+ *   -------------------------------------------------------  --------------------------
+ *   formulateLP_highs      CupdlpWrapper.cpp:104,280-448  \
+ *   Init_Scaling           CupdlpWrapper.cpp:110           |
+ *   PDHG_Scale_Data        CupdlpWrapper.cpp:153           |  pdlp_mi355x_create
+ *   problem_alloc          CupdlpWrapper.cpp:161,517-585   |
+ *   PDHG_Alloc             CupdlpWrapper.cpp:167          /
+ *   LP_SolvePDHG           CupdlpWrapper.cpp:199,
+ *                          cupdlp_solver.c:1437-1498          pdlp_mi355x_run
+ *   PDHG_Destroy + frees   CupdlpWrapper.cpp:218,253-269      pdlp_mi355x_destroy
+ *   (all of the above, one shot)                              pdlp_mi355x_solve
+ *
+ * Plain C types only: pointers, sizes, doubles, int32. No C++/torch types.
+ * All input arrays are caller-owned and read-only; all output arrays are
+ * caller-allocated (mirrors highs_solution.*.resize, CupdlpWrapper.cpp:190-193).
+ * No function here ever calls exit()/abort() or throws across the boundary;
+ * failures are reported through the return code (0 = RETCODE_OK,
+ * cupdlp glbopts.h:250-256) and pdlp_mi355x_last_error().
+ *
+ * Arithmetic is fp64, indices are int32 (cupdlp_int / HighsInt default,
+ * glbopts.h:258-263).
+ */
+#ifndef PDLP_MI355X_H_
+#define PDLP_MI355X_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDLP_MI355X_ABI_VERSION 1
+
+/* Termination codes: same numbering as cuPDLP-C's termination_code
+ * (cupdlp_defs.h:61-68) so the status map of CupdlpWrapper.cpp:225-251
+ * applies unchanged. */
+enum {
+  PDLP_TERM_OPTIMAL = 0,
+  PDLP_TERM_INFEASIBLE = 1,
+  PDLP_TERM_UNBOUNDED = 2,
+  PDLP_TERM_INFEASIBLE_OR_UNBOUNDED = 3,
+  PDLP_TERM_TIMELIMIT_OR_ITERLIMIT = 4,
+  PDLP_TERM_FEASIBLE = 5
+};
+
+/* pdlp_features_off bitmask, HConst.h:417-422 */
+enum {
+  PDLP_FEATURE_SCALING_OFF = 1,
+  PDLP_FEATURE_RESTART_OFF = 2,
+  PDLP_FEATURE_ADAPTIVE_STEP_OFF = 4
+};
+
+/* The LP exactly as HiGHS holds it in HighsLp (lp_data/HighsLp.h), column-wise:
+ *   min/max  sense * (col_cost' x) + offset
+ *   s.t.     row_lower <= A x <= row_upper,  col_lower <= x <= col_upper
+ * Infinite bounds are +-inf or any |value| >= 1e20 (CupdlpWrapper.cpp:316-317). */
+typedef struct pdlp_problem {
+  int32_t num_col;
+  int32_t num_row;
+  int64_t num_nz;
+  const int32_t* a_start; /* [num_col+1] CSC column starts   (lp.a_matrix_.start_) */
+  const int32_t* a_index; /* [num_nz]    row indices         (lp.a_matrix_.index_) */
+  const double* a_value;  /* [num_nz]                         (lp.a_matrix_.value_) */
+  const double* col_cost; /* [num_col] */
+  const double* col_lower;
+  const double* col_upper;
+  const double* row_lower; /* [num_row] */
+  const double* row_upper;
+  double offset;
+  int32_t sense; /* +1 minimise, -1 maximise (ObjSense) */
+  /* Optional hot start (PDHG_PreSolve, cupdlp_solver.c:1217-1279); used only
+   * when BOTH value_valid and dual_valid are non-zero. May be NULL. */
+  const double* start_col_value; /* [num_col] */
+  const double* start_row_value; /* [num_row] */
+  const double* start_row_dual;  /* [num_row] */
+  int32_t start_value_valid;
+  int32_t start_dual_valid;
+} pdlp_problem_t;
+
+/* Options, one field per entry that getUserParamsFromOptions
+ * (CupdlpWrapper.cpp:642-717) forwards to cuPDLP-C. */
+typedef struct pdlp_params {
+  double primal_tol;      /* D_PRIMAL_TOL  <- primal_feasibility_tolerance | kkt_tolerance */
+  double dual_tol;        /* D_DUAL_TOL    <- dual_feasibility_tolerance   | kkt_tolerance */
+  double gap_tol;         /* D_GAP_TOL     <- pdlp_optimality_tolerance    | kkt_tolerance */
+  double time_limit;      /* D_TIME_LIM    <- time_limit (seconds; +inf = none) */
+  int32_t iter_limit;     /* N_ITER_LIM    <- pdlp_iteration_limit (clamped to int32) */
+  int32_t features_off;   /* pdlp_features_off bitmask (scaling/restart/adaptive) */
+  int32_t restart_method; /* pdlp_cupdlpc_restart_method; 0 disables restart */
+  int32_t log_level;      /* 0 silent, 1 summary, 2 verbose (CupdlpWrapper.cpp:839-848) */
+  /* --- MI355X-specific knobs (no reference counterpart) --- */
+  int32_t device;         /* HIP device ordinal of this process (default 0) */
+  int32_t check_interval; /* 0 = reference schedule (CUPDLP_RELEASE_INTERVAL 40) */
+  int32_t reserved[6];
+} pdlp_params_t;
+
+typedef struct pdlp_result {
+  double* col_value; /* [num_col] caller-allocated, may be NULL */
+  double* col_dual;  /* [num_col] */
+  double* row_value; /* [num_row] */
+  double* row_dual;  /* [num_row] */
+  int32_t value_valid;
+  int32_t dual_valid;
+  int32_t term_code;   /* PDLP_TERM_* */
+  int32_t term_iterate; /* 0 = last iterate, 1 = average iterate */
+  int32_t num_iter;    /* outer PDHG iterations = highs_info.pdlp_iteration_count */
+  int32_t num_trials;  /* trial steps incl. rejected ones (nStepSizeIter) */
+  int32_t num_restarts;
+  int32_t reserved_i;
+  /* cuPDLP's own view of the returned iterate (resobj, scaled-problem space
+   * mapped back with row/col scale as in cupdlp_solver.c:12-204) */
+  double primal_obj;
+  double dual_obj;
+  double primal_feas; /* ||r_p||_2 */
+  double dual_feas;   /* ||r_d||_2 */
+  double rel_gap;
+  double norm_rhs;  /* ||b||_2 of the formulated, unscaled problem */
+  double norm_cost; /* ||c||_2 */
+  /* timings, seconds (steady clock; never time(NULL)) */
+  double setup_seconds; /* formulate + scale + transpose + upload */
+  double solve_seconds; /* PDHG loop */
+  double reserved_d[4];
+} pdlp_result_t;
+
+typedef struct pdlp_mi355x_solver pdlp_mi355x_solver_t; /* opaque */
+
+/* Fill *opt with the defaults HiGHS would pass for default options
+ * (tolerances 1e-7, iteration limit INT32_MAX, time limit +inf, all features on). */
+void pdlp_mi355x_default_params(pdlp_params_t* opt);
+
+/* One-shot solve. Returns 0 on success (term_code says how it ended),
+ * non-zero on failure (-> HighsStatus::kError / kSolveError). */
+int pdlp_mi355x_solve(const pdlp_problem_t* P, const pdlp_params_t* opt,
+                      pdlp_result_t* R);
+
+/* Split form (what a long-lived Highs instance would hold). */
+int pdlp_mi355x_create(const pdlp_problem_t* P, const pdlp_params_t* opt,
+                       pdlp_mi355x_solver_t** out);
+int pdlp_mi355x_run(pdlp_mi355x_solver_t* s, pdlp_result_t* R);
+void pdlp_mi355x_destroy(pdlp_mi355x_solver_t* s);
+
+/* ---- measurement / parity hooks (device-resident state) ----------------
+ * These exist so that tests and bench.py can drive and observe the hot loop
+ * with all inputs already resident in HBM. They are not needed by HiGHS. */
+
+/* Formulated sizes: n = nCols (incl. slack columns), m = nRows, nnz, nEqs. */
+int pdlp_mi355x_dims(const pdlp_mi355x_solver_t* s, int32_t* n_cols,
+                     int32_t* n_rows, int64_t* nnz, int32_t* n_eqs);
+
+/* (Re)initialise step sizes and iterates: PDHG_Init_Step_Sizes + PDHG_Init_Variables. */
+int pdlp_mi355x_reset(pdlp_mi355x_solver_t* s);
+
+/* Run exactly n_iters accepted PDHG iterations starting from the current
+ * state, following the reference's check/restart schedule but never
+ * terminating on optimality (fixed work for timing). Reports the number of
+ * trial steps taken and the GPU time of the loop measured with HIP events on
+ * the solver's stream. */
+typedef struct pdlp_iter_stats {
+  int32_t iters;
+  int32_t trials;
+  int32_t checks;
+  int32_t restarts;
+  double gpu_ms;      /* hipEvent elapsed over the whole loop on the solver stream */
+  double wall_ms;     /* host steady clock over the same region */
+  double spmv_ax_ms;  /* filled only when profiling is enabled, else 0 */
+  double spmv_aty_ms;
+  double reserved[4];
+} pdlp_iter_stats_t;
+int pdlp_mi355x_iterate(pdlp_mi355x_solver_t* s, int32_t n_iters,
+                        pdlp_iter_stats_t* st);
+
+/* Device vector access by name for kernel-level parity tests. Names:
+ * "x","y","ax","aty" (current iterate), "x_next","y_next","ax_next","aty_next",
+ * "x_avg","y_avg","ax_avg","aty_avg","x_sum","y_sum","cost","rhs","lower",
+ * "upper","col_scale","row_scale","slack_pos","slack_neg".
+ * len must equal the vector's length (n or m). */
+int pdlp_mi355x_get_vector(pdlp_mi355x_solver_t* s, const char* name,
+                           double* host, int64_t len);
+int pdlp_mi355x_set_vector(pdlp_mi355x_solver_t* s, const char* name,
+                           const double* host, int64_t len);
+
+/* Run one named kernel stage on the current device state. Stages:
+ *  "ax"        ax      = A x            (CSR SpMV,  cupdlp_linalg.c:460 Ax)
+ *  "aty"       aty     = A' y           (CSC SpMV,  cupdlp_linalg.c:496 ATy)
+ *  "trial"     one trial step with the current step sizes (cupdlp_step.c:241-257)
+ *  "residuals" PDHG_Compute_Residuals on current+average (cupdlp_solver.c:473)
+ * scalars_out receives stage-specific scalars, n_scalars its capacity. */
+int pdlp_mi355x_stage(pdlp_mi355x_solver_t* s, const char* stage,
+                      double* scalars_out, int32_t n_scalars);
+
+/* Time `reps` launches of one kernel with HIP events on the solver stream;
+ * returns average milliseconds per launch in *avg_ms. Kernels: "spmv_ax",
+ * "spmv_aty", "primal_step", "trial" (whole trial sequence), "copy" (n+m doubles
+ * device copy, the measured HBM ceiling). */
+int pdlp_mi355x_time_kernel(pdlp_mi355x_solver_t* s, const char* kernel,
+                            int32_t reps, double* avg_ms);
+
+/* Multi-GPU (row-block sharding): the process owning rank r of
+ * world w passes the FULL problem; create() keeps only its row block.
+ * The n-vector exchange uses RCCL; id is the 128-byte ncclUniqueId obtained
+ * on rank 0 with pdlp_mi355x_comm_unique_id and broadcast by the caller
+ * (torch.distributed / MPI / anything). */
+int pdlp_mi355x_comm_unique_id(void* id128);
+int pdlp_mi355x_create_sharded(const pdlp_problem_t* P, const pdlp_params_t* opt,
+                               int32_t rank, int32_t world, const void* id128,
+                               pdlp_mi355x_solver_t** out);
+
+/* Synthetic LP generator of SURVEY §8d / BASELINE.md §3 (std::mt19937_64(seed),
+ * box 0<=x<=1, k = nnz/m draws per row, even rows equalities, odd rows <=).
+ * Two-call protocol: first call with P_out==NULL to get sizes. Arrays are
+ * malloc'ed by the library and released with pdlp_mi355x_free_problem. */
+int pdlp_mi355x_gen_synthetic(int32_t m, int32_t n, int64_t nnz_target,
+                              uint64_t seed, pdlp_problem_t* P_out);
+void pdlp_mi355x_free_problem(pdlp_problem_t* P);
+
+const char* pdlp_mi355x_last_error(void);
+int pdlp_mi355x_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PDLP_MI355X_H_ */
