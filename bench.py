@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py — PDHG iterations/s of the MI355X PDLP path on the BASELINE.json workload.
+
+  python bench.py --gpus 1 --steps K --warmup W            (default: N=1, a few seconds)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one accepted PDHG iteration (two SpMVs + the fused level-1 work +
+the device-side step-size decision), including the reference's check/restart
+schedule (every 40th iteration) — i.e. exactly what `pdlp_iteration_count`
+counts.  The LP (synthetic 1M x 1M, 8M nnz, SURVEY §8d generator, seed 1) is
+formulated, scaled and uploaded before the timed region; the K timed steps run
+with everything resident in HBM.  With N > 1 the SAME LP is row-block sharded
+over the N GPUs (strong scaling) and the A'y partials are all-reduced with RCCL.
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # BASELINE.json configs[3] — the configuration the metric is quoted on; fits one GPU (0.42 GB)
+    "b": dict(m=1_000_000, n=1_000_000, nnz=8_000_000, name="synthetic random sparse LP 1Mx1M, 8M nnz (seed 1)"),
+    # BASELINE.json configs[1]
+    "a": dict(m=100_000, n=100_000, nnz=1_000_000, name="synthetic random sparse LP 100kx100k, 1M nnz (seed 1)"),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured copy ceiling
+
+
+def algorithmic_bytes(n, m, nnz):
+    """B_iter = 2*nnz*(8+4) + 4(m+1) + 4(n+1) + 8*(15n + 12m), and the share of the
+    dominant kernel (A x+ SpMV fused with the dual step): 12 B/nnz + row pointers + read x (n) +
+    write ax (m) + dual step R4W1 (5m)."""
+    b_iter = 2 * nnz * 12 + 4 * (m + 1) + 4 * (n + 1) + 8 * (15 * n + 12 * m)
+    b_spmv_ax = 12 * nnz + 4 * (m + 1) + 8 * n + 8 * m + 8 * 5 * m
+    b_spmv_aty = 12 * nnz + 4 * (n + 1) + 8 * m + 8 * n + 8 * 4 * n
+    return b_iter, b_spmv_ax, b_spmv_aty
+
+
+def cpu_baseline(sp_struct, cfg, budget_iters):
+    """Reference CPU pdlp (single thread) on a bounded sample of the same LP: `budget_iters`
+    iterations, iterations/s over the PDHG loop only (setup excluded, as for the GPU number)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oraclelib as O
+    from highs_amd import abi
+    params = abi.default_params(kkt_tolerance=1e-4, pdlp_iteration_limit=budget_iters)
+    R = abi.ResultHandle(sp_struct.num_col, sp_struct.num_row)
+    if O.ref_available():
+        kind, fn = "reference", O.ref().pdlp_ref_solve
+    else:
+        kind, fn = "port", O.oracle().pdlp_oracle_solve
+    t0 = time.time()
+    rc = fn(C.byref(sp_struct), C.byref(params), C.byref(R.struct))
+    wall = time.time() - t0
+    if rc != 0 or R.num_iter <= 0:
+        return None
+    return {"value": R.num_iter / R.solve_seconds, "unit": "it/s", "cores": 1, "kind": kind,
+            "host_cpus": os.cpu_count(),
+            "sample": "%d PDHG iterations of the same LP (kkt 1e-4), loop time %.1f s, setup %.1f s excluded, 1 thread"
+                      % (R.num_iter, R.solve_seconds, wall - R.solve_seconds)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="b")
+    ap.add_argument("--cpu-iters", type=int, default=None, help="CPU baseline sample size (0 disables)")
+    ap.add_argument("--kernels", action="store_true", help="also print per-kernel timings to stderr")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs a torch.distributed.run launch with %d ranks" % (args.gpus, args.gpus))
+    cfg = CONFIGS[args.config]
+
+    import torch
+    from highs_amd import abi, solver
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the PDLP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    uid = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        idbuf = (C.c_uint8 * 128)()
+        if rank == 0:
+            assert solver.lib().pdlp_mi355x_comm_unique_id(idbuf) == 0, solver.lib().pdlp_mi355x_last_error()
+        t = torch.tensor(list(bytes(idbuf)), dtype=torch.uint8, device="cuda")
+        dist.broadcast(t, src=0)
+        uid = (C.c_uint8 * 128)(*t.cpu().tolist())
+
+    sp_ = solver.SyntheticProblem(cfg["m"], cfg["n"], cfg["nnz"], 1)
+    params = abi.default_params(kkt_tolerance=1e-4, device=local_rank)
+    t_setup = time.time()
+    S = solver.DeviceSolver(problem_struct=sp_.struct, params=params, rank=rank, world=world, unique_id=uid)
+    t_setup = time.time() - t_setup
+    n, m, nnz = S.n, S.m, S.nnz
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    S.iterate(args.warmup)
+    sync()
+    t0 = time.perf_counter()
+    st = S.iterate(args.steps)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    b_iter, b_ax, b_aty = algorithmic_bytes(n, m, nnz)
+    ms_step = elapsed * 1e3 / st.iters
+    # dominant kernel, timed live with HIP events on the solver's own stream
+    k_ax = S.time_kernel("spmv_ax", 50)
+    k_aty = S.time_kernel("spmv_aty", 50)
+    dom_name, dom_ms, dom_bytes = ("spmv_ax_dual", k_ax, b_ax) if k_ax >= k_aty else ("spmv_aty_interact", k_aty, b_aty)
+    if world > 1:  # each rank streams 1/world of the matrix
+        dom_bytes = dom_bytes / world
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(args.config, {}).get(dom_name)
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "PDHG iterations/sec", "value": st.iters / elapsed, "unit": "it/s", "n_gpus": world,
+        "steps": int(st.iters), "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": cfg["name"], "m": m, "n": n, "nnz": nnz,
+                   "parallelism": "single GPU" if world == 1 else "row-block x%d, RCCL all-reduce of A'y" % world,
+                   "options": "presolve=off, kkt_tolerance=1e-4, adaptive step + restarts (reference defaults)"},
+        "trial_steps": int(st.trials), "rejected_trials": int(st.trials - st.iters), "checks": int(st.checks),
+        "restarts": int(st.restarts), "setup_seconds": t_setup,
+        "iter_algorithmic_bytes": b_iter,
+        "iter_hbm_gbs": b_iter / (ms_step * 1e-3) / 1e9,
+        "iter_hbm_frac_of_peak": b_iter / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS / world,
+        "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes,
+                     "avg_launch_ms": dom_ms,
+                     "other_kernels_ms": {"spmv_ax_dual": k_ax, "spmv_aty_interact": k_aty}},
+    }
+    if args.kernels and rank == 0:
+        ks = {k: S.time_kernel(k, 50) for k in ("primal_step", "spmv_ax", "spmv_aty", "decide", "trial",
+                                                "spmv_ax_plain", "spmv_aty_plain", "copy")}
+        ks["copy_GBs"] = 2 * 512 * 2**20 / (ks["copy"] * 1e-3) / 1e9
+        print(json.dumps({"kernels_ms": ks}), file=sys.stderr)
+        out["kernels_ms"] = ks
+    if rank == 0 and world == 1:
+        budget = args.cpu_iters if args.cpu_iters is not None else (120 if args.config == "b" else 3000)
+        if budget > 0:
+            cb = cpu_baseline(sp_.struct, cfg, budget)
+            out["cpu_baseline"] = cb
+            if cb:
+                out["speedup_vs_cpu_pdlp"] = out["value"] / cb["value"]
+    S.close()
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

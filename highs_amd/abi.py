@@ -105,6 +105,20 @@ class PdlpIterStats(C.Structure):
     ]
 
 
+class PdlpPrepared(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("m", C.c_int32), ("n_eqs", C.c_int32), ("n_orig", C.c_int32),
+        ("nnz", C.c_int64),
+        ("csr_beg", c_i32p), ("csr_idx", c_i32p), ("csr_val", c_f64p),
+        ("csc_beg", c_i32p), ("csc_idx", c_i32p), ("csc_val", c_f64p),
+        ("cost", c_f64p), ("rhs", c_f64p), ("lower", c_f64p), ("upper", c_f64p),
+        ("col_scale", c_f64p), ("row_scale", c_f64p),
+        ("row_kind", c_i32p), ("row_new_idx", c_i32p),
+        ("norm_cost", C.c_double), ("norm_rhs", C.c_double), ("mat_norm_inf", C.c_double),
+        ("spmv_blocks_ax", C.c_int32), ("spmv_blocks_aty", C.c_int32),
+    ]
+
+
 def default_params(**kw):
     """Defaults HiGHS passes for default options (CupdlpWrapper.cpp:642-717;
     kkt_tolerance default 1e-7, HConst.h:345)."""

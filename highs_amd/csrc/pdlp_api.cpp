@@ -1,0 +1,205 @@
+// pdlp_api.cpp — the extern "C" boundary (include/pdlp_mi355x.h).  Exceptions
+// never cross it: every entry point catches, records the message for
+// pdlp_mi355x_last_error() and returns non-zero (-> HighsStatus::kError).
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <string>
+
+#include "pdlp_solver.hpp"
+
+struct pdlp_mi355x_solver {
+  pdlp::Solver* impl;
+};
+
+namespace {
+thread_local std::string g_lastError;
+
+template <typename Fn>
+int guarded(Fn&& fn) {
+  try {
+    fn();
+    return 0;
+  } catch (const std::exception& e) {
+    g_lastError = e.what();
+  } catch (...) {
+    g_lastError = "unknown exception";
+  }
+  return 1;
+}
+}  // namespace
+
+namespace {
+template <typename T>
+T* dupVec(const std::vector<T>& v) {
+  T* p = (T*)malloc(sizeof(T) * (v.size() ? v.size() : 1));
+  if (!v.empty()) memcpy(p, v.data(), sizeof(T) * v.size());
+  return p;
+}
+}  // namespace
+
+extern "C" {
+
+const char* pdlp_mi355x_last_error(void) { return g_lastError.c_str(); }
+int pdlp_mi355x_abi_version(void) { return PDLP_MI355X_ABI_VERSION; }
+
+void pdlp_mi355x_default_params(pdlp_params_t* opt) {
+  if (!opt) return;
+  memset(opt, 0, sizeof(*opt));
+  opt->primal_tol = 1e-7;  // kDefaultKktTolerance, HConst.h:345
+  opt->dual_tol = 1e-7;
+  opt->gap_tol = 1e-7;
+  opt->time_limit = std::numeric_limits<double>::infinity();
+  opt->iter_limit = std::numeric_limits<int32_t>::max();
+  opt->features_off = 0;
+  opt->restart_method = 1;
+  opt->log_level = 0;
+  opt->device = 0;
+  opt->check_interval = 0;
+}
+
+int pdlp_mi355x_create(const pdlp_problem_t* P, const pdlp_params_t* opt, pdlp_mi355x_solver_t** out) {
+  return pdlp_mi355x_create_sharded(P, opt, 0, 1, nullptr, out);
+}
+
+int pdlp_mi355x_create_sharded(const pdlp_problem_t* P, const pdlp_params_t* opt, int32_t rank, int32_t world,
+                               const void* id128, pdlp_mi355x_solver_t** out) {
+  return guarded([&] {
+    if (!P || !opt || !out) throw std::runtime_error("null argument");
+    *out = nullptr;
+    pdlp::Solver* s = new pdlp::Solver(*P, *opt, rank, world, id128);
+    *out = new pdlp_mi355x_solver{s};
+  });
+}
+
+int pdlp_mi355x_run(pdlp_mi355x_solver_t* s, pdlp_result_t* R) {
+  return guarded([&] {
+    if (!s || !s->impl) throw std::runtime_error("null solver");
+    s->impl->run(R);
+  });
+}
+
+void pdlp_mi355x_destroy(pdlp_mi355x_solver_t* s) {
+  if (!s) return;
+  try {
+    delete s->impl;
+  } catch (...) {
+  }
+  delete s;
+}
+
+int pdlp_mi355x_solve(const pdlp_problem_t* P, const pdlp_params_t* opt, pdlp_result_t* R) {
+  pdlp_mi355x_solver_t* s = nullptr;
+  int rc = pdlp_mi355x_create(P, opt, &s);
+  if (rc == 0) rc = pdlp_mi355x_run(s, R);
+  pdlp_mi355x_destroy(s);
+  return rc;
+}
+
+int pdlp_mi355x_dims(const pdlp_mi355x_solver_t* s, int32_t* n, int32_t* m, int64_t* nnz, int32_t* nEqs) {
+  return guarded([&] {
+    if (!s || !s->impl) throw std::runtime_error("null solver");
+    s->impl->dims(n, m, nnz, nEqs);
+  });
+}
+
+int pdlp_mi355x_reset(pdlp_mi355x_solver_t* s) {
+  return guarded([&] {
+    if (!s || !s->impl) throw std::runtime_error("null solver");
+    s->impl->reset();
+  });
+}
+
+int pdlp_mi355x_iterate(pdlp_mi355x_solver_t* s, int32_t n_iters, pdlp_iter_stats_t* st) {
+  return guarded([&] {
+    if (!s || !s->impl) throw std::runtime_error("null solver");
+    s->impl->iterate(n_iters, st);
+  });
+}
+
+int pdlp_mi355x_get_vector(pdlp_mi355x_solver_t* s, const char* name, double* host, int64_t len) {
+  return guarded([&] {
+    if (!s || !s->impl || !name || !host) throw std::runtime_error("null argument");
+    s->impl->getVector(name, host, len);
+  });
+}
+
+int pdlp_mi355x_set_vector(pdlp_mi355x_solver_t* s, const char* name, const double* host, int64_t len) {
+  return guarded([&] {
+    if (!s || !s->impl || !name || !host) throw std::runtime_error("null argument");
+    s->impl->setVector(name, host, len);
+  });
+}
+
+int pdlp_mi355x_stage(pdlp_mi355x_solver_t* s, const char* stage, double* scalars_out, int32_t n_scalars) {
+  return guarded([&] {
+    if (!s || !s->impl || !stage) throw std::runtime_error("null argument");
+    s->impl->stage(stage, scalars_out, n_scalars);
+  });
+}
+
+int pdlp_mi355x_time_kernel(pdlp_mi355x_solver_t* s, const char* kernel, int32_t reps, double* avg_ms) {
+  return guarded([&] {
+    if (!s || !s->impl || !kernel || !avg_ms) throw std::runtime_error("null argument");
+    *avg_ms = s->impl->timeKernel(kernel, reps);
+  });
+}
+
+int pdlp_mi355x_host_prepare(const pdlp_problem_t* P, const pdlp_params_t* opt, pdlp_prepared_t* out) {
+  return guarded([&] {
+    if (!P || !opt || !out) throw std::runtime_error("null argument");
+    memset(out, 0, sizeof(*out));
+    pdlp::StandardForm F;
+    pdlp::formulate(*P, F);
+    if (!(opt->features_off & PDLP_FEATURE_SCALING_OFF)) pdlp::scale(F);
+    pdlp::finalize(F);
+    out->n = F.n; out->m = F.m; out->n_eqs = F.nEqs; out->n_orig = F.n0; out->nnz = F.nnz;
+    out->csr_beg = dupVec(F.csr.beg); out->csr_idx = dupVec(F.csr.idx); out->csr_val = dupVec(F.csr.val);
+    out->csc_beg = dupVec(F.cscSorted.beg); out->csc_idx = dupVec(F.cscSorted.idx); out->csc_val = dupVec(F.cscSorted.val);
+    out->cost = dupVec(F.cost); out->rhs = dupVec(F.rhs); out->lower = dupVec(F.lower); out->upper = dupVec(F.upper);
+    out->col_scale = dupVec(F.colScale); out->row_scale = dupVec(F.rowScale);
+    out->row_kind = dupVec(F.rowKind); out->row_new_idx = dupVec(F.rowNewIdx);
+    out->norm_cost = F.normCost; out->norm_rhs = F.normRhs; out->mat_norm_inf = F.matNormInf;
+    out->spmv_blocks_ax = pdlp::planStream(F.csr.beg, F.m, pdlp::kChunk, pdlp::kMaxMajorsPerBlock).nBlocks;
+    out->spmv_blocks_aty = pdlp::planStream(F.cscSorted.beg, F.n, pdlp::kChunk, pdlp::kMaxMajorsPerBlock).nBlocks;
+  });
+}
+
+void pdlp_mi355x_free_prepared(pdlp_prepared_t* o) {
+  if (!o) return;
+  free(o->csr_beg); free(o->csr_idx); free(o->csr_val); free(o->csc_beg); free(o->csc_idx); free(o->csc_val);
+  free(o->cost); free(o->rhs); free(o->lower); free(o->upper); free(o->col_scale); free(o->row_scale);
+  free(o->row_kind); free(o->row_new_idx);
+  memset(o, 0, sizeof(*o));
+}
+
+int pdlp_mi355x_row_partition(const pdlp_prepared_t* prep, int32_t world, int32_t* offsets) {
+  return guarded([&] {
+    if (!prep || !offsets || world < 1) throw std::runtime_error("bad argument");
+    pdlp::Compressed csr;
+    csr.beg.assign(prep->csr_beg, prep->csr_beg + prep->m + 1);
+    std::vector<int32_t> off = pdlp::rowPartition(csr, prep->m, world);
+    for (int32_t g = 0; g <= world; ++g) offsets[g] = off[g];
+  });
+}
+
+int64_t pdlp_mi355x_sizeof(int32_t which) {
+  switch (which) {
+    case 0: return sizeof(pdlp_problem_t);
+    case 1: return sizeof(pdlp_params_t);
+    case 2: return sizeof(pdlp_result_t);
+    case 3: return sizeof(pdlp_iter_stats_t);
+    case 4: return sizeof(pdlp_prepared_t);
+    default: return -1;
+  }
+}
+
+int pdlp_mi355x_comm_unique_id(void* id128) {
+  return guarded([&] {
+    if (!id128) throw std::runtime_error("null argument");
+    pdlp::Comm::uniqueId(id128);
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,262 @@
+// pdlp_host.cpp — see pdlp_host.hpp.
+#include "pdlp_host.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <stdexcept>
+
+namespace pdlp {
+
+namespace {
+constexpr double kBoundInf = 1e20;  // CupdlpWrapper.cpp:316-317,375-378
+const double kInf = std::numeric_limits<double>::infinity();
+}  // namespace
+
+void formulate(const pdlp_problem_t& P, StandardForm& F) {
+  if (P.num_col < 0 || P.num_row < 0) throw std::runtime_error("negative dimensions");
+  if (P.num_col > 0 && (!P.a_start || !P.col_cost || !P.col_lower || !P.col_upper))
+    throw std::runtime_error("null column arrays");
+  if (P.num_row > 0 && (!P.row_lower || !P.row_upper)) throw std::runtime_error("null row arrays");
+  const int32_t n0 = P.num_col, m = P.num_row;
+  const int64_t nnz0 = n0 > 0 ? P.a_start[n0] : 0;
+  if (nnz0 > 0 && (!P.a_index || !P.a_value)) throw std::runtime_error("null matrix arrays");
+  F = StandardForm();
+  F.n0 = n0;
+  F.m = m;
+  F.offset = P.offset;
+  F.sense = P.sense < 0 ? -1.0 : 1.0;
+
+  // Classify rows.  Ranged AND free rows become  a'x - z = 0  with a bounded
+  // slack z (CupdlpWrapper.cpp:320-343).
+  F.rowKind.resize(m);
+  F.rowNewIdx.resize(m);
+  int32_t nSlack = 0, nEq = 0;
+  for (int32_t i = 0; i < m; ++i) {
+    const bool lo = P.row_lower[i] > -kBoundInf, up = P.row_upper[i] < kBoundInf;
+    RowKind k;
+    if (lo && up && P.row_lower[i] == P.row_upper[i]) k = kRowEq;
+    else if (lo && !up) k = kRowGeq;
+    else if (!lo && up) k = kRowLeq;
+    else k = kRowBound;
+    F.rowKind[i] = k;
+    if (k == kRowEq || k == kRowBound) ++nEq;
+    if (k == kRowBound) ++nSlack;
+  }
+  if ((int64_t)n0 + nSlack > std::numeric_limits<int32_t>::max() ||
+      nnz0 + nSlack > std::numeric_limits<int32_t>::max())
+    throw std::runtime_error("problem exceeds 32-bit index range");
+  F.n = n0 + nSlack;
+  F.nEqs = nEq;
+  F.nnz = nnz0 + nSlack;
+
+  // Row permutation: equalities (EQ, BOUND) first in original order, then
+  // inequalities; LEQ rows are negated into GEQ form (:382-404).
+  F.rhs.assign(m, 0.0);
+  int32_t eqPos = 0, inPos = nEq;
+  for (int32_t i = 0; i < m; ++i) {
+    switch (F.rowKind[i]) {
+      case kRowEq: F.rowNewIdx[i] = eqPos; F.rhs[eqPos++] = P.row_lower[i]; break;
+      case kRowBound: F.rowNewIdx[i] = eqPos; F.rhs[eqPos++] = 0.0; break;
+      case kRowLeq: F.rowNewIdx[i] = inPos; F.rhs[inPos++] = -P.row_upper[i]; break;
+      default: F.rowNewIdx[i] = inPos; F.rhs[inPos++] = P.row_lower[i]; break;
+    }
+  }
+
+  // Columns: cost takes the sense, bounds beyond +-1e20 become infinite.
+  F.cost.assign(F.n, 0.0);
+  F.lower.resize(F.n);
+  F.upper.resize(F.n);
+  for (int32_t j = 0; j < n0; ++j) {
+    F.cost[j] = P.col_cost[j] * F.sense;
+    F.lower[j] = P.col_lower[j];
+    F.upper[j] = P.col_upper[j];
+  }
+  for (int32_t i = 0, j = n0; i < m; ++i)
+    if (F.rowKind[i] == kRowBound) { F.lower[j] = P.row_lower[i]; F.upper[j] = P.row_upper[i]; ++j; }
+  for (int32_t j = 0; j < F.n; ++j) {
+    if (F.lower[j] < -kBoundInf) F.lower[j] = -kInf;
+    if (F.upper[j] > kBoundInf) F.upper[j] = kInf;
+  }
+
+  // Matrix in the reference's entry order: per column, equality-type entries
+  // first, then inequality entries (LEQ negated) (:413-436); one -1 per slack.
+  Compressed& A = F.csc;
+  A.beg.resize((size_t)F.n + 1);
+  A.idx.resize((size_t)F.nnz);
+  A.val.resize((size_t)F.nnz);
+  int64_t k = 0;
+  for (int32_t j = 0; j < n0; ++j) {
+    A.beg[j] = (int32_t)k;
+    const int32_t b = P.a_start[j], e = P.a_start[j + 1];
+    if (e < b) throw std::runtime_error("a_start not monotone");
+    for (int32_t p = b; p < e; ++p) {
+      const int32_t r = P.a_index[p];
+      if (r < 0 || r >= m) throw std::runtime_error("row index out of range");
+      const int32_t kind = F.rowKind[r];
+      if (kind == kRowEq || kind == kRowBound) { A.idx[k] = F.rowNewIdx[r]; A.val[k] = P.a_value[p]; ++k; }
+    }
+    for (int32_t p = b; p < e; ++p) {
+      const int32_t r = P.a_index[p];
+      const int32_t kind = F.rowKind[r];
+      if (kind == kRowLeq) { A.idx[k] = F.rowNewIdx[r]; A.val[k] = -P.a_value[p]; ++k; }
+      else if (kind == kRowGeq) { A.idx[k] = F.rowNewIdx[r]; A.val[k] = P.a_value[p]; ++k; }
+    }
+  }
+  for (int32_t i = 0, j = n0; i < m; ++i)
+    if (F.rowKind[i] == kRowBound) { A.beg[j] = (int32_t)k; A.idx[k] = F.rowNewIdx[i]; A.val[k] = -1.0; ++k; ++j; }
+  A.beg[F.n] = (int32_t)k;
+
+  // Termination norms are those of the UNSCALED formulated data (Init_Scaling
+  // runs before PDHG_Scale_Data, CupdlpWrapper.cpp:110 vs :153).
+  double s = 0.0;
+  for (double v : F.cost) s += v * v;
+  F.normCost = std::sqrt(s);
+  s = 0.0;
+  for (double v : F.rhs) s += v * v;
+  F.normRhs = std::sqrt(s);
+  F.colScale.assign(F.n, 1.0);
+  F.rowScale.assign(m, 1.0);
+}
+
+namespace {
+// One diagonal rescaling D_r^-1 A D_c^-1 with the reference's operation order
+// (scale_problem, cupdlp_scaling.c:17-45): rows first, then columns.
+void applyScaling(StandardForm& F, const std::vector<double>& cs, const std::vector<double>& rs) {
+  Compressed& A = F.csc;
+  for (int32_t j = 0; j < F.n; ++j) {
+    F.cost[j] /= cs[j];
+    F.lower[j] *= cs[j];
+    F.upper[j] *= cs[j];
+    F.colScale[j] *= cs[j];
+  }
+  for (int32_t i = 0; i < F.m; ++i) {
+    F.rhs[i] /= rs[i];
+    F.rowScale[i] *= rs[i];
+  }
+  for (int32_t j = 0; j < F.n; ++j) {
+    const double c = cs[j];
+    for (int32_t p = A.beg[j]; p < A.beg[j + 1]; ++p) A.val[p] = (A.val[p] / rs[A.idx[p]]) / c;
+  }
+}
+}  // namespace
+
+void scale(StandardForm& F, int ruizTimes, double pcAlpha) {
+  Compressed& A = F.csc;
+  std::vector<double> cs(F.n), rs(F.m);
+  // Ruiz equilibration in the infinity norm (cupdlp_ruiz_scaling :47-120)
+  for (int it = 0; it < ruizTimes; ++it) {
+    std::fill(rs.begin(), rs.end(), 0.0);
+    for (int32_t j = 0; j < F.n; ++j) {
+      double mx = 0.0;
+      for (int32_t p = A.beg[j]; p < A.beg[j + 1]; ++p) {
+        const double a = std::fabs(A.val[p]);
+        if (a > mx) mx = a;
+        if (rs[A.idx[p]] < a) rs[A.idx[p]] = a;
+      }
+      cs[j] = mx == 0.0 ? 1.0 : std::sqrt(mx);
+    }
+    for (int32_t i = 0; i < F.m; ++i) rs[i] = rs[i] == 0.0 ? 1.0 : std::sqrt(rs[i]);
+    applyScaling(F, cs, rs);
+  }
+  // Pock-Chambolle (cupdlp_pc_scaling :174-231).  The reference fixes alpha=1
+  // (Init_Scaling :409), for which pow(|a|,alpha) and pow(s,1/alpha) are exact
+  // identities; the general form is kept for other alpha.
+  if (pcAlpha < 0.0 || pcAlpha > 2.0) throw std::runtime_error("PC alpha must be in [0,2]");
+  if (F.m > 0) {
+    std::fill(rs.begin(), rs.end(), 0.0);
+    for (int32_t j = 0; j < F.n; ++j) {
+      double sc = 0.0;
+      for (int32_t p = A.beg[j]; p < A.beg[j + 1]; ++p) {
+        const double a = std::fabs(A.val[p]);
+        sc += std::pow(a, pcAlpha);
+        rs[A.idx[p]] += std::pow(a, 2.0 - pcAlpha);
+      }
+      sc = std::sqrt(std::pow(sc, 1.0 / pcAlpha));
+      cs[j] = sc == 0.0 ? 1.0 : sc;
+    }
+    for (int32_t i = 0; i < F.m; ++i) {
+      const double r = std::sqrt(std::pow(rs[i], 1.0 / (2.0 - pcAlpha)));
+      rs[i] = r == 0.0 ? 1.0 : r;
+    }
+  } else {
+    std::fill(cs.begin(), cs.end(), 1.0);
+  }
+  applyScaling(F, cs, rs);
+  F.scaled = true;
+}
+
+namespace {
+// Counting transpose: output majors hold their entries in ascending input-major order.
+void transpose(const Compressed& in, int32_t nMajorIn, int32_t nMajorOut, Compressed& out) {
+  const int64_t nnz = in.beg[nMajorIn];
+  out.beg.assign((size_t)nMajorOut + 1, 0);
+  out.idx.resize((size_t)nnz);
+  out.val.resize((size_t)nnz);
+  for (int64_t p = 0; p < nnz; ++p) ++out.beg[in.idx[p] + 1];
+  for (int32_t i = 0; i < nMajorOut; ++i) out.beg[i + 1] += out.beg[i];
+  std::vector<int32_t> pos(out.beg.begin(), out.beg.end() - 1);
+  for (int32_t j = 0; j < nMajorIn; ++j)
+    for (int32_t p = in.beg[j]; p < in.beg[j + 1]; ++p) {
+      const int32_t q = pos[in.idx[p]]++;
+      out.idx[q] = j;
+      out.val[q] = in.val[p];
+    }
+}
+}  // namespace
+
+void finalize(StandardForm& F) {
+  transpose(F.csc, F.n, F.m, F.csr);        // rows, ascending column
+  transpose(F.csr, F.m, F.n, F.cscSorted);  // columns, ascending row
+  double mx = 0.0;
+  for (double v : F.csc.val) mx = std::max(mx, std::fabs(v));
+  F.matNormInf = mx;
+}
+
+std::vector<int32_t> rowPartition(const Compressed& csr, int32_t m, int32_t world) {
+  std::vector<int32_t> off((size_t)world + 1, m);
+  off[0] = 0;
+  const int64_t nnz = csr.beg[m];
+  // weight = nnz + rows so that empty rows still spread evenly
+  const double total = (double)nnz + (double)m;
+  int32_t r = 0;
+  for (int32_t g = 1; g < world; ++g) {
+    const double target = total * (double)g / (double)world;
+    while (r < m && (double)csr.beg[r] + (double)r < target) ++r;
+    off[g] = r;
+  }
+  off[world] = m;
+  return off;
+}
+
+void extractSlab(const StandardForm& F, int32_t r0, int32_t r1, Compressed& csrSlab, Compressed& cscSlab) {
+  const int32_t mLoc = r1 - r0;
+  const int32_t b = F.csr.beg[r0], e = F.csr.beg[r1];
+  csrSlab.beg.resize((size_t)mLoc + 1);
+  for (int32_t i = 0; i <= mLoc; ++i) csrSlab.beg[i] = F.csr.beg[r0 + i] - b;
+  csrSlab.idx.assign(F.csr.idx.begin() + b, F.csr.idx.begin() + e);
+  csrSlab.val.assign(F.csr.val.begin() + b, F.csr.val.begin() + e);
+  transpose(csrSlab, mLoc, F.n, cscSlab);
+}
+
+StreamPlan planStream(const std::vector<int32_t>& beg, int32_t nMajor, int32_t chunk, int32_t maxMajorsPerBlock) {
+  StreamPlan plan;
+  plan.blockBeg.push_back(0);
+  int32_t start = 0;
+  while (start < nMajor) {
+    const int32_t base = beg[start];
+    int32_t end = start;
+    // extend while the block stays within `chunk` nonzeros and the major cap
+    while (end < nMajor && end - start < maxMajorsPerBlock && beg[end + 1] - base <= chunk) ++end;
+    if (end == start) {  // a single major longer than chunk
+      end = start + 1;
+      ++plan.nLong;
+    }
+    plan.blockBeg.push_back(end);
+    start = end;
+  }
+  plan.nBlocks = (int32_t)plan.blockBeg.size() - 1;
+  return plan;
+}
+
+}  // namespace pdlp

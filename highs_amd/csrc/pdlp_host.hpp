@@ -1,0 +1,67 @@
+// pdlp_host.hpp — host-side problem preparation for the MI355X PDLP path.
+//
+// Turns the caller's HighsLp-shaped arrays (pdlp_problem_t) into the standard
+// form cuPDLP-C iterates on, with the same conventions as the reference so
+// that results are comparable row for row:
+//   formulate      <-> formulateLP_highs          highs/pdlp/CupdlpWrapper.cpp:280-448
+//   scale          <-> Init_Scaling/PDHG_Scale_Data  cupdlp_scaling.c:395-425,233-393
+//   build_csr/csc  <-> csc2csr / cupdlp_dcs_transpose cupdlp_utils.c:1222, cupdlp_cs.c:189
+//   row partition  <-> (no reference: SURVEY §8e multi-GPU row blocks)
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/pdlp_mi355x.h"
+
+namespace pdlp {
+
+enum RowKind : int32_t { kRowEq = 0, kRowLeq = 1, kRowGeq = 2, kRowBound = 3 };  // cupdlp_defs.h types
+
+// Sparse matrix in compressed form; "major" is rows for CSR, columns for CSC.
+struct Compressed {
+  std::vector<int32_t> beg;   // [nMajor+1]
+  std::vector<int32_t> idx;   // [nnz] minor index
+  std::vector<double> val;    // [nnz]
+};
+
+struct StandardForm {
+  int32_t n = 0;      // columns incl. one slack per BOUND row
+  int32_t m = 0;      // rows
+  int32_t n0 = 0;     // original columns
+  int32_t nEqs = 0;   // EQ + BOUND rows, permuted first
+  int64_t nnz = 0;
+  Compressed csc;     // reference column order (EQ/BOUND entries first)
+  Compressed csr;     // rows with ascending column index
+  Compressed cscSorted;  // columns with ascending row index (device copy for A'y)
+  std::vector<double> cost, rhs, lower, upper;
+  std::vector<int32_t> rowKind;    // per ORIGINAL row
+  std::vector<int32_t> rowNewIdx;  // original row -> permuted row
+  std::vector<double> colScale, rowScale;
+  bool scaled = false;
+  double offset = 0.0, sense = 1.0;
+  double normCost = 0.0, normRhs = 0.0;  // of the unscaled formulated data
+  double matNormInf = 0.0;               // max |a_ij| of the (scaled) matrix
+};
+
+// Throws std::runtime_error on malformed input.
+void formulate(const pdlp_problem_t& P, StandardForm& F);
+void scale(StandardForm& F, int ruizTimes = 10, double pcAlpha = 1.0);
+void finalize(StandardForm& F);  // CSR + row-sorted CSC + matNormInf
+
+// Contiguous row blocks balanced by nonzeros: returns world+1 row offsets.
+std::vector<int32_t> rowPartition(const Compressed& csr, int32_t m, int32_t world);
+
+// Row slab [r0,r1) of F as (csr slab, csc-of-slab with local row indices).
+void extractSlab(const StandardForm& F, int32_t r0, int32_t r1, Compressed& csrSlab, Compressed& cscSlab);
+
+// CSR-adaptive launch plan: consecutive majors are grouped into work blocks of
+// at most `chunk` nonzeros; a major longer than `chunk` gets a block of its own.
+struct StreamPlan {
+  std::vector<int32_t> blockBeg;  // [nBlocks+1] first major of each block
+  int32_t nBlocks = 0;
+  int32_t nLong = 0;              // blocks that hold a single over-long major
+};
+StreamPlan planStream(const std::vector<int32_t>& beg, int32_t nMajor, int32_t chunk, int32_t maxMajorsPerBlock);
+
+}  // namespace pdlp

@@ -1,0 +1,518 @@
+// pdlp_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the PDLP hot loop.
+//
+// The loop is HBM-bound (two fp64 SpMVs + level-1 passes, ~0.1 flop/byte), so
+// the rules that matter are: coalesced streaming of the CSR/CSC arrays, many
+// independent loads in flight per lane, no re-reads (every level-1 pass is
+// fused into the SpMV that produces or consumes the vector), deterministic
+// two-stage reductions (no float atomics), and no host round trip per trial.
+// MFMA is not used: nothing here is a dense contraction.
+//
+// Compiled with -ffp-contract=off: the element-wise updates then round exactly
+// like the reference's scalar CPU loops (mul, then add), which makes x+, y+,
+// A x+ and A' y+ of a trial step bit-identical to the oracle; only the
+// reductions (tree order here, left-to-right there) differ in the last bits.
+#include "pdlp_kernels.hpp"
+
+#include <cmath>
+
+namespace pdlp {
+
+namespace {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ double waveSum(double v) {
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+  return v;
+}
+
+// Deterministic block sum for blocks of NT threads; result valid in thread 0.
+template <int NT>
+__device__ __forceinline__ double blockSum(double v, double* scratch /* [NT/64] */) {
+  v = waveSum(v);
+  const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+  if (lane == 0) scratch[w] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < NT / kWave; ++i) r += scratch[i];
+  }
+  __syncthreads();
+  return r;
+}
+
+// LDS slot of the q-th staged product: one pad double per 8 keeps the
+// thread-per-row read-back (stride = row length, typically 8..16 doubles)
+// off a single bank pair.
+__device__ __forceinline__ int slot(int q) { return q + (q >> 3); }
+
+enum Epilogue { kPlain = 0, kDualStep = 1, kAtyInteract = 2, kAtyPartial = 3 };
+
+struct SpmvArgs {
+  SpmvMat A;
+  const DevState* st;  // nullptr for kPlain
+  // kPlain / kAtyPartial
+  const double* in;
+  double* out;
+  // iteration vectors (kDualStep / kAtyInteract / kAtyPartial)
+  IterVecs v;
+  double* part0;  // dY^2 (dual) | dX^2 (aty)
+  double* part1;  // interaction (aty)
+};
+
+// CSR-adaptive SpMV (stream + long-row paths) with a fused, major-local epilogue.
+// One work block = up to kChunk consecutive nonzeros belonging to whole majors.
+//   phase 1: all lanes stream val[]/idx[] with unit stride (coalesced), gather
+//            the input vector, and park the products in LDS;
+//   phase 2: one lane per major adds its products left to right (the
+//            reference's summation order) and runs the epilogue.
+template <int EPI>
+__global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
+  const DevState* st = a.st;
+  if (EPI != kPlain && st->halted) return;
+  __shared__ double prod[kChunk + kChunk / 8 + 8];
+  __shared__ double scratch[2][kSpmvThreads / kWave];
+
+  const int tid = threadIdx.x;
+  const int blk = blockIdx.x;
+  const int r0 = a.A.blockBeg[blk], r1 = a.A.blockBeg[blk + 1];
+  const int p0 = a.A.beg[r0], p1 = a.A.beg[r1];
+  const int32_t* __restrict__ idx = a.A.idx;
+  const double* __restrict__ val = a.A.val;
+
+  int cur = 0, nxt = 1;
+  double sigma = 0.0, avgW = 0.0;
+  if (EPI != kPlain) {
+    cur = st->cur;
+    nxt = cur ^ 1;
+    sigma = st->sigma;
+    avgW = st->avgW;
+  }
+  const double* __restrict__ in;
+  if (EPI == kPlain) in = a.in;
+  else if (EPI == kDualStep) in = a.v.x[nxt];
+  else in = a.v.y[nxt];
+
+  double acc0 = 0.0, acc1 = 0.0;  // per-thread epilogue partials
+
+  auto epilogue = [&](int r, double s) {
+    if (EPI == kPlain || EPI == kAtyPartial) {
+      a.out[r] = s;
+    } else if (EPI == kDualStep) {
+      // y+ = proj(y + sigma*(b - 2 A x+ + A x)), cupdlp_step.c:43-69
+      const double yv = a.v.y[cur][r];
+      if (avgW != 0.0) a.v.ySum[r] += avgW * yv;  // deferred PDHG_Update_Average (step.c:438)
+      double t = yv;
+      t += sigma * a.v.rhs[r];
+      t += (-2.0 * sigma) * s;
+      t += sigma * a.v.ax[cur][r];
+      if (r + a.v.rowOffset >= a.v.nEqs) t = t > 0.0 ? t : 0.0;
+      a.v.ax[nxt][r] = s;
+      a.v.y[nxt][r] = t;
+      const double d = yv - t;
+      acc0 += d * d;
+    } else {  // kAtyInteract: cupdlp_linalg.c:772-801
+      const double dx = a.v.x[cur][r] - a.v.x[nxt][r];
+      const double da = a.v.aty[cur][r] - s;
+      a.v.aty[nxt][r] = s;
+      acc0 += dx * dx;
+      acc1 += dx * da;
+    }
+  };
+
+  if (r1 - r0 == 1 && p1 - p0 > kChunk) {
+    // long major: the whole block strides over it; tree-reduced (deterministic)
+    double s = 0.0;
+    for (int p = p0 + tid; p < p1; p += kSpmvThreads) s += val[p] * in[idx[p]];
+    s = blockSum<kSpmvThreads>(s, scratch[0]);
+    if (tid == 0) epilogue(r0, s);
+  } else {
+    const int cnt = p1 - p0;
+#pragma unroll 8
+    for (int q = tid; q < cnt; q += kSpmvThreads) prod[slot(q)] = val[p0 + q] * in[idx[p0 + q]];
+    __syncthreads();
+    for (int r = r0 + tid; r < r1; r += kSpmvThreads) {
+      const int qb = a.A.beg[r] - p0, qe = a.A.beg[r + 1] - p0;
+      double s = 0.0;
+      for (int q = qb; q < qe; ++q) s += prod[slot(q)];
+      epilogue(r, s);
+    }
+  }
+
+  if (EPI == kDualStep) {
+    const double t = blockSum<kSpmvThreads>(acc0, scratch[0]);
+    if (tid == 0) a.part0[blk] = t;
+  } else if (EPI == kAtyInteract) {
+    const double t0 = blockSum<kSpmvThreads>(acc0, scratch[0]);
+    const double t1 = blockSum<kSpmvThreads>(acc1, scratch[1]);
+    if (tid == 0) { a.part0[blk] = t0; a.part1[blk] = t1; }
+  }
+}
+
+// x+ = clamp(x - tau (c - A'y), l, u): cupdlp_step.c:16-40, rounding as the CPU branch.
+__global__ __launch_bounds__(kVecThreads) void k_primal_step(const IterVecs v, const DevState* st) {
+  if (st->halted) return;
+  const int cur = st->cur, nxt = cur ^ 1;
+  const double tau = st->tau, avgW = st->avgW;
+  const double* __restrict__ x = v.x[cur];
+  const double* __restrict__ aty = v.aty[cur];
+  double* __restrict__ xn = v.x[nxt];
+  const int stride = gridDim.x * blockDim.x;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < v.n; j += stride) {
+    const double xv = x[j];
+    if (avgW != 0.0) v.xSum[j] += avgW * xv;  // deferred PDHG_Update_Average (step.c:437)
+    double t = xv;
+    t += (-tau) * v.cost[j];
+    t += tau * aty[j];
+    const double u = v.upper[j], l = v.lower[j];
+    t = t < u ? t : u;
+    t = t > l ? t : l;
+    xn[j] = t;
+  }
+}
+
+// Sharded: movement/interaction after the all-reduce of the A_g' y partials.
+__global__ __launch_bounds__(kVecThreads) void k_interact(const IterVecs v, const DevState* st,
+                                                          const double* __restrict__ atyReduced, double* partDX,
+                                                          double* partInter) {
+  if (st->halted) return;
+  __shared__ double scratch[2][kVecThreads / kWave];
+  const int cur = st->cur, nxt = cur ^ 1;
+  double a0 = 0.0, a1 = 0.0;
+  const int stride = gridDim.x * blockDim.x;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < v.n; j += stride) {
+    const double s = atyReduced[j];
+    const double dx = v.x[cur][j] - v.x[nxt][j];
+    const double da = v.aty[cur][j] - s;
+    v.aty[nxt][j] = s;
+    a0 += dx * dx;
+    a1 += dx * da;
+  }
+  const double t0 = blockSum<kVecThreads>(a0, scratch[0]);
+  const double t1 = blockSum<kVecThreads>(a1, scratch[1]);
+  if (threadIdx.x == 0) { partDX[blockIdx.x] = t0; partInter[blockIdx.x] = t1; }
+}
+
+// Fixed-order sum of `count` partials by one block of 256 threads.
+__device__ double reducePartials(const double* __restrict__ p, int count, double* scratch) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < count; i += kVecThreads) s += p[i];
+  return blockSum<kVecThreads>(s, scratch);
+}
+
+__global__ __launch_bounds__(kVecThreads) void k_reduce_to(const double* partials, int count, double* out,
+                                                           const DevState* st) {
+  if (st && st->halted) return;
+  __shared__ double scratch[kVecThreads / kWave];
+  const double s = reducePartials(partials, count, scratch);
+  if (threadIdx.x == 0) *out = s;
+}
+
+// Accept/reject and step-size update of PDHG_Update_Iterate_Adaptive_Step_Size
+// (cupdlp_step.c:237-306), the bookkeeping of PDHG_Update_Average (:433-441)
+// and the parity flip that the reference gets from ++nIter.
+__global__ __launch_bounds__(kVecThreads) void k_decide(DevState* st, const double* partDY, int nDY,
+                                                        const double* partDX, const double* partInter, int nDX,
+                                                        const double* dyGlobal) {
+  if (st->halted) return;
+  __shared__ double scratch[kVecThreads / kWave];
+  const double dY2loc = dyGlobal ? 0.0 : reducePartials(partDY, nDY, scratch);
+  const double dX2 = reducePartials(partDX, nDX, scratch);
+  const double inter = reducePartials(partInter, nDX, scratch);
+  if (threadIdx.x != 0) return;
+  const double dY2 = dyGlobal ? *dyGlobal : dY2loc;
+  DevState s = *st;
+  const double sb = sqrt(s.beta);
+  const double movement = dX2 * 0.5 * sb + dY2 / (2.0 * sb);
+  s.nTrials += 1;
+  bool accept = true;
+  double etaNew = s.eta;
+  double limit = INFINITY;
+  if (s.adaptive) {
+    limit = (inter != 0.0) ? movement / fabs(inter) : INFINITY;
+    accept = s.eta <= limit;
+    const double k1 = (double)s.nTrials + 1.0;
+    const double first = (1.0 - pow(k1, -0.3)) * limit;   // PDHG_STEPSIZE_REDUCTION_EXP
+    const double second = (1.0 + pow(k1, -0.6)) * s.eta;  // PDHG_STEPSIZE_GROWTH_EXP
+    etaNew = fmin(first, second);
+  }
+  s.dX2 = dX2; s.dY2 = dY2; s.inter = inter; s.movement = movement; s.limit = limit;
+  s.lastAccepted = accept ? 1 : 0;
+  if (accept) {
+    if (s.adaptive) {
+      s.primalStep = etaNew / sqrt(s.beta);
+      s.dualStep = etaNew * sqrt(s.beta);
+    }
+    const double w = sqrt(s.primalStep * s.dualStep);  // uses the NEXT step sizes (step.c:433)
+    s.sumPrimalStep += w;
+    s.sumDualStep += w;
+    s.avgW = w;
+    s.cur ^= 1;
+    s.nIter += 1;
+    s.eta = w;  // next iteration starts from sqrt(primalStep*dualStep) (step.c:231)
+    if (s.nIter >= s.haltIter) s.halted = 1;
+  } else {
+    s.eta = etaNew;
+    s.avgW = 0.0;
+  }
+  if (s.adaptive) {
+    s.tau = s.eta / sqrt(s.beta);
+    s.sigma = s.eta * sqrt(s.beta);
+  }
+  *st = s;
+}
+
+// Apply a pending average update (before a check iteration reads xSum/ySum).
+__global__ __launch_bounds__(kVecThreads) void k_flush_average(const IterVecs v, const DevState* st) {
+  const double w = st->avgW;
+  if (w == 0.0) return;
+  const int cur = st->cur;
+  const int stride = gridDim.x * blockDim.x;
+  const int tot = v.n + v.m;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += stride) {
+    if (i < v.n) v.xSum[i] += w * v.x[cur][i];
+    else v.ySum[i - v.n] += w * v.y[cur][i - v.n];
+  }
+}
+__global__ void k_clear_avgw(DevState* st) { st->avgW = 0.0; }
+
+__global__ __launch_bounds__(kVecThreads) void k_scale_copy(double* __restrict__ dst, const double* __restrict__ src,
+                                                            double a, int len) {
+  const int stride = gridDim.x * blockDim.x;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += stride) dst[i] = src[i] * a;
+}
+__global__ __launch_bounds__(kVecThreads) void k_fill(double* dst, double value, int len) {
+  const int stride = gridDim.x * blockDim.x;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += stride) dst[i] = value;
+}
+__global__ __launch_bounds__(kVecThreads) void k_project(double* x, const double* lower, const double* upper, int n) {
+  const int stride = gridDim.x * blockDim.x;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    double t = x[i];
+    t = t < upper[i] ? t : upper[i];  // projub then projlb, cupdlp_proj.c:17-25
+    t = t > lower[i] ? t : lower[i];
+    x[i] = t;
+  }
+}
+__global__ __launch_bounds__(kVecThreads) void k_mul(double* x, const double* y, int len) {
+  const int stride = gridDim.x * blockDim.x;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += stride) x[i] *= y[i];
+}
+__global__ __launch_bounds__(kVecThreads) void k_div(double* x, const double* y, int len) {
+  const int stride = gridDim.x * blockDim.x;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += stride) x[i] /= y[i];
+}
+
+// Row pass of PDHG_Compute_Primal_Feasibility / the y-side of the dual
+// objective and of the infeasibility certificates (cupdlp_solver.c:12-67,80,230,339-345).
+__global__ __launch_bounds__(kVecThreads) void k_row_stats(const double* __restrict__ ax, const double* __restrict__ y,
+                                                           const double* __restrict__ rhs,
+                                                           const double* __restrict__ rowScale, int m, int nEqs,
+                                                           int rowOffset, int scaled, double* partials, int pstride) {
+  __shared__ double scratch[kVecThreads / kWave];
+  double a[kRowStats] = {0.0, 0.0, 0.0, 0.0};
+  const int stride = gridDim.x * blockDim.x;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
+    const bool ineq = (i + rowOffset) >= nEqs;
+    const double axv = ax[i], yv = y[i], b = rhs[i];
+    const double rs = scaled ? rowScale[i] : 1.0;
+    double r = axv + (-1.0) * b;
+    if (ineq) r = r < 0.0 ? r : 0.0;
+    r *= rs;
+    a[0] += r * r;
+    a[1] += yv * b;
+    a[2] += yv * yv;
+    double c = axv;
+    if (ineq) c = c < 0.0 ? c : 0.0;
+    c *= rs;
+    a[3] += c * c;
+  }
+#pragma unroll
+  for (int q = 0; q < kRowStats; ++q) {
+    const double t = blockSum<kVecThreads>(a[q], scratch);
+    if (threadIdx.x == 0) partials[q * pstride + blockIdx.x] = t;
+  }
+}
+
+// Column pass of PDHG_Compute_Dual_Feasibility and the x-side certificates
+// (cupdlp_solver.c:69-204, 229-256, 326-366); also stores the slacks s+, s-.
+__global__ __launch_bounds__(kVecThreads) void k_col_stats(const double* __restrict__ aty, const double* __restrict__ x,
+                                                           const double* __restrict__ cost,
+                                                           const double* __restrict__ lower,
+                                                           const double* __restrict__ upper,
+                                                           const double* __restrict__ colScale, int n, int scaled,
+                                                           double* slackPos, double* slackNeg, double* partials,
+                                                           int pstride) {
+  __shared__ double scratch[kVecThreads / kWave];
+  double a[kColStats];
+#pragma unroll
+  for (int q = 0; q < kColStats; ++q) a[q] = 0.0;
+  const int stride = gridDim.x * blockDim.x;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+    const double xv = x[j], c = cost[j], l = lower[j], u = upper[j];
+    const double cs = scaled ? colScale[j] : 1.0;
+    const double hasL = l > -INFINITY ? 1.0 : 0.0, hasU = u < INFINITY ? 1.0 : 0.0;
+    const double lF = l > -INFINITY ? l : 0.0, uF = u < INFINITY ? u : 0.0;
+    const double atyv = aty[j];
+    double r = -atyv + c;                       // c - A'y
+    double sp = (r > 0.0 ? r : 0.0) * hasL;     // s+ (:157-159)
+    double sn = (-(r < 0.0 ? r : 0.0)) * hasU;  // s- (:171-175)
+    slackPos[j] = sp;
+    slackNeg[j] = sn;
+    a[0] += xv * c;
+    a[1] += sp * lF;
+    a[2] += sn * uF;
+    double rd = r + (-1.0) * sp;
+    rd += sn;
+    rd *= cs;
+    a[3] += rd * rd;
+    a[4] += sp * sp;
+    a[5] += sn * sn;
+    double pc = (atyv + sp) - sn;
+    pc *= cs;
+    a[6] += pc * pc;
+    a[7] += xv * xv;
+    double lb = (xv < 0.0 ? xv : 0.0) * hasL;
+    double ub = (xv > 0.0 ? xv : 0.0) * hasU;
+    if (scaled) { lb /= cs; ub /= cs; }
+    a[8] += lb * lb;
+    a[9] += ub * ub;
+  }
+#pragma unroll
+  for (int q = 0; q < kColStats; ++q) {
+    const double t = blockSum<kVecThreads>(a[q], scratch);
+    if (threadIdx.x == 0) partials[q * pstride + blockIdx.x] = t;
+  }
+}
+
+__global__ __launch_bounds__(kVecThreads) void k_final_reduce(const double* partials, int pstride, int nBlocks,
+                                                              double* out) {
+  __shared__ double scratch[kVecThreads / kWave];
+  const double s = reducePartials(partials + (size_t)blockIdx.x * pstride, nBlocks, scratch);
+  if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(kVecThreads) void k_diff_norm2(const double* __restrict__ a, const double* __restrict__ b,
+                                                            int len, double* partials) {
+  __shared__ double scratch[kVecThreads / kWave];
+  double s = 0.0;
+  const int stride = gridDim.x * blockDim.x;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += stride) {
+    const double d = a[i] - b[i];
+    s += d * d;
+  }
+  const double t = blockSum<kVecThreads>(s, scratch);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+__global__ __launch_bounds__(kVecThreads) void k_dot(const double* __restrict__ a, const double* __restrict__ b,
+                                                     int len, double* partials) {
+  __shared__ double scratch[kVecThreads / kWave];
+  double s = 0.0;
+  const int stride = gridDim.x * blockDim.x;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += stride) s += a[i] * b[i];
+  const double t = blockSum<kVecThreads>(s, scratch);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+}  // namespace
+
+// Memory-bound vector kernels: cap the grid at 2048 blocks (8 per CU) and
+// grid-stride the rest.
+int32_t vecBlocks(int32_t len) {
+  int64_t b = ((int64_t)len + kVecThreads - 1) / kVecThreads;
+  if (b < 1) b = 1;
+  if (b > 2048) b = 2048;
+  return (int32_t)b;
+}
+
+void launchPrimalStep(const IterVecs& v, const DevState* st, hipStream_t s) {
+  hipLaunchKernelGGL(k_primal_step, dim3(vecBlocks(v.n)), dim3(kVecThreads), 0, s, v, st);
+}
+
+void launchSpmvAxDual(const SpmvMat& A, const IterVecs& v, const DevState* st, double* partDY, hipStream_t s) {
+  if (A.nBlocks == 0) return;
+  SpmvArgs a{};
+  a.A = A; a.st = st; a.v = v; a.part0 = partDY;
+  hipLaunchKernelGGL(k_spmv<kDualStep>, dim3(A.nBlocks), dim3(kSpmvThreads), 0, s, a);
+}
+void launchSpmvAtyInteract(const SpmvMat& At, const IterVecs& v, const DevState* st, double* partDX,
+                           double* partInter, hipStream_t s) {
+  if (At.nBlocks == 0) return;
+  SpmvArgs a{};
+  a.A = At; a.st = st; a.v = v; a.part0 = partDX; a.part1 = partInter;
+  hipLaunchKernelGGL(k_spmv<kAtyInteract>, dim3(At.nBlocks), dim3(kSpmvThreads), 0, s, a);
+}
+void launchSpmvAtyPartial(const SpmvMat& At, const IterVecs& v, const DevState* st, double* out, hipStream_t s) {
+  if (At.nBlocks == 0) return;
+  SpmvArgs a{};
+  a.A = At; a.st = st; a.v = v; a.out = out;
+  hipLaunchKernelGGL(k_spmv<kAtyPartial>, dim3(At.nBlocks), dim3(kSpmvThreads), 0, s, a);
+}
+void launchSpmvPlain(const SpmvMat& A, const double* in, double* out, hipStream_t s) {
+  if (A.nBlocks == 0) return;
+  SpmvArgs a{};
+  a.A = A; a.st = nullptr; a.in = in; a.out = out;
+  hipLaunchKernelGGL(k_spmv<kPlain>, dim3(A.nBlocks), dim3(kSpmvThreads), 0, s, a);
+}
+void launchInteract(const IterVecs& v, const DevState* st, const double* atyReduced, double* partDX,
+                    double* partInter, int32_t nBlocks, hipStream_t s) {
+  hipLaunchKernelGGL(k_interact, dim3(nBlocks), dim3(kVecThreads), 0, s, v, st, atyReduced, partDX, partInter);
+}
+void launchReduceTo(const double* partials, int32_t count, double* out, const DevState* st, hipStream_t s) {
+  hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(kVecThreads), 0, s, partials, count, out, st);
+}
+void launchDecide(DevState* st, const double* partDY, int32_t nDY, const double* partDX, const double* partInter,
+                  int32_t nDX, const double* dyGlobal, hipStream_t s) {
+  hipLaunchKernelGGL(k_decide, dim3(1), dim3(kVecThreads), 0, s, st, partDY, nDY, partDX, partInter, nDX, dyGlobal);
+}
+void launchFlushAverage(const IterVecs& v, DevState* st, hipStream_t s) {
+  hipLaunchKernelGGL(k_flush_average, dim3(vecBlocks(v.n + v.m)), dim3(kVecThreads), 0, s, v, st);
+  hipLaunchKernelGGL(k_clear_avgw, dim3(1), dim3(1), 0, s, st);
+}
+void launchScaleCopy(double* dst, const double* src, double a, int32_t len, hipStream_t s) {
+  if (len <= 0) return;
+  hipLaunchKernelGGL(k_scale_copy, dim3(vecBlocks(len)), dim3(kVecThreads), 0, s, dst, src, a, len);
+}
+void launchFill(double* dst, double value, int32_t len, hipStream_t s) {
+  if (len <= 0) return;
+  hipLaunchKernelGGL(k_fill, dim3(vecBlocks(len)), dim3(kVecThreads), 0, s, dst, value, len);
+}
+void launchProjectBounds(double* x, const double* lower, const double* upper, int32_t n, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_project, dim3(vecBlocks(n)), dim3(kVecThreads), 0, s, x, lower, upper, n);
+}
+void launchMulInPlace(double* x, const double* y, int32_t len, hipStream_t s) {
+  if (len <= 0) return;
+  hipLaunchKernelGGL(k_mul, dim3(vecBlocks(len)), dim3(kVecThreads), 0, s, x, y, len);
+}
+void launchDivInPlace(double* x, const double* y, int32_t len, hipStream_t s) {
+  if (len <= 0) return;
+  hipLaunchKernelGGL(k_div, dim3(vecBlocks(len)), dim3(kVecThreads), 0, s, x, y, len);
+}
+void launchRowStats(const double* ax, const double* y, const double* rhs, const double* rowScale, int32_t m,
+                    int32_t nEqs, int32_t rowOffset, int scaled, double* partials, int32_t stride, int32_t nBlocks,
+                    hipStream_t s) {
+  hipLaunchKernelGGL(k_row_stats, dim3(nBlocks), dim3(kVecThreads), 0, s, ax, y, rhs, rowScale, m, nEqs, rowOffset,
+                     scaled, partials, stride);
+}
+void launchColStats(const double* aty, const double* x, const double* cost, const double* lower,
+                    const double* upper, const double* colScale, int32_t n, int scaled, double* slackPos,
+                    double* slackNeg, double* partials, int32_t stride, int32_t nBlocks, hipStream_t s) {
+  hipLaunchKernelGGL(k_col_stats, dim3(nBlocks), dim3(kVecThreads), 0, s, aty, x, cost, lower, upper, colScale, n,
+                     scaled, slackPos, slackNeg, partials, stride);
+}
+void launchFinalReduce(const double* partials, int32_t stride, int32_t nBlocks, int32_t nQ, double* out,
+                       hipStream_t s) {
+  hipLaunchKernelGGL(k_final_reduce, dim3(nQ), dim3(kVecThreads), 0, s, partials, stride, nBlocks, out);
+}
+void launchDiffNorm2(const double* a, const double* b, int32_t len, double* partials, int32_t nBlocks,
+                     hipStream_t s) {
+  hipLaunchKernelGGL(k_diff_norm2, dim3(nBlocks), dim3(kVecThreads), 0, s, a, b, len, partials);
+}
+void launchDot(const double* a, const double* b, int32_t len, double* partials, int32_t nBlocks, hipStream_t s) {
+  hipLaunchKernelGGL(k_dot, dim3(nBlocks), dim3(kVecThreads), 0, s, a, b, len, partials);
+}
+
+}  // namespace pdlp

@@ -1,0 +1,122 @@
+// pdlp_kernels.hpp — launch interface of the gfx950 kernels (pdlp_kernels.hip).
+//
+// Every per-trial kernel reads its step sizes, the current/next buffer parity
+// and the "halted" flag from a DevState record in HBM, so a whole batch of
+// trial steps can be enqueued (or replayed from a hipGraph) without the host
+// knowing which trials get accepted: the accept/reject logic of
+// PDHG_Update_Iterate_Adaptive_Step_Size (cupdlp_step.c:215-310) runs on the
+// device in k_decide.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace pdlp {
+
+// Nonzeros staged through LDS per work block of the CSR-adaptive SpMV.
+constexpr int kChunk = 2048;
+constexpr int kSpmvThreads = 256;
+constexpr int kMaxMajorsPerBlock = 2048;
+constexpr int kVecThreads = 256;
+
+// Device-resident solver state (one per solver; lives in HBM).
+struct DevState {
+  double eta;            // dStepSizeUpdate of the NEXT trial = sqrt(tau*sigma)
+  double beta;           // stepsize->dBeta (primal weight squared)
+  double tau, sigma;     // step sizes of the next trial
+  double primalStep, dualStep;        // stepsize->dPrimalStep / dDualStep
+  double sumPrimalStep, sumDualStep;  // stepsize->dSum*Step
+  double avgW;           // weight of the accepted iterate not yet added to xSum/ySum
+  double dX2, dY2, inter, movement, limit;  // last trial (diagnostics / tests)
+  int32_t nIter;         // timers->nIter
+  int32_t nTrials;       // stepsize->nStepSizeIter
+  int32_t cur;           // parity of the current iterate buffers (nIter % 2 in the reference)
+  int32_t halted;        // set when nIter reaches haltIter: remaining queued kernels no-op
+  int32_t haltIter;      // next iteration at which the host must run a check
+  int32_t adaptive;      // PDHG_ADAPTIVE_LINESEARCH (1) or fixed step (0)
+  int32_t lastAccepted;
+  int32_t pad_;
+};
+
+struct SpmvMat {
+  const int32_t* beg;       // [nMajor+1]
+  const int32_t* idx;       // [nnz]
+  const double* val;        // [nnz]
+  const int32_t* blockBeg;  // [nBlocks+1] stream plan
+  int32_t nMajor;
+  int32_t nBlocks;
+};
+
+// Vectors of the iteration (device pointers). Pairs are double-buffered by parity.
+struct IterVecs {
+  double* x[2];
+  double* y[2];
+  double* ax[2];
+  double* aty[2];
+  double* xSum;
+  double* ySum;
+  const double* cost;
+  const double* rhs;
+  const double* lower;
+  const double* upper;
+  int32_t n, m;
+  int32_t nEqs;       // GLOBAL count of equality rows
+  int32_t rowOffset;  // global index of local row 0 (0 unless sharded)
+};
+
+// ---- per-trial kernels ----------------------------------------------------
+void launchPrimalStep(const IterVecs& v, const DevState* st, hipStream_t s);
+// ax_next = A x_next fused with the dual step; writes per-block sum (dy)^2 to partDY[block]
+void launchSpmvAxDual(const SpmvMat& A, const IterVecs& v, const DevState* st, double* partDY, hipStream_t s);
+// aty_next = A' y_next fused with movement/interaction partials
+void launchSpmvAtyInteract(const SpmvMat& At, const IterVecs& v, const DevState* st, double* partDX,
+                           double* partInter, hipStream_t s);
+// sharded variant: partial A_g' y_next into out[n] (no epilogue)
+void launchSpmvAtyPartial(const SpmvMat& At, const IterVecs& v, const DevState* st, double* out, hipStream_t s);
+// sharded: aty_next = reduced; movement/interaction partials
+void launchInteract(const IterVecs& v, const DevState* st, const double* atyReduced, double* partDX,
+                    double* partInter, int32_t nBlocks, hipStream_t s);
+// sums partials[0..count) deterministically into *out (one block)
+void launchReduceTo(const double* partials, int32_t count, double* out, const DevState* st, hipStream_t s);
+// accept/reject + step-size update; dyGlobal != nullptr -> use *dyGlobal instead of partDY
+void launchDecide(DevState* st, const double* partDY, int32_t nDY, const double* partDX, const double* partInter,
+                  int32_t nDX, const double* dyGlobal, hipStream_t s);
+
+// ---- check-iteration kernels (host knows the parity here) -------------------
+void launchFlushAverage(const IterVecs& v, DevState* st, hipStream_t s);
+void launchScaleCopy(double* dst, const double* src, double a, int32_t len, hipStream_t s);  // dst = a*src
+void launchSpmvPlain(const SpmvMat& A, const double* in, double* out, hipStream_t s);
+void launchFill(double* dst, double value, int32_t len, hipStream_t s);
+void launchProjectBounds(double* x, const double* lower, const double* upper, int32_t n, hipStream_t s);
+void launchMulInPlace(double* x, const double* y, int32_t len, hipStream_t s);   // x *= y
+void launchDivInPlace(double* x, const double* y, int32_t len, hipStream_t s);   // x /= y
+
+// Row statistics of one iterate: out[0..kRowStats) (after launchFinalReduce)
+//  0: sum ((ax-b) projected) * rowScale)^2   primal residual^2   (cupdlp_solver.c:12-67)
+//  1: sum y*b                                dual objective part (:80)
+//  2: sum y^2                                ray norm part       (:230)
+//  3: sum ((ax projected)*rowScale)^2        dual-infeasibility constraint part (:339-345)
+constexpr int kRowStats = 4;
+void launchRowStats(const double* ax, const double* y, const double* rhs, const double* rowScale, int32_t m,
+                    int32_t nEqs, int32_t rowOffset, int scaled, double* partials, int32_t stride, int32_t nBlocks,
+                    hipStream_t s);
+// Column statistics: out[0..kColStats)
+//  0: sum c*x   1: sum sp*lowerF   2: sum sn*upperF   3: sum ((r-sp+sn)*colScale)^2
+//  4: sum sp^2  5: sum sn^2        6: sum ((aty+sp-sn)*colScale)^2
+//  7: sum x^2   8: sum (min(x,0)*hasLower/colScale)^2    9: sum (max(x,0)*hasUpper/colScale)^2
+constexpr int kColStats = 10;
+void launchColStats(const double* aty, const double* x, const double* cost, const double* lower,
+                    const double* upper, const double* colScale, int32_t n, int scaled, double* slackPos,
+                    double* slackNeg, double* partials, int32_t stride, int32_t nBlocks, hipStream_t s);
+// out[q] = sum_{b<nBlocks} partials[q*stride+b], q < nQ (deterministic)
+void launchFinalReduce(const double* partials, int32_t stride, int32_t nBlocks, int32_t nQ, double* out,
+                       hipStream_t s);
+// partials of ||a-b||^2
+void launchDiffNorm2(const double* a, const double* b, int32_t len, double* partials, int32_t nBlocks,
+                     hipStream_t s);
+// partials of a.b
+void launchDot(const double* a, const double* b, int32_t len, double* partials, int32_t nBlocks, hipStream_t s);
+
+int32_t vecBlocks(int32_t len);  // grid size used by the vector/statistics kernels
+
+}  // namespace pdlp

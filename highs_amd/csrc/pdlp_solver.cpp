@@ -1,0 +1,804 @@
+// pdlp_solver.cpp — see pdlp_solver.hpp.  Host control flow of the restarted,
+// adaptive-step PDHG loop; every vector lives in HBM and every per-trial
+// decision is taken on the device, so the host only synchronises at the
+// reference's check iterations (nIter < 10, nIter % 40 == 0, last iteration).
+#include "pdlp_solver.hpp"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace pdlp {
+
+namespace {
+constexpr int kStatRowCur = 0, kStatRowAvg = kRowStats, kStatColCur = 2 * kRowStats,
+              kStatColAvg = 2 * kRowStats + kColStats, kStatTotal = 2 * kRowStats + 2 * kColStats;
+constexpr int kGraphTrials = 10;
+constexpr int kCheckInterval = 40;  // CUPDLP_RELEASE_INTERVAL, cupdlp_defs.h:39
+}  // namespace
+
+void DeviceMatrix::upload(const Compressed& c, int32_t nMajor_, hipStream_t s) {
+  nMajor = nMajor_;
+  nnz = c.beg.empty() ? 0 : c.beg[nMajor_];
+  StreamPlan plan = planStream(c.beg, nMajor_, kChunk, kMaxMajorsPerBlock);
+  nBlocks = plan.nBlocks;
+  beg.alloc(c.beg.size());
+  idx.alloc((size_t)nnz);
+  val.alloc((size_t)nnz);
+  blockBeg.alloc(plan.blockBeg.size());
+  beg.upload(c.beg.data(), c.beg.size(), s);
+  idx.upload(c.idx.data(), (size_t)nnz, s);
+  val.upload(c.val.data(), (size_t)nnz, s);
+  blockBeg.upload(plan.blockBeg.data(), plan.blockBeg.size(), s);
+  PDLP_HIP(hipStreamSynchronize(s));  // host vectors may go out of scope
+}
+
+double Solver::elapsed() const {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - solveBeg_).count();
+}
+
+void Solver::log(int level, const char* fmt, ...) const {
+  if (opt_.log_level < level || rank_ != 0) return;
+  va_list ap;
+  va_start(ap, fmt);
+  vprintf(fmt, ap);
+  va_end(ap);
+  fflush(stdout);
+}
+
+Solver::Solver(const pdlp_problem_t& P, const pdlp_params_t& opt, int32_t rank, int32_t world, const void* id128)
+    : opt_(opt), rank_(rank), world_(world) {
+  const auto t0 = std::chrono::steady_clock::now();
+  if (world_ < 1 || rank_ < 0 || rank_ >= world_) throw std::runtime_error("bad rank/world");
+  int nDev = 0;
+  if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0)
+    throw std::runtime_error("pdlp_mi355x: no HIP device available (this library has no CPU fallback)");
+  PDLP_HIP(hipSetDevice(opt_.device));
+  PDLP_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  if (const char* g = getenv("PDLP_MI355X_GRAPH")) useGraph_ = atoi(g) != 0;
+
+  adaptive_ = !(opt_.features_off & PDLP_FEATURE_ADAPTIVE_STEP_OFF);
+  restartOn_ = !(opt_.features_off & PDLP_FEATURE_RESTART_OFF) && opt_.restart_method != 0;
+
+  log(1, "Solving with PDLP on MI355X (gfx950, HIP)\n");
+  formulate(P, F_);
+  if (!(opt_.features_off & PDLP_FEATURE_SCALING_OFF)) scale(F_);
+  finalize(F_);
+  log(1, "Using cost norm = %9.3g and RHS norm = %9.3g\n", F_.normCost, F_.normRhs);
+
+  // hot start in formulated+scaled space (PDHG_PreSolve, cupdlp_solver.c:1217-1279)
+  if (P.start_value_valid && P.start_dual_valid && P.start_col_value && P.start_row_value && P.start_row_dual) {
+    startX_.assign(F_.n, 0.0);
+    startY_.assign(F_.m, 0.0);
+    int32_t j = 0;
+    for (; j < F_.n0; ++j) startX_[j] = P.start_col_value[j];
+    for (int32_t i = 0; i < F_.m; ++i) {
+      const double mu = F_.rowKind[i] == kRowLeq ? -1.0 : 1.0;
+      startY_[F_.rowNewIdx[i]] = F_.sense * mu * P.start_row_dual[i];
+      if (F_.rowKind[i] == kRowBound) startX_[j++] = P.start_row_value[i];
+    }
+    if (F_.scaled) {
+      for (int32_t k = 0; k < F_.n; ++k) startX_[k] *= F_.colScale[k];
+      for (int32_t k = 0; k < F_.m; ++k) startY_[k] *= F_.rowScale[k];
+    }
+    hasStart_ = true;
+  }
+  // cuPDLP treats "either flag set" as has_variables (cupdlp_solver.c:1465) but
+  // only fills x,y when both are; with one flag the start is the zero vector.
+
+  if (world_ > 1) {
+    std::vector<int32_t> off = rowPartition(F_.csr, F_.m, world_);
+    r0_ = off[rank_];
+    r1_ = off[rank_ + 1];
+    comm_ = new Comm(rank_, world_, id128);
+  } else {
+    r0_ = 0;
+    r1_ = F_.m;
+  }
+  mLoc_ = r1_ - r0_;
+  uploadProblem();
+  reset();
+  PDLP_HIP(hipStreamSynchronize(stream_));
+  setupSeconds_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+Solver::~Solver() {
+  if (graphExec_) (void)hipGraphExecDestroy(graphExec_);
+  if (hostState_) (void)hipHostFree(hostState_);
+  if (hostStats_) (void)hipHostFree(hostStats_);
+  delete comm_;
+  if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+void Solver::uploadProblem() {
+  const int32_t n = F_.n;
+  if (world_ == 1) {
+    dA_.upload(F_.csr, F_.m, stream_);
+    dAt_.upload(F_.cscSorted, n, stream_);
+  } else {
+    Compressed csrSlab, cscSlab;
+    extractSlab(F_, r0_, r1_, csrSlab, cscSlab);
+    dA_.upload(csrSlab, mLoc_, stream_);
+    dAt_.upload(cscSlab, n, stream_);
+  }
+  for (int k = 0; k < 2; ++k) {
+    x_[k].alloc(n); y_[k].alloc(mLoc_); ax_[k].alloc(mLoc_); aty_[k].alloc(n);
+    x_[k].zero(stream_); y_[k].zero(stream_); ax_[k].zero(stream_); aty_[k].zero(stream_);
+  }
+  xAvg_.alloc(n); yAvg_.alloc(mLoc_); axAvg_.alloc(mLoc_); atyAvg_.alloc(n);
+  xSum_.alloc(n); ySum_.alloc(mLoc_); xLast_.alloc(n); yLast_.alloc(mLoc_);
+  cost_.alloc(n); rhs_.alloc(mLoc_); lower_.alloc(n); upper_.alloc(n); colScale_.alloc(n); rowScale_.alloc(mLoc_);
+  slackPos_.alloc(n); slackNeg_.alloc(n); slackPosAvg_.alloc(n); slackNegAvg_.alloc(n);
+  slackPos_.zero(stream_); slackNeg_.zero(stream_); slackPosAvg_.zero(stream_); slackNegAvg_.zero(stream_);
+  tmpM_.alloc(mLoc_);
+  cost_.upload(F_.cost.data(), n, stream_);
+  lower_.upload(F_.lower.data(), n, stream_);
+  upper_.upload(F_.upper.data(), n, stream_);
+  colScale_.upload(F_.colScale.data(), n, stream_);
+  rhs_.upload(F_.rhs.data() + r0_, mLoc_, stream_);
+  rowScale_.upload(F_.rowScale.data() + r0_, mLoc_, stream_);
+
+  const int32_t nbV = std::max(vecBlocks(n), vecBlocks(std::max(mLoc_, 1)));
+  partDY_.alloc(std::max(dA_.nBlocks, 1));
+  partDX_.alloc(std::max(std::max(dAt_.nBlocks, nbV), 1));
+  partInter_.alloc(std::max(std::max(dAt_.nBlocks, nbV), 1));
+  statStride_ = nbV;
+  statPart_.alloc((size_t)kStatTotal * statStride_);
+  statOut_.alloc(kStatTotal + 8);
+  commBuf_.alloc((size_t)n + 8);
+  commBuf_.zero(stream_);
+  dState_.alloc(1);
+  PDLP_HIP(hipHostMalloc((void**)&hostState_, sizeof(DevState), hipHostMallocDefault));
+  PDLP_HIP(hipHostMalloc((void**)&hostStats_, sizeof(double) * (kStatTotal + 8), hipHostMallocDefault));
+  memset(hostState_, 0, sizeof(DevState));
+
+  vecs_ = IterVecs{};
+  for (int k = 0; k < 2; ++k) {
+    vecs_.x[k] = x_[k].get(); vecs_.y[k] = y_[k].get(); vecs_.ax[k] = ax_[k].get(); vecs_.aty[k] = aty_[k].get();
+  }
+  vecs_.xSum = xSum_.get(); vecs_.ySum = ySum_.get();
+  vecs_.cost = cost_.get(); vecs_.rhs = rhs_.get(); vecs_.lower = lower_.get(); vecs_.upper = upper_.get();
+  vecs_.n = n; vecs_.m = mLoc_; vecs_.nEqs = F_.nEqs; vecs_.rowOffset = r0_;
+  PDLP_HIP(hipStreamSynchronize(stream_));
+}
+
+void Solver::dims(int32_t* n, int32_t* m, int64_t* nnz, int32_t* nEqs) const {
+  if (n) *n = F_.n;
+  if (m) *m = F_.m;
+  if (nnz) *nnz = F_.nnz;
+  if (nEqs) *nEqs = F_.nEqs;
+}
+
+void Solver::syncState() {
+  PDLP_HIP(hipMemcpyAsync(hostState_, dState_.get(), sizeof(DevState), hipMemcpyDeviceToHost, stream_));
+  PDLP_HIP(hipStreamSynchronize(stream_));
+}
+void Solver::pushState() {
+  PDLP_HIP(hipMemcpyAsync(dState_.get(), hostState_, sizeof(DevState), hipMemcpyHostToDevice, stream_));
+  PDLP_HIP(hipStreamSynchronize(stream_));
+}
+
+// ---- sharding-aware device linear algebra ----------------------------------
+void Solver::deviceAx(const double* x, double* axLocal) { launchSpmvPlain(dA_.view(), x, axLocal, stream_); }
+
+void Solver::deviceATy(const double* yLocal, double* aty) {
+  if (world_ == 1) {
+    launchSpmvPlain(dAt_.view(), yLocal, aty, stream_);
+  } else {
+    launchSpmvPlain(dAt_.view(), yLocal, commBuf_.get(), stream_);
+    comm_->allReduceSum(commBuf_.get(), (size_t)F_.n, stream_);
+    PDLP_HIP(hipMemcpyAsync(aty, commBuf_.get(), sizeof(double) * F_.n, hipMemcpyDeviceToDevice, stream_));
+  }
+}
+
+// Sum per-block partials on the device, bring the scalar to the host; row
+// quantities are additionally summed over the row-block owners.
+double Solver::reduceScalar(const double* partials, int32_t nBlocks, bool rowQuantity) {
+  launchFinalReduce(partials, nBlocks, nBlocks, 1, statOut_.get() + kStatTotal, stream_);
+  if (rowQuantity && world_ > 1) comm_->allReduceSum(statOut_.get() + kStatTotal, 1, stream_);
+  PDLP_HIP(hipMemcpyAsync(hostStats_ + kStatTotal, statOut_.get() + kStatTotal, sizeof(double),
+                          hipMemcpyDeviceToHost, stream_));
+  PDLP_HIP(hipStreamSynchronize(stream_));
+  return hostStats_[kStatTotal];
+}
+
+// ---- initialisation ----------------------------------------------------------
+// PDHG_Init_Step_Sizes, cupdlp_step.c:312-375.  The norms of the scaled c and b
+// are taken on the host with the reference's left-to-right sums.
+void Solver::initStepSizes() {
+  DevState& s = *hostState_;
+  double a = 0.0, b = 0.0;
+  for (double v : F_.cost) a += v * v;
+  for (double v : F_.rhs) b += v * v;
+  s.beta = (std::fmin(a, b) > 1e-6) ? a / b : 1.0;
+  if (adaptive_) {
+    s.primalStep = (1.0 / F_.matNormInf) / std::sqrt(s.beta);
+    s.dualStep = s.primalStep * s.beta;
+  } else {
+    // PDHG_Power_Method, cupdlp_step.c:71-145: 20 iterations on A A'
+    const int32_t n = F_.n;
+    double lambda = 0.0;
+    launchFill(tmpM_.get(), 1.0, mLoc_, stream_);
+    const int32_t nbM = vecBlocks(std::max(mLoc_, 1)), nbN = vecBlocks(n);
+    for (int it = 0; it < 20; ++it) {
+      deviceATy(tmpM_.get(), aty_[0].get());
+      deviceAx(aty_[0].get(), ax_[0].get());
+      launchDot(ax_[0].get(), ax_[0].get(), mLoc_, partDX_.get(), nbM, stream_);
+      const double qn = std::sqrt(reduceScalar(partDX_.get(), nbM, true));
+      launchScaleCopy(tmpM_.get(), ax_[0].get(), 1.0 / qn, mLoc_, stream_);
+      deviceATy(tmpM_.get(), aty_[0].get());
+      launchDot(aty_[0].get(), aty_[0].get(), n, partDX_.get(), nbN, stream_);
+      lambda = reduceScalar(partDX_.get(), nbN, false);
+    }
+    s.primalStep = 0.8 / std::sqrt(lambda);
+    s.dualStep = s.primalStep;
+    s.primalStep /= std::sqrt(s.beta);
+    s.dualStep *= std::sqrt(s.beta);
+    log(2, "Initial step sizes from power method lambda = %g: primal = %g; dual = %g\n", lambda, s.primalStep,
+        s.dualStep);
+  }
+  iLastRestartIter_ = 0;
+  s.sumPrimalStep = 0.0;
+  s.sumDualStep = 0.0;
+}
+
+// PDHG_Init_Variables, cupdlp_solver.c:531-591
+void Solver::initVariables() {
+  const int32_t n = F_.n;
+  if (hasStart_) {
+    x_[0].upload(startX_.data(), n, stream_);
+    y_[0].upload(startY_.data() + r0_, mLoc_, stream_);
+  } else {
+    x_[0].zero(stream_);
+    y_[0].zero(stream_);
+  }
+  launchProjectBounds(x_[0].get(), lower_.get(), upper_.get(), n, stream_);
+  deviceAx(x_[0].get(), ax_[0].get());
+  deviceATy(y_[0].get(), aty_[0].get());
+  xSum_.zero(stream_); ySum_.zero(stream_); xAvg_.zero(stream_); yAvg_.zero(stream_);
+  launchProjectBounds(xSum_.get(), lower_.get(), upper_.get(), n, stream_);  // :583-584
+  launchProjectBounds(xAvg_.get(), lower_.get(), upper_.get(), n, stream_);
+  xLast_.zero(stream_); yLast_.zero(stream_);
+}
+
+void Solver::reset() {
+  DevState& s = *hostState_;
+  memset(&s, 0, sizeof(s));
+  s.adaptive = adaptive_ ? 1 : 0;
+  initStepSizes();
+  initVariables();
+  s.eta = std::sqrt(s.primalStep * s.dualStep);
+  if (adaptive_) {
+    s.tau = s.eta / std::sqrt(s.beta);
+    s.sigma = s.eta * std::sqrt(s.beta);
+  } else {
+    s.tau = s.primalStep;
+    s.sigma = s.dualStep;
+  }
+  s.haltIter = INT_MAX;
+  pushState();
+  cur_ = Residuals();
+  avg_ = Residuals();
+  pFeasLR_ = dFeasLR_ = gapLR_ = pFeasLC_ = dFeasLC_ = gapLC_ = 0.0;
+  nRestarts_ = 0;
+  nChecks_ = 0;
+  termCode_ = PDLP_TERM_TIMELIMIT_OR_ITERLIMIT;
+  termIterate_ = 0;
+}
+
+// ---- the hot loop --------------------------------------------------------------
+// One trial step of cupdlp_step.c:241-257 (+ the decision, on the device).
+void Solver::enqueueTrial() {
+  launchPrimalStep(vecs_, dState_.get(), stream_);
+  launchSpmvAxDual(dA_.view(), vecs_, dState_.get(), partDY_.get(), stream_);
+  if (world_ == 1) {
+    launchSpmvAtyInteract(dAt_.view(), vecs_, dState_.get(), partDX_.get(), partInter_.get(), stream_);
+    launchDecide(dState_.get(), partDY_.get(), dA_.nBlocks, partDX_.get(), partInter_.get(), dAt_.nBlocks, nullptr,
+                 stream_);
+  } else {
+    // row-block sharded: A_g' y_g partials are summed over the ranks together
+    // with the local sum (dy)^2 in one all-reduce of n+1 doubles
+    double* buf = commBuf_.get();
+    launchSpmvAtyPartial(dAt_.view(), vecs_, dState_.get(), buf, stream_);
+    launchReduceTo(partDY_.get(), dA_.nBlocks, buf + F_.n, dState_.get(), stream_);
+    comm_->allReduceSum(buf, (size_t)F_.n + 1, stream_);
+    const int32_t nb = vecBlocks(F_.n);
+    launchInteract(vecs_, dState_.get(), buf, partDX_.get(), partInter_.get(), nb, stream_);
+    launchDecide(dState_.get(), nullptr, 0, partDX_.get(), partInter_.get(), nb, buf + F_.n, stream_);
+  }
+}
+
+void Solver::runUntilHalt() {
+  for (;;) {
+    int64_t remaining = (int64_t)hostState_->haltIter - hostState_->nIter;
+    if (remaining < 1) remaining = 1;
+    if (remaining > 4 * kCheckInterval) remaining = 4 * kCheckInterval;
+    int32_t todo = (int32_t)remaining;
+    if (useGraph_ && world_ == 1 && todo >= kGraphTrials) {
+      if (!graphExec_) {
+        hipGraph_t graph = nullptr;
+        PDLP_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+        for (int i = 0; i < kGraphTrials; ++i) enqueueTrial();
+        PDLP_HIP(hipStreamEndCapture(stream_, &graph));
+        PDLP_HIP(hipGraphInstantiate(&graphExec_, graph, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(graph);
+        graphTrials_ = kGraphTrials;
+      }
+      while (todo >= graphTrials_) {
+        PDLP_HIP(hipGraphLaunch(graphExec_, stream_));
+        todo -= graphTrials_;
+      }
+    }
+    for (int i = 0; i < todo; ++i) enqueueTrial();
+    syncState();
+    if (hostState_->halted) return;
+    if (elapsed() > opt_.time_limit) return;
+  }
+}
+
+int32_t Solver::nextCheckIter(int32_t it) const {
+  const int32_t interval = opt_.check_interval > 0 ? opt_.check_interval : kCheckInterval;
+  int64_t next;
+  if (it + 1 < 10) next = it + 1;
+  else next = ((int64_t)it / interval + 1) * interval;
+  const int64_t last = (int64_t)opt_.iter_limit - 1;
+  if (last > it && last < next) next = last;
+  if (next > INT_MAX) next = INT_MAX;
+  return (int32_t)next;
+}
+
+// ---- check iteration -----------------------------------------------------------
+// PDHG_Compute_Average_Iterate, cupdlp_step.c:377-420
+void Solver::computeAverage() {
+  launchFlushAverage(vecs_, dState_.get(), stream_);
+  hostState_->avgW = 0.0;
+  const double ps = hostState_->sumPrimalStep > 0.0 ? 1.0 / hostState_->sumPrimalStep : 1.0;
+  const double ds = hostState_->sumDualStep > 0.0 ? 1.0 / hostState_->sumDualStep : 1.0;
+  launchScaleCopy(xAvg_.get(), xSum_.get(), ps, F_.n, stream_);
+  launchScaleCopy(yAvg_.get(), ySum_.get(), ds, mLoc_, stream_);
+  deviceAx(xAvg_.get(), axAvg_.get());
+  deviceATy(yAvg_.get(), atyAvg_.get());
+}
+
+// PDHG_Compute_Residuals + PDHG_Compute_Infeas_Residuals (cupdlp_solver.c:433-529)
+// for the current and the average iterate: four fused passes, one D2H of 28 doubles.
+void Solver::computeResiduals() {
+  const int c = hostState_->cur;
+  const int32_t nbM = vecBlocks(std::max(mLoc_, 1)), nbN = vecBlocks(F_.n);
+  double* part = statPart_.get();
+  const int sc = F_.scaled ? 1 : 0;
+  launchRowStats(ax_[c].get(), y_[c].get(), rhs_.get(), rowScale_.get(), mLoc_, F_.nEqs, r0_, sc,
+                 part + (size_t)kStatRowCur * statStride_, statStride_, nbM, stream_);
+  launchRowStats(axAvg_.get(), yAvg_.get(), rhs_.get(), rowScale_.get(), mLoc_, F_.nEqs, r0_, sc,
+                 part + (size_t)kStatRowAvg * statStride_, statStride_, nbM, stream_);
+  launchColStats(aty_[c].get(), x_[c].get(), cost_.get(), lower_.get(), upper_.get(), colScale_.get(), F_.n, sc,
+                 slackPos_.get(), slackNeg_.get(), part + (size_t)kStatColCur * statStride_, statStride_, nbN,
+                 stream_);
+  launchColStats(atyAvg_.get(), xAvg_.get(), cost_.get(), lower_.get(), upper_.get(), colScale_.get(), F_.n, sc,
+                 slackPosAvg_.get(), slackNegAvg_.get(), part + (size_t)kStatColAvg * statStride_, statStride_, nbN,
+                 stream_);
+  launchFinalReduce(part, statStride_, nbM, 2 * kRowStats, statOut_.get(), stream_);
+  launchFinalReduce(part + (size_t)kStatColCur * statStride_, statStride_, nbN, 2 * kColStats,
+                    statOut_.get() + kStatColCur, stream_);
+  if (world_ > 1) comm_->allReduceSum(statOut_.get(), 2 * kRowStats, stream_);
+  PDLP_HIP(hipMemcpyAsync(hostStats_, statOut_.get(), sizeof(double) * kStatTotal, hipMemcpyDeviceToHost, stream_));
+  PDLP_HIP(hipStreamSynchronize(stream_));
+
+  auto fill = [&](Residuals& r, const double* rs, const double* cs) {
+    r.pObj = cs[0] * F_.sense + F_.offset;
+    r.pFeas = std::sqrt(rs[0]);
+    r.dObj = (rs[1] + cs[1] - cs[2]) * F_.sense + F_.offset;
+    r.dFeas = std::sqrt(cs[3]);
+    r.gap = r.pObj - r.dObj;
+    r.relGap = std::fabs(r.pObj - r.dObj) / (1.0 + std::fabs(r.pObj) + std::fabs(r.dObj));
+    double dScale = std::sqrt(rs[2] + cs[4] + cs[5]);  // ||(y, s+, s-)||, cupdlp_solver.c:230-237
+    if (dScale < 1e-8) dScale = 1.0;
+    r.pInfObj = (r.dObj - F_.offset) / F_.sense / dScale;
+    r.pInfRes = std::sqrt(cs[6]) / dScale;
+    double pScale = std::sqrt(cs[7]);  // ||x||, :328-332
+    if (pScale < 1e-8) pScale = 1.0;
+    r.dInfObj = (r.pObj - F_.offset) / F_.sense / pScale;
+    r.dInfRes = std::sqrt(rs[3] + cs[8] + cs[9]) / pScale;
+  };
+  fill(cur_, hostStats_ + kStatRowCur, hostStats_ + kStatColCur);
+  fill(avg_, hostStats_ + kStatRowAvg, hostStats_ + kStatColAvg);
+}
+
+bool Solver::checkTermination(const Residuals& r) const {  // cupdlp_solver.c:797-841
+  return (r.pFeas < opt_.primal_tol * (1.0 + F_.normRhs)) && (r.dFeas < opt_.dual_tol * (1.0 + F_.normCost)) &&
+         (r.relGap < opt_.gap_tol);
+}
+
+bool Solver::checkInfeasibility() {  // cupdlp_solver.c:710-795
+  bool t = false;
+  auto primalInf = [&](const Residuals& r) { return r.pInfObj > 0.0 && r.pInfRes < feasTol_ * r.pInfObj; };
+  auto dualInf = [&](const Residuals& r) { return r.dInfObj < 0.0 && r.dInfRes < -feasTol_ * r.dInfObj; };
+  if (primalInf(cur_)) t = true;
+  if (dualInf(cur_)) t = true;
+  if (primalInf(avg_)) t = true;
+  if (dualInf(avg_)) t = true;
+  return t;
+}
+
+// PDHG_Restart_Iterate_GPU (cupdlp_proj.c:88-148) with PDHG_Check_Restart_GPU
+// (cupdlp_restart.c:3-124) and PDHG_Compute_Step_Size_Ratio (cupdlp_step.c:147-176).
+void Solver::restartIterate() {
+  if (!restartOn_) return;
+  DevState& s = *hostState_;
+  auto score = [](double beta, double p, double d, double g) { return std::sqrt(beta * p * p + d * d / beta + g * g); };
+  const int32_t it = s.nIter;
+  if (it == iLastRestartIter_) {
+    pFeasLR_ = cur_.pFeas; dFeasLR_ = cur_.dFeas; gapLR_ = cur_.gap;
+    pFeasLC_ = cur_.pFeas; dFeasLC_ = cur_.dFeas; gapLC_ = cur_.gap;
+    return;
+  }
+  const double muCur = score(s.beta, cur_.pFeas, cur_.dFeas, cur_.gap);
+  const double muAvg = score(s.beta, avg_.pFeas, avg_.dFeas, avg_.gap);
+  const bool toCurrent = muCur < muAvg;
+  const double muCand = toCurrent ? muCur : muAvg;
+  bool restart = true;
+  if ((it - iLastRestartIter_) >= 0.36 * it) {
+    // artificial restart
+  } else {
+    const double muLR = score(s.beta, pFeasLR_, dFeasLR_, gapLR_);
+    if (muCand < 0.2 * muLR) {
+      // sufficient decay
+    } else {
+      const double muLC = score(s.beta, pFeasLC_, dFeasLC_, gapLC_);
+      if (!(muCand < 0.8 * muLR && muCand > muLC)) restart = false;  // necessary decay
+    }
+  }
+  const Residuals& cand = toCurrent ? cur_ : avg_;
+  pFeasLC_ = cand.pFeas; dFeasLC_ = cand.dFeas; gapLC_ = cand.gap;
+  if (!restart) return;
+
+  const int c = s.cur;
+  const int32_t n = F_.n;
+  s.sumPrimalStep = 0.0;
+  s.sumDualStep = 0.0;
+  xSum_.zero(stream_);
+  ySum_.zero(stream_);
+  if (!toCurrent) {
+    pFeasLR_ = avg_.pFeas; dFeasLR_ = avg_.dFeas; gapLR_ = avg_.gap;
+    PDLP_HIP(hipMemcpyAsync(x_[c].get(), xAvg_.get(), sizeof(double) * n, hipMemcpyDeviceToDevice, stream_));
+    PDLP_HIP(hipMemcpyAsync(y_[c].get(), yAvg_.get(), sizeof(double) * mLoc_, hipMemcpyDeviceToDevice, stream_));
+    PDLP_HIP(hipMemcpyAsync(ax_[c].get(), axAvg_.get(), sizeof(double) * mLoc_, hipMemcpyDeviceToDevice, stream_));
+    PDLP_HIP(hipMemcpyAsync(aty_[c].get(), atyAvg_.get(), sizeof(double) * n, hipMemcpyDeviceToDevice, stream_));
+  } else {
+    pFeasLR_ = cur_.pFeas; dFeasLR_ = cur_.dFeas; gapLR_ = cur_.gap;
+  }
+  // primal weight update
+  const double mean = std::sqrt(s.primalStep * s.dualStep);
+  const int32_t nbN = vecBlocks(n), nbM = vecBlocks(std::max(mLoc_, 1));
+  launchDiffNorm2(x_[c].get(), xLast_.get(), n, partDX_.get(), nbN, stream_);
+  const double dP = std::sqrt(reduceScalar(partDX_.get(), nbN, false));
+  launchDiffNorm2(y_[c].get(), yLast_.get(), mLoc_, partDX_.get(), nbM, stream_);
+  const double dD = std::sqrt(reduceScalar(partDX_.get(), nbM, true));
+  if (std::fmin(dP, dD) > 1e-10) {
+    const double lg = 0.5 * std::log(dD / dP) + 0.5 * std::log(std::sqrt(s.beta));
+    s.beta = std::exp(lg) * std::exp(lg);
+  }
+  s.primalStep = mean / std::sqrt(s.beta);
+  s.dualStep = s.primalStep * s.beta;
+  s.eta = std::sqrt(s.primalStep * s.dualStep);
+  if (adaptive_) {
+    s.tau = s.eta / std::sqrt(s.beta);
+    s.sigma = s.eta * std::sqrt(s.beta);
+  } else {
+    s.tau = s.primalStep;
+    s.sigma = s.dualStep;
+  }
+  PDLP_HIP(hipMemcpyAsync(xLast_.get(), x_[c].get(), sizeof(double) * n, hipMemcpyDeviceToDevice, stream_));
+  PDLP_HIP(hipMemcpyAsync(yLast_.get(), y_[c].get(), sizeof(double) * mLoc_, hipMemcpyDeviceToDevice, stream_));
+  iLastRestartIter_ = it;
+  ++nRestarts_;
+  log(2, "Restart at iter %d to %s: beta = %g\n", it, toCurrent ? "current" : "average", s.beta);
+  // The reference recomputes the residuals here (cupdlp_proj.c:145); the values
+  // are overwritten by the next check before anything reads them, so we don't.
+}
+
+// PDHG_Solve, cupdlp_solver.c:899-1215.  `terminate` false = fixed-work timing loop.
+void Solver::doSolve(bool terminate, int32_t target) {
+  DevState& s = *hostState_;
+  const int64_t iterLim = terminate ? (int64_t)opt_.iter_limit : (int64_t)target;
+  int logSinceHeader = 50;
+  for (;;) {
+    const int32_t it = s.nIter;
+    if (it >= iterLim) break;
+    const double t = elapsed();
+    // Every stop of the device is a check iteration of the reference schedule
+    // (nIter < 10, nIter % 40 == 0, last iteration, or time limit exceeded).
+    computeAverage();
+    computeResiduals();
+    ++nChecks_;
+    if (opt_.log_level > 0 && rank_ == 0) {
+      const bool print = (it % (kCheckInterval * 100) == 0) || it == iterLim - 1 || t > opt_.time_limit;
+      if (print) {
+        if (logSinceHeader >= 50) {
+          printf("%9s  %15s  %15s   %8s  %10s  %8s %7s\n", "Iter", "Primal.Obj", "Dual.Obj", "Gap", "Primal.Inf",
+                 "Dual.Inf", "Time");
+          logSinceHeader = 0;
+        }
+        const Residuals& r = it == 0 ? cur_ : avg_;
+        printf("%9d  %+15.8e  %+15.8e  %+8.2e  %10.2e  %8.2e %6.2fs [%c]\n", it, r.pObj, r.dObj, r.relGap,
+               r.pFeas / (1.0 + F_.normRhs), r.dFeas / (1.0 + F_.normCost), t, it == 0 ? 'L' : 'A');
+        ++logSinceHeader;
+        fflush(stdout);
+      }
+    }
+    if (terminate) {
+      if (checkTermination(cur_)) { termIterate_ = 0; termCode_ = PDLP_TERM_OPTIMAL; break; }
+      if (checkTermination(avg_)) { termIterate_ = 1; termCode_ = PDLP_TERM_OPTIMAL; break; }
+      if (checkInfeasibility()) { termCode_ = PDLP_TERM_INFEASIBLE_OR_UNBOUNDED; break; }
+      if (t > opt_.time_limit) { termCode_ = PDLP_TERM_TIMELIMIT_OR_ITERLIMIT; break; }
+      if (it >= iterLim - 1) { termCode_ = PDLP_TERM_TIMELIMIT_OR_ITERLIMIT; break; }
+    }
+    restartIterate();
+    int64_t halt = nextCheckIter(it);
+    if (!terminate && halt > iterLim) halt = iterLim;
+    s.haltIter = (int32_t)halt;
+    s.halted = 0;
+    pushState();
+    runUntilHalt();
+  }
+}
+
+void Solver::run(pdlp_result_t* R) {
+  reset();
+  solveBeg_ = std::chrono::steady_clock::now();
+  if (hasStart_) log(1, "Hot starting with given column primal values and row dual values\n");
+  doSolve(true, 0);
+  solveSeconds_ = elapsed();
+  if (opt_.log_level > 0 && rank_ == 0) {
+    const Residuals& r = (termCode_ == PDLP_TERM_OPTIMAL && termIterate_ == 1) ? avg_ : cur_;
+    const char* what = termCode_ == PDLP_TERM_OPTIMAL
+                           ? (termIterate_ ? "Optimal average solution." : "Optimal current solution.")
+                           : termCode_ == PDLP_TERM_INFEASIBLE_OR_UNBOUNDED ? "Infeasible or unbounded."
+                                                                            : "Time or iteration limit reached.";
+    printf("\n%-27s %s\n%27s %+15.8e\n%27s %+15.8e\n%27s %8.2e / %8.2e\n%27s %8.2e / %8.2e\n%27s %8.2e\n%27s %d\n\n",
+           "Solving information:", what, "Primal objective:", r.pObj, "Dual objective:", r.dObj,
+           "Primal infeas (abs/rel):", r.pFeas, r.pFeas / (1.0 + F_.normRhs), "Dual infeas (abs/rel):", r.dFeas,
+           r.dFeas / (1.0 + F_.normCost), "Duality gap (rel):", r.relGap, "Number of iterations:",
+           hostState_->nIter);
+  }
+  if (R) postsolve(R);
+}
+
+void Solver::iterate(int32_t nIters, pdlp_iter_stats_t* st) {
+  syncState();
+  const int32_t it0 = hostState_->nIter, tr0 = hostState_->nTrials, ck0 = nChecks_, rs0 = nRestarts_;
+  solveBeg_ = std::chrono::steady_clock::now();
+  const double savedLimit = opt_.time_limit;
+  opt_.time_limit = INFINITY;
+  hipEvent_t e0, e1;
+  PDLP_HIP(hipEventCreate(&e0));
+  PDLP_HIP(hipEventCreate(&e1));
+  PDLP_HIP(hipEventRecord(e0, stream_));
+  doSolve(false, it0 + nIters);
+  PDLP_HIP(hipEventRecord(e1, stream_));
+  PDLP_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  PDLP_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  opt_.time_limit = savedLimit;
+  if (st) {
+    memset(st, 0, sizeof(*st));
+    st->iters = hostState_->nIter - it0;
+    st->trials = hostState_->nTrials - tr0;
+    st->checks = nChecks_ - ck0;
+    st->restarts = nRestarts_ - rs0;
+    st->gpu_ms = ms;
+    st->wall_ms = elapsed() * 1e3;
+  }
+}
+
+// PDHG_PostSolve, cupdlp_solver.c:1281-1435 (un-scale, un-permute, un-negate)
+void Solver::postsolve(pdlp_result_t* R) {
+  const int32_t n = F_.n, m = F_.m, n0 = F_.n0;
+  const bool useAvg = (termCode_ == PDLP_TERM_OPTIMAL && termIterate_ == 1);
+  const int c = hostState_->cur;
+  std::vector<double> x(n), sp(n), sn(n), y(m, 0.0), ax(m, 0.0);
+  (useAvg ? xAvg_ : x_[c]).download(x.data(), n, stream_);
+  (useAvg ? slackPosAvg_ : slackPos_).download(sp.data(), n, stream_);
+  (useAvg ? slackNegAvg_ : slackNeg_).download(sn.data(), n, stream_);
+  (useAvg ? yAvg_ : y_[c]).download(y.data() + r0_, mLoc_, stream_);
+  (useAvg ? axAvg_ : ax_[c]).download(ax.data() + r0_, mLoc_, stream_);
+  PDLP_HIP(hipStreamSynchronize(stream_));
+  if (world_ > 1) {  // assemble the row-sharded vectors on every rank
+    DeviceArray<double> g;
+    g.alloc(2 * (size_t)m);
+    std::vector<double> both(2 * (size_t)m, 0.0);
+    std::copy(y.begin() + r0_, y.begin() + r1_, both.begin() + r0_);
+    std::copy(ax.begin() + r0_, ax.begin() + r1_, both.begin() + m + r0_);
+    g.upload(both.data(), both.size(), stream_);
+    comm_->allReduceSum(g.get(), both.size(), stream_);
+    g.download(both.data(), both.size(), stream_);
+    PDLP_HIP(hipStreamSynchronize(stream_));
+    std::copy(both.begin(), both.begin() + m, y.begin());
+    std::copy(both.begin() + m, both.end(), ax.begin());
+  }
+  if (F_.scaled) {
+    for (int32_t j = 0; j < n; ++j) { x[j] /= F_.colScale[j]; sp[j] *= F_.colScale[j]; sn[j] *= F_.colScale[j]; }
+    for (int32_t i = 0; i < m; ++i) { y[i] /= F_.rowScale[i]; ax[i] *= F_.rowScale[i]; }
+  }
+  bool cv = false, cd = false, rv = false, rd = false;
+  if (R->col_value) { std::copy(x.begin(), x.begin() + n0, R->col_value); cv = true; }
+  if (R->row_value) {
+    for (int32_t i = 0, j = 0; i < m; ++i) {
+      double v = ax[F_.rowNewIdx[i]];
+      if (F_.rowKind[i] == kRowLeq) v = -v;
+      else if (F_.rowKind[i] == kRowBound) { v = v + x[n0 + j]; ++j; }
+      R->row_value[i] = v;
+    }
+    rv = true;
+  }
+  if (R->col_dual) {
+    for (int32_t j = 0; j < n0; ++j) R->col_dual[j] = (sp[j] - sn[j]) * F_.sense;
+    cd = true;
+  }
+  if (R->row_dual) {
+    for (int32_t i = 0; i < m; ++i) {
+      double v = y[F_.rowNewIdx[i]] * F_.sense;
+      if (F_.rowKind[i] == kRowLeq) v = -v;
+      R->row_dual[i] = v;
+    }
+    rd = true;
+  }
+  const Residuals& r = useAvg ? avg_ : cur_;
+  R->value_valid = cv && rv;
+  R->dual_valid = cd && rd;
+  R->term_code = termCode_;
+  R->term_iterate = termIterate_;
+  R->num_iter = hostState_->nIter;
+  R->num_trials = hostState_->nTrials;
+  R->num_restarts = nRestarts_;
+  R->primal_obj = r.pObj; R->dual_obj = r.dObj; R->primal_feas = r.pFeas; R->dual_feas = r.dFeas;
+  R->rel_gap = r.relGap; R->norm_rhs = F_.normRhs; R->norm_cost = F_.normCost;
+  R->setup_seconds = setupSeconds_;
+  R->solve_seconds = solveSeconds_;
+}
+
+// ---- test / measurement hooks -----------------------------------------------------
+std::pair<double*, int64_t> Solver::lookup(const std::string& name) {
+  const int c = hostState_->cur, u = c ^ 1;
+  const int64_t n = F_.n, m = mLoc_;
+  if (name == "x") return {x_[c].get(), n};
+  if (name == "y") return {y_[c].get(), m};
+  if (name == "ax") return {ax_[c].get(), m};
+  if (name == "aty") return {aty_[c].get(), n};
+  if (name == "x_next") return {x_[u].get(), n};
+  if (name == "y_next") return {y_[u].get(), m};
+  if (name == "ax_next") return {ax_[u].get(), m};
+  if (name == "aty_next") return {aty_[u].get(), n};
+  if (name == "x_avg") return {xAvg_.get(), n};
+  if (name == "y_avg") return {yAvg_.get(), m};
+  if (name == "ax_avg") return {axAvg_.get(), m};
+  if (name == "aty_avg") return {atyAvg_.get(), n};
+  if (name == "x_sum") return {xSum_.get(), n};
+  if (name == "y_sum") return {ySum_.get(), m};
+  if (name == "cost") return {cost_.get(), n};
+  if (name == "rhs") return {rhs_.get(), m};
+  if (name == "lower") return {lower_.get(), n};
+  if (name == "upper") return {upper_.get(), n};
+  if (name == "col_scale") return {colScale_.get(), n};
+  if (name == "row_scale") return {rowScale_.get(), m};
+  if (name == "slack_pos") return {slackPos_.get(), n};
+  if (name == "slack_neg") return {slackNeg_.get(), n};
+  throw std::runtime_error("unknown vector name: " + name);
+}
+
+void Solver::getVector(const std::string& name, double* host, int64_t len) {
+  syncState();
+  if (name == "steps") {  // {tau, sigma, beta, eta, primalStep, dualStep, sumPrimalStep, avgW}
+    const DevState& s = *hostState_;
+    const double v[8] = {s.tau, s.sigma, s.beta, s.eta, s.primalStep, s.dualStep, s.sumPrimalStep, s.avgW};
+    for (int64_t i = 0; i < len && i < 8; ++i) host[i] = v[i];
+    return;
+  }
+  auto [p, l] = lookup(name);
+  if (l != len) throw std::runtime_error("length mismatch for vector " + name);
+  PDLP_HIP(hipMemcpyAsync(host, p, sizeof(double) * len, hipMemcpyDeviceToHost, stream_));
+  PDLP_HIP(hipStreamSynchronize(stream_));
+}
+
+void Solver::setVector(const std::string& name, const double* host, int64_t len) {
+  syncState();
+  if (name == "steps") {  // {tau, sigma, beta}
+    if (len < 3) throw std::runtime_error("steps needs tau, sigma, beta");
+    DevState& s = *hostState_;
+    s.tau = host[0]; s.sigma = host[1]; s.beta = host[2];
+    s.eta = std::sqrt(s.tau * s.sigma);
+    s.primalStep = s.tau; s.dualStep = s.sigma;
+    pushState();
+    return;
+  }
+  auto [p, l] = lookup(name);
+  if (l != len) throw std::runtime_error("length mismatch for vector " + name);
+  PDLP_HIP(hipMemcpyAsync(p, host, sizeof(double) * len, hipMemcpyHostToDevice, stream_));
+  PDLP_HIP(hipStreamSynchronize(stream_));
+}
+
+void Solver::stage(const std::string& name, double* out, int32_t cap) {
+  syncState();
+  const int c = hostState_->cur;
+  auto put = [&](int i, double v) { if (out && i < cap) out[i] = v; };
+  if (name == "ax") {
+    deviceAx(x_[c].get(), ax_[c].get());
+  } else if (name == "aty") {
+    deviceATy(y_[c].get(), aty_[c].get());
+  } else if (name == "trial") {
+    hostState_->haltIter = INT_MAX;
+    hostState_->halted = 0;
+    pushState();
+    enqueueTrial();
+    syncState();
+    const DevState& s = *hostState_;
+    put(0, s.dX2); put(1, s.dY2); put(2, s.inter); put(3, (double)s.lastAccepted);
+    put(4, s.tau); put(5, s.sigma); put(6, s.eta); put(7, s.movement); put(8, s.limit);
+  } else if (name == "residuals") {
+    computeAverage();
+    computeResiduals();
+    put(0, cur_.pObj); put(1, cur_.dObj); put(2, cur_.pFeas); put(3, cur_.dFeas);
+    put(4, avg_.pObj); put(5, avg_.dObj); put(6, avg_.pFeas); put(7, avg_.dFeas);
+    put(8, cur_.pInfObj); put(9, cur_.pInfRes); put(10, cur_.dInfObj); put(11, cur_.dInfRes);
+  } else {
+    throw std::runtime_error("unknown stage: " + name);
+  }
+  PDLP_HIP(hipStreamSynchronize(stream_));
+}
+
+double Solver::timeKernel(const std::string& name, int32_t reps) {
+  syncState();
+  if (reps < 1) reps = 1;
+  launchFlushAverage(vecs_, dState_.get(), stream_);
+  hostState_->avgW = 0.0;
+  const int32_t savedHalt = hostState_->haltIter;
+  hostState_->haltIter = INT_MAX;
+  hostState_->halted = 0;
+  pushState();
+  DeviceArray<double> big;
+  size_t bigCount = 0;
+  if (name == "copy") {
+    bigCount = (size_t)64 << 20;  // 2 x 512 MiB: beyond the 256 MiB Infinity Cache
+    big.alloc(2 * bigCount);
+    big.zero(stream_);
+  }
+  auto once = [&]() {
+    if (name == "spmv_ax") launchSpmvAxDual(dA_.view(), vecs_, dState_.get(), partDY_.get(), stream_);
+    else if (name == "spmv_aty") {
+      if (world_ == 1) launchSpmvAtyInteract(dAt_.view(), vecs_, dState_.get(), partDX_.get(), partInter_.get(), stream_);
+      else launchSpmvAtyPartial(dAt_.view(), vecs_, dState_.get(), commBuf_.get(), stream_);
+    } else if (name == "primal_step") launchPrimalStep(vecs_, dState_.get(), stream_);
+    else if (name == "decide")
+      launchDecide(dState_.get(), partDY_.get(), dA_.nBlocks, partDX_.get(), partInter_.get(), dAt_.nBlocks, nullptr, stream_);
+    else if (name == "trial") enqueueTrial();
+    else if (name == "spmv_ax_plain") launchSpmvPlain(dA_.view(), x_[0].get(), tmpM_.get(), stream_);
+    else if (name == "spmv_aty_plain") launchSpmvPlain(dAt_.view(), y_[0].get(), commBuf_.get(), stream_);
+    else if (name == "copy")
+      PDLP_HIP(hipMemcpyAsync(big.get() + bigCount, big.get(), sizeof(double) * bigCount, hipMemcpyDeviceToDevice, stream_));
+    else throw std::runtime_error("unknown kernel: " + name);
+  };
+  for (int i = 0; i < 3; ++i) once();  // warm-up
+  hipEvent_t e0, e1;
+  PDLP_HIP(hipEventCreate(&e0));
+  PDLP_HIP(hipEventCreate(&e1));
+  PDLP_HIP(hipEventRecord(e0, stream_));
+  for (int i = 0; i < reps; ++i) once();
+  PDLP_HIP(hipEventRecord(e1, stream_));
+  PDLP_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  PDLP_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  syncState();
+  hostState_->haltIter = savedHalt;
+  pushState();
+  return (double)ms / reps;
+}
+
+}  // namespace pdlp

@@ -1,0 +1,171 @@
+// pdlp_solver.hpp — device-resident PDHG driver (the MI355X counterpart of
+// cuPDLP-C's LP_SolvePDHG / PDHG_Solve, cupdlp_solver.c:899-1498).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdint>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "pdlp_host.hpp"
+#include "pdlp_kernels.hpp"
+
+namespace pdlp {
+
+#define PDLP_HIP(expr)                                                                              \
+  do {                                                                                              \
+    hipError_t e_ = (expr);                                                                         \
+    if (e_ != hipSuccess)                                                                           \
+      throw std::runtime_error(std::string("HIP error ") + hipGetErrorString(e_) + " at " __FILE__ \
+                               ":" + std::to_string(__LINE__) + " in " #expr);                      \
+  } while (0)
+
+template <typename T>
+class DeviceArray {
+ public:
+  DeviceArray() = default;
+  DeviceArray(const DeviceArray&) = delete;
+  DeviceArray& operator=(const DeviceArray&) = delete;
+  ~DeviceArray() { release(); }
+  void alloc(size_t count) {
+    release();
+    n_ = count;
+    PDLP_HIP(hipMalloc(&p_, sizeof(T) * (count ? count : 1)));
+  }
+  void release() {
+    if (p_) (void)hipFree(p_);
+    p_ = nullptr;
+    n_ = 0;
+  }
+  void upload(const T* host, size_t count, hipStream_t s) {
+    if (count) PDLP_HIP(hipMemcpyAsync(p_, host, sizeof(T) * count, hipMemcpyHostToDevice, s));
+  }
+  void download(T* host, size_t count, hipStream_t s) const {
+    if (count) PDLP_HIP(hipMemcpyAsync(host, p_, sizeof(T) * count, hipMemcpyDeviceToHost, s));
+  }
+  void zero(hipStream_t s) {
+    if (n_) PDLP_HIP(hipMemsetAsync(p_, 0, sizeof(T) * n_, s));
+  }
+  T* get() const { return p_; }
+  size_t size() const { return n_; }
+
+ private:
+  T* p_ = nullptr;
+  size_t n_ = 0;
+};
+
+struct DeviceMatrix {
+  DeviceArray<int32_t> beg, idx, blockBeg;
+  DeviceArray<double> val;
+  int32_t nMajor = 0, nBlocks = 0;
+  int64_t nnz = 0;
+  void upload(const Compressed& c, int32_t nMajor_, hipStream_t s);
+  SpmvMat view() const { return SpmvMat{beg.get(), idx.get(), val.get(), blockBeg.get(), nMajor, nBlocks}; }
+};
+
+class Comm;  // RCCL wrapper (pdlp_comm.cpp)
+
+// Host copy of cuPDLP's CUPDLPresobj numbers for one iterate.
+struct Residuals {
+  double pObj = 0, dObj = 0, gap = 0, relGap = 0, pFeas = 0, dFeas = 0;
+  double pInfObj = 0, pInfRes = 1, dInfObj = 0, dInfRes = 1;
+};
+
+class Solver {
+ public:
+  Solver(const pdlp_problem_t& P, const pdlp_params_t& opt, int32_t rank, int32_t world, const void* id128);
+  ~Solver();
+
+  void run(pdlp_result_t* R);                          // LP_SolvePDHG
+  void iterate(int32_t nIters, pdlp_iter_stats_t* st);  // fixed-work loop for timing
+  void reset();                                        // PDHG_Init_Step_Sizes + PDHG_Init_Variables
+
+  void dims(int32_t* n, int32_t* m, int64_t* nnz, int32_t* nEqs) const;
+  void getVector(const std::string& name, double* host, int64_t len);
+  void setVector(const std::string& name, const double* host, int64_t len);
+  void stage(const std::string& name, double* out, int32_t cap);
+  double timeKernel(const std::string& name, int32_t reps);
+
+ private:
+  // setup
+  void uploadProblem();
+  void initStepSizes();
+  void initVariables();
+  void applyHotStart();
+  // hot loop
+  void enqueueTrial();
+  void runUntilHalt();
+  void syncState();    // device -> host_
+  void pushState();    // host_ -> device
+  // check iteration
+  void computeAverage();
+  void computeResiduals();
+  bool checkTermination(const Residuals& r) const;
+  bool checkInfeasibility();
+  void restartIterate();
+  int32_t nextCheckIter(int32_t it) const;
+  void doSolve(bool terminate, int32_t iterBudget);
+  void postsolve(pdlp_result_t* R);
+  // linear algebra on device (sharding-aware)
+  void deviceAx(const double* x, double* axLocal);
+  void deviceATy(const double* yLocal, double* aty);
+  double reduceScalar(const double* partials, int32_t nBlocks, bool rowQuantity);
+  std::pair<double*, int64_t> lookup(const std::string& name);
+  void log(int level, const char* fmt, ...) const;
+  double elapsed() const;
+
+  pdlp_params_t opt_;
+  StandardForm F_;
+  bool hasStart_ = false;
+  std::vector<double> startX_, startY_;
+  // sharding
+  int32_t rank_ = 0, world_ = 1, r0_ = 0, r1_ = 0, mLoc_ = 0;
+  Comm* comm_ = nullptr;
+  // device
+  hipStream_t stream_ = nullptr;
+  DeviceMatrix dA_, dAt_;
+  DeviceArray<double> x_[2], y_[2], ax_[2], aty_[2];
+  DeviceArray<double> xAvg_, yAvg_, axAvg_, atyAvg_, xSum_, ySum_, xLast_, yLast_;
+  DeviceArray<double> cost_, rhs_, lower_, upper_, colScale_, rowScale_;
+  DeviceArray<double> slackPos_, slackNeg_, slackPosAvg_, slackNegAvg_;
+  DeviceArray<double> partDY_, partDX_, partInter_, statPart_, statOut_, commBuf_, tmpM_;
+  DeviceArray<DevState> dState_;
+  DevState* hostState_ = nullptr;  // pinned mirror
+  double* hostStats_ = nullptr;    // pinned
+  int32_t statStride_ = 0;
+  IterVecs vecs_{};
+  // scalar solver state (host side of CUPDLPresobj / CUPDLPiterates)
+  Residuals cur_, avg_;
+  double pFeasLR_ = 0, dFeasLR_ = 0, gapLR_ = 0, pFeasLC_ = 0, dFeasLC_ = 0, gapLC_ = 0;
+  int32_t iLastRestartIter_ = 0, nRestarts_ = 0, nChecks_ = 0;
+  int32_t termCode_ = PDLP_TERM_TIMELIMIT_OR_ITERLIMIT, termIterate_ = 0;
+  bool adaptive_ = true, restartOn_ = true;
+  double feasTol_ = 1e-8;
+  std::chrono::steady_clock::time_point solveBeg_;
+  double setupSeconds_ = 0, solveSeconds_ = 0;
+  // optional hipGraph of a batch of trials
+  hipGraphExec_t graphExec_ = nullptr;
+  int32_t graphTrials_ = 0;
+  bool useGraph_ = true;
+};
+
+// RCCL communicator, loaded lazily with dlopen so that the library itself has
+// no link-time dependency on librccl.
+class Comm {
+ public:
+  static void uniqueId(void* id128);
+  Comm(int32_t rank, int32_t world, const void* id128);
+  ~Comm();
+  void allReduceSum(double* buf, size_t count, hipStream_t s);
+  int32_t rank() const { return rank_; }
+  int32_t world() const { return world_; }
+
+ private:
+  void* comm_ = nullptr;
+  int32_t rank_, world_;
+};
+
+}  // namespace pdlp

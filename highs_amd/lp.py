@@ -247,50 +247,50 @@ def read_mps(path):
     return HighsLp(n, m, c, cl, cu, rl, ru, a_start, a_index, a_value, sense, offset, name).normalise()
 
 
-def kkt_measures(lp, col_value, col_dual, row_value, row_dual):
+def kkt_measures(lp, col_value, col_dual, row_value, row_dual, primal_feasibility_tolerance=1e-7):
     """The HighsInfo quantities HiGHS derives from a returned LP solution
-    (getKktFailures / getLpKktFailures, lp_data/HighsSolution.cpp): objective,
-    max primal/dual infeasibility, max primal/dual residual error and the
-    relative primal-dual objective error.  Used for the parity columns."""
-    x = np.asarray(col_value)
+    (getKktFailures lp_data/HighsSolution.cpp:73-565, getVariableKktFailures
+    :567-660, computeDualObjectiveValue :1345-1392): objective, max primal /
+    dual infeasibility, max primal / dual residual error and the relative
+    primal-dual objective error.  Used for the parity columns."""
+    x = np.asarray(col_value, dtype=np.float64)
+    rv = np.asarray(row_value, dtype=np.float64)
+    cd = np.asarray(col_dual, dtype=np.float64)
+    rd = np.asarray(row_dual, dtype=np.float64)
     ax = lp.row_activity(x)
     obj = lp.objective_value(x)
-    pinf_c = np.maximum(np.maximum(lp.col_lower - x, x - lp.col_upper), 0.0)
-    pinf_r = np.maximum(np.maximum(lp.row_lower - row_value, row_value - lp.row_upper), 0.0)
-    pres = np.abs(ax - row_value)
-    # dual residual: c - A'y - z = 0  (HiGHS sign convention: col_dual = c - A' row_dual)
     cols = np.repeat(np.arange(lp.num_col), np.diff(lp.a_start))
     aty = np.zeros(lp.num_col)
-    np.add.at(aty, cols, lp.a_value * np.asarray(row_dual)[lp.a_index])
-    dres = np.abs(lp.col_cost - aty - col_dual)
-
-    def dual_infeas(lower, upper, value, dual, tol=1e-7):
-        d = lp.sense * np.asarray(dual)
-        at_lo = np.abs(value - lower) <= tol
-        at_up = np.abs(value - upper) <= tol
-        fixed = lower >= upper
-        out = np.abs(d)  # off bounds / free
-        out = np.where(at_lo & ~at_up, np.maximum(-d, 0.0), out)
-        out = np.where(at_up & ~at_lo, np.maximum(d, 0.0), out)
-        out = np.where(fixed, 0.0, out)
-        return out
-
-    dinf_c = dual_infeas(lp.col_lower, lp.col_upper, x, col_dual)
-    dinf_r = dual_infeas(lp.row_lower, lp.row_upper, np.asarray(row_value), row_dual)
-    # dual objective
-    def bound_term(lower, upper, dual):
-        d = np.asarray(dual)
-        lo = np.where(np.isfinite(lower), lower, 0.0)
-        up = np.where(np.isfinite(upper), upper, 0.0)
-        s = lp.sense
-        return float(np.sum(np.where(s * d > 0, lo * d, up * d)))
-
-    dobj = lp.offset + bound_term(lp.col_lower, lp.col_upper, col_dual) + bound_term(lp.row_lower, lp.row_upper, row_dual)
+    np.add.at(aty, cols, lp.a_value * rd[lp.a_index])
+    lower = np.concatenate([lp.col_lower, lp.row_lower])
+    upper = np.concatenate([lp.col_upper, lp.row_upper])
+    value = np.concatenate([x, rv])
+    dual = lp.sense * np.concatenate([cd, rd])
+    pinf = np.maximum(np.maximum(lower - value, value - upper), 0.0)
+    free = np.isneginf(lower) & np.isposinf(upper)
+    with np.errstate(invalid="ignore"):
+        length = upper - lower
+        middle = (lower + upper) * 0.5
+    meaningful = (lower < upper) & ~free & (length * length > primal_feasibility_tolerance)
+    below = value < middle
+    dinf = np.zeros_like(value)
+    dinf = np.where(free, np.abs(dual), dinf)
+    dinf = np.where(meaningful & below, np.maximum(-dual, 0.0), dinf)
+    dinf = np.where(meaningful & ~below, np.maximum(dual, 0.0), dinf)
+    # residuals: |Ax - row_value| and |A'y + col_dual - c| (HighsSolution.cpp:196-199,263-268,400+)
+    pres = np.abs(ax - rv)
+    dres = np.abs(aty + cd - lp.col_cost)
+    # dual objective: offset + sum bound * dual, bound = lower if primal < mid else upper; free -> 1
+    ndual = np.concatenate([cd, rd])
+    bound = np.where(free, 1.0, np.where(below, lower, upper))
+    with np.errstate(invalid="ignore"):
+        terms = np.where(ndual == 0.0, 0.0, bound * ndual)
+    dobj = float(lp.offset + np.sum(terms))
     return {
         "objective_function_value": obj,
         "dual_objective_value": dobj,
-        "max_primal_infeasibility": float(max(pinf_c.max(initial=0.0), pinf_r.max(initial=0.0))),
-        "max_dual_infeasibility": float(max(dinf_c.max(initial=0.0), dinf_r.max(initial=0.0))),
+        "max_primal_infeasibility": float(pinf.max(initial=0.0)),
+        "max_dual_infeasibility": float(dinf.max(initial=0.0)),
         "max_primal_residual_error": float(pres.max(initial=0.0)),
         "max_dual_residual_error": float(dres.max(initial=0.0)),
         "primal_dual_objective_error": abs(obj - dobj) / (1.0 + abs(obj) + abs(dobj)),

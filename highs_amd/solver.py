@@ -1,0 +1,274 @@
+"""Host-side mirror of the reference interface of the PDLP path.
+
+`solveLpCupdlp(lp, options)` has the role of the reference's
+`HighsStatus solveLpCupdlp(HighsLpSolverObject&)` (highs/pdlp/CupdlpWrapper.cpp:23-278):
+options in (`getUserParamsFromOptions` :642-717), HighsSolution / model status
+/ pdlp_iteration_count out (status map :225-251).  All the arithmetic happens
+in the C-ABI library libpdlp_mi355x.so on the GPU; there is NO CPU fallback —
+if the library or a HIP device is missing this raises.
+"""
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import abi
+from .lp import HighsLp, kkt_measures
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpdlp_mi355x.so")
+
+# HighsModelStatus values (lp_data/HConst.h, highs_c_api.h:74-91)
+kSolveError, kOptimal, kInfeasible, kUnboundedOrInfeasible, kUnbounded = 4, 7, 8, 9, 10
+kTimeLimit, kIterationLimit, kUnknown = 13, 14, 15
+MODEL_STATUS_NAME = {4: "Solve error", 7: "Optimal", 8: "Infeasible", 9: "Primal infeasible or unbounded",
+                     10: "Unbounded", 13: "Time limit reached", 14: "Iteration limit reached", 15: "Unknown"}
+# HighsStatus
+kOk, kWarning, kError = 0, 1, -1
+
+_lib = None
+
+EXPORTS = [
+    "pdlp_mi355x_default_params", "pdlp_mi355x_solve", "pdlp_mi355x_create", "pdlp_mi355x_run",
+    "pdlp_mi355x_destroy", "pdlp_mi355x_dims", "pdlp_mi355x_reset", "pdlp_mi355x_iterate",
+    "pdlp_mi355x_get_vector", "pdlp_mi355x_set_vector", "pdlp_mi355x_stage", "pdlp_mi355x_time_kernel",
+    "pdlp_mi355x_comm_unique_id", "pdlp_mi355x_create_sharded", "pdlp_mi355x_gen_synthetic",
+    "pdlp_mi355x_free_problem", "pdlp_mi355x_last_error", "pdlp_mi355x_abi_version",
+    "pdlp_mi355x_host_prepare", "pdlp_mi355x_free_prepared", "pdlp_mi355x_row_partition", "pdlp_mi355x_sizeof",
+]
+
+
+def build(force=False):
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    src = os.path.join(_HERE, "csrc")
+    if force and os.path.exists(LIB_PATH):
+        os.remove(LIB_PATH)
+    subprocess.check_call(["make", "-s", "-C", src])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(the PDLP path has no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        pP, pO, pR = C.POINTER(abi.PdlpProblem), C.POINTER(abi.PdlpParams), C.POINTER(abi.PdlpResult)
+        H = C.c_void_p
+        L.pdlp_mi355x_default_params.argtypes = [pO]
+        L.pdlp_mi355x_solve.argtypes = [pP, pO, pR]
+        L.pdlp_mi355x_create.argtypes = [pP, pO, C.POINTER(H)]
+        L.pdlp_mi355x_create_sharded.argtypes = [pP, pO, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(H)]
+        L.pdlp_mi355x_run.argtypes = [H, pR]
+        L.pdlp_mi355x_destroy.argtypes = [H]
+        L.pdlp_mi355x_destroy.restype = None
+        L.pdlp_mi355x_dims.argtypes = [H, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+        L.pdlp_mi355x_reset.argtypes = [H]
+        L.pdlp_mi355x_iterate.argtypes = [H, C.c_int32, C.POINTER(abi.PdlpIterStats)]
+        L.pdlp_mi355x_get_vector.argtypes = [H, C.c_char_p, abi.c_f64p, C.c_int64]
+        L.pdlp_mi355x_set_vector.argtypes = [H, C.c_char_p, abi.c_f64p, C.c_int64]
+        L.pdlp_mi355x_stage.argtypes = [H, C.c_char_p, abi.c_f64p, C.c_int32]
+        L.pdlp_mi355x_time_kernel.argtypes = [H, C.c_char_p, C.c_int32, C.POINTER(C.c_double)]
+        L.pdlp_mi355x_comm_unique_id.argtypes = [C.c_void_p]
+        L.pdlp_mi355x_gen_synthetic.argtypes = [C.c_int32, C.c_int32, C.c_int64, C.c_uint64, pP]
+        L.pdlp_mi355x_free_problem.argtypes = [pP]
+        L.pdlp_mi355x_free_problem.restype = None
+        pPrep = C.POINTER(abi.PdlpPrepared)
+        L.pdlp_mi355x_host_prepare.argtypes = [pP, pO, pPrep]
+        L.pdlp_mi355x_free_prepared.argtypes = [pPrep]
+        L.pdlp_mi355x_free_prepared.restype = None
+        L.pdlp_mi355x_row_partition.argtypes = [pPrep, C.c_int32, abi.c_i32p]
+        L.pdlp_mi355x_sizeof.argtypes = [C.c_int32]
+        L.pdlp_mi355x_sizeof.restype = C.c_int64
+        L.pdlp_mi355x_last_error.restype = C.c_char_p
+        L.pdlp_mi355x_abi_version.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed: {lib().pdlp_mi355x_last_error().decode()}")
+
+
+@dataclass
+class HighsSolution:
+    col_value: np.ndarray
+    col_dual: np.ndarray
+    row_value: np.ndarray
+    row_dual: np.ndarray
+    value_valid: bool = False
+    dual_valid: bool = False
+
+
+@dataclass
+class PdlpOutcome:
+    status: int  # HighsStatus
+    model_status: int  # HighsModelStatus
+    solution: HighsSolution
+    pdlp_iteration_count: int
+    info: dict = field(default_factory=dict)
+    result: object = None
+
+
+def model_status_from_term(term_code, num_iter, iter_limit, rc=0):
+    """Status map of CupdlpWrapper.cpp:225-251."""
+    if rc != 0:
+        return kSolveError
+    if term_code == abi.TERM_OPTIMAL:
+        return kOptimal
+    if term_code == abi.TERM_INFEASIBLE:
+        return kInfeasible
+    if term_code == abi.TERM_UNBOUNDED:
+        return kUnbounded
+    if term_code == abi.TERM_INFEASIBLE_OR_UNBOUNDED:
+        return kUnboundedOrInfeasible
+    if term_code == abi.TERM_TIMELIMIT_OR_ITERLIMIT:
+        return kIterationLimit if num_iter >= iter_limit - 1 else kTimeLimit
+    return kUnknown
+
+
+def solveLpCupdlp(lp: HighsLp, start=None, solve_fn=None, **options):
+    """Solve `lp` with the MI355X PDLP path.  Keyword options use the HiGHS
+    option names: kkt_tolerance, primal_feasibility_tolerance (primal_tol),
+    pdlp_iteration_limit, pdlp_features_off, time_limit, log_level, ...
+    `solve_fn` lets the tests run the same marshalling against the oracle."""
+    params = options.pop("params", None) or abi.default_params(**options)
+    P = abi.ProblemHandle(lp, start)
+    R = abi.ResultHandle(lp.num_col, lp.num_row)
+    fn = solve_fn or lib().pdlp_mi355x_solve
+    rc = fn(C.byref(P.struct), C.byref(params), C.byref(R.struct))
+    ms = model_status_from_term(R.term_code, R.num_iter, params.iter_limit, rc)
+    sol = HighsSolution(R.col_value, R.col_dual, R.row_value, R.row_dual, bool(R.value_valid), bool(R.dual_valid))
+    info = kkt_measures(lp, sol.col_value, sol.col_dual, sol.row_value, sol.row_dual) if rc == 0 else {}
+    info["pdlp_iteration_count"] = int(R.num_iter)
+    status = kError if rc != 0 else (kOk if ms == kOptimal or ms == kUnboundedOrInfeasible else kWarning)
+    return PdlpOutcome(status, ms, sol, int(R.num_iter), info, R)
+
+
+class DeviceSolver:
+    """Long-lived solver context with the problem resident in HBM (pdlp_mi355x_create ... destroy)."""
+
+    def __init__(self, lp=None, problem_struct=None, params=None, rank=0, world=1, unique_id=None, **options):
+        self.params = params or abi.default_params(**options)
+        self._keep = None
+        if problem_struct is None:
+            self._keep = abi.ProblemHandle(lp)
+            problem_struct = self._keep.struct
+        self.h = C.c_void_p()
+        if world > 1:
+            rc = lib().pdlp_mi355x_create_sharded(C.byref(problem_struct), C.byref(self.params), rank, world,
+                                                  unique_id, C.byref(self.h))
+        else:
+            rc = lib().pdlp_mi355x_create(C.byref(problem_struct), C.byref(self.params), C.byref(self.h))
+        _check(rc, "pdlp_mi355x_create")
+        n, m, nnz, ne = C.c_int32(), C.c_int32(), C.c_int64(), C.c_int32()
+        _check(lib().pdlp_mi355x_dims(self.h, C.byref(n), C.byref(m), C.byref(nnz), C.byref(ne)), "dims")
+        self.n, self.m, self.nnz, self.n_eqs = n.value, m.value, nnz.value, ne.value
+
+    def close(self):
+        if self.h:
+            lib().pdlp_mi355x_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, num_col, num_row):
+        R = abi.ResultHandle(num_col, num_row)
+        _check(lib().pdlp_mi355x_run(self.h, C.byref(R.struct)), "pdlp_mi355x_run")
+        return R
+
+    def reset(self):
+        _check(lib().pdlp_mi355x_reset(self.h), "reset")
+
+    def iterate(self, n_iters):
+        st = abi.PdlpIterStats()
+        _check(lib().pdlp_mi355x_iterate(self.h, n_iters, C.byref(st)), "iterate")
+        return st
+
+    def get(self, name, length):
+        out = np.zeros(length)
+        _check(lib().pdlp_mi355x_get_vector(self.h, name.encode(), out.ctypes.data_as(abi.c_f64p), length), "get " + name)
+        return out
+
+    def set(self, name, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        _check(lib().pdlp_mi355x_set_vector(self.h, name.encode(), arr.ctypes.data_as(abi.c_f64p), arr.size), "set " + name)
+
+    def stage(self, name, n_out=16):
+        out = np.zeros(n_out)
+        _check(lib().pdlp_mi355x_stage(self.h, name.encode(), out.ctypes.data_as(abi.c_f64p), n_out), "stage " + name)
+        return out
+
+    def time_kernel(self, name, reps=20):
+        ms = C.c_double()
+        _check(lib().pdlp_mi355x_time_kernel(self.h, name.encode(), reps, C.byref(ms)), "time " + name)
+        return ms.value
+
+
+class SyntheticProblem:
+    """The synthetic LP of SURVEY §8d, generated by the library (C++ std::mt19937_64)."""
+
+    def __init__(self, m, n, nnz, seed=1):
+        self.struct = abi.PdlpProblem()
+        rc = lib().pdlp_mi355x_gen_synthetic(m, n, nnz, seed, C.byref(self.struct))
+        if rc != 0:
+            raise RuntimeError("gen_synthetic failed")
+
+    def to_lp(self):
+        P = self.struct
+        n, m, nnz = P.num_col, P.num_row, P.num_nz
+        g = lambda p, k: np.ctypeslib.as_array(p, shape=(k,)).copy()
+        return HighsLp(n, m, g(P.col_cost, n), g(P.col_lower, n), g(P.col_upper, n), g(P.row_lower, m), g(P.row_upper, m),
+                       g(P.a_start, n + 1), g(P.a_index, nnz), g(P.a_value, nnz), int(P.sense), float(P.offset),
+                       "synthetic").normalise()
+
+    def close(self):
+        if self.struct.a_start:
+            lib().pdlp_mi355x_free_problem(C.byref(self.struct))
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Prepared:
+    """Host-side standard form built by the PRODUCT library (pdlp_mi355x_host_prepare); numpy copies."""
+
+    def __init__(self, lp=None, params=None, problem_struct=None, **options):
+        params = params or abi.default_params(**options)
+        keep = None
+        if problem_struct is None:
+            keep = abi.ProblemHandle(lp)
+            problem_struct = keep.struct
+        F = abi.PdlpPrepared()
+        _check(lib().pdlp_mi355x_host_prepare(C.byref(problem_struct), C.byref(params), C.byref(F)), "host_prepare")
+        n, m, nnz = F.n, F.m, F.nnz
+        self.n, self.m, self.n_eqs, self.n_orig, self.nnz = n, m, F.n_eqs, F.n_orig, nnz
+        g = lambda p, k, dt: np.ctypeslib.as_array(p, shape=(max(k, 1),))[:k].astype(dt).copy()
+        self.csr_beg = g(F.csr_beg, m + 1, np.int32); self.csr_idx = g(F.csr_idx, nnz, np.int32); self.csr_val = g(F.csr_val, nnz, np.float64)
+        self.csc_beg = g(F.csc_beg, n + 1, np.int32); self.csc_idx = g(F.csc_idx, nnz, np.int32); self.csc_val = g(F.csc_val, nnz, np.float64)
+        self.cost = g(F.cost, n, np.float64); self.rhs = g(F.rhs, m, np.float64)
+        self.lower = g(F.lower, n, np.float64); self.upper = g(F.upper, n, np.float64)
+        self.col_scale = g(F.col_scale, n, np.float64); self.row_scale = g(F.row_scale, m, np.float64)
+        self.row_kind = g(F.row_kind, m, np.int32); self.row_new_idx = g(F.row_new_idx, m, np.int32)
+        self.norm_cost, self.norm_rhs, self.mat_norm_inf = F.norm_cost, F.norm_rhs, F.mat_norm_inf
+        self.spmv_blocks_ax, self.spmv_blocks_aty = F.spmv_blocks_ax, F.spmv_blocks_aty
+        self._parts = {}
+        for w in (1, 2, 3, 4, 8):
+            off = np.zeros(w + 1, dtype=np.int32)
+            _check(lib().pdlp_mi355x_row_partition(C.byref(F), w, off.ctypes.data_as(abi.c_i32p)), "row_partition")
+            self._parts[w] = off
+        lib().pdlp_mi355x_free_prepared(C.byref(F))
+
+    def row_partition(self, world):
+        return self._parts[world]

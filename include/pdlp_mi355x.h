@@ -222,6 +222,33 @@ int pdlp_mi355x_gen_synthetic(int32_t m, int32_t n, int64_t nnz_target,
                               uint64_t seed, pdlp_problem_t* P_out);
 void pdlp_mi355x_free_problem(pdlp_problem_t* P);
 
+/* ---- host-only introspection (no GPU needed) ---------------------------
+ * The standard form the device iterates on: formulate (CupdlpWrapper.cpp:280-448)
+ * + scaling (cupdlp_scaling.c) + both matrix orientations (cupdlp_utils.c:1222).
+ * Used by the CPU test-suite to check the host logic against the oracle and
+ * by the multi-GPU tests to check the row-block partition.  Arrays are
+ * malloc'ed by the library; release with pdlp_mi355x_free_prepared. */
+typedef struct pdlp_prepared {
+  int32_t n, m, n_eqs, n_orig;
+  int64_t nnz;
+  int32_t *csr_beg, *csr_idx; /* rows, ascending column */
+  double* csr_val;
+  int32_t *csc_beg, *csc_idx; /* columns, ascending row */
+  double* csc_val;
+  double *cost, *rhs, *lower, *upper, *col_scale, *row_scale;
+  int32_t *row_kind, *row_new_idx; /* per original row */
+  double norm_cost, norm_rhs, mat_norm_inf;
+  int32_t spmv_blocks_ax, spmv_blocks_aty; /* CSR-adaptive work blocks */
+} pdlp_prepared_t;
+int pdlp_mi355x_host_prepare(const pdlp_problem_t* P, const pdlp_params_t* opt,
+                             pdlp_prepared_t* out);
+void pdlp_mi355x_free_prepared(pdlp_prepared_t* out);
+/* Row-block partition used by create_sharded: offsets[world+1]. */
+int pdlp_mi355x_row_partition(const pdlp_prepared_t* prep, int32_t world,
+                              int32_t* offsets);
+/* sizeof() of the ABI structs: 0 problem, 1 params, 2 result, 3 iter_stats, 4 prepared */
+int64_t pdlp_mi355x_sizeof(int32_t which);
+
 const char* pdlp_mi355x_last_error(void);
 int pdlp_mi355x_abi_version(void);
 

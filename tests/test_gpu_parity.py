@@ -1,0 +1,280 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the oracle."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oraclelib as O
+from highs_amd import abi, solver
+from highs_amd import lp as L
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+REF = json.load(open(os.path.join(GOLD, "reference_pdlp.json")))
+
+
+def _lp(name):
+    return L.HighsLp.from_npz(os.path.join(GOLD, "instances", name + ".npz"))
+
+
+def _spmv(beg, idx, val, x, m):
+    out = np.zeros(m)
+    p = lambda a, t: np.ascontiguousarray(a).ctypes.data_as(t)
+    O.oracle().pdlp_oracle_spmv_csr(m, p(beg, abi.c_i32p), p(idx, abi.c_i32p), p(val, abi.c_f64p),
+                                    np.ascontiguousarray(x).ctypes.data_as(abi.c_f64p), out.ctypes.data_as(abi.c_f64p))
+    return out
+
+
+def _problems():
+    yield "25fv47", _lp("25fv47"), None
+    yield "shell", _lp("shell"), None
+    sp_ = solver.SyntheticProblem(30000, 25000, 240000, 7)
+    yield "synthetic", None, sp_
+
+
+@pytest.mark.parametrize("which", ["25fv47", "shell", "synthetic"])
+def test_spmv_bit_exact(which):
+    """A x (CSR) and A' y (CSC) — integer-exact placement and, because every major is summed left to
+    right like AxCPU/ATyCPU (cupdlp_linalg.c:35-109), bit-identical values."""
+    for name, lp, sp_ in _problems():
+        if name != which:
+            continue
+        kw = dict(problem_struct=sp_.struct) if sp_ else dict(lp=lp)
+        P = solver.Prepared(**kw)
+        S = solver.DeviceSolver(**kw)
+        rng = np.random.default_rng(0)
+        x = rng.standard_normal(P.n)
+        y = rng.standard_normal(P.m)
+        S.set("x", x)
+        S.set("y", y)
+        S.stage("ax")
+        S.stage("aty")
+        assert np.array_equal(S.get("ax", P.m), _spmv(P.csr_beg, P.csr_idx, P.csr_val, x, P.m))
+        assert np.array_equal(S.get("aty", P.n), _spmv(P.csc_beg, P.csc_idx, P.csc_val, y, P.n))
+        S.close()
+
+
+def test_spmv_long_and_empty_majors():
+    """Rows longer than one LDS chunk (2048 nnz) take the block-per-row path; empty rows/cols give 0."""
+    rng = np.random.default_rng(1)
+    n, m = 6000, 40
+    rows, cols, vals = [], [], []
+    for i in range(m):
+        k = {0: 5000, 1: 0, 2: 2049, 3: 1}.get(i, int(rng.integers(0, 30)))
+        c = np.sort(rng.choice(n, size=k, replace=False))
+        rows += [i] * k
+        cols += list(c)
+        vals += list(rng.standard_normal(k))
+    r_start = np.searchsorted(np.array(rows), np.arange(m + 1))
+    inf = float("inf")
+    lp = L.HighsLp.from_rowwise(n, m, r_start, cols, vals, col_cost=rng.standard_normal(n), col_lower=np.zeros(n),
+                                col_upper=np.ones(n), row_lower=np.full(m, -inf), row_upper=np.ones(m))
+    P = solver.Prepared(lp, pdlp_features_off=1)
+    S = solver.DeviceSolver(lp, pdlp_features_off=1)
+    x = rng.standard_normal(P.n)
+    y = rng.standard_normal(P.m)
+    S.set("x", x); S.set("y", y)
+    S.stage("ax"); S.stage("aty")
+    ax_o = _spmv(P.csr_beg, P.csr_idx, P.csr_val, x, P.m)
+    ax_g = S.get("ax", P.m)
+    lens = np.diff(P.csr_beg)
+    short = lens <= 2048
+    assert np.array_equal(ax_g[short], ax_o[short])
+    assert ax_g[lens == 0].tolist() == [0.0] * int((lens == 0).sum())
+    scale = _spmv(P.csr_beg, P.csr_idx, np.abs(P.csr_val), np.abs(x), P.m)
+    assert np.all(np.abs(ax_g - ax_o) <= 1e-14 * (scale + 1))  # tree-summed long rows
+    assert np.array_equal(S.get("aty", P.n), _spmv(P.csc_beg, P.csc_idx, P.csc_val, y, P.n))
+    S.close()
+
+
+@pytest.mark.parametrize("which", ["25fv47", "synthetic"])
+def test_trial_step_matches_oracle(which):
+    """One trial of cupdlp_step.c:241-257: x+, y+, A x+, A' y+ bit-identical; the three reductions
+    (tree order on the GPU, left-to-right in the oracle) to 1e-12 relative."""
+    for name, lp, sp_ in _problems():
+        if name != which:
+            continue
+        kw = dict(problem_struct=sp_.struct) if sp_ else dict(lp=lp)
+        S = solver.DeviceSolver(**kw)
+        if sp_:
+            lp = sp_.to_lp()
+        Fv = O.FormulatedView(lp)
+        n, m = Fv.n, Fv.m
+        rng = np.random.default_rng(5)
+        x = np.clip(rng.standard_normal(n), Fv.lower, Fv.upper)
+        y = rng.standard_normal(m)
+        y[Fv.n_eqs:] = np.maximum(y[Fv.n_eqs:], 0.0)
+        S.set("x", x); S.set("y", y)
+        S.stage("ax"); S.stage("aty")
+        ax, aty = S.get("ax", m), S.get("aty", n)
+        tau, sigma, beta = 0.37, 0.21, 0.21 / 0.37
+        S.set("steps", [tau, sigma, beta])
+        out = S.stage("trial")
+        accepted = out[3] == 1.0
+        pre = "" if accepted else "_next"  # accepted -> parity flipped, the new iterate is "current"
+        xg, yg = S.get("x" + pre if accepted else "x_next", n), S.get("y" + pre if accepted else "y_next", m)
+        axg, atyg = S.get("ax" if accepted else "ax_next", m), S.get("aty" if accepted else "aty_next", n)
+        # oracle
+        P = abi.ProblemHandle(lp)
+        F = O.Formulated()
+        prm = abi.default_params()
+        assert O.oracle().pdlp_oracle_formulate_scale(C.byref(P.struct), C.byref(prm), C.byref(F)) == 0
+        xo, yo, axo, atyo, o3 = np.zeros(n), np.zeros(m), np.zeros(m), np.zeros(n), np.zeros(3)
+        d = lambda a: a.ctypes.data_as(abi.c_f64p)
+        O.oracle().pdlp_oracle_trial_step(C.byref(F), tau, sigma, d(x), d(y), d(ax), d(aty), d(xo), d(yo), d(axo),
+                                          d(atyo), d(o3))
+        O.oracle().pdlp_oracle_free_formulated(C.byref(F))
+        assert np.array_equal(xg, xo) and np.array_equal(axg, axo)
+        assert np.array_equal(yg, yo) and np.array_equal(atyg, atyo)
+        assert np.allclose(out[:3], o3, rtol=1e-12, atol=0)
+        # the decision itself (cupdlp_step.c:266-285)
+        sb = np.sqrt(beta)
+        movement = o3[0] * 0.5 * sb + o3[1] / (2 * sb)
+        limit = movement / abs(o3[2])
+        eta = np.sqrt(tau * sigma)
+        assert accepted == (eta <= limit)
+        S.close()
+
+
+def test_residuals_match_numpy_restatement():
+    lp = _lp("e226")
+    S = solver.DeviceSolver(lp)
+    S.iterate(120)
+    Fv = O.FormulatedView(lp)
+    n, m = Fv.n, Fv.m
+    out = S.stage("residuals")
+    x, y, ax, aty = S.get("x", n), S.get("y", m), S.get("ax", m), S.get("aty", n)
+    r = ax - Fv.rhs
+    r[Fv.n_eqs:] = np.minimum(r[Fv.n_eqs:], 0)
+    pfeas = np.linalg.norm(r * Fv.row_scale)
+    pobj = float(x @ Fv.cost) * lp.sense + lp.offset
+    rc = Fv.cost - aty
+    hasL, hasU = np.isfinite(Fv.lower), np.isfinite(Fv.upper)
+    sp_, sn_ = np.maximum(rc, 0) * hasL, -np.minimum(rc, 0) * hasU
+    lF, uF = np.where(hasL, Fv.lower, 0.0), np.where(hasU, Fv.upper, 0.0)
+    dobj = (float(y @ Fv.rhs) + float(sp_ @ lF) - float(sn_ @ uF)) * lp.sense + lp.offset
+    dfeas = np.linalg.norm((rc - sp_ + sn_) * Fv.col_scale)
+    assert np.allclose(out[:4], [pobj, dobj, pfeas, dfeas], rtol=1e-11, atol=1e-13)
+    assert np.array_equal(S.get("slack_pos", n), sp_) and np.array_equal(S.get("slack_neg", n), sn_)
+    S.close()
+
+
+SPECIAL_EXPECT = {"distillation": 31.2, "3d": 7.0, "boxed_row": -16.0, "blending": -2850.0}
+
+
+@pytest.mark.parametrize("name", sorted(SPECIAL_EXPECT))
+def test_special_lps_reference_unit_tests(name):
+    """check/TestPdlp.cpp: objective within 1e-3 at kkt_tolerance 1e-4, status Optimal;
+    and to 1e-6 relative at the default tolerance."""
+    lp = L.special_lps()[name]
+    out = solver.solveLpCupdlp(lp, kkt_tolerance=1e-4)
+    assert out.status == solver.kOk and out.model_status == solver.kOptimal
+    assert abs(out.info["objective_function_value"] - SPECIAL_EXPECT[name]) < 1e-3
+    assert out.pdlp_iteration_count > 0
+    out = solver.solveLpCupdlp(lp)
+    assert out.model_status == solver.kOptimal
+    assert abs(out.info["objective_function_value"] - SPECIAL_EXPECT[name]) <= 1e-6 * abs(SPECIAL_EXPECT[name])
+
+
+def test_infeasible_and_unbounded_status():
+    # check/TestPdlp.cpp:186-239 (kUnbounded comes from HiGHS' KKT check upgrading the same PDLP status)
+    for name in ("infeasible", "unbounded"):
+        out = solver.solveLpCupdlp(L.special_lps()[name], kkt_tolerance=1e-4)
+        assert out.status == solver.kOk and out.model_status == solver.kUnboundedOrInfeasible
+
+
+def test_iteration_limit_semantics():
+    # check/TestPdlp.cpp:53-61: limit 80 -> 79 iterations, kIterationLimit, HighsStatus::kWarning
+    out = solver.solveLpCupdlp(L.special_lps()["distillation"], kkt_tolerance=1e-4, pdlp_iteration_limit=80)
+    assert out.model_status == solver.kIterationLimit and out.pdlp_iteration_count == 79
+    assert out.status == solver.kWarning
+
+
+def test_hot_start():
+    lp = L.special_lps()["restart_lp"]
+    a = solver.solveLpCupdlp(lp, kkt_tolerance=1e-4)
+    start = {"col_value": a.solution.col_value, "row_value": a.solution.row_value, "row_dual": a.solution.row_dual}
+    b = solver.solveLpCupdlp(lp, start=start, kkt_tolerance=1e-4)
+    assert b.model_status == solver.kOptimal and b.pdlp_iteration_count < a.pdlp_iteration_count
+    assert abs(b.info["objective_function_value"] - a.info["objective_function_value"]) < 1e-3
+
+
+@pytest.mark.parametrize("features_off", [1, 2, 4, 7])
+def test_feature_switches_converge_to_same_optimum(features_off):
+    lp = _lp("afiro")
+    out = solver.solveLpCupdlp(lp, kkt_tolerance=1e-6, pdlp_features_off=features_off, pdlp_iteration_limit=400000)
+    assert out.model_status == solver.kOptimal
+    assert abs(out.info["objective_function_value"] - (-464.7531428571)) <= 1e-4 * 464.75
+
+
+@pytest.mark.parametrize("name", sorted(REF))
+def test_instances_match_reference_cpu_pdlp(name):
+    """BASELINE config 1 and the 13 ctest instances: same .mps input, default tolerance (1e-7);
+    objective and KKT measures agree with the reference CPU pdlp to 1e-6 relative."""
+    lp = _lp(name)
+    g = REF[name]
+    out = solver.solveLpCupdlp(lp)
+    assert out.model_status == solver.kOptimal  # what PDLP itself reports (HiGHS may downgrade standata/standgub)
+    ref_obj = g["cupdlp"]["objective_function_value"]
+    obj = out.info["objective_function_value"]
+    assert abs(obj - ref_obj) <= 1e-6 * (1.0 + abs(ref_obj)), (obj, ref_obj)
+    R = out.result
+    assert abs(R.primal_obj - g["cupdlp"]["primal_obj"]) <= 1e-6 * (1 + abs(ref_obj))
+    assert abs(R.dual_obj - g["cupdlp"]["dual_obj"]) <= 1e-6 * (1 + abs(ref_obj))
+    # KKT residuals in the reference's own normalisation (termination test, cupdlp_solver.c:813-816)
+    assert R.primal_feas < 1e-7 * (1 + R.norm_rhs) and R.dual_feas < 1e-7 * (1 + R.norm_cost) and R.rel_gap < 1e-7
+    assert R.norm_rhs == g["cupdlp"]["norm_rhs"] and R.norm_cost == g["cupdlp"]["norm_cost"]
+    assert out.info["primal_dual_objective_error"] <= 2e-7
+    # same ballpark of work as the CPU trajectory (not required to be equal: TestPdlp.cpp:98-113)
+    assert 0.25 * g["cupdlp"]["num_iter"] <= out.pdlp_iteration_count <= 4 * g["cupdlp"]["num_iter"]
+
+
+def test_synthetic_100k_matches_oracle_objective():
+    """BASELINE config 2 (100k x 100k, 1M nnz) at kkt 1e-4: both sides converge to the same optimum
+    (the oracle value is the one measured for the reference in BASELINE.md: -1.3466652515e+04)."""
+    sp_ = solver.SyntheticProblem(100000, 100000, 1000000, 1)
+    S = solver.DeviceSolver(problem_struct=sp_.struct, kkt_tolerance=1e-4)
+    R = S.run(100000, 100000)
+    assert R.term_code == abi.TERM_OPTIMAL
+    lp = sp_.to_lp()
+    obj = lp.objective_value(R.col_value)
+    assert abs(obj - (-1.3466652515e+04)) <= 2e-4 * 1.3466652515e+04
+    assert 900 <= R.num_iter <= 3600  # CPU reference: 1800
+    k = L.kkt_measures(lp, R.col_value, R.col_dual, R.row_value, R.row_dual)
+    assert k["max_primal_residual_error"] < 1e-9
+    S.close()
+
+
+def test_full_size_properties_1m():
+    """BASELINE config 4 size (1M x 1M, 8M nnz), size-independent properties:
+    adjointness <A x, y> = <x, A' y>, linearity of both SpMVs, idempotent projection,
+    and the per-iteration invariants ax == A x, aty == A' y after real iterations."""
+    sp_ = solver.SyntheticProblem(1000000, 1000000, 8000000, 1)
+    S = solver.DeviceSolver(problem_struct=sp_.struct, kkt_tolerance=1e-4)
+    n, m = S.n, S.m
+    assert (n, m, S.nnz) == (1000000, 1000000, 7999977)
+    rng = np.random.default_rng(11)
+    x1, x2, y1 = rng.standard_normal(n), rng.standard_normal(n), rng.standard_normal(m)
+
+    def Ax(x):
+        S.set("x", x); S.stage("ax"); return S.get("ax", m)
+
+    def ATy(y):
+        S.set("y", y); S.stage("aty"); return S.get("aty", n)
+
+    a1, a2, a12 = Ax(x1), Ax(x2), Ax(x1 + x2)
+    assert np.allclose(a12, a1 + a2, rtol=0, atol=1e-12 * np.abs(a12).max())
+    t1 = ATy(y1)
+    lhs, rhs = float(a1 @ y1), float(x1 @ t1)
+    assert abs(lhs - rhs) <= 1e-11 * (np.linalg.norm(a1) * np.linalg.norm(y1))
+    S.reset()
+    st = S.iterate(60)
+    assert st.iters == 60 and st.trials >= 60
+    x, y = S.get("x", n), S.get("y", m)
+    ax, aty = S.get("ax", m), S.get("aty", n)
+    lo, up = S.get("lower", n), S.get("upper", n)
+    assert np.all(x >= lo) and np.all(x <= up) and np.all(y[S.n_eqs:] >= 0)
+    assert np.array_equal(Ax(x), ax) and np.array_equal(ATy(y), aty)
+    S.close()

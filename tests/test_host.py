@@ -1,0 +1,137 @@
+"""CPU tests of the PRODUCT's host logic: the C-ABI library loads, exports every
+declared symbol, and its formulate/scale/transpose agree bit for bit with the oracle."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oraclelib as O
+from highs_amd import abi, solver
+from highs_amd import lp as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+NAMES = ["25fv47", "adlittle", "afiro", "avgas", "blending", "chip", "e226", "scrs8", "sctest", "shell", "stair",
+         "standata", "standgub"]
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "pdlp_mi355x.h")).read()
+    declared = set(re.findall(r"\b(pdlp_mi355x_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations found"
+    lib = solver.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/pdlp_mi355x.h but not exported"
+    assert set(solver.EXPORTS) == declared
+    assert lib.pdlp_mi355x_abi_version() == 1
+
+
+def test_struct_sizes_match_ctypes_mirror():
+    lib = solver.lib()
+    for which, ty in enumerate([abi.PdlpProblem, abi.PdlpParams, abi.PdlpResult, abi.PdlpIterStats, abi.PdlpPrepared]):
+        assert lib.pdlp_mi355x_sizeof(which) == C.sizeof(ty), ty.__name__
+
+
+def test_default_params_match_highs_defaults():
+    p = abi.PdlpParams()
+    solver.lib().pdlp_mi355x_default_params(C.byref(p))
+    q = abi.default_params()
+    for k in ("primal_tol", "dual_tol", "gap_tol", "time_limit", "iter_limit", "features_off", "restart_method",
+              "log_level"):
+        assert getattr(p, k) == getattr(q, k), k
+
+
+def _same(P, F):
+    for k in ["csr_beg", "csr_idx", "csr_val", "cost", "rhs", "lower", "upper", "col_scale", "row_scale"]:
+        assert np.array_equal(getattr(P, k), getattr(F, k)), k
+    assert (P.n, P.m, P.n_eqs, P.nnz) == (F.n, F.m, F.n_eqs, F.nnz)
+    assert P.norm_cost == F.norm_cost and P.norm_rhs == F.norm_rhs and P.mat_norm_inf == F.mat_norm_inf
+    assert np.array_equal(P.row_new_idx, F.row_new_idx) and np.array_equal(P.row_kind, F.row_type)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_formulate_scale_bit_exact_vs_oracle(name):
+    lp = L.HighsLp.from_npz(os.path.join(GOLD, "instances", name + ".npz"))
+    _same(solver.Prepared(lp), O.FormulatedView(lp))
+
+
+@pytest.mark.parametrize("name", sorted(L.special_lps()))
+@pytest.mark.parametrize("features_off", [0, 1])
+def test_formulate_special_lps(name, features_off):
+    lp = L.special_lps()[name]
+    _same(solver.Prepared(lp, pdlp_features_off=features_off), O.FormulatedView(lp, pdlp_features_off=features_off))
+
+
+def test_boxed_and_free_rows_get_slack_columns():
+    # ranged AND free rows -> a'x - z = 0 (CupdlpWrapper.cpp:327-343)
+    inf = float("inf")
+    lp = L.HighsLp(2, 3, np.array([1.0, 1.0]), np.zeros(2), np.full(2, inf), np.array([-inf, 1.0, -2.0]),
+                   np.array([inf, 4.0, inf]), np.array([0, 3, 6], np.int32), np.array([0, 1, 2, 0, 1, 2], np.int32),
+                   np.array([1.0, 2.0, 3.0, 4.0, 5.0, 6.0])).normalise()
+    P = solver.Prepared(lp, pdlp_features_off=1)
+    assert (P.n, P.m, P.n_eqs, P.nnz) == (4, 3, 2, 8)
+    assert list(P.row_kind) == [3, 3, 2] and list(P.row_new_idx) == [0, 1, 2]
+    assert P.lower[2] == -inf and P.upper[2] == inf and P.lower[3] == 1.0 and P.upper[3] == 4.0
+    _same(P, O.FormulatedView(lp, pdlp_features_off=1))
+
+
+def test_csc_is_transpose_of_csr_with_sorted_rows():
+    lp = L.HighsLp.from_npz(os.path.join(GOLD, "instances", "e226.npz"))
+    P = solver.Prepared(lp)
+    import scipy.sparse as sp
+    A = sp.csr_matrix((P.csr_val, P.csr_idx, P.csr_beg), shape=(P.m, P.n))
+    At = sp.csr_matrix((P.csc_val, P.csc_idx, P.csc_beg), shape=(P.n, P.m))
+    assert (A.T != At).nnz == 0
+    for j in range(P.n):
+        seg = P.csc_idx[P.csc_beg[j]:P.csc_beg[j + 1]]
+        assert np.all(np.diff(seg) > 0)
+
+
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
+def test_row_partition_covers_and_balances(world):
+    sp_ = solver.SyntheticProblem(20000, 20000, 160000, 3)
+    P = solver.Prepared(problem_struct=sp_.struct)
+    off = P.row_partition(world)
+    assert off[0] == 0 and off[-1] == P.m and np.all(np.diff(off) >= 0)
+    nnz_per = np.diff(P.csr_beg[off])
+    assert nnz_per.max() <= 1.1 * P.nnz / world + 64
+
+
+def test_synthetic_generator_matches_survey_counts():
+    # 100k x 100k, 1M draws -> 999 945 nonzeros after merging duplicates (seed 1)
+    sp_ = solver.SyntheticProblem(100000, 100000, 1000000, 1)
+    assert sp_.struct.num_nz == 999945
+    lp = sp_.to_lp()
+    assert np.all(lp.col_lower == 0) and np.all(lp.col_upper == 1)
+    eq = lp.row_lower == lp.row_upper
+    assert eq[0::2].all() and not eq[1::2].any() and np.isneginf(lp.row_lower[1::2]).all()
+
+
+def test_bad_input_is_reported_not_fatal():
+    lp = L.special_lps()["distillation"]
+    h = abi.ProblemHandle(lp)
+    h.a_index[0] = 99  # row index out of range
+    F = abi.PdlpPrepared()
+    p = abi.default_params()
+    rc = solver.lib().pdlp_mi355x_host_prepare(C.byref(h.struct), C.byref(p), C.byref(F))
+    assert rc != 0 and b"out of range" in solver.lib().pdlp_mi355x_last_error()
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/check/instances"), reason="reference tree not present")
+def test_mps_reader_reproduces_golden_npz():
+    for name in ["afiro", "25fv47", "scrs8"]:
+        a = L.read_mps(f"/root/reference/check/instances/{name}.mps")
+        b = L.HighsLp.from_npz(os.path.join(GOLD, "instances", name + ".npz"))
+        for k in ["col_cost", "col_lower", "col_upper", "row_lower", "row_upper", "a_start", "a_index", "a_value"]:
+            assert np.array_equal(getattr(a, k), getattr(b, k)), (name, k)
+
+
+def test_solver_mirror_runs_against_oracle():
+    # same marshalling as the GPU path, executed against the oracle: exercises solveLpCupdlp's status map
+    lp = L.special_lps()["distillation"]
+    out = solver.solveLpCupdlp(lp, solve_fn=O.oracle().pdlp_oracle_solve, kkt_tolerance=1e-4, pdlp_iteration_limit=80)
+    assert out.model_status == solver.kIterationLimit and out.pdlp_iteration_count == 79 and out.status == solver.kWarning
+    out = solver.solveLpCupdlp(L.special_lps()["infeasible"], solve_fn=O.oracle().pdlp_oracle_solve, kkt_tolerance=1e-4)
+    assert out.model_status == solver.kUnboundedOrInfeasible and out.status == solver.kOk
