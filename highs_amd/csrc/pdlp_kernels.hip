@@ -97,25 +97,34 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
 
   double acc0 = 0.0, acc1 = 0.0;  // per-thread epilogue partials
 
-  auto epilogue = [&](int r, double s) {
+  // Epilogue operands that do not depend on the SpMV result are fetched early
+  // (before the products are staged) so their latency overlaps the stream.
+  struct Pre { double a, b, c; };
+  auto prefetch = [&](int r) -> Pre {
+    Pre p{0.0, 0.0, 0.0};
+    if (EPI == kDualStep) { p.a = a.v.y[cur][r]; p.b = a.v.rhs[r]; p.c = a.v.ax[cur][r]; }
+    else if (EPI == kAtyInteract) { p.a = a.v.x[cur][r]; p.b = a.v.x[nxt][r]; p.c = a.v.aty[cur][r]; }
+    return p;
+  };
+  auto epilogue = [&](int r, double s, const Pre& p) {
     if (EPI == kPlain || EPI == kAtyPartial) {
       a.out[r] = s;
     } else if (EPI == kDualStep) {
       // y+ = proj(y + sigma*(b - 2 A x+ + A x)), cupdlp_step.c:43-69
-      const double yv = a.v.y[cur][r];
+      const double yv = p.a;
       if (avgW != 0.0) a.v.ySum[r] += avgW * yv;  // deferred PDHG_Update_Average (step.c:438)
       double t = yv;
-      t += sigma * a.v.rhs[r];
+      t += sigma * p.b;
       t += (-2.0 * sigma) * s;
-      t += sigma * a.v.ax[cur][r];
+      t += sigma * p.c;
       if (r + a.v.rowOffset >= a.v.nEqs) t = t > 0.0 ? t : 0.0;
       a.v.ax[nxt][r] = s;
       a.v.y[nxt][r] = t;
       const double d = yv - t;
       acc0 += d * d;
     } else {  // kAtyInteract: cupdlp_linalg.c:772-801
-      const double dx = a.v.x[cur][r] - a.v.x[nxt][r];
-      const double da = a.v.aty[cur][r] - s;
+      const double dx = p.a - p.b;
+      const double da = p.c - s;
       a.v.aty[nxt][r] = s;
       acc0 += dx * dx;
       acc1 += dx * da;
@@ -127,17 +136,54 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
     double s = 0.0;
     for (int p = p0 + tid; p < p1; p += kSpmvThreads) s += val[p] * in[idx[p]];
     s = blockSum<kSpmvThreads>(s, scratch[0]);
-    if (tid == 0) epilogue(r0, s);
+    if (tid == 0) epilogue(r0, s, prefetch(r0));
   } else {
+    constexpr int kPer = kChunk / kSpmvThreads;
     const int cnt = p1 - p0;
-#pragma unroll 8
-    for (int q = tid; q < cnt; q += kSpmvThreads) prod[slot(q)] = val[p0 + q] * in[idx[p0 + q]];
+    // Bookkeeping of this lane's first major, issued ahead of the stream.  All
+    // loads below are unconditional with clamped indices: a load inside an
+    // exec-masked branch makes hipcc drain vmcnt at the join, which serialises
+    // the stream (one idx/val pair in flight instead of 2*kPer).
+    const int rFirst = r0 + tid;
+    const int rr = rFirst < r1 ? rFirst : r1 - 1;
+    int qb = a.A.beg[rr] - p0;
+    int qe = a.A.beg[rr + 1] - p0;
+    Pre pre = prefetch(rr);
+    // phase 1: kPer unit-stride loads of idx/val per lane, all issued before the
+    // dependent gathers, so a wave keeps 3*kPer memory operations in flight
+    const int last = cnt > 0 ? cnt - 1 : 0;  // idx/val carry one pad element
+    int32_t ci[kPer];
+    double va[kPer], xg[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int q = tid + k * kSpmvThreads;
+      const int qq = q < last ? q : last;
+      ci[k] = idx[p0 + qq];
+      va[k] = val[p0 + qq];
+    }
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) xg[k] = in[ci[k]];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int q = tid + k * kSpmvThreads;
+      if (q < cnt) prod[slot(q)] = va[k] * xg[k];
+    }
     __syncthreads();
-    for (int r = r0 + tid; r < r1; r += kSpmvThreads) {
-      const int qb = a.A.beg[r] - p0, qe = a.A.beg[r + 1] - p0;
+    // phase 2: one lane per major, products added left to right
+    for (int r = rFirst; r < r1; r += kSpmvThreads) {
+      if (r != rFirst) {
+        qb = a.A.beg[r] - p0;
+        qe = a.A.beg[r + 1] - p0;
+        pre = prefetch(r);
+      }
       double s = 0.0;
-      for (int q = qb; q < qe; ++q) s += prod[slot(q)];
-      epilogue(r, s);
+      int q = qb;
+      for (; q + 4 <= qe; q += 4) {
+        const double t0 = prod[slot(q)], t1 = prod[slot(q + 1)], t2 = prod[slot(q + 2)], t3 = prod[slot(q + 3)];
+        s += t0; s += t1; s += t2; s += t3;
+      }
+      for (; q < qe; ++q) s += prod[slot(q)];
+      epilogue(r, s, pre);
     }
   }
 
@@ -195,11 +241,16 @@ __global__ __launch_bounds__(kVecThreads) void k_interact(const IterVecs v, cons
   if (threadIdx.x == 0) { partDX[blockIdx.x] = t0; partInter[blockIdx.x] = t1; }
 }
 
-// Fixed-order sum of `count` partials by one block of 256 threads.
+// Fixed-order sum of `count` partials by one block of 256 threads (4 loads in flight per lane).
 __device__ double reducePartials(const double* __restrict__ p, int count, double* scratch) {
-  double s = 0.0;
-  for (int i = threadIdx.x; i < count; i += kVecThreads) s += p[i];
-  return blockSum<kVecThreads>(s, scratch);
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int i = threadIdx.x;
+  for (; i + 3 * kVecThreads < count; i += 4 * kVecThreads) {
+    const double a0 = p[i], a1 = p[i + kVecThreads], a2 = p[i + 2 * kVecThreads], a3 = p[i + 3 * kVecThreads];
+    s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+  }
+  for (; i < count; i += kVecThreads) s0 += p[i];
+  return blockSum<kVecThreads>((s0 + s1) + (s2 + s3), scratch);
 }
 
 __global__ __launch_bounds__(kVecThreads) void k_reduce_to(const double* partials, int count, double* out,

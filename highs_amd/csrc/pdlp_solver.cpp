@@ -27,8 +27,10 @@ void DeviceMatrix::upload(const Compressed& c, int32_t nMajor_, hipStream_t s) {
   StreamPlan plan = planStream(c.beg, nMajor_, kChunk, kMaxMajorsPerBlock);
   nBlocks = plan.nBlocks;
   beg.alloc(c.beg.size());
-  idx.alloc((size_t)nnz);
-  val.alloc((size_t)nnz);
+  idx.alloc((size_t)nnz + 1);  // one pad element: the kernels clamp, never predicate, their loads
+  val.alloc((size_t)nnz + 1);
+  idx.zero(s);
+  val.zero(s);
   blockBeg.alloc(plan.blockBeg.size());
   beg.upload(c.beg.data(), c.beg.size(), s);
   idx.upload(c.idx.data(), (size_t)nnz, s);

@@ -171,7 +171,9 @@ def test_special_lps_reference_unit_tests(name):
     lp = L.special_lps()[name]
     out = solver.solveLpCupdlp(lp, kkt_tolerance=1e-4)
     assert out.status == solver.kOk and out.model_status == solver.kOptimal
-    assert abs(out.info["objective_function_value"] - SPECIAL_EXPECT[name]) < 1e-3
+    # TestPdlp.cpp uses an absolute 1e-3 on objectives of magnitude <= 31.2; blending (|obj| = 2850,
+    # not in TestPdlp.cpp) gets the same bound relative to its magnitude
+    assert abs(out.info["objective_function_value"] - SPECIAL_EXPECT[name]) < 1e-3 * max(1.0, abs(SPECIAL_EXPECT[name]) / 31.2)
     assert out.pdlp_iteration_count > 0
     out = solver.solveLpCupdlp(lp)
     assert out.model_status == solver.kOptimal
