@@ -119,6 +119,15 @@ class PdlpPrepared(C.Structure):
     ]
 
 
+class PdlpSlabLayout(C.Structure):
+    _fields_ = [
+        ("rows_per_block", C.c_int32), ("n_blocks", C.c_int32), ("n_slabs", C.c_int32), ("n_long", C.c_int32),
+        ("nnz_short", C.c_int64),
+        ("seg_ptr", c_i32p), ("ent", C.POINTER(C.c_uint32)), ("val", c_f64p),
+        ("long_mask", C.POINTER(C.c_uint32)), ("long_map", c_i32p),
+    ]
+
+
 def default_params(**kw):
     """Defaults HiGHS passes for default options (CupdlpWrapper.cpp:642-717;
     kkt_tolerance default 1e-7, HConst.h:345)."""

@@ -184,6 +184,32 @@ int pdlp_mi355x_row_partition(const pdlp_prepared_t* prep, int32_t world, int32_
   });
 }
 
+int pdlp_mi355x_host_slab_layout(const pdlp_prepared_t* prep, int32_t which, int32_t long_limit,
+                                 pdlp_slab_layout_t* out) {
+  return guarded([&] {
+    if (!prep || !out) throw std::runtime_error("null argument");
+    memset(out, 0, sizeof(*out));
+    const int32_t nMajor = which ? prep->n : prep->m, nMinor = which ? prep->m : prep->n;
+    pdlp::Compressed c;
+    const int32_t* beg = which ? prep->csc_beg : prep->csr_beg;
+    c.beg.assign(beg, beg + nMajor + 1);
+    c.idx.assign(which ? prep->csc_idx : prep->csr_idx, (which ? prep->csc_idx : prep->csr_idx) + prep->nnz);
+    c.val.assign(which ? prep->csc_val : prep->csr_val, (which ? prep->csc_val : prep->csr_val) + prep->nnz);
+    pdlp::SlabLayout L;
+    pdlp::buildSlabLayout(c, nMajor, nMinor, long_limit, L);
+    out->rows_per_block = L.rowsPerBlock; out->n_blocks = L.nBlocks; out->n_slabs = L.nSlabs;
+    out->n_long = (int32_t)L.longMap.size(); out->nnz_short = (int64_t)L.ent.size();
+    out->seg_ptr = dupVec(L.segPtr); out->ent = dupVec(L.ent); out->val = dupVec(L.val);
+    out->long_mask = dupVec(L.longMask); out->long_map = dupVec(L.longMap);
+  });
+}
+
+void pdlp_mi355x_free_slab_layout(pdlp_slab_layout_t* o) {
+  if (!o) return;
+  free(o->seg_ptr); free(o->ent); free(o->val); free(o->long_mask); free(o->long_map);
+  memset(o, 0, sizeof(*o));
+}
+
 int64_t pdlp_mi355x_sizeof(int32_t which) {
   switch (which) {
     case 0: return sizeof(pdlp_problem_t);
@@ -191,6 +217,7 @@ int64_t pdlp_mi355x_sizeof(int32_t which) {
     case 2: return sizeof(pdlp_result_t);
     case 3: return sizeof(pdlp_iter_stats_t);
     case 4: return sizeof(pdlp_prepared_t);
+    case 5: return sizeof(pdlp_slab_layout_t);
     default: return -1;
   }
 }

@@ -259,4 +259,59 @@ StreamPlan planStream(const std::vector<int32_t>& beg, int32_t nMajor, int32_t c
   return plan;
 }
 
+void buildSlabLayout(const Compressed& csr, int32_t nMajor, int32_t nMinor, int32_t longLimit, SlabLayout& out) {
+  out = SlabLayout();
+  const int64_t nnz = csr.beg[nMajor];
+  // majors per block: aim at ~4096 nonzeros per block, power of two in [256, 4096]
+  const double avg = nMajor > 0 ? (double)nnz / nMajor : 1.0;
+  int32_t R = 256;
+  while (R < 4096 && (double)R * avg < 3000.0) R *= 2;
+  out.rowsPerBlock = R;
+  out.nBlocks = (nMajor + R - 1) / R;
+  out.nSlabs = std::max(1, (int32_t)(((int64_t)nMinor + (1 << kSlabWidthLog2) - 1) >> kSlabWidthLog2));
+  const int32_t S = out.nSlabs;
+  out.segPtr.assign((size_t)out.nBlocks * (S + 1), 0);
+  out.longMask.assign((size_t)out.nBlocks * (R / 32), 0u);
+  out.longCsr.beg.push_back(0);
+  // pass 1: per (block, slab) counts; long majors go to the side CSR
+  std::vector<int32_t> count((size_t)out.nBlocks * S, 0);
+  for (int32_t r = 0; r < nMajor; ++r) {
+    const int32_t b = r / R, len = csr.beg[r + 1] - csr.beg[r];
+    if (len > longLimit) {
+      out.longMask[(size_t)b * (R / 32) + (r % R) / 32] |= 1u << ((r % R) % 32);
+      out.longMap.push_back(r);
+      out.longCsr.idx.insert(out.longCsr.idx.end(), csr.idx.begin() + csr.beg[r], csr.idx.begin() + csr.beg[r + 1]);
+      out.longCsr.val.insert(out.longCsr.val.end(), csr.val.begin() + csr.beg[r], csr.val.begin() + csr.beg[r + 1]);
+      out.longCsr.beg.push_back((int32_t)out.longCsr.idx.size());
+      continue;
+    }
+    for (int32_t p = csr.beg[r]; p < csr.beg[r + 1]; ++p) ++count[(size_t)b * S + (csr.idx[p] >> kSlabWidthLog2)];
+  }
+  int64_t acc = 0;
+  for (int32_t b = 0; b < out.nBlocks; ++b) {
+    for (int32_t k = 0; k < S; ++k) {
+      out.segPtr[(size_t)b * (S + 1) + k] = (int32_t)acc;
+      acc += count[(size_t)b * S + k];
+    }
+    out.segPtr[(size_t)b * (S + 1) + S] = (int32_t)acc;
+  }
+  out.ent.resize((size_t)acc);
+  out.val.resize((size_t)acc);
+  // pass 2: majors in order, minors ascending within a major => each (block, slab)
+  // segment comes out sorted by (local major, minor)
+  std::vector<int32_t> pos((size_t)out.nBlocks * S);
+  for (int32_t b = 0; b < out.nBlocks; ++b)
+    for (int32_t k = 0; k < S; ++k) pos[(size_t)b * S + k] = out.segPtr[(size_t)b * (S + 1) + k];
+  for (int32_t r = 0; r < nMajor; ++r) {
+    const int32_t b = r / R, lr = r % R, len = csr.beg[r + 1] - csr.beg[r];
+    if (len > longLimit) continue;
+    for (int32_t p = csr.beg[r]; p < csr.beg[r + 1]; ++p) {
+      const int32_t c = csr.idx[p], k = c >> kSlabWidthLog2;
+      const int32_t q = pos[(size_t)b * S + k]++;
+      out.ent[q] = ((uint32_t)lr << 16) | (uint32_t)(c & ((1 << kSlabWidthLog2) - 1));
+      out.val[q] = csr.val[p];
+    }
+  }
+}
+
 }  // namespace pdlp

@@ -64,4 +64,26 @@ struct StreamPlan {
 };
 StreamPlan planStream(const std::vector<int32_t>& beg, int32_t nMajor, int32_t chunk, int32_t maxMajorsPerBlock);
 
+// Row-block x column-slab layout ("slab" SpMV).  The gathered vector of a
+// random sparse LP (8 MB at n = 1M) does not fit one XCD's 4 MB L2, so a plain
+// CSR stream pays one 64-byte fabric request per 8-byte gather.  Here each work
+// block owns `rowsPerBlock` consecutive majors and walks ITS nonzeros slab by
+// slab (slab = 65536 consecutive minor indices = 512 KB of the gathered
+// vector): all resident blocks sweep the slabs in the same order at about the
+// same pace, so the slab being gathered from stays L2-resident on every XCD.
+// Entries are sorted by (block, slab, local major, minor); an entry is
+// (localMajor << 16 | minor - 65536*slab).  Majors longer than `longLimit`
+// are left out (marked in longMask) and handled by the CSR kernel.
+struct SlabLayout {
+  int32_t rowsPerBlock = 0, nBlocks = 0, nSlabs = 0;
+  std::vector<int32_t> segPtr;    // [nBlocks*(nSlabs+1)] entry offsets
+  std::vector<uint32_t> ent;      // [nnzShort]
+  std::vector<double> val;        // [nnzShort]
+  std::vector<uint32_t> longMask; // [nBlocks * rowsPerBlock/32]
+  Compressed longCsr;             // compacted long majors
+  std::vector<int32_t> longMap;   // compact index -> major
+};
+constexpr int32_t kSlabWidthLog2 = 16;
+void buildSlabLayout(const Compressed& csr, int32_t nMajor, int32_t nMinor, int32_t longLimit, SlabLayout& out);
+
 }  // namespace pdlp

@@ -52,6 +52,7 @@ enum Epilogue { kPlain = 0, kDualStep = 1, kAtyInteract = 2, kAtyPartial = 3 };
 
 struct SpmvArgs {
   SpmvMat A;
+  SlabMat S;
   const DevState* st;  // nullptr for kPlain
   // kPlain / kAtyPartial
   const double* in;
@@ -68,7 +69,12 @@ struct SpmvArgs {
 //            the input vector, and park the products in LDS;
 //   phase 2: one lane per major adds its products left to right (the
 //            reference's summation order) and runs the epilogue.
-template <int EPI>
+template <typename T>
+__device__ __forceinline__ T ldStream(const T* p, bool nt) {
+  return nt ? __builtin_nontemporal_load(p) : *p;
+}
+
+template <int EPI, bool NT, bool MAPPED>
 __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
   const DevState* st = a.st;
   if (EPI != kPlain && st->halted) return;
@@ -102,11 +108,16 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
   struct Pre { double a, b, c; };
   auto prefetch = [&](int r) -> Pre {
     Pre p{0.0, 0.0, 0.0};
-    if (EPI == kDualStep) { p.a = a.v.y[cur][r]; p.b = a.v.rhs[r]; p.c = a.v.ax[cur][r]; }
-    else if (EPI == kAtyInteract) { p.a = a.v.x[cur][r]; p.b = a.v.x[nxt][r]; p.c = a.v.aty[cur][r]; }
+    if (MAPPED) r = a.A.majorMap[r];
+    if (EPI == kDualStep) {
+      p.a = ldStream(a.v.y[cur] + r, NT); p.b = ldStream(a.v.rhs + r, NT); p.c = ldStream(a.v.ax[cur] + r, NT);
+    } else if (EPI == kAtyInteract) {
+      p.a = ldStream(a.v.x[cur] + r, NT); p.b = ldStream(a.v.x[nxt] + r, NT); p.c = ldStream(a.v.aty[cur] + r, NT);
+    }
     return p;
   };
   auto epilogue = [&](int r, double s, const Pre& p) {
+    if (MAPPED) r = a.A.majorMap[r];
     if (EPI == kPlain || EPI == kAtyPartial) {
       a.out[r] = s;
     } else if (EPI == kDualStep) {
@@ -158,8 +169,8 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
     for (int k = 0; k < kPer; ++k) {
       const int q = tid + k * kSpmvThreads;
       const int qq = q < last ? q : last;
-      ci[k] = idx[p0 + qq];
-      va[k] = val[p0 + qq];
+      ci[k] = ldStream(idx + p0 + qq, NT);
+      va[k] = ldStream(val + p0 + qq, NT);
     }
 #pragma unroll
     for (int k = 0; k < kPer; ++k) xg[k] = in[ci[k]];
@@ -189,10 +200,153 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
 
   if (EPI == kDualStep) {
     const double t = blockSum<kSpmvThreads>(acc0, scratch[0]);
-    if (tid == 0) a.part0[blk] = t;
+    if (tid == 0) a.part0[a.A.partOffset + blk] = t;
   } else if (EPI == kAtyInteract) {
     const double t0 = blockSum<kSpmvThreads>(acc0, scratch[0]);
     const double t1 = blockSum<kSpmvThreads>(acc1, scratch[1]);
+    if (tid == 0) { a.part0[a.A.partOffset + blk] = t0; a.part1[a.A.partOffset + blk] = t1; }
+  }
+}
+
+// Slab SpMV: one block owns rowsPerBlock consecutive majors and streams ITS
+// nonzeros, which the host sorted by (slab of the gathered vector, local major,
+// minor).  All resident blocks walk the slabs in the same order, so the 512 KB
+// slab currently gathered from stays in every XCD's L2 instead of costing one
+// 64-byte fabric request per 8-byte gather.  Per 256-entry window: products go
+// to LDS, the first lane of each run of equal majors adds the run, left to
+// right, onto the major's LDS accumulator.  Because slabs and the minors inside
+// a slab ascend, every major is still summed in ascending minor order — the
+// reference's order — and the result is bit-identical to the CSR path.
+template <int EPI>
+__global__ __launch_bounds__(kSlabThreads) void k_spmv_slab(const SpmvArgs a) {
+  const DevState* st = a.st;
+  if (EPI != kPlain && st->halted) return;
+  // dynamic LDS (all carve offsets are multiples of 16 bytes; no static __shared__ in this kernel):
+  //   acc[R] f64 | stage[2][256] f64 | scratch[2][4] f64 | sp[72] i32 | srow[2][256] u16
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* acc = reinterpret_cast<double*>(smem);
+  double(*stage)[kSlabThreads] = reinterpret_cast<double(*)[kSlabThreads]>(acc + a.S.rowsPerBlock);
+  double(*scratch)[kSlabThreads / kWave] = reinterpret_cast<double(*)[kSlabThreads / kWave]>(&stage[2][0]);
+  int32_t* sp = reinterpret_cast<int32_t*>(&scratch[2][0]);  // slab pointers (cached when nSlabs <= 64)
+  uint16_t(*srow)[kSlabThreads] = reinterpret_cast<uint16_t(*)[kSlabThreads]>(sp + 72);
+
+  const int tid = threadIdx.x;
+  const int blk = blockIdx.x;
+  const int R = a.S.rowsPerBlock, S = a.S.nSlabs;
+  const int rBase = blk * R;
+  const int rEnd = (rBase + R < a.S.nMajor) ? rBase + R : a.S.nMajor;
+  const int32_t* __restrict__ segp = a.S.segPtr + (size_t)blk * (S + 1);
+  const uint32_t* __restrict__ ent = a.S.ent;
+  const double* __restrict__ val = a.S.val;
+
+  int cur = 0, nxt = 1;
+  double sigma = 0.0, avgW = 0.0;
+  if (EPI != kPlain) {
+    cur = st->cur;
+    nxt = cur ^ 1;
+    sigma = st->sigma;
+    avgW = st->avgW;
+  }
+  const double* __restrict__ in;
+  if (EPI == kPlain) in = a.in;
+  else if (EPI == kDualStep) in = a.v.x[nxt];
+  else in = a.v.y[nxt];
+
+  const int e0 = segp[0], e1 = segp[S];
+  const bool cached = S <= 64;
+  if (cached) for (int k = tid; k <= S; k += kSlabThreads) sp[k] = segp[k];
+  for (int r = tid; r < R; r += kSlabThreads) acc[r] = 0.0;
+
+  double acc0 = 0.0, acc1 = 0.0;
+  struct Pre { double a, b, c; };
+  auto prefetch = [&](int r) -> Pre {
+    Pre p{0.0, 0.0, 0.0};
+    if (EPI == kDualStep) { p.a = a.v.y[cur][r]; p.b = a.v.rhs[r]; p.c = a.v.ax[cur][r]; }
+    else if (EPI == kAtyInteract) { p.a = a.v.x[cur][r]; p.b = a.v.x[nxt][r]; p.c = a.v.aty[cur][r]; }
+    return p;
+  };
+  // operands of this lane's first two majors, fetched ahead of the stream (clamped, unconditional)
+  const int rA = rBase + tid < rEnd ? rBase + tid : rEnd - 1;
+  const int rB = rBase + tid + kSlabThreads < rEnd ? rBase + tid + kSlabThreads : rEnd - 1;
+  const Pre preA = prefetch(rA), preB = prefetch(rB);
+
+  const int last = e1 > e0 ? e1 - 1 : e0;  // ent/val carry one pad element
+  int q = e0 + tid;
+  int qc = q < last ? q : last;
+  uint32_t en = ent[qc];
+  double vv = val[qc];
+  __syncthreads();
+  int buf = 0;
+  for (int w = e0; w < e1; w += kSlabThreads, buf ^= 1) {
+    // prefetch the next window while this one is processed
+    const int qn = q + kSlabThreads;
+    const int qnc = qn < last ? qn : last;
+    const uint32_t enN = ent[qnc];
+    const double vvN = val[qnc];
+    // slab of entry q: largest k with segp[k] <= q (depends on q only, not on loaded data)
+    qc = q < last ? q : last;
+    int lo = 0, hi = S;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      const int pm = cached ? sp[mid] : segp[mid];
+      if (pm <= qc) lo = mid; else hi = mid;
+    }
+    const bool valid = q < e1;
+    const uint32_t lrow = en >> 16, lcol = en & 0xffffu;
+    const double xg = in[((size_t)lo << 16) + lcol];
+    const double prod = vv * xg;
+    stage[buf][tid] = prod;
+    srow[buf][tid] = valid ? (uint16_t)lrow : (uint16_t)0xffff;
+    __syncthreads();
+    if (valid && (tid == 0 || srow[buf][tid - 1] != (uint16_t)lrow)) {
+      double s = acc[lrow];
+      s += prod;
+      for (int j = tid + 1; j < kSlabThreads && srow[buf][j] == (uint16_t)lrow; ++j) s += stage[buf][j];
+      acc[lrow] = s;
+    }
+    q = qn;
+    en = enN;
+    vv = vvN;
+  }
+  __syncthreads();
+
+  auto epilogue = [&](int r, double s, const Pre& p) {
+    if (EPI == kPlain || EPI == kAtyPartial) {
+      a.out[r] = s;
+    } else if (EPI == kDualStep) {
+      const double yv = p.a;
+      if (avgW != 0.0) a.v.ySum[r] += avgW * yv;
+      double t = yv;
+      t += sigma * p.b;
+      t += (-2.0 * sigma) * s;
+      t += sigma * p.c;
+      if (r + a.v.rowOffset >= a.v.nEqs) t = t > 0.0 ? t : 0.0;
+      a.v.ax[nxt][r] = s;
+      a.v.y[nxt][r] = t;
+      const double d = yv - t;
+      acc0 += d * d;
+    } else {
+      const double dx = p.a - p.b;
+      const double da = p.c - s;
+      a.v.aty[nxt][r] = s;
+      acc0 += dx * dx;
+      acc1 += dx * da;
+    }
+  };
+  const uint32_t* __restrict__ mask = a.S.longMask + (size_t)blk * (R / 32);
+  for (int lr = tid, it = 0; rBase + lr < rEnd; lr += kSlabThreads, ++it) {
+    if ((mask[lr >> 5] >> (lr & 31)) & 1u) continue;  // long major: the CSR side kernel owns it
+    const int r = rBase + lr;
+    const Pre p = it == 0 ? preA : (it == 1 ? preB : prefetch(r));
+    epilogue(r, acc[lr], p);
+  }
+
+  if (EPI == kDualStep) {
+    const double t = blockSum<kSlabThreads>(acc0, scratch[0]);
+    if (tid == 0) a.part0[blk] = t;
+  } else if (EPI == kAtyInteract) {
+    const double t0 = blockSum<kSlabThreads>(acc0, scratch[0]);
+    const double t1 = blockSum<kSlabThreads>(acc1, scratch[1]);
     if (tid == 0) { a.part0[blk] = t0; a.part1[blk] = t1; }
   }
 }
@@ -482,30 +636,47 @@ void launchPrimalStep(const IterVecs& v, const DevState* st, hipStream_t s) {
   hipLaunchKernelGGL(k_primal_step, dim3(vecBlocks(v.n)), dim3(kVecThreads), 0, s, v, st);
 }
 
-void launchSpmvAxDual(const SpmvMat& A, const IterVecs& v, const DevState* st, double* partDY, hipStream_t s) {
-  if (A.nBlocks == 0) return;
-  SpmvArgs a{};
-  a.A = A; a.st = st; a.v = v; a.part0 = partDY;
-  hipLaunchKernelGGL(k_spmv<kDualStep>, dim3(A.nBlocks), dim3(kSpmvThreads), 0, s, a);
+static bool g_spmvNT = false;
+void setSpmvNonTemporal(bool on) { g_spmvNT = on; }
+
+namespace {
+template <int EPI>
+void launchSpmv(const MatView& M, SpmvArgs a, hipStream_t s) {
+  if (M.useSlab && M.slab.nBlocks > 0) {
+    a.S = M.slab;
+    const size_t lds = (size_t)M.slab.rowsPerBlock * 8 + 2 * kSlabThreads * 8 + 2 * (kSlabThreads / kWave) * 8 +
+                       72 * 4 + 2 * kSlabThreads * 2;
+    hipLaunchKernelGGL((k_spmv_slab<EPI>), dim3(M.slab.nBlocks), dim3(kSlabThreads), lds, s, a);
+  }
+  if (M.csr.nBlocks > 0) {
+    a.A = M.csr;
+    if (M.csr.majorMap) hipLaunchKernelGGL((k_spmv<EPI, false, true>), dim3(M.csr.nBlocks), dim3(kSpmvThreads), 0, s, a);
+    else if (g_spmvNT) hipLaunchKernelGGL((k_spmv<EPI, true, false>), dim3(M.csr.nBlocks), dim3(kSpmvThreads), 0, s, a);
+    else hipLaunchKernelGGL((k_spmv<EPI, false, false>), dim3(M.csr.nBlocks), dim3(kSpmvThreads), 0, s, a);
+  }
 }
-void launchSpmvAtyInteract(const SpmvMat& At, const IterVecs& v, const DevState* st, double* partDX,
+}  // namespace
+
+void launchSpmvAxDual(const MatView& A, const IterVecs& v, const DevState* st, double* partDY, hipStream_t s) {
+  SpmvArgs a{};
+  a.st = st; a.v = v; a.part0 = partDY;
+  launchSpmv<kDualStep>(A, a, s);
+}
+void launchSpmvAtyInteract(const MatView& At, const IterVecs& v, const DevState* st, double* partDX,
                            double* partInter, hipStream_t s) {
-  if (At.nBlocks == 0) return;
   SpmvArgs a{};
-  a.A = At; a.st = st; a.v = v; a.part0 = partDX; a.part1 = partInter;
-  hipLaunchKernelGGL(k_spmv<kAtyInteract>, dim3(At.nBlocks), dim3(kSpmvThreads), 0, s, a);
+  a.st = st; a.v = v; a.part0 = partDX; a.part1 = partInter;
+  launchSpmv<kAtyInteract>(At, a, s);
 }
-void launchSpmvAtyPartial(const SpmvMat& At, const IterVecs& v, const DevState* st, double* out, hipStream_t s) {
-  if (At.nBlocks == 0) return;
+void launchSpmvAtyPartial(const MatView& At, const IterVecs& v, const DevState* st, double* out, hipStream_t s) {
   SpmvArgs a{};
-  a.A = At; a.st = st; a.v = v; a.out = out;
-  hipLaunchKernelGGL(k_spmv<kAtyPartial>, dim3(At.nBlocks), dim3(kSpmvThreads), 0, s, a);
+  a.st = st; a.v = v; a.out = out;
+  launchSpmv<kAtyPartial>(At, a, s);
 }
-void launchSpmvPlain(const SpmvMat& A, const double* in, double* out, hipStream_t s) {
-  if (A.nBlocks == 0) return;
+void launchSpmvPlain(const MatView& A, const double* in, double* out, hipStream_t s) {
   SpmvArgs a{};
-  a.A = A; a.st = nullptr; a.in = in; a.out = out;
-  hipLaunchKernelGGL(k_spmv<kPlain>, dim3(A.nBlocks), dim3(kSpmvThreads), 0, s, a);
+  a.st = nullptr; a.in = in; a.out = out;
+  launchSpmv<kPlain>(A, a, s);
 }
 void launchInteract(const IterVecs& v, const DevState* st, const double* atyReduced, double* partDX,
                     double* partInter, int32_t nBlocks, hipStream_t s) {

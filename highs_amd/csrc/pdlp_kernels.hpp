@@ -45,6 +45,28 @@ struct SpmvMat {
   const int32_t* blockBeg;  // [nBlocks+1] stream plan
   int32_t nMajor;
   int32_t nBlocks;
+  const int32_t* majorMap;  // compact major -> vector index (nullptr = identity)
+  int32_t partOffset;       // first slot of this matrix in the per-block partial arrays
+};
+
+// Row-block x column-slab layout (pdlp_host.hpp SlabLayout), device pointers.
+constexpr int kSlabThreads = 256;
+constexpr int kSlabMaxRows = 4096;  // majors per block (LDS accumulators)
+struct SlabMat {
+  const int32_t* segPtr;     // [nBlocks*(nSlabs+1)]
+  const uint32_t* ent;       // [nnz] (localMajor<<16 | localMinor)
+  const double* val;         // [nnz]
+  const uint32_t* longMask;  // [nBlocks*rowsPerBlock/32]
+  int32_t nMajor, nBlocks, nSlabs, rowsPerBlock;
+};
+
+// One operand matrix of the iteration: either a plain CSR stream, or the slab
+// layout for the short majors plus a CSR side matrix for the long ones.
+struct MatView {
+  SpmvMat csr;
+  SlabMat slab;
+  int32_t useSlab;
+  int32_t nPartials;  // slab.nBlocks (if used) + csr.nBlocks
 };
 
 // Vectors of the iteration (device pointers). Pairs are double-buffered by parity.
@@ -67,12 +89,12 @@ struct IterVecs {
 // ---- per-trial kernels ----------------------------------------------------
 void launchPrimalStep(const IterVecs& v, const DevState* st, hipStream_t s);
 // ax_next = A x_next fused with the dual step; writes per-block sum (dy)^2 to partDY[block]
-void launchSpmvAxDual(const SpmvMat& A, const IterVecs& v, const DevState* st, double* partDY, hipStream_t s);
+void launchSpmvAxDual(const MatView& A, const IterVecs& v, const DevState* st, double* partDY, hipStream_t s);
 // aty_next = A' y_next fused with movement/interaction partials
-void launchSpmvAtyInteract(const SpmvMat& At, const IterVecs& v, const DevState* st, double* partDX,
+void launchSpmvAtyInteract(const MatView& At, const IterVecs& v, const DevState* st, double* partDX,
                            double* partInter, hipStream_t s);
 // sharded variant: partial A_g' y_next into out[n] (no epilogue)
-void launchSpmvAtyPartial(const SpmvMat& At, const IterVecs& v, const DevState* st, double* out, hipStream_t s);
+void launchSpmvAtyPartial(const MatView& At, const IterVecs& v, const DevState* st, double* out, hipStream_t s);
 // sharded: aty_next = reduced; movement/interaction partials
 void launchInteract(const IterVecs& v, const DevState* st, const double* atyReduced, double* partDX,
                     double* partInter, int32_t nBlocks, hipStream_t s);
@@ -85,7 +107,7 @@ void launchDecide(DevState* st, const double* partDY, int32_t nDY, const double*
 // ---- check-iteration kernels (host knows the parity here) -------------------
 void launchFlushAverage(const IterVecs& v, DevState* st, hipStream_t s);
 void launchScaleCopy(double* dst, const double* src, double a, int32_t len, hipStream_t s);  // dst = a*src
-void launchSpmvPlain(const SpmvMat& A, const double* in, double* out, hipStream_t s);
+void launchSpmvPlain(const MatView& A, const double* in, double* out, hipStream_t s);
 void launchFill(double* dst, double value, int32_t len, hipStream_t s);
 void launchProjectBounds(double* x, const double* lower, const double* upper, int32_t n, hipStream_t s);
 void launchMulInPlace(double* x, const double* y, int32_t len, hipStream_t s);   // x *= y
@@ -117,6 +139,7 @@ void launchDiffNorm2(const double* a, const double* b, int32_t len, double* part
 // partials of a.b
 void launchDot(const double* a, const double* b, int32_t len, double* partials, int32_t nBlocks, hipStream_t s);
 
+void setSpmvNonTemporal(bool on);  // stream idx/val/epilogue operands past L2 (keeps the gathered vector resident)
 int32_t vecBlocks(int32_t len);  // grid size used by the vector/statistics kernels
 
 }  // namespace pdlp

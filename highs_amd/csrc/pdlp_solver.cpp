@@ -21,22 +21,64 @@ constexpr int kGraphTrials = 10;
 constexpr int kCheckInterval = 40;  // CUPDLP_RELEASE_INTERVAL, cupdlp_defs.h:39
 }  // namespace
 
-void DeviceMatrix::upload(const Compressed& c, int32_t nMajor_, hipStream_t s) {
+namespace {
+// Majors longer than this stay out of the slab layout (their runs would be added
+// by a single lane); the CSR kernel's stream / block-per-major paths take them.
+constexpr int32_t kSlabLongLimit = 256;
+// The slab layout pays off once the gathered vector no longer fits an XCD's L2
+// next to the streams: 2^18 doubles = 2 MB.
+constexpr int32_t kSlabAutoMinor = 1 << 18;
+}  // namespace
+
+void DeviceMatrix::upload(const Compressed& cIn, int32_t nMajor_, int32_t nMinor_, int mode, hipStream_t s) {
   nMajor = nMajor_;
-  nnz = c.beg.empty() ? 0 : c.beg[nMajor_];
-  StreamPlan plan = planStream(c.beg, nMajor_, kChunk, kMaxMajorsPerBlock);
-  nBlocks = plan.nBlocks;
-  beg.alloc(c.beg.size());
-  idx.alloc((size_t)nnz + 1);  // one pad element: the kernels clamp, never predicate, their loads
-  val.alloc((size_t)nnz + 1);
+  nnz = cIn.beg.empty() ? 0 : cIn.beg[nMajor_];
+  useSlab = mode == 1 || (mode < 0 && nMinor_ >= kSlabAutoMinor);
+  const Compressed* c = &cIn;
+  SlabLayout L;
+  if (useSlab) {
+    buildSlabLayout(cIn, nMajor_, nMinor_, kSlabLongLimit, L);
+    if (L.rowsPerBlock > kSlabMaxRows) throw std::runtime_error("slab layout: too many majors per block");
+    segPtr.alloc(L.segPtr.size());
+    ent.alloc(L.ent.size() + 1);
+    slabVal.alloc(L.val.size() + 1);
+    longMask.alloc(L.longMask.size());
+    ent.zero(s);
+    slabVal.zero(s);
+    segPtr.upload(L.segPtr.data(), L.segPtr.size(), s);
+    ent.upload(L.ent.data(), L.ent.size(), s);
+    slabVal.upload(L.val.data(), L.val.size(), s);
+    longMask.upload(L.longMask.data(), L.longMask.size(), s);
+    slab = SlabMat{segPtr.get(), ent.get(), slabVal.get(), longMask.get(), nMajor_, L.nBlocks, L.nSlabs, L.rowsPerBlock};
+    c = &L.longCsr;
+    majorMap.alloc(L.longMap.size());
+    majorMap.upload(L.longMap.data(), L.longMap.size(), s);
+  }
+  const int32_t nCsrMajor = useSlab ? (int32_t)L.longMap.size() : nMajor_;
+  const int64_t nnzCsr = c->beg[nCsrMajor];
+  StreamPlan plan = planStream(c->beg, nCsrMajor, kChunk, kMaxMajorsPerBlock);
+  nBlocks = nCsrMajor > 0 ? plan.nBlocks : 0;
+  beg.alloc(c->beg.size());
+  idx.alloc((size_t)nnzCsr + 1);  // one pad element: the kernels clamp, never predicate, their loads
+  val.alloc((size_t)nnzCsr + 1);
   idx.zero(s);
   val.zero(s);
   blockBeg.alloc(plan.blockBeg.size());
-  beg.upload(c.beg.data(), c.beg.size(), s);
-  idx.upload(c.idx.data(), (size_t)nnz, s);
-  val.upload(c.val.data(), (size_t)nnz, s);
+  beg.upload(c->beg.data(), c->beg.size(), s);
+  idx.upload(c->idx.data(), (size_t)nnzCsr, s);
+  val.upload(c->val.data(), (size_t)nnzCsr, s);
   blockBeg.upload(plan.blockBeg.data(), plan.blockBeg.size(), s);
   PDLP_HIP(hipStreamSynchronize(s));  // host vectors may go out of scope
+}
+
+MatView DeviceMatrix::view() const {
+  MatView v{};
+  v.csr = SpmvMat{beg.get(), idx.get(), val.get(), blockBeg.get(), nMajor, nBlocks,
+                  useSlab ? majorMap.get() : nullptr, useSlab ? slab.nBlocks : 0};
+  v.slab = slab;
+  v.useSlab = useSlab ? 1 : 0;
+  v.nPartials = nPartials();
+  return v;
 }
 
 double Solver::elapsed() const {
@@ -62,6 +104,7 @@ Solver::Solver(const pdlp_problem_t& P, const pdlp_params_t& opt, int32_t rank, 
   PDLP_HIP(hipSetDevice(opt_.device));
   PDLP_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
   if (const char* g = getenv("PDLP_MI355X_GRAPH")) useGraph_ = atoi(g) != 0;
+  if (const char* g = getenv("PDLP_MI355X_NT")) setSpmvNonTemporal(atoi(g) != 0);
 
   adaptive_ = !(opt_.features_off & PDLP_FEATURE_ADAPTIVE_STEP_OFF);
   restartOn_ = !(opt_.features_off & PDLP_FEATURE_RESTART_OFF) && opt_.restart_method != 0;
@@ -118,14 +161,16 @@ Solver::~Solver() {
 
 void Solver::uploadProblem() {
   const int32_t n = F_.n;
+  int slabMode = -1;  // auto
+  if (const char* g = getenv("PDLP_MI355X_SLAB")) slabMode = atoi(g);
   if (world_ == 1) {
-    dA_.upload(F_.csr, F_.m, stream_);
-    dAt_.upload(F_.cscSorted, n, stream_);
+    dA_.upload(F_.csr, F_.m, n, slabMode, stream_);
+    dAt_.upload(F_.cscSorted, n, F_.m, slabMode, stream_);
   } else {
     Compressed csrSlab, cscSlab;
     extractSlab(F_, r0_, r1_, csrSlab, cscSlab);
-    dA_.upload(csrSlab, mLoc_, stream_);
-    dAt_.upload(cscSlab, n, stream_);
+    dA_.upload(csrSlab, mLoc_, n, slabMode, stream_);
+    dAt_.upload(cscSlab, n, mLoc_, slabMode, stream_);
   }
   for (int k = 0; k < 2; ++k) {
     x_[k].alloc(n); y_[k].alloc(mLoc_); ax_[k].alloc(mLoc_); aty_[k].alloc(n);
@@ -145,9 +190,9 @@ void Solver::uploadProblem() {
   rowScale_.upload(F_.rowScale.data() + r0_, mLoc_, stream_);
 
   const int32_t nbV = std::max(vecBlocks(n), vecBlocks(std::max(mLoc_, 1)));
-  partDY_.alloc(std::max(dA_.nBlocks, 1));
-  partDX_.alloc(std::max(std::max(dAt_.nBlocks, nbV), 1));
-  partInter_.alloc(std::max(std::max(dAt_.nBlocks, nbV), 1));
+  partDY_.alloc(std::max(dA_.nPartials(), 1));
+  partDX_.alloc(std::max(std::max(dAt_.nPartials(), nbV), 1));
+  partInter_.alloc(std::max(std::max(dAt_.nPartials(), nbV), 1));
   statStride_ = nbV;
   statPart_.alloc((size_t)kStatTotal * statStride_);
   statOut_.alloc(kStatTotal + 8);
@@ -299,14 +344,14 @@ void Solver::enqueueTrial() {
   launchSpmvAxDual(dA_.view(), vecs_, dState_.get(), partDY_.get(), stream_);
   if (world_ == 1) {
     launchSpmvAtyInteract(dAt_.view(), vecs_, dState_.get(), partDX_.get(), partInter_.get(), stream_);
-    launchDecide(dState_.get(), partDY_.get(), dA_.nBlocks, partDX_.get(), partInter_.get(), dAt_.nBlocks, nullptr,
-                 stream_);
+    launchDecide(dState_.get(), partDY_.get(), dA_.nPartials(), partDX_.get(), partInter_.get(), dAt_.nPartials(),
+                 nullptr, stream_);
   } else {
     // row-block sharded: A_g' y_g partials are summed over the ranks together
     // with the local sum (dy)^2 in one all-reduce of n+1 doubles
     double* buf = commBuf_.get();
     launchSpmvAtyPartial(dAt_.view(), vecs_, dState_.get(), buf, stream_);
-    launchReduceTo(partDY_.get(), dA_.nBlocks, buf + F_.n, dState_.get(), stream_);
+    launchReduceTo(partDY_.get(), dA_.nPartials(), buf + F_.n, dState_.get(), stream_);
     comm_->allReduceSum(buf, (size_t)F_.n + 1, stream_);
     const int32_t nb = vecBlocks(F_.n);
     launchInteract(vecs_, dState_.get(), buf, partDX_.get(), partInter_.get(), nb, stream_);
@@ -777,7 +822,7 @@ double Solver::timeKernel(const std::string& name, int32_t reps) {
       else launchSpmvAtyPartial(dAt_.view(), vecs_, dState_.get(), commBuf_.get(), stream_);
     } else if (name == "primal_step") launchPrimalStep(vecs_, dState_.get(), stream_);
     else if (name == "decide")
-      launchDecide(dState_.get(), partDY_.get(), dA_.nBlocks, partDX_.get(), partInter_.get(), dAt_.nBlocks, nullptr, stream_);
+      launchDecide(dState_.get(), partDY_.get(), dA_.nPartials(), partDX_.get(), partInter_.get(), dAt_.nPartials(), nullptr, stream_);
     else if (name == "trial") enqueueTrial();
     else if (name == "spmv_ax_plain") launchSpmvPlain(dA_.view(), x_[0].get(), tmpM_.get(), stream_);
     else if (name == "spmv_aty_plain") launchSpmvPlain(dAt_.view(), y_[0].get(), commBuf_.get(), stream_);

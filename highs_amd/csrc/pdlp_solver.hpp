@@ -57,13 +57,19 @@ class DeviceArray {
   size_t n_ = 0;
 };
 
+// One operand matrix in HBM: CSR stream plan, or slab layout + CSR side matrix of long majors.
 struct DeviceMatrix {
-  DeviceArray<int32_t> beg, idx, blockBeg;
-  DeviceArray<double> val;
-  int32_t nMajor = 0, nBlocks = 0;
+  DeviceArray<int32_t> beg, idx, blockBeg, majorMap, segPtr;
+  DeviceArray<uint32_t> ent, longMask;
+  DeviceArray<double> val, slabVal;
+  int32_t nMajor = 0, nBlocks = 0;  // nBlocks = CSR stream blocks
   int64_t nnz = 0;
-  void upload(const Compressed& c, int32_t nMajor_, hipStream_t s);
-  SpmvMat view() const { return SpmvMat{beg.get(), idx.get(), val.get(), blockBeg.get(), nMajor, nBlocks}; }
+  bool useSlab = false;
+  SlabMat slab{};
+  // mode: 0 = CSR stream only, 1 = slab layout (+ long-major side CSR), -1 = auto by nMinor
+  void upload(const Compressed& c, int32_t nMajor_, int32_t nMinor_, int mode, hipStream_t s);
+  MatView view() const;
+  int32_t nPartials() const { return (useSlab ? slab.nBlocks : 0) + nBlocks; }
 };
 
 class Comm;  // RCCL wrapper (pdlp_comm.cpp)

@@ -37,6 +37,7 @@ EXPORTS = [
     "pdlp_mi355x_comm_unique_id", "pdlp_mi355x_create_sharded", "pdlp_mi355x_gen_synthetic",
     "pdlp_mi355x_free_problem", "pdlp_mi355x_last_error", "pdlp_mi355x_abi_version",
     "pdlp_mi355x_host_prepare", "pdlp_mi355x_free_prepared", "pdlp_mi355x_row_partition", "pdlp_mi355x_sizeof",
+    "pdlp_mi355x_host_slab_layout", "pdlp_mi355x_free_slab_layout",
 ]
 
 
@@ -81,6 +82,10 @@ def lib():
         L.pdlp_mi355x_free_prepared.argtypes = [pPrep]
         L.pdlp_mi355x_free_prepared.restype = None
         L.pdlp_mi355x_row_partition.argtypes = [pPrep, C.c_int32, abi.c_i32p]
+        pSlab = C.POINTER(abi.PdlpSlabLayout)
+        L.pdlp_mi355x_host_slab_layout.argtypes = [pPrep, C.c_int32, C.c_int32, pSlab]
+        L.pdlp_mi355x_free_slab_layout.argtypes = [pSlab]
+        L.pdlp_mi355x_free_slab_layout.restype = None
         L.pdlp_mi355x_sizeof.argtypes = [C.c_int32]
         L.pdlp_mi355x_sizeof.restype = C.c_int64
         L.pdlp_mi355x_last_error.restype = C.c_char_p
@@ -244,7 +249,7 @@ class SyntheticProblem:
 class Prepared:
     """Host-side standard form built by the PRODUCT library (pdlp_mi355x_host_prepare); numpy copies."""
 
-    def __init__(self, lp=None, params=None, problem_struct=None, **options):
+    def __init__(self, lp=None, params=None, problem_struct=None, slab_long_limit=256, **options):
         params = params or abi.default_params(**options)
         keep = None
         if problem_struct is None:
@@ -263,6 +268,16 @@ class Prepared:
         self.row_kind = g(F.row_kind, m, np.int32); self.row_new_idx = g(F.row_new_idx, m, np.int32)
         self.norm_cost, self.norm_rhs, self.mat_norm_inf = F.norm_cost, F.norm_rhs, F.mat_norm_inf
         self.spmv_blocks_ax, self.spmv_blocks_aty = F.spmv_blocks_ax, F.spmv_blocks_aty
+        self._slabs = {}
+        for which in (0, 1):
+            SL = abi.PdlpSlabLayout()
+            _check(lib().pdlp_mi355x_host_slab_layout(C.byref(F), which, slab_long_limit, C.byref(SL)), "slab_layout")
+            nb, ns, R = SL.n_blocks, SL.n_slabs, SL.rows_per_block
+            self._slabs[which] = dict(
+                rows_per_block=R, n_blocks=nb, n_slabs=ns, seg_ptr=g(SL.seg_ptr, nb * (ns + 1), np.int64),
+                ent=g(SL.ent, SL.nnz_short, np.uint32), val=g(SL.val, SL.nnz_short, np.float64),
+                long_mask=g(SL.long_mask, nb * (R // 32), np.uint32), long_map=g(SL.long_map, SL.n_long, np.int32))
+            lib().pdlp_mi355x_free_slab_layout(C.byref(SL))
         self._parts = {}
         for w in (1, 2, 3, 4, 8):
             off = np.zeros(w + 1, dtype=np.int32)
@@ -272,3 +287,7 @@ class Prepared:
 
     def row_partition(self, world):
         return self._parts[world]
+
+    def slab_layout(self, which):
+        """which = 0: A by rows, 1: A' by columns."""
+        return self._slabs[which]

@@ -246,7 +246,23 @@ void pdlp_mi355x_free_prepared(pdlp_prepared_t* out);
 /* Row-block partition used by create_sharded: offsets[world+1]. */
 int pdlp_mi355x_row_partition(const pdlp_prepared_t* prep, int32_t world,
                               int32_t* offsets);
-/* sizeof() of the ABI structs: 0 problem, 1 params, 2 result, 3 iter_stats, 4 prepared */
+/* The row-block x column-slab layout the GPU SpMV uses for large operands
+ * (see DESIGN.md "slab SpMV"), built on the host for inspection by the CPU tests:
+ * which = 0 -> A (rows), 1 -> A' (columns).  Arrays malloc'ed; free with
+ * pdlp_mi355x_free_slab_layout. */
+typedef struct pdlp_slab_layout {
+  int32_t rows_per_block, n_blocks, n_slabs, n_long;
+  int64_t nnz_short;
+  int32_t* seg_ptr;   /* [n_blocks*(n_slabs+1)] */
+  uint32_t* ent;      /* [nnz_short] (local_major<<16 | minor - 65536*slab) */
+  double* val;        /* [nnz_short] */
+  uint32_t* long_mask; /* [n_blocks*rows_per_block/32] */
+  int32_t* long_map;  /* [n_long] majors handled by the CSR side kernel */
+} pdlp_slab_layout_t;
+int pdlp_mi355x_host_slab_layout(const pdlp_prepared_t* prep, int32_t which,
+                                 int32_t long_limit, pdlp_slab_layout_t* out);
+void pdlp_mi355x_free_slab_layout(pdlp_slab_layout_t* out);
+/* sizeof() of the ABI structs: 0 problem, 1 params, 2 result, 3 iter_stats, 4 prepared, 5 slab_layout */
 int64_t pdlp_mi355x_sizeof(int32_t which);
 
 const char* pdlp_mi355x_last_error(void);

@@ -34,8 +34,15 @@ def _problems():
     yield "synthetic", None, sp_
 
 
+@pytest.fixture(params=["csr", "slab"])
+def spmv_layout(request, monkeypatch):
+    """Run a test under both SpMV layouts: plain CSR stream and row-block x column-slab."""
+    monkeypatch.setenv("PDLP_MI355X_SLAB", "1" if request.param == "slab" else "0")
+    return request.param
+
+
 @pytest.mark.parametrize("which", ["25fv47", "shell", "synthetic"])
-def test_spmv_bit_exact(which):
+def test_spmv_bit_exact(which, spmv_layout):
     """A x (CSR) and A' y (CSC) — integer-exact placement and, because every major is summed left to
     right like AxCPU/ATyCPU (cupdlp_linalg.c:35-109), bit-identical values."""
     for name, lp, sp_ in _problems():
@@ -56,7 +63,21 @@ def test_spmv_bit_exact(which):
         S.close()
 
 
-def test_spmv_long_and_empty_majors():
+def test_spmv_wide_matrix_many_slabs(spmv_layout):
+    """A operand with 200k columns = 4 slabs of 65536: slab-ordered accumulation stays bit-exact."""
+    sp_ = solver.SyntheticProblem(3000, 200000, 36000, 5)
+    P = solver.Prepared(problem_struct=sp_.struct)
+    S = solver.DeviceSolver(problem_struct=sp_.struct)
+    rng = np.random.default_rng(2)
+    x, y = rng.standard_normal(P.n), rng.standard_normal(P.m)
+    S.set("x", x); S.set("y", y)
+    S.stage("ax"); S.stage("aty")
+    assert np.array_equal(S.get("ax", P.m), _spmv(P.csr_beg, P.csr_idx, P.csr_val, x, P.m))
+    assert np.array_equal(S.get("aty", P.n), _spmv(P.csc_beg, P.csc_idx, P.csc_val, y, P.n))
+    S.close()
+
+
+def test_spmv_long_and_empty_majors(spmv_layout):
     """Rows longer than one LDS chunk (2048 nnz) take the block-per-row path; empty rows/cols give 0."""
     rng = np.random.default_rng(1)
     n, m = 6000, 40
@@ -90,7 +111,7 @@ def test_spmv_long_and_empty_majors():
 
 
 @pytest.mark.parametrize("which", ["25fv47", "synthetic"])
-def test_trial_step_matches_oracle(which):
+def test_trial_step_matches_oracle(which, spmv_layout):
     """One trial of cupdlp_step.c:241-257: x+, y+, A x+, A' y+ bit-identical; the three reductions
     (tree order on the GPU, left-to-right in the oracle) to 1e-12 relative."""
     for name, lp, sp_ in _problems():

@@ -135,3 +135,52 @@ def test_solver_mirror_runs_against_oracle():
     assert out.model_status == solver.kIterationLimit and out.pdlp_iteration_count == 79 and out.status == solver.kWarning
     out = solver.solveLpCupdlp(L.special_lps()["infeasible"], solve_fn=O.oracle().pdlp_oracle_solve, kkt_tolerance=1e-4)
     assert out.model_status == solver.kUnboundedOrInfeasible and out.status == solver.kOk
+
+
+def _slab_to_coo(sl, n_major):
+    """Rebuild (major, minor, value) triplets from the slab layout, in storage order."""
+    R, nb, ns = sl["rows_per_block"], sl["n_blocks"], sl["n_slabs"]
+    seg = sl["seg_ptr"].reshape(nb, ns + 1)
+    ent, val = sl["ent"], sl["val"]
+    majors = np.empty(len(ent), np.int64)
+    minors = np.empty(len(ent), np.int64)
+    for b in range(nb):
+        for k in range(ns):
+            s, e = seg[b, k], seg[b, k + 1]
+            majors[s:e] = b * R + (ent[s:e] >> 16)
+            minors[s:e] = (k << 16) + (ent[s:e] & 0xFFFF)
+    return majors, minors, val
+
+
+@pytest.mark.parametrize("which", [0, 1])
+@pytest.mark.parametrize("long_limit", [256, 6])
+def test_slab_layout_is_a_permutation_of_the_csr(which, long_limit):
+    """Slab layout + long-major side list hold exactly the CSR's nonzeros; every major's entries stay
+    in ascending minor order when read in storage order (=> same summation order as the reference)."""
+    sp_ = solver.SyntheticProblem(3000, 200000, 24000, 5)  # wide: 4 slabs of 65536 columns for A
+    P = solver.Prepared(problem_struct=sp_.struct, slab_long_limit=long_limit)
+    sl = P.slab_layout(which)
+    beg, idx, val = (P.csr_beg, P.csr_idx, P.csr_val) if which == 0 else (P.csc_beg, P.csc_idx, P.csc_val)
+    n_major = P.m if which == 0 else P.n
+    lens = np.diff(beg)
+    long_rows = np.nonzero(lens > long_limit)[0]
+    assert np.array_equal(sl["long_map"], long_rows)
+    R = sl["rows_per_block"]
+    mask_rows = [b * R + w * 32 + bit for b in range(sl["n_blocks"]) for w in range(R // 32) for bit in range(32)
+                 if (sl["long_mask"][b * (R // 32) + w] >> bit) & 1]
+    assert mask_rows == list(long_rows)
+    maj, mnr, v = _slab_to_coo(sl, n_major)
+    short = np.ones(n_major, bool)
+    short[long_rows] = False
+    rows_csr = np.repeat(np.arange(n_major), lens)
+    keep = short[rows_csr]
+    # same multiset of triplets
+    a = np.lexsort((mnr, maj))
+    assert np.array_equal(maj[a], rows_csr[keep]) and np.array_equal(mnr[a], idx[keep]) and np.array_equal(v[a], val[keep])
+    # storage order: within a block sorted by (slab, major, minor); so per major minors ascend
+    cand = np.nonzero(short & (lens > 1))[0]
+    for r in (np.random.default_rng(0).choice(cand, size=min(50, len(cand)), replace=False) if len(cand) else []):
+        pos = np.nonzero(maj == r)[0]
+        assert np.all(np.diff(pos) > 0) and np.all(np.diff(mnr[pos]) > 0)
+    blk = maj // R
+    assert np.all(np.diff(blk) >= 0)

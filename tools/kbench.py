@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmark on the bench workload: times individual kernels with HIP events
+(pdlp_mi355x_time_kernel) — also the command run under rocprofv3 for profiles/."""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from highs_amd import abi, solver  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--m", type=int, default=1_000_000)
+ap.add_argument("--n", type=int, default=1_000_000)
+ap.add_argument("--nnz", type=int, default=8_000_000)
+ap.add_argument("--reps", type=int, default=30)
+ap.add_argument("--iters", type=int, default=0, help="also run this many PDHG iterations first")
+ap.add_argument("--kernels", default="primal_step,spmv_ax,spmv_aty,decide,trial,spmv_ax_plain,spmv_aty_plain")
+args = ap.parse_args()
+sp_ = solver.SyntheticProblem(args.m, args.n, args.nnz, 1)
+S = solver.DeviceSolver(problem_struct=sp_.struct, params=abi.default_params(kkt_tolerance=1e-4))
+out = {}
+if args.iters:
+    st = S.iterate(args.iters)
+    out["iterate_ms_per_iter"] = st.gpu_ms / st.iters
+for k in args.kernels.split(","):
+    out[k] = S.time_kernel(k, args.reps)
+print(json.dumps(out))
