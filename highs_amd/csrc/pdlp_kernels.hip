@@ -271,30 +271,37 @@ __global__ __launch_bounds__(kSlabThreads) void k_spmv_slab(const SpmvArgs a) {
   const Pre preA = prefetch(rA), preB = prefetch(rB);
 
   const int last = e1 > e0 ? e1 - 1 : e0;  // ent/val carry one pad element
-  int q = e0 + tid;
+  __syncthreads();  // sp[] and acc[] are ready
+  auto ptr = [&](int k) -> int { return cached ? sp[k] : segp[k]; };
+  // Windows of up to 256 entries that never straddle a slab boundary: inside a
+  // window a major then forms ONE run (entries are sorted by major within the
+  // slab), so each accumulator has a single writer per window and the barrier
+  // between windows orders the runs of a major slab after slab.
+  int k = 0, wbeg = e0;
+  while (k < S - 1 && ptr(k + 1) == wbeg) ++k;  // skip empty leading slabs
+  int q = wbeg + tid;
   int qc = q < last ? q : last;
   uint32_t en = ent[qc];
   double vv = val[qc];
-  __syncthreads();
   int buf = 0;
-  for (int w = e0; w < e1; w += kSlabThreads, buf ^= 1) {
-    // prefetch the next window while this one is processed
-    const int qn = q + kSlabThreads;
+  while (wbeg < e1) {
+    const int slabEnd = ptr(k + 1);
+    const int wend = wbeg + kSlabThreads < slabEnd ? wbeg + kSlabThreads : slabEnd;
+    // next window (uniform): same slab, or the next non-empty one
+    int nk = k;
+    if (wend == slabEnd) {
+      ++nk;
+      while (nk < S - 1 && ptr(nk + 1) == wend) ++nk;
+    }
+    // prefetch the next window's entries while this one is processed
+    const int qn = wend + tid;
     const int qnc = qn < last ? qn : last;
     const uint32_t enN = ent[qnc];
     const double vvN = val[qnc];
-    // slab of entry q: largest k with segp[k] <= q (depends on q only, not on loaded data)
-    qc = q < last ? q : last;
-    int lo = 0, hi = S;
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      const int pm = cached ? sp[mid] : segp[mid];
-      if (pm <= qc) lo = mid; else hi = mid;
-    }
-    const bool valid = q < e1;
+    const bool valid = q < wend;
     const uint32_t lrow = en >> 16, lcol = en & 0xffffu;
-    const double xg = in[((size_t)lo << 16) + lcol];
-    const double prod = vv * xg;
+    const size_t gi = valid ? (((size_t)k << 16) + lcol) : 0;  // clamped, unconditional gather
+    const double prod = vv * in[gi];
     stage[buf][tid] = prod;
     srow[buf][tid] = valid ? (uint16_t)lrow : (uint16_t)0xffff;
     __syncthreads();
@@ -304,9 +311,12 @@ __global__ __launch_bounds__(kSlabThreads) void k_spmv_slab(const SpmvArgs a) {
       for (int j = tid + 1; j < kSlabThreads && srow[buf][j] == (uint16_t)lrow; ++j) s += stage[buf][j];
       acc[lrow] = s;
     }
+    wbeg = wend;
+    k = nk;
     q = qn;
     en = enN;
     vv = vvN;
+    buf ^= 1;
   }
   __syncthreads();
 
