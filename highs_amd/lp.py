@@ -295,3 +295,59 @@ def kkt_measures(lp, col_value, col_dual, row_value, row_dual, primal_feasibilit
         "max_dual_residual_error": float(dres.max(initial=0.0)),
         "primal_dual_objective_error": abs(obj - dobj) / (1.0 + abs(obj) + abs(dobj)),
     }
+
+
+def write_mps(lp, path):
+    """Minimal free-format MPS writer (the inverse of read_mps) — lets the tests hand golden LPs to
+    the reference's own CLI on a box without the reference tree."""
+    inf = kHighsInf
+    with open(path, "w") as f:
+        f.write(f"NAME {lp.model_name or 'LP'}\n")
+        if lp.sense < 0:
+            f.write("OBJSENSE\n    MAX\n")
+        f.write("ROWS\n N COST\n")
+        rt = []
+        for i in range(lp.num_row):
+            lo, up = lp.row_lower[i], lp.row_upper[i]
+            t = "E" if lo == up else ("G" if up >= inf else ("L" if lo <= -inf else "R"))
+            if lo <= -inf and up >= inf:
+                t = "N"
+            rt.append(t)
+            f.write(f" {'G' if t == 'R' else t} R{i}\n")
+        f.write("COLUMNS\n")
+        for j in range(lp.num_col):
+            if lp.col_cost[j] != 0.0:
+                f.write(f" C{j} COST {float(lp.col_cost[j])!r}\n")
+            for p in range(lp.a_start[j], lp.a_start[j + 1]):
+                f.write(f" C{j} R{lp.a_index[p]} {float(lp.a_value[p])!r}\n")
+            if lp.col_cost[j] == 0.0 and lp.a_start[j] == lp.a_start[j + 1]:
+                f.write(f" C{j} COST 0\n")
+        f.write("RHS\n")
+        if lp.offset != 0.0:
+            f.write(f" RHS COST {float(-lp.offset)!r}\n")
+        for i in range(lp.num_row):
+            v = {"E": lp.row_lower[i], "G": lp.row_lower[i], "R": lp.row_lower[i], "L": lp.row_upper[i], "N": 0.0}[rt[i]]
+            if v != 0.0:
+                f.write(f" RHS R{i} {float(v)!r}\n")
+        if "R" in rt:
+            f.write("RANGES\n")
+            for i in range(lp.num_row):
+                if rt[i] == "R":
+                    f.write(f" RNG R{i} {float((lp.row_upper[i] - lp.row_lower[i]))!r}\n")
+        f.write("BOUNDS\n")
+        for j in range(lp.num_col):
+            lo, up = lp.col_lower[j], lp.col_upper[j]
+            if lo == 0.0 and up >= inf:
+                continue
+            if lo <= -inf and up >= inf:
+                f.write(f" FR BND C{j}\n")
+            elif lo == up:
+                f.write(f" FX BND C{j} {float(lo)!r}\n")
+            else:
+                if lo <= -inf:
+                    f.write(f" MI BND C{j}\n")
+                elif lo != 0.0:
+                    f.write(f" LO BND C{j} {float(lo)!r}\n")
+                if up < inf:
+                    f.write(f" UP BND C{j} {float(up)!r}\n")
+        f.write("ENDATA\n")
