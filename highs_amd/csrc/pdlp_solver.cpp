@@ -135,10 +135,19 @@ Solver::Solver(const pdlp_problem_t& P, const pdlp_params_t& opt, int32_t rank, 
   // cuPDLP treats "either flag set" as has_variables (cupdlp_solver.c:1465) but
   // only fills x,y when both are; with one flag the start is the zero vector.
 
-  if (world_ > 1) {
+  // PDLP_MI355X_FORCE_COMM=1 runs the sharded kernel sequence and the RCCL
+  // all-reduce with a single rank (lets a 1-GPU box exercise the multi-GPU path)
+  const char* fc = getenv("PDLP_MI355X_FORCE_COMM");
+  sharded_ = world_ > 1 || (fc && atoi(fc) != 0);
+  if (sharded_) {
     std::vector<int32_t> off = rowPartition(F_.csr, F_.m, world_);
     r0_ = off[rank_];
     r1_ = off[rank_ + 1];
+    unsigned char localId[128];
+    if (world_ == 1 && !id128) {
+      Comm::uniqueId(localId);
+      id128 = localId;
+    }
     comm_ = new Comm(rank_, world_, id128);
   } else {
     r0_ = 0;
@@ -163,7 +172,7 @@ void Solver::uploadProblem() {
   const int32_t n = F_.n;
   int slabMode = -1;  // auto
   if (const char* g = getenv("PDLP_MI355X_SLAB")) slabMode = atoi(g);
-  if (world_ == 1) {
+  if (!sharded_) {
     dA_.upload(F_.csr, F_.m, n, slabMode, stream_);
     dAt_.upload(F_.cscSorted, n, F_.m, slabMode, stream_);
   } else {
@@ -233,7 +242,7 @@ void Solver::pushState() {
 void Solver::deviceAx(const double* x, double* axLocal) { launchSpmvPlain(dA_.view(), x, axLocal, stream_); }
 
 void Solver::deviceATy(const double* yLocal, double* aty) {
-  if (world_ == 1) {
+  if (!sharded_) {
     launchSpmvPlain(dAt_.view(), yLocal, aty, stream_);
   } else {
     launchSpmvPlain(dAt_.view(), yLocal, commBuf_.get(), stream_);
@@ -246,7 +255,7 @@ void Solver::deviceATy(const double* yLocal, double* aty) {
 // quantities are additionally summed over the row-block owners.
 double Solver::reduceScalar(const double* partials, int32_t nBlocks, bool rowQuantity) {
   launchFinalReduce(partials, nBlocks, nBlocks, 1, statOut_.get() + kStatTotal, stream_);
-  if (rowQuantity && world_ > 1) comm_->allReduceSum(statOut_.get() + kStatTotal, 1, stream_);
+  if (rowQuantity && sharded_) comm_->allReduceSum(statOut_.get() + kStatTotal, 1, stream_);
   PDLP_HIP(hipMemcpyAsync(hostStats_ + kStatTotal, statOut_.get() + kStatTotal, sizeof(double),
                           hipMemcpyDeviceToHost, stream_));
   PDLP_HIP(hipStreamSynchronize(stream_));
@@ -342,7 +351,7 @@ void Solver::reset() {
 void Solver::enqueueTrial() {
   launchPrimalStep(vecs_, dState_.get(), stream_);
   launchSpmvAxDual(dA_.view(), vecs_, dState_.get(), partDY_.get(), stream_);
-  if (world_ == 1) {
+  if (!sharded_) {
     launchSpmvAtyInteract(dAt_.view(), vecs_, dState_.get(), partDX_.get(), partInter_.get(), stream_);
     launchDecide(dState_.get(), partDY_.get(), dA_.nPartials(), partDX_.get(), partInter_.get(), dAt_.nPartials(),
                  nullptr, stream_);
@@ -365,7 +374,7 @@ void Solver::runUntilHalt() {
     if (remaining < 1) remaining = 1;
     if (remaining > 4 * kCheckInterval) remaining = 4 * kCheckInterval;
     int32_t todo = (int32_t)remaining;
-    if (useGraph_ && world_ == 1 && todo >= kGraphTrials) {
+    if (useGraph_ && !sharded_ && todo >= kGraphTrials) {
       if (!graphExec_) {
         hipGraph_t graph = nullptr;
         PDLP_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
@@ -431,7 +440,7 @@ void Solver::computeResiduals() {
   launchFinalReduce(part, statStride_, nbM, 2 * kRowStats, statOut_.get(), stream_);
   launchFinalReduce(part + (size_t)kStatColCur * statStride_, statStride_, nbN, 2 * kColStats,
                     statOut_.get() + kStatColCur, stream_);
-  if (world_ > 1) comm_->allReduceSum(statOut_.get(), 2 * kRowStats, stream_);
+  if (sharded_) comm_->allReduceSum(statOut_.get(), 2 * kRowStats, stream_);
   PDLP_HIP(hipMemcpyAsync(hostStats_, statOut_.get(), sizeof(double) * kStatTotal, hipMemcpyDeviceToHost, stream_));
   PDLP_HIP(hipStreamSynchronize(stream_));
 
@@ -656,7 +665,7 @@ void Solver::postsolve(pdlp_result_t* R) {
   (useAvg ? yAvg_ : y_[c]).download(y.data() + r0_, mLoc_, stream_);
   (useAvg ? axAvg_ : ax_[c]).download(ax.data() + r0_, mLoc_, stream_);
   PDLP_HIP(hipStreamSynchronize(stream_));
-  if (world_ > 1) {  // assemble the row-sharded vectors on every rank
+  if (sharded_) {  // assemble the row-sharded vectors on every rank
     DeviceArray<double> g;
     g.alloc(2 * (size_t)m);
     std::vector<double> both(2 * (size_t)m, 0.0);
@@ -818,7 +827,7 @@ double Solver::timeKernel(const std::string& name, int32_t reps) {
   auto once = [&]() {
     if (name == "spmv_ax") launchSpmvAxDual(dA_.view(), vecs_, dState_.get(), partDY_.get(), stream_);
     else if (name == "spmv_aty") {
-      if (world_ == 1) launchSpmvAtyInteract(dAt_.view(), vecs_, dState_.get(), partDX_.get(), partInter_.get(), stream_);
+      if (!sharded_) launchSpmvAtyInteract(dAt_.view(), vecs_, dState_.get(), partDX_.get(), partInter_.get(), stream_);
       else launchSpmvAtyPartial(dAt_.view(), vecs_, dState_.get(), commBuf_.get(), stream_);
     } else if (name == "primal_step") launchPrimalStep(vecs_, dState_.get(), stream_);
     else if (name == "decide")

@@ -130,6 +130,7 @@ class Solver {
   // sharding
   int32_t rank_ = 0, world_ = 1, r0_ = 0, r1_ = 0, mLoc_ = 0;
   Comm* comm_ = nullptr;
+  bool sharded_ = false;  // row-block sharded kernel sequence + RCCL (world > 1, or forced for testing)
   // device
   hipStream_t stream_ = nullptr;
   DeviceMatrix dA_, dAt_;

@@ -1,0 +1,99 @@
+"""Multi-rank (gloo, world_size 2, CPU) check of the row-block sharded trial step:
+every rank owns a contiguous row block of the formulated A (the partition the library's
+create_sharded uses), does the primal step redundantly, the dual step on its rows, a partial
+A_g' y_g, and ONE all-reduce of n+1 doubles (partials + local sum dy^2).  The result must equal the
+unsharded oracle trial step, and every rank must reach the same accept/reject decision bit for bit."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oraclelib as O
+from highs_amd import abi, solver
+
+
+def _worker(rank, world, port, ret):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sp_ = solver.SyntheticProblem(3000, 2500, 24000, 11)
+        lp = sp_.to_lp()
+        P = solver.Prepared(problem_struct=sp_.struct)
+        n, m = P.n, P.m
+        off = P.row_partition(world)
+        r0, r1 = int(off[rank]), int(off[rank + 1])
+        import scipy.sparse as sps
+        A = sps.csr_matrix((P.csr_val, P.csr_idx, P.csr_beg), shape=(m, n))
+        Ag = A[r0:r1]
+        rng = np.random.default_rng(3)  # same on every rank: replicated x, full y sliced per rank
+        x = np.clip(rng.standard_normal(n), P.lower, P.upper)
+        y = rng.standard_normal(m)
+        y[P.n_eqs:] = np.maximum(y[P.n_eqs:], 0)
+        tau, sigma, beta = 0.31, 0.23, 0.23 / 0.31
+        ax_g = Ag @ x
+        # partial A_g' y_g + all-reduce gives aty (replicated)
+        t = torch.from_numpy(np.asarray(Ag.T @ y[r0:r1]).copy())
+        dist.all_reduce(t)
+        aty = t.numpy()
+        # --- sharded trial step ---
+        xU = np.minimum(np.maximum((x + (-tau) * P.cost) + tau * aty, P.lower), P.upper) if False else None
+        v = x.copy(); v += (-tau) * P.cost; v += tau * aty
+        v = np.where(v < P.upper, v, P.upper); v = np.where(v > P.lower, v, P.lower)
+        xU = v
+        axU_g = Ag @ xU
+        yg = y[r0:r1]
+        w = yg.copy(); w += sigma * P.rhs[r0:r1]; w += (-2.0 * sigma) * axU_g; w += sigma * ax_g
+        ineq = (np.arange(r0, r1) >= P.n_eqs)
+        w = np.where(ineq, np.where(w > 0, w, 0.0), w)
+        yU_g = w
+        buf = np.zeros(n + 1)
+        buf[:n] = Ag.T @ yU_g
+        buf[n] = float(np.sum((yg - yU_g) ** 2))
+        tb = torch.from_numpy(buf)
+        dist.all_reduce(tb)  # the one collective of a trial step
+        atyU, dY2 = buf[:n], buf[n]
+        dX2 = float(np.sum((x - xU) ** 2))
+        inter = float(np.sum((x - xU) * (aty - atyU)))
+        sb = np.sqrt(beta)
+        movement = dX2 * 0.5 * sb + dY2 / (2 * sb)
+        limit = movement / abs(inter)
+        accept = np.sqrt(tau * sigma) <= limit
+        # every rank must hold identical replicated data and take the same decision
+        sig = torch.tensor([dX2, dY2, inter, limit, float(accept), float(np.sum(xU)), float(np.sum(atyU))], dtype=torch.float64)
+        gathered = [torch.zeros_like(sig) for _ in range(world)]
+        dist.all_gather(gathered, sig)
+        same = all(torch.equal(g, gathered[0]) for g in gathered)
+        # --- unsharded oracle ---
+        ax = np.zeros(m); tt = torch.zeros(m, dtype=torch.float64); tt[r0:r1] = torch.from_numpy(np.asarray(ax_g)); dist.all_reduce(tt); ax = tt.numpy()
+        Ph = abi.ProblemHandle(lp)
+        F = O.Formulated()
+        prm = abi.default_params()
+        assert O.oracle().pdlp_oracle_formulate_scale(C.byref(Ph.struct), C.byref(prm), C.byref(F)) == 0
+        xo, yo, axo, atyo, o3 = np.zeros(n), np.zeros(m), np.zeros(m), np.zeros(n), np.zeros(3)
+        d = lambda a: np.ascontiguousarray(a).ctypes.data_as(abi.c_f64p)
+        xc, yc, axc, atyc = map(np.ascontiguousarray, (x, y, ax, aty))
+        O.oracle().pdlp_oracle_trial_step(C.byref(F), tau, sigma, d(xc), d(yc), d(axc), d(atyc), d(xo), d(yo), d(axo), d(atyo), d(o3))
+        O.oracle().pdlp_oracle_free_formulated(C.byref(F))
+        ok = (same and np.array_equal(xU, xo) and np.allclose(axU_g, axo[r0:r1], rtol=0, atol=1e-12)
+              and np.allclose(yU_g, yo[r0:r1], rtol=0, atol=1e-12) and np.allclose(atyU, atyo, rtol=0, atol=1e-11)
+              and np.allclose([dX2, dY2, inter], o3, rtol=1e-10))
+        ret[rank] = (bool(ok), r0, r1)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2])
+def test_sharded_trial_step_matches_unsharded_oracle(world):
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    blocks = sorted((v[1], v[2]) for v in ret.values())
+    assert blocks[0][0] == 0 and all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
+    assert all(v[0] for v in ret.values())

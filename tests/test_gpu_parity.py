@@ -301,3 +301,19 @@ def test_full_size_properties_1m():
     assert np.all(x >= lo) and np.all(x <= up) and np.all(y[S.n_eqs:] >= 0)
     assert np.array_equal(Ax(x), ax) and np.array_equal(ATy(y), aty)
     S.close()
+
+
+def test_sharded_kernel_sequence_single_rank(monkeypatch):
+    """The multi-GPU code path (partial A'y -> RCCL all-reduce of n+1 doubles -> interaction kernel ->
+    decision from the reduced sum dy^2) forced onto ONE rank: must reproduce the single-GPU solve."""
+    lp = _lp("e226")
+    base = solver.solveLpCupdlp(lp)
+    monkeypatch.setenv("PDLP_MI355X_FORCE_COMM", "1")
+    sh = solver.solveLpCupdlp(lp)
+    assert sh.model_status == solver.kOptimal
+    # x+, y+, A x+, A'y+ are the same values; only the dX^2 / interaction partial sums are grouped
+    # differently (vector grid instead of SpMV work blocks), so the trajectories agree to rounding
+    a, b = sh.info["objective_function_value"], base.info["objective_function_value"]
+    assert abs(a - b) <= 1e-6 * (1 + abs(b))
+    assert 0.5 * base.pdlp_iteration_count <= sh.pdlp_iteration_count <= 2 * base.pdlp_iteration_count
+    assert sh.result.primal_feas < 1e-7 * (1 + sh.result.norm_rhs) and sh.result.rel_gap < 1e-7
