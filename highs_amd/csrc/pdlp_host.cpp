@@ -297,6 +297,18 @@ void buildSlabLayout(const Compressed& csr, int32_t nMajor, int32_t nMinor, int3
   }
   out.ent.resize((size_t)acc);
   out.val.resize((size_t)acc);
+  if (S > 65535) throw std::runtime_error("slab layout: too many slabs");
+  out.winPtr.assign(1, 0);
+  for (int32_t b = 0; b < out.nBlocks; ++b) {
+    for (int32_t k = 0; k < S; ++k) {
+      const int32_t sb = out.segPtr[(size_t)b * (S + 1) + k], se = out.segPtr[(size_t)b * (S + 1) + k + 1];
+      for (int32_t q = sb; q < se; q += 256) {
+        out.winBeg.push_back(q);
+        out.winInfo.push_back(((uint32_t)k << 16) | (uint32_t)std::min(256, se - q));
+      }
+    }
+    out.winPtr.push_back((int32_t)out.winBeg.size());
+  }
   // pass 2: majors in order, minors ascending within a major => each (block, slab)
   // segment comes out sorted by (local major, minor)
   std::vector<int32_t> pos((size_t)out.nBlocks * S);

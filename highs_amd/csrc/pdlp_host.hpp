@@ -77,6 +77,11 @@ StreamPlan planStream(const std::vector<int32_t>& beg, int32_t nMajor, int32_t c
 struct SlabLayout {
   int32_t rowsPerBlock = 0, nBlocks = 0, nSlabs = 0;
   std::vector<int32_t> segPtr;    // [nBlocks*(nSlabs+1)] entry offsets
+  // Static work list of the kernel: per block, windows of <= 256 entries that never
+  // straddle a slab.  winBeg = first entry, winInfo = (slab << 16 | entry count).
+  std::vector<int32_t> winPtr;    // [nBlocks+1]
+  std::vector<int32_t> winBeg;    // [nWindows]
+  std::vector<uint32_t> winInfo;  // [nWindows]
   std::vector<uint32_t> ent;      // [nnzShort]
   std::vector<double> val;        // [nnzShort]
   std::vector<uint32_t> longMask; // [nBlocks * rowsPerBlock/32]

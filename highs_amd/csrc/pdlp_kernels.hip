@@ -69,6 +69,13 @@ struct SpmvArgs {
 //            the input vector, and park the products in LDS;
 //   phase 2: one lane per major adds its products left to right (the
 //            reference's summation order) and runs the epilogue.
+// Block-uniform read through the scalar (constant) path: s_load counts on lgkmcnt,
+// so it never forces a wait on the vector-memory prefetches in flight.
+template <typename T>
+__device__ __forceinline__ T ldUniform(const T* p) {
+  return *(const __attribute__((address_space(4))) T*)(p);
+}
+
 template <typename T>
 __device__ __forceinline__ T ldStream(const T* p, bool nt) {
   return nt ? __builtin_nontemporal_load(p) : *p;
@@ -217,27 +224,30 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
 // right, onto the major's LDS accumulator.  Because slabs and the minors inside
 // a slab ascend, every major is still summed in ascending minor order — the
 // reference's order — and the result is bit-identical to the CSR path.
-template <int EPI>
-__global__ __launch_bounds__(kSlabThreads) void k_spmv_slab(const SpmvArgs a) {
+template <int EPI, int kGroup>
+__global__ __launch_bounds__(kSlabThreads, 8) void k_spmv_slab(const SpmvArgs a) {
   const DevState* st = a.st;
   if (EPI != kPlain && st->halted) return;
   // dynamic LDS (all carve offsets are multiples of 16 bytes; no static __shared__ in this kernel):
-  //   acc[R] f64 | stage[2][256] f64 | scratch[2][4] f64 | sp[72] i32 | srow[2][256] u16
+  //   acc[R] f64 | stage[2][256] f64 | scratch[2][4] f64 | srow[2][256] u16
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* acc = reinterpret_cast<double*>(smem);
   double(*stage)[kSlabThreads] = reinterpret_cast<double(*)[kSlabThreads]>(acc + a.S.rowsPerBlock);
   double(*scratch)[kSlabThreads / kWave] = reinterpret_cast<double(*)[kSlabThreads / kWave]>(&stage[2][0]);
-  int32_t* sp = reinterpret_cast<int32_t*>(&scratch[2][0]);  // slab pointers (cached when nSlabs <= 64)
-  uint16_t(*srow)[kSlabThreads] = reinterpret_cast<uint16_t(*)[kSlabThreads]>(sp + 72);
+  uint16_t(*srow)[kSlabThreads] = reinterpret_cast<uint16_t(*)[kSlabThreads]>(&scratch[2][0]);
 
   const int tid = threadIdx.x;
   const int blk = blockIdx.x;
-  const int R = a.S.rowsPerBlock, S = a.S.nSlabs;
+  const int R = a.S.rowsPerBlock;
   const int rBase = blk * R;
   const int rEnd = (rBase + R < a.S.nMajor) ? rBase + R : a.S.nMajor;
-  const int32_t* __restrict__ segp = a.S.segPtr + (size_t)blk * (S + 1);
   const uint32_t* __restrict__ ent = a.S.ent;
   const double* __restrict__ val = a.S.val;
+  // this block's static window list (block-uniform -> scalar loads, which do not
+  // touch the vector-memory counter the prefetches below depend on)
+  const int wBeg = a.S.winPtr[blk], wEnd = a.S.winPtr[blk + 1];
+  const int32_t* __restrict__ winBeg = a.S.winBeg;
+  const uint32_t* __restrict__ winInfo = a.S.winInfo;
 
   int cur = 0, nxt = 1;
   double sigma = 0.0, avgW = 0.0;
@@ -252,9 +262,6 @@ __global__ __launch_bounds__(kSlabThreads) void k_spmv_slab(const SpmvArgs a) {
   else if (EPI == kDualStep) in = a.v.x[nxt];
   else in = a.v.y[nxt];
 
-  const int e0 = segp[0], e1 = segp[S];
-  const bool cached = S <= 64;
-  if (cached) for (int k = tid; k <= S; k += kSlabThreads) sp[k] = segp[k];
   for (int r = tid; r < R; r += kSlabThreads) acc[r] = 0.0;
 
   double acc0 = 0.0, acc1 = 0.0;
@@ -270,53 +277,58 @@ __global__ __launch_bounds__(kSlabThreads) void k_spmv_slab(const SpmvArgs a) {
   const int rB = rBase + tid + kSlabThreads < rEnd ? rBase + tid + kSlabThreads : rEnd - 1;
   const Pre preA = prefetch(rA), preB = prefetch(rB);
 
-  const int last = e1 > e0 ? e1 - 1 : e0;  // ent/val carry one pad element
-  __syncthreads();  // sp[] and acc[] are ready
-  auto ptr = [&](int k) -> int { return cached ? sp[k] : segp[k]; };
+  __syncthreads();  // acc[] is zeroed
   // Windows of up to 256 entries that never straddle a slab boundary: inside a
-  // window a major then forms ONE run (entries are sorted by major within the
-  // slab), so each accumulator has a single writer per window and the barrier
-  // between windows orders the runs of a major slab after slab.
-  int k = 0, wbeg = e0;
-  while (k < S - 1 && ptr(k + 1) == wbeg) ++k;  // skip empty leading slabs
-  int q = wbeg + tid;
-  int qc = q < last ? q : last;
-  uint32_t en = ent[qc];
-  double vv = val[qc];
-  int buf = 0;
-  while (wbeg < e1) {
-    const int slabEnd = ptr(k + 1);
-    const int wend = wbeg + kSlabThreads < slabEnd ? wbeg + kSlabThreads : slabEnd;
-    // next window (uniform): same slab, or the next non-empty one
-    int nk = k;
-    if (wend == slabEnd) {
-      ++nk;
-      while (nk < S - 1 && ptr(nk + 1) == wend) ++nk;
+  // window a major forms ONE run (entries are sorted by major within the slab),
+  // so each accumulator has a single writer per window and the barrier between
+  // windows orders the runs of a major slab after slab.
+  struct Win { int beg, cnt, slab; };
+  auto getWin = [&](int i) -> Win {  // block-uniform; windows past the end are empty
+    int ic = i < wEnd ? i : wEnd - 1;  // winBeg/winInfo carry one pad element
+    ic = __builtin_amdgcn_readfirstlane(ic < 0 ? 0 : ic);  // SGPR index -> s_load (lgkmcnt, not vmcnt)
+    const uint32_t info = ldUniform(winInfo + ic);
+    const int beg = ldUniform(winBeg + ic);
+    return Win{beg, i < wEnd ? (int)(info & 0xffffu) : 0, (int)(info >> 16)};
+  };
+  // All loads are unconditional (lanes past the window read the next entries, the
+  // arrays carry a pad element) so that hipcc never drains vmcnt at a branch join.
+  auto gatherIdx = [&](const Win& w, uint32_t en) -> size_t {
+    return tid < w.cnt ? (((size_t)w.slab << 16) + (en & 0xffffu)) : 0;
+  };
+  // Windows are processed in groups of kGroup inside ONE straight-line loop body:
+  // all 2*kGroup entry loads, then all kGroup gathers, are issued up front and each
+  // window then waits only for its own gather (vmcnt(kGroup-1-g)).  (Carrying loads
+  // across the loop back-edge instead makes hipcc insert vmcnt(0) at the loop head,
+  // which serialises the pipeline.)  Windows past the end have cnt = 0: harmless.
+  for (int wg = wBeg; wg < wEnd; wg += kGroup) {
+    Win w[kGroup];
+    uint32_t en[kGroup];
+    double vv[kGroup], xg[kGroup];
+#pragma unroll
+    for (int g = 0; g < kGroup; ++g) {
+      w[g] = getWin(wg + g);
+      en[g] = ent[w[g].beg + tid];
+      vv[g] = val[w[g].beg + tid];
     }
-    // prefetch the next window's entries while this one is processed
-    const int qn = wend + tid;
-    const int qnc = qn < last ? qn : last;
-    const uint32_t enN = ent[qnc];
-    const double vvN = val[qnc];
-    const bool valid = q < wend;
-    const uint32_t lrow = en >> 16, lcol = en & 0xffffu;
-    const size_t gi = valid ? (((size_t)k << 16) + lcol) : 0;  // clamped, unconditional gather
-    const double prod = vv * in[gi];
-    stage[buf][tid] = prod;
-    srow[buf][tid] = valid ? (uint16_t)lrow : (uint16_t)0xffff;
-    __syncthreads();
-    if (valid && (tid == 0 || srow[buf][tid - 1] != (uint16_t)lrow)) {
-      double s = acc[lrow];
-      s += prod;
-      for (int j = tid + 1; j < kSlabThreads && srow[buf][j] == (uint16_t)lrow; ++j) s += stage[buf][j];
-      acc[lrow] = s;
+#pragma unroll
+    for (int g = 0; g < kGroup; ++g) xg[g] = in[gatherIdx(w[g], en[g])];
+#pragma unroll
+    for (int g = 0; g < kGroup; ++g) {
+      constexpr int kBufMask = 1;
+      const int buf = g & kBufMask;
+      const bool valid = tid < w[g].cnt;
+      const uint32_t lrow = en[g] >> 16;
+      const double prod = vv[g] * xg[g];
+      stage[buf][tid] = prod;
+      srow[buf][tid] = valid ? (uint16_t)lrow : (uint16_t)0xffff;
+      __syncthreads();
+      if (valid && (tid == 0 || srow[buf][tid - 1] != (uint16_t)lrow)) {
+        double s = acc[lrow];
+        s += prod;
+        for (int j = tid + 1; j < kSlabThreads && srow[buf][j] == (uint16_t)lrow; ++j) s += stage[buf][j];
+        acc[lrow] = s;
+      }
     }
-    wbeg = wend;
-    k = nk;
-    q = qn;
-    en = enN;
-    vv = vvN;
-    buf ^= 1;
   }
   __syncthreads();
 
@@ -647,6 +659,8 @@ void launchPrimalStep(const IterVecs& v, const DevState* st, hipStream_t s) {
 }
 
 static bool g_spmvNT = false;
+static int g_slabGroup = 1;
+void setSlabGroup(int g) { g_slabGroup = g; }
 void setSpmvNonTemporal(bool on) { g_spmvNT = on; }
 
 namespace {
@@ -655,8 +669,13 @@ void launchSpmv(const MatView& M, SpmvArgs a, hipStream_t s) {
   if (M.useSlab && M.slab.nBlocks > 0) {
     a.S = M.slab;
     const size_t lds = (size_t)M.slab.rowsPerBlock * 8 + 2 * kSlabThreads * 8 + 2 * (kSlabThreads / kWave) * 8 +
-                       72 * 4 + 2 * kSlabThreads * 2;
-    hipLaunchKernelGGL((k_spmv_slab<EPI>), dim3(M.slab.nBlocks), dim3(kSlabThreads), lds, s, a);
+                       2 * kSlabThreads * 2;
+    switch (g_slabGroup) {
+      case 1: hipLaunchKernelGGL((k_spmv_slab<EPI, 1>), dim3(M.slab.nBlocks), dim3(kSlabThreads), lds, s, a); break;
+      case 2: hipLaunchKernelGGL((k_spmv_slab<EPI, 2>), dim3(M.slab.nBlocks), dim3(kSlabThreads), lds, s, a); break;
+      case 4: hipLaunchKernelGGL((k_spmv_slab<EPI, 4>), dim3(M.slab.nBlocks), dim3(kSlabThreads), lds, s, a); break;
+      default: hipLaunchKernelGGL((k_spmv_slab<EPI, 8>), dim3(M.slab.nBlocks), dim3(kSlabThreads), lds, s, a); break;
+    }
   }
   if (M.csr.nBlocks > 0) {
     a.A = M.csr;

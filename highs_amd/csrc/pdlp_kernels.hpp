@@ -53,7 +53,9 @@ struct SpmvMat {
 constexpr int kSlabThreads = 256;
 constexpr int kSlabMaxRows = 4096;  // majors per block (LDS accumulators)
 struct SlabMat {
-  const int32_t* segPtr;     // [nBlocks*(nSlabs+1)]
+  const int32_t* winPtr;     // [nBlocks+1] window list of each block
+  const int32_t* winBeg;     // [nWindows] first entry of the window
+  const uint32_t* winInfo;   // [nWindows] (slab<<16 | entries), entries <= 256, one slab per window
   const uint32_t* ent;       // [nnz] (localMajor<<16 | localMinor)
   const double* val;         // [nnz]
   const uint32_t* longMask;  // [nBlocks*rowsPerBlock/32]
@@ -139,6 +141,7 @@ void launchDiffNorm2(const double* a, const double* b, int32_t len, double* part
 // partials of a.b
 void launchDot(const double* a, const double* b, int32_t len, double* partials, int32_t nBlocks, hipStream_t s);
 
+void setSlabGroup(int g);  // windows in flight per block in the slab SpMV (1, 2, 4 or 8)
 void setSpmvNonTemporal(bool on);  // stream idx/val/epilogue operands past L2 (keeps the gathered vector resident)
 int32_t vecBlocks(int32_t len);  // grid size used by the vector/statistics kernels
 

@@ -39,17 +39,23 @@ void DeviceMatrix::upload(const Compressed& cIn, int32_t nMajor_, int32_t nMinor
   if (useSlab) {
     buildSlabLayout(cIn, nMajor_, nMinor_, kSlabLongLimit, L);
     if (L.rowsPerBlock > kSlabMaxRows) throw std::runtime_error("slab layout: too many majors per block");
-    segPtr.alloc(L.segPtr.size());
-    ent.alloc(L.ent.size() + 1);
-    slabVal.alloc(L.val.size() + 1);
+    winPtr.alloc(L.winPtr.size());
+    winBeg.alloc(L.winBeg.size() + 1);
+    winInfo.alloc(L.winInfo.size() + 1);
+    winBeg.zero(s);
+    winInfo.zero(s);
+    winPtr.upload(L.winPtr.data(), L.winPtr.size(), s);
+    winBeg.upload(L.winBeg.data(), L.winBeg.size(), s);
+    winInfo.upload(L.winInfo.data(), L.winInfo.size(), s);
+    ent.alloc(L.ent.size() + kSlabThreads);  // pad: a window's 256 lanes load unconditionally
+    slabVal.alloc(L.val.size() + kSlabThreads);
     longMask.alloc(L.longMask.size());
     ent.zero(s);
     slabVal.zero(s);
-    segPtr.upload(L.segPtr.data(), L.segPtr.size(), s);
     ent.upload(L.ent.data(), L.ent.size(), s);
     slabVal.upload(L.val.data(), L.val.size(), s);
     longMask.upload(L.longMask.data(), L.longMask.size(), s);
-    slab = SlabMat{segPtr.get(), ent.get(), slabVal.get(), longMask.get(), nMajor_, L.nBlocks, L.nSlabs, L.rowsPerBlock};
+    slab = SlabMat{winPtr.get(), winBeg.get(), winInfo.get(), ent.get(), slabVal.get(), longMask.get(), nMajor_, L.nBlocks, L.nSlabs, L.rowsPerBlock};
     c = &L.longCsr;
     majorMap.alloc(L.longMap.size());
     majorMap.upload(L.longMap.data(), L.longMap.size(), s);
@@ -105,6 +111,7 @@ Solver::Solver(const pdlp_problem_t& P, const pdlp_params_t& opt, int32_t rank, 
   PDLP_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
   if (const char* g = getenv("PDLP_MI355X_GRAPH")) useGraph_ = atoi(g) != 0;
   if (const char* g = getenv("PDLP_MI355X_NT")) setSpmvNonTemporal(atoi(g) != 0);
+  if (const char* g = getenv("PDLP_MI355X_SLAB_GROUP")) setSlabGroup(atoi(g));
 
   adaptive_ = !(opt_.features_off & PDLP_FEATURE_ADAPTIVE_STEP_OFF);
   restartOn_ = !(opt_.features_off & PDLP_FEATURE_RESTART_OFF) && opt_.restart_method != 0;

@@ -59,8 +59,8 @@ class DeviceArray {
 
 // One operand matrix in HBM: CSR stream plan, or slab layout + CSR side matrix of long majors.
 struct DeviceMatrix {
-  DeviceArray<int32_t> beg, idx, blockBeg, majorMap, segPtr;
-  DeviceArray<uint32_t> ent, longMask;
+  DeviceArray<int32_t> beg, idx, blockBeg, majorMap, winPtr, winBeg;
+  DeviceArray<uint32_t> ent, longMask, winInfo;
   DeviceArray<double> val, slabVal;
   int32_t nMajor = 0, nBlocks = 0;  // nBlocks = CSR stream blocks
   int64_t nnz = 0;
