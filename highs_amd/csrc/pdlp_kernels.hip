@@ -48,6 +48,115 @@ __device__ __forceinline__ double blockSum(double v, double* scratch /* [NT/64] 
 // off a single bank pair.
 __device__ __forceinline__ int slot(int q) { return q + (q >> 3); }
 
+// Fixed-order sum of `count` partials by one block of 256 threads (4 loads in flight per lane).
+__device__ double reducePartials(const double* __restrict__ p, int count, double* scratch) {
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int i = threadIdx.x;
+  for (; i + 3 * kVecThreads < count; i += 4 * kVecThreads) {
+    const double a0 = p[i], a1 = p[i + kVecThreads], a2 = p[i + 2 * kVecThreads], a3 = p[i + 3 * kVecThreads];
+    s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+  }
+  for (; i < count; i += kVecThreads) s0 += p[i];
+  return blockSum<kVecThreads>((s0 + s1) + (s2 + s3), scratch);
+}
+
+// Accept/reject and step-size update of PDHG_Update_Iterate_Adaptive_Step_Size
+// (cupdlp_step.c:237-306), the bookkeeping of PDHG_Update_Average (:433-441)
+// and the parity flip that the reference gets from ++nIter.  One thread.
+__device__ void decideUpdate(DevState* st, double dX2, double dY2, double inter) {
+  DevState s = *st;
+  const double sb = sqrt(s.beta);
+  const double movement = dX2 * 0.5 * sb + dY2 / (2.0 * sb);
+  s.nTrials += 1;
+  bool accept = true;
+  double etaNew = s.eta;
+  double limit = INFINITY;
+  if (s.adaptive) {
+    limit = (inter != 0.0) ? movement / fabs(inter) : INFINITY;
+    accept = s.eta <= limit;
+    const double k1 = (double)s.nTrials + 1.0;
+    const double first = (1.0 - pow(k1, -0.3)) * limit;   // PDHG_STEPSIZE_REDUCTION_EXP
+    const double second = (1.0 + pow(k1, -0.6)) * s.eta;  // PDHG_STEPSIZE_GROWTH_EXP
+    etaNew = fmin(first, second);
+  }
+  s.dX2 = dX2; s.dY2 = dY2; s.inter = inter; s.movement = movement; s.limit = limit;
+  s.lastAccepted = accept ? 1 : 0;
+  if (accept) {
+    if (s.adaptive) {
+      s.primalStep = etaNew / sqrt(s.beta);
+      s.dualStep = etaNew * sqrt(s.beta);
+    }
+    const double w = sqrt(s.primalStep * s.dualStep);  // uses the NEXT step sizes (step.c:433)
+    s.sumPrimalStep += w;
+    s.sumDualStep += w;
+    s.avgW = w;
+    s.cur ^= 1;
+    s.nIter += 1;
+    s.eta = w;  // next iteration starts from sqrt(primalStep*dualStep) (step.c:231)
+    if (s.nIter >= s.haltIter) s.halted = 1;
+  } else {
+    s.eta = etaNew;
+    s.avgW = 0.0;
+  }
+  if (s.adaptive) {
+    s.tau = s.eta / sqrt(s.beta);
+    s.sigma = s.eta * sqrt(s.beta);
+  }
+  *st = s;
+}
+
+// Same sum, but of partials other workgroups of THIS launch have just published
+// with agent-scope stores: read them with agent-scope loads (never from L1).
+__device__ double reducePartialsAgent(const double* p, int count, double* scratch) {
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int i = threadIdx.x;
+  for (; i + 3 * kVecThreads < count; i += 4 * kVecThreads) {
+    const double a0 = __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double a1 = __hip_atomic_load(p + i + kVecThreads, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double a2 = __hip_atomic_load(p + i + 2 * kVecThreads, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double a3 = __hip_atomic_load(p + i + 3 * kVecThreads, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+  }
+  for (; i < count; i += kVecThreads) s0 += __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return blockSum<kVecThreads>((s0 + s1) + (s2 + s3), scratch);
+}
+
+// Tail of the A'y kernel when the decision is fused in (single-GPU path): every
+// block publishes its two partials write-through, drains, takes a ticket; the
+// block that draws the last ticket reduces all partials in the fixed order and
+// runs the decision — saving the k_decide launch (MI355X_MICROARCH.md, inter-
+// workgroup visibility: 8-byte agent-scope atomics on both sides + vmcnt drain).
+struct FuseDecide {
+  DevState* st;
+  const double* partDY;  // complete before this launch (kernel boundary)
+  int32_t nDY, nDX;      // nDX = partial slots of the A'y operand (all launches)
+  int32_t expected;      // tickets of THIS launch
+  unsigned int* ticket;  // zeroed by the last block
+};
+__device__ void publishAndMaybeDecide(const FuseDecide& f, double* part0, double* part1, int slot, double t0,
+                                      double t1, double* scratch, double* scratch2) {
+  static_assert(kSpmvThreads == kVecThreads && kSlabThreads == kVecThreads, "block size");
+  // the flag lives in the caller's LDS scratch (no static __shared__ here: it would shift the
+  // 16-byte alignment of the slab kernel's dynamic LDS carve-out)
+  volatile int& isLast = *reinterpret_cast<volatile int*>(scratch2);
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(part0 + slot, t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(part1 + slot, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned int tk = __hip_atomic_fetch_add(f.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    isLast = (tk == (unsigned int)f.expected - 1u) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!isLast) return;
+  const double dY2 = reducePartials(f.partDY, f.nDY, scratch);
+  const double dX2 = reducePartialsAgent(part0, f.nDX, scratch);
+  const double inter = reducePartialsAgent(part1, f.nDX, scratch);
+  if (threadIdx.x == 0) {
+    decideUpdate(f.st, dX2, dY2, inter);
+    __hip_atomic_store(f.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 enum Epilogue { kPlain = 0, kDualStep = 1, kAtyInteract = 2, kAtyPartial = 3 };
 
 struct SpmvArgs {
@@ -61,6 +170,7 @@ struct SpmvArgs {
   IterVecs v;
   double* part0;  // dY^2 (dual) | dX^2 (aty)
   double* part1;  // interaction (aty)
+  FuseDecide fuse;  // fuse.st != nullptr: the A'y kernel also takes the step-size decision
 };
 
 // CSR-adaptive SpMV (stream + long-row paths) with a fused, major-local epilogue.
@@ -211,7 +321,8 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
   } else if (EPI == kAtyInteract) {
     const double t0 = blockSum<kSpmvThreads>(acc0, scratch[0]);
     const double t1 = blockSum<kSpmvThreads>(acc1, scratch[1]);
-    if (tid == 0) { a.part0[a.A.partOffset + blk] = t0; a.part1[a.A.partOffset + blk] = t1; }
+    if (a.fuse.st) publishAndMaybeDecide(a.fuse, a.part0, a.part1, a.A.partOffset + blk, t0, t1, scratch[0], scratch[1]);
+    else if (tid == 0) { a.part0[a.A.partOffset + blk] = t0; a.part1[a.A.partOffset + blk] = t1; }
   }
 }
 
@@ -314,8 +425,7 @@ __global__ __launch_bounds__(kSlabThreads, 8) void k_spmv_slab(const SpmvArgs a)
     for (int g = 0; g < kGroup; ++g) xg[g] = in[gatherIdx(w[g], en[g])];
 #pragma unroll
     for (int g = 0; g < kGroup; ++g) {
-      constexpr int kBufMask = 1;
-      const int buf = g & kBufMask;
+      const int buf = (wg - wBeg + g) & 1;  // alternate LDS staging buffers window by window
       const bool valid = tid < w[g].cnt;
       const uint32_t lrow = en[g] >> 16;
       const double prod = vv[g] * xg[g];
@@ -369,7 +479,8 @@ __global__ __launch_bounds__(kSlabThreads, 8) void k_spmv_slab(const SpmvArgs a)
   } else if (EPI == kAtyInteract) {
     const double t0 = blockSum<kSlabThreads>(acc0, scratch[0]);
     const double t1 = blockSum<kSlabThreads>(acc1, scratch[1]);
-    if (tid == 0) { a.part0[blk] = t0; a.part1[blk] = t1; }
+    if (a.fuse.st) publishAndMaybeDecide(a.fuse, a.part0, a.part1, blk, t0, t1, scratch[0], scratch[1]);
+    else if (tid == 0) { a.part0[blk] = t0; a.part1[blk] = t1; }
   }
 }
 
@@ -417,18 +528,6 @@ __global__ __launch_bounds__(kVecThreads) void k_interact(const IterVecs v, cons
   if (threadIdx.x == 0) { partDX[blockIdx.x] = t0; partInter[blockIdx.x] = t1; }
 }
 
-// Fixed-order sum of `count` partials by one block of 256 threads (4 loads in flight per lane).
-__device__ double reducePartials(const double* __restrict__ p, int count, double* scratch) {
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  int i = threadIdx.x;
-  for (; i + 3 * kVecThreads < count; i += 4 * kVecThreads) {
-    const double a0 = p[i], a1 = p[i + kVecThreads], a2 = p[i + 2 * kVecThreads], a3 = p[i + 3 * kVecThreads];
-    s0 += a0; s1 += a1; s2 += a2; s3 += a3;
-  }
-  for (; i < count; i += kVecThreads) s0 += p[i];
-  return blockSum<kVecThreads>((s0 + s1) + (s2 + s3), scratch);
-}
-
 __global__ __launch_bounds__(kVecThreads) void k_reduce_to(const double* partials, int count, double* out,
                                                            const DevState* st) {
   if (st && st->halted) return;
@@ -437,9 +536,8 @@ __global__ __launch_bounds__(kVecThreads) void k_reduce_to(const double* partial
   if (threadIdx.x == 0) *out = s;
 }
 
-// Accept/reject and step-size update of PDHG_Update_Iterate_Adaptive_Step_Size
-// (cupdlp_step.c:237-306), the bookkeeping of PDHG_Update_Average (:433-441)
-// and the parity flip that the reference gets from ++nIter.
+// k_decide: stand-alone decision kernel (sharded path, or when the decision is not
+// fused into the A'y kernel).
 __global__ __launch_bounds__(kVecThreads) void k_decide(DevState* st, const double* partDY, int nDY,
                                                         const double* partDX, const double* partInter, int nDX,
                                                         const double* dyGlobal) {
@@ -449,46 +547,7 @@ __global__ __launch_bounds__(kVecThreads) void k_decide(DevState* st, const doub
   const double dX2 = reducePartials(partDX, nDX, scratch);
   const double inter = reducePartials(partInter, nDX, scratch);
   if (threadIdx.x != 0) return;
-  const double dY2 = dyGlobal ? *dyGlobal : dY2loc;
-  DevState s = *st;
-  const double sb = sqrt(s.beta);
-  const double movement = dX2 * 0.5 * sb + dY2 / (2.0 * sb);
-  s.nTrials += 1;
-  bool accept = true;
-  double etaNew = s.eta;
-  double limit = INFINITY;
-  if (s.adaptive) {
-    limit = (inter != 0.0) ? movement / fabs(inter) : INFINITY;
-    accept = s.eta <= limit;
-    const double k1 = (double)s.nTrials + 1.0;
-    const double first = (1.0 - pow(k1, -0.3)) * limit;   // PDHG_STEPSIZE_REDUCTION_EXP
-    const double second = (1.0 + pow(k1, -0.6)) * s.eta;  // PDHG_STEPSIZE_GROWTH_EXP
-    etaNew = fmin(first, second);
-  }
-  s.dX2 = dX2; s.dY2 = dY2; s.inter = inter; s.movement = movement; s.limit = limit;
-  s.lastAccepted = accept ? 1 : 0;
-  if (accept) {
-    if (s.adaptive) {
-      s.primalStep = etaNew / sqrt(s.beta);
-      s.dualStep = etaNew * sqrt(s.beta);
-    }
-    const double w = sqrt(s.primalStep * s.dualStep);  // uses the NEXT step sizes (step.c:433)
-    s.sumPrimalStep += w;
-    s.sumDualStep += w;
-    s.avgW = w;
-    s.cur ^= 1;
-    s.nIter += 1;
-    s.eta = w;  // next iteration starts from sqrt(primalStep*dualStep) (step.c:231)
-    if (s.nIter >= s.haltIter) s.halted = 1;
-  } else {
-    s.eta = etaNew;
-    s.avgW = 0.0;
-  }
-  if (s.adaptive) {
-    s.tau = s.eta / sqrt(s.beta);
-    s.sigma = s.eta * sqrt(s.beta);
-  }
-  *st = s;
+  decideUpdate(st, dX2, dyGlobal ? *dyGlobal : dY2loc, inter);
 }
 
 // Apply a pending average update (before a check iteration reads xSum/ySum).
@@ -696,6 +755,27 @@ void launchSpmvAtyInteract(const MatView& At, const IterVecs& v, const DevState*
   SpmvArgs a{};
   a.st = st; a.v = v; a.part0 = partDX; a.part1 = partInter;
   launchSpmv<kAtyInteract>(At, a, s);
+}
+void launchSpmvAtyInteractDecide(const MatView& At, const IterVecs& v, DevState* st, const double* partDY,
+                                 int32_t nDY, double* partDX, double* partInter, unsigned int* ticket,
+                                 hipStream_t s) {
+  SpmvArgs a{};
+  a.st = st; a.v = v; a.part0 = partDX; a.part1 = partInter;
+  // the decision rides on the LAST launch of the operand (slab launch first, CSR side launch second)
+  const bool twoLaunches = At.useSlab && At.slab.nBlocks > 0 && At.csr.nBlocks > 0;
+  if (twoLaunches) {
+    MatView first = At;
+    first.csr.nBlocks = 0;
+    launchSpmv<kAtyInteract>(first, a, s);
+    MatView second = At;
+    second.useSlab = 0;
+    a.fuse = FuseDecide{st, partDY, nDY, At.nPartials, At.csr.nBlocks, ticket};
+    launchSpmv<kAtyInteract>(second, a, s);
+  } else {
+    const int32_t expected = (At.useSlab && At.slab.nBlocks > 0) ? At.slab.nBlocks : At.csr.nBlocks;
+    a.fuse = FuseDecide{st, partDY, nDY, At.nPartials, expected, ticket};
+    launchSpmv<kAtyInteract>(At, a, s);
+  }
 }
 void launchSpmvAtyPartial(const MatView& At, const IterVecs& v, const DevState* st, double* out, hipStream_t s) {
   SpmvArgs a{};

@@ -95,6 +95,10 @@ void launchSpmvAxDual(const MatView& A, const IterVecs& v, const DevState* st, d
 // aty_next = A' y_next fused with movement/interaction partials
 void launchSpmvAtyInteract(const MatView& At, const IterVecs& v, const DevState* st, double* partDX,
                            double* partInter, hipStream_t s);
+// same, with the accept/reject decision fused into the last-finishing block (saves the k_decide launch)
+void launchSpmvAtyInteractDecide(const MatView& At, const IterVecs& v, DevState* st, const double* partDY,
+                                 int32_t nDY, double* partDX, double* partInter, unsigned int* ticket,
+                                 hipStream_t s);
 // sharded variant: partial A_g' y_next into out[n] (no epilogue)
 void launchSpmvAtyPartial(const MatView& At, const IterVecs& v, const DevState* st, double* out, hipStream_t s);
 // sharded: aty_next = reduced; movement/interaction partials
