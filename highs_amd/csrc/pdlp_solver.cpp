@@ -170,6 +170,7 @@ Solver::Solver(const pdlp_problem_t& P, const pdlp_params_t& opt, int32_t rank, 
 
 Solver::~Solver() {
   if (graphExec_) (void)hipGraphExecDestroy(graphExec_);
+  for (hipEvent_t e : profEvents_) (void)hipEventDestroy(e);
   if (hostState_) (void)hipHostFree(hostState_);
   if (hostStats_) (void)hipHostFree(hostStats_);
   delete comm_;
@@ -358,8 +359,40 @@ void Solver::reset() {
 
 // ---- the hot loop --------------------------------------------------------------
 // One trial step of cupdlp_step.c:241-257 (+ the decision, on the device).
+void Solver::profCollect(int32_t realTrials) {
+  // events of trials queued after the device halted time no-op kernels: only the first realTrials count
+  for (int32_t t = 0; t < profTrialsQueued_ && t < realTrials; ++t) {
+    float a = 0.f, b = 0.f, z = 0.f;
+    PDLP_HIP(hipEventElapsedTime(&a, profEvents_[4 * t], profEvents_[4 * t + 1]));
+    PDLP_HIP(hipEventElapsedTime(&b, profEvents_[4 * t + 1], profEvents_[4 * t + 2]));
+    PDLP_HIP(hipEventElapsedTime(&z, profEvents_[4 * t + 2], profEvents_[4 * t + 3]));  // empty interval
+    profAxMs_ += a - z;  // event-to-event time minus the cost of the event pair itself
+    profAtyMs_ += b - z;
+    ++profLaunches_;
+  }
+  profTrialsQueued_ = 0;
+}
+
 void Solver::enqueueTrial() {
   launchPrimalStep(vecs_, dState_.get(), stream_);
+  hipEvent_t* ev = nullptr;
+  if (profile_ && !sharded_) {
+    while ((int32_t)profEvents_.size() < 4 * (profTrialsQueued_ + 1)) {
+      hipEvent_t e;
+      PDLP_HIP(hipEventCreate(&e));
+      profEvents_.push_back(e);
+    }
+    ev = &profEvents_[4 * profTrialsQueued_++];
+    PDLP_HIP(hipEventRecord(ev[0], stream_));
+    launchSpmvAxDual(dA_.view(), vecs_, dState_.get(), partDY_.get(), stream_);
+    PDLP_HIP(hipEventRecord(ev[1], stream_));
+    launchSpmvAtyInteract(dAt_.view(), vecs_, dState_.get(), partDX_.get(), partInter_.get(), stream_);
+    PDLP_HIP(hipEventRecord(ev[2], stream_));
+    PDLP_HIP(hipEventRecord(ev[3], stream_));
+    launchDecide(dState_.get(), partDY_.get(), dA_.nPartials(), partDX_.get(), partInter_.get(), dAt_.nPartials(),
+                 nullptr, stream_);
+    return;
+  }
   launchSpmvAxDual(dA_.view(), vecs_, dState_.get(), partDY_.get(), stream_);
   if (!sharded_ && fuseDecide_ && dAt_.nPartials() > 0) {
     launchSpmvAtyInteractDecide(dAt_.view(), vecs_, dState_.get(), partDY_.get(), dA_.nPartials(), partDX_.get(),
@@ -387,7 +420,8 @@ void Solver::runUntilHalt() {
     if (remaining < 1) remaining = 1;
     if (remaining > 4 * kCheckInterval) remaining = 4 * kCheckInterval;
     int32_t todo = (int32_t)remaining;
-    if (useGraph_ && !sharded_ && todo >= kGraphTrials) {
+    const int32_t trialsBefore = hostState_->nTrials;
+    if (useGraph_ && !profile_ && !sharded_ && todo >= kGraphTrials) {
       if (!graphExec_) {
         hipGraph_t graph = nullptr;
         PDLP_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
@@ -404,6 +438,7 @@ void Solver::runUntilHalt() {
     }
     for (int i = 0; i < todo; ++i) enqueueTrial();
     syncState();
+    if (profile_) profCollect(hostState_->nTrials - trialsBefore);
     if (hostState_->halted) return;
     if (elapsed() > opt_.time_limit) return;
   }
@@ -639,6 +674,8 @@ void Solver::run(pdlp_result_t* R) {
 
 void Solver::iterate(int32_t nIters, pdlp_iter_stats_t* st) {
   syncState();
+  profAxMs_ = profAtyMs_ = 0.0;
+  profLaunches_ = 0;
   const int32_t it0 = hostState_->nIter, tr0 = hostState_->nTrials, ck0 = nChecks_, rs0 = nRestarts_;
   solveBeg_ = std::chrono::steady_clock::now();
   const double savedLimit = opt_.time_limit;
@@ -663,6 +700,11 @@ void Solver::iterate(int32_t nIters, pdlp_iter_stats_t* st) {
     st->restarts = nRestarts_ - rs0;
     st->gpu_ms = ms;
     st->wall_ms = elapsed() * 1e3;
+    if (profLaunches_ > 0) {  // in-loop averages per launch (profile mode)
+      st->spmv_ax_ms = profAxMs_ / (double)profLaunches_;
+      st->spmv_aty_ms = profAtyMs_ / (double)profLaunches_;
+      st->reserved[0] = (double)profLaunches_;
+    }
   }
 }
 
@@ -796,7 +838,9 @@ void Solver::stage(const std::string& name, double* out, int32_t cap) {
   syncState();
   const int c = hostState_->cur;
   auto put = [&](int i, double v) { if (out && i < cap) out[i] = v; };
-  if (name == "ax") {
+  if (name == "profile_on" || name == "profile_off") {
+    profile_ = name == "profile_on";
+  } else if (name == "ax") {
     deviceAx(x_[c].get(), ax_[c].get());
   } else if (name == "aty") {
     deviceATy(y_[c].get(), aty_[c].get());

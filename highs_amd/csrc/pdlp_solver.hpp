@@ -159,6 +159,13 @@ class Solver {
   hipGraphExec_t graphExec_ = nullptr;
   int32_t graphTrials_ = 0;
   bool useGraph_ = true;
+  // in-loop kernel timing (stage "profile_on"): HIP events around the two SpMV launches of every trial
+  bool profile_ = false;
+  std::vector<hipEvent_t> profEvents_;
+  int32_t profTrialsQueued_ = 0;
+  double profAxMs_ = 0, profAtyMs_ = 0;
+  int64_t profLaunches_ = 0;
+  void profCollect(int32_t realTrials);
 };
 
 // RCCL communicator, loaded lazily with dlopen so that the library itself has

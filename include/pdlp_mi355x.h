@@ -193,6 +193,9 @@ int pdlp_mi355x_set_vector(pdlp_mi355x_solver_t* s, const char* name,
  *  "aty"       aty     = A' y           (CSC SpMV,  cupdlp_linalg.c:496 ATy)
  *  "trial"     one trial step with the current step sizes (cupdlp_step.c:241-257)
  *  "residuals" PDHG_Compute_Residuals on current+average (cupdlp_solver.c:473)
+ *  "profile_on" / "profile_off"  bracket the two SpMV launches of every trial with HIP events
+ *              (eager launches, no hipGraph): the next pdlp_mi355x_iterate then reports the
+ *              IN-LOOP average launch durations in spmv_ax_ms / spmv_aty_ms (reserved[0] = launches)
  * scalars_out receives stage-specific scalars, n_scalars its capacity. */
 int pdlp_mi355x_stage(pdlp_mi355x_solver_t* s, const char* stage,
                       double* scalars_out, int32_t n_scalars);
