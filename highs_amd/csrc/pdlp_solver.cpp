@@ -77,6 +77,45 @@ void DeviceMatrix::upload(const Compressed& cIn, int32_t nMajor_, int32_t nMinor
   PDLP_HIP(hipStreamSynchronize(s));  // host vectors may go out of scope
 }
 
+void DeviceMatrix::buildFromDevice(DeviceCsrData& M, int mode, hipStream_t s) {
+  nMajor = M.nMajor;
+  nnz = M.nnz;
+  useSlab = mode == 1 || (mode < 0 && M.nMinor >= kSlabAutoMinor);
+  std::vector<int32_t> hostBeg;
+  int32_t nCsrMajor = nMajor;
+  if (useSlab) {
+    DeviceSlabLayout L;
+    gpuBuildSlabLayout(M, kSlabLongLimit, s, L);
+    if (L.rowsPerBlock > kSlabMaxRows) throw std::runtime_error("slab layout: too many majors per block");
+    winPtr = std::move(L.winPtr);
+    winBeg = std::move(L.winBeg);
+    winInfo = std::move(L.winInfo);
+    ent = std::move(L.ent);
+    slabVal = std::move(L.val);
+    longMask = std::move(L.longMask);
+    slab = SlabMat{winPtr.get(), winBeg.get(), winInfo.get(), ent.get(), slabVal.get(), longMask.get(),
+                   nMajor, L.nBlocks, L.nSlabs, L.rowsPerBlock};
+    beg = std::move(L.longCsr.beg);
+    idx = std::move(L.longCsr.idx);
+    val = std::move(L.longCsr.val);
+    majorMap = std::move(L.longMap);
+    hostBeg = L.hostLongBeg;
+    nCsrMajor = L.nLong;
+  } else {
+    beg = std::move(M.beg);
+    idx = std::move(M.idx);  // allocated with one pad element
+    val = std::move(M.val);
+    hostBeg.resize((size_t)nMajor + 1);
+    beg.download(hostBeg.data(), hostBeg.size(), s);
+    PDLP_HIP(hipStreamSynchronize(s));
+  }
+  StreamPlan plan = planStream(hostBeg, nCsrMajor, kChunk, kMaxMajorsPerBlock);
+  nBlocks = nCsrMajor > 0 ? plan.nBlocks : 0;
+  blockBeg.alloc(plan.blockBeg.size());
+  blockBeg.upload(plan.blockBeg.data(), plan.blockBeg.size(), s);
+  PDLP_HIP(hipStreamSynchronize(s));
+}
+
 MatView DeviceMatrix::view() const {
   MatView v{};
   v.csr = SpmvMat{beg.get(), idx.get(), val.get(), blockBeg.get(), nMajor, nBlocks,
@@ -118,9 +157,34 @@ Solver::Solver(const pdlp_problem_t& P, const pdlp_params_t& opt, int32_t rank, 
   restartOn_ = !(opt_.features_off & PDLP_FEATURE_RESTART_OFF) && opt_.restart_method != 0;
 
   log(1, "Solving with PDLP on MI355X (gfx950, HIP)\n");
-  formulate(P, F_);
-  if (!(opt_.features_off & PDLP_FEATURE_SCALING_OFF)) scale(F_);
-  finalize(F_);
+  const char* fc = getenv("PDLP_MI355X_FORCE_COMM");
+  sharded_ = world_ > 1 || (fc && atoi(fc) != 0);
+  if (const char* g = getenv("PDLP_MI355X_GPU_SETUP")) gpuSetup_ = atoi(g) != 0;
+  if (sharded_) gpuSetup_ = false;  // the row-block shards are cut on the host
+  const bool doScale = !(opt_.features_off & PDLP_FEATURE_SCALING_OFF);
+  DeviceProblem devProb;
+  if (gpuSetup_) {
+    // formulate + scale + both orientations on the device; F_ keeps only the host-side bookkeeping
+    gpuPrepare(P, doScale, stream_, devProb);
+    F_ = StandardForm();
+    F_.n = devProb.n; F_.m = devProb.m; F_.n0 = devProb.n0; F_.nEqs = devProb.nEqs; F_.nnz = devProb.nnz;
+    F_.scaled = devProb.scaled; F_.offset = devProb.offset; F_.sense = devProb.sense;
+    F_.normCost = devProb.normCost; F_.normRhs = devProb.normRhs; F_.matNormInf = devProb.matNormInf;
+    F_.rowKind = std::move(devProb.rowKind);
+    F_.rowNewIdx = std::move(devProb.rowNewIdx);
+    F_.colScale = std::move(devProb.hColScale);
+    F_.rowScale = std::move(devProb.hRowScale);
+    sumCost2_ = devProb.sumCost2;
+    sumRhs2_ = devProb.sumRhs2;
+  } else {
+    formulate(P, F_);
+    if (doScale) scale(F_);
+    finalize(F_);
+    sumCost2_ = 0.0;
+    for (double v : F_.cost) sumCost2_ += v * v;
+    sumRhs2_ = 0.0;
+    for (double v : F_.rhs) sumRhs2_ += v * v;
+  }
   log(1, "Using cost norm = %9.3g and RHS norm = %9.3g\n", F_.normCost, F_.normRhs);
 
   // hot start in formulated+scaled space (PDHG_PreSolve, cupdlp_solver.c:1217-1279)
@@ -145,8 +209,6 @@ Solver::Solver(const pdlp_problem_t& P, const pdlp_params_t& opt, int32_t rank, 
 
   // PDLP_MI355X_FORCE_COMM=1 runs the sharded kernel sequence and the RCCL
   // all-reduce with a single rank (lets a 1-GPU box exercise the multi-GPU path)
-  const char* fc = getenv("PDLP_MI355X_FORCE_COMM");
-  sharded_ = world_ > 1 || (fc && atoi(fc) != 0);
   if (sharded_) {
     std::vector<int32_t> off = rowPartition(F_.csr, F_.m, world_);
     r0_ = off[rank_];
@@ -162,7 +224,8 @@ Solver::Solver(const pdlp_problem_t& P, const pdlp_params_t& opt, int32_t rank, 
     r1_ = F_.m;
   }
   mLoc_ = r1_ - r0_;
-  uploadProblem();
+  if (gpuSetup_) uploadProblemFromDevice(devProb);
+  else uploadProblem();
   reset();
   PDLP_HIP(hipStreamSynchronize(stream_));
   setupSeconds_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -190,22 +253,39 @@ void Solver::uploadProblem() {
     dA_.upload(csrSlab, mLoc_, n, slabMode, stream_);
     dAt_.upload(cscSlab, n, mLoc_, slabMode, stream_);
   }
-  for (int k = 0; k < 2; ++k) {
-    x_[k].alloc(n); y_[k].alloc(mLoc_); ax_[k].alloc(mLoc_); aty_[k].alloc(n);
-    x_[k].zero(stream_); y_[k].zero(stream_); ax_[k].zero(stream_); aty_[k].zero(stream_);
-  }
-  xAvg_.alloc(n); yAvg_.alloc(mLoc_); axAvg_.alloc(mLoc_); atyAvg_.alloc(n);
-  xSum_.alloc(n); ySum_.alloc(mLoc_); xLast_.alloc(n); yLast_.alloc(mLoc_);
   cost_.alloc(n); rhs_.alloc(mLoc_); lower_.alloc(n); upper_.alloc(n); colScale_.alloc(n); rowScale_.alloc(mLoc_);
-  slackPos_.alloc(n); slackNeg_.alloc(n); slackPosAvg_.alloc(n); slackNegAvg_.alloc(n);
-  slackPos_.zero(stream_); slackNeg_.zero(stream_); slackPosAvg_.zero(stream_); slackNegAvg_.zero(stream_);
-  tmpM_.alloc(mLoc_);
   cost_.upload(F_.cost.data(), n, stream_);
   lower_.upload(F_.lower.data(), n, stream_);
   upper_.upload(F_.upper.data(), n, stream_);
   colScale_.upload(F_.colScale.data(), n, stream_);
   rhs_.upload(F_.rhs.data() + r0_, mLoc_, stream_);
   rowScale_.upload(F_.rowScale.data() + r0_, mLoc_, stream_);
+  allocIterates();
+  // the big host copies are not needed any more (postsolve uses only the scale vectors and row maps)
+  F_.csc = Compressed(); F_.csr = Compressed(); F_.cscSorted = Compressed();
+}
+
+void Solver::uploadProblemFromDevice(DeviceProblem& D) {
+  int slabMode = -1;  // auto
+  if (const char* g = getenv("PDLP_MI355X_SLAB")) slabMode = atoi(g);
+  dA_.buildFromDevice(D.A, slabMode, stream_);
+  dAt_.buildFromDevice(D.At, slabMode, stream_);
+  cost_ = std::move(D.cost); rhs_ = std::move(D.rhs); lower_ = std::move(D.lower); upper_ = std::move(D.upper);
+  colScale_ = std::move(D.colScale); rowScale_ = std::move(D.rowScale);
+  allocIterates();
+}
+
+void Solver::allocIterates() {
+  const int32_t n = F_.n;
+  for (int k = 0; k < 2; ++k) {
+    x_[k].alloc(n); y_[k].alloc(mLoc_); ax_[k].alloc(mLoc_); aty_[k].alloc(n);
+    x_[k].zero(stream_); y_[k].zero(stream_); ax_[k].zero(stream_); aty_[k].zero(stream_);
+  }
+  xAvg_.alloc(n); yAvg_.alloc(mLoc_); axAvg_.alloc(mLoc_); atyAvg_.alloc(n);
+  xSum_.alloc(n); ySum_.alloc(mLoc_); xLast_.alloc(n); yLast_.alloc(mLoc_);
+  slackPos_.alloc(n); slackNeg_.alloc(n); slackPosAvg_.alloc(n); slackNegAvg_.alloc(n);
+  slackPos_.zero(stream_); slackNeg_.zero(stream_); slackPosAvg_.zero(stream_); slackNegAvg_.zero(stream_);
+  tmpM_.alloc(mLoc_);
 
   const int32_t nbV = std::max(vecBlocks(n), vecBlocks(std::max(mLoc_, 1)));
   partDY_.alloc(std::max(dA_.nPartials(), 1));
@@ -278,9 +358,7 @@ double Solver::reduceScalar(const double* partials, int32_t nBlocks, bool rowQua
 // are taken on the host with the reference's left-to-right sums.
 void Solver::initStepSizes() {
   DevState& s = *hostState_;
-  double a = 0.0, b = 0.0;
-  for (double v : F_.cost) a += v * v;
-  for (double v : F_.rhs) b += v * v;
+  const double a = sumCost2_, b = sumRhs2_;
   s.beta = (std::fmin(a, b) > 1e-6) ? a / b : 1.0;
   if (adaptive_) {
     s.primalStep = (1.0 / F_.matNormInf) / std::sqrt(s.beta);

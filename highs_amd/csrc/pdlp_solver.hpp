@@ -10,52 +10,12 @@
 #include <string>
 #include <vector>
 
+#include "pdlp_device.hpp"
 #include "pdlp_host.hpp"
 #include "pdlp_kernels.hpp"
+#include "pdlp_setup.hpp"
 
 namespace pdlp {
-
-#define PDLP_HIP(expr)                                                                              \
-  do {                                                                                              \
-    hipError_t e_ = (expr);                                                                         \
-    if (e_ != hipSuccess)                                                                           \
-      throw std::runtime_error(std::string("HIP error ") + hipGetErrorString(e_) + " at " __FILE__ \
-                               ":" + std::to_string(__LINE__) + " in " #expr);                      \
-  } while (0)
-
-template <typename T>
-class DeviceArray {
- public:
-  DeviceArray() = default;
-  DeviceArray(const DeviceArray&) = delete;
-  DeviceArray& operator=(const DeviceArray&) = delete;
-  ~DeviceArray() { release(); }
-  void alloc(size_t count) {
-    release();
-    n_ = count;
-    PDLP_HIP(hipMalloc(&p_, sizeof(T) * (count ? count : 1)));
-  }
-  void release() {
-    if (p_) (void)hipFree(p_);
-    p_ = nullptr;
-    n_ = 0;
-  }
-  void upload(const T* host, size_t count, hipStream_t s) {
-    if (count) PDLP_HIP(hipMemcpyAsync(p_, host, sizeof(T) * count, hipMemcpyHostToDevice, s));
-  }
-  void download(T* host, size_t count, hipStream_t s) const {
-    if (count) PDLP_HIP(hipMemcpyAsync(host, p_, sizeof(T) * count, hipMemcpyDeviceToHost, s));
-  }
-  void zero(hipStream_t s) {
-    if (n_) PDLP_HIP(hipMemsetAsync(p_, 0, sizeof(T) * n_, s));
-  }
-  T* get() const { return p_; }
-  size_t size() const { return n_; }
-
- private:
-  T* p_ = nullptr;
-  size_t n_ = 0;
-};
 
 // One operand matrix in HBM: CSR stream plan, or slab layout + CSR side matrix of long majors.
 struct DeviceMatrix {
@@ -68,6 +28,8 @@ struct DeviceMatrix {
   SlabMat slab{};
   // mode: 0 = CSR stream only, 1 = slab layout (+ long-major side CSR), -1 = auto by nMinor
   void upload(const Compressed& c, int32_t nMajor_, int32_t nMinor_, int mode, hipStream_t s);
+  // same, from a matrix that is already in HBM (GPU-side setup); takes M's arrays
+  void buildFromDevice(DeviceCsrData& M, int mode, hipStream_t s);
   MatView view() const;
   int32_t nPartials() const { return (useSlab ? slab.nBlocks : 0) + nBlocks; }
 };
@@ -98,6 +60,8 @@ class Solver {
  private:
   // setup
   void uploadProblem();
+  void uploadProblemFromDevice(DeviceProblem& D);
+  void allocIterates();
   void initStepSizes();
   void initVariables();
   void applyHotStart();
@@ -130,6 +94,8 @@ class Solver {
   // sharding
   int32_t rank_ = 0, world_ = 1, r0_ = 0, r1_ = 0, mLoc_ = 0;
   Comm* comm_ = nullptr;
+  bool gpuSetup_ = true;   // formulate/scale/transpose/slab layout on the device (pdlp_setup.hip)
+  double sumCost2_ = 0, sumRhs2_ = 0;  // left-to-right sums of the scaled c, b
   bool sharded_ = false;  // row-block sharded kernel sequence + RCCL (world > 1, or forced for testing)
   // device
   hipStream_t stream_ = nullptr;

@@ -348,3 +348,72 @@ def test_fused_decision_large_grid_bit_identical(monkeypatch):
     assert out[0][0] == out[1][0]
     assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
     assert np.array_equal(out[0][3], out[1][3])
+
+
+@pytest.mark.parametrize("name", ["25fv47", "shell", "boxed_row", "restart_lp", "synthetic"])
+@pytest.mark.parametrize("features_off", [0, 1])
+def test_gpu_setup_bit_identical_to_host_setup(name, features_off):
+    """Formulate + Ruiz/Pock-Chambolle scaling on the device (pdlp_setup.hip) vs the host path (which is
+    bit-identical to the oracle / reference): every prepared vector must agree bit for bit."""
+    sp_ = None
+    if name == "synthetic":
+        sp_ = solver.SyntheticProblem(30000, 25000, 240000, 7)
+        kw = dict(problem_struct=sp_.struct)
+    elif name in L.special_lps():
+        kw = dict(lp=L.special_lps()[name])
+    else:
+        kw = dict(lp=_lp(name))
+    P = solver.Prepared(pdlp_features_off=features_off, **kw)
+    S = solver.DeviceSolver(pdlp_features_off=features_off, **kw)  # GPU-side setup is the default
+    assert (S.n, S.m, S.nnz, S.n_eqs) == (P.n, P.m, P.nnz, P.n_eqs)
+    for nm, ref in [("cost", P.cost), ("rhs", P.rhs), ("lower", P.lower), ("upper", P.upper),
+                    ("col_scale", P.col_scale), ("row_scale", P.row_scale)]:
+        assert np.array_equal(S.get(nm, len(ref)), ref), nm
+    # the matrices: A x and A' y through the device-built layouts, bit-exact vs the host-built CSR/CSC
+    rng = np.random.default_rng(3)
+    x, y = rng.standard_normal(P.n), rng.standard_normal(P.m)
+    S.set("x", x); S.set("y", y); S.stage("ax"); S.stage("aty")
+    assert np.array_equal(S.get("ax", P.m), _spmv(P.csr_beg, P.csr_idx, P.csr_val, x, P.m))
+    assert np.array_equal(S.get("aty", P.n), _spmv(P.csc_beg, P.csc_idx, P.csc_val, y, P.n))
+    S.close()
+
+
+@pytest.mark.parametrize("layout", ["0", "1"])
+def test_gpu_setup_gives_identical_solve(layout, monkeypatch):
+    lp = _lp("e226")
+    monkeypatch.setenv("PDLP_MI355X_SLAB", layout)
+    monkeypatch.setenv("PDLP_MI355X_GPU_SETUP", "0")
+    a = solver.solveLpCupdlp(lp)
+    monkeypatch.setenv("PDLP_MI355X_GPU_SETUP", "1")
+    b = solver.solveLpCupdlp(lp)
+    assert a.pdlp_iteration_count == b.pdlp_iteration_count
+    assert np.array_equal(a.solution.col_value, b.solution.col_value)
+    assert np.array_equal(a.solution.row_dual, b.solution.row_dual)
+    assert a.result.norm_rhs == b.result.norm_rhs and a.result.norm_cost == b.result.norm_cost
+
+
+def test_gpu_setup_long_rows_slab_layout(monkeypatch):
+    """Device-built slab layout with long majors (> 256 nnz) routed to the CSR side kernel."""
+    monkeypatch.setenv("PDLP_MI355X_SLAB", "1")
+    rng = np.random.default_rng(1)
+    n, m = 70000, 60
+    rows, cols, vals = [], [], []
+    for i in range(m):
+        k = {0: 5000, 1: 0, 2: 2049, 3: 1, 4: 300}.get(i, int(rng.integers(0, 30)))
+        c = np.sort(rng.choice(n, size=k, replace=False))
+        rows += [i] * k; cols += list(c); vals += list(rng.standard_normal(k))
+    r_start = np.searchsorted(np.array(rows), np.arange(m + 1))
+    inf = float("inf")
+    lp = L.HighsLp.from_rowwise(n, m, r_start, cols, vals, col_cost=rng.standard_normal(n), col_lower=np.zeros(n),
+                                col_upper=np.ones(n), row_lower=np.full(m, -inf), row_upper=np.ones(m))
+    P = solver.Prepared(lp)
+    S = solver.DeviceSolver(lp)
+    x, y = rng.standard_normal(P.n), rng.standard_normal(P.m)
+    S.set("x", x); S.set("y", y); S.stage("ax"); S.stage("aty")
+    ax_o = _spmv(P.csr_beg, P.csr_idx, P.csr_val, x, P.m)
+    lens = np.diff(P.csr_beg)
+    ax_g = S.get("ax", P.m)
+    assert np.array_equal(ax_g[lens <= 2048], ax_o[lens <= 2048])
+    assert np.allclose(ax_g, ax_o, rtol=1e-13, atol=1e-13)
+    assert np.array_equal(S.get("aty", P.n), _spmv(P.csc_beg, P.csc_idx, P.csc_val, y, P.n))
+    S.close()
