@@ -159,6 +159,10 @@ Solver::Solver(const pdlp_problem_t& P, const pdlp_params_t& opt, int32_t rank, 
   log(1, "Solving with PDLP on MI355X (gfx950, HIP)\n");
   const char* fc = getenv("PDLP_MI355X_FORCE_COMM");
   sharded_ = world_ > 1 || (fc && atoi(fc) != 0);
+  // GPU-side setup pays off once the matrix is big enough to amortise its ~40 launches / syncs;
+  // small LPs are prepared on the host (same bits either way)
+  const int64_t nnzIn = P.num_col > 0 && P.a_start ? (int64_t)P.a_start[P.num_col] : 0;
+  gpuSetup_ = nnzIn >= 200000;
   if (const char* g = getenv("PDLP_MI355X_GPU_SETUP")) gpuSetup_ = atoi(g) != 0;
   if (sharded_) gpuSetup_ = false;  // the row-block shards are cut on the host
   const bool doScale = !(opt_.features_off & PDLP_FEATURE_SCALING_OFF);

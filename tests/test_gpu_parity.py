@@ -352,9 +352,10 @@ def test_fused_decision_large_grid_bit_identical(monkeypatch):
 
 @pytest.mark.parametrize("name", ["25fv47", "shell", "boxed_row", "restart_lp", "synthetic"])
 @pytest.mark.parametrize("features_off", [0, 1])
-def test_gpu_setup_bit_identical_to_host_setup(name, features_off):
+def test_gpu_setup_bit_identical_to_host_setup(name, features_off, monkeypatch):
     """Formulate + Ruiz/Pock-Chambolle scaling on the device (pdlp_setup.hip) vs the host path (which is
     bit-identical to the oracle / reference): every prepared vector must agree bit for bit."""
+    monkeypatch.setenv("PDLP_MI355X_GPU_SETUP", "1")  # force it also for the small LPs
     sp_ = None
     if name == "synthetic":
         sp_ = solver.SyntheticProblem(30000, 25000, 240000, 7)
@@ -395,6 +396,7 @@ def test_gpu_setup_gives_identical_solve(layout, monkeypatch):
 def test_gpu_setup_long_rows_slab_layout(monkeypatch):
     """Device-built slab layout with long majors (> 256 nnz) routed to the CSR side kernel."""
     monkeypatch.setenv("PDLP_MI355X_SLAB", "1")
+    monkeypatch.setenv("PDLP_MI355X_GPU_SETUP", "1")
     rng = np.random.default_rng(1)
     n, m = 70000, 60
     rows, cols, vals = [], [], []
