@@ -539,18 +539,38 @@ __global__ __launch_bounds__(kVecThreads) void k_reduce_to(const double* partial
   if (threadIdx.x == 0) *out = s;
 }
 
-// k_decide: stand-alone decision kernel (sharded path, or when the decision is not
-// fused into the A'y kernel).
-__global__ __launch_bounds__(kVecThreads) void k_decide(DevState* st, const double* partDY, int nDY,
-                                                        const double* partDX, const double* partInter, int nDX,
+// k_decide: the decision kernel (one block).  All partial loads of the three sums are issued
+// together and reduced in one pass — the kernel is pure latency (it sits between two trials).
+__global__ __launch_bounds__(kVecThreads) void k_decide(DevState* st, const double* __restrict__ partDY, int nDY,
+                                                        const double* __restrict__ partDX,
+                                                        const double* __restrict__ partInter, int nDX,
                                                         const double* dyGlobal) {
   if (st->halted) return;
-  __shared__ double scratch[kVecThreads / kWave];
-  const double dY2loc = dyGlobal ? 0.0 : reducePartials(partDY, nDY, scratch);
-  const double dX2 = reducePartials(partDX, nDX, scratch);
-  const double inter = reducePartials(partInter, nDX, scratch);
-  if (threadIdx.x != 0) return;
-  decideUpdate(st, dX2, dyGlobal ? *dyGlobal : dY2loc, inter);
+  __shared__ double scratch[3][kVecThreads / kWave];
+  const int tid = threadIdx.x;
+  // fixed order: lane t sums elements t, t+256, ... (4 independent chains), then wave/LDS tree
+  auto laneSum = [&](const double* __restrict__ p, int count) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int i = tid;
+    for (; i + 3 * kVecThreads < count; i += 4 * kVecThreads) {
+      const double a0 = p[i], a1 = p[i + kVecThreads], a2 = p[i + 2 * kVecThreads], a3 = p[i + 3 * kVecThreads];
+      s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+    }
+    for (; i < count; i += kVecThreads) s0 += p[i];
+    return (s0 + s1) + (s2 + s3);
+  };
+  double vY = dyGlobal ? 0.0 : laneSum(partDY, nDY);
+  double vX = laneSum(partDX, nDX);
+  double vI = laneSum(partInter, nDX);
+  vY = waveSum(vY); vX = waveSum(vX); vI = waveSum(vI);
+  const int lane = tid & (kWave - 1), w = tid / kWave;
+  if (lane == 0) { scratch[0][w] = vY; scratch[1][w] = vX; scratch[2][w] = vI; }
+  __syncthreads();
+  if (tid != 0) return;
+  double dY2 = 0.0, dX2 = 0.0, inter = 0.0;
+#pragma unroll
+  for (int i = 0; i < kVecThreads / kWave; ++i) { dY2 += scratch[0][i]; dX2 += scratch[1][i]; inter += scratch[2][i]; }
+  decideUpdate(st, dX2, dyGlobal ? *dyGlobal : dY2, inter);
 }
 
 // Apply a pending average update (before a check iteration reads xSum/ySum).
