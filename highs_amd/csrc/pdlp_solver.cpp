@@ -130,6 +130,21 @@ double Solver::elapsed() const {
   return std::chrono::duration<double>(std::chrono::steady_clock::now() - solveBeg_).count();
 }
 
+// Every rank must take the same branch (they issue the same collectives): when sharded, the
+// time-limit test is the OR over the ranks' clocks.
+bool Solver::timeIsUp() {
+  bool up = elapsed() > opt_.time_limit;
+  if (!sharded_ || !std::isfinite(opt_.time_limit)) return up;
+  hostStats_[kStatTotal + 1] = up ? 1.0 : 0.0;
+  PDLP_HIP(hipMemcpyAsync(statOut_.get() + kStatTotal + 1, hostStats_ + kStatTotal + 1, sizeof(double),
+                          hipMemcpyHostToDevice, stream_));
+  comm_->allReduceSum(statOut_.get() + kStatTotal + 1, 1, stream_);
+  PDLP_HIP(hipMemcpyAsync(hostStats_ + kStatTotal + 1, statOut_.get() + kStatTotal + 1, sizeof(double),
+                          hipMemcpyDeviceToHost, stream_));
+  PDLP_HIP(hipStreamSynchronize(stream_));
+  return hostStats_[kStatTotal + 1] > 0.0;
+}
+
 void Solver::log(int level, const char* fmt, ...) const {
   if (opt_.log_level < level || rank_ != 0) return;
   va_list ap;
@@ -522,7 +537,7 @@ void Solver::runUntilHalt() {
     syncState();
     if (profile_) profCollect(hostState_->nTrials - trialsBefore);
     if (hostState_->halted) return;
-    if (elapsed() > opt_.time_limit) return;
+    if (timeIsUp()) return;
   }
 }
 
@@ -696,13 +711,14 @@ void Solver::doSolve(bool terminate, int32_t target) {
     const int32_t it = s.nIter;
     if (it >= iterLim) break;
     const double t = elapsed();
+    const bool timeUp = timeIsUp();
     // Every stop of the device is a check iteration of the reference schedule
     // (nIter < 10, nIter % 40 == 0, last iteration, or time limit exceeded).
     computeAverage();
     computeResiduals();
     ++nChecks_;
     if (opt_.log_level > 0 && rank_ == 0) {
-      const bool print = (it % (kCheckInterval * 100) == 0) || it == iterLim - 1 || t > opt_.time_limit;
+      const bool print = (it % (kCheckInterval * 100) == 0) || it == iterLim - 1 || timeUp;
       if (print) {
         if (logSinceHeader >= 50) {
           printf("%9s  %15s  %15s   %8s  %10s  %8s %7s\n", "Iter", "Primal.Obj", "Dual.Obj", "Gap", "Primal.Inf",
@@ -720,7 +736,7 @@ void Solver::doSolve(bool terminate, int32_t target) {
       if (checkTermination(cur_)) { termIterate_ = 0; termCode_ = PDLP_TERM_OPTIMAL; break; }
       if (checkTermination(avg_)) { termIterate_ = 1; termCode_ = PDLP_TERM_OPTIMAL; break; }
       if (checkInfeasibility()) { termCode_ = PDLP_TERM_INFEASIBLE_OR_UNBOUNDED; break; }
-      if (t > opt_.time_limit) { termCode_ = PDLP_TERM_TIMELIMIT_OR_ITERLIMIT; break; }
+      if (timeUp) { termCode_ = PDLP_TERM_TIMELIMIT_OR_ITERLIMIT; break; }
       if (it >= iterLim - 1) { termCode_ = PDLP_TERM_TIMELIMIT_OR_ITERLIMIT; break; }
     }
     restartIterate();

@@ -86,6 +86,7 @@ class Solver {
   std::pair<double*, int64_t> lookup(const std::string& name);
   void log(int level, const char* fmt, ...) const;
   double elapsed() const;
+  bool timeIsUp();  // elapsed() > time_limit, agreed across ranks when sharded (identical control flow)
 
   pdlp_params_t opt_;
   StandardForm F_;

@@ -309,7 +309,7 @@ def test_sharded_kernel_sequence_single_rank(monkeypatch):
     lp = _lp("e226")
     base = solver.solveLpCupdlp(lp)
     monkeypatch.setenv("PDLP_MI355X_FORCE_COMM", "1")
-    sh = solver.solveLpCupdlp(lp)
+    sh = solver.solveLpCupdlp(lp, time_limit=1000.0)  # finite limit: the ranks agree on "time is up" with an all-reduce
     assert sh.model_status == solver.kOptimal
     # x+, y+, A x+, A'y+ are the same values; only the dX^2 / interaction partial sums are grouped
     # differently (vector grid instead of SpMV work blocks), so the trajectories agree to rounding
