@@ -105,58 +105,6 @@ __device__ void decideUpdate(DevState* st, double dX2, double dY2, double inter)
   *st = s;
 }
 
-// Same sum, but of partials other workgroups of THIS launch have just published
-// with agent-scope stores: read them with agent-scope loads (never from L1).
-__device__ double reducePartialsAgent(const double* p, int count, double* scratch) {
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  int i = threadIdx.x;
-  for (; i + 3 * kVecThreads < count; i += 4 * kVecThreads) {
-    const double a0 = __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const double a1 = __hip_atomic_load(p + i + kVecThreads, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const double a2 = __hip_atomic_load(p + i + 2 * kVecThreads, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const double a3 = __hip_atomic_load(p + i + 3 * kVecThreads, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s0 += a0; s1 += a1; s2 += a2; s3 += a3;
-  }
-  for (; i < count; i += kVecThreads) s0 += __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return blockSum<kVecThreads>((s0 + s1) + (s2 + s3), scratch);
-}
-
-// Tail of the A'y kernel when the decision is fused in (single-GPU path): every
-// block publishes its two partials write-through, drains, takes a ticket; the
-// block that draws the last ticket reduces all partials in the fixed order and
-// runs the decision — saving the k_decide launch (MI355X_MICROARCH.md, inter-
-// workgroup visibility: 8-byte agent-scope atomics on both sides + vmcnt drain).
-struct FuseDecide {
-  DevState* st;
-  const double* partDY;  // complete before this launch (kernel boundary)
-  int32_t nDY, nDX;      // nDX = partial slots of the A'y operand (all launches)
-  int32_t expected;      // tickets of THIS launch
-  unsigned int* ticket;  // zeroed by the last block
-};
-__device__ void publishAndMaybeDecide(const FuseDecide& f, double* part0, double* part1, int slot, double t0,
-                                      double t1, double* scratch, double* scratch2) {
-  static_assert(kSpmvThreads == kVecThreads && kSlabThreads == kVecThreads, "block size");
-  // the flag lives in the caller's LDS scratch (no static __shared__ here: it would shift the
-  // 16-byte alignment of the slab kernel's dynamic LDS carve-out)
-  volatile int& isLast = *reinterpret_cast<volatile int*>(scratch2);
-  if (threadIdx.x == 0) {
-    __hip_atomic_store(part0 + slot, t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(part1 + slot, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned int tk = __hip_atomic_fetch_add(f.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    isLast = (tk == (unsigned int)f.expected - 1u) ? 1 : 0;
-  }
-  __syncthreads();
-  if (!isLast) return;
-  const double dY2 = reducePartials(f.partDY, f.nDY, scratch);
-  const double dX2 = reducePartialsAgent(part0, f.nDX, scratch);
-  const double inter = reducePartialsAgent(part1, f.nDX, scratch);
-  if (threadIdx.x == 0) {
-    decideUpdate(f.st, dX2, dY2, inter);
-    __hip_atomic_store(f.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
 enum Epilogue { kPlain = 0, kDualStep = 1, kAtyInteract = 2, kAtyPartial = 3 };
 
 struct SpmvArgs {
@@ -170,7 +118,6 @@ struct SpmvArgs {
   IterVecs v;
   double* part0;  // dY^2 (dual) | dX^2 (aty)
   double* part1;  // interaction (aty)
-  FuseDecide fuse;  // fuse.st != nullptr: the A'y kernel also takes the step-size decision
 };
 
 // CSR-adaptive SpMV (stream + long-row paths) with a fused, major-local epilogue.
@@ -186,12 +133,7 @@ __device__ __forceinline__ T ldUniform(const T* p) {
   return *(const __attribute__((address_space(4))) T*)(p);
 }
 
-template <typename T>
-__device__ __forceinline__ T ldStream(const T* p, bool nt) {
-  return nt ? __builtin_nontemporal_load(p) : *p;
-}
-
-template <int EPI, bool NT, bool MAPPED>
+template <int EPI, bool MAPPED>
 __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
   const DevState* st = a.st;
   if (EPI != kPlain && st->halted) return;
@@ -227,9 +169,9 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
     Pre p{0.0, 0.0, 0.0};
     if (MAPPED) r = a.A.majorMap[r];
     if (EPI == kDualStep) {
-      p.a = ldStream(a.v.y[cur] + r, NT); p.b = ldStream(a.v.rhs + r, NT); p.c = ldStream(a.v.ax[cur] + r, NT);
+      p.a = a.v.y[cur][r]; p.b = a.v.rhs[r]; p.c = a.v.ax[cur][r];
     } else if (EPI == kAtyInteract) {
-      p.a = ldStream(a.v.x[cur] + r, NT); p.b = ldStream(a.v.x[nxt] + r, NT); p.c = ldStream(a.v.aty[cur] + r, NT);
+      p.a = a.v.x[cur][r]; p.b = a.v.x[nxt][r]; p.c = a.v.aty[cur][r];
     }
     return p;
   };
@@ -286,8 +228,8 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
     for (int k = 0; k < kPer; ++k) {
       const int q = tid + k * kSpmvThreads;
       const int qq = q < last ? q : last;
-      ci[k] = ldStream(idx + p0 + qq, NT);
-      va[k] = ldStream(val + p0 + qq, NT);
+      ci[k] = idx[p0 + qq];
+      va[k] = val[p0 + qq];
     }
 #pragma unroll
     for (int k = 0; k < kPer; ++k) xg[k] = in[ci[k]];
@@ -321,8 +263,7 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
   } else if (EPI == kAtyInteract) {
     const double t0 = blockSum<kSpmvThreads>(acc0, scratch[0]);
     const double t1 = blockSum<kSpmvThreads>(acc1, scratch[1]);
-    if (a.fuse.st) publishAndMaybeDecide(a.fuse, a.part0, a.part1, a.A.partOffset + blk, t0, t1, scratch[0], scratch[1]);
-    else if (tid == 0) { a.part0[a.A.partOffset + blk] = t0; a.part1[a.A.partOffset + blk] = t1; }
+    if (tid == 0) { a.part0[a.A.partOffset + blk] = t0; a.part1[a.A.partOffset + blk] = t1; }
   }
 }
 
@@ -335,7 +276,7 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
 // right, onto the major's LDS accumulator.  Because slabs and the minors inside
 // a slab ascend, every major is still summed in ascending minor order — the
 // reference's order — and the result is bit-identical to the CSR path.
-template <int EPI, int kGroup, bool NT>
+template <int EPI>
 __global__ __launch_bounds__(kSlabThreads, 8) void k_spmv_slab(const SpmvArgs a) {
   const DevState* st = a.st;
   if (EPI != kPlain && st->halted) return;
@@ -406,41 +347,27 @@ __global__ __launch_bounds__(kSlabThreads, 8) void k_spmv_slab(const SpmvArgs a)
   auto gatherIdx = [&](const Win& w, uint32_t en) -> size_t {
     return tid < w.cnt ? (((size_t)w.slab << 16) + (en & 0xffffu)) : 0;
   };
-  // Windows are processed in groups of kGroup inside ONE straight-line loop body:
-  // all 2*kGroup entry loads, then all kGroup gathers, are issued up front and each
-  // window then waits only for its own gather (vmcnt(kGroup-1-g)).  (Carrying loads
-  // across the loop back-edge instead makes hipcc insert vmcnt(0) at the loop head,
-  // which serialises the pipeline.)  Windows past the end have cnt = 0: harmless.
-  for (int wg = wBeg; wg < wEnd; wg += kGroup) {
-    Win w[kGroup];
-    uint32_t en[kGroup];
-    double vv[kGroup], xg[kGroup];
-#pragma unroll
-    for (int g = 0; g < kGroup; ++g) {
-      w[g] = getWin(wg + g);
-      en[g] = ldStream(ent + w[g].beg + tid, NT);
-      vv[g] = ldStream(val + w[g].beg + tid, NT);
-    }
-    // Gathers are NOT batched: one window's gather in flight per block keeps all
-    // resident blocks on (nearly) the same slab — measured: batching the gathers of
-    // 2/4/8 windows costs 69/79/86 us vs 54 us, the L2 no longer holds the active slabs.
-    // Only the entry stream (which has no locality to lose) is prefetched kGroup deep.
-#pragma unroll
-    for (int g = 0; g < kGroup; ++g) {
-      xg[g] = in[gatherIdx(w[g], en[g])];
-      const int buf = (wg - wBeg + g) & 1;  // alternate LDS staging buffers window by window
-      const bool valid = tid < w[g].cnt;
-      const uint32_t lrow = en[g] >> 16;
-      const double prod = vv[g] * xg[g];
-      stage[buf][tid] = prod;
-      srow[buf][tid] = valid ? (uint16_t)lrow : (uint16_t)0xffff;
-      __syncthreads();
-      if (valid && (tid == 0 || srow[buf][tid - 1] != (uint16_t)lrow)) {
-        double s = acc[lrow];
-        s += prod;
-        for (int j = tid + 1; j < kSlabThreads && srow[buf][j] == (uint16_t)lrow; ++j) s += stage[buf][j];
-        acc[lrow] = s;
-      }
+  // One window per iteration, nothing carried across iterations: entries -> gather -> LDS.
+  // More memory-level parallelism was measured to HURT: batching the gathers of 2/4/8 windows
+  // (69/79/86 us vs 54 us) or prefetching the entry stream 4/8/12 windows ahead (62/64/67 us)
+  // lets the resident blocks drift over more slabs than the L2 holds.  Locality beats MLP here.
+  for (int wi = wBeg; wi < wEnd; ++wi) {
+    const Win w = getWin(wi);
+    const uint32_t en = ent[w.beg + tid];
+    const double vv = val[w.beg + tid];
+    const double xg = in[gatherIdx(w, en)];
+    const int buf = (wi - wBeg) & 1;  // alternate LDS staging buffers: one barrier per window
+    const bool valid = tid < w.cnt;
+    const uint32_t lrow = en >> 16;
+    const double prod = vv * xg;
+    stage[buf][tid] = prod;
+    srow[buf][tid] = valid ? (uint16_t)lrow : (uint16_t)0xffff;
+    __syncthreads();
+    if (valid && (tid == 0 || srow[buf][tid - 1] != (uint16_t)lrow)) {
+      double s = acc[lrow];
+      s += prod;
+      for (int j = tid + 1; j < kSlabThreads && srow[buf][j] == (uint16_t)lrow; ++j) s += stage[buf][j];
+      acc[lrow] = s;
     }
   }
   __syncthreads();
@@ -482,8 +409,7 @@ __global__ __launch_bounds__(kSlabThreads, 8) void k_spmv_slab(const SpmvArgs a)
   } else if (EPI == kAtyInteract) {
     const double t0 = blockSum<kSlabThreads>(acc0, scratch[0]);
     const double t1 = blockSum<kSlabThreads>(acc1, scratch[1]);
-    if (a.fuse.st) publishAndMaybeDecide(a.fuse, a.part0, a.part1, blk, t0, t1, scratch[0], scratch[1]);
-    else if (tid == 0) { a.part0[blk] = t0; a.part1[blk] = t1; }
+    if (tid == 0) { a.part0[blk] = t0; a.part1[blk] = t1; }
   }
 }
 
@@ -740,11 +666,6 @@ void launchPrimalStep(const IterVecs& v, const DevState* st, hipStream_t s) {
   hipLaunchKernelGGL(k_primal_step, dim3(vecBlocks(v.n)), dim3(kVecThreads), 0, s, v, st);
 }
 
-static bool g_spmvNT = false;
-static int g_slabGroup = 1;
-void setSlabGroup(int g) { g_slabGroup = g; }
-void setSpmvNonTemporal(bool on) { g_spmvNT = on; }
-
 namespace {
 template <int EPI>
 void launchSpmv(const MatView& M, SpmvArgs a, hipStream_t s) {
@@ -752,24 +673,12 @@ void launchSpmv(const MatView& M, SpmvArgs a, hipStream_t s) {
     a.S = M.slab;
     const size_t lds = (size_t)M.slab.rowsPerBlock * 8 + 2 * kSlabThreads * 8 + 2 * (kSlabThreads / kWave) * 8 +
                        2 * kSlabThreads * 2;
-#define PDLP_SLAB_LAUNCH(G)                                                                                   \
-  do {                                                                                                        \
-    if (g_spmvNT) hipLaunchKernelGGL((k_spmv_slab<EPI, G, true>), dim3(M.slab.nBlocks), dim3(kSlabThreads), lds, s, a); \
-    else hipLaunchKernelGGL((k_spmv_slab<EPI, G, false>), dim3(M.slab.nBlocks), dim3(kSlabThreads), lds, s, a);         \
-  } while (0)
-    switch (g_slabGroup) {
-      case 1: PDLP_SLAB_LAUNCH(1); break;
-      case 2: PDLP_SLAB_LAUNCH(2); break;
-      case 4: PDLP_SLAB_LAUNCH(4); break;
-      case 12: PDLP_SLAB_LAUNCH(12); break;
-      default: PDLP_SLAB_LAUNCH(8); break;
-    }
+    hipLaunchKernelGGL((k_spmv_slab<EPI>), dim3(M.slab.nBlocks), dim3(kSlabThreads), lds, s, a);
   }
   if (M.csr.nBlocks > 0) {
     a.A = M.csr;
-    if (M.csr.majorMap) hipLaunchKernelGGL((k_spmv<EPI, false, true>), dim3(M.csr.nBlocks), dim3(kSpmvThreads), 0, s, a);
-    else if (g_spmvNT) hipLaunchKernelGGL((k_spmv<EPI, true, false>), dim3(M.csr.nBlocks), dim3(kSpmvThreads), 0, s, a);
-    else hipLaunchKernelGGL((k_spmv<EPI, false, false>), dim3(M.csr.nBlocks), dim3(kSpmvThreads), 0, s, a);
+    if (M.csr.majorMap) hipLaunchKernelGGL((k_spmv<EPI, true>), dim3(M.csr.nBlocks), dim3(kSpmvThreads), 0, s, a);
+    else hipLaunchKernelGGL((k_spmv<EPI, false>), dim3(M.csr.nBlocks), dim3(kSpmvThreads), 0, s, a);
   }
 }
 }  // namespace
@@ -784,27 +693,6 @@ void launchSpmvAtyInteract(const MatView& At, const IterVecs& v, const DevState*
   SpmvArgs a{};
   a.st = st; a.v = v; a.part0 = partDX; a.part1 = partInter;
   launchSpmv<kAtyInteract>(At, a, s);
-}
-void launchSpmvAtyInteractDecide(const MatView& At, const IterVecs& v, DevState* st, const double* partDY,
-                                 int32_t nDY, double* partDX, double* partInter, unsigned int* ticket,
-                                 hipStream_t s) {
-  SpmvArgs a{};
-  a.st = st; a.v = v; a.part0 = partDX; a.part1 = partInter;
-  // the decision rides on the LAST launch of the operand (slab launch first, CSR side launch second)
-  const bool twoLaunches = At.useSlab && At.slab.nBlocks > 0 && At.csr.nBlocks > 0;
-  if (twoLaunches) {
-    MatView first = At;
-    first.csr.nBlocks = 0;
-    launchSpmv<kAtyInteract>(first, a, s);
-    MatView second = At;
-    second.useSlab = 0;
-    a.fuse = FuseDecide{st, partDY, nDY, At.nPartials, At.csr.nBlocks, ticket};
-    launchSpmv<kAtyInteract>(second, a, s);
-  } else {
-    const int32_t expected = (At.useSlab && At.slab.nBlocks > 0) ? At.slab.nBlocks : At.csr.nBlocks;
-    a.fuse = FuseDecide{st, partDY, nDY, At.nPartials, expected, ticket};
-    launchSpmv<kAtyInteract>(At, a, s);
-  }
 }
 void launchSpmvAtyPartial(const MatView& At, const IterVecs& v, const DevState* st, double* out, hipStream_t s) {
   SpmvArgs a{};

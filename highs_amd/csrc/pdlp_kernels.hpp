@@ -95,10 +95,6 @@ void launchSpmvAxDual(const MatView& A, const IterVecs& v, const DevState* st, d
 // aty_next = A' y_next fused with movement/interaction partials
 void launchSpmvAtyInteract(const MatView& At, const IterVecs& v, const DevState* st, double* partDX,
                            double* partInter, hipStream_t s);
-// same, with the accept/reject decision fused into the last-finishing block (saves the k_decide launch)
-void launchSpmvAtyInteractDecide(const MatView& At, const IterVecs& v, DevState* st, const double* partDY,
-                                 int32_t nDY, double* partDX, double* partInter, unsigned int* ticket,
-                                 hipStream_t s);
 // sharded variant: partial A_g' y_next into out[n] (no epilogue)
 void launchSpmvAtyPartial(const MatView& At, const IterVecs& v, const DevState* st, double* out, hipStream_t s);
 // sharded: aty_next = reduced; movement/interaction partials
@@ -145,8 +141,6 @@ void launchDiffNorm2(const double* a, const double* b, int32_t len, double* part
 // partials of a.b
 void launchDot(const double* a, const double* b, int32_t len, double* partials, int32_t nBlocks, hipStream_t s);
 
-void setSlabGroup(int g);  // windows in flight per block in the slab SpMV (1, 2, 4 or 8)
-void setSpmvNonTemporal(bool on);  // stream idx/val/epilogue operands past L2 (keeps the gathered vector resident)
 int32_t vecBlocks(int32_t len);  // grid size used by the vector/statistics kernels
 
 }  // namespace pdlp

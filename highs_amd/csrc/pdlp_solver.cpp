@@ -164,9 +164,6 @@ Solver::Solver(const pdlp_problem_t& P, const pdlp_params_t& opt, int32_t rank, 
   PDLP_HIP(hipSetDevice(opt_.device));
   PDLP_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
   if (const char* g = getenv("PDLP_MI355X_GRAPH")) useGraph_ = atoi(g) != 0;
-  if (const char* g = getenv("PDLP_MI355X_NT")) setSpmvNonTemporal(atoi(g) != 0);
-  if (const char* g = getenv("PDLP_MI355X_FUSE_DECIDE")) fuseDecide_ = atoi(g) != 0;
-  if (const char* g = getenv("PDLP_MI355X_SLAB_GROUP")) setSlabGroup(atoi(g));
 
   adaptive_ = !(opt_.features_off & PDLP_FEATURE_ADAPTIVE_STEP_OFF);
   restartOn_ = !(opt_.features_off & PDLP_FEATURE_RESTART_OFF) && opt_.restart_method != 0;
@@ -316,8 +313,6 @@ void Solver::allocIterates() {
   commBuf_.alloc((size_t)n + 8);
   commBuf_.zero(stream_);
   dState_.alloc(1);
-  ticket_.alloc(4);
-  ticket_.zero(stream_);
   PDLP_HIP(hipHostMalloc((void**)&hostState_, sizeof(DevState), hipHostMallocDefault));
   PDLP_HIP(hipHostMalloc((void**)&hostStats_, sizeof(double) * (kStatTotal + 8), hipHostMallocDefault));
   memset(hostState_, 0, sizeof(DevState));
@@ -491,10 +486,7 @@ void Solver::enqueueTrial() {
     return;
   }
   launchSpmvAxDual(dA_.view(), vecs_, dState_.get(), partDY_.get(), stream_);
-  if (!sharded_ && fuseDecide_ && dAt_.nPartials() > 0) {
-    launchSpmvAtyInteractDecide(dAt_.view(), vecs_, dState_.get(), partDY_.get(), dA_.nPartials(), partDX_.get(),
-                                partInter_.get(), ticket_.get(), stream_);
-  } else if (!sharded_) {
+  if (!sharded_) {
     launchSpmvAtyInteract(dAt_.view(), vecs_, dState_.get(), partDX_.get(), partInter_.get(), stream_);
     launchDecide(dState_.get(), partDY_.get(), dA_.nPartials(), partDX_.get(), partInter_.get(), dAt_.nPartials(),
                  nullptr, stream_);

@@ -107,8 +107,6 @@ class Solver {
   DeviceArray<double> slackPos_, slackNeg_, slackPosAvg_, slackNegAvg_;
   DeviceArray<double> partDY_, partDX_, partInter_, statPart_, statOut_, commBuf_, tmpM_;
   DeviceArray<DevState> dState_;
-  DeviceArray<unsigned int> ticket_;  // arrival counter of the fused decision
-  bool fuseDecide_ = false;  // measured slower than the separate 1-block kernel (177 vs 170 us per trial at 1M)
   DevState* hostState_ = nullptr;  // pinned mirror
   double* hostStats_ = nullptr;    // pinned
   int32_t statStride_ = 0;

@@ -319,37 +319,6 @@ def test_sharded_kernel_sequence_single_rank(monkeypatch):
     assert sh.result.primal_feas < 1e-7 * (1 + sh.result.norm_rhs) and sh.result.rel_gap < 1e-7
 
 
-@pytest.mark.parametrize("name,layout", [("25fv47", "0"), ("e226", "1")])
-def test_fused_decision_is_bit_identical_to_separate_kernel(name, layout, monkeypatch):
-    """The accept/reject decision taken by the last-arriving block of the A'y kernel (agent-scope
-    publish / ticket / acquire) must reproduce the stand-alone k_decide bit for bit over a whole solve:
-    any stale partial would change a step size and with it every later iterate."""
-    lp = _lp(name)
-    monkeypatch.setenv("PDLP_MI355X_SLAB", layout)
-    monkeypatch.setenv("PDLP_MI355X_FUSE_DECIDE", "0")
-    a = solver.solveLpCupdlp(lp)
-    monkeypatch.setenv("PDLP_MI355X_FUSE_DECIDE", "1")
-    b = solver.solveLpCupdlp(lp)
-    assert a.pdlp_iteration_count == b.pdlp_iteration_count and a.result.num_trials == b.result.num_trials
-    assert np.array_equal(a.solution.col_value, b.solution.col_value)
-    assert np.array_equal(a.solution.row_dual, b.solution.row_dual)
-
-
-def test_fused_decision_large_grid_bit_identical(monkeypatch):
-    """Same check with ~2000 publishing workgroups spread over all 8 XCDs (1M x 1M LP, 300 iterations)."""
-    sp_ = solver.SyntheticProblem(1000000, 1000000, 8000000, 1)
-    out = []
-    for fuse in ("0", "1"):
-        monkeypatch.setenv("PDLP_MI355X_FUSE_DECIDE", fuse)
-        S = solver.DeviceSolver(problem_struct=sp_.struct, kkt_tolerance=1e-4)
-        st = S.iterate(300)
-        out.append((st.trials, S.get("x", S.n), S.get("y", S.m), S.get("steps", 8)))
-        S.close()
-    assert out[0][0] == out[1][0]
-    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
-    assert np.array_equal(out[0][3], out[1][3])
-
-
 @pytest.mark.parametrize("name", ["25fv47", "shell", "boxed_row", "restart_lp", "synthetic"])
 @pytest.mark.parametrize("features_off", [0, 1])
 def test_gpu_setup_bit_identical_to_host_setup(name, features_off, monkeypatch):
