@@ -13,7 +13,7 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 REF = json.load(open(os.path.join(GOLD, "reference_pdlp.json")))
 SPECIAL = json.load(open(os.path.join(GOLD, "special_lps.json")))
 FAST = ["afiro", "adlittle", "avgas", "blending", "chip", "sctest", "standata", "standgub", "e226", "shell"]
-SLOW = ["25fv47", "scrs8", "stair"]
+SLOW = ["25fv47", "scrs8", "stair", "80bau3b"]
 
 
 def test_distillation_iteration_counts_pinned():
@@ -58,7 +58,8 @@ def test_instances_match_reference_binary_and_core(name):
         assert r.num_iter == g["highs"]["pdlp_iterations"]
         assert abs(obj - g["highs"]["objective_value"]) <= 1e-9 * max(1.0, abs(obj))
     # ctest's CPU objective prefix (check/CMakeLists.txt:321-335)
-    assert ("%.10e" % obj).replace("e+0", "e").startswith(g["ctest_cpu_prefix"][:6])
+    if g["ctest_cpu_prefix"]:
+        assert ("%.10e" % obj).replace("e+0", "e").startswith(g["ctest_cpu_prefix"][:6])
 
 
 def test_hot_start_matches_reference_core():
