@@ -149,6 +149,9 @@ def default_params(**kw):
             p.iter_limit = int(min(v, 2**31 - 1))
         elif k == "pdlp_features_off":
             p.features_off = int(v)
+        elif k == "device_reduction_order":
+            # ORACLE ONLY: sum the reductions in the HIP kernels' order (oracle/pdlp_oracle.c, GPU-ORDER)
+            p.reserved[0] = 1 if v else 0
         else:
             setattr(p, k, v)
     return p

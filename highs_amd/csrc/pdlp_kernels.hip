@@ -75,8 +75,12 @@ __device__ void decideUpdate(DevState* st, double dX2, double dY2, double inter)
     limit = (inter != 0.0) ? movement / fabs(inter) : INFINITY;
     accept = s.eta <= limit;
     const double k1 = (double)s.nTrials + 1.0;
-    const double first = (1.0 - pow(k1, -0.3)) * limit;   // PDHG_STEPSIZE_REDUCTION_EXP
-    const double second = (1.0 + pow(k1, -0.6)) * s.eta;  // PDHG_STEPSIZE_GROWTH_EXP
+    const int ti = s.nTrials - s.powBase;
+    const bool tab = s.powRed != nullptr && ti >= 0 && ti < s.powCount;
+    const double pRed = tab ? s.powRed[ti] : pow(k1, -0.3);    // PDHG_STEPSIZE_REDUCTION_EXP
+    const double pGrow = tab ? s.powGrow[ti] : pow(k1, -0.6);  // PDHG_STEPSIZE_GROWTH_EXP
+    const double first = (1.0 - pRed) * limit;
+    const double second = (1.0 + pGrow) * s.eta;
     etaNew = fmin(first, second);
   }
   s.dX2 = dX2; s.dY2 = dY2; s.inter = inter; s.movement = movement; s.limit = limit;

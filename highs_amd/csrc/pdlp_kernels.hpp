@@ -35,7 +35,13 @@ struct DevState {
   int32_t haltIter;      // next iteration at which the host must run a check
   int32_t adaptive;      // PDHG_ADAPTIVE_LINESEARCH (1) or fixed step (0)
   int32_t lastAccepted;
+  // (k+1)^-0.3 and (k+1)^-0.6 for the next trial counters k = powBase .. powBase+powCount-1,
+  // tabulated by the host (glibc pow) so that the step-size update is bit-reproducible on the CPU
+  int32_t powBase;
+  int32_t powCount;
   int32_t pad_;
+  const double* powRed;
+  const double* powGrow;
 };
 
 struct SpmvMat {

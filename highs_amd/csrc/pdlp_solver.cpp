@@ -338,7 +338,32 @@ void Solver::syncState() {
   PDLP_HIP(hipMemcpyAsync(hostState_, dState_.get(), sizeof(DevState), hipMemcpyDeviceToHost, stream_));
   PDLP_HIP(hipStreamSynchronize(stream_));
 }
+// (k+1)^-0.3 and (k+1)^-0.6 of the adaptive step rule (cupdlp_step.c:279-284) for the next
+// kPowWindow trial counters, computed with the host's pow so that the device takes exactly the
+// CPU's values (the oracle can then follow a GPU solve bit for bit).
+void Solver::refreshPowTable() {
+  constexpr int32_t kPowWindow = 4096, kPowMargin = 1024;
+  DevState& s = *hostState_;
+  if (s.powRed && s.nTrials >= s.powBase && s.nTrials + kPowMargin < s.powBase + s.powCount) return;
+  if (powRed_.size() == 0) { powRed_.alloc(kPowWindow); powGrow_.alloc(kPowWindow); }
+  std::vector<double> a(kPowWindow), b(kPowWindow);
+  // entry i serves the trial that raises nTrials to powBase + i
+  for (int32_t i = 0; i < kPowWindow; ++i) {
+    const double k1 = (double)(s.nTrials + i) + 1.0;
+    a[i] = std::pow(k1, -0.3);
+    b[i] = std::pow(k1, -0.6);
+  }
+  powRed_.upload(a.data(), kPowWindow, stream_);
+  powGrow_.upload(b.data(), kPowWindow, stream_);
+  PDLP_HIP(hipStreamSynchronize(stream_));
+  s.powBase = s.nTrials;
+  s.powCount = kPowWindow;
+  s.powRed = powRed_.get();
+  s.powGrow = powGrow_.get();
+}
+
 void Solver::pushState() {
+  refreshPowTable();
   PDLP_HIP(hipMemcpyAsync(dState_.get(), hostState_, sizeof(DevState), hipMemcpyHostToDevice, stream_));
   PDLP_HIP(hipStreamSynchronize(stream_));
 }
@@ -856,7 +881,7 @@ void Solver::postsolve(pdlp_result_t* R) {
   R->term_code = termCode_;
   R->term_iterate = termIterate_;
   R->num_iter = hostState_->nIter;
-  R->num_trials = hostState_->nTrials;
+  R->num_trials = adaptive_ ? hostState_->nTrials : 0;  // nStepSizeIter only counts adaptive trials (cupdlp_step.c:238)
   R->num_restarts = nRestarts_;
   R->primal_obj = r.pObj; R->dual_obj = r.dObj; R->primal_feas = r.pFeas; R->dual_feas = r.dFeas;
   R->rel_gap = r.relGap; R->norm_rhs = F_.normRhs; R->norm_cost = F_.normCost;

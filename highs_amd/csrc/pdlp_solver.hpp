@@ -107,6 +107,8 @@ class Solver {
   DeviceArray<double> slackPos_, slackNeg_, slackPosAvg_, slackNegAvg_;
   DeviceArray<double> partDY_, partDX_, partInter_, statPart_, statOut_, commBuf_, tmpM_;
   DeviceArray<DevState> dState_;
+  DeviceArray<double> powRed_, powGrow_;  // host-tabulated powers of the trial counter (see DevState)
+  void refreshPowTable();
   DevState* hostState_ = nullptr;  // pinned mirror
   double* hostStats_ = nullptr;    // pinned
   int32_t statStride_ = 0;

@@ -115,6 +115,12 @@ typedef struct {
   /* counters */
   int nIter, iLastRestartIter, nRestarts;
   double solveBeg, solveTime;
+  /* optional "device reduction order" mode (see the GPU-ORDER section below) */
+  int gpuOrder;
+  int *cssBeg, *cssIdx; /* A' by columns with ascending row index (what the device streams for A'y) */
+  double* cssVal;
+  int *planA, nPlanA, *planAt, nPlanAt; /* CSR-adaptive work plans, identical to the product's */
+  double *gPartA, *gPartB, *gStat;
 } Work;
 
 static double* dalloc(long n) { return (double*)calloc((size_t)(n > 0 ? n : 1), sizeof(double)); }
@@ -131,6 +137,8 @@ static void work_free(Work* w) {
   free(w->xSum); free(w->ySum); free(w->xLast); free(w->yLast);
   free(w->slackPos); free(w->slackNeg); free(w->slackPosAvg); free(w->slackNegAvg);
   free(w->bufN); free(w->bufN2); free(w->bufM); free(w->bufMax2); free(w->bufMax3);
+  free(w->cssBeg); free(w->cssIdx); free(w->cssVal); free(w->planA); free(w->planAt);
+  free(w->gPartA); free(w->gPartB); free(w->gStat);
 }
 
 /* ------------------------------------------------------------------ */
@@ -290,7 +298,9 @@ static void build_csr(Work* w) {
 /* AxCPU linalg.c:35-71 scatters CSC columns in ascending j, so ax[i] is the
  * left-to-right sum over ascending column index — identical to a row gather
  * over the ascending-column CSR built above. */
+static void g_spmv(const int* beg, const int* idx, const double* val, int nMajor, const double* in, double* out);
 static void o_Ax(const Work* w, double* ax, const double* x) {
+  if (w->gpuOrder) { g_spmv(w->csrBeg, w->csrIdx, w->csrVal, w->m, x, ax); return; }
   for (int i = 0; i < w->m; ++i) {
     double s = 0.0;
     for (int p = w->csrBeg[i]; p < w->csrBeg[i + 1]; ++p) s += w->csrVal[p] * x[w->csrIdx[p]];
@@ -301,12 +311,230 @@ static void o_Ax(const Work* w, double* ax, const double* x) {
  * over ascending (permuted) row index.  The CSC column of the formulated
  * matrix is NOT sorted by row (EQ/BOUND entries first), so do the scatter. */
 static void o_ATy(const Work* w, double* aty, const double* y) {
+  if (w->gpuOrder) { g_spmv(w->cssBeg, w->cssIdx, w->cssVal, w->n, y, aty); return; }
   memset(aty, 0, sizeof(double) * (size_t)w->n);
   for (int i = 0; i < w->m; ++i) {
     const double yi = y[i];
     for (int p = w->csrBeg[i]; p < w->csrBeg[i + 1]; ++p) aty[w->csrIdx[p]] += w->csrVal[p] * yi;
   }
 }
+
+
+/* ------------------------------------------------------------------ */
+/* GPU-ORDER mode (opt->reserved[0] == 1)                              */
+/*                                                                    */
+/* The HIP path computes x+, y+, A x+, A' y+ bit-identically to the    */
+/* serial loops above; the ONLY arithmetic difference is the summation */
+/* order of its reductions (per-lane strided accumulation, 64-lane     */
+/* shuffle tree, fixed-order sum of 4 wave results, 4-chain sum of     */
+/* per-block partials).  This section restates those orders exactly   */
+/* (highs_amd/csrc/pdlp_kernels.hip: waveSum, blockSum, reducePartials,*/
+/* k_spmv epilogues, k_row_stats, k_col_stats, k_diff_norm2, k_dot)    */
+/* for the CSR-stream layout, so that a whole GPU solve can be checked */
+/* BIT FOR BIT against this oracle (tests/test_gpu_bitexact.py).       */
+/* Constants mirror pdlp_kernels.hpp: 256 lanes per block, 2048        */
+/* nonzeros / 2048 majors per work block, vector grids capped at 2048. */
+/* ------------------------------------------------------------------ */
+enum { G_T = 256, G_WAVE = 64, G_CHUNK = 2048, G_MAXMAJ = 2048, G_MAXGRID = 2048 };
+
+static double g_wave_tree(const double* lane /* [64] */) {
+  double v[G_WAVE], t[G_WAVE];
+  memcpy(v, lane, sizeof(v));
+  for (int off = G_WAVE / 2; off > 0; off >>= 1) {
+    for (int i = 0; i < G_WAVE; ++i) t[i] = v[i] + (i + off < G_WAVE ? v[i + off] : v[i]); /* __shfl_down */
+    memcpy(v, t, sizeof(v));
+  }
+  return v[0];
+}
+static double g_block_sum(const double* perThread /* [256] */) {
+  double r = 0.0;
+  for (int w = 0; w < G_T / G_WAVE; ++w) r += g_wave_tree(perThread + w * G_WAVE);
+  return r;
+}
+/* reducePartials: lane t sums p[t], p[t+256], ... in 4 independent chains */
+static double g_reduce_partials(const double* p, int count) {
+  double lane[G_T];
+  for (int t = 0; t < G_T; ++t) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int i = t;
+    for (; i + 3 * G_T < count; i += 4 * G_T) { s0 += p[i]; s1 += p[i + G_T]; s2 += p[i + 2 * G_T]; s3 += p[i + 3 * G_T]; }
+    for (; i < count; i += G_T) s0 += p[i];
+    lane[t] = (s0 + s1) + (s2 + s3);
+  }
+  return g_block_sum(lane);
+}
+static int g_vec_blocks(int len) {
+  long b = ((long)len + G_T - 1) / G_T;
+  if (b < 1) b = 1;
+  if (b > G_MAXGRID) b = G_MAXGRID;
+  return (int)b;
+}
+/* planStream (pdlp_host.cpp) */
+static int* g_plan(const int* beg, int nMajor, int* nBlocksOut) {
+  int* plan = ialloc((long)nMajor + 2);
+  int nb = 0, start = 0;
+  plan[0] = 0;
+  while (start < nMajor) {
+    const int base = beg[start];
+    int end = start;
+    while (end < nMajor && end - start < G_MAXMAJ && beg[end + 1] - base <= G_CHUNK) ++end;
+    if (end == start) end = start + 1;
+    plan[++nb] = end;
+    start = end;
+  }
+  *nBlocksOut = nb;
+  return plan;
+}
+/* value of one major: left to right, except majors longer than a chunk (block-strided + tree) */
+static double g_major_sum(const int* beg, const int* idx, const double* val, const double* in, int r) {
+  const int p0 = beg[r], p1 = beg[r + 1];
+  if (p1 - p0 <= G_CHUNK) {
+    double s = 0.0;
+    for (int p = p0; p < p1; ++p) s += val[p] * in[idx[p]];
+    return s;
+  }
+  double lane[G_T];
+  for (int t = 0; t < G_T; ++t) {
+    double s = 0.0;
+    for (int p = p0 + t; p < p1; p += G_T) s += val[p] * in[idx[p]];
+    lane[t] = s;
+  }
+  return g_block_sum(lane);
+}
+static void g_spmv(const int* beg, const int* idx, const double* val, int nMajor, const double* in, double* out) {
+  for (int r = 0; r < nMajor; ++r) out[r] = g_major_sum(beg, idx, val, in, r);
+}
+/* per-block partial of a per-major quantity: lane t accumulates majors r0+t, r0+t+256, ...;
+ * a long-major block has its single value on lane 0 */
+static double g_block_partial(const int* plan, int blk, const double* perMajor) {
+  double lane[G_T];
+  const int r0 = plan[blk], r1 = plan[blk + 1];
+  for (int t = 0; t < G_T; ++t) {
+    double a = 0.0;
+    for (int r = r0 + t; r < r1; r += G_T) a += perMajor[r];
+    lane[t] = a;
+  }
+  return g_block_sum(lane);
+}
+/* grid-stride reduction of f(i), i < len, as the vector kernels do it */
+typedef double (*g_elem_fn)(const void* ctx, int i);
+static double g_grid_sum(int len, g_elem_fn f, const void* ctx, double* partScratch) {
+  const int nb = g_vec_blocks(len > 0 ? len : 1), stride = nb * G_T;
+  for (int b = 0; b < nb; ++b) {
+    double lane[G_T];
+    for (int t = 0; t < G_T; ++t) {
+      double a = 0.0;
+      for (long i = (long)b * G_T + t; i < len; i += stride) a += f(ctx, (int)i);
+      lane[t] = a;
+    }
+    partScratch[b] = g_block_sum(lane);
+  }
+  return g_reduce_partials(partScratch, nb);
+}
+
+static void g_setup(Work* w) {
+  const int n = w->n, m = w->m;
+  /* A' by columns with ascending row (transpose of the CSR) */
+  w->cssBeg = ialloc(n + 1); w->cssIdx = ialloc(w->nnz); w->cssVal = dalloc(w->nnz);
+  int* cnt = ialloc(n);
+  for (long p = 0; p < w->csrBeg[m]; ++p) cnt[w->csrIdx[p]]++;
+  int acc = 0;
+  for (int j = 0; j < n; ++j) { w->cssBeg[j] = acc; acc += cnt[j]; cnt[j] = w->cssBeg[j]; }
+  w->cssBeg[n] = acc;
+  for (int i = 0; i < m; ++i)
+    for (int p = w->csrBeg[i]; p < w->csrBeg[i + 1]; ++p) { const int q = cnt[w->csrIdx[p]]++; w->cssIdx[q] = i; w->cssVal[q] = w->csrVal[p]; }
+  free(cnt);
+  w->planA = g_plan(w->csrBeg, m, &w->nPlanA);
+  w->planAt = g_plan(w->cssBeg, n, &w->nPlanAt);
+  const long mx = (n > m ? n : m) + G_MAXGRID + 8;
+  w->gPartA = dalloc(mx); w->gPartB = dalloc(mx); w->gStat = dalloc(mx);
+}
+
+/* movement / interaction sums of one trial in device order */
+static void g_trial_sums(Work* w, double* dX2, double* dY2, double* inter) {
+  const int n = w->n, m = w->m, c = w->nIter % 2, u = (w->nIter + 1) % 2;
+  double* perM = w->bufMax2;
+  double* perN = w->bufMax3;
+  for (int i = 0; i < m; ++i) { const double d = w->y[c][i] - w->y[u][i]; perM[i] = d * d; }
+  for (int b = 0; b < w->nPlanA; ++b) w->gPartA[b] = g_block_partial(w->planA, b, perM);
+  *dY2 = g_reduce_partials(w->gPartA, w->nPlanA);
+  for (int j = 0; j < n; ++j) { const double d = w->x[c][j] - w->x[u][j]; perN[j] = d * d; }
+  for (int b = 0; b < w->nPlanAt; ++b) w->gPartA[b] = g_block_partial(w->planAt, b, perN);
+  *dX2 = g_reduce_partials(w->gPartA, w->nPlanAt);
+  for (int j = 0; j < n; ++j) { const double dx = w->x[c][j] - w->x[u][j]; const double da = w->aty[c][j] - w->aty[u][j]; perN[j] = dx * da; }
+  for (int b = 0; b < w->nPlanAt; ++b) w->gPartA[b] = g_block_partial(w->planAt, b, perN);
+  *inter = g_reduce_partials(w->gPartA, w->nPlanAt);
+}
+
+/* k_row_stats / k_col_stats element functions */
+typedef struct { const Work* w; const double *ax, *y, *aty, *x; int q; } GStatCtx;
+static double g_row_elem(const void* vc, int i) {
+  const GStatCtx* c = (const GStatCtx*)vc;
+  const Work* w = c->w;
+  const int ineq = i >= w->nEqs;
+  const double axv = c->ax[i], yv = c->y[i], b = w->rhs[i], rs = w->ifScaled ? w->rowScale[i] : 1.0;
+  if (c->q == 0) { double r = axv + (-1.0) * b; if (ineq) r = r < 0.0 ? r : 0.0; r *= rs; return r * r; }
+  if (c->q == 1) return yv * b;
+  if (c->q == 2) return yv * yv;
+  double cc = axv; if (ineq) cc = cc < 0.0 ? cc : 0.0; cc *= rs; return cc * cc;
+}
+static double g_col_elem(const void* vc, int j) {
+  const GStatCtx* c = (const GStatCtx*)vc;
+  const Work* w = c->w;
+  const double xv = c->x[j], cj = w->cost[j], l = w->lower[j], u = w->upper[j];
+  const double cs = w->ifScaled ? w->colScale[j] : 1.0;
+  const double hasL = l > -INFINITY ? 1.0 : 0.0, hasU = u < INFINITY ? 1.0 : 0.0;
+  const double lF = l > -INFINITY ? l : 0.0, uF = u < INFINITY ? u : 0.0;
+  const double atyv = c->aty[j];
+  const double r = -atyv + cj;
+  const double sp = (r > 0.0 ? r : 0.0) * hasL;
+  const double sn = (-(r < 0.0 ? r : 0.0)) * hasU;
+  switch (c->q) {
+    case 0: return xv * cj;
+    case 1: return sp * lF;
+    case 2: return sn * uF;
+    case 3: { double rd = r + (-1.0) * sp; rd += sn; rd *= cs; return rd * rd; }
+    case 4: return sp * sp;
+    case 5: return sn * sn;
+    case 6: { double pc = (atyv + sp) - sn; pc *= cs; return pc * pc; }
+    case 7: return xv * xv;
+    case 8: { double lb = (xv < 0.0 ? xv : 0.0) * hasL; if (w->ifScaled) lb /= cs; return lb * lb; }
+    default: { double ub = (xv > 0.0 ? xv : 0.0) * hasU; if (w->ifScaled) ub /= cs; return ub * ub; }
+  }
+}
+/* residuals + infeasibility numbers of one iterate, as Solver::computeResiduals derives them */
+static void g_residuals(Work* w, const double* x, const double* y, const double* ax, const double* aty,
+                        double* sp, double* sn, double* pObj, double* dObj, double* pFeas, double* dFeas,
+                        double* gap, double* relGap, double* pInfObj, double* pInfRes, double* dInfObj,
+                        double* dInfRes) {
+  GStatCtx c = {w, ax, y, aty, x, 0};
+  double rs[4], cs[10];
+  for (int q = 0; q < 4; ++q) { c.q = q; rs[q] = g_grid_sum(w->m, g_row_elem, &c, w->gStat); }
+  for (int q = 0; q < 10; ++q) { c.q = q; cs[q] = g_grid_sum(w->n, g_col_elem, &c, w->gStat); }
+  for (int j = 0; j < w->n; ++j) { /* slacks as k_col_stats stores them */
+    const double l = w->lower[j], u = w->upper[j];
+    const double r = -aty[j] + w->cost[j];
+    sp[j] = (r > 0.0 ? r : 0.0) * (l > -INFINITY ? 1.0 : 0.0);
+    sn[j] = (-(r < 0.0 ? r : 0.0)) * (u < INFINITY ? 1.0 : 0.0);
+  }
+  *pObj = cs[0] * w->sense + w->offset;
+  *pFeas = sqrt(rs[0]);
+  *dObj = (rs[1] + cs[1] - cs[2]) * w->sense + w->offset;
+  *dFeas = sqrt(cs[3]);
+  *gap = *pObj - *dObj;
+  *relGap = fabs(*pObj - *dObj) / (1.0 + fabs(*pObj) + fabs(*dObj));
+  double dScale = sqrt(rs[2] + cs[4] + cs[5]);
+  if (dScale < 1e-8) dScale = 1.0;
+  *pInfObj = (*dObj - w->offset) / w->sense / dScale;
+  *pInfRes = sqrt(cs[6]) / dScale;
+  double pScale = sqrt(cs[7]);
+  if (pScale < 1e-8) pScale = 1.0;
+  *dInfObj = (*pObj - w->offset) / w->sense / pScale;
+  *dInfRes = sqrt(rs[3] + cs[8] + cs[9]) / pScale;
+}
+typedef struct { const double *a, *b; } GDiffCtx;
+static double g_diff_elem(const void* vc, int i) { const GDiffCtx* c = (const GDiffCtx*)vc; const double d = c->a[i] - c->b[i]; return d * d; }
+static double g_dot_elem(const void* vc, int i) { const GDiffCtx* c = (const GDiffCtx*)vc; return c->a[i] * c->b[i]; }
 
 /* ------------------------------------------------------------------ */
 /* residuals — cupdlp_solver.c:12-204 (CPU branches)                   */
@@ -347,6 +575,14 @@ static void dual_feasibility(Work* w, const double* aty, const double* y, double
 /* PDHG_Compute_Residuals :473-529 */
 static void compute_residuals(Work* w) {
   const int c = w->nIter % 2;
+  if (w->gpuOrder) {
+    g_residuals(w, w->x[c], w->y[c], w->ax[c], w->aty[c], w->slackPos, w->slackNeg, &w->pObj, &w->dObj, &w->pFeas,
+                &w->dFeas, &w->gap, &w->relGap, &w->pInfObj, &w->pInfRes, &w->dInfObj, &w->dInfRes);
+    g_residuals(w, w->xAvg, w->yAvg, w->axAvg, w->atyAvg, w->slackPosAvg, w->slackNegAvg, &w->pObjA, &w->dObjA,
+                &w->pFeasA, &w->dFeasA, &w->gapA, &w->relGapA, &w->pInfObjA, &w->pInfResA, &w->dInfObjA,
+                &w->dInfResA);
+    return;
+  }
   primal_feasibility(w, w->ax[c], w->x[c], &w->pFeas, &w->pObj);
   dual_feasibility(w, w->aty[c], w->y[c], &w->dFeas, &w->dObj, w->slackPos, w->slackNeg);
   primal_feasibility(w, w->axAvg, w->xAvg, &w->pFeasA, &w->pObjA);
@@ -404,6 +640,7 @@ static void dual_infeasibility(Work* w, const double* x, const double* ax, doubl
 /* PDHG_Compute_Infeas_Residuals :433-471 */
 static void compute_infeas_residuals(Work* w) {
   const int c = w->nIter % 2;
+  if (w->gpuOrder) return; /* already produced by g_residuals */
   primal_infeasibility(w, w->y[c], w->slackPos, w->slackNeg, w->aty[c], w->dObj, &w->pInfObj, &w->pInfRes);
   dual_infeasibility(w, w->x[c], w->ax[c], w->pObj, &w->dInfObj, &w->dInfRes);
   primal_infeasibility(w, w->yAvg, w->slackPosAvg, w->slackNegAvg, w->atyAvg, w->dObjA, &w->pInfObjA, &w->pInfResA);
@@ -435,6 +672,12 @@ static void dual_step(Work* w, double* yU, const double* y, const double* ax, co
 static void movement_interaction(Work* w, double* movement, double* interaction) {
   const int n = w->n, m = w->m, c = w->nIter % 2, u = (w->nIter + 1) % 2;
   const double sb = sqrt(w->beta);
+  if (w->gpuOrder) {
+    double dX2, dY2;
+    g_trial_sums(w, &dX2, &dY2, interaction);
+    *movement = dX2 * 0.5 * sb + dY2 / (2.0 * sb);
+    return;
+  }
   double* d2 = w->bufMax2;
   double* d3 = w->bufMax3;
   memcpy(d2, w->x[c], sizeof(double) * (size_t)n); o_axpy(n, -1.0, w->x[u], d2);
@@ -515,10 +758,13 @@ static double power_method(Work* w) {
     o_ATy(w, w->aty[c], q);
     o_Ax(w, w->ax[c], w->aty[c]);
     memcpy(q, w->ax[c], sizeof(double) * (size_t)m);
-    const double qn = o_nrm2(m, q);
+    double qn;
+    if (w->gpuOrder) { GDiffCtx cq = {q, q}; qn = sqrt(g_grid_sum(m, g_dot_elem, &cq, w->gStat)); }
+    else qn = o_nrm2(m, q);
     o_scal(m, 1.0 / qn, q);
     o_ATy(w, w->aty[c], q);
-    lambda = o_dot(n, w->aty[c], w->aty[c]);
+    if (w->gpuOrder) { GDiffCtx ca = {w->aty[c], w->aty[c]}; lambda = g_grid_sum(n, g_dot_elem, &ca, w->gStat); }
+    else lambda = o_dot(n, w->aty[c], w->aty[c]);
     o_axpy(m, -lambda, q, w->ax[c]);
   }
   return lambda;
@@ -605,10 +851,17 @@ static void step_size_ratio(Work* w) {
   const int n = w->n, m = w->m, c = w->nIter % 2;
   const double mean = sqrt(w->primalStep * w->dualStep);
   double* d = w->bufMax2;
-  memcpy(d, w->x[c], sizeof(double) * (size_t)n); o_axpy(n, -1.0, w->xLast, d);
-  const double dP = o_nrm2(n, d);
-  memcpy(d, w->y[c], sizeof(double) * (size_t)m); o_axpy(m, -1.0, w->yLast, d);
-  const double dD = o_nrm2(m, d);
+  double dP, dD;
+  if (w->gpuOrder) {
+    GDiffCtx cx = {w->x[c], w->xLast}, cy = {w->y[c], w->yLast};
+    dP = sqrt(g_grid_sum(n, g_diff_elem, &cx, w->gStat));
+    dD = sqrt(g_grid_sum(m, g_diff_elem, &cy, w->gStat));
+  } else {
+    memcpy(d, w->x[c], sizeof(double) * (size_t)n); o_axpy(n, -1.0, w->xLast, d);
+    dP = o_nrm2(n, d);
+    memcpy(d, w->y[c], sizeof(double) * (size_t)m); o_axpy(m, -1.0, w->yLast, d);
+    dD = o_nrm2(m, d);
+  }
   if (fmin(dP, dD) > 1e-10) {
     const double lg = 0.5 * log(dD / dP) + 0.5 * log(sqrt(w->beta));
     w->beta = exp(lg) * exp(lg);
@@ -809,6 +1062,8 @@ static int work_setup(Work* w, const pdlp_problem_t* P, const pdlp_params_t* opt
   w->adaptive = (opt->features_off & PDLP_FEATURE_ADAPTIVE_STEP_OFF) ? 0 : 1;
   w->restartOn = (opt->features_off & PDLP_FEATURE_RESTART_OFF) ? 0 : 1;
   if (opt->restart_method == 0) w->restartOn = 0;
+  w->gpuOrder = opt->reserved[0] == 1;
+  if (w->gpuOrder) g_setup(w);
   return 0;
 }
 

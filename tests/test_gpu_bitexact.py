@@ -1,0 +1,74 @@
+"""Whole-solve bit-exactness.  The oracle has two summation modes: the reference's left-to-right
+loops (pinned bit for bit to the real cuPDLP-C core) and "device reduction order", which restates
+the lane/wave/block order of the HIP kernels' reductions and nothing else.  In that mode a complete
+GPU solve — every iterate, every accept/reject decision, every restart — must be reproduced BIT FOR
+BIT: the only arithmetic difference between this library and the reference is the order in which
+five kinds of sums are added up."""
+import os
+
+import numpy as np
+import pytest
+
+import oraclelib as O
+from highs_amd import abi, solver
+from highs_amd import lp as L
+from lpgen import random_lp
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _check(lp, **kw):
+    cpu = O.oracle_solve(lp, device_reduction_order=True, **kw)
+    gpu = solver.solveLpCupdlp(lp, **kw)
+    R = gpu.result
+    assert (R.term_code, R.term_iterate, R.num_iter, R.num_trials, R.num_restarts) == \
+           (cpu.term_code, cpu.term_iterate, cpu.num_iter, cpu.num_trials, cpu.num_restarts)
+    assert R.primal_obj == cpu.primal_obj and R.dual_obj == cpu.dual_obj
+    assert R.primal_feas == cpu.primal_feas and R.dual_feas == cpu.dual_feas and R.rel_gap == cpu.rel_gap
+    assert np.array_equal(gpu.solution.col_value, cpu.col_value)
+    assert np.array_equal(gpu.solution.row_dual, cpu.row_dual)
+    assert np.array_equal(gpu.solution.col_dual, cpu.col_dual)
+    assert np.array_equal(gpu.solution.row_value, cpu.row_value)
+    return R.num_iter
+
+
+@pytest.fixture(autouse=True)
+def _csr_layout(monkeypatch):
+    monkeypatch.setenv("PDLP_MI355X_SLAB", "0")  # the oracle restates the CSR-stream work plan
+
+
+@pytest.mark.parametrize("name", ["afiro", "adlittle", "sctest", "e226", "shell", "25fv47"])
+def test_instances_bit_exact(name):
+    lp = L.HighsLp.from_npz(os.path.join(GOLD, "instances", name + ".npz"))
+    assert _check(lp) > 0
+
+
+@pytest.mark.parametrize("name", sorted(L.special_lps()))
+def test_special_lps_bit_exact(name):
+    _check(L.special_lps()[name], kkt_tolerance=1e-4)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_lps_bit_exact(seed):
+    _check(random_lp(seed), kkt_tolerance=1e-6, pdlp_iteration_limit=200000)
+
+
+@pytest.mark.parametrize("features_off", [1, 2, 4, 7])
+def test_feature_switches_bit_exact(features_off):
+    lp = L.HighsLp.from_npz(os.path.join(GOLD, "instances", "afiro.npz"))
+    _check(lp, kkt_tolerance=1e-5, pdlp_features_off=features_off, pdlp_iteration_limit=50000)
+
+
+def test_hot_start_bit_exact():
+    lp = L.special_lps()["restart_lp"]
+    a = solver.solveLpCupdlp(lp, kkt_tolerance=1e-4)
+    start = {"col_value": a.solution.col_value, "row_value": a.solution.row_value, "row_dual": a.solution.row_dual}
+    cpu = O.oracle_solve(lp, start=start, device_reduction_order=True, kkt_tolerance=1e-4)
+    gpu = solver.solveLpCupdlp(lp, start=start, kkt_tolerance=1e-4)
+    assert gpu.result.num_iter == cpu.num_iter and np.array_equal(gpu.solution.col_value, cpu.col_value)
+
+
+def test_synthetic_20k_bit_exact():
+    sp_ = solver.SyntheticProblem(20000, 20000, 160000, 1)
+    _check(sp_.to_lp(), kkt_tolerance=1e-4)
