@@ -152,6 +152,9 @@ def default_params(**kw):
         elif k == "device_reduction_order":
             # ORACLE ONLY: sum the reductions in the HIP kernels' order (oracle/pdlp_oracle.c, GPU-ORDER)
             p.reserved[0] = 1 if v else 0
+        elif k == "device_layout":
+            # ORACLE ONLY: which SpMV work plan to restate: "auto" (the product's rule), "csr", "slab"
+            p.reserved[1] = {"auto": 0, "csr": 1, "slab": 2}[v]
         else:
             setattr(p, k, v)
     return p

@@ -120,6 +120,10 @@ typedef struct {
   int *cssBeg, *cssIdx; /* A' by columns with ascending row index (what the device streams for A'y) */
   double* cssVal;
   int *planA, nPlanA, *planAt, nPlanAt; /* CSR-adaptive work plans, identical to the product's */
+  /* slab layout (operands whose gathered vector has >= 2^18 entries): blocks of R consecutive majors,
+   * majors longer than 256 entries go to a CSR side plan over the compacted long majors */
+  int slabA, slabAt, RA, RAt, nLongA, nLongAt;
+  int *longMapA, *longMapAt, *longBegA, *longBegAt;
   double *gPartA, *gPartB, *gStat;
 } Work;
 
@@ -139,6 +143,7 @@ static void work_free(Work* w) {
   free(w->bufN); free(w->bufN2); free(w->bufM); free(w->bufMax2); free(w->bufMax3);
   free(w->cssBeg); free(w->cssIdx); free(w->cssVal); free(w->planA); free(w->planAt);
   free(w->gPartA); free(w->gPartB); free(w->gStat);
+  free(w->longMapA); free(w->longMapAt); free(w->longBegA); free(w->longBegAt);
 }
 
 /* ------------------------------------------------------------------ */
@@ -432,7 +437,28 @@ static double g_grid_sum(int len, g_elem_fn f, const void* ctx, double* partScra
   return g_reduce_partials(partScratch, nb);
 }
 
-static void g_setup(Work* w) {
+enum { G_SLAB_LONG = 256, G_SLAB_AUTO_MINOR = 1 << 18 };
+/* slab layout parameters of one operand (pdlp_host.cpp buildSlabLayout) */
+static void g_slab_setup(const int* beg, int nMajor, long nnz, int* R, int* nLong, int** longMap, int** longBeg,
+                         int** sidePlan, int* nSidePlan) {
+  const double avg = nMajor > 0 ? (double)nnz / nMajor : 1.0;
+  int r = 256;
+  while (r < 4096 && (double)r * avg < 3000.0) r *= 2;
+  *R = r;
+  int nl = 0;
+  for (int i = 0; i < nMajor; ++i) if (beg[i + 1] - beg[i] > G_SLAB_LONG) ++nl;
+  *nLong = nl;
+  *longMap = ialloc(nl + 1);
+  *longBeg = ialloc(nl + 2);
+  int k = 0;
+  (*longBeg)[0] = 0;
+  for (int i = 0; i < nMajor; ++i)
+    if (beg[i + 1] - beg[i] > G_SLAB_LONG) { (*longMap)[k] = i; (*longBeg)[k + 1] = (*longBeg)[k] + (beg[i + 1] - beg[i]); ++k; }
+  *sidePlan = g_plan(*longBeg, nl, nSidePlan);
+  if (nl == 0) *nSidePlan = 0;
+}
+
+static void g_setup(Work* w, int layoutMode) {
   const int n = w->n, m = w->m;
   /* A' by columns with ascending row (transpose of the CSR) */
   w->cssBeg = ialloc(n + 1); w->cssIdx = ialloc(w->nnz); w->cssVal = dalloc(w->nnz);
@@ -444,10 +470,58 @@ static void g_setup(Work* w) {
   for (int i = 0; i < m; ++i)
     for (int p = w->csrBeg[i]; p < w->csrBeg[i + 1]; ++p) { const int q = cnt[w->csrIdx[p]]++; w->cssIdx[q] = i; w->cssVal[q] = w->csrVal[p]; }
   free(cnt);
-  w->planA = g_plan(w->csrBeg, m, &w->nPlanA);
-  w->planAt = g_plan(w->cssBeg, n, &w->nPlanAt);
+  /* layoutMode: 0 = the product's automatic rule, 1 = CSR stream, 2 = slab */
+  w->slabA = layoutMode == 2 || (layoutMode == 0 && n >= G_SLAB_AUTO_MINOR);   /* A gathers x (n) */
+  w->slabAt = layoutMode == 2 || (layoutMode == 0 && m >= G_SLAB_AUTO_MINOR);  /* A' gathers y (m) */
+  if (w->slabA) g_slab_setup(w->csrBeg, m, w->nnz, &w->RA, &w->nLongA, &w->longMapA, &w->longBegA, &w->planA, &w->nPlanA);
+  else w->planA = g_plan(w->csrBeg, m, &w->nPlanA);
+  if (w->slabAt) g_slab_setup(w->cssBeg, n, w->nnz, &w->RAt, &w->nLongAt, &w->longMapAt, &w->longBegAt, &w->planAt, &w->nPlanAt);
+  else w->planAt = g_plan(w->cssBeg, n, &w->nPlanAt);
   const long mx = (n > m ? n : m) + G_MAXGRID + 8;
   w->gPartA = dalloc(mx); w->gPartB = dalloc(mx); w->gStat = dalloc(mx);
+}
+
+/* Fixed-order total of a per-major quantity exactly as the SpMV epilogues + k_decide add it up.
+ * CSR stream: one partial per work block.  Slab: one partial per block of R majors (long majors
+ * skipped), then one per work block of the CSR side kernel over the compacted long majors. */
+static double g_epilogue_total(Work* w, int isAt, const double* perMajor) {
+  const int nMajor = isAt ? w->n : w->m;
+  const int slab = isAt ? w->slabAt : w->slabA;
+  const int* plan = isAt ? w->planAt : w->planA;
+  const int nPlan = isAt ? w->nPlanAt : w->nPlanA;
+  double* part = w->gPartA;
+  int np = 0;
+  if (!slab) {
+    for (int b = 0; b < nPlan; ++b) part[np++] = g_block_partial(plan, b, perMajor);
+    return g_reduce_partials(part, np);
+  }
+  const int R = isAt ? w->RAt : w->RA, nLong = isAt ? w->nLongAt : w->nLongA;
+  const int* beg = isAt ? w->cssBeg : w->csrBeg;
+  const int* longMap = isAt ? w->longMapAt : w->longMapA;
+  const int nBlocks = (nMajor + R - 1) / R;
+  for (int b = 0; b < nBlocks; ++b) {
+    double lane[G_T];
+    const int rEnd = (b + 1) * R < nMajor ? (b + 1) * R : nMajor;
+    for (int t = 0; t < G_T; ++t) {
+      double a = 0.0;
+      for (int r = b * R + t; r < rEnd; r += G_T)
+        if (beg[r + 1] - beg[r] <= G_SLAB_LONG) a += perMajor[r];
+      lane[t] = a;
+    }
+    part[np++] = g_block_sum(lane);
+  }
+  for (int b = 0; b < nPlan; ++b) { /* side kernel: compact major c stands for major longMap[c] */
+    double lane[G_T];
+    const int c0 = plan[b], c1 = plan[b + 1];
+    for (int t = 0; t < G_T; ++t) {
+      double a = 0.0;
+      for (int c = c0 + t; c < c1; c += G_T) a += perMajor[longMap[c]];
+      lane[t] = a;
+    }
+    part[np++] = g_block_sum(lane);
+  }
+  (void)nLong;
+  return g_reduce_partials(part, np);
 }
 
 /* movement / interaction sums of one trial in device order */
@@ -456,14 +530,11 @@ static void g_trial_sums(Work* w, double* dX2, double* dY2, double* inter) {
   double* perM = w->bufMax2;
   double* perN = w->bufMax3;
   for (int i = 0; i < m; ++i) { const double d = w->y[c][i] - w->y[u][i]; perM[i] = d * d; }
-  for (int b = 0; b < w->nPlanA; ++b) w->gPartA[b] = g_block_partial(w->planA, b, perM);
-  *dY2 = g_reduce_partials(w->gPartA, w->nPlanA);
+  *dY2 = g_epilogue_total(w, 0, perM);
   for (int j = 0; j < n; ++j) { const double d = w->x[c][j] - w->x[u][j]; perN[j] = d * d; }
-  for (int b = 0; b < w->nPlanAt; ++b) w->gPartA[b] = g_block_partial(w->planAt, b, perN);
-  *dX2 = g_reduce_partials(w->gPartA, w->nPlanAt);
+  *dX2 = g_epilogue_total(w, 1, perN);
   for (int j = 0; j < n; ++j) { const double dx = w->x[c][j] - w->x[u][j]; const double da = w->aty[c][j] - w->aty[u][j]; perN[j] = dx * da; }
-  for (int b = 0; b < w->nPlanAt; ++b) w->gPartA[b] = g_block_partial(w->planAt, b, perN);
-  *inter = g_reduce_partials(w->gPartA, w->nPlanAt);
+  *inter = g_epilogue_total(w, 1, perN);
 }
 
 /* k_row_stats / k_col_stats element functions */
@@ -1063,7 +1134,7 @@ static int work_setup(Work* w, const pdlp_problem_t* P, const pdlp_params_t* opt
   w->restartOn = (opt->features_off & PDLP_FEATURE_RESTART_OFF) ? 0 : 1;
   if (opt->restart_method == 0) w->restartOn = 0;
   w->gpuOrder = opt->reserved[0] == 1;
-  if (w->gpuOrder) g_setup(w);
+  if (w->gpuOrder) g_setup(w, opt->reserved[1]);
   return 0;
 }
 

@@ -18,8 +18,8 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def _check(lp, **kw):
-    cpu = O.oracle_solve(lp, device_reduction_order=True, **kw)
+def _check(lp, layout="csr", **kw):
+    cpu = O.oracle_solve(lp, device_reduction_order=True, device_layout=layout, **kw)
     gpu = solver.solveLpCupdlp(lp, **kw)
     R = gpu.result
     assert (R.term_code, R.term_iterate, R.num_iter, R.num_trials, R.num_restarts) == \
@@ -35,7 +35,7 @@ def _check(lp, **kw):
 
 @pytest.fixture(autouse=True)
 def _csr_layout(monkeypatch):
-    monkeypatch.setenv("PDLP_MI355X_SLAB", "0")  # the oracle restates the CSR-stream work plan
+    monkeypatch.setenv("PDLP_MI355X_SLAB", "0")  # default for this module: the CSR-stream work plan
 
 
 @pytest.mark.parametrize("name", ["afiro", "adlittle", "sctest", "e226", "shell", "25fv47"])
@@ -72,3 +72,22 @@ def test_hot_start_bit_exact():
 def test_synthetic_20k_bit_exact():
     sp_ = solver.SyntheticProblem(20000, 20000, 160000, 1)
     _check(sp_.to_lp(), kkt_tolerance=1e-4)
+
+
+@pytest.mark.parametrize("name", ["afiro", "e226", "25fv47"])
+def test_slab_layout_bit_exact(name, monkeypatch):
+    """Same check with the row-block x column-slab SpMV layout forced on both sides (25fv47 has majors
+    longer than 256 entries, which go through the CSR side kernel)."""
+    monkeypatch.setenv("PDLP_MI355X_SLAB", "1")
+    lp = L.HighsLp.from_npz(os.path.join(GOLD, "instances", name + ".npz"))
+    _check(lp, layout="slab")
+
+
+def test_bench_workload_bit_exact_first_iterations(monkeypatch):
+    """The bench workload itself (1M x 1M, 8M nnz; automatic layout = slab, device-side setup): the first
+    60 iterations — checks, restarts and rejected trials included — reproduced bit for bit."""
+    monkeypatch.delenv("PDLP_MI355X_SLAB", raising=False)
+    sp_ = solver.SyntheticProblem(1000000, 1000000, 8000000, 1)
+    lp = sp_.to_lp()
+    n_iter = _check(lp, layout="auto", kkt_tolerance=1e-4, pdlp_iteration_limit=60)
+    assert n_iter == 59
