@@ -1,0 +1,105 @@
+// pdlp_devfn.hpp — device functions shared by the kernel translation units
+// (pdlp_kernels.hip, pdlp_mesh.hip): deterministic wave/block sums and the
+// accept/reject + step-size update of the adaptive rule.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "pdlp_kernels.hpp"
+
+namespace pdlp {
+namespace {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ double waveSum(double v) {
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+  return v;
+}
+
+// Deterministic block sum for blocks of NT threads; result valid in thread 0.
+template <int NT>
+__device__ __forceinline__ double blockSum(double v, double* scratch /* [NT/64] */) {
+  v = waveSum(v);
+  const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+  if (lane == 0) scratch[w] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < NT / kWave; ++i) r += scratch[i];
+  }
+  __syncthreads();
+  return r;
+}
+
+// LDS slot of the q-th staged product: one pad double per 8 keeps the
+// thread-per-row read-back (stride = row length, typically 8..16 doubles)
+// off a single bank pair.
+__device__ __forceinline__ int slot(int q) { return q + (q >> 3); }
+
+// Fixed-order sum of `count` partials by one block of 256 threads (4 loads in flight per lane).
+__device__ __attribute__((unused)) double reducePartials(const double* __restrict__ p, int count, double* scratch) {
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int i = threadIdx.x;
+  for (; i + 3 * kVecThreads < count; i += 4 * kVecThreads) {
+    const double a0 = p[i], a1 = p[i + kVecThreads], a2 = p[i + 2 * kVecThreads], a3 = p[i + 3 * kVecThreads];
+    s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+  }
+  for (; i < count; i += kVecThreads) s0 += p[i];
+  return blockSum<kVecThreads>((s0 + s1) + (s2 + s3), scratch);
+}
+
+// Accept/reject and step-size update of PDHG_Update_Iterate_Adaptive_Step_Size
+// (cupdlp_step.c:237-306), the bookkeeping of PDHG_Update_Average (:433-441)
+// and the parity flip that the reference gets from ++nIter.  One thread.
+__device__ void decideUpdate(DevState* st, double dX2, double dY2, double inter) {
+  DevState s = *st;
+  const double sb = sqrt(s.beta);
+  const double movement = dX2 * 0.5 * sb + dY2 / (2.0 * sb);
+  s.nTrials += 1;
+  bool accept = true;
+  double etaNew = s.eta;
+  double limit = INFINITY;
+  if (s.adaptive) {
+    limit = (inter != 0.0) ? movement / fabs(inter) : INFINITY;
+    accept = s.eta <= limit;
+    const double k1 = (double)s.nTrials + 1.0;
+    const int ti = s.nTrials - s.powBase;
+    const bool tab = s.powRed != nullptr && ti >= 0 && ti < s.powCount;
+    const double pRed = tab ? s.powRed[ti] : pow(k1, -0.3);    // PDHG_STEPSIZE_REDUCTION_EXP
+    const double pGrow = tab ? s.powGrow[ti] : pow(k1, -0.6);  // PDHG_STEPSIZE_GROWTH_EXP
+    const double first = (1.0 - pRed) * limit;
+    const double second = (1.0 + pGrow) * s.eta;
+    etaNew = fmin(first, second);
+  }
+  s.dX2 = dX2; s.dY2 = dY2; s.inter = inter; s.movement = movement; s.limit = limit;
+  s.lastAccepted = accept ? 1 : 0;
+  if (accept) {
+    if (s.adaptive) {
+      s.primalStep = etaNew / sqrt(s.beta);
+      s.dualStep = etaNew * sqrt(s.beta);
+    }
+    const double w = sqrt(s.primalStep * s.dualStep);  // uses the NEXT step sizes (step.c:433)
+    s.sumPrimalStep += w;
+    s.sumDualStep += w;
+    s.avgW = w;
+    s.cur ^= 1;
+    s.nIter += 1;
+    s.eta = w;  // next iteration starts from sqrt(primalStep*dualStep) (step.c:231)
+    if (s.nIter >= s.haltIter) s.halted = 1;
+  } else {
+    s.eta = etaNew;
+    s.avgW = 0.0;
+  }
+  if (s.adaptive) {
+    s.tau = s.eta / sqrt(s.beta);
+    s.sigma = s.eta * sqrt(s.beta);
+  }
+  *st = s;
+}
+
+}  // namespace
+}  // namespace pdlp

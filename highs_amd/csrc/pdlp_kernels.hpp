@@ -39,7 +39,7 @@ struct DevState {
   // tabulated by the host (glibc pow) so that the step-size update is bit-reproducible on the CPU
   int32_t powBase;
   int32_t powCount;
-  int32_t pad_;
+  int32_t commError;     // a mesh exchange wait timed out (sharded path)
   const double* powRed;
   const double* powGrow;
 };

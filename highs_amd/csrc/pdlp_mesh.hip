@@ -1,0 +1,573 @@
+// pdlp_mesh.hip — see pdlp_mesh.hpp.  Kernels that talk to the peers' arenas over
+// xGMI and the host-side IPC rendezvous.
+//
+// Memory-model notes (gfx950, HSA): the arenas are FINE-GRAINED device memory, the
+// only kind that is coherent between agents inside a kernel.  A producer makes its
+// plain remote stores visible with a system-scope release fence before a single
+// thread publishes the epoch with a system-scope atomic store; a consumer acquires
+// the flag with system-scope atomic loads and every thread of the block then issues
+// a system-scope acquire fence before it touches the data.  Buffers are never
+// re-written before every reader has signalled a later phase (see the hazard
+// analysis in DESIGN.md §6), so there is no double buffering.
+#include "pdlp_mesh.hpp"
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <thread>
+
+#include "pdlp_devfn.hpp"
+#include "pdlp_device.hpp"
+
+namespace pdlp {
+
+namespace {
+
+constexpr int kFlagStride = 128;                    // bytes between two flags (own cache line each)
+
+__device__ __forceinline__ long long* flagAt(const MeshView& mv, int rank, int kind, int src) {
+  return (long long*)(mv.arena[rank] + mv.offFlags + ((size_t)kind * kMeshMaxRanks + src) * kFlagStride);
+}
+__device__ __forceinline__ double* recvX(const MeshView& mv, int rank) { return (double*)(mv.arena[rank] + mv.offRecvX); }
+__device__ __forceinline__ double* recvP(const MeshView& mv, int rank, int src) {
+  return (double*)(mv.arena[rank] + mv.offRecvP) + (size_t)src * mv.sliceMax;
+}
+__device__ __forceinline__ double* mailAt(const MeshView& mv, int rank, bool hot, int src) {
+  return (double*)(mv.arena[rank] + (hot ? mv.offMailHot : mv.offMailGen)) + (size_t)src * kMeshMailDoubles;
+}
+
+// One thread: publish epoch e of `kind` to every peer (its earlier stores, and those of
+// every thread that synchronised with it, become visible first).
+__device__ void signalPeers(const MeshView& mv, int kind, long long e) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  for (int h = 0; h < mv.G; ++h) {
+    if (h == mv.g) continue;
+    __hip_atomic_store(flagAt(mv, h, kind, mv.g), e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// Whole block: wait until every peer has published epoch >= e of `kind`.  Returns
+// false on timeout (or if another kernel already failed); the caller bails out.
+__device__ bool waitPeers(const MeshView& mv, int kind, long long e) {
+  __shared__ int ok;
+  if (threadIdx.x == 0) ok = 1;
+  __syncthreads();
+  const int h = threadIdx.x;
+  if (h < mv.G && h != mv.g) {
+    const long long* f = flagAt(mv, mv.g, kind, h);
+    const long long t0 = wall_clock64();
+    int polls = 0;
+    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < e) {
+      if ((++polls & 255) == 0) {
+        if (wall_clock64() - t0 > mv.waitTicks ||
+            __hip_atomic_load(&mv.ms->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+          ok = 0;
+          break;
+        }
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  const bool good = ok != 0;
+  __syncthreads();
+  return good;
+}
+
+__device__ void fail(const MeshView& mv, DevState* st) {
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&mv.ms->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (st) { st->halted = 1; st->commError = 1; }
+  }
+}
+
+// Multi-block producer: every block fences its stores and takes a ticket; the block
+// that takes the last ticket publishes the epoch.
+__device__ void lastBlockSignal(const MeshView& mv, int kind, long long e, int ticket) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned prev =
+        __hip_atomic_fetch_add(&mv.ms->counter[ticket], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == gridDim.x - 1) {
+      __hip_atomic_store(&mv.ms->counter[ticket], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      signalPeers(mv, kind, e);
+    }
+  }
+}
+
+__device__ __forceinline__ bool dead(const MeshView& mv) {
+  return __hip_atomic_load(&mv.ms->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
+
+// ---- hot loop ------------------------------------------------------------------------
+// x+ = clamp(x - tau (c - A'y), l, u) on the own column slice (cupdlp_step.c:16-40), stored
+// locally and pushed into every peer's recvX.
+__global__ __launch_bounds__(kVecThreads) void k_mesh_primal_step(const IterVecs v, const DevState* st,
+                                                                  const MeshView mv) {
+  if (st->halted || dead(mv)) return;
+  const long long e = mv.ms->seq + 1;
+  const int cur = st->cur, nxt = cur ^ 1;
+  const double tau = st->tau, avgW = st->avgW;
+  const double* __restrict__ x = v.x[cur];
+  const double* __restrict__ aty = v.aty[cur];
+  double* __restrict__ xn = v.x[nxt];
+  const int c0 = mv.colOff[mv.g];
+  const int stride = gridDim.x * blockDim.x;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < v.n; j += stride) {
+    const double xv = x[j];
+    if (avgW != 0.0) v.xSum[j] += avgW * xv;  // deferred PDHG_Update_Average (step.c:437)
+    double t = xv;
+    t += (-tau) * v.cost[j];
+    t += tau * aty[j];
+    const double u = v.upper[j], l = v.lower[j];
+    t = t < u ? t : u;
+    t = t > l ? t : l;
+    xn[j] = t;
+    for (int h = 0; h < mv.G; ++h)
+      if (h != mv.g) recvX(mv, h)[c0 + j] = t;
+  }
+  lastBlockSignal(mv, kFlagX, e, 0);
+}
+
+// x+ of the other column slices: recvX -> x[nxt] (ordinary memory, so that the SpMV gathers hit L2).
+__global__ __launch_bounds__(kVecThreads) void k_mesh_wait_copy_x(const IterVecs v, DevState* st, const MeshView mv) {
+  if (st->halted || dead(mv)) return;
+  const long long e = mv.ms->seq + 1;
+  if (!waitPeers(mv, kFlagX, e)) { fail(mv, st); return; }
+  const int nxt = st->cur ^ 1;
+  const int c0 = mv.colOff[mv.g], c1 = mv.colOff[mv.g + 1];
+  const double* __restrict__ src = recvX(mv, mv.g);
+  double* __restrict__ dst = v.x[nxt];
+  const int stride = gridDim.x * blockDim.x;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < v.n; j += stride)
+    if (j < c0 || j >= c1) dst[j] = src[j];
+}
+
+// partial[owner slice] -> owner's recvP[g].  `e` < 0: hot loop (epoch from seq, flag P).
+__global__ __launch_bounds__(kVecThreads) void k_mesh_push_partial(const double* __restrict__ partial, int n,
+                                                                   const DevState* st, const MeshView mv,
+                                                                   long long eGen) {
+  if ((st && st->halted) || dead(mv)) return;
+  const long long e = st ? mv.ms->seq + 1 : eGen;
+  const int stride = gridDim.x * blockDim.x;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+    int h = 0;
+    while (j >= mv.colOff[h + 1]) ++h;
+    if (h != mv.g) recvP(mv, h, mv.g)[j - mv.colOff[h]] = partial[j];
+  }
+  lastBlockSignal(mv, st ? kFlagP : kFlagGen, e, 1);
+}
+
+// Rank-ordered sum of the G contributions to column j of the own slice.
+__device__ __forceinline__ double orderedSum(const MeshView& mv, const double* __restrict__ ownPartial, int c0, int j) {
+  double s = 0.0;
+  for (int h = 0; h < mv.G; ++h) s += (h == mv.g) ? ownPartial[c0 + j] : recvP(mv, mv.g, h)[j];
+  return s;
+}
+
+// aty+[slice] = sum_h partial_h[slice]; movement / interaction partials of the slice
+// (cupdlp_linalg.c:772-801).
+__global__ __launch_bounds__(kVecThreads) void k_mesh_reduce_interact(const IterVecs v, DevState* st,
+                                                                      const MeshView mv,
+                                                                      const double* __restrict__ partial,
+                                                                      double* partDX, double* partInter) {
+  if (st->halted || dead(mv)) return;
+  const long long e = mv.ms->seq + 1;
+  if (!waitPeers(mv, kFlagP, e)) { fail(mv, st); return; }
+  __shared__ double scratch[2][kVecThreads / kWave];
+  const int cur = st->cur, nxt = cur ^ 1;
+  const int c0 = mv.colOff[mv.g];
+  double a0 = 0.0, a1 = 0.0;
+  const int stride = gridDim.x * blockDim.x;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < v.n; j += stride) {
+    const double s = orderedSum(mv, partial, c0, j);
+    const double dx = v.x[cur][j] - v.x[nxt][j];
+    const double da = v.aty[cur][j] - s;
+    v.aty[nxt][j] = s;
+    a0 += dx * dx;
+    a1 += dx * da;
+  }
+  const double t0 = blockSum<kVecThreads>(a0, scratch[0]);
+  const double t1 = blockSum<kVecThreads>(a1, scratch[1]);
+  if (threadIdx.x == 0) { partDX[blockIdx.x] = t0; partInter[blockIdx.x] = t1; }
+}
+
+// One block: local sums of the three partial arrays -> every rank's mailbox -> rank-ordered
+// totals -> the accept/reject decision (identical bits, hence identical decisions, everywhere).
+__global__ __launch_bounds__(kVecThreads) void k_mesh_decide(DevState* st, const MeshView mv,
+                                                             const double* __restrict__ partDY, int nDY,
+                                                             const double* __restrict__ partDX,
+                                                             const double* __restrict__ partInter, int nDX) {
+  if (st->halted) return;
+  if (dead(mv)) { fail(mv, st); return; }  // lets the host loop stop
+  const long long e = mv.ms->seq + 1;
+  __shared__ double scratch[3][kVecThreads / kWave];
+  const int tid = threadIdx.x;
+  auto laneSum = [&](const double* __restrict__ p, int count) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int i = tid;
+    for (; i + 3 * kVecThreads < count; i += 4 * kVecThreads) {
+      const double a0 = p[i], a1 = p[i + kVecThreads], a2 = p[i + 2 * kVecThreads], a3 = p[i + 3 * kVecThreads];
+      s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+    }
+    for (; i < count; i += kVecThreads) s0 += p[i];
+    return (s0 + s1) + (s2 + s3);
+  };
+  double vY = laneSum(partDY, nDY), vX = laneSum(partDX, nDX), vI = laneSum(partInter, nDX);
+  vY = waveSum(vY); vX = waveSum(vX); vI = waveSum(vI);
+  const int lane = tid & (kWave - 1), w = tid / kWave;
+  if (lane == 0) { scratch[0][w] = vY; scratch[1][w] = vX; scratch[2][w] = vI; }
+  __syncthreads();
+  if (tid == 0) {
+    double dY2 = 0.0, dX2 = 0.0, inter = 0.0;
+#pragma unroll
+    for (int i = 0; i < kVecThreads / kWave; ++i) { dY2 += scratch[0][i]; dX2 += scratch[1][i]; inter += scratch[2][i]; }
+    for (int h = 0; h < mv.G; ++h) {
+      double* box = mailAt(mv, h, true, mv.g);
+      box[0] = dX2; box[1] = dY2; box[2] = inter;
+    }
+    signalPeers(mv, kFlagS, e);
+  }
+  if (!waitPeers(mv, kFlagS, e)) { fail(mv, st); return; }
+  if (tid != 0) return;
+  double dX2 = 0.0, dY2 = 0.0, inter = 0.0;
+  for (int h = 0; h < mv.G; ++h) {
+    const double* box = mailAt(mv, mv.g, true, h);
+    dX2 += box[0]; dY2 += box[1]; inter += box[2];
+  }
+  decideUpdate(st, dX2, dY2, inter);
+  mv.ms->seq = e;
+}
+
+// ---- generic collectives (host-counted epochs, off the hot path) ---------------------------
+__global__ __launch_bounds__(kVecThreads) void k_mesh_push_slice(const double* __restrict__ vec, int lo, int hi,
+                                                                 const MeshView mv, long long e) {
+  if (dead(mv)) return;
+  const int stride = gridDim.x * blockDim.x;
+  for (int j = lo + blockIdx.x * blockDim.x + threadIdx.x; j < hi; j += stride) {
+    const double t = vec[j];
+    for (int h = 0; h < mv.G; ++h)
+      if (h != mv.g) recvX(mv, h)[j] = t;
+  }
+  lastBlockSignal(mv, kFlagGen, e, 2);
+}
+
+__global__ __launch_bounds__(kVecThreads) void k_mesh_wait_copy(double* __restrict__ vec, int lo, int hi, int len,
+                                                                const MeshView mv, long long e) {
+  if (dead(mv)) return;
+  if (!waitPeers(mv, kFlagGen, e)) { fail(mv, nullptr); return; }
+  const double* __restrict__ src = recvX(mv, mv.g);
+  const int stride = gridDim.x * blockDim.x;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < len; j += stride)
+    if (j < lo || j >= hi) vec[j] = src[j];
+}
+
+__global__ __launch_bounds__(kVecThreads) void k_mesh_wait_reduce(const double* __restrict__ partial,
+                                                                  double* __restrict__ dst, const MeshView mv,
+                                                                  long long e) {
+  if (dead(mv)) return;
+  if (!waitPeers(mv, kFlagGen, e)) { fail(mv, nullptr); return; }
+  const int c0 = mv.colOff[mv.g], len = mv.colOff[mv.g + 1] - c0;
+  const int stride = gridDim.x * blockDim.x;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < len; j += stride) dst[c0 + j] = orderedSum(mv, partial, c0, j);
+}
+
+// Rendezvous of all ranks: nobody passes before everybody has finished the work queued before it.
+__global__ __launch_bounds__(kVecThreads) void k_mesh_barrier(const MeshView mv, long long e) {
+  if (dead(mv)) return;
+  if (threadIdx.x == 0) signalPeers(mv, kFlagBar, e);
+  if (!waitPeers(mv, kFlagBar, e)) fail(mv, nullptr);
+}
+
+__global__ __launch_bounds__(kVecThreads) void k_mesh_allreduce_scalars(double* buf, int k, const MeshView mv,
+                                                                        long long e) {
+  if (dead(mv)) return;
+  const int tid = threadIdx.x;
+  if (tid < k) {
+    const double t = buf[tid];
+    for (int h = 0; h < mv.G; ++h) mailAt(mv, h, false, mv.g)[tid] = t;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  __syncthreads();
+  if (tid == 0) signalPeers(mv, kFlagGen, e);
+  if (!waitPeers(mv, kFlagGen, e)) { fail(mv, nullptr); return; }
+  if (tid < k) {
+    double s = 0.0;
+    for (int h = 0; h < mv.G; ++h) s += mailAt(mv, mv.g, false, h)[tid];
+    buf[tid] = s;
+  }
+  __syncthreads();
+  // the mailboxes may be overwritten by the next all-reduce only after every rank has read them
+  if (tid == 0) signalPeers(mv, kFlagBar, e);
+  if (!waitPeers(mv, kFlagBar, e)) fail(mv, nullptr);
+}
+
+int32_t meshBlocks(int64_t len) {
+  int64_t b = (len + kVecThreads - 1) / kVecThreads;
+  if (b < 1) b = 1;
+  if (b > 1024) b = 1024;
+  return (int32_t)b;
+}
+
+}  // namespace
+
+// ---- launchers ----------------------------------------------------------------------------
+void launchMeshPrimalStep(const IterVecs& vc, const DevState* st, const MeshView& mv, hipStream_t s) {
+  hipLaunchKernelGGL(k_mesh_primal_step, dim3(meshBlocks(vc.n)), dim3(kVecThreads), 0, s, vc, st, mv);
+}
+void launchMeshWaitCopyX(const IterVecs& vf, const DevState* st, const MeshView& mv, hipStream_t s) {
+  hipLaunchKernelGGL(k_mesh_wait_copy_x, dim3(meshBlocks(vf.n)), dim3(kVecThreads), 0, s, vf,
+                     const_cast<DevState*>(st), mv);
+}
+void launchMeshPushPartial(const double* partial, const DevState* st, const MeshView& mv, hipStream_t s) {
+  const int32_t n = mv.colOff[mv.G];
+  hipLaunchKernelGGL(k_mesh_push_partial, dim3(meshBlocks(n)), dim3(kVecThreads), 0, s, partial, n, st, mv, 0LL);
+}
+void launchMeshReduceInteract(const IterVecs& vc, const DevState* st, const MeshView& mv, const double* partial,
+                              double* partDX, double* partInter, int32_t nBlocks, hipStream_t s) {
+  hipLaunchKernelGGL(k_mesh_reduce_interact, dim3(nBlocks), dim3(kVecThreads), 0, s, vc, const_cast<DevState*>(st), mv,
+                     partial, partDX, partInter);
+}
+void launchMeshDecide(DevState* st, const MeshView& mv, const double* partDY, int32_t nDY, const double* partDX,
+                      const double* partInter, int32_t nDX, hipStream_t s) {
+  hipLaunchKernelGGL(k_mesh_decide, dim3(1), dim3(kVecThreads), 0, s, st, mv, partDY, nDY, partDX, partInter, nDX);
+}
+
+// ---- host side ------------------------------------------------------------------------------
+namespace {
+
+// Rendezvous segment in POSIX shared memory (all ranks are processes of one node).
+struct ShmSlot {
+  std::atomic<uint32_t> ready;
+  uint32_t pid;
+  uint64_t arenaBytes;
+  hipIpcMemHandle_t handle;
+  std::atomic<uint32_t> agree[64];  // round -> 1 ok / 2 not ok
+};
+struct ShmSeg {
+  std::atomic<uint32_t> barrier[16];
+  ShmSlot slot[kMeshMaxRanks];
+};
+
+uint64_t fnv64(const void* p, size_t len) {
+  const unsigned char* b = (const unsigned char*)p;
+  uint64_t h = 1469598103934665603ull;
+  for (size_t i = 0; i < len; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+  return h;
+}
+
+size_t alignUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+void Mesh::hostBarrier(int slot, double timeoutSec) {
+  ShmSeg* seg = (ShmSeg*)shm_;
+  seg->barrier[slot].fetch_add(1, std::memory_order_acq_rel);
+  const auto t0 = std::chrono::steady_clock::now();
+  while (seg->barrier[slot].load(std::memory_order_acquire) < (uint32_t)v_.G) {
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeoutSec)
+      throw std::runtime_error("pdlp_mi355x mesh: timed out waiting for the other ranks (host rendezvous)");
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+}
+
+Mesh::Mesh(int32_t rank, int32_t world, const void* id128, int32_t n, int32_t m, const std::vector<int32_t>& rowOff,
+           hipStream_t s)
+    : n_(n) {
+  if (world > kMeshMaxRanks) throw std::runtime_error("pdlp_mi355x mesh: more than 16 ranks");
+  if (world > 1 && !id128) throw std::runtime_error("pdlp_mi355x mesh: a communicator id is needed");
+  v_.G = world;
+  v_.g = rank;
+  for (int h = 0; h <= kMeshMaxRanks; ++h) {
+    const int hh = h < world ? h : world;
+    v_.colOff[h] = (int32_t)((int64_t)n * hh / world);
+    v_.rowOff[h] = hh < (int)rowOff.size() ? rowOff[hh] : m;
+  }
+  int64_t sliceMax = 1;
+  for (int h = 0; h < world; ++h) sliceMax = std::max<int64_t>(sliceMax, v_.colOff[h + 1] - v_.colOff[h]);
+  v_.sliceMax = sliceMax;
+  v_.waitTicks = 300000000LL;  // 3 s of the 100 MHz wall clock; PDLP_MI355X_MESH_TIMEOUT_MS overrides
+  if (const char* t = getenv("PDLP_MI355X_MESH_TIMEOUT_MS")) v_.waitTicks = std::max(1LL, atoll(t)) * 100000LL;
+  size_t off = 0;
+  v_.offFlags = (int64_t)off;   off += alignUp((size_t)kNumMeshFlags * kMeshMaxRanks * kFlagStride, 4096);
+  v_.offMailHot = (int64_t)off; off += alignUp((size_t)kMeshMaxRanks * kMeshMailDoubles * 8, 4096);
+  v_.offMailGen = (int64_t)off; off += alignUp((size_t)kMeshMaxRanks * kMeshMailDoubles * 8, 4096);
+  v_.offRecvX = (int64_t)off;   off += alignUp((size_t)std::max(n, m) * 8 + 8, 4096);
+  v_.offRecvP = (int64_t)off;   off += alignUp((size_t)world * sliceMax * 8, 4096);
+  arenaBytes_ = off;
+
+  // fine-grained: coherent between agents inside a kernel (PDLP_MI355X_MESH_MEM=coarse is a
+  // diagnostic switch for single-GPU protocol tests)
+  const char* mm = getenv("PDLP_MI355X_MESH_MEM");
+  if (mm && !strcmp(mm, "coarse")) PDLP_HIP(hipMalloc(&arena_, arenaBytes_));
+  else PDLP_HIP(hipExtMallocWithFlags(&arena_, arenaBytes_, hipDeviceMallocFinegrained));
+  PDLP_HIP(hipMemsetAsync(arena_, 0, arenaBytes_, s));
+  PDLP_HIP(hipMalloc((void**)&state_, sizeof(MeshState)));
+  PDLP_HIP(hipMemsetAsync(state_, 0, sizeof(MeshState), s));
+  PDLP_HIP(hipStreamSynchronize(s));
+  v_.ms = state_;
+  for (int h = 0; h < kMeshMaxRanks; ++h) v_.arena[h] = nullptr;
+  v_.arena[rank] = (char*)arena_;
+  if (world == 1) return;
+
+  char name[64];
+  snprintf(name, sizeof(name), "/pdlp_mesh_%016llx", (unsigned long long)fnv64(id128, 128));
+  shmName_ = name;
+  const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
+  if (fd < 0) throw std::runtime_error("pdlp_mi355x mesh: shm_open failed");
+  shmBytes_ = sizeof(ShmSeg);
+  if (ftruncate(fd, (off_t)shmBytes_) != 0) { close(fd); throw std::runtime_error("pdlp_mi355x mesh: ftruncate failed"); }
+  shm_ = mmap(nullptr, shmBytes_, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (shm_ == MAP_FAILED) { shm_ = nullptr; throw std::runtime_error("pdlp_mi355x mesh: mmap failed"); }
+  ShmSeg* seg = (ShmSeg*)shm_;
+  ShmSlot& mine = seg->slot[rank];
+  PDLP_HIP(hipIpcGetMemHandle(&mine.handle, arena_));
+  mine.arenaBytes = arenaBytes_;
+  mine.pid = (uint32_t)getpid();
+  mine.ready.store(1, std::memory_order_release);
+  hostBarrier(0, 120.0);
+  if (rank == 0) shm_unlink(name);  // every rank has it mapped; nothing is left behind on a crash
+  for (int h = 0; h < world; ++h) {
+    if (h == rank) continue;
+    if (seg->slot[h].ready.load(std::memory_order_acquire) != 1 || seg->slot[h].arenaBytes != arenaBytes_)
+      throw std::runtime_error("pdlp_mi355x mesh: ranks disagree on the arena layout");
+    void* p = nullptr;
+    PDLP_HIP(hipIpcOpenMemHandle(&p, seg->slot[h].handle, hipIpcMemLazyEnablePeerAccess));
+    v_.arena[h] = (char*)p;
+  }
+  hostBarrier(1, 120.0);
+}
+
+Mesh::~Mesh() {
+  if (v_.G > 1 && shm_) {
+    // nobody frees an arena that a peer's kernel may still write to
+    (void)hipDeviceSynchronize();
+    try { hostBarrier(2, 20.0); } catch (...) {}
+    for (int h = 0; h < v_.G; ++h)
+      if (h != v_.g && v_.arena[h]) (void)hipIpcCloseMemHandle(v_.arena[h]);
+    try { hostBarrier(3, 20.0); } catch (...) {}
+  }
+  if (arena_) (void)hipFree(arena_);
+  if (state_) (void)hipFree(state_);
+  if (shm_) munmap(shm_, shmBytes_);
+}
+
+void Mesh::allGather(double* vec, bool byRows, hipStream_t s) {
+  if (v_.G == 1) return;
+  const int32_t* off = byRows ? v_.rowOff : v_.colOff;
+  const int32_t lo = off[v_.g], hi = off[v_.g + 1], len = off[v_.G];
+  const long long e = ++epoch_;
+  hipLaunchKernelGGL(k_mesh_push_slice, dim3(meshBlocks(hi - lo)), dim3(kVecThreads), 0, s, vec, lo, hi, v_, e);
+  hipLaunchKernelGGL(k_mesh_wait_copy, dim3(meshBlocks(len)), dim3(kVecThreads), 0, s, vec, lo, hi, len, v_, e);
+  hipLaunchKernelGGL(k_mesh_barrier, dim3(1), dim3(kVecThreads), 0, s, v_, e);
+}
+
+void Mesh::reduceScatterCols(const double* partial, double* dst, hipStream_t s) {
+  const long long e = ++epoch_;
+  const int32_t n = v_.colOff[v_.G];
+  hipLaunchKernelGGL(k_mesh_push_partial, dim3(meshBlocks(n)), dim3(kVecThreads), 0, s, partial, n,
+                     (const DevState*)nullptr, v_, e);
+  hipLaunchKernelGGL(k_mesh_wait_reduce, dim3(meshBlocks(c1() - c0())), dim3(kVecThreads), 0, s, partial, dst, v_, e);
+  hipLaunchKernelGGL(k_mesh_barrier, dim3(1), dim3(kVecThreads), 0, s, v_, e);
+}
+
+void Mesh::allReduceScalars(double* buf, int32_t k, hipStream_t s) {
+  if (k > kMeshMailDoubles) throw std::runtime_error("pdlp_mi355x mesh: too many scalars in one all-reduce");
+  if (v_.G == 1) return;
+  const long long e = ++epoch_;
+  hipLaunchKernelGGL(k_mesh_allreduce_scalars, dim3(1), dim3(kVecThreads), 0, s, buf, k, v_, e);
+}
+
+void Mesh::checkError(hipStream_t s) {
+  MeshState h{};
+  PDLP_HIP(hipMemcpyAsync(&h, state_, sizeof(h), hipMemcpyDeviceToHost, s));
+  PDLP_HIP(hipStreamSynchronize(s));
+  if (h.error)
+    throw std::runtime_error("pdlp_mi355x mesh: a peer did not answer in time (exchange timed out)");
+}
+
+bool Mesh::allAgree(bool ok) {
+  if (v_.G == 1) return ok;
+  ShmSeg* seg = (ShmSeg*)shm_;
+  const int r = agreeRound_++;
+  if (r >= 64) throw std::runtime_error("pdlp_mi355x mesh: too many agreement rounds");
+  seg->slot[v_.g].agree[r].store(ok ? 1u : 2u, std::memory_order_release);
+  bool all = true;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int h = 0; h < v_.G; ++h) {
+    uint32_t a;
+    while ((a = seg->slot[h].agree[r].load(std::memory_order_acquire)) == 0) {
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0)
+        throw std::runtime_error("pdlp_mi355x mesh: timed out waiting for the other ranks (agreement)");
+      std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+    all = all && a == 1u;
+  }
+  return all;
+}
+
+// Known-answer test of the three exchange patterns with rank-dependent data.
+bool Mesh::selfTest(hipStream_t s) {
+  const int32_t n = n_;
+  const int G = v_.G, g = v_.g;
+  auto val = [](int rank, int j, int round) { return (double)((rank + 1) * 1000003 + j * 7 + round); };
+  std::vector<double> host(n), got(n);
+  double* dv = nullptr;
+  double* dp = nullptr;
+  PDLP_HIP(hipMalloc((void**)&dv, sizeof(double) * (size_t)std::max(n, 1)));
+  PDLP_HIP(hipMalloc((void**)&dp, sizeof(double) * (size_t)std::max(n, 1)));
+  bool ok = true;
+  try {
+    for (int round = 0; round < 3 && ok; ++round) {
+      // all-gather by columns
+      for (int j = 0; j < n; ++j) host[j] = (j >= c0() && j < c1()) ? val(g, j, round) : -1.0;
+      PDLP_HIP(hipMemcpyAsync(dv, host.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
+      allGather(dv, false, s);
+      PDLP_HIP(hipMemcpyAsync(got.data(), dv, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+      checkError(s);
+      for (int h = 0; h < G && ok; ++h)
+        for (int j = v_.colOff[h]; j < v_.colOff[h + 1]; ++j)
+          if (got[j] != val(h, j, round)) { ok = false; break; }
+      // reduce-scatter
+      for (int j = 0; j < n; ++j) host[j] = val(g, j, round + 10);
+      PDLP_HIP(hipMemcpyAsync(dp, host.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
+      reduceScatterCols(dp, dv, s);
+      PDLP_HIP(hipMemcpyAsync(got.data(), dv, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+      checkError(s);
+      for (int j = c0(); j < c1() && ok; ++j) {
+        double e = 0.0;
+        for (int h = 0; h < G; ++h) e += val(h, j, round + 10);
+        if (got[j] != e) ok = false;
+      }
+      // scalars
+      double sc[3] = {val(g, 1, round), val(g, 2, round), val(g, 3, round)};
+      PDLP_HIP(hipMemcpyAsync(dp, sc, sizeof(sc), hipMemcpyHostToDevice, s));
+      allReduceScalars(dp, 3, s);
+      PDLP_HIP(hipMemcpyAsync(sc, dp, sizeof(sc), hipMemcpyDeviceToHost, s));
+      checkError(s);
+      for (int q = 0; q < 3; ++q) {
+        double e = 0.0;
+        for (int h = 0; h < G; ++h) e += val(h, q + 1, round);
+        if (sc[q] != e) ok = false;
+      }
+    }
+  } catch (...) {
+    ok = false;
+  }
+  (void)hipFree(dv);
+  (void)hipFree(dp);
+  return ok;
+}
+
+}  // namespace pdlp

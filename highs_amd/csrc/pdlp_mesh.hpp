@@ -1,0 +1,114 @@
+// pdlp_mesh.hpp — direct xGMI exchange for the row-block sharded PDHG loop
+// ("the performance path is a direct full-mesh exchange").
+//
+// One process per GPU on one node.  Every rank owns an ARENA of fine-grained
+// device memory that all peers map through HIP IPC; kernels write straight
+// into the peers' arenas over xGMI (posted remote stores) and announce the data
+// with a system-scope release store of a monotonically increasing epoch into a
+// per-sender flag; the consumer kernel spins (system-scope acquire loads of its
+// own arena, bounded by a wall-clock timeout) before it reads.  No RCCL, no host
+// round trip, nothing that a hipGraph cannot replay.
+//
+// Per trial step (rank g owns row block [r0,r1) and column slice [c0,c1)):
+//   X: x+[c0:c1) is pushed into every peer's recvX      (all-gather of x+)
+//   P: the partial A_g' y+ slice of owner h is pushed into h's recvP[g]; h adds
+//      the G contributions in RANK ORDER                 (reduce-scatter of A'y+)
+//   S: {dX^2, dY^2, interaction} partials go to every peer's mailbox; every rank
+//      adds the G triples in rank order and takes the identical accept/reject
+//      decision                                          (all-reduce of 3 scalars)
+// All sums are in a fixed order, so every rank holds bit-identical x, step sizes
+// and control flow, run after run.
+//
+// The reference has no counterpart: Ax_multi_gpu / ATy_multi_gpu are exit(1)
+// stubs (cupdlp_linalg.c:420-423,453-456).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "pdlp_kernels.hpp"
+
+namespace pdlp {
+
+constexpr int kMeshMaxRanks = 16;
+constexpr int kMeshMailDoubles = 64;  // capacity of one generic scalar all-reduce
+
+// Flag kinds: one array of per-sender epochs each.
+enum MeshFlag : int { kFlagX = 0, kFlagP = 1, kFlagS = 2, kFlagGen = 3, kFlagBar = 4, kNumMeshFlags = 5 };
+
+// Mutable exchange state in (ordinary) device memory of the owning rank.
+struct MeshState {
+  long long seq;        // executed trial steps so far == epoch of the hot-loop flags
+  int32_t error;        // set by a kernel whose wait timed out (host turns it into an exception)
+  int32_t pad_;
+  uint32_t counter[4];  // "last block signals" tickets
+};
+
+// Passed by value to the kernels.
+struct MeshView {
+  char* arena[kMeshMaxRanks];  // arena base of every rank as mapped into THIS process (own = local)
+  int32_t G, g;
+  int32_t colOff[kMeshMaxRanks + 1];
+  int32_t rowOff[kMeshMaxRanks + 1];
+  int64_t offFlags, offMailHot, offMailGen, offRecvX, offRecvP;
+  int64_t sliceMax;  // doubles per recvP slot
+  int64_t waitTicks; // wall-clock (100 MHz) budget of one wait
+  MeshState* ms;
+};
+
+// Host side: arena allocation, IPC rendezvous through a POSIX shared-memory
+// segment named after the 128-byte communicator id, generic collectives.
+class Mesh {
+ public:
+  // Collective over the `world` ranks (all on one node).  Throws on failure.
+  Mesh(int32_t rank, int32_t world, const void* id128, int32_t n, int32_t m, const std::vector<int32_t>& rowOff,
+       hipStream_t s);
+  ~Mesh();
+  Mesh(const Mesh&) = delete;
+  Mesh& operator=(const Mesh&) = delete;
+
+  const MeshView& view() const { return v_; }
+  int32_t c0() const { return v_.colOff[v_.g]; }
+  int32_t c1() const { return v_.colOff[v_.g + 1]; }
+
+  // vec[lo_h:hi_h) of every rank h -> vec of every rank (partition = colOff or rowOff)
+  void allGather(double* vec, bool byRows, hipStream_t s);
+  // dst[c0:c1) = sum over ranks (rank order) of their partial[c0:c1)
+  void reduceScatterCols(const double* partial, double* dst, hipStream_t s);
+  // buf[0:k) = sum over ranks (rank order), k <= kMeshMailDoubles; identical bits on every rank
+  void allReduceScalars(double* buf, int32_t k, hipStream_t s);
+  // throws if a kernel reported a timed-out wait (call after a stream sync)
+  void checkError(hipStream_t s);
+  // exchange self-test (pattern all-gather + reduce-scatter + scalars); false = mismatch
+  bool selfTest(hipStream_t s);
+  // host-level agreement: true iff every rank passed `ok`
+  bool allAgree(bool ok);
+
+ private:
+  void hostBarrier(int slot, double timeoutSec);
+  MeshView v_{};
+  void* arena_ = nullptr;
+  size_t arenaBytes_ = 0;
+  MeshState* state_ = nullptr;
+  void* shm_ = nullptr;
+  size_t shmBytes_ = 0;
+  std::string shmName_;
+  long long epoch_ = 0;  // generic collectives (host-counted, identical on every rank)
+  int agreeRound_ = 0;
+  int32_t n_ = 0;
+};
+
+// ---- hot-loop kernels (mesh flavour of enqueueTrial) -----------------------------
+// vc = column-sliced view of the iteration vectors (pointers offset by c0, n = c1-c0);
+// vf = the full-length view.
+void launchMeshPrimalStep(const IterVecs& vc, const DevState* st, const MeshView& mv, hipStream_t s);
+void launchMeshWaitCopyX(const IterVecs& vf, const DevState* st, const MeshView& mv, hipStream_t s);
+void launchMeshPushPartial(const double* partial, const DevState* st, const MeshView& mv, hipStream_t s);
+void launchMeshReduceInteract(const IterVecs& vc, const DevState* st, const MeshView& mv, const double* partial,
+                              double* partDX, double* partInter, int32_t nBlocks, hipStream_t s);
+void launchMeshDecide(DevState* st, const MeshView& mv, const double* partDY, int32_t nDY, const double* partDX,
+                      const double* partInter, int32_t nDX, hipStream_t s);
+
+}  // namespace pdlp

@@ -138,7 +138,7 @@ bool Solver::timeIsUp() {
   hostStats_[kStatTotal + 1] = up ? 1.0 : 0.0;
   PDLP_HIP(hipMemcpyAsync(statOut_.get() + kStatTotal + 1, hostStats_ + kStatTotal + 1, sizeof(double),
                           hipMemcpyHostToDevice, stream_));
-  comm_->allReduceSum(statOut_.get() + kStatTotal + 1, 1, stream_);
+  sumOverRanks(statOut_.get() + kStatTotal + 1, 1);
   PDLP_HIP(hipMemcpyAsync(hostStats_ + kStatTotal + 1, statOut_.get() + kStatTotal + 1, sizeof(double),
                           hipMemcpyDeviceToHost, stream_));
   PDLP_HIP(hipStreamSynchronize(stream_));
@@ -225,16 +225,46 @@ Solver::Solver(const pdlp_problem_t& P, const pdlp_params_t& opt, int32_t rank, 
 
   // PDLP_MI355X_FORCE_COMM=1 runs the sharded kernel sequence and the RCCL
   // all-reduce with a single rank (lets a 1-GPU box exercise the multi-GPU path)
+  c0_ = 0;
+  c1_ = nLoc_ = F_.n;
   if (sharded_) {
     std::vector<int32_t> off = rowPartition(F_.csr, F_.m, world_);
     r0_ = off[rank_];
     r1_ = off[rank_ + 1];
-    unsigned char localId[128];
-    if (world_ == 1 && !id128) {
-      Comm::uniqueId(localId);
-      id128 = localId;
+    // Exchange: the direct xGMI mesh unless PDLP_MI355X_EXCHANGE=rccl, or the mesh cannot be
+    // set up / fails its known-answer test on some rank (then EVERY rank uses RCCL).
+    const char* ex = getenv("PDLP_MI355X_EXCHANGE");
+    bool wantMesh = !(ex && !strcmp(ex, "rccl"));
+    if (wantMesh) {
+      try {
+        mesh_ = new Mesh(rank_, world_, id128, F_.n, F_.m, off, stream_);
+      } catch (const std::exception& e) {
+        fprintf(stderr, "pdlp_mi355x[rank %d]: mesh exchange unavailable (%s); using RCCL\n", rank_, e.what());
+        mesh_ = nullptr;
+      }
+      if (mesh_) {
+        const bool ok = mesh_->selfTest(stream_);
+        if (!mesh_->allAgree(ok)) {
+          if (rank_ == 0) fprintf(stderr, "pdlp_mi355x: mesh exchange failed its self-test; using RCCL\n");
+          delete mesh_;
+          mesh_ = nullptr;
+        }
+      }
     }
-    comm_ = new Comm(rank_, world_, id128);
+    meshMode_ = mesh_ != nullptr;
+    if (meshMode_) {
+      c0_ = mesh_->c0();
+      c1_ = mesh_->c1();
+      nLoc_ = c1_ - c0_;
+    } else {
+      unsigned char localId[128];
+      if (world_ == 1 && !id128) {
+        Comm::uniqueId(localId);
+        id128 = localId;
+      }
+      comm_ = new Comm(rank_, world_, id128);
+    }
+    log(1, "Row-block sharded over %d GPUs, exchange: %s\n", world_, meshMode_ ? "direct xGMI mesh" : "RCCL all-reduce");
   } else {
     r0_ = 0;
     r1_ = F_.m;
@@ -253,6 +283,7 @@ Solver::~Solver() {
   if (hostState_) (void)hipHostFree(hostState_);
   if (hostStats_) (void)hipHostFree(hostStats_);
   delete comm_;
+  delete mesh_;
   if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -324,6 +355,10 @@ void Solver::allocIterates() {
   vecs_.xSum = xSum_.get(); vecs_.ySum = ySum_.get();
   vecs_.cost = cost_.get(); vecs_.rhs = rhs_.get(); vecs_.lower = lower_.get(); vecs_.upper = upper_.get();
   vecs_.n = n; vecs_.m = mLoc_; vecs_.nEqs = F_.nEqs; vecs_.rowOffset = r0_;
+  vecsCol_ = vecs_;
+  for (int k = 0; k < 2; ++k) { vecsCol_.x[k] += c0_; vecsCol_.aty[k] += c0_; }
+  vecsCol_.xSum += c0_; vecsCol_.cost += c0_; vecsCol_.lower += c0_; vecsCol_.upper += c0_;
+  vecsCol_.n = nLoc_;
   PDLP_HIP(hipStreamSynchronize(stream_));
 }
 
@@ -337,6 +372,8 @@ void Solver::dims(int32_t* n, int32_t* m, int64_t* nnz, int32_t* nEqs) const {
 void Solver::syncState() {
   PDLP_HIP(hipMemcpyAsync(hostState_, dState_.get(), sizeof(DevState), hipMemcpyDeviceToHost, stream_));
   PDLP_HIP(hipStreamSynchronize(stream_));
+  if (hostState_->commError)
+    throw std::runtime_error("pdlp_mi355x mesh: a peer did not answer in time (exchange timed out)");
 }
 // (k+1)^-0.3 and (k+1)^-0.6 of the adaptive step rule (cupdlp_step.c:279-284) for the next
 // kPowWindow trial counters, computed with the host's pow so that the device takes exactly the
@@ -374,6 +411,11 @@ void Solver::deviceAx(const double* x, double* axLocal) { launchSpmvPlain(dA_.vi
 void Solver::deviceATy(const double* yLocal, double* aty) {
   if (!sharded_) {
     launchSpmvPlain(dAt_.view(), yLocal, aty, stream_);
+  } else if (meshMode_) {
+    // reduce-scatter of the partials to the column owners, then all-gather: full vector everywhere
+    launchSpmvPlain(dAt_.view(), yLocal, commBuf_.get(), stream_);
+    mesh_->reduceScatterCols(commBuf_.get(), aty, stream_);
+    mesh_->allGather(aty, false, stream_);
   } else {
     launchSpmvPlain(dAt_.view(), yLocal, commBuf_.get(), stream_);
     comm_->allReduceSum(commBuf_.get(), (size_t)F_.n, stream_);
@@ -381,11 +423,31 @@ void Solver::deviceATy(const double* yLocal, double* aty) {
   }
 }
 
+void Solver::sumOverRanks(double* devBuf, int32_t count) {
+  if (meshMode_) mesh_->allReduceScalars(devBuf, count, stream_);
+  else if (comm_) comm_->allReduceSum(devBuf, (size_t)count, stream_);
+}
+
+// Assemble a vector that is distributed by rows or columns on every rank's host
+// (devLocal holds [lo,hi) of it).
+void Solver::gatherToHost(const double* devLocal, int32_t lo, int32_t hi, bool byRows, std::vector<double>& full) {
+  const int32_t len = byRows ? F_.m : F_.n;
+  full.assign((size_t)len, 0.0);
+  DeviceArray<double> g;
+  g.alloc((size_t)len);
+  g.zero(stream_);
+  PDLP_HIP(hipMemcpyAsync(g.get() + lo, devLocal, sizeof(double) * (size_t)(hi - lo), hipMemcpyDeviceToDevice, stream_));
+  if (meshMode_) mesh_->allGather(g.get(), byRows, stream_);
+  else if (comm_) comm_->allReduceSum(g.get(), (size_t)len, stream_);
+  g.download(full.data(), (size_t)len, stream_);
+  PDLP_HIP(hipStreamSynchronize(stream_));
+}
+
 // Sum per-block partials on the device, bring the scalar to the host; row
 // quantities are additionally summed over the row-block owners.
-double Solver::reduceScalar(const double* partials, int32_t nBlocks, bool rowQuantity) {
+double Solver::reduceScalar(const double* partials, int32_t nBlocks, bool overRanks) {
   launchFinalReduce(partials, nBlocks, nBlocks, 1, statOut_.get() + kStatTotal, stream_);
-  if (rowQuantity && sharded_) comm_->allReduceSum(statOut_.get() + kStatTotal, 1, stream_);
+  if (overRanks && sharded_) sumOverRanks(statOut_.get() + kStatTotal, 1);
   PDLP_HIP(hipMemcpyAsync(hostStats_ + kStatTotal, statOut_.get() + kStatTotal, sizeof(double),
                           hipMemcpyDeviceToHost, stream_));
   PDLP_HIP(hipStreamSynchronize(stream_));
@@ -491,6 +553,20 @@ void Solver::profCollect(int32_t realTrials) {
 }
 
 void Solver::enqueueTrial() {
+  if (meshMode_) {
+    // direct-exchange sequence (pdlp_mesh.hpp): X all-gather, P reduce-scatter, S scalars
+    const MeshView& mv = mesh_->view();
+    double* buf = commBuf_.get();
+    const int32_t nb = vecBlocks(std::max(nLoc_, 1));
+    launchMeshPrimalStep(vecsCol_, dState_.get(), mv, stream_);
+    launchMeshWaitCopyX(vecs_, dState_.get(), mv, stream_);
+    launchSpmvAxDual(dA_.view(), vecs_, dState_.get(), partDY_.get(), stream_);
+    launchSpmvAtyPartial(dAt_.view(), vecs_, dState_.get(), buf, stream_);
+    launchMeshPushPartial(buf, dState_.get(), mv, stream_);
+    launchMeshReduceInteract(vecsCol_, dState_.get(), mv, buf, partDX_.get(), partInter_.get(), nb, stream_);
+    launchMeshDecide(dState_.get(), mv, partDY_.get(), dA_.nPartials(), partDX_.get(), partInter_.get(), nb, stream_);
+    return;
+  }
   launchPrimalStep(vecs_, dState_.get(), stream_);
   hipEvent_t* ev = nullptr;
   if (profile_ && !sharded_) {
@@ -535,7 +611,7 @@ void Solver::runUntilHalt() {
     if (remaining > 4 * kCheckInterval) remaining = 4 * kCheckInterval;
     int32_t todo = (int32_t)remaining;
     const int32_t trialsBefore = hostState_->nTrials;
-    if (useGraph_ && !profile_ && !sharded_ && todo >= kGraphTrials) {
+    if (useGraph_ && !profile_ && (!sharded_ || meshMode_) && todo >= kGraphTrials) {
       if (!graphExec_) {
         hipGraph_t graph = nullptr;
         PDLP_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
@@ -572,11 +648,12 @@ int32_t Solver::nextCheckIter(int32_t it) const {
 // ---- check iteration -----------------------------------------------------------
 // PDHG_Compute_Average_Iterate, cupdlp_step.c:377-420
 void Solver::computeAverage() {
-  launchFlushAverage(vecs_, dState_.get(), stream_);
+  launchFlushAverage(vecsCol_, dState_.get(), stream_);
   hostState_->avgW = 0.0;
   const double ps = hostState_->sumPrimalStep > 0.0 ? 1.0 / hostState_->sumPrimalStep : 1.0;
   const double ds = hostState_->sumDualStep > 0.0 ? 1.0 / hostState_->sumDualStep : 1.0;
-  launchScaleCopy(xAvg_.get(), xSum_.get(), ps, F_.n, stream_);
+  launchScaleCopy(xAvg_.get() + c0_, xSum_.get() + c0_, ps, nLoc_, stream_);
+  if (meshMode_) mesh_->allGather(xAvg_.get(), false, stream_);
   launchScaleCopy(yAvg_.get(), ySum_.get(), ds, mLoc_, stream_);
   deviceAx(xAvg_.get(), axAvg_.get());
   deviceATy(yAvg_.get(), atyAvg_.get());
@@ -586,25 +663,27 @@ void Solver::computeAverage() {
 // for the current and the average iterate: four fused passes, one D2H of 28 doubles.
 void Solver::computeResiduals() {
   const int c = hostState_->cur;
-  const int32_t nbM = vecBlocks(std::max(mLoc_, 1)), nbN = vecBlocks(F_.n);
+  const int32_t nbM = vecBlocks(std::max(mLoc_, 1)), nbN = vecBlocks(std::max(nLoc_, 1));
   double* part = statPart_.get();
+  const size_t co = (size_t)c0_;  // column statistics run on the own column slice (everything unless mesh-sharded)
   const int sc = F_.scaled ? 1 : 0;
   launchRowStats(ax_[c].get(), y_[c].get(), rhs_.get(), rowScale_.get(), mLoc_, F_.nEqs, r0_, sc,
                  part + (size_t)kStatRowCur * statStride_, statStride_, nbM, stream_);
   launchRowStats(axAvg_.get(), yAvg_.get(), rhs_.get(), rowScale_.get(), mLoc_, F_.nEqs, r0_, sc,
                  part + (size_t)kStatRowAvg * statStride_, statStride_, nbM, stream_);
-  launchColStats(aty_[c].get(), x_[c].get(), cost_.get(), lower_.get(), upper_.get(), colScale_.get(), F_.n, sc,
-                 slackPos_.get(), slackNeg_.get(), part + (size_t)kStatColCur * statStride_, statStride_, nbN,
-                 stream_);
-  launchColStats(atyAvg_.get(), xAvg_.get(), cost_.get(), lower_.get(), upper_.get(), colScale_.get(), F_.n, sc,
-                 slackPosAvg_.get(), slackNegAvg_.get(), part + (size_t)kStatColAvg * statStride_, statStride_, nbN,
-                 stream_);
+  launchColStats(aty_[c].get() + co, x_[c].get() + co, cost_.get() + co, lower_.get() + co, upper_.get() + co,
+                 colScale_.get() + co, nLoc_, sc, slackPos_.get() + co, slackNeg_.get() + co,
+                 part + (size_t)kStatColCur * statStride_, statStride_, nbN, stream_);
+  launchColStats(atyAvg_.get() + co, xAvg_.get() + co, cost_.get() + co, lower_.get() + co, upper_.get() + co,
+                 colScale_.get() + co, nLoc_, sc, slackPosAvg_.get() + co, slackNegAvg_.get() + co,
+                 part + (size_t)kStatColAvg * statStride_, statStride_, nbN, stream_);
   launchFinalReduce(part, statStride_, nbM, 2 * kRowStats, statOut_.get(), stream_);
   launchFinalReduce(part + (size_t)kStatColCur * statStride_, statStride_, nbN, 2 * kColStats,
                     statOut_.get() + kStatColCur, stream_);
-  if (sharded_) comm_->allReduceSum(statOut_.get(), 2 * kRowStats, stream_);
+  if (sharded_) sumOverRanks(statOut_.get(), meshMode_ ? kStatTotal : 2 * kRowStats);
   PDLP_HIP(hipMemcpyAsync(hostStats_, statOut_.get(), sizeof(double) * kStatTotal, hipMemcpyDeviceToHost, stream_));
   PDLP_HIP(hipStreamSynchronize(stream_));
+  if (meshMode_) mesh_->checkError(stream_);
 
   auto fill = [&](Residuals& r, const double* rs, const double* cs) {
     r.pObj = cs[0] * F_.sense + F_.offset;
@@ -691,9 +770,9 @@ void Solver::restartIterate() {
   }
   // primal weight update
   const double mean = std::sqrt(s.primalStep * s.dualStep);
-  const int32_t nbN = vecBlocks(n), nbM = vecBlocks(std::max(mLoc_, 1));
-  launchDiffNorm2(x_[c].get(), xLast_.get(), n, partDX_.get(), nbN, stream_);
-  const double dP = std::sqrt(reduceScalar(partDX_.get(), nbN, false));
+  const int32_t nbN = vecBlocks(std::max(nLoc_, 1)), nbM = vecBlocks(std::max(mLoc_, 1));
+  launchDiffNorm2(x_[c].get() + c0_, xLast_.get() + c0_, nLoc_, partDX_.get(), nbN, stream_);
+  const double dP = std::sqrt(reduceScalar(partDX_.get(), nbN, meshMode_));
   launchDiffNorm2(y_[c].get(), yLast_.get(), mLoc_, partDX_.get(), nbM, stream_);
   const double dD = std::sqrt(reduceScalar(partDX_.get(), nbM, true));
   if (std::fmin(dP, dD) > 1e-10) {
@@ -835,18 +914,13 @@ void Solver::postsolve(pdlp_result_t* R) {
   (useAvg ? yAvg_ : y_[c]).download(y.data() + r0_, mLoc_, stream_);
   (useAvg ? axAvg_ : ax_[c]).download(ax.data() + r0_, mLoc_, stream_);
   PDLP_HIP(hipStreamSynchronize(stream_));
-  if (sharded_) {  // assemble the row-sharded vectors on every rank
-    DeviceArray<double> g;
-    g.alloc(2 * (size_t)m);
-    std::vector<double> both(2 * (size_t)m, 0.0);
-    std::copy(y.begin() + r0_, y.begin() + r1_, both.begin() + r0_);
-    std::copy(ax.begin() + r0_, ax.begin() + r1_, both.begin() + m + r0_);
-    g.upload(both.data(), both.size(), stream_);
-    comm_->allReduceSum(g.get(), both.size(), stream_);
-    g.download(both.data(), both.size(), stream_);
-    PDLP_HIP(hipStreamSynchronize(stream_));
-    std::copy(both.begin(), both.begin() + m, y.begin());
-    std::copy(both.begin() + m, both.end(), ax.begin());
+  if (sharded_) {  // assemble the row-sharded (and, with the mesh, column-sliced) vectors on every rank
+    gatherToHost((useAvg ? yAvg_ : y_[c]).get(), r0_, r1_, true, y);
+    gatherToHost((useAvg ? axAvg_ : ax_[c]).get(), r0_, r1_, true, ax);
+    if (meshMode_) {
+      gatherToHost((useAvg ? slackPosAvg_ : slackPos_).get() + c0_, c0_, c1_, false, sp);
+      gatherToHost((useAvg ? slackNegAvg_ : slackNeg_).get() + c0_, c0_, c1_, false, sn);
+    }
   }
   if (F_.scaled) {
     for (int32_t j = 0; j < n; ++j) { x[j] /= F_.colScale[j]; sp[j] *= F_.colScale[j]; sn[j] *= F_.colScale[j]; }
@@ -968,6 +1042,8 @@ void Solver::stage(const std::string& name, double* out, int32_t cap) {
     const DevState& s = *hostState_;
     put(0, s.dX2); put(1, s.dY2); put(2, s.inter); put(3, (double)s.lastAccepted);
     put(4, s.tau); put(5, s.sigma); put(6, s.eta); put(7, s.movement); put(8, s.limit);
+  } else if (name == "exchange") {  // 0 = not sharded, 1 = RCCL all-reduce, 2 = direct xGMI mesh
+    put(0, !sharded_ ? 0.0 : meshMode_ ? 2.0 : 1.0);
   } else if (name == "residuals") {
     computeAverage();
     computeResiduals();

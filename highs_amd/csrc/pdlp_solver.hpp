@@ -13,6 +13,7 @@
 #include "pdlp_device.hpp"
 #include "pdlp_host.hpp"
 #include "pdlp_kernels.hpp"
+#include "pdlp_mesh.hpp"
 #include "pdlp_setup.hpp"
 
 namespace pdlp {
@@ -82,7 +83,9 @@ class Solver {
   // linear algebra on device (sharding-aware)
   void deviceAx(const double* x, double* axLocal);
   void deviceATy(const double* yLocal, double* aty);
-  double reduceScalar(const double* partials, int32_t nBlocks, bool rowQuantity);
+  double reduceScalar(const double* partials, int32_t nBlocks, bool overRanks);
+  void sumOverRanks(double* devBuf, int32_t count);  // RCCL all-reduce or mesh rank-ordered sum
+  void gatherToHost(const double* devLocal, int32_t lo, int32_t hi, bool byRows, std::vector<double>& full);
   std::pair<double*, int64_t> lookup(const std::string& name);
   void log(int level, const char* fmt, ...) const;
   double elapsed() const;
@@ -97,7 +100,13 @@ class Solver {
   Comm* comm_ = nullptr;
   bool gpuSetup_ = true;   // formulate/scale/transpose/slab layout on the device (pdlp_setup.hip)
   double sumCost2_ = 0, sumRhs2_ = 0;  // left-to-right sums of the scaled c, b
-  bool sharded_ = false;  // row-block sharded kernel sequence + RCCL (world > 1, or forced for testing)
+  bool sharded_ = false;  // row-block sharded kernel sequence (world > 1, or forced for testing)
+  // exchange of the sharded path: direct xGMI mesh (pdlp_mesh.hpp; columns are then sliced as
+  // well, [c0_, c1_)) or, as the fallback, RCCL all-reduce with replicated column work
+  Mesh* mesh_ = nullptr;
+  bool meshMode_ = false;
+  int32_t c0_ = 0, c1_ = 0, nLoc_ = 0;
+  IterVecs vecsCol_{};  // vecs_ restricted to the own column slice
   // device
   hipStream_t stream_ = nullptr;
   DeviceMatrix dA_, dAt_;

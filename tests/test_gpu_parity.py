@@ -303,22 +303,6 @@ def test_full_size_properties_1m():
     S.close()
 
 
-def test_sharded_kernel_sequence_single_rank(monkeypatch):
-    """The multi-GPU code path (partial A'y -> RCCL all-reduce of n+1 doubles -> interaction kernel ->
-    decision from the reduced sum dy^2) forced onto ONE rank: must reproduce the single-GPU solve."""
-    lp = _lp("e226")
-    base = solver.solveLpCupdlp(lp)
-    monkeypatch.setenv("PDLP_MI355X_FORCE_COMM", "1")
-    sh = solver.solveLpCupdlp(lp, time_limit=1000.0)  # finite limit: the ranks agree on "time is up" with an all-reduce
-    assert sh.model_status == solver.kOptimal
-    # x+, y+, A x+, A'y+ are the same values; only the dX^2 / interaction partial sums are grouped
-    # differently (vector grid instead of SpMV work blocks), so the trajectories agree to rounding
-    a, b = sh.info["objective_function_value"], base.info["objective_function_value"]
-    assert abs(a - b) <= 1e-6 * (1 + abs(b))
-    assert 0.5 * base.pdlp_iteration_count <= sh.pdlp_iteration_count <= 2 * base.pdlp_iteration_count
-    assert sh.result.primal_feas < 1e-7 * (1 + sh.result.norm_rhs) and sh.result.rel_gap < 1e-7
-
-
 @pytest.mark.parametrize("name", ["25fv47", "shell", "boxed_row", "restart_lp", "synthetic"])
 @pytest.mark.parametrize("features_off", [0, 1])
 def test_gpu_setup_bit_identical_to_host_setup(name, features_off, monkeypatch):
