@@ -124,6 +124,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    exchange = {0.0: "none", 1.0: "RCCL all-reduce of A'y", 2.0: "direct xGMI mesh (all-gather x+, reduce-scatter A'y+)"}[
+        float(S.stage("exchange")[0])]
     b_iter, b_ax, b_aty = algorithmic_bytes(n, m, nnz)
     ms_step = elapsed * 1e3 / st.iters
     # dominant kernel, timed live with HIP events on the solver's own stream, IN the loop (same
@@ -153,7 +155,7 @@ def main():
         "steps": int(st.iters), "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": cfg["name"], "m": m, "n": n, "nnz": nnz,
-                   "parallelism": "single GPU" if world == 1 else "row-block x%d, RCCL all-reduce of A'y" % world,
+                   "parallelism": "single GPU" if world == 1 else "row-block x%d, %s" % (world, exchange),
                    "options": "presolve=off, kkt_tolerance=1e-4, adaptive step + restarts (reference defaults)"},
         "trial_steps": int(st.trials), "rejected_trials": int(st.trials - st.iters), "checks": int(st.checks),
         "restarts": int(st.restarts), "setup_seconds": t_setup,
@@ -166,7 +168,7 @@ def main():
                      "other_kernels_ms": {"spmv_ax_dual": k_ax, "spmv_aty_interact": k_aty},
                      "isolated_relaunch_ms": {"spmv_ax_dual": iso_ax, "spmv_aty_interact": iso_aty}},
     }
-    if args.kernels and rank == 0:
+    if args.kernels and rank == 0 and world == 1:
         ks = {k: S.time_kernel(k, 50) for k in ("primal_step", "spmv_ax", "spmv_aty", "decide", "trial",
                                                 "spmv_ax_plain", "spmv_aty_plain", "copy")}
         ks["copy_GBs"] = 2 * 512 * 2**20 / (ks["copy"] * 1e-3) / 1e9

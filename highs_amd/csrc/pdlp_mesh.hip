@@ -33,169 +33,233 @@ namespace {
 
 constexpr int kFlagStride = 128;                    // bytes between two flags (own cache line each)
 
-__device__ __forceinline__ long long* flagAt(const MeshView& mv, int rank, int kind, int src) {
-  return (long long*)(mv.arena[rank] + mv.offFlags + ((size_t)kind * kMeshMaxRanks + src) * kFlagStride);
+__device__ __forceinline__ long long* flagAt(const MeshView* __restrict__ mv, int rank, int kind, int src) {
+  return (long long*)(mv->arena[rank] + mv->offFlags + ((size_t)kind * kMeshMaxRanks + src) * kFlagStride);
 }
-__device__ __forceinline__ double* recvX(const MeshView& mv, int rank) { return (double*)(mv.arena[rank] + mv.offRecvX); }
-__device__ __forceinline__ double* recvP(const MeshView& mv, int rank, int src) {
-  return (double*)(mv.arena[rank] + mv.offRecvP) + (size_t)src * mv.sliceMax;
+__device__ __forceinline__ double* recvX(const MeshView* __restrict__ mv, int rank) { return (double*)(mv->arena[rank] + mv->offRecvX); }
+__device__ __forceinline__ double* recvP(const MeshView* __restrict__ mv, int rank, int src) {
+  return (double*)(mv->arena[rank] + mv->offRecvP) + (size_t)src * mv->sliceMax;
 }
-__device__ __forceinline__ double* mailAt(const MeshView& mv, int rank, bool hot, int src) {
-  return (double*)(mv.arena[rank] + (hot ? mv.offMailHot : mv.offMailGen)) + (size_t)src * kMeshMailDoubles;
+__device__ __forceinline__ double* mailAt(const MeshView* __restrict__ mv, int rank, bool hot, int src) {
+  return (double*)(mv->arena[rank] + (hot ? mv->offMailHot : mv->offMailGen)) + (size_t)src * kMeshMailDoubles;
 }
 
-// One thread: publish epoch e of `kind` to every peer (its earlier stores, and those of
-// every thread that synchronised with it, become visible first).
-__device__ void signalPeers(const MeshView& mv, int kind, long long e) {
+// One thread: publish epoch e of `kind` to every peer.  The system-scope release makes this
+// thread's earlier stores — and, by cumulativity, those of every thread that synchronised with it
+// (block barrier, ticket) — visible first.
+__device__ void signalPeers(const MeshView* __restrict__ mv, int kind, long long e) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-  for (int h = 0; h < mv.G; ++h) {
-    if (h == mv.g) continue;
-    __hip_atomic_store(flagAt(mv, h, kind, mv.g), e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  const int G = mv->G, g = mv->g;
+  for (int h = 0; h < G; ++h) {
+    if (h == g) continue;
+    __hip_atomic_store(flagAt(mv, h, kind, g), e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
-// Whole block: wait until every peer has published epoch >= e of `kind`.  Returns
-// false on timeout (or if another kernel already failed); the caller bails out.
-__device__ bool waitPeers(const MeshView& mv, int kind, long long e) {
+// Whole block: wait until every peer has published epoch >= e of `kind`.  Wave 0 spins (one lane
+// per peer) and issues the system-scope acquire (it invalidates this CU's L1 and this XCD's L2,
+// which is what the other waves of the block read through); the block barrier hands that on.
+// Returns false on timeout (or if another kernel already failed); the caller bails out.
+__device__ bool waitPeers(const MeshView* __restrict__ mv, int kind, long long e) {
   __shared__ int ok;
   if (threadIdx.x == 0) ok = 1;
   __syncthreads();
-  const int h = threadIdx.x;
-  if (h < mv.G && h != mv.g) {
-    const long long* f = flagAt(mv, mv.g, kind, h);
-    const long long t0 = wall_clock64();
-    int polls = 0;
-    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < e) {
-      if ((++polls & 255) == 0) {
-        if (wall_clock64() - t0 > mv.waitTicks ||
-            __hip_atomic_load(&mv.ms->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-          ok = 0;
-          break;
+  if (threadIdx.x < kWave) {
+    const int h = threadIdx.x, G = mv->G, g = mv->g;
+    if (h < G && h != g) {
+      const long long* f = flagAt(mv, g, kind, h);
+      const long long t0 = wall_clock64(), budget = mv->waitTicks;
+      int polls = 0;
+      while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < e) {
+        if ((++polls & 255) == 0) {
+          if (wall_clock64() - t0 > budget ||
+              __hip_atomic_load(&mv->ms->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+            ok = 0;
+            break;
+          }
         }
+        __builtin_amdgcn_s_sleep(1);
       }
-      __builtin_amdgcn_s_sleep(2);
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   }
   __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   const bool good = ok != 0;
   __syncthreads();
   return good;
 }
 
-__device__ void fail(const MeshView& mv, DevState* st) {
+__device__ void fail(const MeshView* __restrict__ mv, DevState* st) {
   if (threadIdx.x == 0) {
-    __hip_atomic_store(&mv.ms->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&mv->ms->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (st) { st->halted = 1; st->commError = 1; }
   }
 }
 
-// Multi-block producer: every block fences its stores and takes a ticket; the block
-// that takes the last ticket publishes the epoch.
-__device__ void lastBlockSignal(const MeshView& mv, int kind, long long e, int ticket) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+// Multi-block producer: after the block barrier ONE thread per block releases the block's stores
+// at system scope (a write-back of its XCD's L2) and takes a ticket; the block that takes the last
+// ticket publishes the epoch.
+__device__ void lastBlockSignal(const MeshView* __restrict__ mv, int kind, long long e, int ticket) {
   __syncthreads();
   if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     const unsigned prev =
-        __hip_atomic_fetch_add(&mv.ms->counter[ticket], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&mv->ms->counter[ticket], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     if (prev == gridDim.x - 1) {
-      __hip_atomic_store(&mv.ms->counter[ticket], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&mv->ms->counter[ticket], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       signalPeers(mv, kind, e);
     }
   }
 }
 
-__device__ __forceinline__ bool dead(const MeshView& mv) {
-  return __hip_atomic_load(&mv.ms->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+__device__ __forceinline__ bool dead(const MeshView* __restrict__ mv) {
+  return __hip_atomic_load(&mv->ms->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
+
+// Peer base pointers in registers (statically indexed, fully unrolled: no scratch).
+struct PeerPtrs { double* p[kMeshMaxRanks]; };
+__device__ __forceinline__ void peerRecvX(const MeshView* __restrict__ mv, PeerPtrs& P) {
+  const int G = mv->G, g = mv->g;
+#pragma unroll
+  for (int h = 0; h < kMeshMaxRanks; ++h) P.p[h] = (h < G && h != g) ? recvX(mv, h) : nullptr;
 }
 
 // ---- hot loop ------------------------------------------------------------------------
 // x+ = clamp(x - tau (c - A'y), l, u) on the own column slice (cupdlp_step.c:16-40), stored
 // locally and pushed into every peer's recvX.
 __global__ __launch_bounds__(kVecThreads) void k_mesh_primal_step(const IterVecs v, const DevState* st,
-                                                                  const MeshView mv) {
+                                                                  const MeshView* __restrict__ mv) {
   if (st->halted || dead(mv)) return;
-  const long long e = mv.ms->seq + 1;
+  const long long e = mv->ms->seq + 1;
   const int cur = st->cur, nxt = cur ^ 1;
   const double tau = st->tau, avgW = st->avgW;
   const double* __restrict__ x = v.x[cur];
   const double* __restrict__ aty = v.aty[cur];
   double* __restrict__ xn = v.x[nxt];
-  const int c0 = mv.colOff[mv.g];
+  const int c0 = mv->colOff[mv->g];
+  PeerPtrs peer;
+  peerRecvX(mv, peer);
   const int stride = gridDim.x * blockDim.x;
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < v.n; j += stride) {
-    const double xv = x[j];
-    if (avgW != 0.0) v.xSum[j] += avgW * xv;  // deferred PDHG_Update_Average (step.c:437)
-    double t = xv;
-    t += (-tau) * v.cost[j];
-    t += tau * aty[j];
-    const double u = v.upper[j], l = v.lower[j];
-    t = t < u ? t : u;
-    t = t > l ? t : l;
-    xn[j] = t;
-    for (int h = 0; h < mv.G; ++h)
-      if (h != mv.g) recvX(mv, h)[c0 + j] = t;
+  const int last = v.n - 1;
+  // four independent elements per pass (clamped, unconditional loads: all 20 loads in flight)
+  for (int j0 = blockIdx.x * blockDim.x + threadIdx.x; j0 < v.n; j0 += 4 * stride) {
+    double xv[4], cv[4], av[4], uv[4], lv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int j = min(j0 + q * stride, last);
+      xv[q] = x[j]; cv[q] = v.cost[j]; av[q] = aty[j]; uv[q] = v.upper[j]; lv[q] = v.lower[j];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int j = j0 + q * stride;
+      if (j > last) break;
+      if (avgW != 0.0) v.xSum[j] += avgW * xv[q];  // deferred PDHG_Update_Average (step.c:437)
+      double t = xv[q];
+      t += (-tau) * cv[q];
+      t += tau * av[q];
+      t = t < uv[q] ? t : uv[q];
+      t = t > lv[q] ? t : lv[q];
+      xn[j] = t;
+#pragma unroll
+      for (int h = 0; h < kMeshMaxRanks; ++h)
+        if (peer.p[h]) peer.p[h][c0 + j] = t;
+    }
   }
   lastBlockSignal(mv, kFlagX, e, 0);
 }
 
 // x+ of the other column slices: recvX -> x[nxt] (ordinary memory, so that the SpMV gathers hit L2).
-__global__ __launch_bounds__(kVecThreads) void k_mesh_wait_copy_x(const IterVecs v, DevState* st, const MeshView mv) {
+__global__ __launch_bounds__(kVecThreads) void k_mesh_wait_copy_x(const IterVecs v, DevState* st,
+                                                                  const MeshView* __restrict__ mv) {
   if (st->halted || dead(mv)) return;
-  const long long e = mv.ms->seq + 1;
+  const long long e = mv->ms->seq + 1;
   if (!waitPeers(mv, kFlagX, e)) { fail(mv, st); return; }
   const int nxt = st->cur ^ 1;
-  const int c0 = mv.colOff[mv.g], c1 = mv.colOff[mv.g + 1];
-  const double* __restrict__ src = recvX(mv, mv.g);
+  const int c0 = mv->colOff[mv->g], c1 = mv->colOff[mv->g + 1];
+  const double* __restrict__ src = recvX(mv, mv->g);
   double* __restrict__ dst = v.x[nxt];
   const int stride = gridDim.x * blockDim.x;
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < v.n; j += stride)
-    if (j < c0 || j >= c1) dst[j] = src[j];
+  // [0, c0) and [c1, n): the own slice is already in place
+  const int other = v.n - (c1 - c0);
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < other; q += stride) {
+    const int j = q < c0 ? q : q + (c1 - c0);
+    dst[j] = src[j];
+  }
 }
 
-// partial[owner slice] -> owner's recvP[g].  `e` < 0: hot loop (epoch from seq, flag P).
-__global__ __launch_bounds__(kVecThreads) void k_mesh_push_partial(const double* __restrict__ partial, int n,
-                                                                   const DevState* st, const MeshView mv,
+// partial[slice of owner h] -> h's recvP[g], one short coalesced loop per peer.  st != nullptr:
+// hot loop (epoch from seq, flag P), else generic (epoch eGen, flag Gen).
+__global__ __launch_bounds__(kVecThreads) void k_mesh_push_partial(const double* __restrict__ partial,
+                                                                   const DevState* st, const MeshView* __restrict__ mv,
                                                                    long long eGen) {
   if ((st && st->halted) || dead(mv)) return;
-  const long long e = st ? mv.ms->seq + 1 : eGen;
-  const int stride = gridDim.x * blockDim.x;
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
-    int h = 0;
-    while (j >= mv.colOff[h + 1]) ++h;
-    if (h != mv.g) recvP(mv, h, mv.g)[j - mv.colOff[h]] = partial[j];
+  const long long e = st ? mv->ms->seq + 1 : eGen;
+  const int G = mv->G, g = mv->g;
+  const int stride = gridDim.x * blockDim.x, first = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int h = 0; h < G; ++h) {
+    if (h == g) continue;
+    const int lo = mv->colOff[h], len = mv->colOff[h + 1] - lo;
+    double* __restrict__ dst = recvP(mv, h, g);
+    const double* __restrict__ src = partial + lo;
+    for (int j = first; j < len; j += stride) dst[j] = src[j];
   }
   lastBlockSignal(mv, st ? kFlagP : kFlagGen, e, 1);
 }
 
-// Rank-ordered sum of the G contributions to column j of the own slice.
-__device__ __forceinline__ double orderedSum(const MeshView& mv, const double* __restrict__ ownPartial, int c0, int j) {
+// The G contributions to the own slice, in rank order: src[h] = recvP[h] (or the own partial).
+__device__ __forceinline__ void reduceSources(const MeshView* __restrict__ mv, const double* ownPartialSlice,
+                                              PeerPtrs& S) {
+  const int G = mv->G, g = mv->g;
+#pragma unroll
+  for (int h = 0; h < kMeshMaxRanks; ++h)
+    S.p[h] = h >= G ? nullptr : (h == g ? const_cast<double*>(ownPartialSlice) : recvP(mv, g, h));
+}
+__device__ __forceinline__ double orderedSum(const PeerPtrs& S, int j) {
   double s = 0.0;
-  for (int h = 0; h < mv.G; ++h) s += (h == mv.g) ? ownPartial[c0 + j] : recvP(mv, mv.g, h)[j];
+#pragma unroll
+  for (int h = 0; h < kMeshMaxRanks; ++h)
+    if (S.p[h]) s += S.p[h][j];
   return s;
 }
 
 // aty+[slice] = sum_h partial_h[slice]; movement / interaction partials of the slice
 // (cupdlp_linalg.c:772-801).
 __global__ __launch_bounds__(kVecThreads) void k_mesh_reduce_interact(const IterVecs v, DevState* st,
-                                                                      const MeshView mv,
+                                                                      const MeshView* __restrict__ mv,
                                                                       const double* __restrict__ partial,
                                                                       double* partDX, double* partInter) {
   if (st->halted || dead(mv)) return;
-  const long long e = mv.ms->seq + 1;
+  const long long e = mv->ms->seq + 1;
   if (!waitPeers(mv, kFlagP, e)) { fail(mv, st); return; }
   __shared__ double scratch[2][kVecThreads / kWave];
   const int cur = st->cur, nxt = cur ^ 1;
-  const int c0 = mv.colOff[mv.g];
+  PeerPtrs src;
+  reduceSources(mv, partial + mv->colOff[mv->g], src);
+  const double* __restrict__ xc = v.x[cur];
+  const double* __restrict__ xn = v.x[nxt];
+  const double* __restrict__ ac = v.aty[cur];
+  double* __restrict__ an = v.aty[nxt];
   double a0 = 0.0, a1 = 0.0;
   const int stride = gridDim.x * blockDim.x;
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < v.n; j += stride) {
-    const double s = orderedSum(mv, partial, c0, j);
-    const double dx = v.x[cur][j] - v.x[nxt][j];
-    const double da = v.aty[cur][j] - s;
-    v.aty[nxt][j] = s;
-    a0 += dx * dx;
-    a1 += dx * da;
+  const int last = v.n - 1;
+  for (int j0 = blockIdx.x * blockDim.x + threadIdx.x; j0 < v.n; j0 += 4 * stride) {
+    double sv[4], dxv[4], acv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int j = min(j0 + q * stride, last);
+      sv[q] = orderedSum(src, j);
+      dxv[q] = xc[j] - xn[j];
+      acv[q] = ac[j];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {  // accumulation order: ascending j within the lane
+      const int j = j0 + q * stride;
+      if (j > last) break;
+      const double da = acv[q] - sv[q];
+      an[j] = sv[q];
+      a0 += dxv[q] * dxv[q];
+      a1 += dxv[q] * da;
+    }
   }
   const double t0 = blockSum<kVecThreads>(a0, scratch[0]);
   const double t1 = blockSum<kVecThreads>(a1, scratch[1]);
@@ -204,13 +268,13 @@ __global__ __launch_bounds__(kVecThreads) void k_mesh_reduce_interact(const Iter
 
 // One block: local sums of the three partial arrays -> every rank's mailbox -> rank-ordered
 // totals -> the accept/reject decision (identical bits, hence identical decisions, everywhere).
-__global__ __launch_bounds__(kVecThreads) void k_mesh_decide(DevState* st, const MeshView mv,
+__global__ __launch_bounds__(kVecThreads) void k_mesh_decide(DevState* st, const MeshView* __restrict__ mv,
                                                              const double* __restrict__ partDY, int nDY,
                                                              const double* __restrict__ partDX,
                                                              const double* __restrict__ partInter, int nDX) {
   if (st->halted) return;
   if (dead(mv)) { fail(mv, st); return; }  // lets the host loop stop
-  const long long e = mv.ms->seq + 1;
+  const long long e = mv->ms->seq + 1;
   __shared__ double scratch[3][kVecThreads / kWave];
   const int tid = threadIdx.x;
   auto laneSum = [&](const double* __restrict__ p, int count) {
@@ -232,8 +296,8 @@ __global__ __launch_bounds__(kVecThreads) void k_mesh_decide(DevState* st, const
     double dY2 = 0.0, dX2 = 0.0, inter = 0.0;
 #pragma unroll
     for (int i = 0; i < kVecThreads / kWave; ++i) { dY2 += scratch[0][i]; dX2 += scratch[1][i]; inter += scratch[2][i]; }
-    for (int h = 0; h < mv.G; ++h) {
-      double* box = mailAt(mv, h, true, mv.g);
+    for (int h = 0; h < mv->G; ++h) {
+      double* box = mailAt(mv, h, true, mv->g);
       box[0] = dX2; box[1] = dY2; box[2] = inter;
     }
     signalPeers(mv, kFlagS, e);
@@ -241,61 +305,66 @@ __global__ __launch_bounds__(kVecThreads) void k_mesh_decide(DevState* st, const
   if (!waitPeers(mv, kFlagS, e)) { fail(mv, st); return; }
   if (tid != 0) return;
   double dX2 = 0.0, dY2 = 0.0, inter = 0.0;
-  for (int h = 0; h < mv.G; ++h) {
-    const double* box = mailAt(mv, mv.g, true, h);
+  for (int h = 0; h < mv->G; ++h) {
+    const double* box = mailAt(mv, mv->g, true, h);
     dX2 += box[0]; dY2 += box[1]; inter += box[2];
   }
   decideUpdate(st, dX2, dY2, inter);
-  mv.ms->seq = e;
+  mv->ms->seq = e;
 }
 
 // ---- generic collectives (host-counted epochs, off the hot path) ---------------------------
 __global__ __launch_bounds__(kVecThreads) void k_mesh_push_slice(const double* __restrict__ vec, int lo, int hi,
-                                                                 const MeshView mv, long long e) {
+                                                                 const MeshView* __restrict__ mv, long long e) {
   if (dead(mv)) return;
+  PeerPtrs peer;
+  peerRecvX(mv, peer);
   const int stride = gridDim.x * blockDim.x;
   for (int j = lo + blockIdx.x * blockDim.x + threadIdx.x; j < hi; j += stride) {
     const double t = vec[j];
-    for (int h = 0; h < mv.G; ++h)
-      if (h != mv.g) recvX(mv, h)[j] = t;
+#pragma unroll
+    for (int h = 0; h < kMeshMaxRanks; ++h)
+      if (peer.p[h]) peer.p[h][j] = t;
   }
   lastBlockSignal(mv, kFlagGen, e, 2);
 }
 
 __global__ __launch_bounds__(kVecThreads) void k_mesh_wait_copy(double* __restrict__ vec, int lo, int hi, int len,
-                                                                const MeshView mv, long long e) {
+                                                                const MeshView* __restrict__ mv, long long e) {
   if (dead(mv)) return;
   if (!waitPeers(mv, kFlagGen, e)) { fail(mv, nullptr); return; }
-  const double* __restrict__ src = recvX(mv, mv.g);
+  const double* __restrict__ src = recvX(mv, mv->g);
   const int stride = gridDim.x * blockDim.x;
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < len; j += stride)
     if (j < lo || j >= hi) vec[j] = src[j];
 }
 
 __global__ __launch_bounds__(kVecThreads) void k_mesh_wait_reduce(const double* __restrict__ partial,
-                                                                  double* __restrict__ dst, const MeshView mv,
+                                                                  double* __restrict__ dst, const MeshView* __restrict__ mv,
                                                                   long long e) {
   if (dead(mv)) return;
   if (!waitPeers(mv, kFlagGen, e)) { fail(mv, nullptr); return; }
-  const int c0 = mv.colOff[mv.g], len = mv.colOff[mv.g + 1] - c0;
+  const int c0 = mv->colOff[mv->g], len = mv->colOff[mv->g + 1] - c0;
+  PeerPtrs src;
+  reduceSources(mv, partial + c0, src);
   const int stride = gridDim.x * blockDim.x;
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < len; j += stride) dst[c0 + j] = orderedSum(mv, partial, c0, j);
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < len; j += stride) dst[c0 + j] = orderedSum(src, j);
 }
 
 // Rendezvous of all ranks: nobody passes before everybody has finished the work queued before it.
-__global__ __launch_bounds__(kVecThreads) void k_mesh_barrier(const MeshView mv, long long e) {
+__global__ __launch_bounds__(kVecThreads) void k_mesh_barrier(const MeshView* __restrict__ mv, long long e) {
   if (dead(mv)) return;
   if (threadIdx.x == 0) signalPeers(mv, kFlagBar, e);
   if (!waitPeers(mv, kFlagBar, e)) fail(mv, nullptr);
 }
 
-__global__ __launch_bounds__(kVecThreads) void k_mesh_allreduce_scalars(double* buf, int k, const MeshView mv,
+__global__ __launch_bounds__(kVecThreads) void k_mesh_allreduce_scalars(double* buf, int k, const MeshView* __restrict__ mv,
                                                                         long long e) {
   if (dead(mv)) return;
   const int tid = threadIdx.x;
   if (tid < k) {
     const double t = buf[tid];
-    for (int h = 0; h < mv.G; ++h) mailAt(mv, h, false, mv.g)[tid] = t;
+    for (int h = 0; h < mv->G; ++h) mailAt(mv, h, false, mv->g)[tid] = t;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
   __syncthreads();
@@ -303,7 +372,7 @@ __global__ __launch_bounds__(kVecThreads) void k_mesh_allreduce_scalars(double* 
   if (!waitPeers(mv, kFlagGen, e)) { fail(mv, nullptr); return; }
   if (tid < k) {
     double s = 0.0;
-    for (int h = 0; h < mv.G; ++h) s += mailAt(mv, mv.g, false, h)[tid];
+    for (int h = 0; h < mv->G; ++h) s += mailAt(mv, mv->g, false, h)[tid];
     buf[tid] = s;
   }
   __syncthreads();
@@ -312,35 +381,43 @@ __global__ __launch_bounds__(kVecThreads) void k_mesh_allreduce_scalars(double* 
   if (!waitPeers(mv, kFlagBar, e)) fail(mv, nullptr);
 }
 
+// Grid of a mesh kernel: every block pays one system-scope fence (an L2 write-back or
+// invalidate), so these grids stay small; PDLP_MI355X_MESH_BLOCKS overrides the cap.
 int32_t meshBlocks(int64_t len) {
+  static const int cap = [] {
+    const char* e = getenv("PDLP_MI355X_MESH_BLOCKS");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 256;
+  }();
   int64_t b = (len + kVecThreads - 1) / kVecThreads;
   if (b < 1) b = 1;
-  if (b > 1024) b = 1024;
+  if (b > cap) b = cap;
   return (int32_t)b;
 }
 
 }  // namespace
 
-// ---- launchers ----------------------------------------------------------------------------
-void launchMeshPrimalStep(const IterVecs& vc, const DevState* st, const MeshView& mv, hipStream_t s) {
-  hipLaunchKernelGGL(k_mesh_primal_step, dim3(meshBlocks(vc.n)), dim3(kVecThreads), 0, s, vc, st, mv);
+int32_t meshGrid(int64_t len) { return meshBlocks(len); }
+
+// ---- launchers (dmv = the view in device memory) --------------------------------------------
+void launchMeshPrimalStep(const IterVecs& vc, const DevState* st, const MeshView* dmv, hipStream_t s) {
+  hipLaunchKernelGGL(k_mesh_primal_step, dim3(meshBlocks(vc.n)), dim3(kVecThreads), 0, s, vc, st, dmv);
 }
-void launchMeshWaitCopyX(const IterVecs& vf, const DevState* st, const MeshView& mv, hipStream_t s) {
+void launchMeshWaitCopyX(const IterVecs& vf, const DevState* st, const MeshView* dmv, hipStream_t s) {
   hipLaunchKernelGGL(k_mesh_wait_copy_x, dim3(meshBlocks(vf.n)), dim3(kVecThreads), 0, s, vf,
-                     const_cast<DevState*>(st), mv);
+                     const_cast<DevState*>(st), dmv);
 }
-void launchMeshPushPartial(const double* partial, const DevState* st, const MeshView& mv, hipStream_t s) {
-  const int32_t n = mv.colOff[mv.G];
-  hipLaunchKernelGGL(k_mesh_push_partial, dim3(meshBlocks(n)), dim3(kVecThreads), 0, s, partial, n, st, mv, 0LL);
+void launchMeshPushPartial(const double* partial, int32_t n, const DevState* st, const MeshView* dmv, hipStream_t s) {
+  hipLaunchKernelGGL(k_mesh_push_partial, dim3(meshBlocks(n)), dim3(kVecThreads), 0, s, partial, st, dmv, 0LL);
 }
-void launchMeshReduceInteract(const IterVecs& vc, const DevState* st, const MeshView& mv, const double* partial,
+void launchMeshReduceInteract(const IterVecs& vc, const DevState* st, const MeshView* dmv, const double* partial,
                               double* partDX, double* partInter, int32_t nBlocks, hipStream_t s) {
-  hipLaunchKernelGGL(k_mesh_reduce_interact, dim3(nBlocks), dim3(kVecThreads), 0, s, vc, const_cast<DevState*>(st), mv,
-                     partial, partDX, partInter);
+  hipLaunchKernelGGL(k_mesh_reduce_interact, dim3(nBlocks), dim3(kVecThreads), 0, s, vc, const_cast<DevState*>(st),
+                     dmv, partial, partDX, partInter);
 }
-void launchMeshDecide(DevState* st, const MeshView& mv, const double* partDY, int32_t nDY, const double* partDX,
+void launchMeshDecide(DevState* st, const MeshView* dmv, const double* partDY, int32_t nDY, const double* partDX,
                       const double* partInter, int32_t nDX, hipStream_t s) {
-  hipLaunchKernelGGL(k_mesh_decide, dim3(1), dim3(kVecThreads), 0, s, st, mv, partDY, nDY, partDX, partInter, nDX);
+  hipLaunchKernelGGL(k_mesh_decide, dim3(1), dim3(kVecThreads), 0, s, st, dmv, partDY, nDY, partDX, partInter, nDX);
 }
 
 // ---- host side ------------------------------------------------------------------------------
@@ -418,7 +495,11 @@ Mesh::Mesh(int32_t rank, int32_t world, const void* id128, int32_t n, int32_t m,
   v_.ms = state_;
   for (int h = 0; h < kMeshMaxRanks; ++h) v_.arena[h] = nullptr;
   v_.arena[rank] = (char*)arena_;
-  if (world == 1) return;
+  PDLP_HIP(hipMalloc((void**)&dView_, sizeof(MeshView)));
+  if (world == 1) {
+    PDLP_HIP(hipMemcpy(dView_, &v_, sizeof(MeshView), hipMemcpyHostToDevice));
+    return;
+  }
 
   char name[64];
   snprintf(name, sizeof(name), "/pdlp_mesh_%016llx", (unsigned long long)fnv64(id128, 128));
@@ -446,6 +527,7 @@ Mesh::Mesh(int32_t rank, int32_t world, const void* id128, int32_t n, int32_t m,
     PDLP_HIP(hipIpcOpenMemHandle(&p, seg->slot[h].handle, hipIpcMemLazyEnablePeerAccess));
     v_.arena[h] = (char*)p;
   }
+  PDLP_HIP(hipMemcpy(dView_, &v_, sizeof(MeshView), hipMemcpyHostToDevice));
   hostBarrier(1, 120.0);
 }
 
@@ -460,6 +542,7 @@ Mesh::~Mesh() {
   }
   if (arena_) (void)hipFree(arena_);
   if (state_) (void)hipFree(state_);
+  if (dView_) (void)hipFree(dView_);
   if (shm_) munmap(shm_, shmBytes_);
 }
 
@@ -468,25 +551,25 @@ void Mesh::allGather(double* vec, bool byRows, hipStream_t s) {
   const int32_t* off = byRows ? v_.rowOff : v_.colOff;
   const int32_t lo = off[v_.g], hi = off[v_.g + 1], len = off[v_.G];
   const long long e = ++epoch_;
-  hipLaunchKernelGGL(k_mesh_push_slice, dim3(meshBlocks(hi - lo)), dim3(kVecThreads), 0, s, vec, lo, hi, v_, e);
-  hipLaunchKernelGGL(k_mesh_wait_copy, dim3(meshBlocks(len)), dim3(kVecThreads), 0, s, vec, lo, hi, len, v_, e);
-  hipLaunchKernelGGL(k_mesh_barrier, dim3(1), dim3(kVecThreads), 0, s, v_, e);
+  hipLaunchKernelGGL(k_mesh_push_slice, dim3(meshBlocks(hi - lo)), dim3(kVecThreads), 0, s, vec, lo, hi, dView_, e);
+  hipLaunchKernelGGL(k_mesh_wait_copy, dim3(meshBlocks(len)), dim3(kVecThreads), 0, s, vec, lo, hi, len, dView_, e);
+  hipLaunchKernelGGL(k_mesh_barrier, dim3(1), dim3(kVecThreads), 0, s, dView_, e);
 }
 
 void Mesh::reduceScatterCols(const double* partial, double* dst, hipStream_t s) {
   const long long e = ++epoch_;
   const int32_t n = v_.colOff[v_.G];
-  hipLaunchKernelGGL(k_mesh_push_partial, dim3(meshBlocks(n)), dim3(kVecThreads), 0, s, partial, n,
-                     (const DevState*)nullptr, v_, e);
-  hipLaunchKernelGGL(k_mesh_wait_reduce, dim3(meshBlocks(c1() - c0())), dim3(kVecThreads), 0, s, partial, dst, v_, e);
-  hipLaunchKernelGGL(k_mesh_barrier, dim3(1), dim3(kVecThreads), 0, s, v_, e);
+  hipLaunchKernelGGL(k_mesh_push_partial, dim3(meshBlocks(n)), dim3(kVecThreads), 0, s, partial,
+                     (const DevState*)nullptr, dView_, e);
+  hipLaunchKernelGGL(k_mesh_wait_reduce, dim3(meshBlocks(c1() - c0())), dim3(kVecThreads), 0, s, partial, dst, dView_, e);
+  hipLaunchKernelGGL(k_mesh_barrier, dim3(1), dim3(kVecThreads), 0, s, dView_, e);
 }
 
 void Mesh::allReduceScalars(double* buf, int32_t k, hipStream_t s) {
   if (k > kMeshMailDoubles) throw std::runtime_error("pdlp_mi355x mesh: too many scalars in one all-reduce");
   if (v_.G == 1) return;
   const long long e = ++epoch_;
-  hipLaunchKernelGGL(k_mesh_allreduce_scalars, dim3(1), dim3(kVecThreads), 0, s, buf, k, v_, e);
+  hipLaunchKernelGGL(k_mesh_allreduce_scalars, dim3(1), dim3(kVecThreads), 0, s, buf, k, dView_, e);
 }
 
 void Mesh::checkError(hipStream_t s) {

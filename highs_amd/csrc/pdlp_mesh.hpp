@@ -46,7 +46,7 @@ struct MeshState {
   uint32_t counter[4];  // "last block signals" tickets
 };
 
-// Passed by value to the kernels.
+// Lives in device memory (the kernels index its arrays dynamically); the host keeps a copy.
 struct MeshView {
   char* arena[kMeshMaxRanks];  // arena base of every rank as mapped into THIS process (own = local)
   int32_t G, g;
@@ -70,6 +70,7 @@ class Mesh {
   Mesh& operator=(const Mesh&) = delete;
 
   const MeshView& view() const { return v_; }
+  const MeshView* deviceView() const { return dView_; }
   int32_t c0() const { return v_.colOff[v_.g]; }
   int32_t c1() const { return v_.colOff[v_.g + 1]; }
 
@@ -89,6 +90,7 @@ class Mesh {
  private:
   void hostBarrier(int slot, double timeoutSec);
   MeshView v_{};
+  MeshView* dView_ = nullptr;
   void* arena_ = nullptr;
   size_t arenaBytes_ = 0;
   MeshState* state_ = nullptr;
@@ -103,12 +105,13 @@ class Mesh {
 // ---- hot-loop kernels (mesh flavour of enqueueTrial) -----------------------------
 // vc = column-sliced view of the iteration vectors (pointers offset by c0, n = c1-c0);
 // vf = the full-length view.
-void launchMeshPrimalStep(const IterVecs& vc, const DevState* st, const MeshView& mv, hipStream_t s);
-void launchMeshWaitCopyX(const IterVecs& vf, const DevState* st, const MeshView& mv, hipStream_t s);
-void launchMeshPushPartial(const double* partial, const DevState* st, const MeshView& mv, hipStream_t s);
-void launchMeshReduceInteract(const IterVecs& vc, const DevState* st, const MeshView& mv, const double* partial,
+int32_t meshGrid(int64_t len);  // grid size of the mesh kernels for a vector of `len`
+void launchMeshPrimalStep(const IterVecs& vc, const DevState* st, const MeshView* dmv, hipStream_t s);
+void launchMeshWaitCopyX(const IterVecs& vf, const DevState* st, const MeshView* dmv, hipStream_t s);
+void launchMeshPushPartial(const double* partial, int32_t n, const DevState* st, const MeshView* dmv, hipStream_t s);
+void launchMeshReduceInteract(const IterVecs& vc, const DevState* st, const MeshView* dmv, const double* partial,
                               double* partDX, double* partInter, int32_t nBlocks, hipStream_t s);
-void launchMeshDecide(DevState* st, const MeshView& mv, const double* partDY, int32_t nDY, const double* partDX,
+void launchMeshDecide(DevState* st, const MeshView* dmv, const double* partDY, int32_t nDY, const double* partDX,
                       const double* partInter, int32_t nDX, hipStream_t s);
 
 }  // namespace pdlp

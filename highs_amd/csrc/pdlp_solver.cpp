@@ -555,14 +555,14 @@ void Solver::profCollect(int32_t realTrials) {
 void Solver::enqueueTrial() {
   if (meshMode_) {
     // direct-exchange sequence (pdlp_mesh.hpp): X all-gather, P reduce-scatter, S scalars
-    const MeshView& mv = mesh_->view();
+    const MeshView* mv = mesh_->deviceView();
     double* buf = commBuf_.get();
-    const int32_t nb = vecBlocks(std::max(nLoc_, 1));
+    const int32_t nb = meshGrid(std::max(nLoc_, 1));  // every block waits + fences once
     launchMeshPrimalStep(vecsCol_, dState_.get(), mv, stream_);
     launchMeshWaitCopyX(vecs_, dState_.get(), mv, stream_);
     launchSpmvAxDual(dA_.view(), vecs_, dState_.get(), partDY_.get(), stream_);
     launchSpmvAtyPartial(dAt_.view(), vecs_, dState_.get(), buf, stream_);
-    launchMeshPushPartial(buf, dState_.get(), mv, stream_);
+    launchMeshPushPartial(buf, F_.n, dState_.get(), mv, stream_);
     launchMeshReduceInteract(vecsCol_, dState_.get(), mv, buf, partDX_.get(), partInter_.get(), nb, stream_);
     launchMeshDecide(dState_.get(), mv, partDY_.get(), dA_.nPartials(), partDX_.get(), partInter_.get(), nb, stream_);
     return;
@@ -1059,7 +1059,7 @@ void Solver::stage(const std::string& name, double* out, int32_t cap) {
 double Solver::timeKernel(const std::string& name, int32_t reps) {
   syncState();
   if (reps < 1) reps = 1;
-  launchFlushAverage(vecs_, dState_.get(), stream_);
+  launchFlushAverage(vecsCol_, dState_.get(), stream_);
   hostState_->avgW = 0.0;
   const int32_t savedHalt = hostState_->haltIter;
   hostState_->haltIter = INT_MAX;

