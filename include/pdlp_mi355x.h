@@ -196,6 +196,7 @@ int pdlp_mi355x_set_vector(pdlp_mi355x_solver_t* s, const char* name,
  *  "profile_on" / "profile_off"  bracket the two SpMV launches of every trial with HIP events
  *              (eager launches, no hipGraph): the next pdlp_mi355x_iterate then reports the
  *              IN-LOOP average launch durations in spmv_ax_ms / spmv_aty_ms (reserved[0] = launches)
+ *  "exchange"  scalars_out[0] = 0 not sharded, 1 RCCL all-reduce, 2 direct xGMI mesh
  * scalars_out receives stage-specific scalars, n_scalars its capacity. */
 int pdlp_mi355x_stage(pdlp_mi355x_solver_t* s, const char* stage,
                       double* scalars_out, int32_t n_scalars);
@@ -209,9 +210,13 @@ int pdlp_mi355x_time_kernel(pdlp_mi355x_solver_t* s, const char* kernel,
 
 /* Multi-GPU (row-block sharding): the process owning rank r of
  * world w passes the FULL problem; create() keeps only its row block.
- * The n-vector exchange uses RCCL; id is the 128-byte ncclUniqueId obtained
- * on rank 0 with pdlp_mi355x_comm_unique_id and broadcast by the caller
- * (torch.distributed / MPI / anything). */
+ * id is the 128-byte communicator id obtained on rank 0 with
+ * pdlp_mi355x_comm_unique_id and broadcast by the caller (torch.distributed /
+ * MPI / anything).  All ranks must be processes of ONE node: the n-vector
+ * exchange writes directly into the peers' HIP-IPC-mapped device memory over
+ * xGMI; the id names their rendezvous and is also a valid
+ * ncclUniqueId for the RCCL all-reduce fallback.  run/iterate/stage("residuals")
+ * are collective afterwards. */
 int pdlp_mi355x_comm_unique_id(void* id128);
 int pdlp_mi355x_create_sharded(const pdlp_problem_t* P, const pdlp_params_t* opt,
                                int32_t rank, int32_t world, const void* id128,
