@@ -60,7 +60,11 @@ class PdlpParams(C.Structure):
         ("log_level", C.c_int32),
         ("device", C.c_int32),
         ("check_interval", C.c_int32),
-        ("reserved", C.c_int32 * 6),
+        ("reserved", C.c_int32 * 2),
+        ("algorithm", C.c_int32),           # 0 = cuPDLP-C path, 1 = HiPDLP (solver="hipdlp")
+        ("scaling_mode", C.c_int32),        # pdlp_scaling_mode: 1 Ruiz | 2 L2 | 4 PC
+        ("ruiz_iterations", C.c_int32),     # pdlp_ruiz_iterations
+        ("step_size_strategy", C.c_int32),  # pdlp_step_size_strategy: 0 fixed, else PID
     ]
 
 
@@ -142,6 +146,10 @@ def default_params(**kw):
     p.log_level = 0
     p.device = 0
     p.check_interval = 0
+    p.algorithm = 0
+    p.scaling_mode = 5          # kPdlpScalingRuiz + kPdlpScalingPC, HighsOptions.h:1345-1349
+    p.ruiz_iterations = 10      # HighsOptions.h:1353-1355
+    p.step_size_strategy = 1    # kPdlpStepSizeStrategyAdaptive, HighsOptions.h:1374-1378 (HiPDLP: -> PID)
     for k, v in kw.items():
         if k == "kkt_tolerance":
             p.primal_tol = p.dual_tol = p.gap_tol = float(v)
@@ -149,6 +157,10 @@ def default_params(**kw):
             p.iter_limit = int(min(v, 2**31 - 1))
         elif k == "pdlp_features_off":
             p.features_off = int(v)
+        elif k == "solver":
+            p.algorithm = {"pdlp": 0, "hipdlp": 1}[v]
+        elif k in ("pdlp_scaling_mode", "pdlp_ruiz_iterations", "pdlp_step_size_strategy"):
+            setattr(p, k[5:], int(v))
         elif k == "device_reduction_order":
             # ORACLE ONLY: sum the reductions in the HIP kernels' order (oracle/pdlp_oracle.c, GPU-ORDER)
             p.reserved[0] = 1 if v else 0

@@ -7,10 +7,11 @@
 #include <limits>
 #include <string>
 
+#include "pdlp_halpern.hpp"
 #include "pdlp_solver.hpp"
 
 struct pdlp_mi355x_solver {
-  pdlp::Solver* impl;
+  pdlp::SolverBase* impl;
 };
 
 namespace {
@@ -57,6 +58,10 @@ void pdlp_mi355x_default_params(pdlp_params_t* opt) {
   opt->log_level = 0;
   opt->device = 0;
   opt->check_interval = 0;
+  opt->algorithm = 0;
+  opt->scaling_mode = 5;        // kPdlpScalingRuiz + kPdlpScalingPC (HighsOptions.h:1345-1349)
+  opt->ruiz_iterations = 10;    // HighsOptions.h:1353-1355
+  opt->step_size_strategy = 1;  // kPdlpStepSizeStrategyAdaptive (HighsOptions.h:1374-1378)
 }
 
 int pdlp_mi355x_create(const pdlp_problem_t* P, const pdlp_params_t* opt, pdlp_mi355x_solver_t** out) {
@@ -68,7 +73,15 @@ int pdlp_mi355x_create_sharded(const pdlp_problem_t* P, const pdlp_params_t* opt
   return guarded([&] {
     if (!P || !opt || !out) throw std::runtime_error("null argument");
     *out = nullptr;
-    pdlp::Solver* s = new pdlp::Solver(*P, *opt, rank, world, id128);
+    pdlp::SolverBase* s = nullptr;
+    if (opt->algorithm == 1) {
+      if (world != 1) throw std::runtime_error("the HiPDLP path (algorithm = 1) is single-GPU");
+      s = new pdlp::HalpernSolver(*P, *opt);
+    } else if (opt->algorithm == 0) {
+      s = new pdlp::Solver(*P, *opt, rank, world, id128);
+    } else {
+      throw std::runtime_error("unknown algorithm (0 = cuPDLP-C path, 1 = HiPDLP path)");
+    }
     *out = new pdlp_mi355x_solver{s};
   });
 }
@@ -151,8 +164,14 @@ int pdlp_mi355x_host_prepare(const pdlp_problem_t* P, const pdlp_params_t* opt, 
     if (!P || !opt || !out) throw std::runtime_error("null argument");
     memset(out, 0, sizeof(*out));
     pdlp::StandardForm F;
-    pdlp::formulate(*P, F);
-    if (!(opt->features_off & PDLP_FEATURE_SCALING_OFF)) pdlp::scale(F);
+    if (opt->algorithm == 1) {  // HiPDLP form: rhs = row lower bounds (row upper bounds are not exported)
+      pdlp::formulateHipdlp(*P, F);
+      if (!(opt->features_off & PDLP_FEATURE_SCALING_OFF))
+        pdlp::scaleHipdlp(F, opt->scaling_mode & 1, opt->scaling_mode & 4, opt->scaling_mode & 2, opt->ruiz_iterations);
+    } else {
+      pdlp::formulate(*P, F);
+      if (!(opt->features_off & PDLP_FEATURE_SCALING_OFF)) pdlp::scale(F);
+    }
     pdlp::finalize(F);
     out->n = F.n; out->m = F.m; out->n_eqs = F.nEqs; out->n_orig = F.n0; out->nnz = F.nnz;
     out->csr_beg = dupVec(F.csr.beg); out->csr_idx = dupVec(F.csr.idx); out->csr_val = dupVec(F.csr.val);

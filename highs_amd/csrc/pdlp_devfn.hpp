@@ -55,7 +55,7 @@ __device__ __attribute__((unused)) double reducePartials(const double* __restric
 // Accept/reject and step-size update of PDHG_Update_Iterate_Adaptive_Step_Size
 // (cupdlp_step.c:237-306), the bookkeeping of PDHG_Update_Average (:433-441)
 // and the parity flip that the reference gets from ++nIter.  One thread.
-__device__ void decideUpdate(DevState* st, double dX2, double dY2, double inter) {
+__device__ __attribute__((unused)) void decideUpdate(DevState* st, double dX2, double dY2, double inter) {
   DevState s = *st;
   const double sb = sqrt(s.beta);
   const double movement = dX2 * 0.5 * sb + dY2 / (2.0 * sb);

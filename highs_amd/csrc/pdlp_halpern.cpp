@@ -1,0 +1,553 @@
+// pdlp_halpern.cpp — see pdlp_halpern.hpp.  Host control flow of PDLPSolver::solve
+// (hipdlp/pdhg.cc:494-707); every vector lives in HBM.
+#include "pdlp_halpern.hpp"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+
+namespace pdlp {
+
+namespace {
+constexpr int kCheckInterval = 40;  // PDHG_CHECK_INTERVAL, pdhg.cc:32
+constexpr int kStatSlots = 8;       // rows of the partial-sum table
+}  // namespace
+
+double HalpernSolver::elapsed() const {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - solveBeg_).count();
+}
+
+void HalpernSolver::log(int level, const char* fmt, ...) const {
+  if (opt_.log_level < level) return;
+  va_list ap;
+  va_start(ap, fmt);
+  vprintf(fmt, ap);
+  va_end(ap);
+  fflush(stdout);
+}
+
+HalpernSolver::HalpernSolver(const pdlp_problem_t& P, const pdlp_params_t& opt) : opt_(opt) {
+  const auto t0 = std::chrono::steady_clock::now();
+  int nDev = 0;
+  if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0)
+    throw std::runtime_error("pdlp_mi355x: no HIP device available (this library has no CPU fallback)");
+  PDLP_HIP(hipSetDevice(opt_.device));
+  PDLP_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  if (const char* g = getenv("PDLP_MI355X_GRAPH")) useGraph_ = atoi(g) != 0;
+  log(1, "Solving with HiPDLP (restarted Halpern PDHG) on MI355X (gfx950, HIP)\n");
+  if ((opt_.features_off & PDLP_FEATURE_RESTART_OFF) != 0)
+    log(1, "HiPDLP uses Halpern restart only; ignoring the restart-off feature flag.\n");  // pdhg.cc:1846-1852
+  pid_ = opt_.step_size_strategy != 0;  // 0 fixed; everything else runs as PID (pdhg.cc:1856-1864)
+
+  formulateHipdlp(P, F_);
+  if (P.num_col > 0) {
+    origBeg_.assign(P.a_start, P.a_start + P.num_col + 1);
+    origIdx_.assign(P.a_index, P.a_index + origBeg_[P.num_col]);
+    origVal_.assign(P.a_value, P.a_value + origBeg_[P.num_col]);
+    origCost_.assign(P.col_cost, P.col_cost + P.num_col);
+  }
+  if (!(opt_.features_off & PDLP_FEATURE_SCALING_OFF))
+    scaleHipdlp(F_, opt_.scaling_mode & 1, opt_.scaling_mode & 4, opt_.scaling_mode & 2, opt_.ruiz_iterations);
+  finalize(F_);  // rows ascending column; columns are already ascending row
+  const int32_t n = F_.n, m = F_.m;
+  int slabMode = -1;
+  if (const char* g = getenv("PDLP_MI355X_SLAB")) slabMode = atoi(g);
+  dA_.upload(F_.csr, m, n, slabMode, stream_);
+  dAt_.upload(F_.cscSorted, n, m, slabMode, stream_);
+  auto up = [&](DeviceArray<double>& d, const std::vector<double>& h) {
+    d.alloc(h.size());
+    d.upload(h.data(), h.size(), stream_);
+  };
+  up(cost_, F_.cost); up(lower_, F_.lower); up(upper_, F_.upper); up(rl_, F_.rhs); up(ru_, F_.rowUpper);
+  up(colScale_, F_.colScale); up(rowScale_, F_.rowScale);
+  isEq_.alloc((size_t)m);
+  isEq_.upload(F_.rowIsEq.data(), (size_t)m, stream_);
+  for (DeviceArray<double>* d : {&xc_, &xn_, &rx_, &xa_, &slack_, &sp_, &sn_, &outX_, &tmpN_}) { d->alloc(n); d->zero(stream_); }
+  for (DeviceArray<double>* d : {&yc_, &yn_, &ry_, &ya_, &outY_, &tmpM_, &tmpM2_}) { d->alloc(m); d->zero(stream_); }
+  stride_ = std::max(vecBlocks(std::max(n, 1)), vecBlocks(std::max(m, 1)));
+  part_.alloc((size_t)kStatSlots * stride_);
+  statOut_.alloc(kStatSlots);
+  dState_.alloc(1);
+  PDLP_HIP(hipHostMalloc((void**)&hostState_, sizeof(HalpernState), hipHostMallocDefault));
+  PDLP_HIP(hipHostMalloc((void**)&hostStats_, sizeof(double) * kStatSlots, hipHostMallocDefault));
+  memset(hostState_, 0, sizeof(HalpernState));
+  PDLP_HIP(hipStreamSynchronize(stream_));
+  F_.csc = Compressed(); F_.csr = Compressed(); F_.cscSorted = Compressed();
+  reset();
+  setupSeconds_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+HalpernSolver::~HalpernSolver() {
+  if (graphExec_) (void)hipGraphExecDestroy(graphExec_);
+  if (hostState_) (void)hipHostFree(hostState_);
+  if (hostStats_) (void)hipHostFree(hostStats_);
+  if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+void HalpernSolver::dims(int32_t* n, int32_t* m, int64_t* nnz, int32_t* nEqs) const {
+  if (n) *n = F_.n;
+  if (m) *m = F_.m;
+  if (nnz) *nnz = F_.nnz;
+  if (nEqs) *nEqs = F_.nEqs;
+}
+
+// Deterministic sum of per-block partials, brought to the host.
+double HalpernSolver::sum(const double* partials, int32_t nBlocks) {
+  launchFinalReduce(partials, nBlocks, nBlocks, 1, statOut_.get(), stream_);
+  PDLP_HIP(hipMemcpyAsync(hostStats_, statOut_.get(), sizeof(double), hipMemcpyDeviceToHost, stream_));
+  PDLP_HIP(hipStreamSynchronize(stream_));
+  return hostStats_[0];
+}
+
+// powerMethod, pdhg.cc:1529-1670 (kCuPdlpAATPowerMethod): 20 iterations on A A' from the ones vector
+double HalpernSolver::powerMethod() {
+  const int32_t n = F_.n, m = F_.m;
+  if (n == 0 || m == 0) return 1.0;
+  const int32_t nbM = vecBlocks(m), nbN = vecBlocks(n);
+  double* x = tmpM_.get();   // x_vec / z_vec (rows)
+  double* z = tmpM2_.get();
+  double* y = tmpN_.get();   // y_vec (columns)
+  launchFill(x, 1.0, m, stream_);
+  double lambda = 0.0;
+  for (int it = 0; it < 20; ++it) {
+    launchSpmvPlain(dAt_.view(), x, y, stream_);  // y = A' x
+    launchSpmvPlain(dA_.view(), y, z, stream_);   // z = A y
+    launchDot(z, z, m, part_.get(), nbM, stream_);
+    const double zn = std::sqrt(sum(part_.get(), nbM));
+    launchDivScalar(z, zn, m, stream_);
+    launchSpmvPlain(dAt_.view(), z, y, stream_);  // w = A' q
+    launchDot(y, y, n, part_.get(), nbN, stream_);
+    lambda = sum(part_.get(), nbN);
+    std::swap(x, z);  // x_vec = z_vec
+  }
+  return lambda;
+}
+
+// initializeStepSizes, pdhg.cc:1944-1977
+void HalpernSolver::initStepSizes() {
+  omega_ = (F_.normCost + 1.0) / (F_.normRhs + 1.0);
+  primalWeight_ = omega_;
+  bestPrimalWeight_ = primalWeight_;
+  beta_ = primalWeight_ * primalWeight_;
+  lambda_ = powerMethod();
+  const double base = 0.998 / std::sqrt(lambda_);
+  eta_ = base;
+  hostState_->tau = base / omega_;
+  hostState_->sigma = base * omega_;
+  hostState_->rho = 1.0;  // halpern_gamma, pdhg.cc:1913
+  log(2, "Initial step sizes from power method lambda = %g: primal step = %g; dual step = %g, eta = %g, omega = %g\n",
+      lambda_, hostState_->tau, hostState_->sigma, eta_, omega_);
+}
+
+void HalpernSolver::pushState() {
+  hostState_->hIter = halpernIter_;
+  PDLP_HIP(hipMemcpyAsync(dState_.get(), hostState_, sizeof(HalpernState), hipMemcpyHostToDevice, stream_));
+  PDLP_HIP(hipStreamSynchronize(stream_));
+}
+
+// initializeStepSizes + initialize + the start of solve() (pdhg.cc:499-553)
+void HalpernSolver::reset() {
+  const int32_t n = F_.n, m = F_.m;
+  initStepSizes();
+  bestGap_ = std::numeric_limits<double>::infinity();
+  errSum_ = lastErr_ = 0.0;
+  for (DeviceArray<double>* d : {&xc_, &xn_, &rx_, &xa_, &slack_, &sp_, &sn_, &outX_}) d->zero(stream_);
+  for (DeviceArray<double>* d : {&yc_, &yn_, &ry_, &ya_, &outY_}) d->zero(stream_);
+  launchProjectBounds(xc_.get(), lower_.get(), upper_.get(), n, stream_);  // linalg::projectBounds of x = 0
+  PDLP_HIP(hipMemcpyAsync(xa_.get(), xc_.get(), sizeof(double) * n, hipMemcpyDeviceToDevice, stream_));
+  PDLP_HIP(hipMemcpyAsync(ya_.get(), yc_.get(), sizeof(double) * m, hipMemcpyDeviceToDevice, stream_));
+  halpernIter_ = 0;
+  iters_ = 0;
+  nRestarts_ = nChecks_ = 0;
+  doRestart_ = false;
+  slackValid_ = false;
+  fpe_ = initialFpe_ = 0.0;
+  lastTrialFpe_ = std::numeric_limits<double>::infinity();
+  termStatus_ = -1;
+  haveOutput_ = false;
+  res_ = Res();
+  pushState();
+}
+
+// performHalpernPdhgStep, pdhg.cc:961-1018, as two fused SpMV launches
+void HalpernSolver::enqueueStep(bool major, int32_t kOff) {
+  HalpernVecs h{};
+  h.xc = xc_.get(); h.yc = yc_.get(); h.xn = xn_.get(); h.yn = yn_.get(); h.rx = rx_.get(); h.ry = ry_.get();
+  h.xa = xa_.get(); h.ya = ya_.get(); h.slack = slack_.get();
+  h.cost = cost_.get(); h.lower = lower_.get(); h.upper = upper_.get(); h.rowLower = rl_.get(); h.rowUpper = ru_.get();
+  h.hs = dState_.get();
+  h.kOff = kOff;
+  h.major = major ? 1 : 0;
+  launchHalpernPrimal(dAt_.view(), h, stream_);
+  launchHalpernDual(dA_.view(), h, stream_);
+}
+
+// One block of the main loop (pdhg.cc:578-641): major step 1, [fixed-point error if a restart
+// just happened], minor steps 2..39, major step 40.
+void HalpernSolver::runBlock(bool fpeAfterFirst) {
+  pushState();
+  enqueueStep(true, 1);
+  slackValid_ = true;
+  if (fpeAfterFirst) {
+    fpe_ = fixedPointError();
+    initialFpe_ = fpe_;
+  }
+  if (useGraph_) {
+    if (!graphExec_) {
+      hipGraph_t graph = nullptr;
+      PDLP_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+      for (int i = 2; i <= kCheckInterval - 1; ++i) enqueueStep(false, i);
+      enqueueStep(true, kCheckInterval);
+      PDLP_HIP(hipStreamEndCapture(stream_, &graph));
+      PDLP_HIP(hipGraphInstantiate(&graphExec_, graph, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(graph);
+    }
+    PDLP_HIP(hipGraphLaunch(graphExec_, stream_));
+  } else {
+    for (int i = 2; i <= kCheckInterval - 1; ++i) enqueueStep(false, i);
+    enqueueStep(true, kCheckInterval);
+  }
+}
+
+// computeFixedPointError, pdhg.cc:709-739
+double HalpernSolver::fixedPointError() {
+  const int32_t n = F_.n, m = F_.m;
+  const int32_t nbM = vecBlocks(std::max(m, 1)), nbN = vecBlocks(std::max(n, 1));
+  double* part = part_.get();
+  launchHalpernFpeRows(yn_.get(), ry_.get(), tmpM_.get(), m, part, nbM, stream_);
+  launchSpmvPlain(dAt_.view(), tmpM_.get(), tmpN_.get(), stream_);
+  launchHalpernFpeCols(xn_.get(), rx_.get(), tmpN_.get(), n, part + stride_, part + 2 * (size_t)stride_, nbN, stream_);
+  launchFinalReduce(part, stride_, nbM, 1, statOut_.get(), stream_);
+  launchFinalReduce(part + stride_, stride_, nbN, 2, statOut_.get() + 1, stream_);
+  PDLP_HIP(hipMemcpyAsync(hostStats_, statOut_.get(), sizeof(double) * 3, hipMemcpyDeviceToHost, stream_));
+  PDLP_HIP(hipStreamSynchronize(stream_));
+  const double dn = hostStats_[0], pn = hostStats_[1], cross = hostStats_[2];
+  const double movement = pn * omega_ + dn / omega_;
+  const double interaction = 2.0 * eta_ * cross;
+  return std::sqrt(std::max(0.0, movement + interaction));
+}
+
+// runConvergenceCheck's "current" leg (pdhg.cc:820-833) + checkConvergence (:1474-1527)
+bool HalpernSolver::check(const double* x, const double* y, bool cachedSlack, Res& r) {
+  const int32_t n = F_.n, m = F_.m;
+  const int32_t nbM = vecBlocks(std::max(m, 1)), nbN = vecBlocks(std::max(n, 1));
+  const int sc = F_.scaled ? 1 : 0;
+  double* part = part_.get();
+  launchSpmvPlain(dA_.view(), x, tmpM_.get(), stream_);
+  launchSpmvPlain(dAt_.view(), y, tmpN_.get(), stream_);
+  launchHalpernRowStats(tmpM_.get(), y, rl_.get(), rowScale_.get(), isEq_.get(), m, sc, part, stride_, nbM, stream_);
+  launchHalpernColStats(tmpN_.get(), x, cost_.get(), lower_.get(), upper_.get(), colScale_.get(),
+                        cachedSlack ? slack_.get() : nullptr, n, sc, sp_.get(), sn_.get(),
+                        part + (size_t)kHRowStats * stride_, stride_, nbN, stream_);
+  launchFinalReduce(part, stride_, nbM, kHRowStats, statOut_.get(), stream_);
+  launchFinalReduce(part + (size_t)kHRowStats * stride_, stride_, nbN, kHColStats, statOut_.get() + kHRowStats, stream_);
+  PDLP_HIP(hipMemcpyAsync(hostStats_, statOut_.get(), sizeof(double) * (kHRowStats + kHColStats), hipMemcpyDeviceToHost,
+                          stream_));
+  PDLP_HIP(hipStreamSynchronize(stream_));
+  ++nChecks_;
+  const double* rs = hostStats_;
+  const double* cs = hostStats_ + kHRowStats;
+  r.pFeas = std::sqrt(rs[0]);
+  r.dFeas = std::sqrt(cs[0]);
+  r.pObj = F_.offset + cs[1];
+  r.dObj = ((F_.offset + rs[1]) + cs[2]) - cs[3];
+  const double gap = r.pObj - r.dObj;
+  r.gap = std::fabs(gap);
+  r.relGap = std::fabs(gap) / (1.0 + std::fabs(r.pObj) + std::fabs(r.dObj));
+  const double eps = opt_.gap_tol;  // params_.tolerance
+  return r.pFeas < eps * (1.0 + F_.normRhs) && r.dFeas < eps * (1.0 + F_.normCost) && r.relGap < eps;
+}
+
+// checkRestartCriteria, pdhg.cc:901-927 (factors restart.hpp:91-93)
+bool HalpernSolver::restartCriteria() const {
+  if (iters_ == kCheckInterval) return true;
+  if (iters_ > kCheckInterval) {
+    if (fpe_ <= 0.2 * initialFpe_) return true;
+    if (fpe_ <= 0.8 * initialFpe_ && fpe_ > lastTrialFpe_) return true;
+    if ((double)halpernIter_ >= 0.36 * (double)iters_) return true;
+  }
+  return false;
+}
+
+// updatePrimalWeightAtRestart, pdhg.cc:1979-2049
+void HalpernSolver::updatePrimalWeight(const Res& r) {
+  const int32_t n = F_.n, m = F_.m;
+  const int32_t nbM = vecBlocks(std::max(m, 1)), nbN = vecBlocks(std::max(n, 1));
+  launchDiffNorm2(xn_.get(), xa_.get(), n, part_.get(), nbN, stream_);
+  launchDiffNorm2(yn_.get(), ya_.get(), m, part_.get() + stride_, nbM, stream_);
+  launchFinalReduce(part_.get(), stride_, nbN, 1, statOut_.get(), stream_);
+  launchFinalReduce(part_.get() + stride_, stride_, nbM, 1, statOut_.get() + 1, stream_);
+  PDLP_HIP(hipMemcpyAsync(hostStats_, statOut_.get(), sizeof(double) * 2, hipMemcpyDeviceToHost, stream_));
+  PDLP_HIP(hipStreamSynchronize(stream_));
+  const double primalDist = std::sqrt(hostStats_[0]), dualDist = std::sqrt(hostStats_[1]);
+  const double relP = r.pFeas / (1.0 + F_.normRhs), relD = r.dFeas / (1.0 + F_.normCost);
+  const double ratio = relP > 0.0 ? relD / relP : 1e300;
+  if (primalDist > 1e-16 && dualDist > 1e-16 && primalDist < 1e12 && dualDist < 1e12 && ratio > 1e-8 && ratio < 1e8) {
+    const double err = std::log(dualDist) - std::log(primalDist) - std::log(primalWeight_);
+    errSum_ = 0.3 * errSum_ + err;                // i_smooth
+    const double dErr = err - lastErr_;
+    primalWeight_ *= std::exp(0.99 * err + 0.01 * errSum_ + 0.0 * dErr);  // k_p, k_i, k_d
+    lastErr_ = err;
+  } else {
+    primalWeight_ = bestPrimalWeight_;
+    errSum_ = 0.0;
+    lastErr_ = 0.0;
+  }
+  const double gap = (relP > 0.0 && relD > 0.0) ? std::fabs(std::log10(relD / relP)) : bestGap_;
+  if (gap < bestGap_) { bestGap_ = gap; bestPrimalWeight_ = primalWeight_; }
+  const double eta = std::sqrt(hostState_->tau * hostState_->sigma);
+  beta_ = primalWeight_ * primalWeight_;
+  hostState_->tau = eta / primalWeight_;
+  hostState_->sigma = eta * primalWeight_;
+  omega_ = std::sqrt(beta_);  // params_.omega = primal_weight_, then RestartScheme::updateBeta
+}
+
+// pdhg.cc:663-692: anchor and current iterate <- pdhg iterate of the last major step
+void HalpernSolver::restart() {
+  const int32_t n = F_.n, m = F_.m;
+  if (pid_) updatePrimalWeight(res_);
+  PDLP_HIP(hipMemcpyAsync(xa_.get(), xn_.get(), sizeof(double) * n, hipMemcpyDeviceToDevice, stream_));
+  PDLP_HIP(hipMemcpyAsync(ya_.get(), yn_.get(), sizeof(double) * m, hipMemcpyDeviceToDevice, stream_));
+  PDLP_HIP(hipMemcpyAsync(xc_.get(), xn_.get(), sizeof(double) * n, hipMemcpyDeviceToDevice, stream_));
+  PDLP_HIP(hipMemcpyAsync(yc_.get(), yn_.get(), sizeof(double) * m, hipMemcpyDeviceToDevice, stream_));
+  halpernIter_ = 0;
+  lastTrialFpe_ = std::numeric_limits<double>::infinity();
+  ++nRestarts_;
+}
+
+// PDLPSolver::solve, pdhg.cc:494-707.  terminate = false: fixed-work loop for timing (same
+// kernels, checks and restarts; convergence is ignored).
+void HalpernSolver::doSolve(bool terminate, int64_t iterTarget) {
+  const int32_t n = F_.n, m = F_.m;
+  auto keepOutput = [&](const double* x, const double* y) {
+    PDLP_HIP(hipMemcpyAsync(outX_.get(), x, sizeof(double) * n, hipMemcpyDeviceToDevice, stream_));
+    PDLP_HIP(hipMemcpyAsync(outY_.get(), y, sizeof(double) * m, hipMemcpyDeviceToDevice, stream_));
+    haveOutput_ = true;
+  };
+  if (iters_ == 0 && terminate) {  // initial convergence check, pdhg.cc:563-570
+    Res r;
+    if (check(xc_.get(), yc_.get(), false, r)) {
+      keepOutput(xc_.get(), yc_.get());
+      res_ = r;
+      termStatus_ = 0;
+      return;
+    }
+    res_ = r;
+  }
+  const int64_t limit = terminate ? (int64_t)opt_.iter_limit : iterTarget;
+  while (iters_ < limit) {
+    if (terminate && elapsed() > opt_.time_limit) { termStatus_ = 2; return; }
+    runBlock(doRestart_);
+    doRestart_ = false;
+    fpe_ = fixedPointError();
+    halpernIter_ += kCheckInterval;
+    iters_ += kCheckInterval;
+    Res r;
+    const bool converged = check(xn_.get(), yn_.get(), slackValid_, r);
+    res_ = r;
+    if (opt_.log_level > 1)
+      printf("%9lld  %+15.8e  %+15.8e  %8.2e  %10.2e  %8.2e  fpe %8.2e  w %8.2e\n", (long long)iters_, r.pObj, r.dObj,
+             r.relGap, r.pFeas / (1.0 + F_.normRhs), r.dFeas / (1.0 + F_.normCost), fpe_, primalWeight_);
+    if (converged && terminate) {
+      keepOutput(xn_.get(), yn_.get());
+      termStatus_ = 0;
+      return;
+    }
+    doRestart_ = restartCriteria();
+    lastTrialFpe_ = fpe_;
+    if (doRestart_) restart();
+  }
+  if (terminate) termStatus_ = 1;
+}
+
+void HalpernSolver::run(pdlp_result_t* R) {
+  reset();
+  solveBeg_ = std::chrono::steady_clock::now();
+  doSolve(true, 0);
+  solveSeconds_ = elapsed();
+  if (opt_.log_level > 0)
+    printf("\nHiPDLP: %s after %lld iterations (%d restarts): primal obj %+.10e, dual obj %+.10e, rel gap %.2e\n",
+           termStatus_ == 0 ? "converged" : termStatus_ == 2 ? "time limit" : "iteration limit", (long long)iters_,
+           nRestarts_, res_.pObj, res_.dObj, res_.relGap);
+  if (R) postsolve(R);
+}
+
+void HalpernSolver::iterate(int32_t nIters, pdlp_iter_stats_t* st) {
+  const int64_t it0 = iters_;
+  const int32_t ck0 = nChecks_, rs0 = nRestarts_;
+  solveBeg_ = std::chrono::steady_clock::now();
+  hipEvent_t e0, e1;
+  PDLP_HIP(hipEventCreate(&e0));
+  PDLP_HIP(hipEventCreate(&e1));
+  PDLP_HIP(hipEventRecord(e0, stream_));
+  const int64_t blocks = ((int64_t)nIters + kCheckInterval - 1) / kCheckInterval;
+  doSolve(false, it0 + blocks * kCheckInterval);
+  PDLP_HIP(hipEventRecord(e1, stream_));
+  PDLP_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  PDLP_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (st) {
+    memset(st, 0, sizeof(*st));
+    st->iters = (int32_t)(iters_ - it0);
+    st->trials = st->iters;
+    st->checks = nChecks_ - ck0;
+    st->restarts = nRestarts_ - rs0;
+    st->gpu_ms = ms;
+    st->wall_ms = elapsed() * 1e3;
+  }
+}
+
+// unscaleSolution (pdhg.cc:1883-1897, scaling.cc:264-278) + postprocess (pdhg.cc:359-492)
+void HalpernSolver::postsolve(pdlp_result_t* R) {
+  const int32_t n = F_.n, m = F_.m, n0 = F_.n0;
+  std::vector<double> x(n, 0.0), y(m, 0.0), sp(n), sn(n);
+  // only a converged check writes the output vectors (pdhg.cc:866-877): otherwise they are the zero start
+  if (haveOutput_) {
+    outX_.download(x.data(), n, stream_);
+    outY_.download(y.data(), m, stream_);
+  }
+  sp_.download(sp.data(), n, stream_);
+  sn_.download(sn.data(), n, stream_);
+  PDLP_HIP(hipStreamSynchronize(stream_));
+  if (F_.scaled) {
+    for (int32_t j = 0; j < n; ++j) x[j] /= F_.colScale[j];
+    for (int32_t i = 0; i < m; ++i) y[i] /= F_.rowScale[i];
+  }
+  for (int32_t j = 0; j < n; ++j) { sp[j] *= F_.colScale[j]; sn[j] *= F_.colScale[j]; }
+  if (R->col_value) std::copy(x.begin(), x.begin() + n0, R->col_value);
+  if (R->row_dual)
+    for (int32_t i = 0; i < m; ++i) {
+      const double v = y[F_.rowNewIdx[i]];
+      R->row_dual[i] = F_.rowKind[i] == kRowLeq ? -v : v;
+    }
+  if (R->col_dual)
+    for (int32_t j = 0; j < n0; ++j) R->col_dual[j] = (sp[j] - sn[j]) * F_.sense;
+  if (R->row_value) {  // A_original x over the original columns, column by column (:447-468)
+    std::fill(R->row_value, R->row_value + m, 0.0);
+    for (int32_t c = 0; c < n0; ++c)
+      for (int32_t p = origBeg_[c]; p < origBeg_[c + 1]; ++p) R->row_value[origIdx_[p]] += origVal_[p] * x[c];
+  }
+  double finalObj = F_.offset;  // results_.primal_obj, :409-414
+  for (int32_t c = 0; c < n0; ++c) finalObj += origCost_[c] * x[c];
+  res_.pObj = finalObj;
+  R->value_valid = 1;
+  R->dual_valid = 1;
+  R->term_code = termStatus_ == 0 ? PDLP_TERM_OPTIMAL : PDLP_TERM_TIMELIMIT_OR_ITERLIMIT;
+  R->reserved_i = termStatus_ == 2 ? 1 : 0;
+  R->term_iterate = 0;
+  R->num_iter = (int32_t)std::min<int64_t>(iters_, INT_MAX);
+  R->num_trials = 0;
+  R->num_restarts = nRestarts_;
+  R->primal_obj = res_.pObj; R->dual_obj = res_.dObj; R->primal_feas = res_.pFeas; R->dual_feas = res_.dFeas;
+  R->rel_gap = res_.relGap; R->norm_rhs = F_.normRhs; R->norm_cost = F_.normCost;
+  R->setup_seconds = setupSeconds_;
+  R->solve_seconds = solveSeconds_;
+}
+
+std::pair<double*, int64_t> HalpernSolver::lookup(const std::string& name) {
+  const int64_t n = F_.n, m = F_.m;
+  if (name == "x") return {xc_.get(), n};
+  if (name == "y") return {yc_.get(), m};
+  if (name == "x_next") return {xn_.get(), n};
+  if (name == "y_next") return {yn_.get(), m};
+  if (name == "x_reflected") return {rx_.get(), n};
+  if (name == "y_reflected") return {ry_.get(), m};
+  if (name == "x_anchor") return {xa_.get(), n};
+  if (name == "y_anchor") return {ya_.get(), m};
+  if (name == "dual_slack") return {slack_.get(), n};
+  if (name == "cost") return {cost_.get(), n};
+  if (name == "lower") return {lower_.get(), n};
+  if (name == "upper") return {upper_.get(), n};
+  if (name == "rhs" || name == "row_lower") return {rl_.get(), m};
+  if (name == "row_upper") return {ru_.get(), m};
+  if (name == "col_scale") return {colScale_.get(), n};
+  if (name == "row_scale") return {rowScale_.get(), m};
+  throw std::runtime_error("unknown vector name: " + name);
+}
+
+void HalpernSolver::getVector(const std::string& name, double* host, int64_t len) {
+  if (name == "steps") {  // {tau, sigma, omega, eta, lambda, primal weight, fpe, initial fpe}
+    const double v[8] = {hostState_->tau, hostState_->sigma, omega_, eta_, lambda_, primalWeight_, fpe_, initialFpe_};
+    for (int64_t i = 0; i < len && i < 8; ++i) host[i] = v[i];
+    return;
+  }
+  auto [p, l] = lookup(name);
+  if (l != len) throw std::runtime_error("length mismatch for vector " + name);
+  PDLP_HIP(hipMemcpyAsync(host, p, sizeof(double) * len, hipMemcpyDeviceToHost, stream_));
+  PDLP_HIP(hipStreamSynchronize(stream_));
+}
+
+void HalpernSolver::setVector(const std::string& name, const double* host, int64_t len) {
+  if (name == "steps") {  // {tau, sigma}: impose step sizes (parity tests)
+    if (len < 2) throw std::runtime_error("steps needs tau, sigma");
+    hostState_->tau = host[0];
+    hostState_->sigma = host[1];
+    pushState();
+    return;
+  }
+  auto [p, l] = lookup(name);
+  if (l != len) throw std::runtime_error("length mismatch for vector " + name);
+  PDLP_HIP(hipMemcpyAsync(p, host, sizeof(double) * len, hipMemcpyHostToDevice, stream_));
+  PDLP_HIP(hipStreamSynchronize(stream_));
+}
+
+void HalpernSolver::stage(const std::string& name, double* out, int32_t cap) {
+  auto put = [&](int i, double v) { if (out && i < cap) out[i] = v; };
+  if (name == "block") {  // one block of 40 steps from the current state, then the fixed-point error
+    runBlock(false);
+    fpe_ = fixedPointError();
+    put(0, fpe_);
+  } else if (name == "steps") {  // out[0] = number of steps (1..40), the last one major: returns nothing
+    const int k = out && cap > 0 ? (int)out[0] : kCheckInterval;
+    if (k < 1 || k > kCheckInterval) throw std::runtime_error("steps: 1..40");
+    pushState();
+    for (int i = 1; i <= k; ++i) enqueueStep(i == 1 || i == k, i);
+  } else if (name == "exchange") {
+    put(0, 0.0);
+  } else if (name == "profile_on" || name == "profile_off") {
+    // (no in-loop event timing on this path: use time_kernel)
+  } else {
+    throw std::runtime_error("unknown stage: " + name);
+  }
+  PDLP_HIP(hipStreamSynchronize(stream_));
+}
+
+double HalpernSolver::timeKernel(const std::string& name, int32_t reps) {
+  if (reps < 1) reps = 1;
+  pushState();
+  HalpernVecs h{};
+  h.xc = xc_.get(); h.yc = yc_.get(); h.xn = xn_.get(); h.yn = yn_.get(); h.rx = rx_.get(); h.ry = ry_.get();
+  h.xa = xa_.get(); h.ya = ya_.get(); h.slack = slack_.get();
+  h.cost = cost_.get(); h.lower = lower_.get(); h.upper = upper_.get(); h.rowLower = rl_.get(); h.rowUpper = ru_.get();
+  h.hs = dState_.get();
+  h.kOff = 2;
+  h.major = 0;
+  auto once = [&]() {
+    if (name == "spmv_aty" || name == "halpern_primal") launchHalpernPrimal(dAt_.view(), h, stream_);
+    else if (name == "spmv_ax" || name == "halpern_dual") launchHalpernDual(dA_.view(), h, stream_);
+    else if (name == "trial") enqueueStep(false, 2);
+    else throw std::runtime_error("unknown kernel: " + name);
+  };
+  for (int i = 0; i < 3; ++i) once();
+  hipEvent_t e0, e1;
+  PDLP_HIP(hipEventCreate(&e0));
+  PDLP_HIP(hipEventCreate(&e1));
+  PDLP_HIP(hipEventRecord(e0, stream_));
+  for (int i = 0; i < reps; ++i) once();
+  PDLP_HIP(hipEventRecord(e1, stream_));
+  PDLP_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  PDLP_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return (double)ms / reps;
+}
+
+}  // namespace pdlp

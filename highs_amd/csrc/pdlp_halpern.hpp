@@ -1,0 +1,97 @@
+// pdlp_halpern.hpp — device-resident driver of the reference's second PDLP path, solver="hipdlp"
+// (highs/pdlp/HiPdlpWrapper.cpp, hipdlp/pdhg.cc): restarted Halpern PDHG with reflection, fixed
+// step sizes from a power method, PID-controlled primal weight.  One Halpern step is TWO launches —
+// the A'y SpMV with the primal projection/reflection/blend as its epilogue, and the A x SpMV with
+// the dual ones — and a block of 40 steps replays from a hipGraph; the host only acts at the
+// reference's check iterations (every PDHG_CHECK_INTERVAL = 40 steps, pdhg.cc:32).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <string>
+#include <vector>
+
+#include "pdlp_solver.hpp"
+
+namespace pdlp {
+
+// vector kernels of the check iterations (pdlp_halpern.hip); partial layouts as in pdlp_kernels.hpp
+void launchHalpernFpeRows(const double* yn, const double* ry, double* dy, int32_t m, double* part, int32_t nBlocks,
+                          hipStream_t s);
+void launchHalpernFpeCols(const double* xn, const double* rx, const double* atd, int32_t n, double* partDx2,
+                          double* partCross, int32_t nBlocks, hipStream_t s);
+constexpr int kHRowStats = 2;  // 0: sum (((ax - rl) [min 0 on inequality rows]) * rowScale)^2   1: sum rl*y
+void launchHalpernRowStats(const double* ax, const double* y, const double* rl, const double* rowScale,
+                           const uint8_t* isEq, int32_t m, int scaled, double* part, int32_t stride, int32_t nBlocks,
+                           hipStream_t s);
+constexpr int kHColStats = 4;  // 0: sum ((c - A'y - s+ + s-) * colScale)^2  1: sum c*x  2: sum l*s+  3: sum u*s-
+void launchHalpernColStats(const double* aty, const double* x, const double* cost, const double* lower,
+                           const double* upper, const double* colScale, const double* cachedSlack, int32_t n,
+                           int scaled, double* sp, double* sn, double* part, int32_t stride, int32_t nBlocks,
+                           hipStream_t s);
+void launchDivScalar(double* v, double denom, int32_t len, hipStream_t s);  // v[i] /= denom
+
+class HalpernSolver : public SolverBase {
+ public:
+  HalpernSolver(const pdlp_problem_t& P, const pdlp_params_t& opt);
+  ~HalpernSolver() override;
+  void run(pdlp_result_t* R) override;
+  void iterate(int32_t nIters, pdlp_iter_stats_t* st) override;
+  void reset() override;
+  void dims(int32_t* n, int32_t* m, int64_t* nnz, int32_t* nEqs) const override;
+  void getVector(const std::string& name, double* host, int64_t len) override;
+  void setVector(const std::string& name, const double* host, int64_t len) override;
+  void stage(const std::string& name, double* out, int32_t cap) override;
+  double timeKernel(const std::string& name, int32_t reps) override;
+
+ private:
+  struct Res { double pObj = 0, dObj = 0, gap = 0, relGap = 0, pFeas = 0, dFeas = 0; };
+  double powerMethod();
+  void initStepSizes();
+  void pushState();
+  void enqueueStep(bool major, int32_t kOff);
+  void runBlock(bool fpeAfterFirst);           // steps 1..40 of one block
+  double fixedPointError();
+  bool check(const double* x, const double* y, bool cachedSlack, Res& r);  // A x, A'y + checkConvergence
+  void updatePrimalWeight(const Res& r);
+  void restart();
+  bool restartCriteria() const;
+  void doSolve(bool terminate, int64_t iterTarget);
+  void postsolve(pdlp_result_t* R);
+  double sum(const double* partials, int32_t nBlocks);
+  double elapsed() const;
+  void log(int level, const char* fmt, ...) const;
+  std::pair<double*, int64_t> lookup(const std::string& name);
+
+  pdlp_params_t opt_;
+  StandardForm F_;
+  // the caller's LP (postprocess computes row activities and the objective from it, pdhg.cc:409-468)
+  std::vector<int32_t> origBeg_, origIdx_;
+  std::vector<double> origVal_, origCost_;
+  hipStream_t stream_ = nullptr;
+  DeviceMatrix dA_, dAt_;
+  DeviceArray<double> xc_, yc_, xn_, yn_, rx_, ry_, xa_, ya_, slack_, sp_, sn_, outX_, outY_;
+  DeviceArray<double> cost_, lower_, upper_, rl_, ru_, colScale_, rowScale_, tmpN_, tmpM_, tmpM2_;
+  DeviceArray<uint8_t> isEq_;
+  DeviceArray<double> part_, statOut_;
+  DeviceArray<HalpernState> dState_;
+  HalpernState* hostState_ = nullptr;  // pinned
+  double* hostStats_ = nullptr;        // pinned
+  int32_t stride_ = 0;
+  // host scalars of PDLPSolver (pdhg.hpp)
+  double eta_ = 0, omega_ = 0, beta_ = 0, primalWeight_ = 0, bestPrimalWeight_ = 0, bestGap_ = 0;
+  double errSum_ = 0, lastErr_ = 0, lambda_ = 0;
+  double fpe_ = 0, initialFpe_ = 0, lastTrialFpe_ = 0;
+  bool doRestart_ = false, slackValid_ = false, pid_ = true;
+  int32_t halpernIter_ = 0, nRestarts_ = 0, nChecks_ = 0;
+  int64_t iters_ = 0;
+  int termStatus_ = -1;  // -1 not set, 0 optimal, 1 iteration limit, 2 time limit
+  bool haveOutput_ = false;
+  Res res_;
+  hipGraphExec_t graphExec_ = nullptr;
+  bool useGraph_ = true;
+  std::chrono::steady_clock::time_point solveBeg_;
+  double setupSeconds_ = 0, solveSeconds_ = 0;
+};
+
+}  // namespace pdlp

@@ -35,6 +35,8 @@ struct StandardForm {
   Compressed csr;     // rows with ascending column index
   Compressed cscSorted;  // columns with ascending row index (device copy for A'y)
   std::vector<double> cost, rhs, lower, upper;
+  std::vector<double> rowUpper;  // HiPDLP form only (rhs is then the row LOWER bound)
+  std::vector<uint8_t> rowIsEq;  // HiPDLP form only: per PERMUTED row (is_equality_row_)
   std::vector<int32_t> rowKind;    // per ORIGINAL row
   std::vector<int32_t> rowNewIdx;  // original row -> permuted row
   std::vector<double> colScale, rowScale;
@@ -48,6 +50,16 @@ struct StandardForm {
 void formulate(const pdlp_problem_t& P, StandardForm& F);
 void scale(StandardForm& F, int ruizTimes = 10, double pcAlpha = 1.0);
 void finalize(StandardForm& F);  // CSR + row-sorted CSC + matNormInf
+
+// ---- HiPDLP path (solver="hipdlp") -------------------------------------------------------------
+// preprocessLp, hipdlp/pdhg.cc:152-357: same row kinds as above but classified with +-inf (not 1e20),
+// free rows get their own kind (4), rows keep BOTH bounds (rhs = row_lower, rowUpper), the costs do
+// NOT take the objective sense, and column entries are sorted by permuted row index.
+enum { kRowFree = 4 };
+void formulateHipdlp(const pdlp_problem_t& P, StandardForm& F);
+// Scaling::scaleProblem, hipdlp/scaling.cc:31-262: Ruiz (inf-norm) x ruizIters, Pock-Chambolle
+// (alpha 1), L2 — each optional (pdlp_scaling_mode bits 1, 4, 2).
+void scaleHipdlp(StandardForm& F, bool ruiz, bool pc, bool l2, int ruizIters);
 
 // Contiguous row blocks balanced by nonzeros: returns world+1 row offsets.
 std::vector<int32_t> rowPartition(const Compressed& csr, int32_t m, int32_t world);

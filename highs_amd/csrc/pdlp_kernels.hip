@@ -21,7 +21,8 @@ namespace pdlp {
 
 namespace {
 
-enum Epilogue { kPlain = 0, kDualStep = 1, kAtyInteract = 2, kAtyPartial = 3 };
+enum Epilogue { kPlain = 0, kDualStep = 1, kAtyInteract = 2, kAtyPartial = 3, kHalpernPrimal = 4, kHalpernDual = 5 };
+constexpr bool usesDevState(int epi) { return epi == kDualStep || epi == kAtyInteract || epi == kAtyPartial; }
 
 struct SpmvArgs {
   SpmvMat A;
@@ -34,7 +35,45 @@ struct SpmvArgs {
   IterVecs v;
   double* part0;  // dY^2 (dual) | dX^2 (aty)
   double* part1;  // interaction (aty)
+  HalpernVecs h;  // kHalpernPrimal / kHalpernDual
 };
+
+// Epilogue operands that do not depend on the SpMV result.
+struct Pre { double a, b, c, d, e; };
+
+// HiPDLP step, column side (pdhg.cc:975-990 and :1008-1011): s = (A'y)_j.
+__device__ __forceinline__ void halpernPrimal(const HalpernVecs& h, int j, double s, const Pre& p, double tau,
+                                              double rho, double w) {
+  const double xc = p.a, cost = p.b, xa = p.c, l = p.d, u = p.e;
+  const double temp = xc - tau * (cost - s);
+  const double t = (u < temp) ? u : temp;  // std::min(temp, u)
+  const double proj = (l < t) ? t : l;     // std::max(l, .)   (linalg::projectBox)
+  if (h.major) {
+    h.xn[j] = proj;
+    h.slack[j] = (proj - temp) / tau;
+  }
+  const double rx = 2.0 * proj - xc;
+  h.rx[j] = rx;
+  const double blended = rho * rx + (1.0 - rho) * xc;
+  h.xc[j] = w * blended + (1.0 - w) * xa;
+}
+// HiPDLP step, row side (pdhg.cc:995-1006 and :1012-1015): s = (A reflected_x)_i.
+__device__ __forceinline__ void halpernDual(const HalpernVecs& h, int i, double s, const Pre& p, double sigma,
+                                            double rho, double w) {
+  const double yc = p.a, ya = p.b, rl = p.c, ru = p.d;
+  const double temp = yc / sigma - s;
+  const double lo = -ru, up = -rl;
+  const double t = (up < temp) ? up : temp;
+  const double proj = (lo < t) ? t : lo;
+  const double pd = (temp - proj) * sigma;
+  const double ry = 2.0 * pd - yc;
+  if (h.major) {
+    h.yn[i] = pd;
+    h.ry[i] = ry;
+  }
+  const double blended = rho * ry + (1.0 - rho) * yc;
+  h.yc[i] = w * blended + (1.0 - w) * ya;
+}
 
 // CSR-adaptive SpMV (stream + long-row paths) with a fused, major-local epilogue.
 // One work block = up to kChunk consecutive nonzeros belonging to whole majors.
@@ -52,7 +91,7 @@ __device__ __forceinline__ T ldUniform(const T* p) {
 template <int EPI, bool MAPPED>
 __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
   const DevState* st = a.st;
-  if (EPI != kPlain && st->halted) return;
+  if (usesDevState(EPI) && st->halted) return;
   __shared__ double prod[kChunk + kChunk / 8 + 8];
   __shared__ double scratch[2][kSpmvThreads / kWave];
 
@@ -65,29 +104,41 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
 
   int cur = 0, nxt = 1;
   double sigma = 0.0, avgW = 0.0;
-  if (EPI != kPlain) {
+  if (usesDevState(EPI)) {
     cur = st->cur;
     nxt = cur ^ 1;
     sigma = st->sigma;
     avgW = st->avgW;
   }
+  double hTau = 0.0, hRho = 1.0, hW = 0.0;
+  if (EPI == kHalpernPrimal || EPI == kHalpernDual) {
+    const HalpernState hs = *a.h.hs;
+    hTau = hs.tau; sigma = hs.sigma; hRho = hs.rho;
+    const int k = hs.hIter + a.h.kOff;
+    hW = (double)k / ((double)k + 1.0);
+  }
   const double* __restrict__ in;
   if (EPI == kPlain) in = a.in;
   else if (EPI == kDualStep) in = a.v.x[nxt];
+  else if (EPI == kHalpernPrimal) in = a.h.yc;
+  else if (EPI == kHalpernDual) in = a.h.rx;
   else in = a.v.y[nxt];
 
   double acc0 = 0.0, acc1 = 0.0;  // per-thread epilogue partials
 
   // Epilogue operands that do not depend on the SpMV result are fetched early
   // (before the products are staged) so their latency overlaps the stream.
-  struct Pre { double a, b, c; };
   auto prefetch = [&](int r) -> Pre {
-    Pre p{0.0, 0.0, 0.0};
+    Pre p{0.0, 0.0, 0.0, 0.0, 0.0};
     if (MAPPED) r = a.A.majorMap[r];
     if (EPI == kDualStep) {
       p.a = a.v.y[cur][r]; p.b = a.v.rhs[r]; p.c = a.v.ax[cur][r];
     } else if (EPI == kAtyInteract) {
       p.a = a.v.x[cur][r]; p.b = a.v.x[nxt][r]; p.c = a.v.aty[cur][r];
+    } else if (EPI == kHalpernPrimal) {
+      p.a = a.h.xc[r]; p.b = a.h.cost[r]; p.c = a.h.xa[r]; p.d = a.h.lower[r]; p.e = a.h.upper[r];
+    } else if (EPI == kHalpernDual) {
+      p.a = a.h.yc[r]; p.b = a.h.ya[r]; p.c = a.h.rowLower[r]; p.d = a.h.rowUpper[r];
     }
     return p;
   };
@@ -95,6 +146,10 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
     if (MAPPED) r = a.A.majorMap[r];
     if (EPI == kPlain || EPI == kAtyPartial) {
       a.out[r] = s;
+    } else if (EPI == kHalpernPrimal) {
+      halpernPrimal(a.h, r, s, p, hTau, hRho, hW);
+    } else if (EPI == kHalpernDual) {
+      halpernDual(a.h, r, s, p, sigma, hRho, hW);
     } else if (EPI == kDualStep) {
       // y+ = proj(y + sigma*(b - 2 A x+ + A x)), cupdlp_step.c:43-69
       const double yv = p.a;
@@ -195,7 +250,7 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
 template <int EPI>
 __global__ __launch_bounds__(kSlabThreads, 8) void k_spmv_slab(const SpmvArgs a) {
   const DevState* st = a.st;
-  if (EPI != kPlain && st->halted) return;
+  if (usesDevState(EPI) && st->halted) return;
   // dynamic LDS (all carve offsets are multiples of 16 bytes; no static __shared__ in this kernel):
   //   acc[R] f64 | stage[2][256] f64 | scratch[2][4] f64 | srow[2][256] u16
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -219,25 +274,38 @@ __global__ __launch_bounds__(kSlabThreads, 8) void k_spmv_slab(const SpmvArgs a)
 
   int cur = 0, nxt = 1;
   double sigma = 0.0, avgW = 0.0;
-  if (EPI != kPlain) {
+  if (usesDevState(EPI)) {
     cur = st->cur;
     nxt = cur ^ 1;
     sigma = st->sigma;
     avgW = st->avgW;
   }
+  double hTau = 0.0, hRho = 1.0, hW = 0.0;
+  if (EPI == kHalpernPrimal || EPI == kHalpernDual) {
+    const HalpernState hs = *a.h.hs;
+    hTau = hs.tau; sigma = hs.sigma; hRho = hs.rho;
+    const int k = hs.hIter + a.h.kOff;
+    hW = (double)k / ((double)k + 1.0);
+  }
   const double* __restrict__ in;
   if (EPI == kPlain) in = a.in;
   else if (EPI == kDualStep) in = a.v.x[nxt];
+  else if (EPI == kHalpernPrimal) in = a.h.yc;
+  else if (EPI == kHalpernDual) in = a.h.rx;
   else in = a.v.y[nxt];
 
   for (int r = tid; r < R; r += kSlabThreads) acc[r] = 0.0;
 
   double acc0 = 0.0, acc1 = 0.0;
-  struct Pre { double a, b, c; };
   auto prefetch = [&](int r) -> Pre {
-    Pre p{0.0, 0.0, 0.0};
+    Pre p{0.0, 0.0, 0.0, 0.0, 0.0};
     if (EPI == kDualStep) { p.a = a.v.y[cur][r]; p.b = a.v.rhs[r]; p.c = a.v.ax[cur][r]; }
     else if (EPI == kAtyInteract) { p.a = a.v.x[cur][r]; p.b = a.v.x[nxt][r]; p.c = a.v.aty[cur][r]; }
+    else if (EPI == kHalpernPrimal) {
+      p.a = a.h.xc[r]; p.b = a.h.cost[r]; p.c = a.h.xa[r]; p.d = a.h.lower[r]; p.e = a.h.upper[r];
+    } else if (EPI == kHalpernDual) {
+      p.a = a.h.yc[r]; p.b = a.h.ya[r]; p.c = a.h.rowLower[r]; p.d = a.h.rowUpper[r];
+    }
     return p;
   };
   // operands of this lane's first two majors, fetched ahead of the stream (clamped, unconditional)
@@ -291,6 +359,10 @@ __global__ __launch_bounds__(kSlabThreads, 8) void k_spmv_slab(const SpmvArgs a)
   auto epilogue = [&](int r, double s, const Pre& p) {
     if (EPI == kPlain || EPI == kAtyPartial) {
       a.out[r] = s;
+    } else if (EPI == kHalpernPrimal) {
+      halpernPrimal(a.h, r, s, p, hTau, hRho, hW);
+    } else if (EPI == kHalpernDual) {
+      halpernDual(a.h, r, s, p, sigma, hRho, hW);
     } else if (EPI == kDualStep) {
       const double yv = p.a;
       if (avgW != 0.0) a.v.ySum[r] += avgW * yv;
@@ -614,6 +686,16 @@ void launchSpmvAtyPartial(const MatView& At, const IterVecs& v, const DevState* 
   SpmvArgs a{};
   a.st = st; a.v = v; a.out = out;
   launchSpmv<kAtyPartial>(At, a, s);
+}
+void launchHalpernPrimal(const MatView& At, const HalpernVecs& h, hipStream_t s) {
+  SpmvArgs a{};
+  a.h = h;
+  launchSpmv<kHalpernPrimal>(At, a, s);
+}
+void launchHalpernDual(const MatView& A, const HalpernVecs& h, hipStream_t s) {
+  SpmvArgs a{};
+  a.h = h;
+  launchSpmv<kHalpernDual>(A, a, s);
 }
 void launchSpmvPlain(const MatView& A, const double* in, double* out, hipStream_t s) {
   SpmvArgs a{};

@@ -94,6 +94,32 @@ struct IterVecs {
   int32_t rowOffset;  // global index of local row 0 (0 unless sharded)
 };
 
+// ---- HiPDLP path (solver="hipdlp"): restarted Halpern PDHG, hipdlp/pdhg.cc:961-1018 ----------
+// Step sizes and the Halpern counter live in HBM so that a block of 40 steps replays from a
+// hipGraph; they only change at restarts (host, check iterations).
+struct HalpernState {
+  double tau, sigma;  // stepsize_.primal_step / dual_step
+  double rho;         // params_.halpern_gamma (1 = full reflection)
+  int32_t hIter;      // halpern_iteration_ at the start of the block
+  int32_t pad_;
+};
+struct HalpernVecs {
+  double* xc; double* yc;          // x_current_, y_current_
+  double* xn; double* yn;          // x_next_, y_next_ (pdhg iterate of the last MAJOR step)
+  double* rx; double* ry;          // reflected_x_ (every step), reflected_y_ (major steps)
+  const double* xa; const double* ya;  // anchors
+  double* slack;                   // halpern_dual_slack_next_ (major steps)
+  const double* cost; const double* lower; const double* upper;
+  const double* rowLower; const double* rowUpper;
+  const HalpernState* hs;
+  int32_t kOff;    // k_offset of this step inside the block (1..40)
+  int32_t major;   // is_major
+};
+// A' y_current fused with the primal projection, reflection and Halpern blend (steps 5+1+4x)
+void launchHalpernPrimal(const MatView& At, const HalpernVecs& h, hipStream_t s);
+// A reflected_x fused with the dual projection, reflection and Halpern blend (steps 2+3+4y)
+void launchHalpernDual(const MatView& A, const HalpernVecs& h, hipStream_t s);
+
 // ---- per-trial kernels ----------------------------------------------------
 void launchPrimalStep(const IterVecs& v, const DevState* st, hipStream_t s);
 // ax_next = A x_next fused with the dual step; writes per-block sum (dy)^2 to partDY[block]

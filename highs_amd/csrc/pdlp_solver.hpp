@@ -43,20 +43,35 @@ struct Residuals {
   double pInfObj = 0, pInfRes = 1, dInfObj = 0, dInfRes = 1;
 };
 
-class Solver {
+// What the C ABI drives: one implementation per reference path (cuPDLP-C: Solver below;
+// HiPDLP: HalpernSolver, pdlp_halpern.hpp).
+class SolverBase {
+ public:
+  virtual ~SolverBase() = default;
+  virtual void run(pdlp_result_t* R) = 0;
+  virtual void iterate(int32_t nIters, pdlp_iter_stats_t* st) = 0;
+  virtual void reset() = 0;
+  virtual void dims(int32_t* n, int32_t* m, int64_t* nnz, int32_t* nEqs) const = 0;
+  virtual void getVector(const std::string& name, double* host, int64_t len) = 0;
+  virtual void setVector(const std::string& name, const double* host, int64_t len) = 0;
+  virtual void stage(const std::string& name, double* out, int32_t cap) = 0;
+  virtual double timeKernel(const std::string& name, int32_t reps) = 0;
+};
+
+class Solver : public SolverBase {
  public:
   Solver(const pdlp_problem_t& P, const pdlp_params_t& opt, int32_t rank, int32_t world, const void* id128);
-  ~Solver();
+  ~Solver() override;
 
-  void run(pdlp_result_t* R);                          // LP_SolvePDHG
-  void iterate(int32_t nIters, pdlp_iter_stats_t* st);  // fixed-work loop for timing
-  void reset();                                        // PDHG_Init_Step_Sizes + PDHG_Init_Variables
+  void run(pdlp_result_t* R) override;                          // LP_SolvePDHG
+  void iterate(int32_t nIters, pdlp_iter_stats_t* st) override;  // fixed-work loop for timing
+  void reset() override;                                        // PDHG_Init_Step_Sizes + PDHG_Init_Variables
 
-  void dims(int32_t* n, int32_t* m, int64_t* nnz, int32_t* nEqs) const;
-  void getVector(const std::string& name, double* host, int64_t len);
-  void setVector(const std::string& name, const double* host, int64_t len);
-  void stage(const std::string& name, double* out, int32_t cap);
-  double timeKernel(const std::string& name, int32_t reps);
+  void dims(int32_t* n, int32_t* m, int64_t* nnz, int32_t* nEqs) const override;
+  void getVector(const std::string& name, double* host, int64_t len) override;
+  void setVector(const std::string& name, const double* host, int64_t len) override;
+  void stage(const std::string& name, double* out, int32_t cap) override;
+  double timeKernel(const std::string& name, int32_t reps) override;
 
  private:
   // setup

@@ -154,6 +154,32 @@ def solveLpCupdlp(lp: HighsLp, start=None, solve_fn=None, **options):
     return PdlpOutcome(status, ms, sol, int(R.num_iter), info, R)
 
 
+def solveLpHiPdlp(lp: HighsLp, solve_fn=None, **options):
+    """Mirror of the reference's second PDLP entry point, solveLpHiPdlp (highs/pdlp/HiPdlpWrapper.cpp:26-141):
+    restarted Halpern PDHG.  Same option names as HiGHS (kkt_tolerance / pdlp_optimality_tolerance ->
+    gap_tol, pdlp_iteration_limit, time_limit, pdlp_features_off, pdlp_scaling_mode, pdlp_ruiz_iterations,
+    pdlp_step_size_strategy); status map of HiPdlpWrapper.cpp:99-128."""
+    options = dict(options)
+    options["solver"] = "hipdlp"
+    params = options.pop("params", None) or abi.default_params(**options)
+    P = abi.ProblemHandle(lp)
+    R = abi.ResultHandle(lp.num_col, lp.num_row)
+    fn = solve_fn or lib().pdlp_mi355x_solve
+    rc = fn(C.byref(P.struct), C.byref(params), C.byref(R.struct))
+    if rc != 0:
+        ms = kSolveError
+    elif R.term_code == abi.TERM_OPTIMAL:
+        ms = kOptimal
+    elif R.term_code == abi.TERM_TIMELIMIT_OR_ITERLIMIT:
+        ms = kTimeLimit if R.reserved_i == 1 else kIterationLimit
+    else:
+        ms = kUnknown
+    sol = HighsSolution(R.col_value, R.col_dual, R.row_value, R.row_dual, bool(R.value_valid), bool(R.dual_valid))
+    info = kkt_measures(lp, sol.col_value, sol.col_dual, sol.row_value, sol.row_dual) if rc == 0 else {}
+    info["pdlp_iteration_count"] = int(R.num_iter)
+    return PdlpOutcome(kError if rc != 0 else kOk, ms, sol, int(R.num_iter), info, R)
+
+
 class DeviceSolver:
     """Long-lived solver context with the problem resident in HBM (pdlp_mi355x_create ... destroy)."""
 
@@ -207,8 +233,10 @@ class DeviceSolver:
         arr = np.ascontiguousarray(arr, dtype=np.float64)
         _check(lib().pdlp_mi355x_set_vector(self.h, name.encode(), arr.ctypes.data_as(abi.c_f64p), arr.size), "set " + name)
 
-    def stage(self, name, n_out=16):
+    def stage(self, name, n_out=16, init=None):
         out = np.zeros(n_out)
+        if init is not None:  # a few stages read their argument from the scalar array
+            out[:len(init)] = init
         _check(lib().pdlp_mi355x_stage(self.h, name.encode(), out.ctypes.data_as(abi.c_f64p), n_out), "stage " + name)
         return out
 

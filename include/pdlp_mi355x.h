@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define PDLP_MI355X_ABI_VERSION 1
+#define PDLP_MI355X_ABI_VERSION 2
 
 /* Termination codes: same numbering as cuPDLP-C's termination_code
  * (cupdlp_defs.h:61-68) so the status map of CupdlpWrapper.cpp:225-251
@@ -100,7 +100,13 @@ typedef struct pdlp_params {
   /* --- MI355X-specific knobs (no reference counterpart) --- */
   int32_t device;         /* HIP device ordinal of this process (default 0) */
   int32_t check_interval; /* 0 = reference schedule (CUPDLP_RELEASE_INTERVAL 40) */
-  int32_t reserved[6];
+  int32_t reserved[2];    /* test-infrastructure switches (ignored by the product) */
+  /* --- second reference path: solver="hipdlp" (HiPdlpWrapper.cpp, hipdlp/pdhg.cc:1783-1874) --- */
+  int32_t algorithm;          /* 0 = cuPDLP-C path (solver="pdlp"), 1 = HiPDLP restarted Halpern PDHG */
+  int32_t scaling_mode;       /* pdlp_scaling_mode bitmask: 1 Ruiz, 2 L2, 4 Pock-Chambolle (default 5) */
+  int32_t ruiz_iterations;    /* pdlp_ruiz_iterations (default 10) */
+  int32_t step_size_strategy; /* pdlp_step_size_strategy: 0 fixed; anything else = PID primal weight
+                                 (HiGHS default 1 -> PID, pdhg.cc:1856-1864) */
 } pdlp_params_t;
 
 typedef struct pdlp_result {
@@ -115,7 +121,7 @@ typedef struct pdlp_result {
   int32_t num_iter;    /* outer PDHG iterations = highs_info.pdlp_iteration_count */
   int32_t num_trials;  /* trial steps incl. rejected ones (nStepSizeIter) */
   int32_t num_restarts;
-  int32_t reserved_i;
+  int32_t reserved_i;  /* HiPDLP path: 1 = stopped by the time limit (TerminationStatus::TIMEOUT) */
   /* cuPDLP's own view of the returned iterate (resobj, scaled-problem space
    * mapped back with row/col scale as in cupdlp_solver.c:12-204) */
   double primal_obj;

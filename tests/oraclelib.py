@@ -44,8 +44,8 @@ def oracle():
     global _oracle
     if _oracle is None:
         path = os.path.join(ORACLE_DIR, "liboracle.so")
-        src = os.path.join(ORACLE_DIR, "pdlp_oracle.c")
-        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+        srcs = [os.path.join(ORACLE_DIR, f) for f in ("pdlp_oracle.c", "hipdlp_oracle.c")]
+        if not os.path.exists(path) or os.path.getmtime(path) < max(os.path.getmtime(f) for f in srcs):
             build_oracle()
         lib = C.CDLL(path)
         lib.pdlp_oracle_solve.argtypes = [C.POINTER(abi.PdlpProblem), C.POINTER(abi.PdlpParams), C.POINTER(abi.PdlpResult)]
@@ -125,3 +125,73 @@ class FormulatedView:
         self.row_type = g(F.row_type, m, np.int32); self.row_new_idx = g(F.row_new_idx, m, np.int32)
         self.norm_cost, self.norm_rhs, self.mat_norm_inf = F.norm_cost, F.norm_rhs, F.mat_norm_inf
         oracle().pdlp_oracle_free_formulated(C.byref(F))
+
+
+# ---- HiPDLP path (oracle/hipdlp_oracle.c) -------------------------------------------------------
+class HipdlpProbe(C.Structure):
+    _fields_ = [("steps", C.c_int), ("tau", C.c_double), ("sigma", C.c_double),
+                ("x_cur", abi.c_f64p), ("y_cur", abi.c_f64p), ("x_next", abi.c_f64p), ("y_next", abi.c_f64p),
+                ("out_tau", C.c_double), ("out_sigma", C.c_double), ("out_fpe", C.c_double), ("out_lambda", C.c_double),
+                ("n", C.c_int), ("m", C.c_int)]
+
+
+class HipdlpPrepared(C.Structure):
+    _fields_ = [("n", C.c_int), ("m", C.c_int), ("n_eqs", C.c_int), ("nnz", C.c_long),
+                ("beg", abi.c_i32p), ("idx", abi.c_i32p), ("val", abi.c_f64p),
+                ("cost", abi.c_f64p), ("lower", abi.c_f64p), ("upper", abi.c_f64p), ("row_lower", abi.c_f64p),
+                ("row_upper", abi.c_f64p), ("col_scale", abi.c_f64p), ("row_scale", abi.c_f64p),
+                ("norm_cost", C.c_double), ("norm_rhs", C.c_double)]
+
+
+def _hipdlp_lib():
+    lib = oracle()
+    if not getattr(lib, "_hipdlp_ready", False):
+        sig = [C.POINTER(abi.PdlpProblem), C.POINTER(abi.PdlpParams)]
+        lib.hipdlp_oracle_solve.argtypes = sig + [C.POINTER(abi.PdlpResult)]
+        lib.hipdlp_oracle_solve.restype = C.c_int
+        lib.hipdlp_oracle_probe.argtypes = sig + [C.POINTER(HipdlpProbe)]
+        lib.hipdlp_oracle_probe.restype = C.c_int
+        lib.hipdlp_oracle_prepare.argtypes = sig + [C.POINTER(HipdlpPrepared)]
+        lib.hipdlp_oracle_prepare.restype = C.c_int
+        lib.hipdlp_oracle_free_prepared.argtypes = [C.POINTER(HipdlpPrepared)]
+        lib._hipdlp_ready = True
+    return lib
+
+
+def hipdlp_solve_fn():
+    return _hipdlp_lib().hipdlp_oracle_solve
+
+
+def hipdlp_probe(lp, steps, tau=0.0, sigma=0.0, **kw):
+    """State of the oracle after `steps` Halpern steps of the first block (last step major)."""
+    params = abi.default_params(solver="hipdlp", **kw)
+    P = abi.ProblemHandle(lp)
+    prep = hipdlp_prepared(lp, **kw)
+    n, m = prep["n"], prep["m"]
+    out = {k: np.zeros(n if k[0] == "x" else m) for k in ("x_cur", "y_cur", "x_next", "y_next")}
+    pr = HipdlpProbe()
+    pr.steps, pr.tau, pr.sigma = steps, tau, sigma
+    for k, v in out.items():
+        setattr(pr, k, v.ctypes.data_as(abi.c_f64p))
+    rc = _hipdlp_lib().hipdlp_oracle_probe(C.byref(P.struct), C.byref(params), C.byref(pr))
+    if rc:
+        raise RuntimeError("hipdlp probe failed")
+    out.update(tau=pr.out_tau, sigma=pr.out_sigma, fpe=pr.out_fpe, lam=pr.out_lambda)
+    return out
+
+
+def hipdlp_prepared(lp, **kw):
+    params = abi.default_params(solver="hipdlp", **kw)
+    P = abi.ProblemHandle(lp)
+    F = HipdlpPrepared()
+    if _hipdlp_lib().hipdlp_oracle_prepare(C.byref(P.struct), C.byref(params), C.byref(F)):
+        raise RuntimeError("hipdlp prepare failed")
+    n, m, nnz = F.n, F.m, F.nnz
+    g = lambda p, k, dt: np.ctypeslib.as_array(p, shape=(max(k, 1),))[:k].astype(dt).copy()
+    out = dict(n=n, m=m, n_eqs=F.n_eqs, nnz=nnz, beg=g(F.beg, n + 1, np.int32), idx=g(F.idx, nnz, np.int32),
+               val=g(F.val, nnz, np.float64), cost=g(F.cost, n, np.float64), lower=g(F.lower, n, np.float64),
+               upper=g(F.upper, n, np.float64), row_lower=g(F.row_lower, m, np.float64),
+               row_upper=g(F.row_upper, m, np.float64), col_scale=g(F.col_scale, n, np.float64),
+               row_scale=g(F.row_scale, m, np.float64), norm_cost=F.norm_cost, norm_rhs=F.norm_rhs)
+    _hipdlp_lib().hipdlp_oracle_free_prepared(C.byref(F))
+    return out

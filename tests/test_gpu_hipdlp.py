@@ -1,0 +1,113 @@
+"""GPU parity tests of the HiPDLP path (solver="hipdlp"), through the C ABI, against the
+oracle (oracle/hipdlp_oracle.c, itself pinned on the reference binary) and the reference goldens."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oraclelib as O
+from highs_amd import solver
+from highs_amd import lp as L
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+REF = json.load(open(os.path.join(GOLD, "reference_hipdlp.json")))
+
+
+def _lp(name):
+    return L.HighsLp.from_npz(os.path.join(GOLD, "instances", name + ".npz"))
+
+
+@pytest.fixture(params=["csr", "slab"])
+def spmv_layout(request, monkeypatch):
+    monkeypatch.setenv("PDLP_MI355X_SLAB", "1" if request.param == "slab" else "0")
+    return request.param
+
+
+@pytest.mark.parametrize("name,steps", [("afiro", 1), ("afiro", 40), ("adlittle", 7), ("25fv47", 40), ("shell", 40),
+                                        ("standgub", 23)])
+def test_halpern_steps_bit_exact(name, steps, spmv_layout):
+    """The fused step kernels (A'y + primal projection/reflection/blend, A x + dual ones) reproduce the
+    oracle's x, y, x_next, y_next bit for bit over a block of Halpern steps with the same step sizes
+    (element-wise arithmetic in the reference's order, majors summed left to right)."""
+    lp = _lp(name)
+    ref = O.hipdlp_probe(lp, steps)
+    S = solver.DeviceSolver(lp=lp, solver="hipdlp")
+    st = S.get("steps", 8)
+    # the device power method differs from the CPU's only in the order of its dot products
+    assert abs(st[4] - ref["lam"]) <= 1e-12 * ref["lam"]
+    S.set("steps", [ref["tau"], ref["sigma"]])
+    S.stage("steps", init=[steps])
+    assert np.array_equal(S.get("x", S.n), ref["x_cur"])
+    assert np.array_equal(S.get("y", S.m), ref["y_cur"])
+    assert np.array_equal(S.get("x_next", S.n), ref["x_next"])
+    assert np.array_equal(S.get("y_next", S.m), ref["y_next"])
+    S.close()
+
+
+def test_fixed_point_error_matches_oracle():
+    lp = _lp("25fv47")
+    ref = O.hipdlp_probe(lp, 40)
+    S = solver.DeviceSolver(lp=lp, solver="hipdlp")
+    S.set("steps", [ref["tau"], ref["sigma"]])
+    fpe = S.stage("block")[0]
+    assert abs(fpe - ref["fpe"]) <= 1e-10 * abs(ref["fpe"])
+    S.close()
+
+
+@pytest.mark.parametrize("name", ["afiro", "adlittle", "avgas", "blending", "chip", "shell"])
+def test_solve_matches_oracle_and_reference(name):
+    lp = _lp(name)
+    ora = solver.solveLpHiPdlp(lp, solve_fn=O.hipdlp_solve_fn())
+    gpu = solver.solveLpHiPdlp(lp)
+    assert gpu.model_status == solver.kOptimal
+    a, b = lp.objective_value(gpu.solution.col_value), lp.objective_value(ora.solution.col_value)
+    assert abs(a - b) <= 1e-6 * (1 + abs(b))  # north-star tolerance on objectives
+    assert abs(gpu.result.dual_obj - ora.result.dual_obj) <= 1e-6 * (1 + abs(ora.result.dual_obj))
+    # the trajectories only differ by the summation order of the check-iteration reductions
+    assert abs(gpu.pdlp_iteration_count - ora.pdlp_iteration_count) <= max(80, 0.1 * ora.pdlp_iteration_count)
+    g = REF.get(name, {}).get("default", {})
+    if g.get("objective"):
+        assert abs(a - float(g["objective"])) <= 1e-6 * (1 + abs(a))
+    r = gpu.result
+    assert r.primal_feas < 1e-7 * (1 + r.norm_rhs) and r.dual_feas < 1e-7 * (1 + r.norm_cost) and r.rel_gap < 1e-7
+    assert np.allclose(lp.row_activity(gpu.solution.col_value), gpu.solution.row_value, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("opts", [{"pdlp_step_size_strategy": 0}, {"pdlp_features_off": 1},
+                                  {"pdlp_scaling_mode": 7, "pdlp_ruiz_iterations": 4}])
+def test_option_variants_match_oracle(opts):
+    lp = _lp("afiro")
+    ora = solver.solveLpHiPdlp(lp, solve_fn=O.hipdlp_solve_fn(), kkt_tolerance=1e-5, **opts)
+    gpu = solver.solveLpHiPdlp(lp, kkt_tolerance=1e-5, **opts)
+    assert gpu.model_status == ora.model_status == solver.kOptimal
+    a, b = lp.objective_value(gpu.solution.col_value), lp.objective_value(ora.solution.col_value)
+    assert abs(a - b) <= 1e-4 * (1 + abs(b))
+    assert abs(gpu.pdlp_iteration_count - ora.pdlp_iteration_count) <= max(80, 0.1 * ora.pdlp_iteration_count)
+
+
+def test_iteration_limit_semantics():
+    lp = _lp("adlittle")
+    gpu = solver.solveLpHiPdlp(lp, pdlp_iteration_limit=200)
+    assert gpu.model_status == solver.kIterationLimit and gpu.pdlp_iteration_count == 200
+    assert not gpu.solution.col_value.any()  # the reference returns the zero start (pdhg.cc:866-877)
+
+
+def test_large_synthetic_block_bit_exact_and_runs():
+    """20k x 20k synthetic LP (slab layout off/on by size rule): first block vs the oracle, then 400 more
+    iterations stay finite and inside the bounds."""
+    sp_ = solver.SyntheticProblem(20000, 20000, 160000, 3)
+    lp = sp_.to_lp()
+    ref = O.hipdlp_probe(lp, 40)
+    S = solver.DeviceSolver(problem_struct=sp_.struct, solver="hipdlp")
+    S.set("steps", [ref["tau"], ref["sigma"]])
+    S.stage("steps", init=[40])
+    assert np.array_equal(S.get("x", S.n), ref["x_cur"]) and np.array_equal(S.get("y", S.m), ref["y_cur"])
+    S.reset()
+    st = S.iterate(400)
+    assert st.iters == 400 and st.checks == 10
+    x = S.get("x_next", S.n)
+    lo, up = S.get("lower", S.n), S.get("upper", S.n)
+    assert np.all(np.isfinite(x)) and np.all(x >= lo) and np.all(x <= up)
+    S.close()
