@@ -42,15 +42,17 @@ def algorithmic_bytes(n, m, nnz):
     return b_iter, b_spmv_ax, b_spmv_aty
 
 
-def cpu_baseline(sp_struct, cfg, budget_iters):
+def cpu_baseline(sp_struct, cfg, budget_iters, solver_name="pdlp"):
     """Reference CPU pdlp (single thread) on a bounded sample of the same LP: `budget_iters`
     iterations, iterations/s over the PDHG loop only (setup excluded, as for the GPU number)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oraclelib as O
     from highs_amd import abi
-    params = abi.default_params(kkt_tolerance=1e-4, pdlp_iteration_limit=budget_iters)
+    params = abi.default_params(kkt_tolerance=1e-4, pdlp_iteration_limit=budget_iters, solver=solver_name)
     R = abi.ResultHandle(sp_struct.num_col, sp_struct.num_row)
-    if O.ref_available():
+    if solver_name == "hipdlp":  # no compiled reference for this path: the oracle restatement
+        kind, fn = "port", O.hipdlp_solve_fn()
+    elif O.ref_available():
         kind, fn = "reference", O.ref().pdlp_ref_solve
     else:
         kind, fn = "port", O.oracle().pdlp_oracle_solve
@@ -73,6 +75,8 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="b")
     ap.add_argument("--cpu-iters", type=int, default=None, help="CPU baseline sample size (0 disables)")
     ap.add_argument("--kernels", action="store_true", help="also print per-kernel timings to stderr")
+    ap.add_argument("--solver", choices=["pdlp", "hipdlp"], default="pdlp",
+                    help="pdlp = the headline path (cuPDLP-C semantics); hipdlp = the reference's Halpern PDHG path")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -102,7 +106,9 @@ def main():
         uid = (C.c_uint8 * 128)(*t.cpu().tolist())
 
     sp_ = solver.SyntheticProblem(cfg["m"], cfg["n"], cfg["nnz"], 1)
-    params = abi.default_params(kkt_tolerance=1e-4, device=local_rank)
+    params = abi.default_params(kkt_tolerance=1e-4, device=local_rank, solver=args.solver)
+    if args.solver == "hipdlp" and world > 1:
+        raise SystemExit("the hipdlp path is single-GPU")
     t_setup = time.time()
     S = solver.DeviceSolver(problem_struct=sp_.struct, params=params, rank=rank, world=world, unique_id=uid)
     t_setup = time.time() - t_setup
@@ -151,7 +157,8 @@ def main():
         except Exception:
             traffic = None
     out = {
-        "metric": "PDHG iterations/sec", "value": st.iters / elapsed, "unit": "it/s", "n_gpus": world,
+        "metric": "PDHG iterations/sec" if args.solver == "pdlp" else "PDHG iterations/sec (HiPDLP path)",
+        "value": st.iters / elapsed, "unit": "it/s", "n_gpus": world,
         "steps": int(st.iters), "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": cfg["name"], "m": m, "n": n, "nnz": nnz,
@@ -168,7 +175,9 @@ def main():
                      "other_kernels_ms": {"spmv_ax_dual": k_ax, "spmv_aty_interact": k_aty},
                      "isolated_relaunch_ms": {"spmv_ax_dual": iso_ax, "spmv_aty_interact": iso_aty}},
     }
-    if args.kernels and rank == 0 and world == 1:
+    if args.solver == "hipdlp":
+        out["config"]["options"] = "presolve=off, kkt_tolerance=1e-4, Halpern restarts + PID primal weight (reference defaults)"
+    if args.kernels and rank == 0 and world == 1 and args.solver == "pdlp":
         ks = {k: S.time_kernel(k, 50) for k in ("primal_step", "spmv_ax", "spmv_aty", "decide", "trial",
                                                 "spmv_ax_plain", "spmv_aty_plain", "copy")}
         ks["copy_GBs"] = 2 * 512 * 2**20 / (ks["copy"] * 1e-3) / 1e9
@@ -177,7 +186,9 @@ def main():
     if rank == 0 and world == 1:
         budget = args.cpu_iters if args.cpu_iters is not None else (120 if args.config == "b" else 3000)
         if budget > 0:
-            cb = cpu_baseline(sp_.struct, cfg, budget)
+            if args.solver == "hipdlp":
+                budget = max(40, budget // 40 * 40)
+            cb = cpu_baseline(sp_.struct, cfg, budget, args.solver)
             out["cpu_baseline"] = cb
             if cb:
                 out["speedup_vs_cpu_pdlp"] = out["value"] / cb["value"]

@@ -498,6 +498,7 @@ Mesh::Mesh(int32_t rank, int32_t world, const void* id128, int32_t n, int32_t m,
   PDLP_HIP(hipMalloc((void**)&dView_, sizeof(MeshView)));
   if (world == 1) {
     PDLP_HIP(hipMemcpy(dView_, &v_, sizeof(MeshView), hipMemcpyHostToDevice));
+    setupOk_ = true;
     return;
   }
 
@@ -513,22 +514,30 @@ Mesh::Mesh(int32_t rank, int32_t world, const void* id128, int32_t n, int32_t m,
   if (shm_ == MAP_FAILED) { shm_ = nullptr; throw std::runtime_error("pdlp_mi355x mesh: mmap failed"); }
   ShmSeg* seg = (ShmSeg*)shm_;
   ShmSlot& mine = seg->slot[rank];
-  PDLP_HIP(hipIpcGetMemHandle(&mine.handle, arena_));
+  // From here on a failure must not desert the other ranks: it is recorded, this rank keeps taking part
+  // in the rendezvous, and selfTest()/allAgree() then turn it into "every rank falls back to RCCL".
+  bool ok = hipIpcGetMemHandle(&mine.handle, arena_) == hipSuccess;
   mine.arenaBytes = arenaBytes_;
   mine.pid = (uint32_t)getpid();
-  mine.ready.store(1, std::memory_order_release);
-  hostBarrier(0, 120.0);
+  mine.ready.store(ok ? 1u : 2u, std::memory_order_release);
+  hostBarrier(0, 60.0);
   if (rank == 0) shm_unlink(name);  // every rank has it mapped; nothing is left behind on a crash
   for (int h = 0; h < world; ++h) {
     if (h == rank) continue;
-    if (seg->slot[h].ready.load(std::memory_order_acquire) != 1 || seg->slot[h].arenaBytes != arenaBytes_)
-      throw std::runtime_error("pdlp_mi355x mesh: ranks disagree on the arena layout");
+    if (seg->slot[h].ready.load(std::memory_order_acquire) != 1 || seg->slot[h].arenaBytes != arenaBytes_) {
+      ok = false;
+      continue;
+    }
     void* p = nullptr;
-    PDLP_HIP(hipIpcOpenMemHandle(&p, seg->slot[h].handle, hipIpcMemLazyEnablePeerAccess));
+    if (!ok || hipIpcOpenMemHandle(&p, seg->slot[h].handle, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+      ok = false;
+      continue;
+    }
     v_.arena[h] = (char*)p;
   }
-  PDLP_HIP(hipMemcpy(dView_, &v_, sizeof(MeshView), hipMemcpyHostToDevice));
-  hostBarrier(1, 120.0);
+  if (ok) ok = hipMemcpy(dView_, &v_, sizeof(MeshView), hipMemcpyHostToDevice) == hipSuccess;
+  setupOk_ = ok;
+  hostBarrier(1, 60.0);
 }
 
 Mesh::~Mesh() {
@@ -602,6 +611,7 @@ bool Mesh::allAgree(bool ok) {
 
 // Known-answer test of the three exchange patterns with rank-dependent data.
 bool Mesh::selfTest(hipStream_t s) {
+  if (!setupOk_) return false;
   const int32_t n = n_;
   const int G = v_.G, g = v_.g;
   auto val = [](int rank, int j, int round) { return (double)((rank + 1) * 1000003 + j * 7 + round); };

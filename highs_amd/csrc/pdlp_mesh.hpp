@@ -100,6 +100,7 @@ class Mesh {
   long long epoch_ = 0;  // generic collectives (host-counted, identical on every rank)
   int agreeRound_ = 0;
   int32_t n_ = 0;
+  bool setupOk_ = false;  // arenas exported and mapped on this rank
 };
 
 // ---- hot-loop kernels (mesh flavour of enqueueTrial) -----------------------------

@@ -238,17 +238,14 @@ Solver::Solver(const pdlp_problem_t& P, const pdlp_params_t& opt, int32_t rank, 
     if (wantMesh) {
       try {
         mesh_ = new Mesh(rank_, world_, id128, F_.n, F_.m, off, stream_);
-      } catch (const std::exception& e) {
-        fprintf(stderr, "pdlp_mi355x[rank %d]: mesh exchange unavailable (%s); using RCCL\n", rank_, e.what());
-        mesh_ = nullptr;
-      }
-      if (mesh_) {
         const bool ok = mesh_->selfTest(stream_);
-        if (!mesh_->allAgree(ok)) {
-          if (rank_ == 0) fprintf(stderr, "pdlp_mi355x: mesh exchange failed its self-test; using RCCL\n");
-          delete mesh_;
-          mesh_ = nullptr;
-        }
+        if (!mesh_->allAgree(ok)) throw std::runtime_error("the exchange self-test failed on some rank");
+      } catch (const std::exception& e) {
+        // every failure path ends here on EVERY rank (a rank that fails keeps taking part in the
+        // rendezvous and votes "not ok"; a rank that vanished makes the others time out)
+        fprintf(stderr, "pdlp_mi355x[rank %d]: direct xGMI exchange unavailable (%s); using RCCL\n", rank_, e.what());
+        delete mesh_;
+        mesh_ = nullptr;
       }
     }
     meshMode_ = mesh_ != nullptr;

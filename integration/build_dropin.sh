@@ -1,7 +1,7 @@
 #!/bin/bash
 # Drop-in proof (build container only): link a libhighs.so from the REFERENCE's own object
 # files with the PDLP wrapper TU + vendored cuPDLP-C objects replaced by
-# integration/CupdlpWrapperMi355x.cpp -> libpdlp_mi355x.so.  The reference's unmodified
+# integration/CupdlpWrapperMi355x.cpp / HiPdlpWrapperMi355x.cpp -> libpdlp_mi355x.so.  The reference's unmodified
 # bin/highs and bin/unit_tests then run the MI355X path (LD_LIBRARY_PATH picks this libhighs).
 #   $REF_BUILD : an existing CPU build of the reference (object files are reused; its build
 #                system is NOT run here).  Outputs go to integration/_build/ (git-ignored; the
@@ -13,10 +13,12 @@ HERE=$(cd "$(dirname "$0")" && pwd)
 ROOT=$(dirname "$HERE")
 OUT=$HERE/_build
 mkdir -p "$OUT"
-g++ -std=c++17 -O2 -fPIC -I"$REF/highs" -I"$REF_BUILD" -I"$ROOT/include" \
-    -c "$HERE/CupdlpWrapperMi355x.cpp" -o "$OUT/CupdlpWrapperMi355x.o"
-OBJS=$(find "$REF_BUILD/highs/CMakeFiles/highs.dir" -name '*.o' | grep -v -E 'pdlp/CupdlpWrapper\.cpp\.o|pdlp/cupdlp/')
-/opt/rocm/lib/llvm/bin/clang++ -flto=thin -fuse-ld=lld -O3 -shared -o "$OUT/libhighs.so.1" -Wl,-soname,libhighs.so.1 $OBJS "$OUT/CupdlpWrapperMi355x.o" \
+for w in CupdlpWrapperMi355x HiPdlpWrapperMi355x; do
+  g++ -std=c++17 -O2 -fPIC -I"$REF/highs" -I"$REF_BUILD" -I"$ROOT/include" -c "$HERE/$w.cpp" -o "$OUT/$w.o"
+done
+# both reference PDLP paths are left out: cuPDLP-C (wrapper + vendored C) and HiPDLP (wrapper + hipdlp/*.cc)
+OBJS=$(find "$REF_BUILD/highs/CMakeFiles/highs.dir" -name '*.o' | grep -v -E 'pdlp/CupdlpWrapper\.cpp\.o|pdlp/cupdlp/|pdlp/HiPdlpWrapper\.cpp\.o|pdlp/hipdlp/')
+/opt/rocm/lib/llvm/bin/clang++ -flto=thin -fuse-ld=lld -O3 -shared -o "$OUT/libhighs.so.1" -Wl,-soname,libhighs.so.1 $OBJS "$OUT/CupdlpWrapperMi355x.o" "$OUT/HiPdlpWrapperMi355x.o" \
     -L"$ROOT/highs_amd/lib" -lpdlp_mi355x -Wl,-rpath,'$ORIGIN/../../highs_amd/lib' -lz -lpthread -ldl
 cp "$REF_BUILD/bin/highs" "$OUT/highs_ref_cli"
 cp "$REF_BUILD/bin/unit_tests" "$OUT/unit_tests_ref"

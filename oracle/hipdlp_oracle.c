@@ -444,6 +444,7 @@ static int h_solve(const pdlp_problem_t* P, const pdlp_params_t* opt, pdlp_resul
   memcpy(S.ya, S.yc, sizeof(double) * (size_t)m);
   h_ax(L, S.xc, axT);
   h_aty(L, S.yc, S.aty);
+  const double tLoop = nowSec();
   int term = -1; /* -1 not set; 0 optimal; 1 maxiter; 2 timeout */
   int iters = 0, restarts = 0, doRestart = 0;
   double fpe = 0.0, initFpe = 0.0, lastFpe = INFINITY;
@@ -534,7 +535,7 @@ static int h_solve(const pdlp_problem_t* P, const pdlp_params_t* opt, pdlp_resul
     R->num_iter = iters; R->num_trials = 0; R->num_restarts = restarts;
     R->primal_obj = pobj; R->dual_obj = res.dObj; R->primal_feas = res.pFeas; R->dual_feas = res.dFeas;
     R->rel_gap = res.relGap; R->norm_rhs = L->bNorm; R->norm_cost = L->cNorm;
-    R->setup_seconds = 0.0; R->solve_seconds = nowSec() - t0;
+    R->setup_seconds = tLoop - t0; R->solve_seconds = nowSec() - tLoop;
   }
   free(S.xc); free(S.yc); free(S.xn); free(S.yn); free(S.rx); free(S.ry); free(S.xa); free(S.ya); free(S.aty);
   free(S.axn); free(S.slack); free(S.sp); free(S.sn); free(outX); free(outY); free(axT); free(atyT);
