@@ -72,7 +72,39 @@ def run(name, kkt):
         return rec
 
 
+def random_lps():
+    """Small random LPs with every row / column kind (tests/lpgen.py), written as MPS for the reference binary:
+    tests/golden/reference_hipdlp_random.json = {seed: {model_status, pdlp_iterations, objective}} at
+    kkt_tolerance 1e-6 (minimisation seeds), and at an iteration limit of 400 for maximisation seeds (the
+    reference does not apply the objective sense on this path)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE)))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    import lpgen
+    from highs_amd import lp as L
+    out = {}
+    for seed in list(range(0, 40, 2)) + [1, 3]:
+        lp = lpgen.drop_free_rows(lpgen.random_lp(seed))
+        with tempfile.TemporaryDirectory() as td:
+            mps, sol, opt = (os.path.join(td, f) for f in ("a.mps", "s.sol", "o.txt"))
+            L.write_mps(lp, mps)
+            limit = 20000 if seed % 2 == 0 else 400
+            open(opt, "w").write(f"kkt_tolerance = 1e-6\npdlp_iteration_limit = {limit}\n")
+            txt = subprocess.run([HIGHS, "--solver=hipdlp", "--presolve=off", f"--options_file={opt}",
+                                  f"--solution_file={sol}", mps], capture_output=True, text=True, timeout=BUDGET, cwd=td).stdout
+            g = lambda pat: (re.search(pat, txt) or [None, None])[1]
+            rec = {"model_status": g(r"Model status\s*:\s*(.+)"), "pdlp_iterations": int(g(r"PDLP\s+iterations:\s*(\d+)") or -1),
+                   "iteration_limit": limit}
+            if os.path.exists(sol):
+                rec["objective"] = parse_solution(sol).get("objective")
+                rec["col_value"] = parse_solution(sol).get("primal_col")
+        out[str(seed)] = rec
+        print("random", seed, rec["model_status"], rec["pdlp_iterations"], rec.get("objective"), flush=True)
+    json.dump(out, open(os.path.join(HERE, "reference_hipdlp_random.json"), "w"), indent=0, sort_keys=True)
+
+
 def main():
+    if "--random-only" in sys.argv:
+        return random_lps()
     recs = {}
     for name in NAMES:
         recs[name] = {"default": run(name, None)}
@@ -81,6 +113,7 @@ def main():
         print(name, {k: (v.get("pdlp_iterations"), v.get("objective"), v.get("skipped")) for k, v in recs[name].items()},
               flush=True)
         json.dump(recs, open(os.path.join(HERE, "reference_hipdlp.json"), "w"), indent=0, sort_keys=True)
+    random_lps()
 
 
 if __name__ == "__main__":

@@ -48,3 +48,19 @@ def random_lp(seed, m=None, n=None):
     a_start[1:] = np.cumsum(np.bincount(rows, minlength=n))
     return L.HighsLp(n, m, sense * c, cl, cu, rl, ru, a_start, cols.astype(np.int32), A.T[rows, cols], sense,
                      float(seed % 5) - 2.0, f"rand{seed}").normalise()
+
+
+def drop_free_rows(lp):
+    """The same LP without its free rows (an MPS file cannot carry them to the reference binary:
+    HiGHS' reader discards extra N rows)."""
+    keep = ~(np.isinf(lp.row_lower) & np.isinf(lp.row_upper))
+    if keep.all():
+        return lp
+    newidx = np.cumsum(keep) - 1
+    cols = np.repeat(np.arange(lp.num_col), np.diff(lp.a_start))
+    sel = keep[lp.a_index]
+    a_start = np.zeros(lp.num_col + 1, np.int32)
+    a_start[1:] = np.cumsum(np.bincount(cols[sel], minlength=lp.num_col))
+    return L.HighsLp(lp.num_col, int(keep.sum()), lp.col_cost, lp.col_lower, lp.col_upper, lp.row_lower[keep],
+                     lp.row_upper[keep], a_start, newidx[lp.a_index[sel]].astype(np.int32), lp.a_value[sel],
+                     lp.sense, lp.offset).normalise()

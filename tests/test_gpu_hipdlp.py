@@ -111,3 +111,17 @@ def test_large_synthetic_block_bit_exact_and_runs():
     lo, up = S.get("lower", S.n), S.get("upper", S.n)
     assert np.all(np.isfinite(x)) and np.all(x >= lo) and np.all(x <= up)
     S.close()
+
+
+@pytest.mark.parametrize("seed", [0, 4, 14, 28, 3])
+def test_random_lps_with_every_row_and_column_kind(seed):
+    import lpgen
+    lp = lpgen.random_lp(seed)  # free rows included here (the oracle covers them; MPS goldens cannot)
+    limit = 20000 if seed % 2 == 0 else 400
+    ora = solver.solveLpHiPdlp(lp, solve_fn=O.hipdlp_solve_fn(), kkt_tolerance=1e-6, pdlp_iteration_limit=limit)
+    gpu = solver.solveLpHiPdlp(lp, kkt_tolerance=1e-6, pdlp_iteration_limit=limit)
+    assert gpu.model_status == ora.model_status
+    assert abs(gpu.pdlp_iteration_count - ora.pdlp_iteration_count) <= max(40, 0.1 * ora.pdlp_iteration_count)
+    a, b = lp.objective_value(gpu.solution.col_value), lp.objective_value(ora.solution.col_value)
+    assert abs(a - b) <= 1e-6 * (1 + abs(b))
+    assert np.allclose(gpu.solution.row_dual, ora.solution.row_dual, rtol=1e-4, atol=1e-5 * (1 + np.abs(ora.solution.row_dual).max()))

@@ -77,3 +77,26 @@ def test_fixed_step_strategy_and_scaling_off_still_converge():
     for o in (a, b):
         assert o.model_status == solver.kOptimal
         assert abs(lp.objective_value(o.solution.col_value) + 464.753) < 0.1
+
+
+RAND = json.load(open(os.path.join(GOLD, "reference_hipdlp_random.json")))
+
+
+@pytest.mark.parametrize("seed", sorted(int(k) for k in RAND))
+def test_oracle_reproduces_reference_binary_on_random_lps(seed):
+    """Every row kind (EQ / GEQ / LEQ / ranged) and column kind, empty rows and columns, an offset; odd
+    seeds are maximisation LPs, which the reference MINIMISES on this path (pdhg.cc:171,481) — they hit the
+    iteration limit and come back as the zero start."""
+    import lpgen
+    g = RAND[str(seed)]
+    lp = lpgen.drop_free_rows(lpgen.random_lp(seed))
+    out = solver.solveLpHiPdlp(lp, solve_fn=O.hipdlp_solve_fn(), kkt_tolerance=1e-6,
+                               pdlp_iteration_limit=g["iteration_limit"])
+    assert out.pdlp_iteration_count == g["pdlp_iterations"]
+    assert (out.model_status == solver.kOptimal) == (g["model_status"] == "Optimal")
+    if g["model_status"] != "Optimal":
+        assert out.model_status == solver.kIterationLimit
+    obj, ref_obj = lp.objective_value(out.solution.col_value), float(g["objective"])
+    assert abs(obj - ref_obj) <= 1e-12 * max(1.0, abs(ref_obj))  # the file prints ~14 significant digits
+    b = np.asarray(g["col_value"])
+    assert np.allclose(out.solution.col_value, b, rtol=1e-9, atol=1e-9 * (1 + np.abs(b).max()))
