@@ -2,7 +2,9 @@
  * pdlp_mi355x.h — C ABI of the MI355X-native PDLP hot path for HiGHS.
  *
  * This is the drop-in boundary for ONE path of ERGO-Code/HiGHS: the PDLP
- * first-order LP solver reached through Highs::run() with solver="pdlp".
+ * first-order LP solver reached through Highs::run() with solver="pdlp"
+ * (and, with pdlp_params_t.algorithm = 1, its sibling solver="hipdlp":
+ * highs/pdlp/HiPdlpWrapper.cpp, replaced by integration/HiPdlpWrapperMi355x.cpp).
  * The entry points below are exactly what the reference wrapper
  * (highs/pdlp/CupdlpWrapper.cpp) would bind instead of its calls into the
  * vendored cuPDLP-C:
@@ -203,6 +205,10 @@ int pdlp_mi355x_set_vector(pdlp_mi355x_solver_t* s, const char* name,
  *              (eager launches, no hipGraph): the next pdlp_mi355x_iterate then reports the
  *              IN-LOOP average launch durations in spmv_ax_ms / spmv_aty_ms (reserved[0] = launches)
  *  "exchange"  scalars_out[0] = 0 not sharded, 1 RCCL all-reduce, 2 direct xGMI mesh
+ * HiPDLP solvers (algorithm = 1) instead know:
+ *  "steps"     scalars_out[0] holds k on entry (1..40): run Halpern steps 1..k of a block, first and
+ *              last one "major" (pdhg.cc:961-1018), from the current state and step sizes
+ *  "block"     one whole block of 40 steps, then scalars_out[0] = fixed-point error (pdhg.cc:709-739)
  * scalars_out receives stage-specific scalars, n_scalars its capacity. */
 int pdlp_mi355x_stage(pdlp_mi355x_solver_t* s, const char* stage,
                       double* scalars_out, int32_t n_scalars);
