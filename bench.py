@@ -132,6 +132,16 @@ def main():
 
     exchange = {0.0: "none", 1.0: "RCCL all-reduce of A'y", 2.0: "direct xGMI mesh (all-gather x+, reduce-scatter A'y+)"}[
         float(S.stage("exchange")[0])]
+    rank_consistent = None
+    if dist is not None:
+        # every rank must hold bit-identical iterates (same decisions everywhere): compare a checksum of x
+        import numpy as np
+        chk = float(np.frombuffer(S.get("x", n).tobytes(), dtype=np.uint64).astype(np.float64).sum())
+        lo = torch.tensor([chk], dtype=torch.float64, device="cuda")
+        hi = lo.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        rank_consistent = bool(lo.item() == hi.item())
     b_iter, b_ax, b_aty = algorithmic_bytes(n, m, nnz)
     ms_step = elapsed * 1e3 / st.iters
     # dominant kernel, timed live with HIP events on the solver's own stream, IN the loop (same
@@ -165,7 +175,7 @@ def main():
                    "parallelism": "single GPU" if world == 1 else "row-block x%d, %s" % (world, exchange),
                    "options": "presolve=off, kkt_tolerance=1e-4, adaptive step + restarts (reference defaults)"},
         "trial_steps": int(st.trials), "rejected_trials": int(st.trials - st.iters), "checks": int(st.checks),
-        "restarts": int(st.restarts), "setup_seconds": t_setup,
+        "restarts": int(st.restarts), "setup_seconds": t_setup, "ranks_bit_identical": rank_consistent,
         "iter_algorithmic_bytes": b_iter,
         "iter_hbm_gbs": b_iter / (ms_step * 1e-3) / 1e9,
         "iter_hbm_frac_of_peak": b_iter / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS / world,

@@ -473,7 +473,7 @@ Mesh::Mesh(int32_t rank, int32_t world, const void* id128, int32_t n, int32_t m,
   int64_t sliceMax = 1;
   for (int h = 0; h < world; ++h) sliceMax = std::max<int64_t>(sliceMax, v_.colOff[h + 1] - v_.colOff[h]);
   v_.sliceMax = sliceMax;
-  v_.waitTicks = 300000000LL;  // 3 s of the 100 MHz wall clock; PDLP_MI355X_MESH_TIMEOUT_MS overrides
+  v_.waitTicks = 1000000000LL;  // 10 s of the 100 MHz wall clock; PDLP_MI355X_MESH_TIMEOUT_MS overrides
   if (const char* t = getenv("PDLP_MI355X_MESH_TIMEOUT_MS")) v_.waitTicks = std::max(1LL, atoll(t)) * 100000LL;
   size_t off = 0;
   v_.offFlags = (int64_t)off;   off += alignUp((size_t)kNumMeshFlags * kMeshMaxRanks * kFlagStride, 4096);
