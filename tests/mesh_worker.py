@@ -24,10 +24,11 @@ def main():
     uid = (C.c_ubyte * 128).from_buffer_copy(bytes.fromhex(idhex))
     kind, name, *rest = case.split(":")
     sp_ = None
-    if name == "synth":
-        sp_ = solver.SyntheticProblem(20000, 20000, 160000, 3)
+    if name in ("synth", "synthbig"):
+        dims = (20000, 20000, 160000, 3) if name == "synth" else (1000000, 1000000, 8000000, 1)
+        sp_ = solver.SyntheticProblem(*dims)
         kw = dict(problem_struct=sp_.struct)
-        nc, nr = 20000, 20000
+        nc, nr = dims[1], dims[0]
     else:
         lp = L.HighsLp.from_npz(os.path.join(GOLD, "instances", name + ".npz"))
         kw = dict(lp=lp)

@@ -61,12 +61,13 @@ def test_mesh_sharded_solve(world, name, tmp_path):
     assert np.allclose(lp.row_activity(r0["col_value"]), r0["row_value"], rtol=1e-9, atol=1e-9)
 
 
-@pytest.mark.parametrize("case,world", [("iterate:25fv47:40", 4), ("iterate:synth:120", 2), ("iterate:synth:120", 8)])
+@pytest.mark.parametrize("case,world", [("iterate:25fv47:40", 4), ("iterate:synth:120", 2), ("iterate:synth:120", 8),
+                                        ("iterate:synthbig:80", 4)])  # the bench workload (1M x 1M, slab layout, 2 MB slices)
 def test_mesh_fixed_iterations_match_single_gpu(case, world, tmp_path):
     _, name, k = case.split(":")
     k = int(k)
-    if name == "synth":
-        sp_ = solver.SyntheticProblem(20000, 20000, 160000, 3)
+    if name in ("synth", "synthbig"):
+        sp_ = solver.SyntheticProblem(*((20000, 20000, 160000, 3) if name == "synth" else (1000000, 1000000, 8000000, 1)))
         S = solver.DeviceSolver(problem_struct=sp_.struct)
     else:
         S = solver.DeviceSolver(lp=_lp(name))
