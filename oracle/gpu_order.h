@@ -1,0 +1,66 @@
+/*
+ * gpu_order.h — TEST INFRASTRUCTURE ONLY (shared by pdlp_oracle.c and hipdlp_oracle.c).
+ *
+ * The summation orders of the HIP kernels' reductions, restated on the CPU so that the oracles
+ * can follow a GPU solve bit for bit ("device reduction order" mode, opt->reserved[0] == 1):
+ * per-lane strided accumulation, 64-lane shuffle tree (waveSum), fixed-order sum of the 4 wave
+ * results (blockSum), 4-chain sum of the per-block partials (reducePartials) —
+ * highs_amd/csrc/pdlp_devfn.hpp, pdlp_kernels.hip (vector kernels), pdlp_halpern.hip.
+ * Constants mirror pdlp_kernels.hpp: 256 lanes per block, vector grids capped at 2048 blocks.
+ */
+#ifndef ORACLE_GPU_ORDER_H_
+#define ORACLE_GPU_ORDER_H_
+#include <string.h>
+
+enum { G_T = 256, G_WAVE = 64, G_CHUNK = 2048, G_MAXMAJ = 2048, G_MAXGRID = 2048 };
+
+static inline double g_wave_tree(const double* lane /* [64] */) {
+  double v[G_WAVE], t[G_WAVE];
+  memcpy(v, lane, sizeof(v));
+  for (int off = G_WAVE / 2; off > 0; off >>= 1) {
+    for (int i = 0; i < G_WAVE; ++i) t[i] = v[i] + (i + off < G_WAVE ? v[i + off] : v[i]); /* __shfl_down */
+    memcpy(v, t, sizeof(v));
+  }
+  return v[0];
+}
+static inline double g_block_sum(const double* perThread /* [256] */) {
+  double r = 0.0;
+  for (int w = 0; w < G_T / G_WAVE; ++w) r += g_wave_tree(perThread + w * G_WAVE);
+  return r;
+}
+/* reducePartials: lane t sums p[t], p[t+256], ... in 4 independent chains */
+static inline double g_reduce_partials(const double* p, int count) {
+  double lane[G_T];
+  for (int t = 0; t < G_T; ++t) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int i = t;
+    for (; i + 3 * G_T < count; i += 4 * G_T) { s0 += p[i]; s1 += p[i + G_T]; s2 += p[i + 2 * G_T]; s3 += p[i + 3 * G_T]; }
+    for (; i < count; i += G_T) s0 += p[i];
+    lane[t] = (s0 + s1) + (s2 + s3);
+  }
+  return g_block_sum(lane);
+}
+static inline int g_vec_blocks(int len) {
+  long b = ((long)len + G_T - 1) / G_T;
+  if (b < 1) b = 1;
+  if (b > G_MAXGRID) b = G_MAXGRID;
+  return (int)b;
+}
+/* grid-stride reduction of f(i), i < len, as the vector kernels do it */
+typedef double (*g_elem_fn)(const void* ctx, int i);
+static inline double g_grid_sum(int len, g_elem_fn f, const void* ctx, double* partScratch) {
+  const int nb = g_vec_blocks(len > 0 ? len : 1), stride = nb * G_T;
+  for (int b = 0; b < nb; ++b) {
+    double lane[G_T];
+    for (int t = 0; t < G_T; ++t) {
+      double a = 0.0;
+      for (long i = (long)b * G_T + t; i < len; i += stride) a += f(ctx, (int)i);
+      lane[t] = a;
+    }
+    partScratch[b] = g_block_sum(lane);
+  }
+  return g_reduce_partials(partScratch, nb);
+}
+
+
+#endif

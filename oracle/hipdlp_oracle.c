@@ -29,6 +29,13 @@
  * (tests/golden/make_golden_hipdlp.py -> tests/golden/reference_hipdlp.json:
  * iteration counts, objectives and full solutions of the check instances).
  *
+ * Second summation mode (opt->reserved[0] == 1, "device reduction order"): the HIP path's Halpern steps
+ * are bit-identical to the loops below; its only arithmetic difference is the ORDER in which the
+ * power method's dot products, the fixed-point error sums, the check statistics and the two restart
+ * norms are added (vector-kernel grid sums, gpu_order.h).  In that mode this oracle follows a whole GPU
+ * solve bit for bit (tests/test_gpu_hipdlp.py).  Limitation of the mode: majors longer than 2048
+ * nonzeros (summed block-strided on the GPU) are not restated.
+ *
  * Reference behaviours reproduced on purpose (they are what a drop-in must match):
  *  - the objective sense is NOT applied to the costs (pdhg.cc:171 only stores it, :481 uses
  *    it for col_dual): a maximisation LP is minimised;
@@ -41,6 +48,7 @@
 #include <string.h>
 #include <time.h>
 
+#include "gpu_order.h"
 #include "pdlp_oracle.h"
 
 enum { H_EQ = 0, H_LEQ = 1, H_GEQ = 2, H_BOUND = 3, H_FREE = 4 };
@@ -79,6 +87,29 @@ static void h_aty(const HLp* L, const double* y, double* out) {
 static double h_dot(const double* a, const double* b, int n) {
   double s = 0.0;
   for (int i = 0; i < n; ++i) s += a[i] * b[i];
+  return s;
+}
+
+/* ---- device reduction order (gpu_order.h) ------------------------------------------------ */
+typedef struct { const double *a, *b, *c, *d, *e, *f; const unsigned char* flag; int scaled; } HCtx;
+static double e_dot(const void* v, int i) { const HCtx* c = (const HCtx*)v; return c->a[i] * c->b[i]; }
+static double e_diff2(const void* v, int i) { const HCtx* c = (const HCtx*)v; const double d = c->a[i] - c->b[i]; return d * d; }
+static double e_diffdot(const void* v, int i) { const HCtx* c = (const HCtx*)v; return (c->a[i] - c->b[i]) * c->c[i]; }
+static double g_sum(int len, g_elem_fn f, const HCtx* c) {
+  double* scratch = (double*)xmalloc(sizeof(double) * (size_t)G_MAXGRID);
+  const double r = g_grid_sum(len, f, c, scratch);
+  free(scratch);
+  return r;
+}
+static double x_dot(int dev, const double* a, const double* b, int n) {
+  if (!dev) return h_dot(a, b, n);
+  HCtx c = {a, b, 0, 0, 0, 0, 0, 0};
+  return g_sum(n, e_dot, &c);
+}
+static double x_diff2(int dev, const double* a, const double* b, int n) {
+  if (dev) { HCtx c = {a, b, 0, 0, 0, 0, 0, 0}; return g_sum(n, e_diff2, &c); }
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) { const double d = a[i] - b[i]; s += d * d; }
   return s;
 }
 
@@ -242,7 +273,7 @@ static void h_scale(HLp* L, int ruiz, int pc, int l2, int ruizIters) {
 }
 
 /* powerMethod, pdhg.cc:1529-1670, kCuPdlpAATPowerMethod */
-static double h_power_method(const HLp* L) {
+static double h_power_method(const HLp* L, int dev) {
   if (L->n == 0 || L->m == 0) return 1.0;
   double* x = dvec(L->m);
   double* y = dvec(L->n);
@@ -252,10 +283,10 @@ static double h_power_method(const HLp* L) {
   for (int it = 0; it < 20; ++it) {
     h_aty(L, x, y);
     h_ax(L, y, z);
-    const double zn = sqrt(h_dot(z, z, L->m));
+    const double zn = sqrt(x_dot(dev, z, z, L->m));
     for (int i = 0; i < L->m; ++i) z[i] /= zn;
     h_aty(L, z, y);
-    lambda = h_dot(y, y, L->n);
+    lambda = x_dot(dev, y, y, L->n);
     memcpy(x, z, sizeof(double) * (size_t)L->m);
   }
   free(x); free(y); free(z);
@@ -268,8 +299,58 @@ typedef struct {
 
 /* checkConvergence, pdhg.cc:1474-1527.  cachedSlack != NULL: the major-step dual slack
  * (computeDualSlacks :1336-1346), else the sign projection. */
+/* element functions of the device-order check (k_h_row_stats / k_h_col_stats, pdlp_halpern.hip) */
+static double e_row0(const void* v, int i) {
+  const HCtx* c = (const HCtx*)v; /* a=ax b=rl c=rowScale flag=isEq */
+  double r = c->a[i] - c->b[i];
+  if (!c->flag[i]) r = r < 0.0 ? r : 0.0;
+  if (c->scaled) r *= c->c[i];
+  return r * r;
+}
+static double e_row1(const void* v, int i) { const HCtx* c = (const HCtx*)v; return c->b[i] * c->d[i]; } /* rl*y */
+typedef struct { const HLp* L; const double *x, *aty, *sp, *sn; } HColCtx;
+static double e_col0(const void* v, int j) {
+  const HColCtx* c = (const HColCtx*)v;
+  double t = (c->L->cost[j] - c->aty[j]) - c->sp[j] + c->sn[j];
+  if (c->L->scaled) t *= c->L->colScale[j];
+  return t * t;
+}
+static double e_col1(const void* v, int j) { const HColCtx* c = (const HColCtx*)v; return c->L->cost[j] * c->x[j]; }
+static double e_col2(const void* v, int j) { const HColCtx* c = (const HColCtx*)v; return c->L->lower[j] > -INFINITY ? c->L->lower[j] * c->sp[j] : 0.0; }
+static double e_col3(const void* v, int j) { const HColCtx* c = (const HColCtx*)v; return c->L->upper[j] < INFINITY ? c->L->upper[j] * c->sn[j] : 0.0; }
+
 static int h_check(const HLp* L, const double* x, const double* y, const double* ax, const double* aty,
-                   const double* cachedSlack, double eps, HRes* r, double* sp, double* sn) {
+                   const double* cachedSlack, double eps, HRes* r, double* sp, double* sn, int dev) {
+  if (dev) { /* same quantities, sums in the kernels' order and the host's combination (pdlp_halpern.cpp check()) */
+    for (int j = 0; j < L->n; ++j) {
+      const double dr = L->cost[j] - aty[j];
+      double ds = 0.0;
+      if (cachedSlack) ds = cachedSlack[j];
+      else {
+        const int hasL = L->lower[j] > -INFINITY, hasU = L->upper[j] < INFINITY;
+        if (hasL && hasU) ds = dr;
+        else if (hasL) ds = dr > 0.0 ? dr : 0.0;
+        else if (hasU) ds = dr < 0.0 ? dr : 0.0;
+      }
+      sp[j] = ds > 0.0 ? ds : 0.0;
+      sn[j] = -ds > 0.0 ? -ds : 0.0;
+    }
+    HCtx rc = {ax, L->rl, L->rowScale, y, 0, 0, L->isEq, L->scaled};
+    HColCtx cc = {L, x, aty, sp, sn};
+    double* scratch = (double*)xmalloc(sizeof(double) * (size_t)G_MAXGRID);
+    const double rs0 = g_grid_sum(L->m, e_row0, &rc, scratch), rs1 = g_grid_sum(L->m, e_row1, &rc, scratch);
+    const double cs0 = g_grid_sum(L->n, e_col0, &cc, scratch), cs1 = g_grid_sum(L->n, e_col1, &cc, scratch);
+    const double cs2 = g_grid_sum(L->n, e_col2, &cc, scratch), cs3 = g_grid_sum(L->n, e_col3, &cc, scratch);
+    free(scratch);
+    r->pFeas = sqrt(rs0);
+    r->dFeas = sqrt(cs0);
+    r->pObj = L->offset + cs1;
+    r->dObj = ((L->offset + rs1) + cs2) - cs3;
+    const double g = r->pObj - r->dObj;
+    r->gap = fabs(g);
+    r->relGap = fabs(g) / (1.0 + fabs(r->pObj) + fabs(r->dObj));
+    return r->pFeas < eps * (1.0 + L->bNorm) && r->dFeas < eps * (1.0 + L->cNorm) && r->relGap < eps;
+  }
   double s = 0.0;
   for (int i = 0; i < L->m; ++i) {
     double v = ax[i] - L->rl[i];
@@ -313,7 +394,7 @@ typedef struct {
   HLp L;
   double *xc, *yc, *xn, *yn, *rx, *ry, *xa, *ya, *aty, *axn, *slack, *sp, *sn;
   double tau, sigma, eta, omega, beta, pw, bestPw, bestGap, errSum, lastErr;
-  int hIter, slackValid;
+  int hIter, slackValid, dev;
 } HState;
 
 /* performHalpernPdhgStep, pdhg.cc:961-1018 */
@@ -360,6 +441,12 @@ static double h_fpe(const HState* S) {
   for (int i = 0; i < L->m; ++i) { dy[i] = S->yn[i] - S->ry[i]; dn += dy[i] * dy[i]; }
   h_aty(L, dy, atd);
   for (int j = 0; j < L->n; ++j) cross += dx[j] * atd[j];
+  if (S->dev) { /* k_h_fpe_rows / k_h_fpe_cols */
+    HCtx c = {S->xn, S->rx, atd, 0, 0, 0, 0, 0};
+    dn = x_diff2(1, S->yn, S->ry, L->m);
+    pn = x_diff2(1, S->xn, S->rx, L->n);
+    cross = g_sum(L->n, e_diffdot, &c);
+  }
   free(dx); free(dy); free(atd);
   const double movement = pn * S->omega + dn / S->omega;
   const double interaction = 2.0 * S->eta * cross;
@@ -370,8 +457,8 @@ static double h_fpe(const HState* S) {
 static void h_update_weight(HState* S, const HRes* res) {
   const HLp* L = &S->L;
   double pd = 0.0, dd = 0.0;
-  for (int j = 0; j < L->n; ++j) { const double d = S->xn[j] - S->xa[j]; pd += d * d; }
-  for (int i = 0; i < L->m; ++i) { const double d = S->yn[i] - S->ya[i]; dd += d * d; }
+  pd = x_diff2(S->dev, S->xn, S->xa, L->n);
+  dd = x_diff2(S->dev, S->yn, S->ya, L->m);
   pd = sqrt(pd); dd = sqrt(dd);
   const double relP = res->pFeas / (1.0 + L->bNorm), relD = res->dFeas / (1.0 + L->cNorm);
   const double ratio = relP > 0.0 ? relD / relP : 1e300;
@@ -421,10 +508,11 @@ static int h_solve(const pdlp_problem_t* P, const pdlp_params_t* opt, pdlp_resul
   const int n = L->n, m = L->m;
   const double eps = opt->gap_tol;
   const int pid = opt->step_size_strategy != 0;
+  S.dev = opt->reserved[0] == 1;
   /* initializeStepSizes */
   S.omega = (L->cNorm + 1.0) / (L->bNorm + 1.0);
   S.pw = S.omega; S.bestPw = S.pw; S.beta = S.pw * S.pw;
-  const double lambda = h_power_method(L);
+  const double lambda = h_power_method(L, S.dev);
   const double base = 0.998 / sqrt(lambda);
   S.eta = base; S.tau = base / S.omega; S.sigma = base * S.omega;
   S.bestGap = INFINITY;
@@ -450,7 +538,7 @@ static int h_solve(const pdlp_problem_t* P, const pdlp_params_t* opt, pdlp_resul
   double fpe = 0.0, initFpe = 0.0, lastFpe = INFINITY;
   HRes res;
   memset(&res, 0, sizeof(res));
-  if (h_check(L, S.xc, S.yc, axT, S.aty, NULL, eps, &res, S.sp, S.sn)) {
+  if (h_check(L, S.xc, S.yc, axT, S.aty, NULL, eps, &res, S.sp, S.sn, S.dev)) {
     memcpy(outX, S.xc, sizeof(double) * (size_t)n);
     memcpy(outY, S.yc, sizeof(double) * (size_t)m);
     term = 0;
@@ -471,7 +559,7 @@ static int h_solve(const pdlp_problem_t* P, const pdlp_params_t* opt, pdlp_resul
     iters += H_CHECK_INTERVAL;
     h_ax(L, S.xn, axT);
     h_aty(L, S.yn, atyT);
-    if (h_check(L, S.xn, S.yn, axT, atyT, S.slackValid ? S.slack : NULL, eps, &res, S.sp, S.sn)) {
+    if (h_check(L, S.xn, S.yn, axT, atyT, S.slackValid ? S.slack : NULL, eps, &res, S.sp, S.sn, S.dev)) {
       memcpy(outX, S.xn, sizeof(double) * (size_t)n);
       memcpy(outY, S.yn, sizeof(double) * (size_t)m);
       term = 0;

@@ -125,3 +125,24 @@ def test_random_lps_with_every_row_and_column_kind(seed):
     a, b = lp.objective_value(gpu.solution.col_value), lp.objective_value(ora.solution.col_value)
     assert abs(a - b) <= 1e-6 * (1 + abs(b))
     assert np.allclose(gpu.solution.row_dual, ora.solution.row_dual, rtol=1e-4, atol=1e-5 * (1 + np.abs(ora.solution.row_dual).max()))
+
+
+@pytest.mark.parametrize("name,opts", [("afiro", {}), ("adlittle", {}), ("shell", {}), ("blending", {}), ("standgub", {}),
+                                       ("e226", {}), ("afiro", {"pdlp_step_size_strategy": 0, "kkt_tolerance": 1e-5}),
+                                       ("adlittle", {"pdlp_features_off": 1, "kkt_tolerance": 1e-4})])
+def test_whole_solve_bit_exact_in_device_reduction_order(name, opts, monkeypatch):
+    """With the oracle summing its reductions in the HIP kernels' order (oracle/gpu_order.h) a complete
+    HiPDLP solve on the GPU — power method, every Halpern step, fixed-point errors, checks, restarts, PID
+    primal weight, post-solve — is reproduced BIT FOR BIT.  (In its other mode the same oracle reproduces
+    the reference binary's iteration counts and objectives: tests/test_hipdlp_oracle.py.)"""
+    monkeypatch.setenv("PDLP_MI355X_SLAB", "0")  # the oracle's mode restates the CSR-stream SpMV (short majors)
+    lp = _lp(name)
+    ora = solver.solveLpHiPdlp(lp, solve_fn=O.hipdlp_solve_fn(), device_reduction_order=True, **opts)
+    gpu = solver.solveLpHiPdlp(lp, **opts)
+    assert gpu.model_status == ora.model_status == solver.kOptimal
+    assert gpu.pdlp_iteration_count == ora.pdlp_iteration_count
+    assert gpu.result.num_restarts == ora.result.num_restarts
+    for k in ("col_value", "col_dual", "row_value", "row_dual"):
+        assert np.array_equal(getattr(gpu.solution, k), getattr(ora.solution, k)), k
+    for k in ("primal_obj", "dual_obj", "primal_feas", "dual_feas", "rel_gap"):
+        assert getattr(gpu.result, k) == getattr(ora.result, k), k

@@ -39,7 +39,7 @@ def test_oracle_reproduces_reference_binary(name, key):
     assert out.pdlp_iteration_count == g["pdlp_iterations"]
     obj = lp.objective_value(out.solution.col_value)
     ref_obj = float(g["objective"])
-    assert abs(obj - ref_obj) <= 4e-16 * max(1.0, abs(ref_obj)) * 4, (obj, ref_obj)
+    assert abs(obj - ref_obj) <= 1e-12 * max(1.0, abs(ref_obj)), (obj, ref_obj)  # the file prints 14-16 digits
     for k, a in (("col_value", out.solution.col_value), ("row_value", out.solution.row_value),
                  ("col_dual", out.solution.col_dual), ("row_dual", out.solution.row_dual)):
         b = np.asarray(g[k])
