@@ -97,3 +97,109 @@ def test_sharded_trial_step_matches_unsharded_oracle(world):
     blocks = sorted((v[1], v[2]) for v in ret.values())
     assert blocks[0][0] == 0 and all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
     assert all(v[0] for v in ret.values())
+
+
+def _mesh_worker(rank, world, port, ret):
+    """The exchange pattern of the direct xGMI mesh path (highs_amd/csrc/pdlp_mesh.hip), restated with gloo:
+    rank g owns row block [r0,r1) AND column slice [c0,c1); X = all-gather of x+ slices, P = the partials of
+    every rank added IN RANK ORDER by the slice owner (reduce-scatter), S = the three scalars added in rank
+    order on every rank."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sp_ = solver.SyntheticProblem(3000, 2500, 24000, 11)
+        lp = sp_.to_lp()
+        P = solver.Prepared(problem_struct=sp_.struct)
+        n, m = P.n, P.m
+        off = P.row_partition(world)
+        r0, r1 = int(off[rank]), int(off[rank + 1])
+        col = [n * h // world for h in range(world + 1)]  # Mesh::Mesh: colOff[h] = n*h/world
+        c0, c1 = col[rank], col[rank + 1]
+        import scipy.sparse as sps
+        A = sps.csr_matrix((P.csr_val, P.csr_idx, P.csr_beg), shape=(m, n))
+        Ag = A[r0:r1]
+        rng = np.random.default_rng(3)
+        x = np.clip(rng.standard_normal(n), P.lower, P.upper)
+        y = rng.standard_normal(m)
+        y[P.n_eqs:] = np.maximum(y[P.n_eqs:], 0)
+        tau, sigma, beta = 0.31, 0.23, 0.23 / 0.31
+
+        def all_gather(arr):
+            t = torch.from_numpy(np.ascontiguousarray(arr))
+            outs = [torch.zeros(len(arr), dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(outs, t)
+            return [o.numpy() for o in outs]
+
+        def reduce_scatter_rank_order(partial_full):  # every rank's full-length partial -> own slice, rank order
+            parts = all_gather(partial_full)
+            s = np.zeros(c1 - c0)
+            for h in range(world):
+                s = s + parts[h][c0:c1]
+            return s
+
+        ax_g = Ag @ x
+        aty_slice = reduce_scatter_rank_order(np.asarray(Ag.T @ y[r0:r1]))  # aty of the current iterate, own slice
+        # 1. primal step on the own slice, then X: all-gather of the x+ slices
+        v = x[c0:c1].copy(); v += (-tau) * P.cost[c0:c1]; v += tau * aty_slice
+        v = np.where(v < P.upper[c0:c1], v, P.upper[c0:c1]); v = np.where(v > P.lower[c0:c1], v, P.lower[c0:c1])
+        # (slices have different lengths: pad to n for the gather)
+        pad = np.zeros(n); pad[c0:c1] = v
+        xU = np.zeros(n)
+        for h, part in enumerate(all_gather(pad)):
+            xU[col[h]:col[h + 1]] = part[col[h]:col[h + 1]]
+        # 2. local rows: A_g x+ and the dual step
+        axU_g = Ag @ xU
+        yg = y[r0:r1]
+        w = yg.copy(); w += sigma * P.rhs[r0:r1]; w += (-2.0 * sigma) * axU_g; w += sigma * ax_g
+        ineq = (np.arange(r0, r1) >= P.n_eqs)
+        yU_g = np.where(ineq, np.where(w > 0, w, 0.0), w)
+        # 3. P: partial A_g' y+ -> owner slices in rank order; interaction partials on the slice
+        atyU_slice = reduce_scatter_rank_order(np.asarray(Ag.T @ yU_g))
+        dx = x[c0:c1] - xU[c0:c1]
+        mine = np.array([float(np.sum(dx * dx)), float(np.sum((yg - yU_g) ** 2)), float(np.sum(dx * (aty_slice - atyU_slice)))])
+        # 4. S: scalars of every rank, added in rank order by every rank
+        tot = np.zeros(3)
+        for part in all_gather(mine):
+            tot = tot + part
+        dX2, dY2, inter = tot
+        sb = np.sqrt(beta)
+        limit = (dX2 * 0.5 * sb + dY2 / (2 * sb)) / abs(inter)
+        accept = np.sqrt(tau * sigma) <= limit
+        sig = np.array([dX2, dY2, inter, limit, float(accept), float(np.sum(xU))])
+        same = all(np.array_equal(g, sig) for g in all_gather(sig))
+        # unsharded oracle on the assembled vectors
+        aty = np.zeros(n)
+        padA = np.zeros(n); padA[c0:c1] = aty_slice
+        for h, part in enumerate(all_gather(padA)):
+            aty[col[h]:col[h + 1]] = part[col[h]:col[h + 1]]
+        axp = np.zeros(m); axp[r0:r1] = ax_g
+        ax = np.sum(all_gather(axp), axis=0)
+        Ph = abi.ProblemHandle(lp)
+        F = O.Formulated()
+        prm = abi.default_params()
+        assert O.oracle().pdlp_oracle_formulate_scale(C.byref(Ph.struct), C.byref(prm), C.byref(F)) == 0
+        xo, yo, axo, atyo, o3 = np.zeros(n), np.zeros(m), np.zeros(m), np.zeros(n), np.zeros(3)
+        d = lambda a: np.ascontiguousarray(a).ctypes.data_as(abi.c_f64p)
+        xc, yc, axc, atyc = map(np.ascontiguousarray, (x, y, ax, aty))
+        O.oracle().pdlp_oracle_trial_step(C.byref(F), tau, sigma, d(xc), d(yc), d(axc), d(atyc), d(xo), d(yo), d(axo), d(atyo), d(o3))
+        O.oracle().pdlp_oracle_free_formulated(C.byref(F))
+        ok = (same and np.array_equal(xU, xo) and np.allclose(yU_g, yo[r0:r1], rtol=0, atol=1e-12)
+              and np.allclose(atyU_slice, atyo[c0:c1], rtol=0, atol=1e-11) and np.allclose([dX2, dY2, inter], o3, rtol=1e-10))
+        ret[rank] = (bool(ok), c0, c1)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_mesh_exchange_pattern_matches_unsharded_oracle(world):
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 31500 + (os.getpid() % 2000) + world
+    mp.spawn(_mesh_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert len(ret) == world and all(v[0] for v in ret.values())
+    sl = sorted((v[1], v[2]) for v in ret.values())
+    assert sl[0][0] == 0 and all(sl[i][1] == sl[i + 1][0] for i in range(world - 1))
