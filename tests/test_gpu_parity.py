@@ -372,3 +372,57 @@ def test_gpu_setup_long_rows_slab_layout(monkeypatch):
     assert np.allclose(ax_g, ax_o, rtol=1e-13, atol=1e-13)
     assert np.array_equal(S.get("aty", P.n), _spmv(P.csc_beg, P.csc_idx, P.csc_val, y, P.n))
     S.close()
+
+
+def test_concurrent_solver_contexts_on_two_threads():
+    """SURVEY §8b threading contract: several Highs instances may call the path concurrently from different
+    threads, so a context holds no process-global mutable state.  Two threads solve different LPs (both
+    reference paths) at the same time; every result must be bit-identical to the same solve done alone."""
+    import threading
+    lps = {"afiro": _lp("afiro"), "adlittle": _lp("adlittle"), "shell": _lp("shell"), "sctest": _lp("sctest")}
+    fns = {"afiro": solver.solveLpCupdlp, "adlittle": solver.solveLpHiPdlp, "shell": solver.solveLpHiPdlp,
+           "sctest": solver.solveLpCupdlp}
+    alone = {k: fns[k](lp) for k, lp in lps.items()}
+    out, errs = {}, []
+
+    def work(name):
+        try:
+            for _ in range(3):
+                out[name] = fns[name](lps[name])
+        except Exception as e:  # noqa: BLE001
+            errs.append((name, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in lps]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    for k in lps:
+        assert out[k].model_status == alone[k].model_status == solver.kOptimal
+        assert out[k].pdlp_iteration_count == alone[k].pdlp_iteration_count
+        assert np.array_equal(out[k].solution.col_value, alone[k].solution.col_value), k
+        assert np.array_equal(out[k].solution.row_dual, alone[k].solution.row_dual), k
+
+
+def test_time_limit_status_on_both_paths():
+    """time_limit exceeded -> kTimeLimit (CupdlpWrapper.cpp:235: iters < limit-1; HiPdlpWrapper.cpp:120-123)."""
+    sp_ = solver.SyntheticProblem(200000, 200000, 1600000, 5)
+    lp = sp_.to_lp()
+    a = solver.solveLpCupdlp(lp, kkt_tolerance=1e-12, time_limit=0.2)
+    assert a.model_status == solver.kTimeLimit and a.pdlp_iteration_count > 0
+    b = solver.solveLpHiPdlp(lp, kkt_tolerance=1e-12, time_limit=0.2)
+    assert b.model_status == solver.kTimeLimit and b.pdlp_iteration_count > 0 and b.pdlp_iteration_count % 40 == 0
+
+
+def test_bad_arguments_are_reported_not_thrown():
+    import ctypes as C
+    L_ = solver.lib()
+    assert L_.pdlp_mi355x_solve(None, None, None) != 0
+    assert b"null" in L_.pdlp_mi355x_last_error()
+    prm = abi.default_params()
+    prm.algorithm = 7
+    P = abi.ProblemHandle(_lp("afiro"))
+    R = abi.ResultHandle(32, 27)
+    assert L_.pdlp_mi355x_solve(C.byref(P.struct), C.byref(prm), C.byref(R.struct)) != 0
+    assert b"algorithm" in L_.pdlp_mi355x_last_error()
