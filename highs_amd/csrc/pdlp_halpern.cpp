@@ -44,29 +44,53 @@ HalpernSolver::HalpernSolver(const pdlp_problem_t& P, const pdlp_params_t& opt) 
     log(1, "HiPDLP uses Halpern restart only; ignoring the restart-off feature flag.\n");  // pdhg.cc:1846-1852
   pid_ = opt_.step_size_strategy != 0;  // 0 fixed; everything else runs as PID (pdhg.cc:1856-1864)
 
-  formulateHipdlp(P, F_);
-  if (P.num_col > 0) {
+  if (P.num_col > 0 && P.a_start) {
     origBeg_.assign(P.a_start, P.a_start + P.num_col + 1);
     origIdx_.assign(P.a_index, P.a_index + origBeg_[P.num_col]);
     origVal_.assign(P.a_value, P.a_value + origBeg_[P.num_col]);
     origCost_.assign(P.col_cost, P.col_cost + P.num_col);
   }
-  if (!(opt_.features_off & PDLP_FEATURE_SCALING_OFF))
-    scaleHipdlp(F_, opt_.scaling_mode & 1, opt_.scaling_mode & 4, opt_.scaling_mode & 2, opt_.ruiz_iterations);
-  finalize(F_);  // rows ascending column; columns are already ascending row
-  const int32_t n = F_.n, m = F_.m;
+  const bool doScale = !(opt_.features_off & PDLP_FEATURE_SCALING_OFF);
   int slabMode = -1;
   if (const char* g = getenv("PDLP_MI355X_SLAB")) slabMode = atoi(g);
-  dA_.upload(F_.csr, m, n, slabMode, stream_);
-  dAt_.upload(F_.cscSorted, n, m, slabMode, stream_);
-  auto up = [&](DeviceArray<double>& d, const std::vector<double>& h) {
-    d.alloc(h.size());
-    d.upload(h.data(), h.size(), stream_);
-  };
-  up(cost_, F_.cost); up(lower_, F_.lower); up(upper_, F_.upper); up(rl_, F_.rhs); up(ru_, F_.rowUpper);
-  up(colScale_, F_.colScale); up(rowScale_, F_.rowScale);
-  isEq_.alloc((size_t)m);
-  isEq_.upload(F_.rowIsEq.data(), (size_t)m, stream_);
+  // preprocessing + scaling + both orientations (+ slab layouts) on the device for big LPs, on the host
+  // for small ones: same bits either way (tests)
+  const int64_t nnzIn = P.num_col > 0 && P.a_start ? (int64_t)P.a_start[P.num_col] : 0;
+  bool gpuSetup = nnzIn >= 200000;
+  if (const char* g = getenv("PDLP_MI355X_GPU_SETUP")) gpuSetup = atoi(g) != 0;
+  if (gpuSetup) {
+    HipdlpSetup hs;
+    hs.ruiz = opt_.scaling_mode & 1; hs.pc = opt_.scaling_mode & 4; hs.l2 = opt_.scaling_mode & 2;
+    hs.ruizIters = opt_.ruiz_iterations;
+    DeviceProblem D;
+    gpuPrepare(P, doScale, stream_, D, &hs);
+    F_ = StandardForm();
+    F_.n = D.n; F_.m = D.m; F_.n0 = D.n0; F_.nEqs = D.nEqs; F_.nnz = D.nnz;
+    F_.scaled = D.scaled; F_.offset = D.offset; F_.sense = D.sense;
+    F_.normCost = D.normCost; F_.normRhs = D.normRhs;
+    F_.rowKind = std::move(D.rowKind); F_.rowNewIdx = std::move(D.rowNewIdx);
+    F_.colScale = std::move(D.hColScale); F_.rowScale = std::move(D.hRowScale);
+    dA_.buildFromDevice(D.A, slabMode, stream_);
+    dAt_.buildFromDevice(D.At, slabMode, stream_);
+    cost_ = std::move(D.cost); lower_ = std::move(D.lower); upper_ = std::move(D.upper); rl_ = std::move(D.rhs);
+    ru_ = std::move(D.rowUpper); colScale_ = std::move(D.colScale); rowScale_ = std::move(D.rowScale);
+    isEq_ = std::move(D.rowIsEq);
+  } else {
+    formulateHipdlp(P, F_);
+    if (doScale) scaleHipdlp(F_, opt_.scaling_mode & 1, opt_.scaling_mode & 4, opt_.scaling_mode & 2, opt_.ruiz_iterations);
+    finalize(F_);  // rows ascending column; columns are already ascending row
+    dA_.upload(F_.csr, F_.m, F_.n, slabMode, stream_);
+    dAt_.upload(F_.cscSorted, F_.n, F_.m, slabMode, stream_);
+    auto up = [&](DeviceArray<double>& d, const std::vector<double>& h) {
+      d.alloc(h.size());
+      d.upload(h.data(), h.size(), stream_);
+    };
+    up(cost_, F_.cost); up(lower_, F_.lower); up(upper_, F_.upper); up(rl_, F_.rhs); up(ru_, F_.rowUpper);
+    up(colScale_, F_.colScale); up(rowScale_, F_.rowScale);
+    isEq_.alloc((size_t)F_.m);
+    isEq_.upload(F_.rowIsEq.data(), (size_t)F_.m, stream_);
+  }
+  const int32_t n = F_.n, m = F_.m;
   for (DeviceArray<double>* d : {&xc_, &xn_, &rx_, &xa_, &slack_, &sp_, &sn_, &outX_, &tmpN_}) { d->alloc(n); d->zero(stream_); }
   for (DeviceArray<double>* d : {&yc_, &yn_, &ry_, &ya_, &outY_, &tmpM_, &tmpM2_}) { d->alloc(m); d->zero(stream_); }
   stride_ = std::max(vecBlocks(std::max(n, 1)), vecBlocks(std::max(m, 1)));

@@ -23,19 +23,23 @@ inline int gridFor(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_
 constexpr double kBoundInf = 1e20;
 
 // ---- formulate -----------------------------------------------------------------
-__global__ void k_row_classify(const double* __restrict__ lo, const double* __restrict__ up, int m, int32_t* kind,
-                               int32_t* eqFlag, int32_t* ineqFlag, int32_t* slackFlag) {
+// infThresh / freeKind: 1e20 and kRowBound on the cuPDLP-C path (CupdlpWrapper.cpp:316-343); +inf and
+// kRowFree on the HiPDLP path (pdhg.cc:175-197)
+__device__ __forceinline__ bool isEqKind(int k) { return k == kRowEq || k == kRowBound || k == kRowFree; }
+__global__ void k_row_classify(const double* __restrict__ lo, const double* __restrict__ up, int m, double infThresh,
+                               int freeKind, int32_t* kind, int32_t* eqFlag, int32_t* ineqFlag, int32_t* slackFlag) {
   GSTRIDE(i, m) {
-    const bool hl = lo[i] > -kBoundInf, hu = up[i] < kBoundInf;
+    const bool hl = lo[i] > -infThresh, hu = up[i] < infThresh;
     int k;
     if (hl && hu && lo[i] == up[i]) k = kRowEq;
     else if (hl && !hu) k = kRowGeq;
     else if (!hl && hu) k = kRowLeq;
-    else k = kRowBound;  // ranged or free: a'x - z = 0 with a bounded slack
+    else if (hl && hu) k = kRowBound;  // ranged: a'x - z = 0 with a bounded slack
+    else k = freeKind;                 // free: the same, unbounded slack
     kind[i] = k;
-    eqFlag[i] = (k == kRowEq || k == kRowBound) ? 1 : 0;
+    eqFlag[i] = isEqKind(k) ? 1 : 0;
     ineqFlag[i] = (k == kRowLeq || k == kRowGeq) ? 1 : 0;
-    slackFlag[i] = (k == kRowBound) ? 1 : 0;
+    slackFlag[i] = (k == kRowBound || k == kRowFree) ? 1 : 0;
   }
 }
 
@@ -45,22 +49,24 @@ __device__ __forceinline__ double clampInfUp(double v) { return v > kBoundInf ? 
 __global__ void k_row_finish(const double* __restrict__ lo, const double* __restrict__ up, const int32_t* kind,
                              const int32_t* eqRank, const int32_t* ineqRank, const int32_t* slackRank, int m, int n0,
                              int nEq, int64_t nnz0, int32_t* rowNewIdx, double* rhs, double* cost, double* lower,
-                             double* upper, int32_t* cscBeg, int32_t* cscIdx, int32_t* cscCol, double* cscVal) {
+                             double* upper, int32_t* cscBeg, int32_t* cscIdx, int32_t* cscCol, double* cscVal,
+                             double* rowUpper /* HiPDLP form only, else nullptr */) {
   GSTRIDE(i, m) {
     const int k = kind[i];
-    const int ni = (k == kRowEq || k == kRowBound) ? eqRank[i] : nEq + ineqRank[i];
+    const int ni = isEqKind(k) ? eqRank[i] : nEq + ineqRank[i];
     rowNewIdx[i] = ni;
     double r;
     if (k == kRowEq) r = lo[i];
-    else if (k == kRowBound) r = 0.0;
+    else if (k == kRowBound || k == kRowFree) r = 0.0;
     else if (k == kRowLeq) r = -up[i];
     else r = lo[i];
     rhs[ni] = r;
-    if (k == kRowBound) {
+    if (rowUpper) rowUpper[ni] = (k == kRowEq) ? up[i] : ((k == kRowBound || k == kRowFree) ? 0.0 : INFINITY);
+    if (k == kRowBound || k == kRowFree) {
       const int j = n0 + slackRank[i];
       cost[j] = 0.0;
-      lower[j] = clampInfLo(lo[i]);
-      upper[j] = clampInfUp(up[i]);
+      lower[j] = rowUpper ? lo[i] : clampInfLo(lo[i]);
+      upper[j] = rowUpper ? up[i] : clampInfUp(up[i]);
       const int64_t p = nnz0 + slackRank[i];
       cscBeg[j] = (int32_t)p;
       cscIdx[p] = ni;
@@ -71,12 +77,12 @@ __global__ void k_row_finish(const double* __restrict__ lo, const double* __rest
 }
 
 __global__ void k_col_setup(const double* __restrict__ c, const double* __restrict__ lo, const double* __restrict__ up,
-                            const int32_t* __restrict__ aStart, int n0, double sense, double* cost, double* lower,
-                            double* upper, int32_t* cscBeg) {
+                            const int32_t* __restrict__ aStart, int n0, double sense, int clampInf, double* cost,
+                            double* lower, double* upper, int32_t* cscBeg) {
   GSTRIDE(j, n0) {
     cost[j] = c[j] * sense;
-    lower[j] = clampInfLo(lo[j]);
-    upper[j] = clampInfUp(up[j]);
+    lower[j] = clampInf ? clampInfLo(lo[j]) : lo[j];
+    upper[j] = clampInf ? clampInfUp(up[j]) : up[j];
     cscBeg[j] = aStart[j];
   }
 }
@@ -93,7 +99,7 @@ __global__ void k_col_entries(const int32_t* __restrict__ aStart, const int32_t*
       const int r = aIndex[p];
       if (r < 0 || r >= m) { *badFlag = 1; continue; }
       const int t = kind[r];
-      if (t == kRowEq || t == kRowBound) { cscIdx[k] = rowNewIdx[r]; cscCol[k] = (int)j; cscVal[k] = aValue[p]; ++k; }
+      if (isEqKind(t)) { cscIdx[k] = rowNewIdx[r]; cscCol[k] = (int)j; cscVal[k] = aValue[p]; ++k; }
     }
     for (int p = b; p < e; ++p) {
       const int r = aIndex[p];
@@ -164,6 +170,49 @@ __global__ void k_apply_rows(const double* __restrict__ rs, int m, double* rhs, 
 __global__ void k_scale_vals(const int32_t* __restrict__ rowOf, const int32_t* __restrict__ colOf,
                              const double* __restrict__ rs, const double* __restrict__ cs, int64_t nnz, double* val) {
   GSTRIDE(p, nnz) val[p] = (val[p] / rs[rowOf[p]]) / cs[colOf[p]];
+}
+// HiPDLP (scaling.cc): MODE 0 sqrt(max|a|) (Ruiz), 1 sqrt(sum|a|) (Pock-Chambolle, alpha 1), 2 sqrt(sqrt(sum a^2)) (L2);
+// zero or empty majors -> 1
+template <int MODE>
+__global__ void k_major_reduce_h(const int32_t* __restrict__ beg, const double* __restrict__ val, int nMajor,
+                                 double* out) {
+  GSTRIDE(r, nMajor) {
+    double s = 0.0;
+    for (int p = beg[r]; p < beg[r + 1]; ++p) {
+      const double a = fabs(val[p]);
+      if (MODE == 0) s = a > s ? a : s;
+      else if (MODE == 1) s += a;
+      else s += val[p] * val[p];
+    }
+    if (MODE == 0) out[r] = (s == 0.0) ? 1.0 : sqrt(s);
+    else if (MODE == 1) out[r] = s > 0.0 ? sqrt(s) : 1.0;
+    else out[r] = s > 0.0 ? sqrt(sqrt(s)) : 1.0;
+  }
+}
+__global__ void k_apply_rows_h(const double* __restrict__ rs, int m, double* rowLower, double* rowUpper,
+                               double* rowScale) {
+  GSTRIDE(i, m) {
+    if (rowLower[i] > -INFINITY) rowLower[i] /= rs[i];
+    if (rowUpper[i] < INFINITY) rowUpper[i] /= rs[i];
+    rowScale[i] *= rs[i];
+  }
+}
+__global__ void k_apply_cols_h(const double* __restrict__ cs, int n, double* cost, double* lower, double* upper,
+                               double* colScale) {
+  GSTRIDE(j, n) {
+    cost[j] /= cs[j];
+    if (lower[j] > -INFINITY) lower[j] *= cs[j];
+    if (upper[j] < INFINITY) upper[j] *= cs[j];
+    colScale[j] *= cs[j];
+  }
+}
+// a /= (rs[row] * cs[col]): Scaling::applyScaling, scaling.cc:251-259
+__global__ void k_scale_vals_h(const int32_t* __restrict__ rowOf, const int32_t* __restrict__ colOf,
+                               const double* __restrict__ rs, const double* __restrict__ cs, int64_t nnz, double* val) {
+  GSTRIDE(p, nnz) val[p] /= (rs[rowOf[p]] * cs[colOf[p]]);
+}
+__global__ void k_is_eq(const int32_t* __restrict__ kind, const int32_t* __restrict__ rowNewIdx, int m, uint8_t* isEq) {
+  GSTRIDE(i, m) isEq[rowNewIdx[i]] = isEqKind(kind[i]) ? 1 : 0;
 }
 __global__ void k_absmax_partial(const double* __restrict__ val, int64_t nnz, double* partial) {
   __shared__ double sm[kT];
@@ -315,7 +364,8 @@ void transposeOnDevice(const int32_t* majorIn, const int32_t* minorIn, const dou
 
 }  // namespace
 
-void gpuPrepare(const pdlp_problem_t& P, bool doScale, hipStream_t s, DeviceProblem& D) {
+void gpuPrepare(const pdlp_problem_t& P, bool doScale, hipStream_t s, DeviceProblem& D, const HipdlpSetup* hp) {
+  const bool H = hp != nullptr;  // HiPDLP form (pdhg.cc:152-357 + scaling.cc) instead of the cuPDLP-C one
   if (P.num_col < 0 || P.num_row < 0) throw std::runtime_error("negative dimensions");
   if (P.num_col > 0 && (!P.a_start || !P.col_cost || !P.col_lower || !P.col_upper))
     throw std::runtime_error("null column arrays");
@@ -329,6 +379,7 @@ void gpuPrepare(const pdlp_problem_t& P, bool doScale, hipStream_t s, DeviceProb
   D.m = m;
   D.offset = P.offset;
   D.sense = P.sense < 0 ? -1.0 : 1.0;
+  const double costSense = H ? 1.0 : D.sense;  // HiPDLP does not apply the objective sense (pdhg.cc:171)
 
   // upload the caller's arrays
   DeviceArray<int32_t> aStart, aIndex;
@@ -343,8 +394,9 @@ void gpuPrepare(const pdlp_problem_t& P, bool doScale, hipStream_t s, DeviceProb
   // rows: classify, rank, permute
   DeviceArray<int32_t> kind, eqF, inF, slF, eqR, inR, slR, rowNew;
   kind.alloc(m); eqF.alloc(m); inF.alloc(m); slF.alloc(m); eqR.alloc(m); inR.alloc(m); slR.alloc(m); rowNew.alloc(m);
-  hipLaunchKernelGGL(k_row_classify, dim3(gridFor(m)), dim3(kT), 0, s, rlIn.get(), ruIn.get(), m, kind.get(),
-                     eqF.get(), inF.get(), slF.get());
+  hipLaunchKernelGGL(k_row_classify, dim3(gridFor(m)), dim3(kT), 0, s, rlIn.get(), ruIn.get(), m,
+                     H ? (double)INFINITY : kBoundInf, H ? (int)kRowFree : (int)kRowBound, kind.get(), eqF.get(),
+                     inF.get(), slF.get());
   exclusiveSum(eqF.get(), eqR.get(), m, s);
   exclusiveSum(inF.get(), inR.get(), m, s);
   exclusiveSum(slF.get(), slR.get(), m, s);
@@ -361,16 +413,19 @@ void gpuPrepare(const pdlp_problem_t& P, bool doScale, hipStream_t s, DeviceProb
   D.n = n; D.nEqs = nEq; D.nnz = nnz;
 
   D.cost.alloc(n); D.lower.alloc(n); D.upper.alloc(n); D.rhs.alloc(m); D.colScale.alloc(n); D.rowScale.alloc(m);
+  if (H) { D.rowUpper.alloc(m); D.rowIsEq.alloc((size_t)m); }
   DeviceArray<int32_t> cscBeg, cscIdx, cscCol, bad;
   DeviceArray<double> cscVal;
   cscBeg.alloc((size_t)n + 1); cscIdx.alloc((size_t)nnz); cscCol.alloc((size_t)nnz); cscVal.alloc((size_t)nnz);
   bad.alloc(1);
   bad.zero(s);
   hipLaunchKernelGGL(k_col_setup, dim3(gridFor(n0)), dim3(kT), 0, s, cIn.get(), clIn.get(), cuIn.get(), aStart.get(),
-                     n0, D.sense, D.cost.get(), D.lower.get(), D.upper.get(), cscBeg.get());
+                     n0, costSense, H ? 0 : 1, D.cost.get(), D.lower.get(), D.upper.get(), cscBeg.get());
   hipLaunchKernelGGL(k_row_finish, dim3(gridFor(m)), dim3(kT), 0, s, rlIn.get(), ruIn.get(), kind.get(), eqR.get(),
                      inR.get(), slR.get(), m, n0, nEq, nnz0, rowNew.get(), D.rhs.get(), D.cost.get(), D.lower.get(),
-                     D.upper.get(), cscBeg.get(), cscIdx.get(), cscCol.get(), cscVal.get());
+                     D.upper.get(), cscBeg.get(), cscIdx.get(), cscCol.get(), cscVal.get(),
+                     H ? D.rowUpper.get() : nullptr);
+  if (H) hipLaunchKernelGGL(k_is_eq, dim3(gridFor(m)), dim3(kT), 0, s, kind.get(), rowNew.get(), m, D.rowIsEq.get());
   {
     const int32_t last = (int32_t)nnz;
     PDLP_HIP(hipMemcpyAsync(cscBeg.get() + n, &last, sizeof(int32_t), hipMemcpyHostToDevice, s));
@@ -389,12 +444,12 @@ void gpuPrepare(const pdlp_problem_t& P, bool doScale, hipStream_t s, DeviceProb
   PDLP_HIP(hipStreamSynchronize(s));
   {
     double sc = 0.0;
-    for (int32_t j = 0; j < n0; ++j) { const double v = P.col_cost[j] * D.sense; sc += v * v; }
+    for (int32_t j = 0; j < n0; ++j) { const double v = P.col_cost[j] * costSense; sc += v * v; }
     D.normCost = std::sqrt(sc);  // slack costs are 0
     double sr = 0.0;  // permuted order: equality-type rows first, then inequalities
     for (int32_t i = 0; i < m; ++i)
       if (D.rowKind[i] == kRowEq) sr += P.row_lower[i] * P.row_lower[i];
-      else if (D.rowKind[i] == kRowBound) sr += 0.0;
+      else if (D.rowKind[i] == kRowBound || D.rowKind[i] == kRowFree) sr += 0.0;
     for (int32_t i = 0; i < m; ++i)
       if (D.rowKind[i] == kRowLeq) sr += (-P.row_upper[i]) * (-P.row_upper[i]);
       else if (D.rowKind[i] == kRowGeq) sr += P.row_lower[i] * P.row_lower[i];
@@ -409,6 +464,48 @@ void gpuPrepare(const pdlp_problem_t& P, bool doScale, hipStream_t s, DeviceProb
   // passes) receive the same two divisions, so they stay bit-identical
   hipLaunchKernelGGL(k_fill_d, dim3(gridFor(n)), dim3(kT), 0, s, D.colScale.get(), 1.0, (int64_t)n);
   hipLaunchKernelGGL(k_fill_d, dim3(gridFor(m)), dim3(kT), 0, s, D.rowScale.get(), 1.0, (int64_t)m);
+  if (H) {
+    // HiPDLP: columns are kept with ascending row index (pdhg.cc:311), so the column passes run on A' and
+    // both copies receive the identical division a /= (rs * cs) (scaling.cc:251-259)
+    transposeOnDevice(D.A.major.get(), D.A.idx.get(), D.A.val.get(), nnz, n, m, s, D.At);
+    if (doScale && (hp->ruiz || hp->pc || hp->l2)) {
+      DeviceArray<double> cs, rs;
+      cs.alloc(n);
+      rs.alloc(m);
+      auto pass = [&](int mode) {
+        if (mode == 0) {
+          hipLaunchKernelGGL(k_major_reduce_h<0>, dim3(gridFor(n)), dim3(kT), 0, s, D.At.beg.get(), D.At.val.get(), n, cs.get());
+          hipLaunchKernelGGL(k_major_reduce_h<0>, dim3(gridFor(m)), dim3(kT), 0, s, D.A.beg.get(), D.A.val.get(), m, rs.get());
+        } else if (mode == 1) {
+          hipLaunchKernelGGL(k_major_reduce_h<1>, dim3(gridFor(n)), dim3(kT), 0, s, D.At.beg.get(), D.At.val.get(), n, cs.get());
+          hipLaunchKernelGGL(k_major_reduce_h<1>, dim3(gridFor(m)), dim3(kT), 0, s, D.A.beg.get(), D.A.val.get(), m, rs.get());
+        } else {
+          hipLaunchKernelGGL(k_major_reduce_h<2>, dim3(gridFor(n)), dim3(kT), 0, s, D.At.beg.get(), D.At.val.get(), n, cs.get());
+          hipLaunchKernelGGL(k_major_reduce_h<2>, dim3(gridFor(m)), dim3(kT), 0, s, D.A.beg.get(), D.A.val.get(), m, rs.get());
+        }
+        hipLaunchKernelGGL(k_apply_cols_h, dim3(gridFor(n)), dim3(kT), 0, s, cs.get(), n, D.cost.get(), D.lower.get(),
+                           D.upper.get(), D.colScale.get());
+        hipLaunchKernelGGL(k_apply_rows_h, dim3(gridFor(m)), dim3(kT), 0, s, rs.get(), m, D.rhs.get(),
+                           D.rowUpper.get(), D.rowScale.get());
+        // A: major = row, idx = column;  A': major = column, idx = row
+        hipLaunchKernelGGL(k_scale_vals_h, dim3(gridFor(nnz)), dim3(kT), 0, s, D.A.major.get(), D.A.idx.get(), rs.get(),
+                           cs.get(), nnz, D.A.val.get());
+        hipLaunchKernelGGL(k_scale_vals_h, dim3(gridFor(nnz)), dim3(kT), 0, s, D.At.idx.get(), D.At.major.get(), rs.get(),
+                           cs.get(), nnz, D.At.val.get());
+      };
+      if (hp->ruiz) for (int it = 0; it < hp->ruizIters; ++it) pass(0);
+      if (hp->pc) pass(1);
+      if (hp->l2) pass(2);
+      D.scaled = true;
+      PDLP_HIP(hipStreamSynchronize(s));
+    }
+    D.hColScale.resize(n);
+    D.hRowScale.resize(m);
+    D.colScale.download(D.hColScale.data(), n, s);
+    D.rowScale.download(D.hRowScale.data(), m, s);
+    PDLP_HIP(hipStreamSynchronize(s));
+    return;
+  }
   if (doScale) {
     DeviceArray<double> cs, rs;
     cs.alloc(n);

@@ -40,6 +40,8 @@ struct DeviceProblem {
   DeviceCsrData A;   // rows, ascending column
   DeviceCsrData At;  // columns, ascending row
   DeviceArray<double> cost, rhs, lower, upper, colScale, rowScale;
+  DeviceArray<double> rowUpper;   // HiPDLP form only (rhs then holds the row lower bounds)
+  DeviceArray<uint8_t> rowIsEq;   // HiPDLP form only, per permuted row
   // host copies of what the host side of the solver needs
   std::vector<int32_t> rowKind, rowNewIdx;
   std::vector<double> hColScale, hRowScale;
@@ -47,8 +49,14 @@ struct DeviceProblem {
   double sumCost2 = 0, sumRhs2 = 0;  // left-to-right sums of the SCALED c, b (PDHG_Init_Step_Sizes)
 };
 
+// Options of the HiPDLP form (pdlp_host.hpp formulateHipdlp / scaleHipdlp); nullptr = cuPDLP-C form.
+struct HipdlpSetup {
+  bool ruiz = true, pc = true, l2 = false;
+  int ruizIters = 10;
+};
 // Formulate + scale + both orientations on the device.  Throws std::runtime_error.
-void gpuPrepare(const pdlp_problem_t& P, bool doScale, hipStream_t s, DeviceProblem& out);
+void gpuPrepare(const pdlp_problem_t& P, bool doScale, hipStream_t s, DeviceProblem& out,
+                const HipdlpSetup* hipdlp = nullptr);
 
 // Slab layout (pdlp_host.hpp SlabLayout) built on the device from a device CSR.
 struct DeviceSlabLayout {

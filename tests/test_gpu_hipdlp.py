@@ -146,3 +146,34 @@ def test_whole_solve_bit_exact_in_device_reduction_order(name, opts, monkeypatch
         assert np.array_equal(getattr(gpu.solution, k), getattr(ora.solution, k)), k
     for k in ("primal_obj", "dual_obj", "primal_feas", "dual_feas", "rel_gap"):
         assert getattr(gpu.result, k) == getattr(ora.result, k), k
+
+
+@pytest.mark.parametrize("name", ["25fv47", "shell", "standgub", "random6", "synthetic"])
+@pytest.mark.parametrize("opts", [{}, {"pdlp_features_off": 1}, {"pdlp_scaling_mode": 7, "pdlp_ruiz_iterations": 3}])
+def test_device_side_setup_bit_identical_to_host_setup(name, opts, monkeypatch):
+    """Preprocessing + scaling + both orientations built on the device (pdlp_setup.hip, HiPDLP form) vs the
+    host path, which is bit-identical to the oracle: every prepared vector, and a block of Halpern steps
+    through the device-built matrices."""
+    sp_ = None
+    if name == "synthetic":
+        sp_ = solver.SyntheticProblem(30000, 25000, 240000, 7)
+        kw = dict(problem_struct=sp_.struct)
+    elif name.startswith("random"):
+        import lpgen
+        kw = dict(lp=lpgen.random_lp(int(name[6:])))  # has ranged AND free rows
+    else:
+        kw = dict(lp=_lp(name))
+    out = []
+    for dev in ("0", "1"):
+        monkeypatch.setenv("PDLP_MI355X_GPU_SETUP", dev)
+        S = solver.DeviceSolver(solver="hipdlp", **kw, **opts)
+        vec = {k: S.get(k, S.n if k in ("cost", "lower", "upper", "col_scale") else S.m)
+               for k in ("cost", "lower", "upper", "col_scale", "row_lower", "row_upper", "row_scale")}
+        S.set("steps", [0.37, 0.21])
+        S.stage("steps", init=[40])
+        vec["x"], vec["y"], vec["xn"], vec["yn"] = S.get("x", S.n), S.get("y", S.m), S.get("x_next", S.n), S.get("y_next", S.m)
+        out.append(((S.n, S.m, S.nnz, S.n_eqs), vec))
+        S.close()
+    assert out[0][0] == out[1][0]
+    for k in out[0][1]:
+        assert np.array_equal(out[0][1][k], out[1][1][k]), k
