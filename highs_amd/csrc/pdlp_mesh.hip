@@ -542,12 +542,15 @@ Mesh::Mesh(int32_t rank, int32_t world, const void* id128, int32_t n, int32_t m,
 
 Mesh::~Mesh() {
   if (v_.G > 1 && shm_) {
-    // nobody frees an arena that a peer's kernel may still write to
+    // nobody frees an arena that a peer's kernel may still write to — unless the exchange already broke
+    // (a peer vanished or timed out): then waiting for it again would only delay the error
     (void)hipDeviceSynchronize();
-    try { hostBarrier(2, 20.0); } catch (...) {}
-    for (int h = 0; h < v_.G; ++h)
-      if (h != v_.g && v_.arena[h]) (void)hipIpcCloseMemHandle(v_.arena[h]);
-    try { hostBarrier(3, 20.0); } catch (...) {}
+    MeshState h{};
+    const bool broken = !state_ || hipMemcpy(&h, state_, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess || h.error != 0;
+    if (!broken) { try { hostBarrier(2, 20.0); } catch (...) {} }
+    for (int r = 0; r < v_.G; ++r)
+      if (r != v_.g && v_.arena[r]) (void)hipIpcCloseMemHandle(v_.arena[r]);
+    if (!broken) { try { hostBarrier(3, 20.0); } catch (...) {} }
   }
   if (arena_) (void)hipFree(arena_);
   if (state_) (void)hipFree(state_);

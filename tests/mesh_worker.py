@@ -33,6 +33,21 @@ def main():
         lp = L.HighsLp.from_npz(os.path.join(GOLD, "instances", name + ".npz"))
         kw = dict(lp=lp)
         nc, nr = lp.num_col, lp.num_row
+    if kind == "die":
+        # rank 1 disappears right after the collective creation; rank 0 must get an error, not a hung GPU
+        S = solver.DeviceSolver(rank=rank, world=world, unique_id=uid, **kw)
+        if rank == 1:
+            os._exit(0)
+        import time
+        t0 = time.time()
+        try:
+            S.iterate(200)
+            msg = "no error"
+        except RuntimeError as e:
+            msg = str(e)
+        np.savez(out, msg=msg, seconds=time.time() - t0)
+        S.close()
+        return
     if kind == "solve":
         foff = int(rest[0]) if rest else 0
         S = solver.DeviceSolver(rank=rank, world=world, unique_id=uid, time_limit=1000.0, pdlp_features_off=foff, **kw)

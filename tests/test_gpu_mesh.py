@@ -23,7 +23,7 @@ def _lp(name):
     return L.HighsLp.from_npz(os.path.join(GOLD, "instances", name + ".npz"))
 
 
-def _run_ranks(world, case, tmp_path, extra_env=None):
+def _run_ranks(world, case, tmp_path, extra_env=None, must_finish=None):
     uid = (C.c_ubyte * 128)()
     assert solver.lib().pdlp_mi355x_comm_unique_id(uid) == 0
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -35,7 +35,7 @@ def _run_ranks(world, case, tmp_path, extra_env=None):
     logs = [p.communicate()[0].decode(errors="replace") for p in procs]
     for r, p in enumerate(procs):
         assert p.returncode == 0, f"rank {r} failed:\n{logs[r][-2000:]}"
-    return [dict(np.load(o)) for o in outs]
+    return [dict(np.load(o)) for r, o in enumerate(outs) if must_finish is None or r in must_finish]
 
 
 # (8 processes time-share the one GPU's hardware queues: keep the 8-rank case small)
@@ -107,3 +107,11 @@ def test_sharded_sequence_single_rank(exchange, monkeypatch):
     a, b = sh.info["objective_function_value"], base.info["objective_function_value"]
     assert abs(a - b) <= 1e-6 * (1 + abs(b))
     assert 0.5 * base.pdlp_iteration_count <= sh.pdlp_iteration_count <= 2 * base.pdlp_iteration_count
+
+
+def test_vanished_peer_becomes_an_error_not_a_hang(tmp_path):
+    """Every device-side wait is bounded: when a peer disappears the surviving rank's next exchange times
+    out and the C ABI reports it (here after 2 s), instead of spinning on the GPU forever."""
+    res = _run_ranks(2, "die:afiro", tmp_path, extra_env={"PDLP_MI355X_MESH_TIMEOUT_MS": "2000"}, must_finish={0})
+    assert "timed out" in str(res[0]["msg"]), res[0]["msg"]
+    assert float(res[0]["seconds"]) < 30.0
