@@ -1,14 +1,16 @@
 // pdlp_mesh.hip — see pdlp_mesh.hpp.  Kernels that talk to the peers' arenas over
 // xGMI and the host-side IPC rendezvous.
 //
-// Memory-model notes (gfx950, HSA): the arenas are FINE-GRAINED device memory, the
-// only kind that is coherent between agents inside a kernel.  A producer makes its
-// plain remote stores visible with a system-scope release fence before a single
-// thread publishes the epoch with a system-scope atomic store; a consumer acquires
-// the flag with system-scope atomic loads and every thread of the block then issues
-// a system-scope acquire fence before it touches the data.  Buffers are never
-// re-written before every reader has signalled a later phase (see the hazard
-// analysis in DESIGN.md §6), so there is no double buffering.
+// Memory-model notes (gfx950, HSA): the arenas are FINE-GRAINED device memory, the only kind that is
+// coherent between agents inside a kernel, and every access to an arena is a SYSTEM-SCOPE relaxed atomic
+// (`global_store/load ... sc0 sc1`: write-through / read-through, no reliance on any cache state).
+// Publishing: each wave drains its stores (`s_waitcnt vmcnt(0)`: the writes have landed), the block
+// barrier collects the waves, one lane takes a ticket, and the block that takes the last ticket stores the
+// epoch flags — ordering by COMPLETION, so no L2 write-back fence (measured 5-8 us per kernel with
+// release/acquire fences, MI355X_MICROARCH "publish-large": write-through wins).  Consuming: wave 0 polls
+// the flags (one lane per peer), block barrier, then system-scope loads of the payload.  Buffers are
+// never re-written before every reader has signalled a later phase (hazard analysis in DESIGN.md §6), so
+// there is no double buffering.
 #include "pdlp_mesh.hpp"
 
 #include <fcntl.h>
@@ -33,47 +35,58 @@ namespace {
 
 constexpr int kFlagStride = 128;                    // bytes between two flags (own cache line each)
 
-__device__ __forceinline__ long long* flagAt(const MeshView* __restrict__ mv, int rank, int kind, int src) {
+__device__ __forceinline__ long long* flagAt(const MeshArgs& ma, int rank, int kind, int src) {
+  const MeshView* __restrict__ mv = ma.v; (void)mv;
   return (long long*)(mv->arena[rank] + mv->offFlags + ((size_t)kind * kMeshMaxRanks + src) * kFlagStride);
 }
-__device__ __forceinline__ double* recvX(const MeshView* __restrict__ mv, int rank) { return (double*)(mv->arena[rank] + mv->offRecvX); }
-__device__ __forceinline__ double* recvP(const MeshView* __restrict__ mv, int rank, int src) {
+__device__ __forceinline__ double* recvX(const MeshArgs& ma, int rank) {
+  const MeshView* __restrict__ mv = ma.v; (void)mv; return (double*)(mv->arena[rank] + mv->offRecvX); }
+__device__ __forceinline__ double* recvP(const MeshArgs& ma, int rank, int src) {
+  const MeshView* __restrict__ mv = ma.v; (void)mv;
   return (double*)(mv->arena[rank] + mv->offRecvP) + (size_t)src * mv->sliceMax;
 }
-__device__ __forceinline__ double* mailAt(const MeshView* __restrict__ mv, int rank, bool hot, int src) {
+__device__ __forceinline__ double* mailAt(const MeshArgs& ma, int rank, bool hot, int src) {
+  const MeshView* __restrict__ mv = ma.v; (void)mv;
   return (double*)(mv->arena[rank] + (hot ? mv->offMailHot : mv->offMailGen)) + (size_t)src * kMeshMailDoubles;
 }
 
-// One thread: publish epoch e of `kind` to every peer.  The system-scope release makes this
-// thread's earlier stores — and, by cumulativity, those of every thread that synchronised with it
-// (block barrier, ticket) — visible first.
-__device__ void signalPeers(const MeshView* __restrict__ mv, int kind, long long e) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-  const int G = mv->G, g = mv->g;
+__device__ __forceinline__ void sysStore(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ double sysLoad(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void drainStores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// One thread: publish epoch e of `kind` to every peer.  The caller guarantees that the payload stores
+// (write-through, system scope) of every contributing wave have COMPLETED (drainStores + barrier + ticket).
+__device__ void signalPeers(const MeshArgs& ma, int kind, long long e) {
+  const MeshView* __restrict__ mv = ma.v; (void)mv;
+  const int G = ma.G, g = ma.g;
   for (int h = 0; h < G; ++h) {
     if (h == g) continue;
-    __hip_atomic_store(flagAt(mv, h, kind, g), e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(flagAt(ma, h, kind, g), e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
 // Whole block: wait until every peer has published epoch >= e of `kind`.  Wave 0 spins (one lane
-// per peer) and issues the system-scope acquire (it invalidates this CU's L1 and this XCD's L2,
-// which is what the other waves of the block read through); the block barrier hands that on.
+// per peer); the payload is then read with system-scope loads (sysLoad), which need no invalidate.
 // Returns false on timeout (or if another kernel already failed); the caller bails out.
-__device__ bool waitPeers(const MeshView* __restrict__ mv, int kind, long long e) {
+__device__ bool waitPeers(const MeshArgs& ma, int kind, long long e) {
+  const MeshView* __restrict__ mv = ma.v; (void)mv;
   __shared__ int ok;
   if (threadIdx.x == 0) ok = 1;
   __syncthreads();
   if (threadIdx.x < kWave) {
-    const int h = threadIdx.x, G = mv->G, g = mv->g;
+    const int h = threadIdx.x, G = ma.G, g = ma.g;
     if (h < G && h != g) {
-      const long long* f = flagAt(mv, g, kind, h);
-      const long long t0 = wall_clock64(), budget = mv->waitTicks;
+      const long long* f = flagAt(ma, g, kind, h);
+      const long long t0 = wall_clock64(), budget = ma.waitTicks;
       int polls = 0;
       while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < e) {
         if ((++polls & 255) == 0) {
           if (wall_clock64() - t0 > budget ||
-              __hip_atomic_load(&mv->ms->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+              __hip_atomic_load(&ma.ms->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
             ok = 0;
             break;
           }
@@ -81,7 +94,6 @@ __device__ bool waitPeers(const MeshView* __restrict__ mv, int kind, long long e
         __builtin_amdgcn_s_sleep(1);
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   }
   __syncthreads();
   const bool good = ok != 0;
@@ -89,56 +101,60 @@ __device__ bool waitPeers(const MeshView* __restrict__ mv, int kind, long long e
   return good;
 }
 
-__device__ void fail(const MeshView* __restrict__ mv, DevState* st) {
+__device__ void fail(const MeshArgs& ma, DevState* st) {
+  const MeshView* __restrict__ mv = ma.v; (void)mv;
   if (threadIdx.x == 0) {
-    __hip_atomic_store(&mv->ms->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&ma.ms->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (st) { st->halted = 1; st->commError = 1; }
   }
 }
 
-// Multi-block producer: after the block barrier ONE thread per block releases the block's stores
-// at system scope (a write-back of its XCD's L2) and takes a ticket; the block that takes the last
-// ticket publishes the epoch.
-__device__ void lastBlockSignal(const MeshView* __restrict__ mv, int kind, long long e, int ticket) {
+// Multi-block producer: every wave drains its stores, the block barrier collects them, one lane takes a
+// ticket; the block that takes the last ticket publishes the epoch.
+__device__ void lastBlockSignal(const MeshArgs& ma, int kind, long long e, int ticket) {
+  const MeshView* __restrict__ mv = ma.v; (void)mv;
+  drainStores();  // this wave's write-through stores have landed in the peers' arenas
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     const unsigned prev =
-        __hip_atomic_fetch_add(&mv->ms->counter[ticket], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (prev == gridDim.x - 1) {
-      __hip_atomic_store(&mv->ms->counter[ticket], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      signalPeers(mv, kind, e);
+        __hip_atomic_fetch_add(&ma.ms->counter[ticket], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == gridDim.x - 1) {  // every other block drained its stores before it took its ticket
+      __hip_atomic_store(&ma.ms->counter[ticket], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      signalPeers(ma, kind, e);
     }
   }
 }
 
-__device__ __forceinline__ bool dead(const MeshView* __restrict__ mv) {
-  return __hip_atomic_load(&mv->ms->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+__device__ __forceinline__ bool dead(const MeshArgs& ma) {
+  const MeshView* __restrict__ mv = ma.v; (void)mv;
+  return __hip_atomic_load(&ma.ms->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
 }
 
 // Peer base pointers in registers (statically indexed, fully unrolled: no scratch).
 struct PeerPtrs { double* p[kMeshMaxRanks]; };
-__device__ __forceinline__ void peerRecvX(const MeshView* __restrict__ mv, PeerPtrs& P) {
-  const int G = mv->G, g = mv->g;
+__device__ __forceinline__ void peerRecvX(const MeshArgs& ma, PeerPtrs& P) {
+  const MeshView* __restrict__ mv = ma.v; (void)mv;
+  const int G = ma.G, g = ma.g;
 #pragma unroll
-  for (int h = 0; h < kMeshMaxRanks; ++h) P.p[h] = (h < G && h != g) ? recvX(mv, h) : nullptr;
+  for (int h = 0; h < kMeshMaxRanks; ++h) P.p[h] = (h < G && h != g) ? recvX(ma, h) : nullptr;
 }
 
 // ---- hot loop ------------------------------------------------------------------------
 // x+ = clamp(x - tau (c - A'y), l, u) on the own column slice (cupdlp_step.c:16-40), stored
 // locally and pushed into every peer's recvX.
 __global__ __launch_bounds__(kVecThreads) void k_mesh_primal_step(const IterVecs v, const DevState* st,
-                                                                  const MeshView* __restrict__ mv) {
-  if (st->halted || dead(mv)) return;
-  const long long e = mv->ms->seq + 1;
+                                                                  const MeshArgs ma) {
+  const MeshView* __restrict__ mv = ma.v; (void)mv;
+  if (st->halted || dead(ma)) return;
+  const long long e = ma.ms->seq + 1;
   const int cur = st->cur, nxt = cur ^ 1;
   const double tau = st->tau, avgW = st->avgW;
   const double* __restrict__ x = v.x[cur];
   const double* __restrict__ aty = v.aty[cur];
   double* __restrict__ xn = v.x[nxt];
-  const int c0 = mv->colOff[mv->g];
+  const int c0 = mv->colOff[ma.g];
   PeerPtrs peer;
-  peerRecvX(mv, peer);
+  peerRecvX(ma, peer);
   const int stride = gridDim.x * blockDim.x;
   const int last = v.n - 1;
   // four independent elements per pass (clamped, unconditional loads: all 20 loads in flight)
@@ -162,79 +178,83 @@ __global__ __launch_bounds__(kVecThreads) void k_mesh_primal_step(const IterVecs
       xn[j] = t;
 #pragma unroll
       for (int h = 0; h < kMeshMaxRanks; ++h)
-        if (peer.p[h]) peer.p[h][c0 + j] = t;
+        if (peer.p[h]) sysStore(peer.p[h] + c0 + j, t);
     }
   }
-  lastBlockSignal(mv, kFlagX, e, 0);
+  lastBlockSignal(ma, kFlagX, e, 0);
 }
 
 // x+ of the other column slices: recvX -> x[nxt] (ordinary memory, so that the SpMV gathers hit L2).
 __global__ __launch_bounds__(kVecThreads) void k_mesh_wait_copy_x(const IterVecs v, DevState* st,
-                                                                  const MeshView* __restrict__ mv) {
-  if (st->halted || dead(mv)) return;
-  const long long e = mv->ms->seq + 1;
-  if (!waitPeers(mv, kFlagX, e)) { fail(mv, st); return; }
+                                                                  const MeshArgs ma) {
+  const MeshView* __restrict__ mv = ma.v; (void)mv;
+  if (st->halted || dead(ma)) return;
+  const long long e = ma.ms->seq + 1;
+  if (!waitPeers(ma, kFlagX, e)) { fail(ma, st); return; }
   const int nxt = st->cur ^ 1;
-  const int c0 = mv->colOff[mv->g], c1 = mv->colOff[mv->g + 1];
-  const double* __restrict__ src = recvX(mv, mv->g);
+  const int c0 = mv->colOff[ma.g], c1 = mv->colOff[ma.g + 1];
+  const double* __restrict__ src = recvX(ma, ma.g);
   double* __restrict__ dst = v.x[nxt];
   const int stride = gridDim.x * blockDim.x;
   // [0, c0) and [c1, n): the own slice is already in place
   const int other = v.n - (c1 - c0);
   for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < other; q += stride) {
     const int j = q < c0 ? q : q + (c1 - c0);
-    dst[j] = src[j];
+    dst[j] = sysLoad(src + j);
   }
 }
 
 // partial[slice of owner h] -> h's recvP[g], one short coalesced loop per peer.  st != nullptr:
 // hot loop (epoch from seq, flag P), else generic (epoch eGen, flag Gen).
 __global__ __launch_bounds__(kVecThreads) void k_mesh_push_partial(const double* __restrict__ partial,
-                                                                   const DevState* st, const MeshView* __restrict__ mv,
+                                                                   const DevState* st, const MeshArgs ma,
                                                                    long long eGen) {
-  if ((st && st->halted) || dead(mv)) return;
-  const long long e = st ? mv->ms->seq + 1 : eGen;
-  const int G = mv->G, g = mv->g;
+  const MeshView* __restrict__ mv = ma.v; (void)mv;
+  if ((st && st->halted) || dead(ma)) return;
+  const long long e = st ? ma.ms->seq + 1 : eGen;
+  const int G = ma.G, g = ma.g;
   const int stride = gridDim.x * blockDim.x, first = blockIdx.x * blockDim.x + threadIdx.x;
   for (int h = 0; h < G; ++h) {
     if (h == g) continue;
     const int lo = mv->colOff[h], len = mv->colOff[h + 1] - lo;
-    double* __restrict__ dst = recvP(mv, h, g);
+    double* __restrict__ dst = recvP(ma, h, g);
     const double* __restrict__ src = partial + lo;
-    for (int j = first; j < len; j += stride) dst[j] = src[j];
+    for (int j = first; j < len; j += stride) sysStore(dst + j, src[j]);
   }
-  lastBlockSignal(mv, st ? kFlagP : kFlagGen, e, 1);
+  lastBlockSignal(ma, st ? kFlagP : kFlagGen, e, 1);
 }
 
 // The G contributions to the own slice, in rank order: src[h] = recvP[h] (or the own partial).
-__device__ __forceinline__ void reduceSources(const MeshView* __restrict__ mv, const double* ownPartialSlice,
+__device__ __forceinline__ void reduceSources(const MeshArgs& ma, const double* ownPartialSlice,
                                               PeerPtrs& S) {
-  const int G = mv->G, g = mv->g;
+  const MeshView* __restrict__ mv = ma.v; (void)mv;
+  const int G = ma.G, g = ma.g;
 #pragma unroll
   for (int h = 0; h < kMeshMaxRanks; ++h)
-    S.p[h] = h >= G ? nullptr : (h == g ? const_cast<double*>(ownPartialSlice) : recvP(mv, g, h));
+    S.p[h] = h >= G ? nullptr : (h == g ? const_cast<double*>(ownPartialSlice) : recvP(ma, g, h));
 }
 __device__ __forceinline__ double orderedSum(const PeerPtrs& S, int j) {
   double s = 0.0;
 #pragma unroll
   for (int h = 0; h < kMeshMaxRanks; ++h)
-    if (S.p[h]) s += S.p[h][j];
+    if (S.p[h]) s += sysLoad(S.p[h] + j);
   return s;
 }
 
 // aty+[slice] = sum_h partial_h[slice]; movement / interaction partials of the slice
 // (cupdlp_linalg.c:772-801).
 __global__ __launch_bounds__(kVecThreads) void k_mesh_reduce_interact(const IterVecs v, DevState* st,
-                                                                      const MeshView* __restrict__ mv,
+                                                                      const MeshArgs ma,
                                                                       const double* __restrict__ partial,
                                                                       double* partDX, double* partInter) {
-  if (st->halted || dead(mv)) return;
-  const long long e = mv->ms->seq + 1;
-  if (!waitPeers(mv, kFlagP, e)) { fail(mv, st); return; }
+  const MeshView* __restrict__ mv = ma.v; (void)mv;
+  if (st->halted || dead(ma)) return;
+  const long long e = ma.ms->seq + 1;
+  if (!waitPeers(ma, kFlagP, e)) { fail(ma, st); return; }
   __shared__ double scratch[2][kVecThreads / kWave];
   const int cur = st->cur, nxt = cur ^ 1;
   PeerPtrs src;
-  reduceSources(mv, partial + mv->colOff[mv->g], src);
+  reduceSources(ma, partial + mv->colOff[ma.g], src);
   const double* __restrict__ xc = v.x[cur];
   const double* __restrict__ xn = v.x[nxt];
   const double* __restrict__ ac = v.aty[cur];
@@ -268,13 +288,14 @@ __global__ __launch_bounds__(kVecThreads) void k_mesh_reduce_interact(const Iter
 
 // One block: local sums of the three partial arrays -> every rank's mailbox -> rank-ordered
 // totals -> the accept/reject decision (identical bits, hence identical decisions, everywhere).
-__global__ __launch_bounds__(kVecThreads) void k_mesh_decide(DevState* st, const MeshView* __restrict__ mv,
+__global__ __launch_bounds__(kVecThreads) void k_mesh_decide(DevState* st, const MeshArgs ma,
                                                              const double* __restrict__ partDY, int nDY,
                                                              const double* __restrict__ partDX,
                                                              const double* __restrict__ partInter, int nDX) {
+  const MeshView* __restrict__ mv = ma.v; (void)mv;
   if (st->halted) return;
-  if (dead(mv)) { fail(mv, st); return; }  // lets the host loop stop
-  const long long e = mv->ms->seq + 1;
+  if (dead(ma)) { fail(ma, st); return; }  // lets the host loop stop
+  const long long e = ma.ms->seq + 1;
   __shared__ double scratch[3][kVecThreads / kWave];
   const int tid = threadIdx.x;
   auto laneSum = [&](const double* __restrict__ p, int count) {
@@ -296,89 +317,98 @@ __global__ __launch_bounds__(kVecThreads) void k_mesh_decide(DevState* st, const
     double dY2 = 0.0, dX2 = 0.0, inter = 0.0;
 #pragma unroll
     for (int i = 0; i < kVecThreads / kWave; ++i) { dY2 += scratch[0][i]; dX2 += scratch[1][i]; inter += scratch[2][i]; }
-    for (int h = 0; h < mv->G; ++h) {
-      double* box = mailAt(mv, h, true, mv->g);
-      box[0] = dX2; box[1] = dY2; box[2] = inter;
+    for (int h = 0; h < ma.G; ++h) {
+      double* box = mailAt(ma, h, true, ma.g);
+      sysStore(box + 0, dX2); sysStore(box + 1, dY2); sysStore(box + 2, inter);
     }
-    signalPeers(mv, kFlagS, e);
+    drainStores();
+    signalPeers(ma, kFlagS, e);
   }
-  if (!waitPeers(mv, kFlagS, e)) { fail(mv, st); return; }
+  if (!waitPeers(ma, kFlagS, e)) { fail(ma, st); return; }
   if (tid != 0) return;
   double dX2 = 0.0, dY2 = 0.0, inter = 0.0;
-  for (int h = 0; h < mv->G; ++h) {
-    const double* box = mailAt(mv, mv->g, true, h);
-    dX2 += box[0]; dY2 += box[1]; inter += box[2];
+  for (int h = 0; h < ma.G; ++h) {
+    const double* box = mailAt(ma, ma.g, true, h);
+    dX2 += sysLoad(box + 0); dY2 += sysLoad(box + 1); inter += sysLoad(box + 2);
   }
   decideUpdate(st, dX2, dY2, inter);
-  mv->ms->seq = e;
+  ma.ms->seq = e;
 }
 
 // ---- generic collectives (host-counted epochs, off the hot path) ---------------------------
 __global__ __launch_bounds__(kVecThreads) void k_mesh_push_slice(const double* __restrict__ vec, int lo, int hi,
-                                                                 const MeshView* __restrict__ mv, long long e) {
-  if (dead(mv)) return;
+                                                                 const MeshArgs ma, long long e) {
+  const MeshView* __restrict__ mv = ma.v; (void)mv;
+
+  if (dead(ma)) return;
   PeerPtrs peer;
-  peerRecvX(mv, peer);
+  peerRecvX(ma, peer);
   const int stride = gridDim.x * blockDim.x;
   for (int j = lo + blockIdx.x * blockDim.x + threadIdx.x; j < hi; j += stride) {
     const double t = vec[j];
 #pragma unroll
     for (int h = 0; h < kMeshMaxRanks; ++h)
-      if (peer.p[h]) peer.p[h][j] = t;
+      if (peer.p[h]) sysStore(peer.p[h] + j, t);
   }
-  lastBlockSignal(mv, kFlagGen, e, 2);
+  lastBlockSignal(ma, kFlagGen, e, 2);
 }
 
 __global__ __launch_bounds__(kVecThreads) void k_mesh_wait_copy(double* __restrict__ vec, int lo, int hi, int len,
-                                                                const MeshView* __restrict__ mv, long long e) {
-  if (dead(mv)) return;
-  if (!waitPeers(mv, kFlagGen, e)) { fail(mv, nullptr); return; }
-  const double* __restrict__ src = recvX(mv, mv->g);
+                                                                const MeshArgs ma, long long e) {
+  const MeshView* __restrict__ mv = ma.v; (void)mv;
+
+  if (dead(ma)) return;
+  if (!waitPeers(ma, kFlagGen, e)) { fail(ma, nullptr); return; }
+  const double* __restrict__ src = recvX(ma, ma.g);
   const int stride = gridDim.x * blockDim.x;
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < len; j += stride)
-    if (j < lo || j >= hi) vec[j] = src[j];
+    if (j < lo || j >= hi) vec[j] = sysLoad(src + j);
 }
 
 __global__ __launch_bounds__(kVecThreads) void k_mesh_wait_reduce(const double* __restrict__ partial,
-                                                                  double* __restrict__ dst, const MeshView* __restrict__ mv,
+                                                                  double* __restrict__ dst, const MeshArgs ma,
                                                                   long long e) {
-  if (dead(mv)) return;
-  if (!waitPeers(mv, kFlagGen, e)) { fail(mv, nullptr); return; }
-  const int c0 = mv->colOff[mv->g], len = mv->colOff[mv->g + 1] - c0;
+  const MeshView* __restrict__ mv = ma.v; (void)mv;
+  if (dead(ma)) return;
+  if (!waitPeers(ma, kFlagGen, e)) { fail(ma, nullptr); return; }
+  const int c0 = mv->colOff[ma.g], len = mv->colOff[ma.g + 1] - c0;
   PeerPtrs src;
-  reduceSources(mv, partial + c0, src);
+  reduceSources(ma, partial + c0, src);
   const int stride = gridDim.x * blockDim.x;
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < len; j += stride) dst[c0 + j] = orderedSum(src, j);
 }
 
 // Rendezvous of all ranks: nobody passes before everybody has finished the work queued before it.
-__global__ __launch_bounds__(kVecThreads) void k_mesh_barrier(const MeshView* __restrict__ mv, long long e) {
-  if (dead(mv)) return;
-  if (threadIdx.x == 0) signalPeers(mv, kFlagBar, e);
-  if (!waitPeers(mv, kFlagBar, e)) fail(mv, nullptr);
+__global__ __launch_bounds__(kVecThreads) void k_mesh_barrier(const MeshArgs ma, long long e) {
+  const MeshView* __restrict__ mv = ma.v; (void)mv;
+
+  if (dead(ma)) return;
+  if (threadIdx.x == 0) signalPeers(ma, kFlagBar, e);
+  if (!waitPeers(ma, kFlagBar, e)) fail(ma, nullptr);
 }
 
-__global__ __launch_bounds__(kVecThreads) void k_mesh_allreduce_scalars(double* buf, int k, const MeshView* __restrict__ mv,
+__global__ __launch_bounds__(kVecThreads) void k_mesh_allreduce_scalars(double* buf, int k, const MeshArgs ma,
                                                                         long long e) {
-  if (dead(mv)) return;
+  const MeshView* __restrict__ mv = ma.v; (void)mv;
+  if (dead(ma)) return;
   const int tid = threadIdx.x;
   if (tid < k) {
     const double t = buf[tid];
-    for (int h = 0; h < mv->G; ++h) mailAt(mv, h, false, mv->g)[tid] = t;
+    for (int h = 0; h < ma.G; ++h) sysStore(mailAt(ma, h, false, ma.g) + tid, t);
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  drainStores();
   __syncthreads();
-  if (tid == 0) signalPeers(mv, kFlagGen, e);
-  if (!waitPeers(mv, kFlagGen, e)) { fail(mv, nullptr); return; }
+  if (tid == 0) signalPeers(ma, kFlagGen, e);
+  if (!waitPeers(ma, kFlagGen, e)) { fail(ma, nullptr); return; }
   if (tid < k) {
     double s = 0.0;
-    for (int h = 0; h < mv->G; ++h) s += mailAt(mv, mv->g, false, h)[tid];
+    for (int h = 0; h < ma.G; ++h) s += sysLoad(mailAt(ma, ma.g, false, h) + tid);
     buf[tid] = s;
   }
   __syncthreads();
   // the mailboxes may be overwritten by the next all-reduce only after every rank has read them
-  if (tid == 0) signalPeers(mv, kFlagBar, e);
-  if (!waitPeers(mv, kFlagBar, e)) fail(mv, nullptr);
+  if (tid == 0) signalPeers(ma, kFlagBar, e);
+  if (!waitPeers(ma, kFlagBar, e)) fail(ma, nullptr);
 }
 
 // Grid of a mesh kernel: every block pays one system-scope fence (an L2 write-back or
@@ -400,22 +430,22 @@ int32_t meshBlocks(int64_t len) {
 int32_t meshGrid(int64_t len) { return meshBlocks(len); }
 
 // ---- launchers (dmv = the view in device memory) --------------------------------------------
-void launchMeshPrimalStep(const IterVecs& vc, const DevState* st, const MeshView* dmv, hipStream_t s) {
+void launchMeshPrimalStep(const IterVecs& vc, const DevState* st, const MeshArgs& dmv, hipStream_t s) {
   hipLaunchKernelGGL(k_mesh_primal_step, dim3(meshBlocks(vc.n)), dim3(kVecThreads), 0, s, vc, st, dmv);
 }
-void launchMeshWaitCopyX(const IterVecs& vf, const DevState* st, const MeshView* dmv, hipStream_t s) {
+void launchMeshWaitCopyX(const IterVecs& vf, const DevState* st, const MeshArgs& dmv, hipStream_t s) {
   hipLaunchKernelGGL(k_mesh_wait_copy_x, dim3(meshBlocks(vf.n)), dim3(kVecThreads), 0, s, vf,
                      const_cast<DevState*>(st), dmv);
 }
-void launchMeshPushPartial(const double* partial, int32_t n, const DevState* st, const MeshView* dmv, hipStream_t s) {
+void launchMeshPushPartial(const double* partial, int32_t n, const DevState* st, const MeshArgs& dmv, hipStream_t s) {
   hipLaunchKernelGGL(k_mesh_push_partial, dim3(meshBlocks(n)), dim3(kVecThreads), 0, s, partial, st, dmv, 0LL);
 }
-void launchMeshReduceInteract(const IterVecs& vc, const DevState* st, const MeshView* dmv, const double* partial,
+void launchMeshReduceInteract(const IterVecs& vc, const DevState* st, const MeshArgs& dmv, const double* partial,
                               double* partDX, double* partInter, int32_t nBlocks, hipStream_t s) {
   hipLaunchKernelGGL(k_mesh_reduce_interact, dim3(nBlocks), dim3(kVecThreads), 0, s, vc, const_cast<DevState*>(st),
                      dmv, partial, partDX, partInter);
 }
-void launchMeshDecide(DevState* st, const MeshView* dmv, const double* partDY, int32_t nDY, const double* partDX,
+void launchMeshDecide(DevState* st, const MeshArgs& dmv, const double* partDY, int32_t nDY, const double* partDX,
                       const double* partInter, int32_t nDX, hipStream_t s) {
   hipLaunchKernelGGL(k_mesh_decide, dim3(1), dim3(kVecThreads), 0, s, st, dmv, partDY, nDY, partDX, partInter, nDX);
 }
@@ -499,6 +529,7 @@ Mesh::Mesh(int32_t rank, int32_t world, const void* id128, int32_t n, int32_t m,
   if (world == 1) {
     PDLP_HIP(hipMemcpy(dView_, &v_, sizeof(MeshView), hipMemcpyHostToDevice));
     setupOk_ = true;
+    args_ = MeshArgs{dView_, state_, v_.G, v_.g, v_.waitTicks};
     return;
   }
 
@@ -537,6 +568,7 @@ Mesh::Mesh(int32_t rank, int32_t world, const void* id128, int32_t n, int32_t m,
   }
   if (ok) ok = hipMemcpy(dView_, &v_, sizeof(MeshView), hipMemcpyHostToDevice) == hipSuccess;
   setupOk_ = ok;
+  args_ = MeshArgs{dView_, state_, v_.G, v_.g, v_.waitTicks};
   hostBarrier(1, 60.0);
 }
 
@@ -563,25 +595,25 @@ void Mesh::allGather(double* vec, bool byRows, hipStream_t s) {
   const int32_t* off = byRows ? v_.rowOff : v_.colOff;
   const int32_t lo = off[v_.g], hi = off[v_.g + 1], len = off[v_.G];
   const long long e = ++epoch_;
-  hipLaunchKernelGGL(k_mesh_push_slice, dim3(meshBlocks(hi - lo)), dim3(kVecThreads), 0, s, vec, lo, hi, dView_, e);
-  hipLaunchKernelGGL(k_mesh_wait_copy, dim3(meshBlocks(len)), dim3(kVecThreads), 0, s, vec, lo, hi, len, dView_, e);
-  hipLaunchKernelGGL(k_mesh_barrier, dim3(1), dim3(kVecThreads), 0, s, dView_, e);
+  hipLaunchKernelGGL(k_mesh_push_slice, dim3(meshBlocks(hi - lo)), dim3(kVecThreads), 0, s, vec, lo, hi, args_, e);
+  hipLaunchKernelGGL(k_mesh_wait_copy, dim3(meshBlocks(len)), dim3(kVecThreads), 0, s, vec, lo, hi, len, args_, e);
+  hipLaunchKernelGGL(k_mesh_barrier, dim3(1), dim3(kVecThreads), 0, s, args_, e);
 }
 
 void Mesh::reduceScatterCols(const double* partial, double* dst, hipStream_t s) {
   const long long e = ++epoch_;
   const int32_t n = v_.colOff[v_.G];
   hipLaunchKernelGGL(k_mesh_push_partial, dim3(meshBlocks(n)), dim3(kVecThreads), 0, s, partial,
-                     (const DevState*)nullptr, dView_, e);
-  hipLaunchKernelGGL(k_mesh_wait_reduce, dim3(meshBlocks(c1() - c0())), dim3(kVecThreads), 0, s, partial, dst, dView_, e);
-  hipLaunchKernelGGL(k_mesh_barrier, dim3(1), dim3(kVecThreads), 0, s, dView_, e);
+                     (const DevState*)nullptr, args_, e);
+  hipLaunchKernelGGL(k_mesh_wait_reduce, dim3(meshBlocks(c1() - c0())), dim3(kVecThreads), 0, s, partial, dst, args_, e);
+  hipLaunchKernelGGL(k_mesh_barrier, dim3(1), dim3(kVecThreads), 0, s, args_, e);
 }
 
 void Mesh::allReduceScalars(double* buf, int32_t k, hipStream_t s) {
   if (k > kMeshMailDoubles) throw std::runtime_error("pdlp_mi355x mesh: too many scalars in one all-reduce");
   if (v_.G == 1) return;
   const long long e = ++epoch_;
-  hipLaunchKernelGGL(k_mesh_allreduce_scalars, dim3(1), dim3(kVecThreads), 0, s, buf, k, dView_, e);
+  hipLaunchKernelGGL(k_mesh_allreduce_scalars, dim3(1), dim3(kVecThreads), 0, s, buf, k, args_, e);
 }
 
 void Mesh::checkError(hipStream_t s) {

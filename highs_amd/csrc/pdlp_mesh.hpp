@@ -58,6 +58,15 @@ struct MeshView {
   MeshState* ms;
 };
 
+// Kernel argument (by value): the scalars every mesh kernel needs right away, so that its first
+// instructions do not chase pointers through the view.
+struct MeshArgs {
+  const MeshView* v;  // device copy of the view (arena pointers, offsets, partitions)
+  MeshState* ms;
+  int32_t G, g;
+  int64_t waitTicks;
+};
+
 // Host side: arena allocation, IPC rendezvous through a POSIX shared-memory
 // segment named after the 128-byte communicator id, generic collectives.
 class Mesh {
@@ -70,7 +79,7 @@ class Mesh {
   Mesh& operator=(const Mesh&) = delete;
 
   const MeshView& view() const { return v_; }
-  const MeshView* deviceView() const { return dView_; }
+  const MeshArgs& args() const { return args_; }
   int32_t c0() const { return v_.colOff[v_.g]; }
   int32_t c1() const { return v_.colOff[v_.g + 1]; }
 
@@ -91,6 +100,7 @@ class Mesh {
   void hostBarrier(int slot, double timeoutSec);
   MeshView v_{};
   MeshView* dView_ = nullptr;
+  MeshArgs args_{};
   void* arena_ = nullptr;
   size_t arenaBytes_ = 0;
   MeshState* state_ = nullptr;
@@ -107,12 +117,12 @@ class Mesh {
 // vc = column-sliced view of the iteration vectors (pointers offset by c0, n = c1-c0);
 // vf = the full-length view.
 int32_t meshGrid(int64_t len);  // grid size of the mesh kernels for a vector of `len`
-void launchMeshPrimalStep(const IterVecs& vc, const DevState* st, const MeshView* dmv, hipStream_t s);
-void launchMeshWaitCopyX(const IterVecs& vf, const DevState* st, const MeshView* dmv, hipStream_t s);
-void launchMeshPushPartial(const double* partial, int32_t n, const DevState* st, const MeshView* dmv, hipStream_t s);
-void launchMeshReduceInteract(const IterVecs& vc, const DevState* st, const MeshView* dmv, const double* partial,
+void launchMeshPrimalStep(const IterVecs& vc, const DevState* st, const MeshArgs& dmv, hipStream_t s);
+void launchMeshWaitCopyX(const IterVecs& vf, const DevState* st, const MeshArgs& dmv, hipStream_t s);
+void launchMeshPushPartial(const double* partial, int32_t n, const DevState* st, const MeshArgs& dmv, hipStream_t s);
+void launchMeshReduceInteract(const IterVecs& vc, const DevState* st, const MeshArgs& dmv, const double* partial,
                               double* partDX, double* partInter, int32_t nBlocks, hipStream_t s);
-void launchMeshDecide(DevState* st, const MeshView* dmv, const double* partDY, int32_t nDY, const double* partDX,
+void launchMeshDecide(DevState* st, const MeshArgs& dmv, const double* partDY, int32_t nDY, const double* partDX,
                       const double* partInter, int32_t nDX, hipStream_t s);
 
 }  // namespace pdlp

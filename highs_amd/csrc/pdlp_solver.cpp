@@ -552,7 +552,7 @@ void Solver::profCollect(int32_t realTrials) {
 void Solver::enqueueTrial() {
   if (meshMode_) {
     // direct-exchange sequence (pdlp_mesh.hpp): X all-gather, P reduce-scatter, S scalars
-    const MeshView* mv = mesh_->deviceView();
+    const MeshArgs& mv = mesh_->args();
     double* buf = commBuf_.get();
     const int32_t nb = meshGrid(std::max(nLoc_, 1));  // every block waits + fences once
     launchMeshPrimalStep(vecsCol_, dState_.get(), mv, stream_);
