@@ -159,6 +159,10 @@ def main():
     if world > 1:  # each rank streams 1/world of the matrix
         dom_bytes = dom_bytes / world
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+    copy_gbs = None
+    if args.solver == "pdlp" and world == 1:
+        # measured device-copy ceiling: 2 x 512 MiB hipMemcpyDtoD, beyond the Infinity Cache
+        copy_gbs = 2 * 512 * 2**20 / (S.time_kernel("copy", 10) * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
@@ -181,6 +185,8 @@ def main():
         "iter_hbm_frac_of_peak": b_iter / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS / world,
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes,
+                     "measured_copy_ceiling_gbs": copy_gbs,
+                     "frac_of_copy_ceiling": (achieved / copy_gbs) if copy_gbs else None,
                      "avg_launch_ms": dom_ms, "timed_launches_in_loop": prof_launches,
                      "other_kernels_ms": {"spmv_ax_dual": k_ax, "spmv_aty_interact": k_aty},
                      "isolated_relaunch_ms": {"spmv_ax_dual": iso_ax, "spmv_aty_interact": iso_aty}},

@@ -513,11 +513,19 @@ Mesh::Mesh(int32_t rank, int32_t world, const void* id128, int32_t n, int32_t m,
   v_.offRecvP = (int64_t)off;   off += alignUp((size_t)world * sliceMax * 8, 4096);
   arenaBytes_ = off;
 
-  // fine-grained: coherent between agents inside a kernel (PDLP_MI355X_MESH_MEM=coarse is a
-  // diagnostic switch for single-GPU protocol tests)
+  // memory that is coherent between agents inside a kernel (PDLP_MI355X_MESH_MEM=finegrained|coarse are
+  // diagnostic switches; coarse only for single-GPU protocol tests)
   const char* mm = getenv("PDLP_MI355X_MESH_MEM");
-  if (mm && !strcmp(mm, "coarse")) PDLP_HIP(hipMalloc(&arena_, arenaBytes_));
-  else PDLP_HIP(hipExtMallocWithFlags(&arena_, arenaBytes_, hipDeviceMallocFinegrained));
+  if (mm && !strcmp(mm, "coarse")) {
+    PDLP_HIP(hipMalloc(&arena_, arenaBytes_));
+  } else if (mm && !strcmp(mm, "finegrained")) {
+    PDLP_HIP(hipExtMallocWithFlags(&arena_, arenaBytes_, hipDeviceMallocFinegrained));
+  } else if (hipExtMallocWithFlags(&arena_, arenaBytes_, hipDeviceMallocUncached) != hipSuccess) {
+    // default: uncached (MTYPE_UC) device memory — what RCCL uses for its peer-visible buffers; every arena
+    // access is a system-scope write-/read-through anyway.  Fine-grained as the second choice.
+    (void)hipGetLastError();
+    PDLP_HIP(hipExtMallocWithFlags(&arena_, arenaBytes_, hipDeviceMallocFinegrained));
+  }
   PDLP_HIP(hipMemsetAsync(arena_, 0, arenaBytes_, s));
   PDLP_HIP(hipMalloc((void**)&state_, sizeof(MeshState)));
   PDLP_HIP(hipMemsetAsync(state_, 0, sizeof(MeshState), s));
