@@ -1,8 +1,8 @@
 // pdlp_mesh.hip — see pdlp_mesh.hpp.  Kernels that talk to the peers' arenas over
 // xGMI and the host-side IPC rendezvous.
 //
-// Memory-model notes (gfx950, HSA): the arenas are FINE-GRAINED device memory, the only kind that is
-// coherent between agents inside a kernel, and every access to an arena is a SYSTEM-SCOPE relaxed atomic
+// Memory-model notes (gfx950, HSA): the arenas are uncached (or fine-grained) device memory — the kinds
+// that are coherent between agents inside a kernel — and every access to an arena is a SYSTEM-SCOPE relaxed atomic
 // (`global_store/load ... sc0 sc1`: write-through / read-through, no reliance on any cache state).
 // Publishing: each wave drains its stores (`s_waitcnt vmcnt(0)`: the writes have landed), the block
 // barrier collects the waves, one lane takes a ticket, and the block that takes the last ticket stores the

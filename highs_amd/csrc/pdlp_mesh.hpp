@@ -1,13 +1,14 @@
 // pdlp_mesh.hpp — direct xGMI exchange for the row-block sharded PDHG loop
 // ("the performance path is a direct full-mesh exchange").
 //
-// One process per GPU on one node.  Every rank owns an ARENA of fine-grained
-// device memory that all peers map through HIP IPC; kernels write straight
-// into the peers' arenas over xGMI (posted remote stores) and announce the data
-// with a system-scope release store of a monotonically increasing epoch into a
-// per-sender flag; the consumer kernel spins (system-scope acquire loads of its
-// own arena, bounded by a wall-clock timeout) before it reads.  No RCCL, no host
-// round trip, nothing that a hipGraph cannot replay.
+// One process per GPU on one node.  Every rank owns an ARENA of uncached device
+// memory that all peers map through HIP IPC; kernels write straight into the
+// peers' arenas over xGMI (write-through system-scope stores), wait until those
+// stores have landed, and then announce the data by storing a monotonically
+// increasing epoch into a per-sender flag; the consumer kernel spins on its own
+// flags (system-scope loads, bounded by a wall-clock timeout) before it reads the
+// payload with system-scope loads.  No RCCL, no host round trip, no cache fences,
+// nothing that a hipGraph cannot replay.
 //
 // Per trial step (rank g owns row block [r0,r1) and column slice [c0,c1)):
 //   X: x+[c0:c1) is pushed into every peer's recvX      (all-gather of x+)
