@@ -32,6 +32,15 @@ void HalpernSolver::log(int level, const char* fmt, ...) const {
 }
 
 HalpernSolver::HalpernSolver(const pdlp_problem_t& P, const pdlp_params_t& opt) : opt_(opt) {
+  try {
+    construct(P);
+  } catch (...) {
+    release();  // a throwing constructor never runs the destructor
+    throw;
+  }
+}
+
+void HalpernSolver::construct(const pdlp_problem_t& P) {
   const auto t0 = std::chrono::steady_clock::now();
   int nDev = 0;
   if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0)
@@ -106,12 +115,15 @@ HalpernSolver::HalpernSolver(const pdlp_problem_t& P, const pdlp_params_t& opt) 
   setupSeconds_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
-HalpernSolver::~HalpernSolver() {
+void HalpernSolver::release() noexcept {
   if (graphExec_) (void)hipGraphExecDestroy(graphExec_);
   if (hostState_) (void)hipHostFree(hostState_);
   if (hostStats_) (void)hipHostFree(hostStats_);
   if (stream_) (void)hipStreamDestroy(stream_);
+  graphExec_ = nullptr; hostState_ = nullptr; hostStats_ = nullptr; stream_ = nullptr;
 }
+
+HalpernSolver::~HalpernSolver() { release(); }
 
 void HalpernSolver::dims(int32_t* n, int32_t* m, int64_t* nnz, int32_t* nEqs) const {
   if (n) *n = F_.n;

@@ -45,6 +45,8 @@ class HalpernSolver : public SolverBase {
   double timeKernel(const std::string& name, int32_t reps) override;
 
  private:
+  void construct(const pdlp_problem_t& P);
+  void release() noexcept;
   struct Res { double pObj = 0, dObj = 0, gap = 0, relGap = 0, pFeas = 0, dFeas = 0; };
   double powerMethod();
   void initStepSizes();

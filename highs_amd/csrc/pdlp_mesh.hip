@@ -491,6 +491,19 @@ void Mesh::hostBarrier(int slot, double timeoutSec) {
 Mesh::Mesh(int32_t rank, int32_t world, const void* id128, int32_t n, int32_t m, const std::vector<int32_t>& rowOff,
            hipStream_t s)
     : n_(n) {
+  try {
+    construct(rank, world, id128, n, m, rowOff, s);
+  } catch (...) {
+    // a constructor that throws never runs its destructor: free what was allocated, but do not wait for the
+    // peers (the exchange is unusable; they time out in their own rendezvous and fall back as well)
+    if (state_) (void)hipMemset(state_, 0xff, sizeof(MeshState));  // marks the exchange broken
+    release();
+    throw;
+  }
+}
+
+void Mesh::construct(int32_t rank, int32_t world, const void* id128, int32_t n, int32_t m,
+                     const std::vector<int32_t>& rowOff, hipStream_t s) {
   if (world > kMeshMaxRanks) throw std::runtime_error("pdlp_mi355x mesh: more than 16 ranks");
   if (world > 1 && !id128) throw std::runtime_error("pdlp_mi355x mesh: a communicator id is needed");
   v_.G = world;
@@ -580,7 +593,7 @@ Mesh::Mesh(int32_t rank, int32_t world, const void* id128, int32_t n, int32_t m,
   hostBarrier(1, 60.0);
 }
 
-Mesh::~Mesh() {
+void Mesh::release() noexcept {
   if (v_.G > 1 && shm_) {
     // nobody frees an arena that a peer's kernel may still write to — unless the exchange already broke
     // (a peer vanished or timed out): then waiting for it again would only delay the error
@@ -596,7 +609,10 @@ Mesh::~Mesh() {
   if (state_) (void)hipFree(state_);
   if (dView_) (void)hipFree(dView_);
   if (shm_) munmap(shm_, shmBytes_);
+  arena_ = nullptr; state_ = nullptr; dView_ = nullptr; shm_ = nullptr;
 }
+
+Mesh::~Mesh() { release(); }
 
 void Mesh::allGather(double* vec, bool byRows, hipStream_t s) {
   if (v_.G == 1) return;

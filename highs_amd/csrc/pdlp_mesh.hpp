@@ -98,6 +98,9 @@ class Mesh {
   bool allAgree(bool ok);
 
  private:
+  void construct(int32_t rank, int32_t world, const void* id128, int32_t n, int32_t m,
+                 const std::vector<int32_t>& rowOff, hipStream_t s);
+  void release() noexcept;
   void hostBarrier(int slot, double timeoutSec);
   MeshView v_{};
   MeshView* dView_ = nullptr;

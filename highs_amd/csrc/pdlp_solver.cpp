@@ -156,6 +156,15 @@ void Solver::log(int level, const char* fmt, ...) const {
 
 Solver::Solver(const pdlp_problem_t& P, const pdlp_params_t& opt, int32_t rank, int32_t world, const void* id128)
     : opt_(opt), rank_(rank), world_(world) {
+  try {
+    construct(P, id128);
+  } catch (...) {
+    release();  // a throwing constructor never runs the destructor
+    throw;
+  }
+}
+
+void Solver::construct(const pdlp_problem_t& P, const void* id128) {
   const auto t0 = std::chrono::steady_clock::now();
   if (world_ < 1 || rank_ < 0 || rank_ >= world_) throw std::runtime_error("bad rank/world");
   int nDev = 0;
@@ -274,15 +283,19 @@ Solver::Solver(const pdlp_problem_t& P, const pdlp_params_t& opt, int32_t rank, 
   setupSeconds_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
-Solver::~Solver() {
+void Solver::release() noexcept {
   if (graphExec_) (void)hipGraphExecDestroy(graphExec_);
   for (hipEvent_t e : profEvents_) (void)hipEventDestroy(e);
+  profEvents_.clear();
   if (hostState_) (void)hipHostFree(hostState_);
   if (hostStats_) (void)hipHostFree(hostStats_);
   delete comm_;
   delete mesh_;
   if (stream_) (void)hipStreamDestroy(stream_);
+  graphExec_ = nullptr; hostState_ = nullptr; hostStats_ = nullptr; comm_ = nullptr; mesh_ = nullptr; stream_ = nullptr;
 }
+
+Solver::~Solver() { release(); }
 
 void Solver::uploadProblem() {
   const int32_t n = F_.n;

@@ -75,6 +75,8 @@ class Solver : public SolverBase {
 
  private:
   // setup
+  void construct(const pdlp_problem_t& P, const void* id128);
+  void release() noexcept;
   void uploadProblem();
   void uploadProblemFromDevice(DeviceProblem& D);
   void allocIterates();
