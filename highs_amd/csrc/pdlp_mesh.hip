@@ -139,6 +139,16 @@ __device__ __forceinline__ void peerRecvX(const MeshArgs& ma, PeerPtrs& P) {
   for (int h = 0; h < kMeshMaxRanks; ++h) P.p[h] = (h < G && h != g) ? recvX(ma, h) : nullptr;
 }
 
+// ONE block per rank ever spins on the peers' flags (a spinning grid could starve the very kernels it waits
+// for when several ranks share a device, as in the single-GPU tests): the wait is its own tiny kernel,
+// and the kernel boundary orders it before the consumers of the payload.
+// st != nullptr: hot loop (epoch from seq); else a generic collective with the host-counted epoch eGen.
+__global__ __launch_bounds__(kWave) void k_mesh_wait(DevState* st, const MeshArgs ma, int kind, long long eGen) {
+  if ((st && st->halted) || dead(ma)) return;
+  const long long e = st ? ma.ms->seq + 1 : eGen;
+  if (!waitPeers(ma, kind, e)) fail(ma, st);
+}
+
 // ---- hot loop ------------------------------------------------------------------------
 // x+ = clamp(x - tau (c - A'y), l, u) on the own column slice (cupdlp_step.c:16-40), stored
 // locally and pushed into every peer's recvX.
@@ -188,9 +198,7 @@ __global__ __launch_bounds__(kVecThreads) void k_mesh_primal_step(const IterVecs
 __global__ __launch_bounds__(kVecThreads) void k_mesh_wait_copy_x(const IterVecs v, DevState* st,
                                                                   const MeshArgs ma) {
   const MeshView* __restrict__ mv = ma.v; (void)mv;
-  if (st->halted || dead(ma)) return;
-  const long long e = ma.ms->seq + 1;
-  if (!waitPeers(ma, kFlagX, e)) { fail(ma, st); return; }
+  if (st->halted || dead(ma)) return;  // (k_mesh_wait ran before: flag X has arrived, or the exchange is dead)
   const int nxt = st->cur ^ 1;
   const int c0 = mv->colOff[ma.g], c1 = mv->colOff[ma.g + 1];
   const double* __restrict__ src = recvX(ma, ma.g);
@@ -198,9 +206,19 @@ __global__ __launch_bounds__(kVecThreads) void k_mesh_wait_copy_x(const IterVecs
   const int stride = gridDim.x * blockDim.x;
   // [0, c0) and [c1, n): the own slice is already in place
   const int other = v.n - (c1 - c0);
-  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < other; q += stride) {
-    const int j = q < c0 ? q : q + (c1 - c0);
-    dst[j] = sysLoad(src + j);
+  const int lastQ = other - 1;
+  for (int q0 = blockIdx.x * blockDim.x + threadIdx.x; q0 < other; q0 += 4 * stride) {
+    double t[4];
+    int jj[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {  // four independent system-scope loads in flight
+      const int q = min(q0 + u * stride, lastQ);
+      jj[u] = q < c0 ? q : q + (c1 - c0);
+      t[u] = sysLoad(src + jj[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (q0 + u * stride <= lastQ) dst[jj[u]] = t[u];
   }
 }
 
@@ -219,7 +237,14 @@ __global__ __launch_bounds__(kVecThreads) void k_mesh_push_partial(const double*
     const int lo = mv->colOff[h], len = mv->colOff[h + 1] - lo;
     double* __restrict__ dst = recvP(ma, h, g);
     const double* __restrict__ src = partial + lo;
-    for (int j = first; j < len; j += stride) sysStore(dst + j, src[j]);
+    for (int j0 = first; j0 < len; j0 += 4 * stride) {
+      double t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) t[u] = src[min(j0 + u * stride, len - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (j0 + u * stride < len) sysStore(dst + j0 + u * stride, t[u]);
+    }
   }
   lastBlockSignal(ma, st ? kFlagP : kFlagGen, e, 1);
 }
@@ -248,9 +273,7 @@ __global__ __launch_bounds__(kVecThreads) void k_mesh_reduce_interact(const Iter
                                                                       const double* __restrict__ partial,
                                                                       double* partDX, double* partInter) {
   const MeshView* __restrict__ mv = ma.v; (void)mv;
-  if (st->halted || dead(ma)) return;
-  const long long e = ma.ms->seq + 1;
-  if (!waitPeers(ma, kFlagP, e)) { fail(ma, st); return; }
+  if (st->halted || dead(ma)) return;  // (k_mesh_wait ran before: flag P has arrived)
   __shared__ double scratch[2][kVecThreads / kWave];
   const int cur = st->cur, nxt = cur ^ 1;
   PeerPtrs src;
@@ -358,11 +381,22 @@ __global__ __launch_bounds__(kVecThreads) void k_mesh_wait_copy(double* __restri
   const MeshView* __restrict__ mv = ma.v; (void)mv;
 
   if (dead(ma)) return;
-  if (!waitPeers(ma, kFlagGen, e)) { fail(ma, nullptr); return; }
   const double* __restrict__ src = recvX(ma, ma.g);
   const int stride = gridDim.x * blockDim.x;
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < len; j += stride)
-    if (j < lo || j >= hi) vec[j] = sysLoad(src + j);
+  const int other = len - (hi - lo), lastQ = other - 1;
+  for (int q0 = blockIdx.x * blockDim.x + threadIdx.x; q0 < other; q0 += 4 * stride) {
+    double t[4];
+    int jj[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q = min(q0 + u * stride, lastQ);
+      jj[u] = q < lo ? q : q + (hi - lo);
+      t[u] = sysLoad(src + jj[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (q0 + u * stride <= lastQ) vec[jj[u]] = t[u];
+  }
 }
 
 __global__ __launch_bounds__(kVecThreads) void k_mesh_wait_reduce(const double* __restrict__ partial,
@@ -370,7 +404,6 @@ __global__ __launch_bounds__(kVecThreads) void k_mesh_wait_reduce(const double* 
                                                                   long long e) {
   const MeshView* __restrict__ mv = ma.v; (void)mv;
   if (dead(ma)) return;
-  if (!waitPeers(ma, kFlagGen, e)) { fail(ma, nullptr); return; }
   const int c0 = mv->colOff[ma.g], len = mv->colOff[ma.g + 1] - c0;
   PeerPtrs src;
   reduceSources(ma, partial + c0, src);
@@ -411,30 +444,37 @@ __global__ __launch_bounds__(kVecThreads) void k_mesh_allreduce_scalars(double* 
   if (!waitPeers(ma, kFlagBar, e)) fail(ma, nullptr);
 }
 
-// Grid of a mesh kernel: every block pays one system-scope fence (an L2 write-back or
-// invalidate), so these grids stay small; PDLP_MI355X_MESH_BLOCKS overrides the cap.
-int32_t meshBlocks(int64_t len) {
-  static const int cap = [] {
-    const char* e = getenv("PDLP_MI355X_MESH_BLOCKS");
-    const int v = e ? atoi(e) : 0;
-    return v > 0 ? v : 256;
-  }();
+// Grids of the mesh kernels.  Producers end with one ticket atomic per block on a single counter
+// (~12 ns each, serialised): few blocks.  Consumers only poll their flags: many blocks, a handful of
+// elements per thread, so that the system-scope payload loads (not pipelined by the compiler) overlap.
+// PDLP_MI355X_MESH_BLOCKS overrides the producer cap.
+int32_t capped(int64_t len, int cap) {
   int64_t b = (len + kVecThreads - 1) / kVecThreads;
   if (b < 1) b = 1;
   if (b > cap) b = cap;
   return (int32_t)b;
 }
+int32_t meshBlocks(int64_t len) {  // producers
+  static const int cap = [] {
+    const char* e = getenv("PDLP_MI355X_MESH_BLOCKS");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 128;
+  }();
+  return capped(len, cap);
+}
+int32_t meshConsumerBlocks(int64_t len) { return capped((len + 3) / 4, 1024); }  // ~4 elements per thread
 
 }  // namespace
 
-int32_t meshGrid(int64_t len) { return meshBlocks(len); }
+int32_t meshGrid(int64_t len) { return meshConsumerBlocks(len); }
 
 // ---- launchers (dmv = the view in device memory) --------------------------------------------
 void launchMeshPrimalStep(const IterVecs& vc, const DevState* st, const MeshArgs& dmv, hipStream_t s) {
   hipLaunchKernelGGL(k_mesh_primal_step, dim3(meshBlocks(vc.n)), dim3(kVecThreads), 0, s, vc, st, dmv);
 }
 void launchMeshWaitCopyX(const IterVecs& vf, const DevState* st, const MeshArgs& dmv, hipStream_t s) {
-  hipLaunchKernelGGL(k_mesh_wait_copy_x, dim3(meshBlocks(vf.n)), dim3(kVecThreads), 0, s, vf,
+  hipLaunchKernelGGL(k_mesh_wait, dim3(1), dim3(kWave), 0, s, const_cast<DevState*>(st), dmv, (int)kFlagX, 0LL);
+  hipLaunchKernelGGL(k_mesh_wait_copy_x, dim3(meshConsumerBlocks(vf.n)), dim3(kVecThreads), 0, s, vf,
                      const_cast<DevState*>(st), dmv);
 }
 void launchMeshPushPartial(const double* partial, int32_t n, const DevState* st, const MeshArgs& dmv, hipStream_t s) {
@@ -442,6 +482,7 @@ void launchMeshPushPartial(const double* partial, int32_t n, const DevState* st,
 }
 void launchMeshReduceInteract(const IterVecs& vc, const DevState* st, const MeshArgs& dmv, const double* partial,
                               double* partDX, double* partInter, int32_t nBlocks, hipStream_t s) {
+  hipLaunchKernelGGL(k_mesh_wait, dim3(1), dim3(kWave), 0, s, const_cast<DevState*>(st), dmv, (int)kFlagP, 0LL);
   hipLaunchKernelGGL(k_mesh_reduce_interact, dim3(nBlocks), dim3(kVecThreads), 0, s, vc, const_cast<DevState*>(st),
                      dmv, partial, partDX, partInter);
 }
@@ -620,7 +661,8 @@ void Mesh::allGather(double* vec, bool byRows, hipStream_t s) {
   const int32_t lo = off[v_.g], hi = off[v_.g + 1], len = off[v_.G];
   const long long e = ++epoch_;
   hipLaunchKernelGGL(k_mesh_push_slice, dim3(meshBlocks(hi - lo)), dim3(kVecThreads), 0, s, vec, lo, hi, args_, e);
-  hipLaunchKernelGGL(k_mesh_wait_copy, dim3(meshBlocks(len)), dim3(kVecThreads), 0, s, vec, lo, hi, len, args_, e);
+  hipLaunchKernelGGL(k_mesh_wait, dim3(1), dim3(kWave), 0, s, (DevState*)nullptr, args_, (int)kFlagGen, e);
+  hipLaunchKernelGGL(k_mesh_wait_copy, dim3(meshConsumerBlocks(len)), dim3(kVecThreads), 0, s, vec, lo, hi, len, args_, e);
   hipLaunchKernelGGL(k_mesh_barrier, dim3(1), dim3(kVecThreads), 0, s, args_, e);
 }
 
@@ -629,7 +671,8 @@ void Mesh::reduceScatterCols(const double* partial, double* dst, hipStream_t s) 
   const int32_t n = v_.colOff[v_.G];
   hipLaunchKernelGGL(k_mesh_push_partial, dim3(meshBlocks(n)), dim3(kVecThreads), 0, s, partial,
                      (const DevState*)nullptr, args_, e);
-  hipLaunchKernelGGL(k_mesh_wait_reduce, dim3(meshBlocks(c1() - c0())), dim3(kVecThreads), 0, s, partial, dst, args_, e);
+  hipLaunchKernelGGL(k_mesh_wait, dim3(1), dim3(kWave), 0, s, (DevState*)nullptr, args_, (int)kFlagGen, e);
+  hipLaunchKernelGGL(k_mesh_wait_reduce, dim3(meshConsumerBlocks(c1() - c0())), dim3(kVecThreads), 0, s, partial, dst, args_, e);
   hipLaunchKernelGGL(k_mesh_barrier, dim3(1), dim3(kVecThreads), 0, s, args_, e);
 }
 

@@ -567,7 +567,7 @@ void Solver::enqueueTrial() {
     // direct-exchange sequence (pdlp_mesh.hpp): X all-gather, P reduce-scatter, S scalars
     const MeshArgs& mv = mesh_->args();
     double* buf = commBuf_.get();
-    const int32_t nb = meshGrid(std::max(nLoc_, 1));  // every block waits + fences once
+    const int32_t nb = meshGrid(std::max(nLoc_, 1));  // consumer grid: ~4 slice elements per thread
     launchMeshPrimalStep(vecsCol_, dState_.get(), mv, stream_);
     launchMeshWaitCopyX(vecs_, dState_.get(), mv, stream_);
     launchSpmvAxDual(dA_.view(), vecs_, dState_.get(), partDY_.get(), stream_);
