@@ -92,16 +92,26 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the PDLP path has no CPU fallback")
+    # Test hooks (the 1-GPU build box): PDLP_BENCH_SINGLE_DEVICE=1 puts every rank on device 0 (the mesh
+    # exchange only needs HIP IPC) and PDLP_BENCH_DIST_BACKEND=gloo replaces RCCL for the launcher-side
+    # collectives, which RCCL cannot do with two ranks on one device.  The driver uses neither.
+    if os.environ.get("PDLP_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("PDLP_BENCH_DIST_BACKEND", "nccl")
+    tdev = "cuda" if backend == "nccl" else "cpu"
     torch.cuda.set_device(local_rank)
     dist = None
     uid = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
         idbuf = (C.c_uint8 * 128)()
         if rank == 0:
             assert solver.lib().pdlp_mi355x_comm_unique_id(idbuf) == 0, solver.lib().pdlp_mi355x_last_error()
-        t = torch.tensor(list(bytes(idbuf)), dtype=torch.uint8, device="cuda")
+        t = torch.tensor(list(bytes(idbuf)), dtype=torch.uint8, device=tdev)
         dist.broadcast(t, src=0)
         uid = (C.c_uint8 * 128)(*t.cpu().tolist())
 
@@ -126,7 +136,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -137,7 +147,7 @@ def main():
         # every rank must hold bit-identical iterates (same decisions everywhere): compare a checksum of x
         import numpy as np
         chk = float(np.frombuffer(S.get("x", n).tobytes(), dtype=np.uint64).astype(np.float64).sum())
-        lo = torch.tensor([chk], dtype=torch.float64, device="cuda")
+        lo = torch.tensor([chk], dtype=torch.float64, device=tdev)
         hi = lo.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)

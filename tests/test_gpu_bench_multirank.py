@@ -1,0 +1,32 @@
+"""bench.py's multi-rank code path (id broadcast, sharded create, barrier + max-over-ranks timing, the
+cross-rank bit-identity check, rank-0 JSON) exercised end to end on the 1-GPU box: two ranks on device 0
+(mesh exchange over HIP IPC), launcher collectives over gloo.  On a real node the driver launches the same
+script with one rank per GPU over RCCL."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_two_ranks_one_device(world):
+    env = dict(os.environ, PDLP_BENCH_SINGLE_DEVICE="1", PDLP_BENCH_DIST_BACKEND="gloo",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", PDLP_MI355X_MESH_TIMEOUT_MS="30000")
+    port = 29700 + os.getpid() % 200 + world
+    cmd = ["timeout", "400", sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world),
+           "--config", "a", "--steps", "400", "--warmup", "80"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints exactly one JSON line"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["steps"] == 400 and d["scaling"] == "strong"
+    assert d["ranks_bit_identical"] is True
+    assert "mesh" in d["config"]["parallelism"]
+    assert d["value"] > 0 and d["roofline"]["achieved"] > 0
