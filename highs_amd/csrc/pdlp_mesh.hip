@@ -720,8 +720,8 @@ bool Mesh::selfTest(hipStream_t s) {
   std::vector<double> host(n), got(n);
   double* dv = nullptr;
   double* dp = nullptr;
-  PDLP_HIP(hipMalloc((void**)&dv, sizeof(double) * (size_t)std::max(n, 1)));
-  PDLP_HIP(hipMalloc((void**)&dp, sizeof(double) * (size_t)std::max(n, 1)));
+  PDLP_HIP(hipMalloc((void**)&dv, sizeof(double) * (size_t)std::max(n, 4)));
+  PDLP_HIP(hipMalloc((void**)&dp, sizeof(double) * (size_t)std::max(n, 4)));  // also carries the 3 test scalars
   bool ok = true;
   try {
     for (int round = 0; round < 3 && ok; ++round) {

@@ -30,7 +30,7 @@ def main():
         kw = dict(problem_struct=sp_.struct)
         nc, nr = dims[1], dims[0]
     else:
-        lp = L.HighsLp.from_npz(os.path.join(GOLD, "instances", name + ".npz"))
+        lp = L.special_lps()[name] if name in L.special_lps() else L.HighsLp.from_npz(os.path.join(GOLD, "instances", name + ".npz"))
         kw = dict(lp=lp)
         nc, nr = lp.num_col, lp.num_row
     if kind == "die":

@@ -115,3 +115,17 @@ def test_vanished_peer_becomes_an_error_not_a_hang(tmp_path):
     res = _run_ranks(2, "die:afiro", tmp_path, extra_env={"PDLP_MI355X_MESH_TIMEOUT_MS": "2000"}, must_finish={0})
     assert "timed out" in str(res[0]["msg"]), res[0]["msg"]
     assert float(res[0]["seconds"]) < 30.0
+
+
+@pytest.mark.parametrize("name", sorted(L.special_lps()))
+def test_mesh_special_lps_same_status_as_single_gpu(name, tmp_path):
+    """The reference's unit-test LPs (optimal, infeasible, unbounded, ranged rows, maximisation) on two ranks:
+    the certificates and objectives are assembled from row-sharded AND column-sliced statistics."""
+    lp = L.special_lps()[name]
+    base = solver.solveLpCupdlp(lp)
+    res = _run_ranks(2, f"solve:{name}", tmp_path)
+    assert np.array_equal(res[0]["col_value"], res[1]["col_value"]) and int(res[0]["term"]) == int(res[1]["term"])
+    assert int(res[0]["term"]) == int(base.result.term_code)
+    if base.model_status == solver.kOptimal:
+        a, b = lp.objective_value(res[0]["col_value"]), base.info["objective_function_value"]
+        assert abs(a - b) <= 1e-6 * (1 + abs(b))
