@@ -24,8 +24,9 @@ def _lp(name):
 
 
 def _run_ranks(world, case, tmp_path, extra_env=None, must_finish=None):
-    uid = (C.c_ubyte * 128)()
-    assert solver.lib().pdlp_mi355x_comm_unique_id(uid) == 0
+    # the mesh exchange only hashes the 128-byte id into the name of its rendezvous segment; random bytes
+    # keep librccl (whose first ncclGetUniqueId can take a minute on a box without network) out of these tests
+    uid = (C.c_ubyte * 128).from_buffer_copy(os.urandom(128))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.update(extra_env or {})
     outs = [str(tmp_path / f"r{r}.npz") for r in range(world)]
