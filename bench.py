@@ -117,8 +117,6 @@ def main():
 
     sp_ = solver.SyntheticProblem(cfg["m"], cfg["n"], cfg["nnz"], 1)
     params = abi.default_params(kkt_tolerance=1e-4, device=local_rank, solver=args.solver)
-    if args.solver == "hipdlp" and world > 1:
-        raise SystemExit("the hipdlp path is single-GPU")
     t_setup = time.time()
     S = solver.DeviceSolver(problem_struct=sp_.struct, params=params, rank=rank, world=world, unique_id=uid)
     t_setup = time.time() - t_setup
@@ -146,7 +144,9 @@ def main():
     if dist is not None:
         # every rank must hold bit-identical iterates (same decisions everywhere): compare a checksum of x
         import numpy as np
-        chk = float(np.frombuffer(S.get("x", n).tobytes(), dtype=np.uint64).astype(np.float64).sum())
+        # (cuPDLP path: x is replicated; HiPDLP path: the reflected x is the vector every rank holds in full)
+        rep = "x" if args.solver == "pdlp" else "x_reflected"
+        chk = float(np.frombuffer(S.get(rep, n).tobytes(), dtype=np.uint64).astype(np.float64).sum())
         lo = torch.tensor([chk], dtype=torch.float64, device=tdev)
         hi = lo.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)

@@ -75,8 +75,7 @@ int pdlp_mi355x_create_sharded(const pdlp_problem_t* P, const pdlp_params_t* opt
     *out = nullptr;
     pdlp::SolverBase* s = nullptr;
     if (opt->algorithm == 1) {
-      if (world != 1) throw std::runtime_error("the HiPDLP path (algorithm = 1) is single-GPU");
-      s = new pdlp::HalpernSolver(*P, *opt);
+      s = new pdlp::HalpernSolver(*P, *opt, rank, world, id128);
     } else if (opt->algorithm == 0) {
       s = new pdlp::Solver(*P, *opt, rank, world, id128);
     } else {

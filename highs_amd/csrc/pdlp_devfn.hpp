@@ -101,5 +101,43 @@ __device__ __attribute__((unused)) void decideUpdate(DevState* st, double dX2, d
   *st = s;
 }
 
+// Epilogue operands that do not depend on the SpMV result.
+struct Pre { double a, b, c, d, e; };
+
+// HiPDLP step, column side (pdhg.cc:975-990 and :1008-1011): s = (A'y)_j.
+__device__ __forceinline__ __attribute__((unused)) void halpernPrimal(const HalpernVecs& h, int j, double s, const Pre& p, double tau,
+                                              double rho, double w) {
+  const double xc = p.a, cost = p.b, xa = p.c, l = p.d, u = p.e;
+  const double temp = xc - tau * (cost - s);
+  const double t = (u < temp) ? u : temp;  // std::min(temp, u)
+  const double proj = (l < t) ? t : l;     // std::max(l, .)   (linalg::projectBox)
+  if (h.major) {
+    h.xn[j] = proj;
+    h.slack[j] = (proj - temp) / tau;
+  }
+  const double rx = 2.0 * proj - xc;
+  h.rx[j] = rx;
+  const double blended = rho * rx + (1.0 - rho) * xc;
+  h.xc[j] = w * blended + (1.0 - w) * xa;
+}
+// HiPDLP step, row side (pdhg.cc:995-1006 and :1012-1015): s = (A reflected_x)_i.
+__device__ __forceinline__ __attribute__((unused)) void halpernDual(const HalpernVecs& h, int i, double s, const Pre& p, double sigma,
+                                            double rho, double w) {
+  const double yc = p.a, ya = p.b, rl = p.c, ru = p.d;
+  const double temp = yc / sigma - s;
+  const double lo = -ru, up = -rl;
+  const double t = (up < temp) ? up : temp;
+  const double proj = (lo < t) ? t : lo;
+  const double pd = (temp - proj) * sigma;
+  const double ry = 2.0 * pd - yc;
+  if (h.major) {
+    h.yn[i] = pd;
+    h.ry[i] = ry;
+  }
+  const double blended = rho * ry + (1.0 - rho) * yc;
+  h.yc[i] = w * blended + (1.0 - w) * ya;
+}
+
+
 }  // namespace
 }  // namespace pdlp

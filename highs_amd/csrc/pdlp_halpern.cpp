@@ -31,16 +31,18 @@ void HalpernSolver::log(int level, const char* fmt, ...) const {
   fflush(stdout);
 }
 
-HalpernSolver::HalpernSolver(const pdlp_problem_t& P, const pdlp_params_t& opt) : opt_(opt) {
+HalpernSolver::HalpernSolver(const pdlp_problem_t& P, const pdlp_params_t& opt, int32_t rank, int32_t world,
+                             const void* id128)
+    : opt_(opt), rank_(rank), world_(world) {
   try {
-    construct(P);
+    construct(P, id128);
   } catch (...) {
     release();  // a throwing constructor never runs the destructor
     throw;
   }
 }
 
-void HalpernSolver::construct(const pdlp_problem_t& P) {
+void HalpernSolver::construct(const pdlp_problem_t& P, const void* id128) {
   const auto t0 = std::chrono::steady_clock::now();
   int nDev = 0;
   if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0)
@@ -48,7 +50,10 @@ void HalpernSolver::construct(const pdlp_problem_t& P) {
   PDLP_HIP(hipSetDevice(opt_.device));
   PDLP_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
   if (const char* g = getenv("PDLP_MI355X_GRAPH")) useGraph_ = atoi(g) != 0;
-  log(1, "Solving with HiPDLP (restarted Halpern PDHG) on MI355X (gfx950, HIP)\n");
+  if (world_ < 1 || rank_ < 0 || rank_ >= world_) throw std::runtime_error("bad rank/world");
+  const char* fc = getenv("PDLP_MI355X_FORCE_COMM");
+  sharded_ = world_ > 1 || (fc && atoi(fc) != 0);
+  if (rank_ == 0) log(1, "Solving with HiPDLP (restarted Halpern PDHG) on MI355X (gfx950, HIP)\n");
   if ((opt_.features_off & PDLP_FEATURE_RESTART_OFF) != 0)
     log(1, "HiPDLP uses Halpern restart only; ignoring the restart-off feature flag.\n");  // pdhg.cc:1846-1852
   pid_ = opt_.step_size_strategy != 0;  // 0 fixed; everything else runs as PID (pdhg.cc:1856-1864)
@@ -67,6 +72,7 @@ void HalpernSolver::construct(const pdlp_problem_t& P) {
   const int64_t nnzIn = P.num_col > 0 && P.a_start ? (int64_t)P.a_start[P.num_col] : 0;
   bool gpuSetup = nnzIn >= 200000;
   if (const char* g = getenv("PDLP_MI355X_GPU_SETUP")) gpuSetup = atoi(g) != 0;
+  if (sharded_) gpuSetup = false;  // the row-block shards are cut on the host
   if (gpuSetup) {
     HipdlpSetup hs;
     hs.ruiz = opt_.scaling_mode & 1; hs.pc = opt_.scaling_mode & 4; hs.l2 = opt_.scaling_mode & 2;
@@ -88,21 +94,45 @@ void HalpernSolver::construct(const pdlp_problem_t& P) {
     formulateHipdlp(P, F_);
     if (doScale) scaleHipdlp(F_, opt_.scaling_mode & 1, opt_.scaling_mode & 4, opt_.scaling_mode & 2, opt_.ruiz_iterations);
     finalize(F_);  // rows ascending column; columns are already ascending row
-    dA_.upload(F_.csr, F_.m, F_.n, slabMode, stream_);
-    dAt_.upload(F_.cscSorted, F_.n, F_.m, slabMode, stream_);
-    auto up = [&](DeviceArray<double>& d, const std::vector<double>& h) {
-      d.alloc(h.size());
-      d.upload(h.data(), h.size(), stream_);
+    r0_ = 0; r1_ = F_.m;
+    if (sharded_) {
+      std::vector<int32_t> off = rowPartition(F_.csr, F_.m, world_);
+      r0_ = off[rank_]; r1_ = off[rank_ + 1];
+      mesh_ = new Mesh(rank_, world_, id128, F_.n, F_.m, off, stream_);
+      const bool ok = mesh_->selfTest(stream_);
+      if (!mesh_->allAgree(ok))
+        throw std::runtime_error("pdlp_mi355x: the sharded HiPDLP path needs the direct xGMI exchange, whose self-test failed");
+      c0_ = mesh_->c0(); c1_ = mesh_->c1();
+      Compressed csrSlab, cscSlab;
+      extractSlab(F_, r0_, r1_, csrSlab, cscSlab);
+      dA_.upload(csrSlab, r1_ - r0_, F_.n, slabMode, stream_);
+      dAt_.upload(cscSlab, F_.n, r1_ - r0_, slabMode, stream_);
+      commBuf_.alloc((size_t)F_.n + 8);
+      commBuf_.zero(stream_);
+    } else {
+      dA_.upload(F_.csr, F_.m, F_.n, slabMode, stream_);
+      dAt_.upload(F_.cscSorted, F_.n, F_.m, slabMode, stream_);
+    }
+    auto up = [&](DeviceArray<double>& d, const double* h, size_t count) {
+      d.alloc(count);
+      d.upload(h, count, stream_);
     };
-    up(cost_, F_.cost); up(lower_, F_.lower); up(upper_, F_.upper); up(rl_, F_.rhs); up(ru_, F_.rowUpper);
-    up(colScale_, F_.colScale); up(rowScale_, F_.rowScale);
-    isEq_.alloc((size_t)F_.m);
-    isEq_.upload(F_.rowIsEq.data(), (size_t)F_.m, stream_);
+    const size_t mL = (size_t)(r1_ - r0_);
+    up(cost_, F_.cost.data(), F_.n); up(lower_, F_.lower.data(), F_.n); up(upper_, F_.upper.data(), F_.n);
+    up(colScale_, F_.colScale.data(), F_.n);
+    up(rl_, F_.rhs.data() + r0_, mL); up(ru_, F_.rowUpper.data() + r0_, mL); up(rowScale_, F_.rowScale.data() + r0_, mL);
+    isEq_.alloc(mL);
+    isEq_.upload(F_.rowIsEq.data() + r0_, mL, stream_);
   }
-  const int32_t n = F_.n, m = F_.m;
+  if (!sharded_) { r0_ = 0; r1_ = F_.m; }
+  mLoc_ = r1_ - r0_;
+  if (!mesh_) { c0_ = 0; c1_ = F_.n; }
+  nLoc_ = c1_ - c0_;
+  const int32_t n = F_.n, m = mLoc_;
   for (DeviceArray<double>* d : {&xc_, &xn_, &rx_, &xa_, &slack_, &sp_, &sn_, &outX_, &tmpN_}) { d->alloc(n); d->zero(stream_); }
   for (DeviceArray<double>* d : {&yc_, &yn_, &ry_, &ya_, &outY_, &tmpM_, &tmpM2_}) { d->alloc(m); d->zero(stream_); }
   stride_ = std::max(vecBlocks(std::max(n, 1)), vecBlocks(std::max(m, 1)));
+  (void)m;
   part_.alloc((size_t)kStatSlots * stride_);
   statOut_.alloc(kStatSlots);
   dState_.alloc(1);
@@ -119,8 +149,9 @@ void HalpernSolver::release() noexcept {
   if (graphExec_) (void)hipGraphExecDestroy(graphExec_);
   if (hostState_) (void)hipHostFree(hostState_);
   if (hostStats_) (void)hipHostFree(hostStats_);
+  delete mesh_;
   if (stream_) (void)hipStreamDestroy(stream_);
-  graphExec_ = nullptr; hostState_ = nullptr; hostStats_ = nullptr; stream_ = nullptr;
+  graphExec_ = nullptr; hostState_ = nullptr; hostStats_ = nullptr; stream_ = nullptr; mesh_ = nullptr;
 }
 
 HalpernSolver::~HalpernSolver() { release(); }
@@ -132,32 +163,61 @@ void HalpernSolver::dims(int32_t* n, int32_t* m, int64_t* nnz, int32_t* nEqs) co
   if (nEqs) *nEqs = F_.nEqs;
 }
 
-// Deterministic sum of per-block partials, brought to the host.
+// Deterministic sum of per-block partials, brought to the host (and over the ranks when sharded).
 double HalpernSolver::sum(const double* partials, int32_t nBlocks) {
   launchFinalReduce(partials, nBlocks, nBlocks, 1, statOut_.get(), stream_);
+  if (sharded_) sumOverRanks(statOut_.get(), 1);
   PDLP_HIP(hipMemcpyAsync(hostStats_, statOut_.get(), sizeof(double), hipMemcpyDeviceToHost, stream_));
   PDLP_HIP(hipStreamSynchronize(stream_));
   return hostStats_[0];
 }
 
+void HalpernSolver::sumOverRanks(double* devBuf, int32_t count) {
+  if (mesh_) mesh_->allReduceScalars(devBuf, count, stream_);
+}
+
+// A' y for row-local y: the full vector on one GPU; when sharded, the rank-ordered sum of the ranks'
+// partials on the OWN column slice of `aty` (a full-length buffer)
+void HalpernSolver::spmvAt(const double* yLocal, double* aty) {
+  if (!sharded_) {
+    launchSpmvPlain(dAt_.view(), yLocal, aty, stream_);
+  } else {
+    launchSpmvPlain(dAt_.view(), yLocal, commBuf_.get(), stream_);
+    mesh_->reduceScatterCols(commBuf_.get(), aty, stream_);
+  }
+}
+
+void HalpernSolver::gatherToHost(const double* devLocal, int32_t lo, int32_t hi, bool byRows, std::vector<double>& full) {
+  const int32_t len = byRows ? F_.m : F_.n;
+  full.assign((size_t)len, 0.0);
+  DeviceArray<double> g;
+  g.alloc((size_t)std::max(len, 1));
+  g.zero(stream_);
+  PDLP_HIP(hipMemcpyAsync(g.get() + lo, devLocal, sizeof(double) * (size_t)(hi - lo), hipMemcpyDeviceToDevice, stream_));
+  if (mesh_) mesh_->allGather(g.get(), byRows, stream_);
+  g.download(full.data(), (size_t)len, stream_);
+  PDLP_HIP(hipStreamSynchronize(stream_));
+}
+
 // powerMethod, pdhg.cc:1529-1670 (kCuPdlpAATPowerMethod): 20 iterations on A A' from the ones vector
 double HalpernSolver::powerMethod() {
-  const int32_t n = F_.n, m = F_.m;
-  if (n == 0 || m == 0) return 1.0;
-  const int32_t nbM = vecBlocks(m), nbN = vecBlocks(n);
-  double* x = tmpM_.get();   // x_vec / z_vec (rows)
+  const int32_t n = F_.n, m = mLoc_;
+  if (n == 0 || F_.m == 0) return 1.0;
+  const int32_t nbM = vecBlocks(std::max(m, 1)), nbN = vecBlocks(std::max(nLoc_, 1));
+  double* x = tmpM_.get();   // x_vec / z_vec (rows, local)
   double* z = tmpM2_.get();
   double* y = tmpN_.get();   // y_vec (columns)
   launchFill(x, 1.0, m, stream_);
   double lambda = 0.0;
   for (int it = 0; it < 20; ++it) {
-    launchSpmvPlain(dAt_.view(), x, y, stream_);  // y = A' x
-    launchSpmvPlain(dA_.view(), y, z, stream_);   // z = A y
+    spmvAt(x, y);                                                 // y = A' x
+    if (sharded_) mesh_->allGather(y, false, stream_);            // A y needs all of y
+    launchSpmvPlain(dA_.view(), y, z, stream_);                   // z = A y
     launchDot(z, z, m, part_.get(), nbM, stream_);
     const double zn = std::sqrt(sum(part_.get(), nbM));
     launchDivScalar(z, zn, m, stream_);
-    launchSpmvPlain(dAt_.view(), z, y, stream_);  // w = A' q
-    launchDot(y, y, n, part_.get(), nbN, stream_);
+    spmvAt(z, y);                                                 // w = A' q  (own slice when sharded)
+    launchDot(y + c0_, y + c0_, nLoc_, part_.get(), nbN, stream_);
     lambda = sum(part_.get(), nbN);
     std::swap(x, z);  // x_vec = z_vec
   }
@@ -188,7 +248,7 @@ void HalpernSolver::pushState() {
 
 // initializeStepSizes + initialize + the start of solve() (pdhg.cc:499-553)
 void HalpernSolver::reset() {
-  const int32_t n = F_.n, m = F_.m;
+  const int32_t n = F_.n, m = mLoc_;
   initStepSizes();
   bestGap_ = std::numeric_limits<double>::infinity();
   errSum_ = lastErr_ = 0.0;
@@ -210,8 +270,7 @@ void HalpernSolver::reset() {
   pushState();
 }
 
-// performHalpernPdhgStep, pdhg.cc:961-1018, as two fused SpMV launches
-void HalpernSolver::enqueueStep(bool major, int32_t kOff) {
+HalpernVecs HalpernSolver::stepVecs(bool major, int32_t kOff) const {
   HalpernVecs h{};
   h.xc = xc_.get(); h.yc = yc_.get(); h.xn = xn_.get(); h.yn = yn_.get(); h.rx = rx_.get(); h.ry = ry_.get();
   h.xa = xa_.get(); h.ya = ya_.get(); h.slack = slack_.get();
@@ -219,8 +278,22 @@ void HalpernSolver::enqueueStep(bool major, int32_t kOff) {
   h.hs = dState_.get();
   h.kOff = kOff;
   h.major = major ? 1 : 0;
-  launchHalpernPrimal(dAt_.view(), h, stream_);
-  launchHalpernDual(dA_.view(), h, stream_);
+  return h;
+}
+
+// performHalpernPdhgStep, pdhg.cc:961-1018, as two fused SpMV launches (one GPU), or the
+// partial-A'y / exchange / slice-primal / exchange / local-dual sequence of pdlp_mesh.hpp (sharded)
+void HalpernSolver::enqueueStep(bool major, int32_t kOff) {
+  const HalpernVecs h = stepVecs(major, kOff);
+  if (!sharded_) {
+    launchHalpernPrimal(dAt_.view(), h, stream_);
+    launchHalpernDual(dA_.view(), h, stream_);
+    return;
+  }
+  HalpernVecs hc = h;  // column vectors offset to the own slice
+  hc.xc += c0_; hc.xn += c0_; hc.rx += c0_; hc.xa += c0_; hc.slack += c0_;
+  hc.cost += c0_; hc.lower += c0_; hc.upper += c0_;
+  launchMeshHalpernStep(dA_.view(), dAt_.view(), h, hc, F_.n, nLoc_, commBuf_.get(), mesh_->args(), stream_);
 }
 
 // One block of the main loop (pdhg.cc:578-641): major step 1, [fixed-point error if a restart
@@ -252,39 +325,47 @@ void HalpernSolver::runBlock(bool fpeAfterFirst) {
 
 // computeFixedPointError, pdhg.cc:709-739
 double HalpernSolver::fixedPointError() {
-  const int32_t n = F_.n, m = F_.m;
-  const int32_t nbM = vecBlocks(std::max(m, 1)), nbN = vecBlocks(std::max(n, 1));
+  const int32_t m = mLoc_;
+  const int32_t nbM = vecBlocks(std::max(m, 1)), nbN = vecBlocks(std::max(nLoc_, 1));
   double* part = part_.get();
   launchHalpernFpeRows(yn_.get(), ry_.get(), tmpM_.get(), m, part, nbM, stream_);
-  launchSpmvPlain(dAt_.view(), tmpM_.get(), tmpN_.get(), stream_);
-  launchHalpernFpeCols(xn_.get(), rx_.get(), tmpN_.get(), n, part + stride_, part + 2 * (size_t)stride_, nbN, stream_);
+  spmvAt(tmpM_.get(), tmpN_.get());
+  launchHalpernFpeCols(xn_.get() + c0_, rx_.get() + c0_, tmpN_.get() + c0_, nLoc_, part + stride_,
+                       part + 2 * (size_t)stride_, nbN, stream_);
   launchFinalReduce(part, stride_, nbM, 1, statOut_.get(), stream_);
   launchFinalReduce(part + stride_, stride_, nbN, 2, statOut_.get() + 1, stream_);
+  if (sharded_) sumOverRanks(statOut_.get(), 3);
   PDLP_HIP(hipMemcpyAsync(hostStats_, statOut_.get(), sizeof(double) * 3, hipMemcpyDeviceToHost, stream_));
   PDLP_HIP(hipStreamSynchronize(stream_));
+  if (mesh_) mesh_->checkError(stream_);
   const double dn = hostStats_[0], pn = hostStats_[1], cross = hostStats_[2];
   const double movement = pn * omega_ + dn / omega_;
   const double interaction = 2.0 * eta_ * cross;
   return std::sqrt(std::max(0.0, movement + interaction));
 }
 
-// runConvergenceCheck's "current" leg (pdhg.cc:820-833) + checkConvergence (:1474-1527)
-bool HalpernSolver::check(const double* x, const double* y, bool cachedSlack, Res& r) {
-  const int32_t n = F_.n, m = F_.m;
-  const int32_t nbM = vecBlocks(std::max(m, 1)), nbN = vecBlocks(std::max(n, 1));
+// runConvergenceCheck's "current" leg (pdhg.cc:820-833) + checkConvergence (:1474-1527).
+// x: full-length buffer whose own column slice is valid (all of it on one GPU); y: local rows.
+bool HalpernSolver::check(double* x, const double* y, bool cachedSlack, Res& r) {
+  const int32_t m = mLoc_;
+  const int32_t nbM = vecBlocks(std::max(m, 1)), nbN = vecBlocks(std::max(nLoc_, 1));
   const int sc = F_.scaled ? 1 : 0;
+  const size_t co = (size_t)c0_;
   double* part = part_.get();
+  if (sharded_) mesh_->allGather(x, false, stream_);  // A x needs every column slice
   launchSpmvPlain(dA_.view(), x, tmpM_.get(), stream_);
-  launchSpmvPlain(dAt_.view(), y, tmpN_.get(), stream_);
+  spmvAt(y, tmpN_.get());
   launchHalpernRowStats(tmpM_.get(), y, rl_.get(), rowScale_.get(), isEq_.get(), m, sc, part, stride_, nbM, stream_);
-  launchHalpernColStats(tmpN_.get(), x, cost_.get(), lower_.get(), upper_.get(), colScale_.get(),
-                        cachedSlack ? slack_.get() : nullptr, n, sc, sp_.get(), sn_.get(),
-                        part + (size_t)kHRowStats * stride_, stride_, nbN, stream_);
+  launchHalpernColStats(tmpN_.get() + co, x + co, cost_.get() + co, lower_.get() + co, upper_.get() + co,
+                        colScale_.get() + co, cachedSlack ? slack_.get() + co : nullptr, nLoc_, sc, sp_.get() + co,
+                        sn_.get() + co, part + (size_t)kHRowStats * stride_, stride_, nbN, stream_);
   launchFinalReduce(part, stride_, nbM, kHRowStats, statOut_.get(), stream_);
   launchFinalReduce(part + (size_t)kHRowStats * stride_, stride_, nbN, kHColStats, statOut_.get() + kHRowStats, stream_);
+  if (sharded_) sumOverRanks(statOut_.get(), kHRowStats + kHColStats);
   PDLP_HIP(hipMemcpyAsync(hostStats_, statOut_.get(), sizeof(double) * (kHRowStats + kHColStats), hipMemcpyDeviceToHost,
                           stream_));
   PDLP_HIP(hipStreamSynchronize(stream_));
+  if (mesh_) mesh_->checkError(stream_);
   ++nChecks_;
   const double* rs = hostStats_;
   const double* cs = hostStats_ + kHRowStats;
@@ -312,12 +393,13 @@ bool HalpernSolver::restartCriteria() const {
 
 // updatePrimalWeightAtRestart, pdhg.cc:1979-2049
 void HalpernSolver::updatePrimalWeight(const Res& r) {
-  const int32_t n = F_.n, m = F_.m;
-  const int32_t nbM = vecBlocks(std::max(m, 1)), nbN = vecBlocks(std::max(n, 1));
-  launchDiffNorm2(xn_.get(), xa_.get(), n, part_.get(), nbN, stream_);
+  const int32_t m = mLoc_;
+  const int32_t nbM = vecBlocks(std::max(m, 1)), nbN = vecBlocks(std::max(nLoc_, 1));
+  launchDiffNorm2(xn_.get() + c0_, xa_.get() + c0_, nLoc_, part_.get(), nbN, stream_);
   launchDiffNorm2(yn_.get(), ya_.get(), m, part_.get() + stride_, nbM, stream_);
   launchFinalReduce(part_.get(), stride_, nbN, 1, statOut_.get(), stream_);
   launchFinalReduce(part_.get() + stride_, stride_, nbM, 1, statOut_.get() + 1, stream_);
+  if (sharded_) sumOverRanks(statOut_.get(), 2);
   PDLP_HIP(hipMemcpyAsync(hostStats_, statOut_.get(), sizeof(double) * 2, hipMemcpyDeviceToHost, stream_));
   PDLP_HIP(hipStreamSynchronize(stream_));
   const double primalDist = std::sqrt(hostStats_[0]), dualDist = std::sqrt(hostStats_[1]);
@@ -345,7 +427,7 @@ void HalpernSolver::updatePrimalWeight(const Res& r) {
 
 // pdhg.cc:663-692: anchor and current iterate <- pdhg iterate of the last major step
 void HalpernSolver::restart() {
-  const int32_t n = F_.n, m = F_.m;
+  const int32_t n = F_.n, m = mLoc_;
   if (pid_) updatePrimalWeight(res_);
   PDLP_HIP(hipMemcpyAsync(xa_.get(), xn_.get(), sizeof(double) * n, hipMemcpyDeviceToDevice, stream_));
   PDLP_HIP(hipMemcpyAsync(ya_.get(), yn_.get(), sizeof(double) * m, hipMemcpyDeviceToDevice, stream_));
@@ -359,7 +441,7 @@ void HalpernSolver::restart() {
 // PDLPSolver::solve, pdhg.cc:494-707.  terminate = false: fixed-work loop for timing (same
 // kernels, checks and restarts; convergence is ignored).
 void HalpernSolver::doSolve(bool terminate, int64_t iterTarget) {
-  const int32_t n = F_.n, m = F_.m;
+  const int32_t n = F_.n, m = mLoc_;
   auto keepOutput = [&](const double* x, const double* y) {
     PDLP_HIP(hipMemcpyAsync(outX_.get(), x, sizeof(double) * n, hipMemcpyDeviceToDevice, stream_));
     PDLP_HIP(hipMemcpyAsync(outY_.get(), y, sizeof(double) * m, hipMemcpyDeviceToDevice, stream_));
@@ -377,7 +459,18 @@ void HalpernSolver::doSolve(bool terminate, int64_t iterTarget) {
   }
   const int64_t limit = terminate ? (int64_t)opt_.iter_limit : iterTarget;
   while (iters_ < limit) {
-    if (terminate && elapsed() > opt_.time_limit) { termStatus_ = 2; return; }
+    if (terminate) {  // every rank must take the same branch: the ranks' clocks are OR-ed
+      bool up = elapsed() > opt_.time_limit;
+      if (sharded_ && std::isfinite(opt_.time_limit)) {
+        hostStats_[0] = up ? 1.0 : 0.0;
+        PDLP_HIP(hipMemcpyAsync(statOut_.get(), hostStats_, sizeof(double), hipMemcpyHostToDevice, stream_));
+        sumOverRanks(statOut_.get(), 1);
+        PDLP_HIP(hipMemcpyAsync(hostStats_, statOut_.get(), sizeof(double), hipMemcpyDeviceToHost, stream_));
+        PDLP_HIP(hipStreamSynchronize(stream_));
+        up = hostStats_[0] > 0.0;
+      }
+      if (up) { termStatus_ = 2; return; }
+    }
     runBlock(doRestart_);
     doRestart_ = false;
     fpe_ = fixedPointError();
@@ -386,7 +479,7 @@ void HalpernSolver::doSolve(bool terminate, int64_t iterTarget) {
     Res r;
     const bool converged = check(xn_.get(), yn_.get(), slackValid_, r);
     res_ = r;
-    if (opt_.log_level > 1)
+    if (opt_.log_level > 1 && rank_ == 0)
       printf("%9lld  %+15.8e  %+15.8e  %8.2e  %10.2e  %8.2e  fpe %8.2e  w %8.2e\n", (long long)iters_, r.pObj, r.dObj,
              r.relGap, r.pFeas / (1.0 + F_.normRhs), r.dFeas / (1.0 + F_.normCost), fpe_, primalWeight_);
     if (converged && terminate) {
@@ -406,7 +499,7 @@ void HalpernSolver::run(pdlp_result_t* R) {
   solveBeg_ = std::chrono::steady_clock::now();
   doSolve(true, 0);
   solveSeconds_ = elapsed();
-  if (opt_.log_level > 0)
+  if (opt_.log_level > 0 && rank_ == 0)
     printf("\nHiPDLP: %s after %lld iterations (%d restarts): primal obj %+.10e, dual obj %+.10e, rel gap %.2e\n",
            termStatus_ == 0 ? "converged" : termStatus_ == 2 ? "time limit" : "iteration limit", (long long)iters_,
            nRestarts_, res_.pObj, res_.dObj, res_.relGap);
@@ -445,13 +538,23 @@ void HalpernSolver::postsolve(pdlp_result_t* R) {
   const int32_t n = F_.n, m = F_.m, n0 = F_.n0;
   std::vector<double> x(n, 0.0), y(m, 0.0), sp(n), sn(n);
   // only a converged check writes the output vectors (pdhg.cc:866-877): otherwise they are the zero start
-  if (haveOutput_) {
-    outX_.download(x.data(), n, stream_);
-    outY_.download(y.data(), m, stream_);
+  if (!sharded_) {
+    if (haveOutput_) {
+      outX_.download(x.data(), n, stream_);
+      outY_.download(y.data(), m, stream_);
+    }
+    sp_.download(sp.data(), n, stream_);
+    sn_.download(sn.data(), n, stream_);
+    PDLP_HIP(hipStreamSynchronize(stream_));
+  } else {  // x was all-gathered by the converged check; y is row-local, the slacks column-sliced
+    if (haveOutput_) {
+      outX_.download(x.data(), n, stream_);
+      PDLP_HIP(hipStreamSynchronize(stream_));
+      gatherToHost(outY_.get(), r0_, r1_, true, y);
+    }
+    gatherToHost(sp_.get() + c0_, c0_, c1_, false, sp);
+    gatherToHost(sn_.get() + c0_, c0_, c1_, false, sn);
   }
-  sp_.download(sp.data(), n, stream_);
-  sn_.download(sn.data(), n, stream_);
-  PDLP_HIP(hipStreamSynchronize(stream_));
   if (F_.scaled) {
     for (int32_t j = 0; j < n; ++j) x[j] /= F_.colScale[j];
     for (int32_t i = 0; i < m; ++i) y[i] /= F_.rowScale[i];
@@ -488,7 +591,7 @@ void HalpernSolver::postsolve(pdlp_result_t* R) {
 }
 
 std::pair<double*, int64_t> HalpernSolver::lookup(const std::string& name) {
-  const int64_t n = F_.n, m = F_.m;
+  const int64_t n = F_.n, m = mLoc_;  // row vectors are local when sharded
   if (name == "x") return {xc_.get(), n};
   if (name == "y") return {yc_.get(), m};
   if (name == "x_next") return {xn_.get(), n};
@@ -546,7 +649,7 @@ void HalpernSolver::stage(const std::string& name, double* out, int32_t cap) {
     pushState();
     for (int i = 1; i <= k; ++i) enqueueStep(i == 1 || i == k, i);
   } else if (name == "exchange") {
-    put(0, 0.0);
+    put(0, sharded_ ? 2.0 : 0.0);
   } else if (name == "profile_on" || name == "profile_off") {
     // (no in-loop event timing on this path: use time_kernel)
   } else {
@@ -558,13 +661,7 @@ void HalpernSolver::stage(const std::string& name, double* out, int32_t cap) {
 double HalpernSolver::timeKernel(const std::string& name, int32_t reps) {
   if (reps < 1) reps = 1;
   pushState();
-  HalpernVecs h{};
-  h.xc = xc_.get(); h.yc = yc_.get(); h.xn = xn_.get(); h.yn = yn_.get(); h.rx = rx_.get(); h.ry = ry_.get();
-  h.xa = xa_.get(); h.ya = ya_.get(); h.slack = slack_.get();
-  h.cost = cost_.get(); h.lower = lower_.get(); h.upper = upper_.get(); h.rowLower = rl_.get(); h.rowUpper = ru_.get();
-  h.hs = dState_.get();
-  h.kOff = 2;
-  h.major = 0;
+  const HalpernVecs h = stepVecs(false, 2);
   auto once = [&]() {
     if (name == "spmv_aty" || name == "halpern_primal") launchHalpernPrimal(dAt_.view(), h, stream_);
     else if (name == "spmv_ax" || name == "halpern_dual") launchHalpernDual(dA_.view(), h, stream_);

@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 
+#include "pdlp_mesh.hpp"
 #include "pdlp_solver.hpp"
 
 namespace pdlp {
@@ -33,7 +34,9 @@ void launchDivScalar(double* v, double denom, int32_t len, hipStream_t s);  // v
 
 class HalpernSolver : public SolverBase {
  public:
-  HalpernSolver(const pdlp_problem_t& P, const pdlp_params_t& opt);
+  // world > 1: row-block shards over the direct xGMI mesh exchange (pdlp_mesh.hpp); id128 as for Solver
+  HalpernSolver(const pdlp_problem_t& P, const pdlp_params_t& opt, int32_t rank = 0, int32_t world = 1,
+                const void* id128 = nullptr);
   ~HalpernSolver() override;
   void run(pdlp_result_t* R) override;
   void iterate(int32_t nIters, pdlp_iter_stats_t* st) override;
@@ -45,7 +48,11 @@ class HalpernSolver : public SolverBase {
   double timeKernel(const std::string& name, int32_t reps) override;
 
  private:
-  void construct(const pdlp_problem_t& P);
+  void construct(const pdlp_problem_t& P, const void* id128);
+  HalpernVecs stepVecs(bool major, int32_t kOff) const;
+  void sumOverRanks(double* devBuf, int32_t count);
+  void gatherToHost(const double* devLocal, int32_t lo, int32_t hi, bool byRows, std::vector<double>& full);
+  void spmvAt(const double* yLocal, double* atySliceInFull);  // A'y: full vector, or own column slice when sharded
   void release() noexcept;
   struct Res { double pObj = 0, dObj = 0, gap = 0, relGap = 0, pFeas = 0, dFeas = 0; };
   double powerMethod();
@@ -54,7 +61,7 @@ class HalpernSolver : public SolverBase {
   void enqueueStep(bool major, int32_t kOff);
   void runBlock(bool fpeAfterFirst);           // steps 1..40 of one block
   double fixedPointError();
-  bool check(const double* x, const double* y, bool cachedSlack, Res& r);  // A x, A'y + checkConvergence
+  bool check(double* x, const double* y, bool cachedSlack, Res& r);  // A x, A'y + checkConvergence
   void updatePrimalWeight(const Res& r);
   void restart();
   bool restartCriteria() const;
@@ -70,6 +77,11 @@ class HalpernSolver : public SolverBase {
   // the caller's LP (postprocess computes row activities and the objective from it, pdhg.cc:409-468)
   std::vector<int32_t> origBeg_, origIdx_;
   std::vector<double> origVal_, origCost_;
+  // sharding (rows [r0_, r1_) and column slice [c0_, c1_) are owned; everything when world == 1)
+  int32_t rank_ = 0, world_ = 1, r0_ = 0, r1_ = 0, mLoc_ = 0, c0_ = 0, c1_ = 0, nLoc_ = 0;
+  bool sharded_ = false;
+  Mesh* mesh_ = nullptr;
+  DeviceArray<double> commBuf_;  // partial A_g' y (n)
   hipStream_t stream_ = nullptr;
   DeviceMatrix dA_, dAt_;
   DeviceArray<double> xc_, yc_, xn_, yn_, rx_, ry_, xa_, ya_, slack_, sp_, sn_, outX_, outY_;

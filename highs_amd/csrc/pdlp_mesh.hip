@@ -145,7 +145,7 @@ __device__ __forceinline__ void peerRecvX(const MeshArgs& ma, PeerPtrs& P) {
 // st != nullptr: hot loop (epoch from seq); else a generic collective with the host-counted epoch eGen.
 __global__ __launch_bounds__(kWave) void k_mesh_wait(DevState* st, const MeshArgs ma, int kind, long long eGen) {
   if ((st && st->halted) || dead(ma)) return;
-  const long long e = st ? ma.ms->seq + 1 : eGen;
+  const long long e = (st || eGen < 0) ? ma.ms->seq + 1 : eGen;  // eGen < 0: hot loop without a DevState (HiPDLP)
   if (!waitPeers(ma, kind, e)) fail(ma, st);
 }
 
@@ -229,7 +229,8 @@ __global__ __launch_bounds__(kVecThreads) void k_mesh_push_partial(const double*
                                                                    long long eGen) {
   const MeshView* __restrict__ mv = ma.v; (void)mv;
   if ((st && st->halted) || dead(ma)) return;
-  const long long e = st ? ma.ms->seq + 1 : eGen;
+  const bool hot = st || eGen < 0;
+  const long long e = hot ? ma.ms->seq + 1 : eGen;
   const int G = ma.G, g = ma.g;
   const int stride = gridDim.x * blockDim.x, first = blockIdx.x * blockDim.x + threadIdx.x;
   for (int h = 0; h < G; ++h) {
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(kVecThreads) void k_mesh_push_partial(const double*
         if (j0 + u * stride < len) sysStore(dst + j0 + u * stride, t[u]);
     }
   }
-  lastBlockSignal(ma, st ? kFlagP : kFlagGen, e, 1);
+  lastBlockSignal(ma, hot ? kFlagP : kFlagGen, e, 1);
 }
 
 // The G contributions to the own slice, in rank order: src[h] = recvP[h] (or the own partial).
@@ -356,6 +357,61 @@ __global__ __launch_bounds__(kVecThreads) void k_mesh_decide(DevState* st, const
   }
   decideUpdate(st, dX2, dY2, inter);
   ma.ms->seq = e;
+}
+
+// ---- HiPDLP step, sharded (pdlp_halpern.cpp): P exchange -> primal side on the column slice -> X exchange
+// of the REFLECTED x -> dual side on the local rows.  No scalar phase: step sizes only change at restarts.
+// h holds column-sliced pointers (offset by c0) except rx, which is the full-length reflected vector.
+__global__ __launch_bounds__(kVecThreads) void k_mesh_h_reduce_primal(const HalpernVecs h, int nLoc,
+                                                                      const double* __restrict__ partial,
+                                                                      const MeshArgs ma) {
+  const MeshView* __restrict__ mv = ma.v; (void)mv;
+  if (dead(ma)) return;
+  const long long e = ma.ms->seq + 1;
+  const HalpernState hs = *h.hs;
+  const int k = hs.hIter + h.kOff;
+  const double w = (double)k / ((double)k + 1.0);
+  const int c0 = mv->colOff[ma.g];
+  PeerPtrs src, peer;
+  reduceSources(ma, partial + c0, src);
+  peerRecvX(ma, peer);
+  const int stride = gridDim.x * blockDim.x;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nLoc; j += stride) {
+    const double s = orderedSum(src, j);  // (A'y)_j, contributions in rank order
+    const Pre p{h.xc[j], h.cost[j], h.xa[j], h.lower[j], h.upper[j]};
+    halpernPrimal(h, j, s, p, hs.tau, hs.rho, w);  // writes xc, rx (slice positions), xn/slack on major steps
+    const double rx = h.rx[j];
+#pragma unroll
+    for (int q = 0; q < kMeshMaxRanks; ++q)
+      if (peer.p[q]) sysStore(peer.p[q] + c0 + j, rx);
+  }
+  lastBlockSignal(ma, kFlagX, e, 0);
+}
+// reflected x of the other column slices: recvX -> rx
+__global__ __launch_bounds__(kVecThreads) void k_mesh_h_copy_x(double* __restrict__ rx, int n, const MeshArgs ma) {
+  const MeshView* __restrict__ mv = ma.v; (void)mv;
+  if (dead(ma)) return;
+  const int c0 = mv->colOff[ma.g], c1 = mv->colOff[ma.g + 1];
+  const double* __restrict__ src = recvX(ma, ma.g);
+  const int stride = gridDim.x * blockDim.x;
+  const int other = n - (c1 - c0), lastQ = other - 1;
+  for (int q0 = blockIdx.x * blockDim.x + threadIdx.x; q0 < other; q0 += 4 * stride) {
+    double t[4];
+    int jj[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q = min(q0 + u * stride, lastQ);
+      jj[u] = q < c0 ? q : q + (c1 - c0);
+      t[u] = sysLoad(src + jj[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (q0 + u * stride <= lastQ) rx[jj[u]] = t[u];
+  }
+}
+__global__ void k_mesh_bump(const MeshArgs ma) {
+  if (dead(ma)) return;
+  ma.ms->seq = ma.ms->seq + 1;
 }
 
 // ---- generic collectives (host-counted epochs, off the hot path) ---------------------------
@@ -489,6 +545,22 @@ void launchMeshReduceInteract(const IterVecs& vc, const DevState* st, const Mesh
 void launchMeshDecide(DevState* st, const MeshArgs& dmv, const double* partDY, int32_t nDY, const double* partDX,
                       const double* partInter, int32_t nDX, hipStream_t s) {
   hipLaunchKernelGGL(k_mesh_decide, dim3(1), dim3(kVecThreads), 0, s, st, dmv, partDY, nDY, partDX, partInter, nDX);
+}
+
+void launchMeshHalpernStep(const MatView& A, const MatView& At, const HalpernVecs& hFull, const HalpernVecs& hCol,
+                           int32_t n, int32_t nLoc, double* partial, const MeshArgs& ma, hipStream_t s) {
+  // 1. partial A_g' y_current, pushed to the slice owners (flag P)
+  launchSpmvPlain(At, hFull.yc, partial, s);
+  hipLaunchKernelGGL(k_mesh_push_partial, dim3(meshBlocks(n)), dim3(kVecThreads), 0, s, partial,
+                     (const DevState*)nullptr, ma, -1LL);
+  // 2. rank-ordered reduce + primal projection / reflection / blend on the slice; reflected x pushed (flag X)
+  hipLaunchKernelGGL(k_mesh_wait, dim3(1), dim3(kWave), 0, s, (DevState*)nullptr, ma, (int)kFlagP, -1LL);
+  hipLaunchKernelGGL(k_mesh_h_reduce_primal, dim3(meshBlocks(nLoc)), dim3(kVecThreads), 0, s, hCol, nLoc, partial, ma);
+  // 3. the other slices of the reflected x, then the dual side on the local rows
+  hipLaunchKernelGGL(k_mesh_wait, dim3(1), dim3(kWave), 0, s, (DevState*)nullptr, ma, (int)kFlagX, -1LL);
+  hipLaunchKernelGGL(k_mesh_h_copy_x, dim3(meshConsumerBlocks(n)), dim3(kVecThreads), 0, s, hFull.rx, n, ma);
+  launchHalpernDual(A, hFull, s);
+  hipLaunchKernelGGL(k_mesh_bump, dim3(1), dim3(1), 0, s, ma);
 }
 
 // ---- host side ------------------------------------------------------------------------------

@@ -129,4 +129,9 @@ void launchMeshReduceInteract(const IterVecs& vc, const DevState* st, const Mesh
 void launchMeshDecide(DevState* st, const MeshArgs& dmv, const double* partDY, int32_t nDY, const double* partDX,
                       const double* partInter, int32_t nDX, hipStream_t s);
 
+// One sharded HiPDLP step (pdhg.cc:961-1018 over row-block shards): hFull = full-length / local-row
+// pointers, hCol = the same with the column vectors offset to the own slice (rx stays full-length).
+void launchMeshHalpernStep(const MatView& A, const MatView& At, const HalpernVecs& hFull, const HalpernVecs& hCol,
+                           int32_t n, int32_t nLoc, double* partial, const MeshArgs& ma, hipStream_t s);
+
 }  // namespace pdlp

@@ -48,6 +48,16 @@ def main():
         np.savez(out, msg=msg, seconds=time.time() - t0)
         S.close()
         return
+    if kind == "hsolve":  # the HiPDLP path, sharded
+        S = solver.DeviceSolver(rank=rank, world=world, unique_id=uid, solver="hipdlp", **kw)
+        ex = S.stage("exchange")[0]
+        R = S.run(nc, nr)
+        np.savez(out, exchange=ex, col_value=R.col_value, col_dual=R.col_dual, row_value=R.row_value,
+                 row_dual=R.row_dual, num_iter=R.num_iter, num_restarts=R.num_restarts, term=R.term_code,
+                 primal_obj=R.primal_obj, dual_obj=R.dual_obj, primal_feas=R.primal_feas, dual_feas=R.dual_feas,
+                 rel_gap=R.rel_gap, norm_rhs=R.norm_rhs, norm_cost=R.norm_cost)
+        S.close()
+        return
     if kind == "solve":
         foff = int(rest[0]) if rest else 0
         S = solver.DeviceSolver(rank=rank, world=world, unique_id=uid, time_limit=1000.0, pdlp_features_off=foff, **kw)

@@ -13,14 +13,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_bench_two_ranks_one_device(world):
+@pytest.mark.parametrize("world,solver_name", [(2, "pdlp"), (4, "pdlp"), (2, "hipdlp")])
+def test_bench_two_ranks_one_device(world, solver_name):
     env = dict(os.environ, PDLP_BENCH_SINGLE_DEVICE="1", PDLP_BENCH_DIST_BACKEND="gloo",
                HSA_ENABLE_IPC_MODE_LEGACY="0", PDLP_MI355X_MESH_TIMEOUT_MS="30000")
     port = 29700 + os.getpid() % 200 + world
     cmd = ["timeout", "400", sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world),
-           "--config", "a", "--steps", "400", "--warmup", "80"]
+           "--config", "a", "--steps", "400", "--warmup", "80", "--solver", solver_name]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
