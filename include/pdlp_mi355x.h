@@ -228,7 +228,8 @@ int pdlp_mi355x_time_kernel(pdlp_mi355x_solver_t* s, const char* kernel,
  * exchange writes directly into the peers' HIP-IPC-mapped device memory over
  * xGMI; the id names their rendezvous and is also a valid
  * ncclUniqueId for the RCCL all-reduce fallback.  run/iterate/stage("residuals")
- * are collective afterwards. */
+ * are collective afterwards.  Both algorithms shard (algorithm = 1 over the direct
+ * exchange only). */
 int pdlp_mi355x_comm_unique_id(void* id128);
 int pdlp_mi355x_create_sharded(const pdlp_problem_t* P, const pdlp_params_t* opt,
                                int32_t rank, int32_t world, const void* id128,
