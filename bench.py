@@ -175,9 +175,9 @@ def main():
         copy_gbs = 2 * 512 * 2**20 / (S.time_kernel("copy", 10) * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if args.solver == "hipdlp":  # same SpMV kernels, different epilogues: no PMC pass was made for them
+    if args.solver == "hipdlp":  # same SpMV kernels with the Halpern epilogues
         dom_name = {"spmv_ax_dual": "spmv_ax_halpern_dual", "spmv_aty_interact": "spmv_aty_halpern_primal"}[dom_name]
-    elif os.path.exists(tpath):
+    if os.path.exists(tpath):
         try:
             traffic = json.load(open(tpath)).get(args.config, {}).get(dom_name)
         except Exception:

@@ -15,10 +15,11 @@ ap.add_argument("--n", type=int, default=1_000_000)
 ap.add_argument("--nnz", type=int, default=8_000_000)
 ap.add_argument("--reps", type=int, default=30)
 ap.add_argument("--iters", type=int, default=0, help="also run this many PDHG iterations first")
+ap.add_argument("--solver", choices=["pdlp", "hipdlp"], default="pdlp")
 ap.add_argument("--kernels", default="primal_step,spmv_ax,spmv_aty,decide,trial,spmv_ax_plain,spmv_aty_plain")
 args = ap.parse_args()
 sp_ = solver.SyntheticProblem(args.m, args.n, args.nnz, 1)
-S = solver.DeviceSolver(problem_struct=sp_.struct, params=abi.default_params(kkt_tolerance=1e-4))
+S = solver.DeviceSolver(problem_struct=sp_.struct, params=abi.default_params(kkt_tolerance=1e-4, solver=args.solver))
 out = {}
 if args.iters:
     st = S.iterate(args.iters)
