@@ -42,6 +42,15 @@ def algorithmic_bytes(n, m, nnz):
     return b_iter, b_spmv_ax, b_spmv_aty
 
 
+def algorithmic_bytes_hipdlp(n, m, nnz):
+    """One Halpern step = two fused kernels.  A'y side: matrix 12 B/nnz + column pointers + read y (m)
+    + read x, c, anchor, l, u (5n) + write x, reflected x (2n).  A x side: matrix + row pointers + read reflected
+    x (n) + read y, anchor, row bounds (4m) + write y (m).  (Major steps, 2 in 40, also write x_next/slack/y_next.)"""
+    b_aty = 12 * nnz + 4 * (n + 1) + 8 * m + 8 * 7 * n
+    b_ax = 12 * nnz + 4 * (m + 1) + 8 * n + 8 * 5 * m
+    return b_ax + b_aty, b_ax, b_aty
+
+
 def cpu_baseline(sp_struct, cfg, budget_iters, solver_name="pdlp"):
     """Reference CPU pdlp (single thread) on a bounded sample of the same LP: `budget_iters`
     iterations, iterations/s over the PDHG loop only (setup excluded, as for the GPU number)."""
@@ -152,7 +161,7 @@ def main():
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         rank_consistent = bool(lo.item() == hi.item())
-    b_iter, b_ax, b_aty = algorithmic_bytes(n, m, nnz)
+    b_iter, b_ax, b_aty = (algorithmic_bytes if args.solver == "pdlp" else algorithmic_bytes_hipdlp)(n, m, nnz)
     ms_step = elapsed * 1e3 / st.iters
     # dominant kernel, timed live with HIP events on the solver's own stream, IN the loop (same
     # kernel sequence and cache state as the timed region; what rocprofv3 --kernel-trace reports)
