@@ -147,6 +147,8 @@ void HalpernSolver::construct(const pdlp_problem_t& P, const void* id128) {
 
 void HalpernSolver::release() noexcept {
   if (graphExec_) (void)hipGraphExecDestroy(graphExec_);
+  for (hipEvent_t e : profEvents_) (void)hipEventDestroy(e);
+  profEvents_.clear();
   if (hostState_) (void)hipHostFree(hostState_);
   if (hostStats_) (void)hipHostFree(hostStats_);
   delete mesh_;
@@ -285,6 +287,21 @@ HalpernVecs HalpernSolver::stepVecs(bool major, int32_t kOff) const {
 // partial-A'y / exchange / slice-primal / exchange / local-dual sequence of pdlp_mesh.hpp (sharded)
 void HalpernSolver::enqueueStep(bool major, int32_t kOff) {
   const HalpernVecs h = stepVecs(major, kOff);
+  if (!sharded_ && profile_) {  // eager launches bracketed by events (4th event: cost of an empty event pair)
+    while ((int32_t)profEvents_.size() < 4 * (profQueued_ + 1)) {
+      hipEvent_t e;
+      PDLP_HIP(hipEventCreate(&e));
+      profEvents_.push_back(e);
+    }
+    hipEvent_t* ev = &profEvents_[4 * profQueued_++];
+    PDLP_HIP(hipEventRecord(ev[0], stream_));
+    launchHalpernPrimal(dAt_.view(), h, stream_);
+    PDLP_HIP(hipEventRecord(ev[1], stream_));
+    launchHalpernDual(dA_.view(), h, stream_);
+    PDLP_HIP(hipEventRecord(ev[2], stream_));
+    PDLP_HIP(hipEventRecord(ev[3], stream_));
+    return;
+  }
   if (!sharded_) {
     launchHalpernPrimal(dAt_.view(), h, stream_);
     launchHalpernDual(dA_.view(), h, stream_);
@@ -294,6 +311,20 @@ void HalpernSolver::enqueueStep(bool major, int32_t kOff) {
   hc.xc += c0_; hc.xn += c0_; hc.rx += c0_; hc.xa += c0_; hc.slack += c0_;
   hc.cost += c0_; hc.lower += c0_; hc.upper += c0_;
   launchMeshHalpernStep(dA_.view(), dAt_.view(), h, hc, F_.n, nLoc_, commBuf_.get(), mesh_->args(), stream_);
+}
+
+void HalpernSolver::profCollect() {
+  PDLP_HIP(hipStreamSynchronize(stream_));
+  for (int32_t t = 0; t < profQueued_; ++t) {
+    float a = 0.f, b = 0.f, z = 0.f;
+    PDLP_HIP(hipEventElapsedTime(&a, profEvents_[4 * t], profEvents_[4 * t + 1]));
+    PDLP_HIP(hipEventElapsedTime(&b, profEvents_[4 * t + 1], profEvents_[4 * t + 2]));
+    PDLP_HIP(hipEventElapsedTime(&z, profEvents_[4 * t + 2], profEvents_[4 * t + 3]));
+    profAtyMs_ += a - z;
+    profAxMs_ += b - z;
+    ++profLaunches_;
+  }
+  profQueued_ = 0;
 }
 
 // One block of the main loop (pdhg.cc:578-641): major step 1, [fixed-point error if a restart
@@ -306,7 +337,11 @@ void HalpernSolver::runBlock(bool fpeAfterFirst) {
     fpe_ = fixedPointError();
     initialFpe_ = fpe_;
   }
-  if (useGraph_) {
+  if (profile_ && !sharded_) {
+    for (int i = 2; i <= kCheckInterval - 1; ++i) enqueueStep(false, i);
+    enqueueStep(true, kCheckInterval);
+    profCollect();
+  } else if (useGraph_) {
     if (!graphExec_) {
       hipGraph_t graph = nullptr;
       PDLP_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
@@ -509,6 +544,8 @@ void HalpernSolver::run(pdlp_result_t* R) {
 void HalpernSolver::iterate(int32_t nIters, pdlp_iter_stats_t* st) {
   const int64_t it0 = iters_;
   const int32_t ck0 = nChecks_, rs0 = nRestarts_;
+  profAxMs_ = profAtyMs_ = 0.0;
+  profLaunches_ = 0;
   solveBeg_ = std::chrono::steady_clock::now();
   hipEvent_t e0, e1;
   PDLP_HIP(hipEventCreate(&e0));
@@ -530,6 +567,11 @@ void HalpernSolver::iterate(int32_t nIters, pdlp_iter_stats_t* st) {
     st->restarts = nRestarts_ - rs0;
     st->gpu_ms = ms;
     st->wall_ms = elapsed() * 1e3;
+    if (profLaunches_ > 0) {  // in-loop averages per launch (profile mode)
+      st->spmv_ax_ms = profAxMs_ / (double)profLaunches_;
+      st->spmv_aty_ms = profAtyMs_ / (double)profLaunches_;
+      st->reserved[0] = (double)profLaunches_;
+    }
   }
 }
 
@@ -651,7 +693,7 @@ void HalpernSolver::stage(const std::string& name, double* out, int32_t cap) {
   } else if (name == "exchange") {
     put(0, sharded_ ? 2.0 : 0.0);
   } else if (name == "profile_on" || name == "profile_off") {
-    // (no in-loop event timing on this path: use time_kernel)
+    profile_ = name == "profile_on";
   } else {
     throw std::runtime_error("unknown stage: " + name);
   }

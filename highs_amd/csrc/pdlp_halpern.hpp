@@ -104,6 +104,13 @@ class HalpernSolver : public SolverBase {
   Res res_;
   hipGraphExec_t graphExec_ = nullptr;
   bool useGraph_ = true;
+  // in-loop kernel timing (stage "profile_on"): HIP events around the two launches of every step
+  bool profile_ = false;
+  std::vector<hipEvent_t> profEvents_;
+  int32_t profQueued_ = 0;
+  double profAxMs_ = 0, profAtyMs_ = 0;
+  int64_t profLaunches_ = 0;
+  void profCollect();
   std::chrono::steady_clock::time_point solveBeg_;
   double setupSeconds_ = 0, solveSeconds_ = 0;
 };
