@@ -125,9 +125,10 @@ class PdlpPrepared(C.Structure):
 
 class PdlpSlabLayout(C.Structure):
     _fields_ = [
-        ("rows_per_block", C.c_int32), ("n_blocks", C.c_int32), ("n_slabs", C.c_int32), ("n_long", C.c_int32),
+        ("rows_per_block", C.c_int32), ("rows_per_wave", C.c_int32), ("n_blocks", C.c_int32), ("minor_bits", C.c_int32),
+        ("slab_width_log2", C.c_int32), ("n_long", C.c_int32),
         ("nnz_short", C.c_int64),
-        ("seg_ptr", c_i32p), ("ent", C.POINTER(C.c_uint32)), ("val", c_f64p),
+        ("wave_ptr", c_i32p), ("ent", C.POINTER(C.c_uint32)), ("val", c_f64p),
         ("long_mask", C.POINTER(C.c_uint32)), ("long_map", c_i32p),
     ]
 

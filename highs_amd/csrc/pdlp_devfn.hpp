@@ -13,6 +13,17 @@ namespace {
 
 constexpr int kWave = 64;
 
+// Streamed vector traffic (iterates, costs, bounds, sums: everything that is touched once per kernel)
+// is loaded and stored NON-TEMPORALLY: it then does not displace the two matrix copies (192 MB at the
+// bench size) from the 256 MB Infinity Cache, and the entry/value streams of both SpMVs are served from
+// there instead of HBM — measured -15 us per SpMV inside the iteration.  The two GATHERED vectors
+// (x+ for A x+, y+ for A' y+; HiPDLP: y_current, reflected x) are written with ordinary stores: every
+// XCD reads them right after.
+template <typename T>
+__device__ __forceinline__ T ldStream(const T* p) { return __builtin_nontemporal_load(p); }
+template <typename T>
+__device__ __forceinline__ void stStream(T* p, T v) { __builtin_nontemporal_store(v, p); }
+
 __device__ __forceinline__ double waveSum(double v) {
 #pragma unroll
   for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
@@ -112,13 +123,13 @@ __device__ __forceinline__ __attribute__((unused)) void halpernPrimal(const Halp
   const double t = (u < temp) ? u : temp;  // std::min(temp, u)
   const double proj = (l < t) ? t : l;     // std::max(l, .)   (linalg::projectBox)
   if (h.major) {
-    h.xn[j] = proj;
-    h.slack[j] = (proj - temp) / tau;
+    stStream(h.xn + j, proj);
+    stStream(h.slack + j, (proj - temp) / tau);
   }
   const double rx = 2.0 * proj - xc;
-  h.rx[j] = rx;
+  h.rx[j] = rx;  // gathered by the A x kernel: ordinary store
   const double blended = rho * rx + (1.0 - rho) * xc;
-  h.xc[j] = w * blended + (1.0 - w) * xa;
+  stStream(h.xc + j, w * blended + (1.0 - w) * xa);
 }
 // HiPDLP step, row side (pdhg.cc:995-1006 and :1012-1015): s = (A reflected_x)_i.
 __device__ __forceinline__ __attribute__((unused)) void halpernDual(const HalpernVecs& h, int i, double s, const Pre& p, double sigma,
@@ -131,11 +142,11 @@ __device__ __forceinline__ __attribute__((unused)) void halpernDual(const Halper
   const double pd = (temp - proj) * sigma;
   const double ry = 2.0 * pd - yc;
   if (h.major) {
-    h.yn[i] = pd;
-    h.ry[i] = ry;
+    stStream(h.yn + i, pd);
+    stStream(h.ry + i, ry);
   }
   const double blended = rho * ry + (1.0 - rho) * yc;
-  h.yc[i] = w * blended + (1.0 - w) * ya;
+  h.yc[i] = w * blended + (1.0 - w) * ya;  // gathered by the A' y kernel: ordinary store
 }
 
 

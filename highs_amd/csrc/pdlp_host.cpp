@@ -259,22 +259,44 @@ StreamPlan planStream(const std::vector<int32_t>& beg, int32_t nMajor, int32_t c
   return plan;
 }
 
-void buildSlabLayout(const Compressed& csr, int32_t nMajor, int32_t nMinor, int32_t longLimit, SlabLayout& out) {
+namespace {
+int32_t bitsForRows(int32_t rows) {
+  int rb = 0;
+  while ((1 << rb) < rows) ++rb;
+  return rb;
+}
+}  // namespace
+
+int32_t slabRowsPerWave(int32_t nMajor, int32_t nMinor) {
+  const int64_t waves = (int64_t)kSlabTargetBlocks * kSlabWavesPerBlock;
+  int64_t Rw = ((int64_t)nMajor + waves - 1) / waves;
+  Rw = (Rw + 1) / 2 * 2;  // even: rowsPerBlock is then a multiple of 32 (longMask words)
+  if (Rw < 16) Rw = 16;
+  if (Rw > 512) Rw = 512;
+  // (localMajor << minorBits | minor) must fit 32 bits: shrink the waves until it does
+  while (Rw > 16 && ((int64_t)1 << (32 - bitsForRows((int32_t)Rw))) < (int64_t)nMinor) Rw = (Rw / 2 + 1) / 2 * 2;
+  if (((int64_t)1 << (32 - bitsForRows((int32_t)Rw))) < (int64_t)nMinor) return 0;
+  return (int32_t)Rw;
+}
+
+void buildSlabLayout(const Compressed& csr, int32_t nMajor, int32_t nMinor, int32_t longLimit, int32_t slabWidthLog2,
+                     SlabLayout& out) {
   out = SlabLayout();
-  const int64_t nnz = csr.beg[nMajor];
-  // majors per block: aim at ~4096 nonzeros per block, power of two in [256, 4096]
-  const double avg = nMajor > 0 ? (double)nnz / nMajor : 1.0;
-  int32_t R = 256;
-  while (R < 4096 && (double)R * avg < 3000.0) R *= 2;
+  const int32_t Rw = slabRowsPerWave(nMajor, nMinor);
+  if (Rw == 0) throw std::runtime_error("slab layout: minor index does not fit the entry packing");
+  const int32_t R = Rw * kSlabWavesPerBlock;
+  out.rowsPerWave = Rw;
   out.rowsPerBlock = R;
   out.nBlocks = (nMajor + R - 1) / R;
-  out.nSlabs = std::max(1, (int32_t)(((int64_t)nMinor + (1 << kSlabWidthLog2) - 1) >> kSlabWidthLog2));
-  const int32_t S = out.nSlabs;
-  out.segPtr.assign((size_t)out.nBlocks * (S + 1), 0);
+  out.minorBits = 32 - bitsForRows(Rw);
+  out.slabWidthLog2 = slabWidthLog2;
+  const int32_t nWaves = out.nBlocks * kSlabWavesPerBlock;
+  const int32_t S = std::max(1, (int32_t)(((int64_t)nMinor + ((int64_t)1 << slabWidthLog2) - 1) >> slabWidthLog2));
+  if ((int64_t)nWaves * S >= (int64_t)0x7fffffff) throw std::runtime_error("slab layout: too many segments");
   out.longMask.assign((size_t)out.nBlocks * (R / 32), 0u);
   out.longCsr.beg.push_back(0);
-  // pass 1: per (block, slab) counts; long majors go to the side CSR
-  std::vector<int32_t> count((size_t)out.nBlocks * S, 0);
+  // pass 1: per (wave, slab) counts; long majors go to the side CSR
+  std::vector<int32_t> count((size_t)nWaves * S, 0);
   for (int32_t r = 0; r < nMajor; ++r) {
     const int32_t b = r / R, len = csr.beg[r + 1] - csr.beg[r];
     if (len > longLimit) {
@@ -285,42 +307,34 @@ void buildSlabLayout(const Compressed& csr, int32_t nMajor, int32_t nMinor, int3
       out.longCsr.beg.push_back((int32_t)out.longCsr.idx.size());
       continue;
     }
-    for (int32_t p = csr.beg[r]; p < csr.beg[r + 1]; ++p) ++count[(size_t)b * S + (csr.idx[p] >> kSlabWidthLog2)];
+    const size_t w = (size_t)(r / Rw);
+    for (int32_t p = csr.beg[r]; p < csr.beg[r + 1]; ++p) ++count[w * S + (csr.idx[p] >> slabWidthLog2)];
   }
+  // exclusive scan in (wave, slab) order; wavePtr = the wave boundaries of it
+  out.wavePtr.assign((size_t)nWaves + 1, 0);
+  std::vector<int32_t> pos((size_t)nWaves * S);
   int64_t acc = 0;
-  for (int32_t b = 0; b < out.nBlocks; ++b) {
+  for (int32_t w = 0; w < nWaves; ++w) {
+    out.wavePtr[w] = (int32_t)acc;
     for (int32_t k = 0; k < S; ++k) {
-      out.segPtr[(size_t)b * (S + 1) + k] = (int32_t)acc;
-      acc += count[(size_t)b * S + k];
+      pos[(size_t)w * S + k] = (int32_t)acc;
+      acc += count[(size_t)w * S + k];
     }
-    out.segPtr[(size_t)b * (S + 1) + S] = (int32_t)acc;
   }
+  out.wavePtr[nWaves] = (int32_t)acc;
   out.ent.resize((size_t)acc);
   out.val.resize((size_t)acc);
-  if (S > 65535) throw std::runtime_error("slab layout: too many slabs");
-  out.winPtr.assign(1, 0);
-  for (int32_t b = 0; b < out.nBlocks; ++b) {
-    for (int32_t k = 0; k < S; ++k) {
-      const int32_t sb = out.segPtr[(size_t)b * (S + 1) + k], se = out.segPtr[(size_t)b * (S + 1) + k + 1];
-      for (int32_t q = sb; q < se; q += 256) {
-        out.winBeg.push_back(q);
-        out.winInfo.push_back(((uint32_t)k << 16) | (uint32_t)std::min(256, se - q));
-      }
-    }
-    out.winPtr.push_back((int32_t)out.winBeg.size());
-  }
-  // pass 2: majors in order, minors ascending within a major => each (block, slab)
-  // segment comes out sorted by (local major, minor)
-  std::vector<int32_t> pos((size_t)out.nBlocks * S);
-  for (int32_t b = 0; b < out.nBlocks; ++b)
-    for (int32_t k = 0; k < S; ++k) pos[(size_t)b * S + k] = out.segPtr[(size_t)b * (S + 1) + k];
+  // pass 2: majors in order, minors ascending within a major => each (wave, slab) segment comes out
+  // sorted by (local major, minor)
   for (int32_t r = 0; r < nMajor; ++r) {
-    const int32_t b = r / R, lr = r % R, len = csr.beg[r + 1] - csr.beg[r];
+    const int32_t len = csr.beg[r + 1] - csr.beg[r];
     if (len > longLimit) continue;
+    const size_t w = (size_t)(r / Rw);
+    const uint32_t lr = (uint32_t)(r % Rw);
     for (int32_t p = csr.beg[r]; p < csr.beg[r + 1]; ++p) {
-      const int32_t c = csr.idx[p], k = c >> kSlabWidthLog2;
-      const int32_t q = pos[(size_t)b * S + k]++;
-      out.ent[q] = ((uint32_t)lr << 16) | (uint32_t)(c & ((1 << kSlabWidthLog2) - 1));
+      const int32_t c = csr.idx[p];
+      const int32_t q = pos[w * S + (c >> slabWidthLog2)]++;
+      out.ent[q] = (lr << out.minorBits) | (uint32_t)c;
       out.val[q] = csr.val[p];
     }
   }

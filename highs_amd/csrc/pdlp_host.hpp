@@ -76,24 +76,22 @@ struct StreamPlan {
 };
 StreamPlan planStream(const std::vector<int32_t>& beg, int32_t nMajor, int32_t chunk, int32_t maxMajorsPerBlock);
 
-// Row-block x column-slab layout ("slab" SpMV).  The gathered vector of a
-// random sparse LP (8 MB at n = 1M) does not fit one XCD's 4 MB L2, so a plain
-// CSR stream pays one 64-byte fabric request per 8-byte gather.  Here each work
-// block owns `rowsPerBlock` consecutive majors and walks ITS nonzeros slab by
-// slab (slab = 65536 consecutive minor indices = 512 KB of the gathered
-// vector): all resident blocks sweep the slabs in the same order at about the
-// same pace, so the slab being gathered from stays L2-resident on every XCD.
-// Entries are sorted by (block, slab, local major, minor); an entry is
-// (localMajor << 16 | minor - 65536*slab).  Majors longer than `longLimit`
-// are left out (marked in longMask) and handled by the CSR kernel.
+// Slab layout (the layout of k_spmv_slab).  The gathered vector of a random sparse LP (8 MB at
+// n = 1M) does not fit one XCD's 4 MB L2, so a plain CSR stream pays one fabric request per 8-byte
+// gather.  Here every wave sweeps the gathered vector slab by slab (slab = 2^slabWidthLog2 consecutive
+// minor indices, 512 KB by default), in step with all the others, so the slab being gathered from stays
+// in every XCD's L2.  The unit of ownership is the WAVE: a block of 16 waves (one block per CU) owns
+// rowsPerBlock = 16*rowsPerWave consecutive majors, wave w of it the majors [w*rowsPerWave,
+// (w+1)*rowsPerWave).  A wave's nonzeros are ONE dense stream sorted by (minor >> slabWidthLog2, local
+// major, minor): no windows, no per-slab padding.  An entry packs (localMajor << minorBits | minor) with
+// minorBits = 32 - ceil(log2(rowsPerWave)): the GLOBAL minor, so the kernel needs no slab table at all —
+// a slab boundary inside a 64-entry group shows up as a descent of the local major.  rowsPerWave is
+// chosen so that the blocks just cover the 256 CUs of an MI355X (every CU then does the same work per
+// slab).  Majors longer than `longLimit` are left out (marked in longMask) and handled by the CSR
+// kernel.
 struct SlabLayout {
-  int32_t rowsPerBlock = 0, nBlocks = 0, nSlabs = 0;
-  std::vector<int32_t> segPtr;    // [nBlocks*(nSlabs+1)] entry offsets
-  // Static work list of the kernel: per block, windows of <= 256 entries that never
-  // straddle a slab.  winBeg = first entry, winInfo = (slab << 16 | entry count).
-  std::vector<int32_t> winPtr;    // [nBlocks+1]
-  std::vector<int32_t> winBeg;    // [nWindows]
-  std::vector<uint32_t> winInfo;  // [nWindows]
+  int32_t rowsPerBlock = 0, rowsPerWave = 0, nBlocks = 0, minorBits = 0, slabWidthLog2 = 0;
+  std::vector<int32_t> wavePtr;   // [16*nBlocks+1] entry offsets
   std::vector<uint32_t> ent;      // [nnzShort]
   std::vector<double> val;        // [nnzShort]
   std::vector<uint32_t> longMask; // [nBlocks * rowsPerBlock/32]
@@ -101,6 +99,13 @@ struct SlabLayout {
   std::vector<int32_t> longMap;   // compact index -> major
 };
 constexpr int32_t kSlabWidthLog2 = 16;
-void buildSlabLayout(const Compressed& csr, int32_t nMajor, int32_t nMinor, int32_t longLimit, SlabLayout& out);
+constexpr int32_t kSlabWavesPerBlock = 16;
+constexpr int32_t kSlabTargetBlocks = 256;  // CUs of an MI355X
+// Majors per wave for an operand of this shape: even, in [16, 512], ceil(nMajor / (256*16)) when that
+// fits; halved until the minor index fits the entry packing; 0 when it cannot (nMinor > 2^28: the
+// caller then uses the CSR stream kernel).
+int32_t slabRowsPerWave(int32_t nMajor, int32_t nMinor);
+void buildSlabLayout(const Compressed& csr, int32_t nMajor, int32_t nMinor, int32_t longLimit, int32_t slabWidthLog2,
+                     SlabLayout& out);
 
 }  // namespace pdlp

@@ -38,12 +38,6 @@ struct SpmvArgs {
   HalpernVecs h;  // kHalpernPrimal / kHalpernDual
 };
 
-// CSR-adaptive SpMV (stream + long-row paths) with a fused, major-local epilogue.
-// One work block = up to kChunk consecutive nonzeros belonging to whole majors.
-//   phase 1: all lanes stream val[]/idx[] with unit stride (coalesced), gather
-//            the input vector, and park the products in LDS;
-//   phase 2: one lane per major adds its products left to right (the
-//            reference's summation order) and runs the epilogue.
 // Block-uniform read through the scalar (constant) path: s_load counts on lgkmcnt,
 // so it never forces a wait on the vector-memory prefetches in flight.
 template <typename T>
@@ -51,10 +45,105 @@ __device__ __forceinline__ T ldUniform(const T* p) {
   return *(const __attribute__((address_space(4))) T*)(p);
 }
 
+// The major-local epilogue fused into both SpMV kernels: what happens to (A v)_r once it is known.
+//   kDualStep     y+ = proj(y + sigma (b - 2 A x+ + A x)), sum (dy)^2        cupdlp_step.c:43-69
+//   kAtyInteract  sum (dx)^2, sum dx . d(A'y)                                cupdlp_linalg.c:772-801
+//   kHalpern*     the Halpern PDHG step of the HiPDLP path                   hipdlp/pdhg.cc:961-1018
+template <int EPI>
+struct Epi {
+  const SpmvArgs& a;
+  int cur = 0, nxt = 1;
+  double sigma = 0.0, avgW = 0.0, hTau = 0.0, hRho = 1.0, hW = 0.0;
+  double acc0 = 0.0, acc1 = 0.0;  // per-thread reduction partials
+
+  __device__ __forceinline__ explicit Epi(const SpmvArgs& args) : a(args) {
+    if (usesDevState(EPI)) {
+      cur = a.st->cur;
+      nxt = cur ^ 1;
+      sigma = a.st->sigma;
+      avgW = a.st->avgW;
+    }
+    if (EPI == kHalpernPrimal || EPI == kHalpernDual) {
+      const HalpernState hs = *a.h.hs;
+      hTau = hs.tau; sigma = hs.sigma; hRho = hs.rho;
+      const int k = hs.hIter + a.h.kOff;
+      hW = (double)k / ((double)k + 1.0);
+    }
+  }
+  // the gathered vector
+  __device__ __forceinline__ const double* input() const {
+    if (EPI == kPlain) return a.in;
+    if (EPI == kDualStep) return a.v.x[nxt];
+    if (EPI == kHalpernPrimal) return a.h.yc;
+    if (EPI == kHalpernDual) return a.h.rx;
+    return a.v.y[nxt];
+  }
+  // operands that do not depend on the SpMV result: fetched early, so their latency overlaps the stream
+  __device__ __forceinline__ Pre prefetch(int r) const {
+    Pre p{0.0, 0.0, 0.0, 0.0, 0.0};
+    if (EPI == kDualStep) {
+      p.a = ldStream(a.v.y[cur] + r); p.b = ldStream(a.v.rhs + r); p.c = ldStream(a.v.ax[cur] + r);
+    } else if (EPI == kAtyInteract) {
+      p.a = ldStream(a.v.x[cur] + r); p.b = ldStream(a.v.x[nxt] + r); p.c = ldStream(a.v.aty[cur] + r);
+    } else if (EPI == kHalpernPrimal) {
+      p.a = ldStream(a.h.xc + r); p.b = ldStream(a.h.cost + r); p.c = ldStream(a.h.xa + r);
+      p.d = ldStream(a.h.lower + r); p.e = ldStream(a.h.upper + r);
+    } else if (EPI == kHalpernDual) {
+      p.a = ldStream(a.h.yc + r); p.b = ldStream(a.h.ya + r); p.c = ldStream(a.h.rowLower + r);
+      p.d = ldStream(a.h.rowUpper + r);
+    }
+    return p;
+  }
+  __device__ __forceinline__ void apply(int r, double s, const Pre& p) {
+    if (EPI == kPlain || EPI == kAtyPartial) {
+      a.out[r] = s;
+    } else if (EPI == kHalpernPrimal) {
+      halpernPrimal(a.h, r, s, p, hTau, hRho, hW);
+    } else if (EPI == kHalpernDual) {
+      halpernDual(a.h, r, s, p, sigma, hRho, hW);
+    } else if (EPI == kDualStep) {
+      const double yv = p.a;
+      if (avgW != 0.0) stStream(a.v.ySum + r, ldStream(a.v.ySum + r) + avgW * yv);  // deferred PDHG_Update_Average (step.c:438)
+      double t = yv;
+      t += sigma * p.b;
+      t += (-2.0 * sigma) * s;
+      t += sigma * p.c;
+      if (r + a.v.rowOffset >= a.v.nEqs) t = t > 0.0 ? t : 0.0;
+      stStream(a.v.ax[nxt] + r, s);
+      a.v.y[nxt][r] = t;  // gathered by the next kernel: ordinary store
+      const double d = yv - t;
+      acc0 += d * d;
+    } else {  // kAtyInteract
+      const double dx = p.a - p.b;
+      const double da = p.c - s;
+      stStream(a.v.aty[nxt] + r, s);
+      acc0 += dx * dx;
+      acc1 += dx * da;
+    }
+  }
+  // per-block partials of the reductions (deterministic: wave shuffle tree -> fixed-order sum of the waves)
+  template <int NT>
+  __device__ __forceinline__ void finish(int slot, double (*scratch)[NT / 64]) {
+    if (EPI == kDualStep) {
+      const double t = blockSum<NT>(acc0, scratch[0]);
+      if (threadIdx.x == 0) a.part0[slot] = t;
+    } else if (EPI == kAtyInteract) {
+      const double t0 = blockSum<NT>(acc0, scratch[0]);
+      const double t1 = blockSum<NT>(acc1, scratch[1]);
+      if (threadIdx.x == 0) { a.part0[slot] = t0; a.part1[slot] = t1; }
+    }
+  }
+};
+
+// CSR-adaptive SpMV (stream + long-row paths) with the fused epilogue.
+// One work block = up to kChunk consecutive nonzeros belonging to whole majors.
+//   phase 1: all lanes stream val[]/idx[] with unit stride (coalesced), gather
+//            the input vector, and park the products in LDS;
+//   phase 2: one lane per major adds its products left to right (the
+//            reference's summation order) and runs the epilogue.
 template <int EPI, bool MAPPED>
 __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
-  const DevState* st = a.st;
-  if (usesDevState(EPI) && st->halted) return;
+  if (usesDevState(EPI) && a.st->halted) return;
   __shared__ double prod[kChunk + kChunk / 8 + 8];
   __shared__ double scratch[2][kSpmvThreads / kWave];
 
@@ -64,83 +153,16 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
   const int p0 = a.A.beg[r0], p1 = a.A.beg[r1];
   const int32_t* __restrict__ idx = a.A.idx;
   const double* __restrict__ val = a.A.val;
-
-  int cur = 0, nxt = 1;
-  double sigma = 0.0, avgW = 0.0;
-  if (usesDevState(EPI)) {
-    cur = st->cur;
-    nxt = cur ^ 1;
-    sigma = st->sigma;
-    avgW = st->avgW;
-  }
-  double hTau = 0.0, hRho = 1.0, hW = 0.0;
-  if (EPI == kHalpernPrimal || EPI == kHalpernDual) {
-    const HalpernState hs = *a.h.hs;
-    hTau = hs.tau; sigma = hs.sigma; hRho = hs.rho;
-    const int k = hs.hIter + a.h.kOff;
-    hW = (double)k / ((double)k + 1.0);
-  }
-  const double* __restrict__ in;
-  if (EPI == kPlain) in = a.in;
-  else if (EPI == kDualStep) in = a.v.x[nxt];
-  else if (EPI == kHalpernPrimal) in = a.h.yc;
-  else if (EPI == kHalpernDual) in = a.h.rx;
-  else in = a.v.y[nxt];
-
-  double acc0 = 0.0, acc1 = 0.0;  // per-thread epilogue partials
-
-  // Epilogue operands that do not depend on the SpMV result are fetched early
-  // (before the products are staged) so their latency overlaps the stream.
-  auto prefetch = [&](int r) -> Pre {
-    Pre p{0.0, 0.0, 0.0, 0.0, 0.0};
-    if (MAPPED) r = a.A.majorMap[r];
-    if (EPI == kDualStep) {
-      p.a = a.v.y[cur][r]; p.b = a.v.rhs[r]; p.c = a.v.ax[cur][r];
-    } else if (EPI == kAtyInteract) {
-      p.a = a.v.x[cur][r]; p.b = a.v.x[nxt][r]; p.c = a.v.aty[cur][r];
-    } else if (EPI == kHalpernPrimal) {
-      p.a = a.h.xc[r]; p.b = a.h.cost[r]; p.c = a.h.xa[r]; p.d = a.h.lower[r]; p.e = a.h.upper[r];
-    } else if (EPI == kHalpernDual) {
-      p.a = a.h.yc[r]; p.b = a.h.ya[r]; p.c = a.h.rowLower[r]; p.d = a.h.rowUpper[r];
-    }
-    return p;
-  };
-  auto epilogue = [&](int r, double s, const Pre& p) {
-    if (MAPPED) r = a.A.majorMap[r];
-    if (EPI == kPlain || EPI == kAtyPartial) {
-      a.out[r] = s;
-    } else if (EPI == kHalpernPrimal) {
-      halpernPrimal(a.h, r, s, p, hTau, hRho, hW);
-    } else if (EPI == kHalpernDual) {
-      halpernDual(a.h, r, s, p, sigma, hRho, hW);
-    } else if (EPI == kDualStep) {
-      // y+ = proj(y + sigma*(b - 2 A x+ + A x)), cupdlp_step.c:43-69
-      const double yv = p.a;
-      if (avgW != 0.0) a.v.ySum[r] += avgW * yv;  // deferred PDHG_Update_Average (step.c:438)
-      double t = yv;
-      t += sigma * p.b;
-      t += (-2.0 * sigma) * s;
-      t += sigma * p.c;
-      if (r + a.v.rowOffset >= a.v.nEqs) t = t > 0.0 ? t : 0.0;
-      a.v.ax[nxt][r] = s;
-      a.v.y[nxt][r] = t;
-      const double d = yv - t;
-      acc0 += d * d;
-    } else {  // kAtyInteract: cupdlp_linalg.c:772-801
-      const double dx = p.a - p.b;
-      const double da = p.c - s;
-      a.v.aty[nxt][r] = s;
-      acc0 += dx * dx;
-      acc1 += dx * da;
-    }
-  };
+  Epi<EPI> epi(a);
+  const double* __restrict__ in = epi.input();
+  auto vecIndex = [&](int r) { return MAPPED ? a.A.majorMap[r] : r; };
 
   if (r1 - r0 == 1 && p1 - p0 > kChunk) {
     // long major: the whole block strides over it; tree-reduced (deterministic)
     double s = 0.0;
     for (int p = p0 + tid; p < p1; p += kSpmvThreads) s += val[p] * in[idx[p]];
     s = blockSum<kSpmvThreads>(s, scratch[0]);
-    if (tid == 0) epilogue(r0, s, prefetch(r0));
+    if (tid == 0) { const int r = vecIndex(r0); epi.apply(r, s, epi.prefetch(r)); }
   } else {
     constexpr int kPer = kChunk / kSpmvThreads;
     const int cnt = p1 - p0;
@@ -152,7 +174,7 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
     const int rr = rFirst < r1 ? rFirst : r1 - 1;
     int qb = a.A.beg[rr] - p0;
     int qe = a.A.beg[rr + 1] - p0;
-    Pre pre = prefetch(rr);
+    Pre pre = epi.prefetch(vecIndex(rr));
     // phase 1: kPer unit-stride loads of idx/val per lane, all issued before the
     // dependent gathers, so a wave keeps 3*kPer memory operations in flight
     const int last = cnt > 0 ? cnt - 1 : 0;  // idx/val carry one pad element
@@ -178,7 +200,7 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
       if (r != rFirst) {
         qb = a.A.beg[r] - p0;
         qe = a.A.beg[r + 1] - p0;
-        pre = prefetch(r);
+        pre = epi.prefetch(vecIndex(r));
       }
       double s = 0.0;
       int q = qb;
@@ -187,181 +209,159 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
         s += t0; s += t1; s += t2; s += t3;
       }
       for (; q < qe; ++q) s += prod[slot(q)];
-      epilogue(r, s, pre);
+      epi.apply(vecIndex(r), s, pre);
     }
   }
-
-  if (EPI == kDualStep) {
-    const double t = blockSum<kSpmvThreads>(acc0, scratch[0]);
-    if (tid == 0) a.part0[a.A.partOffset + blk] = t;
-  } else if (EPI == kAtyInteract) {
-    const double t0 = blockSum<kSpmvThreads>(acc0, scratch[0]);
-    const double t1 = blockSum<kSpmvThreads>(acc1, scratch[1]);
-    if (tid == 0) { a.part0[a.A.partOffset + blk] = t0; a.part1[a.A.partOffset + blk] = t1; }
-  }
+  epi.template finish<kSpmvThreads>(a.A.partOffset + blk, scratch);
 }
 
-// Slab SpMV: one block owns rowsPerBlock consecutive majors and streams ITS
-// nonzeros, which the host sorted by (slab of the gathered vector, local major,
-// minor).  All resident blocks walk the slabs in the same order, so the 512 KB
-// slab currently gathered from stays in every XCD's L2 instead of costing one
-// 64-byte fabric request per 8-byte gather.  Per 256-entry window: products go
-// to LDS, the first lane of each run of equal majors adds the run, left to
-// right, onto the major's LDS accumulator.  Because slabs and the minors inside
-// a slab ascend, every major is still summed in ascending minor order — the
-// reference's order — and the result is bit-identical to the CSR path.
+// Slab SpMV (layout: pdlp_host.hpp SlabLayout) — for operands whose gathered vector does not fit an
+// XCD's 4 MB L2.  One 1024-thread block per CU; each of its 16 WAVES owns rowsPerBlock/16 consecutive
+// majors and streams its own nonzeros — one dense list sorted by (slab of the gathered vector, local
+// major, minor) — 64 at a time through a register pipeline: entry/value loads kSlabSlots groups ahead of
+// the accumulation, the gather one group ahead, all counted on vmcnt by the compiler.  A workgroup
+// barrier per group keeps the CU's waves on the same slab (pacing only: a wave touches nothing but its
+// own accumulators), and since every CU has the same amount of work per slab, all CUs of an XCD sweep
+// the gathered vector together: measured L2 misses = the compulsory ones (TCC_MISS 1.33 M per launch at
+// the bench size, of which 0.5 M are the fill of x into 8 L2s and 0.75 M the matrix stream); free-running
+// waves (no barrier, 8 blocks/CU) drift apart — the SIMDs issue oldest-first once the vector-memory
+// queue is full — and miss 3.9 M times.
+//   What bounds the kernel: a CU keeps ~128 cache-line requests in flight (the vector L1's miss queue;
+// the same ~16 KB per CU that limits a streaming copy to ~6 TB/s), and every gathered double is its own
+// line request: 8 M gathers x ~300 cycles L2-hit latency / (256 CUs x 128) = 36 us, plus the matrix and
+// vector streams through the same queue.
+//   Accumulation: the 64 products go to a wave-private LDS strip; the first lane of each run of equal
+// local majors adds the run, left to right, onto the major's LDS accumulator.  A 64-entry group may
+// straddle slabs, so the same major can own two runs in it: those are in different ASCENDING stretches
+// of the group (a slab boundary that matters shows up as a descent of the local major), and the
+// stretches are applied one after the other.  Slabs ascend and minors ascend inside a slab, so every
+// major is summed in ascending minor order — the reference's order: bit-identical to the CSR path.
+constexpr int kSlabSlots = 3;  // register pipeline depth (groups of 64 entries per wave)
 template <int EPI>
-__global__ __launch_bounds__(kSlabThreads, 8) void k_spmv_slab(const SpmvArgs a) {
-  const DevState* st = a.st;
-  if (usesDevState(EPI) && st->halted) return;
-  // dynamic LDS (all carve offsets are multiples of 16 bytes; no static __shared__ in this kernel):
-  //   acc[R] f64 | stage[2][256] f64 | scratch[2][4] f64 | srow[2][256] u16
+__global__ __launch_bounds__(kSlabThreads, kSlabThreads / 256) void k_spmv_slab(const SpmvArgs a) {
+  if (usesDevState(EPI) && a.st->halted) return;
+  constexpr int NB = kSlabSlots, kWaves = kSlabThreads / kWave;
+  // dynamic LDS: acc[R] f64 | stg[16][64] f64 | scratch[2][16] f64
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  double* acc = reinterpret_cast<double*>(smem);
-  double(*stage)[kSlabThreads] = reinterpret_cast<double(*)[kSlabThreads]>(acc + a.S.rowsPerBlock);
-  double(*scratch)[kSlabThreads / kWave] = reinterpret_cast<double(*)[kSlabThreads / kWave]>(&stage[2][0]);
-  uint16_t(*srow)[kSlabThreads] = reinterpret_cast<uint16_t(*)[kSlabThreads]>(&scratch[2][0]);
-
-  const int tid = threadIdx.x;
-  const int blk = blockIdx.x;
   const int R = a.S.rowsPerBlock;
+  double* acc = reinterpret_cast<double*>(smem);
+  double* stgAll = acc + R;
+  double(*scratch)[kWaves] = reinterpret_cast<double(*)[kWaves]>(stgAll + kSlabThreads);
+
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+  const int blk = blockIdx.x;
+  const int Rw = R / kWaves;
+  const int mb = a.S.minorBits;
+  const uint32_t mmask = (1u << mb) - 1u;
   const int rBase = blk * R;
   const int rEnd = (rBase + R < a.S.nMajor) ? rBase + R : a.S.nMajor;
-  const uint32_t* __restrict__ ent = a.S.ent;
-  const double* __restrict__ val = a.S.val;
-  // this block's static window list (block-uniform -> scalar loads, which do not
-  // touch the vector-memory counter the prefetches below depend on)
-  const int wBeg = a.S.winPtr[blk], wEnd = a.S.winPtr[blk + 1];
-  const int32_t* __restrict__ winBeg = a.S.winBeg;
-  const uint32_t* __restrict__ winInfo = a.S.winInfo;
+  const int gw = blk * kWaves + wave;
+  const int e0 = ldUniform(a.S.wavePtr + gw), e1 = ldUniform(a.S.wavePtr + gw + 1);
+  double* wacc = acc + wave * Rw;
+  double* stg = stgAll + wave * kWave;
+  Epi<EPI> epi(a);
+  const double* __restrict__ in = epi.input();
 
-  int cur = 0, nxt = 1;
-  double sigma = 0.0, avgW = 0.0;
-  if (usesDevState(EPI)) {
-    cur = st->cur;
-    nxt = cur ^ 1;
-    sigma = st->sigma;
-    avgW = st->avgW;
-  }
-  double hTau = 0.0, hRho = 1.0, hW = 0.0;
-  if (EPI == kHalpernPrimal || EPI == kHalpernDual) {
-    const HalpernState hs = *a.h.hs;
-    hTau = hs.tau; sigma = hs.sigma; hRho = hs.rho;
-    const int k = hs.hIter + a.h.kOff;
-    hW = (double)k / ((double)k + 1.0);
-  }
-  const double* __restrict__ in;
-  if (EPI == kPlain) in = a.in;
-  else if (EPI == kDualStep) in = a.v.x[nxt];
-  else if (EPI == kHalpernPrimal) in = a.h.yc;
-  else if (EPI == kHalpernDual) in = a.h.rx;
-  else in = a.v.y[nxt];
-
-  for (int r = tid; r < R; r += kSlabThreads) acc[r] = 0.0;
-
-  double acc0 = 0.0, acc1 = 0.0;
-  auto prefetch = [&](int r) -> Pre {
-    Pre p{0.0, 0.0, 0.0, 0.0, 0.0};
-    if (EPI == kDualStep) { p.a = a.v.y[cur][r]; p.b = a.v.rhs[r]; p.c = a.v.ax[cur][r]; }
-    else if (EPI == kAtyInteract) { p.a = a.v.x[cur][r]; p.b = a.v.x[nxt][r]; p.c = a.v.aty[cur][r]; }
-    else if (EPI == kHalpernPrimal) {
-      p.a = a.h.xc[r]; p.b = a.h.cost[r]; p.c = a.h.xa[r]; p.d = a.h.lower[r]; p.e = a.h.upper[r];
-    } else if (EPI == kHalpernDual) {
-      p.a = a.h.yc[r]; p.b = a.h.ya[r]; p.c = a.h.rowLower[r]; p.d = a.h.rowUpper[r];
-    }
-    return p;
-  };
-  // operands of this lane's first two majors, fetched ahead of the stream (clamped, unconditional)
+  for (int r = lane; r < Rw; r += kWave) wacc[r] = 0.0;
+  // operands of this thread's first two majors, fetched ahead of the stream (clamped, unconditional)
   const int rA = rBase + tid < rEnd ? rBase + tid : rEnd - 1;
   const int rB = rBase + tid + kSlabThreads < rEnd ? rBase + tid + kSlabThreads : rEnd - 1;
-  const Pre preA = prefetch(rA), preB = prefetch(rB);
+  const Pre preA = epi.prefetch(rA), preB = epi.prefetch(rB);
 
-  __syncthreads();  // acc[] is zeroed
-  // Windows of up to 256 entries that never straddle a slab boundary: inside a
-  // window a major forms ONE run (entries are sorted by major within the slab),
-  // so each accumulator has a single writer per window and the barrier between
-  // windows orders the runs of a major slab after slab.
-  struct Win { int beg, cnt, slab; };
-  auto getWin = [&](int i) -> Win {  // block-uniform; windows past the end are empty
-    int ic = i < wEnd ? i : wEnd - 1;  // winBeg/winInfo carry one pad element
-    ic = __builtin_amdgcn_readfirstlane(ic < 0 ? 0 : ic);  // SGPR index -> s_load (lgkmcnt, not vmcnt)
-    const uint32_t info = ldUniform(winInfo + ic);
-    const int beg = ldUniform(winBeg + ic);
-    return Win{beg, i < wEnd ? (int)(info & 0xffffu) : 0, (int)(info >> 16)};
+  // ---- the stream ----
+  // Register pipeline over NB slots, unrolled NB times so that a slot is a fixed register (no moves of
+  // values still in flight, which would drain vmcnt): step g gathers for group g+1, then consumes
+  // group g (slot g % NB) and refills that slot with group g+NB.  All loads are unconditional; past the
+  // wave's last entry they re-read that entry (same cache line), and groups past nG contribute nothing.
+  const uint32_t* __restrict__ ent = a.S.ent + e0;
+  const double* __restrict__ val = a.S.val + e0;
+  const int cnt = e1 - e0;
+  const int nG = (cnt + kWave - 1) / kWave;
+  const int last = cnt > 0 ? cnt - 1 : 0;  // (an empty wave reads entry e0, which exists: ent/val carry one pad element)
+  auto entryIndex = [&](int g) { const int q = g * kWave + lane; return q < last ? q : last; };
+  auto gather = [&](uint32_t e) -> double {
+    const uint32_t off = (e & mmask) << 3;  // byte offset: minor < 2^26
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(in) + off);
   };
-  // All loads are unconditional (lanes past the window read the next entries, the
-  // arrays carry a pad element) so that hipcc never drains vmcnt at a branch join.
-  auto gatherIdx = [&](const Win& w, uint32_t en) -> size_t {
-    return tid < w.cnt ? (((size_t)w.slab << 16) + (en & 0xffffu)) : 0;
-  };
-  // One window per iteration, nothing carried across iterations: entries -> gather -> LDS.
-  // More memory-level parallelism was measured to HURT: batching the gathers of 2/4/8 windows
-  // (69/79/86 us vs 54 us) or prefetching the entry stream 4/8/12 windows ahead (62/64/67 us)
-  // lets the resident blocks drift over more slabs than the L2 holds.  Locality beats MLP here.
-  for (int wi = wBeg; wi < wEnd; ++wi) {
-    const Win w = getWin(wi);
-    const uint32_t en = ent[w.beg + tid];
-    const double vv = val[w.beg + tid];
-    const double xg = in[gatherIdx(w, en)];
-    const int buf = (wi - wBeg) & 1;  // alternate LDS staging buffers: one barrier per window
-    const bool valid = tid < w.cnt;
-    const uint32_t lrow = en >> 16;
-    const double prod = vv * xg;
-    stage[buf][tid] = prod;
-    srow[buf][tid] = valid ? (uint16_t)lrow : (uint16_t)0xffff;
+  uint32_t E[NB];
+  double V[NB], X[NB];
+  // prologue = the steps -NB..-1 of the same schedule (same issue order as the steady state, so the
+  // compiler's vmcnt bookkeeping at the loop header does not have to assume the worst)
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    if (k + 1 >= NB) X[(k + 1) % NB] = gather(E[(k + 1) % NB]);
+    const int q = entryIndex(k);
+    E[k] = ent[q];
+    V[k] = val[q];
+    __builtin_amdgcn_sched_barrier(0);  // keep this issue order
+  }
+  // block-uniform trip count: the per-step barrier must be reached by every wave
+  int nRounds = (nG + NB - 1) / NB;
+  {
+    int* share = reinterpret_cast<int*>(scratch);
+    if (lane == 0) share[wave] = nRounds;
     __syncthreads();
-    if (valid && (tid == 0 || srow[buf][tid - 1] != (uint16_t)lrow)) {
-      double s = acc[lrow];
-      s += prod;
-      for (int j = tid + 1; j < kSlabThreads && srow[buf][j] == (uint16_t)lrow; ++j) s += stage[buf][j];
-      acc[lrow] = s;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) nRounds = share[w] > nRounds ? share[w] : nRounds;
+    __syncthreads();
+  }
+  for (int o = 0; o < nRounds; ++o) {
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int g = o * NB + u;
+      X[(u + 1) % NB] = gather(E[(u + 1) % NB]);  // group g+1
+      // consume group g
+      const int nValid = cnt - g * kWave;  // lanes >= nValid hold nothing of this wave (<= 0: phantom group)
+      const bool valid = lane < nValid;
+      const uint32_t lrow = valid ? (E[u] >> mb) : 0xffffffffu;
+      const double prod = V[u] * X[u];
+      {  // slot u is free: refill it with group g+NB
+        const int q = entryIndex(g + NB);
+        E[u] = ent[q];
+        V[u] = val[q];
+      }
+      __builtin_amdgcn_sched_barrier(0);  // gather, then refill, then the LDS work: in this order
+      stg[lane] = prod;
+      const uint32_t prev = (uint32_t)__shfl_up((int)lrow, 1, kWave);
+      const bool isHead = valid && (lane == 0 || lrow != prev);
+      const bool desc = valid && lane != 0 && lrow < prev;
+      const uint64_t heads = __ballot(isHead);
+      const uint64_t descs = __ballot(desc);
+      // end of this lane's run = next head above it (or the end of the group)
+      const uint64_t above = (heads >> lane) >> 1;
+      const int vEnd = nValid < kWave ? nValid : kWave;
+      const int end = above ? lane + __ffsll((unsigned long long)above) : vEnd;
+      __builtin_amdgcn_wave_barrier();
+      auto addRun = [&]() {
+        double s = wacc[lrow];
+        s += prod;
+        for (int j = lane + 1; j < end; ++j) s += stg[j];
+        wacc[lrow] = s;
+      };
+      if (descs == 0) {
+        if (isHead) addRun();
+      } else {
+        // the group straddles slabs: ascending stretches one after the other (a major may own a run in each)
+        const int seg = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(descs >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)descs, 0u)) + (desc ? 1 : 0);
+        const int nSeg = __popcll(descs) + 1;
+        for (int sg = 0; sg < nSeg; ++sg) {
+          if (isHead && seg == sg) addRun();
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+      __syncthreads();  // pacing: the CU's waves stay on the same slab (and order this step's LDS traffic)
     }
   }
-  __syncthreads();
 
-  auto epilogue = [&](int r, double s, const Pre& p) {
-    if (EPI == kPlain || EPI == kAtyPartial) {
-      a.out[r] = s;
-    } else if (EPI == kHalpernPrimal) {
-      halpernPrimal(a.h, r, s, p, hTau, hRho, hW);
-    } else if (EPI == kHalpernDual) {
-      halpernDual(a.h, r, s, p, sigma, hRho, hW);
-    } else if (EPI == kDualStep) {
-      const double yv = p.a;
-      if (avgW != 0.0) a.v.ySum[r] += avgW * yv;
-      double t = yv;
-      t += sigma * p.b;
-      t += (-2.0 * sigma) * s;
-      t += sigma * p.c;
-      if (r + a.v.rowOffset >= a.v.nEqs) t = t > 0.0 ? t : 0.0;
-      a.v.ax[nxt][r] = s;
-      a.v.y[nxt][r] = t;
-      const double d = yv - t;
-      acc0 += d * d;
-    } else {
-      const double dx = p.a - p.b;
-      const double da = p.c - s;
-      a.v.aty[nxt][r] = s;
-      acc0 += dx * dx;
-      acc1 += dx * da;
-    }
-  };
   const uint32_t* __restrict__ mask = a.S.longMask + (size_t)blk * (R / 32);
   for (int lr = tid, it = 0; rBase + lr < rEnd; lr += kSlabThreads, ++it) {
     if ((mask[lr >> 5] >> (lr & 31)) & 1u) continue;  // long major: the CSR side kernel owns it
     const int r = rBase + lr;
-    const Pre p = it == 0 ? preA : (it == 1 ? preB : prefetch(r));
-    epilogue(r, acc[lr], p);
+    const Pre p = it == 0 ? preA : (it == 1 ? preB : epi.prefetch(r));
+    epi.apply(r, acc[lr], p);
   }
-
-  if (EPI == kDualStep) {
-    const double t = blockSum<kSlabThreads>(acc0, scratch[0]);
-    if (tid == 0) a.part0[blk] = t;
-  } else if (EPI == kAtyInteract) {
-    const double t0 = blockSum<kSlabThreads>(acc0, scratch[0]);
-    const double t1 = blockSum<kSlabThreads>(acc1, scratch[1]);
-    if (tid == 0) { a.part0[blk] = t0; a.part1[blk] = t1; }
-  }
+  epi.template finish<kSlabThreads>(blk, scratch);
 }
 
 // x+ = clamp(x - tau (c - A'y), l, u): cupdlp_step.c:16-40, rounding as the CPU branch.
@@ -374,12 +374,12 @@ __global__ __launch_bounds__(kVecThreads) void k_primal_step(const IterVecs v, c
   double* __restrict__ xn = v.x[nxt];
   const int stride = gridDim.x * blockDim.x;
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < v.n; j += stride) {
-    const double xv = x[j];
-    if (avgW != 0.0) v.xSum[j] += avgW * xv;  // deferred PDHG_Update_Average (step.c:437)
+    const double xv = ldStream(x + j);
+    if (avgW != 0.0) stStream(v.xSum + j, ldStream(v.xSum + j) + avgW * xv);  // deferred PDHG_Update_Average (step.c:437)
     double t = xv;
-    t += (-tau) * v.cost[j];
-    t += tau * aty[j];
-    const double u = v.upper[j], l = v.lower[j];
+    t += (-tau) * ldStream(v.cost + j);
+    t += tau * ldStream(aty + j);
+    const double u = ldStream(v.upper + j), l = ldStream(v.lower + j);
     t = t < u ? t : u;
     t = t > l ? t : l;
     xn[j] = t;
@@ -622,8 +622,7 @@ template <int EPI>
 void launchSpmv(const MatView& M, SpmvArgs a, hipStream_t s) {
   if (M.useSlab && M.slab.nBlocks > 0) {
     a.S = M.slab;
-    const size_t lds = (size_t)M.slab.rowsPerBlock * 8 + 2 * kSlabThreads * 8 + 2 * (kSlabThreads / kWave) * 8 +
-                       2 * kSlabThreads * 2;
+    const size_t lds = (size_t)M.slab.rowsPerBlock * 8 + kSlabThreads * 8 + 2 * (kSlabThreads / kWave) * 8;
     hipLaunchKernelGGL((k_spmv_slab<EPI>), dim3(M.slab.nBlocks), dim3(kSlabThreads), lds, s, a);
   }
   if (M.csr.nBlocks > 0) {

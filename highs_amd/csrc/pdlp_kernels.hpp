@@ -55,17 +55,16 @@ struct SpmvMat {
   int32_t partOffset;       // first slot of this matrix in the per-block partial arrays
 };
 
-// Row-block x column-slab layout (pdlp_host.hpp SlabLayout), device pointers.
-constexpr int kSlabThreads = 256;
-constexpr int kSlabMaxRows = 4096;  // majors per block (LDS accumulators)
+// Slab layout (pdlp_host.hpp SlabLayout), device pointers.  One 1024-thread block = 16 waves, each
+// owning rowsPerBlock/16 consecutive majors and its own sorted entry list.
+constexpr int kSlabThreads = 1024;
+constexpr int kSlabMaxRows = 8192;  // majors per block (LDS accumulators: 64 KB)
 struct SlabMat {
-  const int32_t* winPtr;     // [nBlocks+1] window list of each block
-  const int32_t* winBeg;     // [nWindows] first entry of the window
-  const uint32_t* winInfo;   // [nWindows] (slab<<16 | entries), entries <= 256, one slab per window
-  const uint32_t* ent;       // [nnz] (localMajor<<16 | localMinor)
+  const int32_t* wavePtr;    // [16*nBlocks+1] entry offsets per wave
+  const uint32_t* ent;       // [nnz] (localMajor << minorBits | minor)
   const double* val;         // [nnz]
   const uint32_t* longMask;  // [nBlocks*rowsPerBlock/32]
-  int32_t nMajor, nBlocks, nSlabs, rowsPerBlock;
+  int32_t nMajor, nBlocks, rowsPerBlock, minorBits;
 };
 
 // One operand matrix of the iteration: either a plain CSR stream, or the slab

@@ -229,21 +229,33 @@ __global__ void k_absmax_partial(const double* __restrict__ val, int64_t nnz, do
 
 // ---- slab layout ------------------------------------------------------------------
 __global__ void k_slab_keys(const int32_t* __restrict__ beg, const int32_t* __restrict__ major,
-                            const int32_t* __restrict__ idx, int64_t nnz, int R, int S, int longLimit, uint32_t keyMax,
-                            uint32_t* keys) {
+                            const int32_t* __restrict__ idx, int64_t nnz, int Rw, int S, int W, int longLimit,
+                            uint32_t keyMax, uint32_t* keys) {
   GSTRIDE(p, nnz) {
     const int r = major[p];
     const int len = beg[r + 1] - beg[r];
-    keys[p] = len > longLimit ? keyMax : (uint32_t)(r / R) * (uint32_t)S + ((uint32_t)idx[p] >> kSlabWidthLog2);
+    keys[p] = len > longLimit ? keyMax : (uint32_t)(r / Rw) * (uint32_t)S + ((uint32_t)idx[p] >> W);
   }
 }
 __global__ void k_slab_entries(const int32_t* __restrict__ perm, const int32_t* __restrict__ major,
-                               const int32_t* __restrict__ idx, const double* __restrict__ valIn, int64_t nShort, int R,
-                               uint32_t* ent, double* val) {
+                               const int32_t* __restrict__ idx, const double* __restrict__ valIn, int64_t nShort, int Rw,
+                               int minorBits, uint32_t* ent, double* val) {
   GSTRIDE(q, nShort) {
     const int p = perm[q];
-    ent[q] = ((uint32_t)(major[p] % R) << 16) | ((uint32_t)idx[p] & 0xffffu);
+    ent[q] = ((uint32_t)(major[p] % Rw) << minorBits) | (uint32_t)idx[p];
     val[q] = valIn[p];
+  }
+}
+// wavePtr[w] = first q with sortedKey[q] >= w*S  (w = 0..nWaves; keyMax sorts after every wave)
+__global__ void k_wave_ptr(const uint32_t* __restrict__ sortedKeys, int64_t nnz, int nWaves, int S, int32_t* out) {
+  GSTRIDE(w, nWaves + 1) {
+    const uint64_t key = (uint64_t)w * (uint64_t)S;
+    int64_t lo = 0, hi = nnz;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if ((uint64_t)sortedKeys[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    out[w] = (int32_t)lo;
   }
 }
 __global__ void k_long_mask(const int32_t* __restrict__ beg, int nMajor, int R, int longLimit, int nWords,
@@ -259,25 +271,6 @@ __global__ void k_long_mask(const int32_t* __restrict__ beg, int nMajor, int R, 
     mask[w] = bits;
   }
   GSTRIDE(r, nMajor) longFlag[r] = (beg[r + 1] - beg[r] > longLimit) ? 1 : 0;
-}
-// windows per (block, slab) segment
-__global__ void k_seg_windows(const int32_t* __restrict__ segPtr, int64_t nSeg, int32_t* nWin) {
-  GSTRIDE(g, nSeg) nWin[g] = (segPtr[g + 1] - segPtr[g] + 255) / 256;
-}
-__global__ void k_fill_windows(const int32_t* __restrict__ segPtr, const int32_t* __restrict__ wOff, int64_t nSeg,
-                               int S, int32_t* winBeg, uint32_t* winInfo) {
-  GSTRIDE(g, nSeg) {
-    const int sb = segPtr[g], se = segPtr[g + 1];
-    int w = wOff[g];
-    const uint32_t slab = (uint32_t)(g % S);
-    for (int q = sb; q < se; q += 256, ++w) {
-      winBeg[w] = q;
-      winInfo[w] = (slab << 16) | (uint32_t)min(256, se - q);
-    }
-  }
-}
-__global__ void k_win_ptr(const int32_t* __restrict__ wOff, int nBlocks, int S, int32_t nWinTotal, int32_t* winPtr) {
-  GSTRIDE(b, nBlocks + 1) winPtr[b] = b < nBlocks ? wOff[(int64_t)b * S] : nWinTotal;
 }
 // long-major compaction
 __global__ void k_long_rows(const int32_t* __restrict__ beg, const int32_t* __restrict__ longFlag,
@@ -564,18 +557,21 @@ void gpuPrepare(const pdlp_problem_t& P, bool doScale, hipStream_t s, DeviceProb
   for (double v : hb) D.sumRhs2 += v * v;
 }
 
-void gpuBuildSlabLayout(const DeviceCsrData& M, int32_t longLimit, hipStream_t s, DeviceSlabLayout& L) {
+void gpuBuildSlabLayout(const DeviceCsrData& M, int32_t longLimit, int32_t W, hipStream_t s, DeviceSlabLayout& L) {
   const int32_t nMajor = M.nMajor, nMinor = M.nMinor;
   const int64_t nnz = M.nnz;
-  const double avg = nMajor > 0 ? (double)nnz / nMajor : 1.0;
-  int32_t R = 256;
-  while (R < 4096 && (double)R * avg < 3000.0) R *= 2;
+  const int32_t Rw = slabRowsPerWave(nMajor, nMinor);
+  if (Rw == 0) throw std::runtime_error("slab layout: minor index does not fit the entry packing");
+  const int32_t R = Rw * kSlabWavesPerBlock;
+  int rb = 0;
+  while ((1 << rb) < Rw) ++rb;
+  L.rowsPerWave = Rw;
   L.rowsPerBlock = R;
   L.nBlocks = (nMajor + R - 1) / R;
-  L.nSlabs = std::max(1, (int32_t)(((int64_t)nMinor + (1 << kSlabWidthLog2) - 1) >> kSlabWidthLog2));
-  const int32_t S = L.nSlabs;
-  if (S > 65535) throw std::runtime_error("slab layout: too many slabs");
-  const int64_t nSeg = (int64_t)L.nBlocks * S;
+  L.minorBits = 32 - rb;
+  const int32_t nWaves = L.nBlocks * kSlabWavesPerBlock;
+  const int32_t S = std::max(1, (int32_t)(((int64_t)nMinor + ((int64_t)1 << W) - 1) >> W));
+  const int64_t nSeg = (int64_t)nWaves * S;
   if (nSeg >= (int64_t)0x7fffffff) throw std::runtime_error("slab layout: too many segments");
   const uint32_t keyMax = (uint32_t)nSeg;  // sorts after every real segment
 
@@ -622,42 +618,25 @@ void gpuBuildSlabLayout(const DeviceCsrData& M, int32_t longLimit, hipStream_t s
     L.longCsr.val.alloc(1);
   }
 
-  // short entries sorted by (block, slab); the stable sort keeps (major, minor) order inside
+  // short entries sorted by (wave, slab); the stable sort keeps (major, minor) order inside
   DeviceArray<uint32_t> keys, sortedKeys;
   DeviceArray<int32_t> perm;
   keys.alloc((size_t)std::max<int64_t>(nnz, 1));
   if (nnz > 0)
-    hipLaunchKernelGGL(k_slab_keys, dim3(gridFor(nnz)), dim3(kT), 0, s, M.beg.get(), M.major.get(), M.idx.get(), nnz, R,
-                       S, longLimit, keyMax, keys.get());
+    hipLaunchKernelGGL(k_slab_keys, dim3(gridFor(nnz)), dim3(kT), 0, s, M.beg.get(), M.major.get(), M.idx.get(), nnz, Rw,
+                       S, W, longLimit, keyMax, keys.get());
   sortByKey(keys.get(), nnz, (uint64_t)keyMax, sortedKeys, perm, s);
-  DeviceArray<int32_t> segPtr;
-  segPtr.alloc((size_t)nSeg + 1);
-  hipLaunchKernelGGL(k_lower_bounds, dim3(gridFor(nSeg + 1)), dim3(kT), 0, s,
-                     reinterpret_cast<const int32_t*>(sortedKeys.get()), nnz, nSeg + 1, segPtr.get());
-  L.nnzShort = nSeg >= 0 ? fetchOne(segPtr.get() + nSeg, s) : 0;
-  L.ent.alloc((size_t)L.nnzShort + kSlabThreads);
-  L.val.alloc((size_t)L.nnzShort + kSlabThreads);
+  L.wavePtr.alloc((size_t)nWaves + 1);
+  hipLaunchKernelGGL(k_wave_ptr, dim3(gridFor(nWaves + 1)), dim3(kT), 0, s, sortedKeys.get(), nnz, nWaves, S,
+                     L.wavePtr.get());
+  L.nnzShort = fetchOne(L.wavePtr.get() + nWaves, s);
+  L.ent.alloc((size_t)L.nnzShort + 1);
+  L.val.alloc((size_t)L.nnzShort + 1);
   L.ent.zero(s);
   L.val.zero(s);
   if (L.nnzShort > 0)
     hipLaunchKernelGGL(k_slab_entries, dim3(gridFor(L.nnzShort)), dim3(kT), 0, s, perm.get(), M.major.get(),
-                       M.idx.get(), M.val.get(), L.nnzShort, R, L.ent.get(), L.val.get());
-  // static window list
-  DeviceArray<int32_t> nWin, wOff;
-  nWin.alloc((size_t)std::max<int64_t>(nSeg, 1));
-  wOff.alloc((size_t)std::max<int64_t>(nSeg, 1));
-  hipLaunchKernelGGL(k_seg_windows, dim3(gridFor(nSeg)), dim3(kT), 0, s, segPtr.get(), nSeg, nWin.get());
-  exclusiveSum(nWin.get(), wOff.get(), nSeg, s);
-  L.nWindows = nSeg > 0 ? fetchOne(wOff.get() + (nSeg - 1), s) + fetchOne(nWin.get() + (nSeg - 1), s) : 0;
-  L.winBeg.alloc((size_t)L.nWindows + 1);
-  L.winInfo.alloc((size_t)L.nWindows + 1);
-  L.winBeg.zero(s);
-  L.winInfo.zero(s);
-  L.winPtr.alloc((size_t)L.nBlocks + 1);
-  hipLaunchKernelGGL(k_fill_windows, dim3(gridFor(nSeg)), dim3(kT), 0, s, segPtr.get(), wOff.get(), nSeg, S,
-                     L.winBeg.get(), L.winInfo.get());
-  hipLaunchKernelGGL(k_win_ptr, dim3(gridFor(L.nBlocks + 1)), dim3(kT), 0, s, wOff.get(), L.nBlocks, S, L.nWindows,
-                     L.winPtr.get());
+                       M.idx.get(), M.val.get(), L.nnzShort, Rw, L.minorBits, L.ent.get(), L.val.get());
   PDLP_HIP(hipStreamSynchronize(s));
 }
 

@@ -60,15 +60,16 @@ void gpuPrepare(const pdlp_problem_t& P, bool doScale, hipStream_t s, DeviceProb
 
 // Slab layout (pdlp_host.hpp SlabLayout) built on the device from a device CSR.
 struct DeviceSlabLayout {
-  int32_t rowsPerBlock = 0, nBlocks = 0, nSlabs = 0, nWindows = 0, nLong = 0;
+  int32_t rowsPerBlock = 0, rowsPerWave = 0, nBlocks = 0, minorBits = 0, nLong = 0;
   int64_t nnzShort = 0;
-  DeviceArray<int32_t> winPtr, winBeg;
-  DeviceArray<uint32_t> winInfo, ent, longMask;
+  DeviceArray<int32_t> wavePtr;
+  DeviceArray<uint32_t> ent, longMask;
   DeviceArray<double> val;
   DeviceCsrData longCsr;            // compacted long majors (major[] unused)
   DeviceArray<int32_t> longMap;     // compact index -> major
   std::vector<int32_t> hostLongBeg; // for the stream plan of the side kernel
 };
-void gpuBuildSlabLayout(const DeviceCsrData& M, int32_t longLimit, hipStream_t s, DeviceSlabLayout& out);
+void gpuBuildSlabLayout(const DeviceCsrData& M, int32_t longLimit, int32_t slabWidthLog2, hipStream_t s,
+                        DeviceSlabLayout& out);
 
 }  // namespace pdlp

@@ -30,32 +30,38 @@ constexpr int32_t kSlabLongLimit = 256;
 constexpr int32_t kSlabAutoMinor = 1 << 18;
 }  // namespace
 
+namespace {
+int32_t slabWidthLog2() {
+  if (const char* e = getenv("PDLP_MI355X_SLAB_W")) return atoi(e);  // development switch
+  return kSlabWidthLog2;
+}
+// mode (PDLP_MI355X_SLAB or auto) -> is the slab layout used for an operand of this shape
+bool chooseSlab(int mode, int32_t nMajor, int32_t nMinor) {
+  const bool want = mode == 1 || (mode < 0 && nMinor >= kSlabAutoMinor);
+  return want && slabRowsPerWave(nMajor, nMinor) != 0;  // minors that do not fit the packing: CSR stream
+}
+}  // namespace
+
 void DeviceMatrix::upload(const Compressed& cIn, int32_t nMajor_, int32_t nMinor_, int mode, hipStream_t s) {
   nMajor = nMajor_;
   nnz = cIn.beg.empty() ? 0 : cIn.beg[nMajor_];
-  useSlab = mode == 1 || (mode < 0 && nMinor_ >= kSlabAutoMinor);
+  useSlab = chooseSlab(mode, nMajor_, nMinor_);
   const Compressed* c = &cIn;
   SlabLayout L;
   if (useSlab) {
-    buildSlabLayout(cIn, nMajor_, nMinor_, kSlabLongLimit, L);
+    buildSlabLayout(cIn, nMajor_, nMinor_, kSlabLongLimit, slabWidthLog2(), L);
     if (L.rowsPerBlock > kSlabMaxRows) throw std::runtime_error("slab layout: too many majors per block");
-    winPtr.alloc(L.winPtr.size());
-    winBeg.alloc(L.winBeg.size() + 1);
-    winInfo.alloc(L.winInfo.size() + 1);
-    winBeg.zero(s);
-    winInfo.zero(s);
-    winPtr.upload(L.winPtr.data(), L.winPtr.size(), s);
-    winBeg.upload(L.winBeg.data(), L.winBeg.size(), s);
-    winInfo.upload(L.winInfo.data(), L.winInfo.size(), s);
-    ent.alloc(L.ent.size() + kSlabThreads);  // pad: a window's 256 lanes load unconditionally
-    slabVal.alloc(L.val.size() + kSlabThreads);
+    wavePtr.alloc(L.wavePtr.size());
+    wavePtr.upload(L.wavePtr.data(), L.wavePtr.size(), s);
+    ent.alloc(L.ent.size() + 1);  // one pad element: an empty wave still reads its first entry
+    slabVal.alloc(L.val.size() + 1);
     longMask.alloc(L.longMask.size());
     ent.zero(s);
     slabVal.zero(s);
     ent.upload(L.ent.data(), L.ent.size(), s);
     slabVal.upload(L.val.data(), L.val.size(), s);
     longMask.upload(L.longMask.data(), L.longMask.size(), s);
-    slab = SlabMat{winPtr.get(), winBeg.get(), winInfo.get(), ent.get(), slabVal.get(), longMask.get(), nMajor_, L.nBlocks, L.nSlabs, L.rowsPerBlock};
+    slab = SlabMat{wavePtr.get(), ent.get(), slabVal.get(), longMask.get(), nMajor_, L.nBlocks, L.rowsPerBlock, L.minorBits};
     c = &L.longCsr;
     majorMap.alloc(L.longMap.size());
     majorMap.upload(L.longMap.data(), L.longMap.size(), s);
@@ -80,21 +86,18 @@ void DeviceMatrix::upload(const Compressed& cIn, int32_t nMajor_, int32_t nMinor
 void DeviceMatrix::buildFromDevice(DeviceCsrData& M, int mode, hipStream_t s) {
   nMajor = M.nMajor;
   nnz = M.nnz;
-  useSlab = mode == 1 || (mode < 0 && M.nMinor >= kSlabAutoMinor);
+  useSlab = chooseSlab(mode, M.nMajor, M.nMinor);
   std::vector<int32_t> hostBeg;
   int32_t nCsrMajor = nMajor;
   if (useSlab) {
     DeviceSlabLayout L;
-    gpuBuildSlabLayout(M, kSlabLongLimit, s, L);
+    gpuBuildSlabLayout(M, kSlabLongLimit, slabWidthLog2(), s, L);
     if (L.rowsPerBlock > kSlabMaxRows) throw std::runtime_error("slab layout: too many majors per block");
-    winPtr = std::move(L.winPtr);
-    winBeg = std::move(L.winBeg);
-    winInfo = std::move(L.winInfo);
+    wavePtr = std::move(L.wavePtr);
     ent = std::move(L.ent);
     slabVal = std::move(L.val);
     longMask = std::move(L.longMask);
-    slab = SlabMat{winPtr.get(), winBeg.get(), winInfo.get(), ent.get(), slabVal.get(), longMask.get(),
-                   nMajor, L.nBlocks, L.nSlabs, L.rowsPerBlock};
+    slab = SlabMat{wavePtr.get(), ent.get(), slabVal.get(), longMask.get(), nMajor, L.nBlocks, L.rowsPerBlock, L.minorBits};
     beg = std::move(L.longCsr.beg);
     idx = std::move(L.longCsr.idx);
     val = std::move(L.longCsr.val);

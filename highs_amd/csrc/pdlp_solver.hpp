@@ -20,8 +20,8 @@ namespace pdlp {
 
 // One operand matrix in HBM: CSR stream plan, or slab layout + CSR side matrix of long majors.
 struct DeviceMatrix {
-  DeviceArray<int32_t> beg, idx, blockBeg, majorMap, winPtr, winBeg;
-  DeviceArray<uint32_t> ent, longMask, winInfo;
+  DeviceArray<int32_t> beg, idx, blockBeg, majorMap, wavePtr;
+  DeviceArray<uint32_t> ent, longMask;
   DeviceArray<double> val, slabVal;
   int32_t nMajor = 0, nBlocks = 0;  // nBlocks = CSR stream blocks
   int64_t nnz = 0;

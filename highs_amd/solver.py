@@ -19,6 +19,8 @@ from .lp import HighsLp, kkt_measures
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpdlp_mi355x.so")
+if os.environ.get("PDLP_MI355X_LIB"):  # development: an experimental build of the same library
+    LIB_PATH = os.environ["PDLP_MI355X_LIB"]
 
 # HighsModelStatus values (lp_data/HConst.h, highs_c_api.h:74-91)
 kSolveError, kOptimal, kInfeasible, kUnboundedOrInfeasible, kUnbounded = 4, 7, 8, 9, 10
@@ -300,9 +302,10 @@ class Prepared:
         for which in (0, 1):
             SL = abi.PdlpSlabLayout()
             _check(lib().pdlp_mi355x_host_slab_layout(C.byref(F), which, slab_long_limit, C.byref(SL)), "slab_layout")
-            nb, ns, R = SL.n_blocks, SL.n_slabs, SL.rows_per_block
+            nb, R = SL.n_blocks, SL.rows_per_block
             self._slabs[which] = dict(
-                rows_per_block=R, n_blocks=nb, n_slabs=ns, seg_ptr=g(SL.seg_ptr, nb * (ns + 1), np.int64),
+                rows_per_block=R, rows_per_wave=SL.rows_per_wave, n_blocks=nb, minor_bits=SL.minor_bits,
+                slab_width_log2=SL.slab_width_log2, wave_ptr=g(SL.wave_ptr, 16 * nb + 1, np.int64),
                 ent=g(SL.ent, SL.nnz_short, np.uint32), val=g(SL.val, SL.nnz_short, np.float64),
                 long_mask=g(SL.long_mask, nb * (R // 32), np.uint32), long_map=g(SL.long_map, SL.n_long, np.int32))
             lib().pdlp_mi355x_free_slab_layout(C.byref(SL))

@@ -267,18 +267,17 @@ void pdlp_mi355x_free_prepared(pdlp_prepared_t* out);
 /* Row-block partition used by create_sharded: offsets[world+1]. */
 int pdlp_mi355x_row_partition(const pdlp_prepared_t* prep, int32_t world,
                               int32_t* offsets);
-/* The row-block x column-slab layout the GPU SpMV uses for large operands
- * (see DESIGN.md "slab SpMV"), built on the host for inspection by the CPU tests:
- * which = 0 -> A (rows), 1 -> A' (columns).  Arrays malloc'ed; free with
+/* The slab layout the GPU SpMV uses for large operands (see DESIGN.md "slab SpMV"), built on the
+ * host for inspection by the CPU tests: which = 0 for A (rows), 1 for A' (columns).  Free with
  * pdlp_mi355x_free_slab_layout. */
 typedef struct pdlp_slab_layout {
-  int32_t rows_per_block, n_blocks, n_slabs, n_long;
+  int32_t rows_per_block, rows_per_wave, n_blocks, minor_bits, slab_width_log2, n_long;
   int64_t nnz_short;
-  int32_t* seg_ptr;   /* [n_blocks*(n_slabs+1)] */
-  uint32_t* ent;      /* [nnz_short] (local_major<<16 | minor - 65536*slab) */
+  int32_t* wave_ptr;  /* [16*n_blocks+1] */
+  uint32_t* ent;      /* [nnz_short] (local_major << minor_bits | minor), local to the owning wave */
   double* val;        /* [nnz_short] */
-  uint32_t* long_mask; /* [n_blocks*rows_per_block/32] */
-  int32_t* long_map;  /* [n_long] majors handled by the CSR side kernel */
+  uint32_t* long_mask;/* [n_blocks*rows_per_block/32] */
+  int32_t* long_map;  /* [n_long] */
 } pdlp_slab_layout_t;
 int pdlp_mi355x_host_slab_layout(const pdlp_prepared_t* prep, int32_t which,
                                  int32_t long_limit, pdlp_slab_layout_t* out);

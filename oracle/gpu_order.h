@@ -13,6 +13,22 @@
 #include <string.h>
 
 enum { G_T = 256, G_WAVE = 64, G_CHUNK = 2048, G_MAXMAJ = 2048, G_MAXGRID = 2048 };
+/* slab SpMV (k_spmv_slab): 1024-thread blocks of 16 waves, rows per wave by slabRowsPerWave (pdlp_host.cpp) */
+enum { G_SLAB_T = 1024, G_SLAB_WAVES = 16, G_SLAB_BLOCKS = 256 };
+static inline int g_slab_rows_per_wave(int nMajor, int nMinor) {
+  const long waves = (long)G_SLAB_BLOCKS * G_SLAB_WAVES;
+  long rw = ((long)nMajor + waves - 1) / waves;
+  rw = (rw + 1) / 2 * 2;
+  if (rw < 16) rw = 16;
+  if (rw > 512) rw = 512;
+  for (;;) {
+    int rb = 0;
+    while ((1L << rb) < rw) ++rb;
+    if ((1L << (32 - rb)) >= (long)nMinor) return (int)rw;
+    if (rw <= 16) return 0;
+    rw = (rw / 2 + 1) / 2 * 2;
+  }
+}
 
 static inline double g_wave_tree(const double* lane /* [64] */) {
   double v[G_WAVE], t[G_WAVE];
@@ -23,11 +39,12 @@ static inline double g_wave_tree(const double* lane /* [64] */) {
   }
   return v[0];
 }
-static inline double g_block_sum(const double* perThread /* [256] */) {
+static inline double g_block_sum_n(const double* perThread, int nThreads) {
   double r = 0.0;
-  for (int w = 0; w < G_T / G_WAVE; ++w) r += g_wave_tree(perThread + w * G_WAVE);
+  for (int w = 0; w < nThreads / G_WAVE; ++w) r += g_wave_tree(perThread + w * G_WAVE);
   return r;
 }
+static inline double g_block_sum(const double* perThread /* [256] */) { return g_block_sum_n(perThread, G_T); }
 /* reducePartials: lane t sums p[t], p[t+256], ... in 4 independent chains */
 static inline double g_reduce_partials(const double* p, int count) {
   double lane[G_T];

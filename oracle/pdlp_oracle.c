@@ -390,12 +390,9 @@ static double g_block_partial(const int* plan, int blk, const double* perMajor) 
 }
 enum { G_SLAB_LONG = 256, G_SLAB_AUTO_MINOR = 1 << 18 };
 /* slab layout parameters of one operand (pdlp_host.cpp buildSlabLayout) */
-static void g_slab_setup(const int* beg, int nMajor, long nnz, int* R, int* nLong, int** longMap, int** longBeg,
+static void g_slab_setup(const int* beg, int nMajor, int nMinor, int* R, int* nLong, int** longMap, int** longBeg,
                          int** sidePlan, int* nSidePlan) {
-  const double avg = nMajor > 0 ? (double)nnz / nMajor : 1.0;
-  int r = 256;
-  while (r < 4096 && (double)r * avg < 3000.0) r *= 2;
-  *R = r;
+  *R = g_slab_rows_per_wave(nMajor, nMinor) * G_SLAB_WAVES;
   int nl = 0;
   for (int i = 0; i < nMajor; ++i) if (beg[i + 1] - beg[i] > G_SLAB_LONG) ++nl;
   *nLong = nl;
@@ -424,16 +421,18 @@ static void g_setup(Work* w, int layoutMode) {
   /* layoutMode: 0 = the product's automatic rule, 1 = CSR stream, 2 = slab */
   w->slabA = layoutMode == 2 || (layoutMode == 0 && n >= G_SLAB_AUTO_MINOR);   /* A gathers x (n) */
   w->slabAt = layoutMode == 2 || (layoutMode == 0 && m >= G_SLAB_AUTO_MINOR);  /* A' gathers y (m) */
-  if (w->slabA) g_slab_setup(w->csrBeg, m, w->nnz, &w->RA, &w->nLongA, &w->longMapA, &w->longBegA, &w->planA, &w->nPlanA);
+  if (w->slabA && g_slab_rows_per_wave(m, n) == 0) w->slabA = 0;   /* minors do not fit the entry packing */
+  if (w->slabAt && g_slab_rows_per_wave(n, m) == 0) w->slabAt = 0;
+  if (w->slabA) g_slab_setup(w->csrBeg, m, n, &w->RA, &w->nLongA, &w->longMapA, &w->longBegA, &w->planA, &w->nPlanA);
   else w->planA = g_plan(w->csrBeg, m, &w->nPlanA);
-  if (w->slabAt) g_slab_setup(w->cssBeg, n, w->nnz, &w->RAt, &w->nLongAt, &w->longMapAt, &w->longBegAt, &w->planAt, &w->nPlanAt);
+  if (w->slabAt) g_slab_setup(w->cssBeg, n, m, &w->RAt, &w->nLongAt, &w->longMapAt, &w->longBegAt, &w->planAt, &w->nPlanAt);
   else w->planAt = g_plan(w->cssBeg, n, &w->nPlanAt);
   const long mx = (n > m ? n : m) + G_MAXGRID + 8;
   w->gPartA = dalloc(mx); w->gPartB = dalloc(mx); w->gStat = dalloc(mx);
 }
 
 /* Fixed-order total of a per-major quantity exactly as the SpMV epilogues + k_decide add it up.
- * CSR stream: one partial per work block.  Slab: one partial per block of R majors (long majors
+ * CSR stream: one partial per work block.  Slab: one partial per 1024-thread block of R majors (long majors
  * skipped), then one per work block of the CSR side kernel over the compacted long majors. */
 static double g_epilogue_total(Work* w, int isAt, const double* perMajor) {
   const int nMajor = isAt ? w->n : w->m;
@@ -450,16 +449,16 @@ static double g_epilogue_total(Work* w, int isAt, const double* perMajor) {
   const int* beg = isAt ? w->cssBeg : w->csrBeg;
   const int* longMap = isAt ? w->longMapAt : w->longMapA;
   const int nBlocks = (nMajor + R - 1) / R;
-  for (int b = 0; b < nBlocks; ++b) {
-    double lane[G_T];
+  for (int b = 0; b < nBlocks; ++b) { /* k_spmv_slab: 1024 threads, thread t owns majors b*R + t, + 1024, ... */
+    double lane[G_SLAB_T];
     const int rEnd = (b + 1) * R < nMajor ? (b + 1) * R : nMajor;
-    for (int t = 0; t < G_T; ++t) {
+    for (int t = 0; t < G_SLAB_T; ++t) {
       double a = 0.0;
-      for (int r = b * R + t; r < rEnd; r += G_T)
+      for (int r = b * R + t; r < rEnd; r += G_SLAB_T)
         if (beg[r + 1] - beg[r] <= G_SLAB_LONG) a += perMajor[r];
       lane[t] = a;
     }
-    part[np++] = g_block_sum(lane);
+    part[np++] = g_block_sum_n(lane, G_SLAB_T);
   }
   for (int b = 0; b < nPlan; ++b) { /* side kernel: compact major c stands for major longMap[c] */
     double lane[G_T];

@@ -139,16 +139,12 @@ def test_solver_mirror_runs_against_oracle():
 
 def _slab_to_coo(sl, n_major):
     """Rebuild (major, minor, value) triplets from the slab layout, in storage order."""
-    R, nb, ns = sl["rows_per_block"], sl["n_blocks"], sl["n_slabs"]
-    seg = sl["seg_ptr"].reshape(nb, ns + 1)
-    ent, val = sl["ent"], sl["val"]
-    majors = np.empty(len(ent), np.int64)
-    minors = np.empty(len(ent), np.int64)
-    for b in range(nb):
-        for k in range(ns):
-            s, e = seg[b, k], seg[b, k + 1]
-            majors[s:e] = b * R + (ent[s:e] >> 16)
-            minors[s:e] = (k << 16) + (ent[s:e] & 0xFFFF)
+    Rw, mb = sl["rows_per_wave"], sl["minor_bits"]
+    wp = sl["wave_ptr"]
+    ent, val = sl["ent"].astype(np.int64), sl["val"]
+    wave = np.repeat(np.arange(len(wp) - 1), np.diff(wp))
+    majors = wave * Rw + (ent >> mb)
+    minors = ent & ((1 << mb) - 1)
     return majors, minors, val
 
 
@@ -177,10 +173,15 @@ def test_slab_layout_is_a_permutation_of_the_csr(which, long_limit):
     # same multiset of triplets
     a = np.lexsort((mnr, maj))
     assert np.array_equal(maj[a], rows_csr[keep]) and np.array_equal(mnr[a], idx[keep]) and np.array_equal(v[a], val[keep])
-    # storage order: within a block sorted by (slab, major, minor); so per major minors ascend
+    # storage order: within a wave sorted by (slab, major, minor); so per major minors ascend
     cand = np.nonzero(short & (lens > 1))[0]
     for r in (np.random.default_rng(0).choice(cand, size=min(50, len(cand)), replace=False) if len(cand) else []):
         pos = np.nonzero(maj == r)[0]
         assert np.all(np.diff(pos) > 0) and np.all(np.diff(mnr[pos]) > 0)
-    blk = maj // R
-    assert np.all(np.diff(blk) >= 0)
+    Rw, W = sl["rows_per_wave"], sl["slab_width_log2"]
+    assert R == 16 * Rw and Rw % 2 == 0 and (1 << sl["minor_bits"]) >= (P.n if which == 0 else P.m)
+    wave = maj // Rw
+    assert np.all(np.diff(wave) >= 0)
+    # inside a wave the key (slab, local major, minor) ascends
+    key = (wave << 52) | ((mnr >> W) << 40) | ((maj % Rw) << 28) | (mnr & ((1 << W) - 1))
+    assert np.all(np.diff(key) > 0)
