@@ -29,6 +29,7 @@ CONFIGS = {
     # BASELINE.json configs[1]
     "a": dict(m=100_000, n=100_000, nnz=1_000_000, name="synthetic random sparse LP 100kx100k, 1M nnz (seed 1)"),
 }
+PRE_ROLL = 40  # iterations of start-up excluded from every timed window
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured copy ceiling
 
 
@@ -92,8 +93,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs a torch.distributed.run launch with %d ranks" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with `python -m torch.distributed.run --nproc-per-node %d "
+                         "... bench.py --gpus %d`" % (args.gpus, world, args.gpus, args.gpus))
     cfg = CONFIGS[args.config]
 
     import torch
@@ -136,6 +137,15 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    # Start-up phase, reported separately: the reference checks convergence at EVERY one of the first 10
+    # iterations (cupdlp_solver.c:953-962) and restarts for the first time; from iteration 40 on the
+    # schedule is one check in 40.  The timed region therefore never starts before iteration 40, whatever
+    # --warmup says (the hipGraph of a trial batch is captured in create(), i.e. in setup_seconds).
+    sync()
+    t0 = time.perf_counter()
+    S.iterate(PRE_ROLL)
+    sync()
+    startup_ms = (time.perf_counter() - t0) * 1e3
     S.iterate(args.warmup)
     sync()
     t0 = time.perf_counter()
@@ -163,6 +173,17 @@ def main():
         rank_consistent = bool(lo.item() == hi.item())
     b_iter, b_ax, b_aty = (algorithmic_bytes if args.solver == "pdlp" else algorithmic_bytes_hipdlp)(n, m, nnz)
     ms_step = elapsed * 1e3 / st.iters
+    # long-run rate over >= 400 further iterations (whole multiples of the 40-iteration check period), so that
+    # a short --steps window (which may contain no check iteration at all) can be read next to the average
+    sync()
+    t0 = time.perf_counter()
+    ss = S.iterate(max(400, (args.steps + 39) // 40 * 40))
+    sync()
+    ss_elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([ss_elapsed], dtype=torch.float64, device=tdev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ss_elapsed = float(tt.item())
     # dominant kernel, timed live with HIP events on the solver's own stream, IN the loop (same
     # kernel sequence and cache state as the timed region; what rocprofv3 --kernel-trace reports)
     iso_ax = S.time_kernel("spmv_ax", 50)
@@ -201,11 +222,18 @@ def main():
                    "options": "presolve=off, kkt_tolerance=1e-4, adaptive step + restarts (reference defaults)"},
         "trial_steps": int(st.trials), "rejected_trials": int(st.trials - st.iters), "checks": int(st.checks),
         "restarts": int(st.restarts), "setup_seconds": t_setup, "ranks_bit_identical": rank_consistent,
+        "startup_ms_first_40": startup_ms, "timed_window": "iterations %d..%d" % (PRE_ROLL + args.warmup,
+                                                                                  PRE_ROLL + args.warmup + int(st.iters)),
+        "steady_state": {"value": ss.iters / ss_elapsed, "unit": "it/s", "iters": int(ss.iters), "checks": int(ss.checks),
+                         "restarts": int(ss.restarts), "ms_per_step": ss_elapsed * 1e3 / ss.iters},
         "iter_algorithmic_bytes": b_iter,
         "iter_hbm_gbs": b_iter / (ms_step * 1e-3) / 1e9,
         "iter_hbm_frac_of_peak": b_iter / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS / world,
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_source": "profiles/pmc_traffic.json (static: rocprofv3 --pmc passes of tools/pmc.sh, not "
+                                       "measured in this run)" if traffic is not None else None,
+                     "algorithmic_bytes_per_launch": dom_bytes,
                      "measured_copy_ceiling_gbs": copy_gbs,
                      "frac_of_copy_ceiling": (achieved / copy_gbs) if copy_gbs else None,
                      "avg_launch_ms": dom_ms, "timed_launches_in_loop": prof_launches,
@@ -215,7 +243,7 @@ def main():
     if args.solver == "hipdlp":
         out["config"]["options"] = "presolve=off, kkt_tolerance=1e-4, Halpern restarts + PID primal weight (reference defaults)"
     if args.kernels and rank == 0 and world == 1 and args.solver == "pdlp":
-        ks = {k: S.time_kernel(k, 50) for k in ("primal_step", "spmv_ax", "spmv_aty", "decide", "trial",
+        ks = {k: S.time_kernel(k, 50) for k in ("decide_primal", "primal_step", "spmv_ax", "spmv_aty", "decide", "trial",
                                                 "spmv_ax_plain", "spmv_aty_plain", "copy")}
         ks["copy_GBs"] = 2 * 512 * 2**20 / (ks["copy"] * 1e-3) / 1e9
         print(json.dumps({"kernels_ms": ks}), file=sys.stderr)

@@ -88,6 +88,7 @@ __device__ __attribute__((unused)) void decideUpdate(DevState* st, double dX2, d
   }
   s.dX2 = dX2; s.dY2 = dY2; s.inter = inter; s.movement = movement; s.limit = limit;
   s.lastAccepted = accept ? 1 : 0;
+  s.pending = 0;
   if (accept) {
     if (s.adaptive) {
       s.primalStep = etaNew / sqrt(s.beta);

@@ -416,16 +416,13 @@ __global__ __launch_bounds__(kVecThreads) void k_reduce_to(const double* partial
   if (threadIdx.x == 0) *out = s;
 }
 
-// k_decide: the decision kernel (one block).  All partial loads of the three sums are issued
-// together and reduced in one pass — the kernel is pure latency (it sits between two trials).
-__global__ __launch_bounds__(kVecThreads) void k_decide(DevState* st, const double* __restrict__ partDY, int nDY,
-                                                        const double* __restrict__ partDX,
-                                                        const double* __restrict__ partInter, int nDX,
-                                                        const double* dyGlobal) {
-  if (st->halted) return;
-  __shared__ double scratch[3][kVecThreads / kWave];
+// Fixed-order sums of the three per-block partial arrays by one 256-thread block: lane t sums elements
+// t, t+256, ... (4 independent chains), then wave shuffle tree, then the 4 wave results in order.
+// Results valid in thread 0.  Shared by k_decide and k_decide_primal, so both take identical decisions.
+__device__ __forceinline__ void trialSums(const double* __restrict__ partDY, int nDY, const double* __restrict__ partDX,
+                                          const double* __restrict__ partInter, int nDX, double (*scratch)[kVecThreads / kWave],
+                                          double& dY2, double& dX2, double& inter) {
   const int tid = threadIdx.x;
-  // fixed order: lane t sums elements t, t+256, ... (4 independent chains), then wave/LDS tree
   auto laneSum = [&](const double* __restrict__ p, int count) {
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int i = tid;
@@ -436,18 +433,83 @@ __global__ __launch_bounds__(kVecThreads) void k_decide(DevState* st, const doub
     for (; i < count; i += kVecThreads) s0 += p[i];
     return (s0 + s1) + (s2 + s3);
   };
-  double vY = dyGlobal ? 0.0 : laneSum(partDY, nDY);
+  double vY = partDY ? laneSum(partDY, nDY) : 0.0;
   double vX = laneSum(partDX, nDX);
   double vI = laneSum(partInter, nDX);
   vY = waveSum(vY); vX = waveSum(vX); vI = waveSum(vI);
   const int lane = tid & (kWave - 1), w = tid / kWave;
   if (lane == 0) { scratch[0][w] = vY; scratch[1][w] = vX; scratch[2][w] = vI; }
   __syncthreads();
-  if (tid != 0) return;
-  double dY2 = 0.0, dX2 = 0.0, inter = 0.0;
+  dY2 = dX2 = inter = 0.0;
+  if (tid == 0) {
 #pragma unroll
-  for (int i = 0; i < kVecThreads / kWave; ++i) { dY2 += scratch[0][i]; dX2 += scratch[1][i]; inter += scratch[2][i]; }
+    for (int i = 0; i < kVecThreads / kWave; ++i) { dY2 += scratch[0][i]; dX2 += scratch[1][i]; inter += scratch[2][i]; }
+  }
+}
+
+// k_decide: the decision kernel (one block).  All partial loads of the three sums are issued
+// together and reduced in one pass — the kernel is pure latency (it sits between two trials).
+__global__ __launch_bounds__(kVecThreads) void k_decide(DevState* st, const double* __restrict__ partDY, int nDY,
+                                                        const double* __restrict__ partDX,
+                                                        const double* __restrict__ partInter, int nDX,
+                                                        const double* dyGlobal, int onlyIfPending) {
+  if (st->halted) return;
+  if (onlyIfPending && !st->pending) return;
+  __shared__ double scratch[3][kVecThreads / kWave];
+  double dY2, dX2, inter;
+  trialSums(dyGlobal ? nullptr : partDY, nDY, partDX, partInter, nDX, scratch, dY2, dX2, inter);
+  if (threadIdx.x != 0) return;
   decideUpdate(st, dX2, dyGlobal ? *dyGlobal : dY2, inter);
+}
+
+// Single-GPU loop: decision of the previous trial + primal step of this one in ONE launch (see
+// launchDecidePrimal).  x+ = clamp(x - tau (c - A'y), l, u): cupdlp_step.c:16-40, rounding as the CPU branch.
+__global__ __launch_bounds__(kVecThreads) void k_decide_primal(const IterVecs v, const DevState* __restrict__ stIn,
+                                                               DevState* __restrict__ stOut,
+                                                               const double* __restrict__ partDY, int nDY,
+                                                               const double* __restrict__ partDX,
+                                                               const double* __restrict__ partInter, int nDX) {
+  const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
+  if (stIn->halted) {  // keep the two slots identical while the queue drains
+    if (writer) *stOut = *stIn;
+    return;
+  }
+  __shared__ double scratch[3][kVecThreads / kWave];
+  __shared__ DevState sh;
+  if (stIn->pending) {
+    double dY2, dX2, inter;
+    trialSums(partDY, nDY, partDX, partInter, nDX, scratch, dY2, dX2, inter);
+    if (threadIdx.x == 0) {
+      sh = *stIn;
+      decideUpdate(&sh, dX2, dY2, inter);
+    }
+  } else if (threadIdx.x == 0) {
+    sh = *stIn;
+  }
+  __syncthreads();
+  const int halted = sh.halted, cur = sh.cur, nxt = cur ^ 1;
+  const double tau = sh.tau, avgW = sh.avgW;
+  if (writer) {
+    DevState t = sh;
+    t.pending = halted ? 0 : 1;
+    *stOut = t;
+  }
+  if (halted) return;
+  const double* __restrict__ x = v.x[cur];
+  const double* __restrict__ aty = v.aty[cur];
+  double* __restrict__ xn = v.x[nxt];
+  const int stride = gridDim.x * blockDim.x;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < v.n; j += stride) {
+    const double xv = ldStream(x + j);
+    if (avgW != 0.0) stStream(v.xSum + j, ldStream(v.xSum + j) + avgW * xv);  // deferred PDHG_Update_Average (step.c:437)
+    double t = xv;
+    t += (-tau) * ldStream(v.cost + j);
+    t += tau * ldStream(aty + j);
+    const double u = ldStream(v.upper + j), l = ldStream(v.lower + j);
+    t = t < u ? t : u;
+    t = t > l ? t : l;
+    xn[j] = t;  // gathered by the A x+ kernel: ordinary store
+  }
 }
 
 // Apply a pending average update (before a check iteration reads xSum/ySum).
@@ -672,8 +734,14 @@ void launchReduceTo(const double* partials, int32_t count, double* out, const De
   hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(kVecThreads), 0, s, partials, count, out, st);
 }
 void launchDecide(DevState* st, const double* partDY, int32_t nDY, const double* partDX, const double* partInter,
-                  int32_t nDX, const double* dyGlobal, hipStream_t s) {
-  hipLaunchKernelGGL(k_decide, dim3(1), dim3(kVecThreads), 0, s, st, partDY, nDY, partDX, partInter, nDX, dyGlobal);
+                  int32_t nDX, const double* dyGlobal, hipStream_t s, bool onlyIfPending) {
+  hipLaunchKernelGGL(k_decide, dim3(1), dim3(kVecThreads), 0, s, st, partDY, nDY, partDX, partInter, nDX, dyGlobal,
+                     onlyIfPending ? 1 : 0);
+}
+void launchDecidePrimal(const IterVecs& v, const DevState* stIn, DevState* stOut, const double* partDY, int32_t nDY,
+                        const double* partDX, const double* partInter, int32_t nDX, hipStream_t s) {
+  hipLaunchKernelGGL(k_decide_primal, dim3(vecBlocks(v.n)), dim3(kVecThreads), 0, s, v, stIn, stOut, partDY, nDY, partDX,
+                     partInter, nDX);
 }
 void launchFlushAverage(const IterVecs& v, DevState* st, hipStream_t s) {
   hipLaunchKernelGGL(k_flush_average, dim3(vecBlocks(v.n + v.m)), dim3(kVecThreads), 0, s, v, st);

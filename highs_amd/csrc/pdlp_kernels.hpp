@@ -40,6 +40,8 @@ struct DevState {
   int32_t powBase;
   int32_t powCount;
   int32_t commError;     // a mesh exchange wait timed out (sharded path)
+  int32_t pending;       // single-GPU loop: a trial has been computed whose accept/reject decision is still to be taken
+  int32_t pad_;
   const double* powRed;
   const double* powGrow;
 };
@@ -120,6 +122,12 @@ void launchHalpernPrimal(const MatView& At, const HalpernVecs& h, hipStream_t s)
 void launchHalpernDual(const MatView& A, const HalpernVecs& h, hipStream_t s);
 
 // ---- per-trial kernels ----------------------------------------------------
+// Single-GPU loop, first launch of a trial: takes the accept/reject decision of the PREVIOUS trial (if one is
+// pending: every block re-reduces the per-block partials in the fixed order of k_decide and comes to the same
+// result), then the primal step of this trial with the new step sizes.  Reads *stIn, block 0 writes *stOut
+// (the two slots alternate from trial to trial, so no block can read a half-written state).
+void launchDecidePrimal(const IterVecs& v, const DevState* stIn, DevState* stOut, const double* partDY, int32_t nDY,
+                        const double* partDX, const double* partInter, int32_t nDX, hipStream_t s);
 void launchPrimalStep(const IterVecs& v, const DevState* st, hipStream_t s);
 // ax_next = A x_next fused with the dual step; writes per-block sum (dy)^2 to partDY[block]
 void launchSpmvAxDual(const MatView& A, const IterVecs& v, const DevState* st, double* partDY, hipStream_t s);
@@ -133,9 +141,10 @@ void launchInteract(const IterVecs& v, const DevState* st, const double* atyRedu
                     double* partInter, int32_t nBlocks, hipStream_t s);
 // sums partials[0..count) deterministically into *out (one block)
 void launchReduceTo(const double* partials, int32_t count, double* out, const DevState* st, hipStream_t s);
-// accept/reject + step-size update; dyGlobal != nullptr -> use *dyGlobal instead of partDY
+// accept/reject + step-size update; dyGlobal != nullptr -> use *dyGlobal instead of partDY;
+// onlyIfPending: the flush of the single-GPU loop (no-op unless st->pending)
 void launchDecide(DevState* st, const double* partDY, int32_t nDY, const double* partDX, const double* partInter,
-                  int32_t nDX, const double* dyGlobal, hipStream_t s);
+                  int32_t nDX, const double* dyGlobal, hipStream_t s, bool onlyIfPending = false);
 
 // ---- check-iteration kernels (host knows the parity here) -------------------
 void launchFlushAverage(const IterVecs& v, DevState* st, hipStream_t s);

@@ -282,6 +282,8 @@ void Solver::construct(const pdlp_problem_t& P, const void* id128) {
   if (gpuSetup_) uploadProblemFromDevice(devProb);
   else uploadProblem();
   reset();
+  // the trial-batch graph is part of the setup, not of the first iterations
+  if (useGraph_ && (!sharded_ || meshMode_)) captureGraph();
   PDLP_HIP(hipStreamSynchronize(stream_));
   setupSeconds_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
@@ -356,7 +358,8 @@ void Solver::allocIterates() {
   statOut_.alloc(kStatTotal + 8);
   commBuf_.alloc((size_t)n + 8);
   commBuf_.zero(stream_);
-  dState_.alloc(1);
+  dState_.alloc(2);
+  dState_.zero(stream_);
   PDLP_HIP(hipHostMalloc((void**)&hostState_, sizeof(DevState), hipHostMallocDefault));
   PDLP_HIP(hipHostMalloc((void**)&hostStats_, sizeof(double) * (kStatTotal + 8), hipHostMallocDefault));
   memset(hostState_, 0, sizeof(DevState));
@@ -383,7 +386,11 @@ void Solver::dims(int32_t* n, int32_t* m, int64_t* nnz, int32_t* nEqs) const {
 }
 
 void Solver::syncState() {
-  PDLP_HIP(hipMemcpyAsync(hostState_, dState_.get(), sizeof(DevState), hipMemcpyDeviceToHost, stream_));
+  // the decision of the last enqueued trial is still pending in the single-GPU loop: take it now
+  if (!sharded_)
+    launchDecide(dst(), partDY_.get(), dA_.nPartials(), partDX_.get(), partInter_.get(), dAt_.nPartials(), nullptr,
+                 stream_, true);
+  PDLP_HIP(hipMemcpyAsync(hostState_, dst(), sizeof(DevState), hipMemcpyDeviceToHost, stream_));
   PDLP_HIP(hipStreamSynchronize(stream_));
   if (hostState_->commError)
     throw std::runtime_error("pdlp_mi355x mesh: a peer did not answer in time (exchange timed out)");
@@ -414,7 +421,8 @@ void Solver::refreshPowTable() {
 
 void Solver::pushState() {
   refreshPowTable();
-  PDLP_HIP(hipMemcpyAsync(dState_.get(), hostState_, sizeof(DevState), hipMemcpyHostToDevice, stream_));
+  hostState_->pending = 0;
+  PDLP_HIP(hipMemcpyAsync(dst(), hostState_, sizeof(DevState), hipMemcpyHostToDevice, stream_));
   PDLP_HIP(hipStreamSynchronize(stream_));
 }
 
@@ -571,50 +579,69 @@ void Solver::enqueueTrial() {
     const MeshArgs& mv = mesh_->args();
     double* buf = commBuf_.get();
     const int32_t nb = meshGrid(std::max(nLoc_, 1));  // consumer grid: ~4 slice elements per thread
-    launchMeshPrimalStep(vecsCol_, dState_.get(), mv, stream_);
-    launchMeshWaitCopyX(vecs_, dState_.get(), mv, stream_);
-    launchSpmvAxDual(dA_.view(), vecs_, dState_.get(), partDY_.get(), stream_);
-    launchSpmvAtyPartial(dAt_.view(), vecs_, dState_.get(), buf, stream_);
-    launchMeshPushPartial(buf, F_.n, dState_.get(), mv, stream_);
-    launchMeshReduceInteract(vecsCol_, dState_.get(), mv, buf, partDX_.get(), partInter_.get(), nb, stream_);
-    launchMeshDecide(dState_.get(), mv, partDY_.get(), dA_.nPartials(), partDX_.get(), partInter_.get(), nb, stream_);
+    launchMeshPrimalStep(vecsCol_, dst(), mv, stream_);
+    launchMeshWaitCopyX(vecs_, dst(), mv, stream_);
+    launchSpmvAxDual(dA_.view(), vecs_, dst(), partDY_.get(), stream_);
+    launchSpmvAtyPartial(dAt_.view(), vecs_, dst(), buf, stream_);
+    launchMeshPushPartial(buf, F_.n, dst(), mv, stream_);
+    launchMeshReduceInteract(vecsCol_, dst(), mv, buf, partDX_.get(), partInter_.get(), nb, stream_);
+    launchMeshDecide(dst(), mv, partDY_.get(), dA_.nPartials(), partDX_.get(), partInter_.get(), nb, stream_);
     return;
   }
-  launchPrimalStep(vecs_, dState_.get(), stream_);
-  hipEvent_t* ev = nullptr;
-  if (profile_ && !sharded_) {
-    while ((int32_t)profEvents_.size() < 4 * (profTrialsQueued_ + 1)) {
-      hipEvent_t e;
-      PDLP_HIP(hipEventCreate(&e));
-      profEvents_.push_back(e);
-    }
-    ev = &profEvents_[4 * profTrialsQueued_++];
-    PDLP_HIP(hipEventRecord(ev[0], stream_));
-    launchSpmvAxDual(dA_.view(), vecs_, dState_.get(), partDY_.get(), stream_);
-    PDLP_HIP(hipEventRecord(ev[1], stream_));
-    launchSpmvAtyInteract(dAt_.view(), vecs_, dState_.get(), partDX_.get(), partInter_.get(), stream_);
-    PDLP_HIP(hipEventRecord(ev[2], stream_));
-    PDLP_HIP(hipEventRecord(ev[3], stream_));
-    launchDecide(dState_.get(), partDY_.get(), dA_.nPartials(), partDX_.get(), partInter_.get(), dAt_.nPartials(),
-                 nullptr, stream_);
-    return;
-  }
-  launchSpmvAxDual(dA_.view(), vecs_, dState_.get(), partDY_.get(), stream_);
   if (!sharded_) {
-    launchSpmvAtyInteract(dAt_.view(), vecs_, dState_.get(), partDX_.get(), partInter_.get(), stream_);
-    launchDecide(dState_.get(), partDY_.get(), dA_.nPartials(), partDX_.get(), partInter_.get(), dAt_.nPartials(),
-                 nullptr, stream_);
-  } else {
-    // row-block sharded: A_g' y_g partials are summed over the ranks together
-    // with the local sum (dy)^2 in one all-reduce of n+1 doubles
-    double* buf = commBuf_.get();
-    launchSpmvAtyPartial(dAt_.view(), vecs_, dState_.get(), buf, stream_);
-    launchReduceTo(partDY_.get(), dA_.nPartials(), buf + F_.n, dState_.get(), stream_);
-    comm_->allReduceSum(buf, (size_t)F_.n + 1, stream_);
-    const int32_t nb = vecBlocks(F_.n);
-    launchInteract(vecs_, dState_.get(), buf, partDX_.get(), partInter_.get(), nb, stream_);
-    launchDecide(dState_.get(), nullptr, 0, partDX_.get(), partInter_.get(), nb, buf + F_.n, stream_);
+    // single GPU: 3 launches per trial — [decision of the previous trial + primal step], A x+ (+ dual step),
+    // A' y+ (+ movement / interaction partials); the state alternates between the two slots
+    const DevState* stIn = dst();
+    stPar_ ^= 1;
+    DevState* st = dst();
+    launchDecidePrimal(vecs_, stIn, st, partDY_.get(), dA_.nPartials(), partDX_.get(), partInter_.get(),
+                       dAt_.nPartials(), stream_);
+    hipEvent_t* ev = nullptr;
+    if (profile_) {
+      while ((int32_t)profEvents_.size() < 4 * (profTrialsQueued_ + 1)) {
+        hipEvent_t e;
+        PDLP_HIP(hipEventCreate(&e));
+        profEvents_.push_back(e);
+      }
+      ev = &profEvents_[4 * profTrialsQueued_++];
+      PDLP_HIP(hipEventRecord(ev[0], stream_));
+    }
+    launchSpmvAxDual(dA_.view(), vecs_, st, partDY_.get(), stream_);
+    if (ev) PDLP_HIP(hipEventRecord(ev[1], stream_));
+    launchSpmvAtyInteract(dAt_.view(), vecs_, st, partDX_.get(), partInter_.get(), stream_);
+    if (ev) {
+      PDLP_HIP(hipEventRecord(ev[2], stream_));
+      PDLP_HIP(hipEventRecord(ev[3], stream_));
+    }
+    return;
   }
+  // row-block sharded, RCCL exchange: A_g' y_g partials are summed over the ranks together
+  // with the local sum (dy)^2 in one all-reduce of n+1 doubles
+  launchPrimalStep(vecs_, dst(), stream_);
+  launchSpmvAxDual(dA_.view(), vecs_, dst(), partDY_.get(), stream_);
+  double* buf = commBuf_.get();
+  launchSpmvAtyPartial(dAt_.view(), vecs_, dst(), buf, stream_);
+  launchReduceTo(partDY_.get(), dA_.nPartials(), buf + F_.n, dst(), stream_);
+  comm_->allReduceSum(buf, (size_t)F_.n + 1, stream_);
+  const int32_t nb = vecBlocks(F_.n);
+  launchInteract(vecs_, dst(), buf, partDX_.get(), partInter_.get(), nb, stream_);
+  launchDecide(dst(), nullptr, 0, partDX_.get(), partInter_.get(), nb, buf + F_.n, stream_);
+}
+
+// The batch of kGraphTrials (even) trials as one hipGraph.  Capturing enqueues nothing; the state-slot
+// parity the capture started with is restored afterwards and remembered for the launches.
+void Solver::captureGraph() {
+  if (graphExec_) return;
+  static_assert(kGraphTrials % 2 == 0, "the graph must leave the state-slot parity unchanged");
+  hipGraph_t graph = nullptr;
+  graphPar_ = stPar_;
+  PDLP_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+  for (int i = 0; i < kGraphTrials; ++i) enqueueTrial();
+  PDLP_HIP(hipStreamEndCapture(stream_, &graph));
+  PDLP_HIP(hipGraphInstantiate(&graphExec_, graph, nullptr, nullptr, 0));
+  (void)hipGraphDestroy(graph);
+  graphTrials_ = kGraphTrials;
+  stPar_ = graphPar_;
 }
 
 void Solver::runUntilHalt() {
@@ -625,17 +652,14 @@ void Solver::runUntilHalt() {
     int32_t todo = (int32_t)remaining;
     const int32_t trialsBefore = hostState_->nTrials;
     if (useGraph_ && !profile_ && (!sharded_ || meshMode_) && todo >= kGraphTrials) {
-      if (!graphExec_) {
-        hipGraph_t graph = nullptr;
-        PDLP_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
-        for (int i = 0; i < kGraphTrials; ++i) enqueueTrial();
-        PDLP_HIP(hipStreamEndCapture(stream_, &graph));
-        PDLP_HIP(hipGraphInstantiate(&graphExec_, graph, nullptr, nullptr, 0));
-        (void)hipGraphDestroy(graph);
-        graphTrials_ = kGraphTrials;
-      }
+      if (!graphExec_) captureGraph();
       while (todo >= graphTrials_) {
-        PDLP_HIP(hipGraphLaunch(graphExec_, stream_));
+        if (stPar_ != graphPar_) {  // the graph starts from the state slot it was captured with
+          enqueueTrial();
+          --todo;
+          continue;
+        }
+        PDLP_HIP(hipGraphLaunch(graphExec_, stream_));  // an even number of trials: the slot parity is unchanged
         todo -= graphTrials_;
       }
     }
@@ -661,7 +685,7 @@ int32_t Solver::nextCheckIter(int32_t it) const {
 // ---- check iteration -----------------------------------------------------------
 // PDHG_Compute_Average_Iterate, cupdlp_step.c:377-420
 void Solver::computeAverage() {
-  launchFlushAverage(vecsCol_, dState_.get(), stream_);
+  launchFlushAverage(vecsCol_, dst(), stream_);
   hostState_->avgW = 0.0;
   const double ps = hostState_->sumPrimalStep > 0.0 ? 1.0 / hostState_->sumPrimalStep : 1.0;
   const double ds = hostState_->sumDualStep > 0.0 ? 1.0 / hostState_->sumDualStep : 1.0;
@@ -822,7 +846,21 @@ void Solver::doSolve(bool terminate, int32_t target) {
     const double t = elapsed();
     const bool timeUp = timeIsUp();
     // Every stop of the device is a check iteration of the reference schedule
-    // (nIter < 10, nIter % 40 == 0, last iteration, or time limit exceeded).
+    // (nIter < 10, nIter % 40 == 0, last iteration, or time limit exceeded) — except the entry of
+    // a fixed-work timing loop at an iteration that is not on the schedule: a continuous run would
+    // not check there either, so neither does the measurement.
+    if (!terminate) {
+      const int32_t interval = opt_.check_interval > 0 ? opt_.check_interval : kCheckInterval;
+      if (!(it < 10 || it % interval == 0)) {
+        int64_t halt = nextCheckIter(it);
+        if (halt > iterLim) halt = iterLim;
+        s.haltIter = (int32_t)halt;
+        s.halted = 0;
+        pushState();
+        runUntilHalt();
+        continue;
+      }
+    }
     computeAverage();
     computeResiduals();
     ++nChecks_;
@@ -1072,7 +1110,7 @@ void Solver::stage(const std::string& name, double* out, int32_t cap) {
 double Solver::timeKernel(const std::string& name, int32_t reps) {
   syncState();
   if (reps < 1) reps = 1;
-  launchFlushAverage(vecsCol_, dState_.get(), stream_);
+  launchFlushAverage(vecsCol_, dst(), stream_);
   hostState_->avgW = 0.0;
   const int32_t savedHalt = hostState_->haltIter;
   hostState_->haltIter = INT_MAX;
@@ -1086,13 +1124,19 @@ double Solver::timeKernel(const std::string& name, int32_t reps) {
     big.zero(stream_);
   }
   auto once = [&]() {
-    if (name == "spmv_ax") launchSpmvAxDual(dA_.view(), vecs_, dState_.get(), partDY_.get(), stream_);
+    if (name == "spmv_ax") launchSpmvAxDual(dA_.view(), vecs_, dst(), partDY_.get(), stream_);
     else if (name == "spmv_aty") {
-      if (!sharded_) launchSpmvAtyInteract(dAt_.view(), vecs_, dState_.get(), partDX_.get(), partInter_.get(), stream_);
-      else launchSpmvAtyPartial(dAt_.view(), vecs_, dState_.get(), commBuf_.get(), stream_);
-    } else if (name == "primal_step") launchPrimalStep(vecs_, dState_.get(), stream_);
+      if (!sharded_) launchSpmvAtyInteract(dAt_.view(), vecs_, dst(), partDX_.get(), partInter_.get(), stream_);
+      else launchSpmvAtyPartial(dAt_.view(), vecs_, dst(), commBuf_.get(), stream_);
+    } else if (name == "primal_step") launchPrimalStep(vecs_, dst(), stream_);
+    else if (name == "decide_primal") {  // (pending is set by the kernel itself: from the second launch on it decides too)
+      const DevState* in = dst();
+      stPar_ ^= 1;
+      launchDecidePrimal(vecs_, in, dst(), partDY_.get(), dA_.nPartials(), partDX_.get(), partInter_.get(),
+                         dAt_.nPartials(), stream_);
+    }
     else if (name == "decide")
-      launchDecide(dState_.get(), partDY_.get(), dA_.nPartials(), partDX_.get(), partInter_.get(), dAt_.nPartials(), nullptr, stream_);
+      launchDecide(dst(), partDY_.get(), dA_.nPartials(), partDX_.get(), partInter_.get(), dAt_.nPartials(), nullptr, stream_);
     else if (name == "trial") enqueueTrial();
     else if (name == "spmv_ax_plain") launchSpmvPlain(dA_.view(), x_[0].get(), tmpM_.get(), stream_);
     else if (name == "spmv_aty_plain") launchSpmvPlain(dAt_.view(), y_[0].get(), commBuf_.get(), stream_);

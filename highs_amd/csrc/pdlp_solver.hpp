@@ -85,6 +85,7 @@ class Solver : public SolverBase {
   void applyHotStart();
   // hot loop
   void enqueueTrial();
+  void captureGraph();
   void runUntilHalt();
   void syncState();    // device -> host_
   void pushState();    // host_ -> device
@@ -132,7 +133,11 @@ class Solver : public SolverBase {
   DeviceArray<double> cost_, rhs_, lower_, upper_, colScale_, rowScale_;
   DeviceArray<double> slackPos_, slackNeg_, slackPosAvg_, slackNegAvg_;
   DeviceArray<double> partDY_, partDX_, partInter_, statPart_, statOut_, commBuf_, tmpM_;
+  // Two slots: the single-GPU loop alternates between them from trial to trial (k_decide_primal reads
+  // one, writes the other); stPar_ = the slot that holds the state after everything enqueued so far.
   DeviceArray<DevState> dState_;
+  int32_t stPar_ = 0, graphPar_ = 0;
+  DevState* dst() const { return dState_.get() + stPar_; }
   DeviceArray<double> powRed_, powGrow_;  // host-tabulated powers of the trial counter (see DevState)
   void refreshPowTable();
   DevState* hostState_ = nullptr;  // pinned mirror
