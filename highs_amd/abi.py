@@ -65,6 +65,10 @@ class PdlpParams(C.Structure):
         ("scaling_mode", C.c_int32),        # pdlp_scaling_mode: 1 Ruiz | 2 L2 | 4 PC
         ("ruiz_iterations", C.c_int32),     # pdlp_ruiz_iterations
         ("step_size_strategy", C.c_int32),  # pdlp_step_size_strategy: 0 fixed, else PID
+        ("num_devices", C.c_int32),         # pdlp_mi355x_solve: shard over this many devices of the process
+        ("reserved2", C.c_int32),
+        ("log_callback", C.c_void_p),       # void (*)(void* ctx, int level, const char* text); NULL = stdout
+        ("log_ctx", C.c_void_p),
     ]
 
 

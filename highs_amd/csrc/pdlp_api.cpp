@@ -5,7 +5,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <memory>
+#include <random>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "pdlp_halpern.hpp"
 #include "pdlp_solver.hpp"
@@ -101,7 +105,90 @@ void pdlp_mi355x_destroy(pdlp_mi355x_solver_t* s) {
   delete s;
 }
 
+namespace {
+// The multi-GPU form of the one-call boundary: the LP is row-block sharded over G devices of THIS process,
+// one host thread per device (each thread owns its device's solver from construction to destruction; the
+// ranks meet inside Mesh / Comm exactly as G processes would).  Rank 0 fills the caller's result.
+void solveSharded(const pdlp_problem_t& P, const pdlp_params_t& opt, int G, pdlp_result_t* R) {
+  int nDev = 0;
+  if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0)
+    throw std::runtime_error("pdlp_mi355x: no HIP device available (this library has no CPU fallback)");
+  // PDLP_MI355X_FOLD_DEVICES=1 (tests on a 1-GPU box): several ranks share a physical device
+  const char* f = getenv("PDLP_MI355X_FOLD_DEVICES");
+  const bool fold = f && atoi(f) != 0;
+  if (!fold && opt.device + G > nDev)
+    throw std::runtime_error("pdlp_mi355x: num_devices = " + std::to_string(G) + " starting at device " +
+                             std::to_string(opt.device) + ", but only " + std::to_string(nDev) + " HIP devices are visible");
+  if (G > 16) throw std::runtime_error("pdlp_mi355x: at most 16 devices");
+  unsigned char id[128];
+  {
+    std::random_device rd;
+    for (unsigned char& b : id) b = (unsigned char)rd();
+  }
+  std::vector<std::string> errors((size_t)G);
+  std::vector<pdlp_result_t> scratch((size_t)G);
+  // PDLP_MI355X_VERIFY_RANKS=1 (tests): every rank returns its full solution, compared bit for bit below
+  const char* vr = getenv("PDLP_MI355X_VERIFY_RANKS");
+  const bool verify = vr && atoi(vr) != 0;
+  std::vector<std::vector<double>> keep;
+  if (verify) keep.resize((size_t)G * 4);
+  std::vector<std::thread> workers;
+  for (int g = 0; g < G; ++g) {
+    workers.emplace_back([&, g] {
+      try {
+        pdlp_params_t o = opt;
+        o.device = fold ? (opt.device + g) % nDev : opt.device + g;
+        o.num_devices = 1;
+        if (hipSetDevice(o.device) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
+        std::unique_ptr<pdlp::SolverBase> s;
+        if (o.algorithm == 1) s.reset(new pdlp::HalpernSolver(P, o, g, G, id));
+        else if (o.algorithm == 0) s.reset(new pdlp::Solver(P, o, g, G, id));
+        else throw std::runtime_error("unknown algorithm (0 = cuPDLP-C path, 1 = HiPDLP path)");
+        memset(&scratch[g], 0, sizeof(pdlp_result_t));
+        if (verify && g > 0) {
+          keep[4 * g + 0].assign((size_t)P.num_col, 0.0); keep[4 * g + 1].assign((size_t)P.num_col, 0.0);
+          keep[4 * g + 2].assign((size_t)P.num_row + 1, 0.0); keep[4 * g + 3].assign((size_t)P.num_row + 1, 0.0);
+          scratch[g].col_value = keep[4 * g + 0].data(); scratch[g].col_dual = keep[4 * g + 1].data();
+          scratch[g].row_value = keep[4 * g + 2].data(); scratch[g].row_dual = keep[4 * g + 3].data();
+        }
+        s->run(g == 0 ? R : &scratch[g]);
+        if (g == 0) scratch[0] = *R;
+      } catch (const std::exception& e) {
+        errors[g] = e.what()[0] ? e.what() : "error";
+      } catch (...) {
+        errors[g] = "unknown exception";
+      }
+    });
+  }
+  for (std::thread& t : workers) t.join();
+  for (int g = 0; g < G; ++g)
+    if (!errors[g].empty()) throw std::runtime_error("device rank " + std::to_string(g) + ": " + errors[g]);
+  // every rank takes every decision from rank-ordered sums, so they must all report the same bits
+  for (int g = 1; g < G; ++g) {
+    const pdlp_result_t& a = scratch[0];
+    const pdlp_result_t& b = scratch[g];
+    bool same = a.term_code == b.term_code && a.num_iter == b.num_iter && a.num_trials == b.num_trials &&
+                memcmp(&a.primal_obj, &b.primal_obj, sizeof(double)) == 0 && memcmp(&a.dual_obj, &b.dual_obj, sizeof(double)) == 0;
+    if (same && verify && R->col_value && R->row_dual)
+      same = memcmp(R->col_value, b.col_value, sizeof(double) * (size_t)P.num_col) == 0 &&
+             memcmp(R->row_dual, b.row_dual, sizeof(double) * (size_t)P.num_row) == 0;
+    if (!same) throw std::runtime_error("device ranks 0 and " + std::to_string(g) + " disagree (exchange inconsistent)");
+  }
+}
+}  // namespace
+
 int pdlp_mi355x_solve(const pdlp_problem_t* P, const pdlp_params_t* opt, pdlp_result_t* R) {
+  int G = opt ? opt->num_devices : 0;
+  if (G <= 0) {
+    const char* e = getenv("PDLP_MI355X_DEVICES");
+    G = e ? atoi(e) : 1;
+  }
+  if (G > 1) {
+    return guarded([&] {
+      if (!P || !opt || !R) throw std::runtime_error("null argument");
+      solveSharded(*P, *opt, G, R);
+    });
+  }
   pdlp_mi355x_solver_t* s = nullptr;
   int rc = pdlp_mi355x_create(P, opt, &s);
   if (rc == 0) rc = pdlp_mi355x_run(s, R);

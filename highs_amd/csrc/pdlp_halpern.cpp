@@ -26,9 +26,8 @@ void HalpernSolver::log(int level, const char* fmt, ...) const {
   if (opt_.log_level < level) return;
   va_list ap;
   va_start(ap, fmt);
-  vprintf(fmt, ap);
+  logLineV(opt_, level, fmt, ap);
   va_end(ap);
-  fflush(stdout);
 }
 
 HalpernSolver::HalpernSolver(const pdlp_problem_t& P, const pdlp_params_t& opt, int32_t rank, int32_t world,
@@ -192,13 +191,16 @@ void HalpernSolver::spmvAt(const double* yLocal, double* aty) {
 void HalpernSolver::gatherToHost(const double* devLocal, int32_t lo, int32_t hi, bool byRows, std::vector<double>& full) {
   const int32_t len = byRows ? F_.m : F_.n;
   full.assign((size_t)len, 0.0);
-  DeviceArray<double> g;
-  g.alloc((size_t)std::max(len, 1));
+  // persistent scratch: a hipFree here would synchronise the whole device, and with several ranks of one
+  // process on one device (the folded test mode) it would wait for a peer's kernel that waits for us
+  DeviceArray<double>& g = gatherBuf_;
+  if (g.size() < (size_t)std::max(len, 1)) g.alloc((size_t)std::max(std::max(F_.n, F_.m), 1));
   g.zero(stream_);
   PDLP_HIP(hipMemcpyAsync(g.get() + lo, devLocal, sizeof(double) * (size_t)(hi - lo), hipMemcpyDeviceToDevice, stream_));
   if (mesh_) mesh_->allGather(g.get(), byRows, stream_);
   g.download(full.data(), (size_t)len, stream_);
   PDLP_HIP(hipStreamSynchronize(stream_));
+  if (mesh_) mesh_->checkError(stream_);  // a timed-out exchange must not return a half-gathered vector
 }
 
 // powerMethod, pdhg.cc:1529-1670 (kCuPdlpAATPowerMethod): 20 iterations on A A' from the ones vector
@@ -515,7 +517,7 @@ void HalpernSolver::doSolve(bool terminate, int64_t iterTarget) {
     const bool converged = check(xn_.get(), yn_.get(), slackValid_, r);
     res_ = r;
     if (opt_.log_level > 1 && rank_ == 0)
-      printf("%9lld  %+15.8e  %+15.8e  %8.2e  %10.2e  %8.2e  fpe %8.2e  w %8.2e\n", (long long)iters_, r.pObj, r.dObj,
+      logLine(opt_, 2, "%9lld  %+15.8e  %+15.8e  %8.2e  %10.2e  %8.2e  fpe %8.2e  w %8.2e\n", (long long)iters_, r.pObj, r.dObj,
              r.relGap, r.pFeas / (1.0 + F_.normRhs), r.dFeas / (1.0 + F_.normCost), fpe_, primalWeight_);
     if (converged && terminate) {
       keepOutput(xn_.get(), yn_.get());
@@ -535,7 +537,7 @@ void HalpernSolver::run(pdlp_result_t* R) {
   doSolve(true, 0);
   solveSeconds_ = elapsed();
   if (opt_.log_level > 0 && rank_ == 0)
-    printf("\nHiPDLP: %s after %lld iterations (%d restarts): primal obj %+.10e, dual obj %+.10e, rel gap %.2e\n",
+    logLine(opt_, 1, "\nHiPDLP: %s after %lld iterations (%d restarts): primal obj %+.10e, dual obj %+.10e, rel gap %.2e\n",
            termStatus_ == 0 ? "converged" : termStatus_ == 2 ? "time limit" : "iteration limit", (long long)iters_,
            nRestarts_, res_.pObj, res_.dObj, res_.relGap);
   if (R) postsolve(R);

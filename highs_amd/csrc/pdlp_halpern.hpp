@@ -85,7 +85,7 @@ class HalpernSolver : public SolverBase {
   hipStream_t stream_ = nullptr;
   DeviceMatrix dA_, dAt_;
   DeviceArray<double> xc_, yc_, xn_, yn_, rx_, ry_, xa_, ya_, slack_, sp_, sn_, outX_, outY_;
-  DeviceArray<double> cost_, lower_, upper_, rl_, ru_, colScale_, rowScale_, tmpN_, tmpM_, tmpM2_;
+  DeviceArray<double> cost_, lower_, upper_, rl_, ru_, colScale_, rowScale_, tmpN_, tmpM_, tmpM2_, gatherBuf_;
   DeviceArray<uint8_t> isEq_;
   DeviceArray<double> part_, statOut_;
   DeviceArray<HalpernState> dState_;

@@ -2,11 +2,29 @@
 #include "pdlp_host.hpp"
 
 #include <algorithm>
+#include <cstdio>
 #include <cmath>
 #include <limits>
 #include <stdexcept>
 
 namespace pdlp {
+
+void logLineV(const pdlp_params_t& opt, int level, const char* fmt, va_list ap) {
+  if (!opt.log_callback) {
+    vprintf(fmt, ap);
+    fflush(stdout);
+    return;
+  }
+  char buf[1024];
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  opt.log_callback(opt.log_ctx, level, buf);
+}
+void logLine(const pdlp_params_t& opt, int level, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  logLineV(opt, level, fmt, ap);
+  va_end(ap);
+}
 
 namespace {
 constexpr double kBoundInf = 1e20;  // CupdlpWrapper.cpp:316-317,375-378

@@ -8,6 +8,7 @@
 //   build_csr/csc  <-> csc2csr / cupdlp_dcs_transpose cupdlp_utils.c:1222, cupdlp_cs.c:189
 //   row partition  <-> (no reference: SURVEY §8e multi-GPU row blocks)
 #pragma once
+#include <cstdarg>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -15,6 +16,11 @@
 #include "../../include/pdlp_mi355x.h"
 
 namespace pdlp {
+
+// One formatted log line to the caller's sink (pdlp_params_t::log_callback, e.g. highsLogUser) or, without
+// one, to stdout like the reference's cuPDLP-C.
+void logLine(const pdlp_params_t& opt, int level, const char* fmt, ...) __attribute__((format(printf, 3, 4)));
+void logLineV(const pdlp_params_t& opt, int level, const char* fmt, va_list ap);
 
 enum RowKind : int32_t { kRowEq = 0, kRowLeq = 1, kRowGeq = 2, kRowBound = 3 };  // cupdlp_defs.h types
 

@@ -571,6 +571,9 @@ struct ShmSlot {
   std::atomic<uint32_t> ready;
   uint32_t pid;
   uint64_t arenaBytes;
+  uint64_t rawPtr;   // the arena's device pointer: what a rank of the SAME process maps (peer access, no IPC)
+  int32_t device;    // HIP device ordinal of the owner
+  int32_t pad_;
   hipIpcMemHandle_t handle;
   std::atomic<uint32_t> agree[64];  // round -> 1 ok / 2 not ok
 };
@@ -660,6 +663,8 @@ void Mesh::construct(int32_t rank, int32_t world, const void* id128, int32_t n, 
   for (int h = 0; h < kMeshMaxRanks; ++h) v_.arena[h] = nullptr;
   v_.arena[rank] = (char*)arena_;
   PDLP_HIP(hipMalloc((void**)&dView_, sizeof(MeshView)));
+  PDLP_HIP(hipMalloc((void**)&testV_, sizeof(double) * (size_t)std::max(n, 4)));  // selfTest() scratch
+  PDLP_HIP(hipMalloc((void**)&testP_, sizeof(double) * (size_t)std::max(n, 4)));
   if (world == 1) {
     PDLP_HIP(hipMemcpy(dView_, &v_, sizeof(MeshView), hipMemcpyHostToDevice));
     setupOk_ = true;
@@ -681,24 +686,50 @@ void Mesh::construct(int32_t rank, int32_t world, const void* id128, int32_t n, 
   ShmSlot& mine = seg->slot[rank];
   // From here on a failure must not desert the other ranks: it is recorded, this rank keeps taking part
   // in the rendezvous, and selfTest()/allAgree() then turn it into "every rank falls back to RCCL".
-  bool ok = hipIpcGetMemHandle(&mine.handle, arena_) == hipSuccess;
+  // One process, one host thread per device (pdlp_mi355x_solve with num_devices > 1): the peers' arenas
+  // are ordinary pointers of this address space and only need peer access; across processes they are
+  // mapped through HIP IPC.  A rank whose IPC export fails is still usable by same-process peers (ready = 3).
+  bool ok = true;
+  int myDevice = 0;
+  (void)hipGetDevice(&myDevice);
+  const char* forceIpc = getenv("PDLP_MI355X_MESH_FORCE_IPC");  // diagnostic: IPC also inside one process
+  const bool allLocal = !(forceIpc && atoi(forceIpc) != 0);
+  const bool exported = hipIpcGetMemHandle(&mine.handle, arena_) == hipSuccess;
+  if (!exported) (void)hipGetLastError();
   mine.arenaBytes = arenaBytes_;
+  mine.rawPtr = (uint64_t)(uintptr_t)arena_;
+  mine.device = myDevice;
   mine.pid = (uint32_t)getpid();
-  mine.ready.store(ok ? 1u : 2u, std::memory_order_release);
+  mine.ready.store(exported ? 1u : 3u, std::memory_order_release);
   hostBarrier(0, 60.0);
   if (rank == 0) shm_unlink(name);  // every rank has it mapped; nothing is left behind on a crash
   for (int h = 0; h < world; ++h) {
     if (h == rank) continue;
-    if (seg->slot[h].ready.load(std::memory_order_acquire) != 1 || seg->slot[h].arenaBytes != arenaBytes_) {
+    const uint32_t rdy = seg->slot[h].ready.load(std::memory_order_acquire);
+    const bool samePid = allLocal && seg->slot[h].pid == mine.pid;
+    if (!(rdy == 1u || (rdy == 3u && samePid)) || seg->slot[h].arenaBytes != arenaBytes_) {
       ok = false;
       continue;
     }
     void* p = nullptr;
-    if (!ok || hipIpcOpenMemHandle(&p, seg->slot[h].handle, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+    if (allLocal && seg->slot[h].pid == mine.pid) {
+      p = (void*)(uintptr_t)seg->slot[h].rawPtr;
+      if (seg->slot[h].device != myDevice) {
+        const hipError_t e = hipDeviceEnablePeerAccess(seg->slot[h].device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) ok = false;
+        (void)hipGetLastError();
+      }
+      if (!ok) continue;
+      v_.arena[h] = (char*)p;
+      continue;
+    }
+    if (hipIpcOpenMemHandle(&p, seg->slot[h].handle, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+      (void)hipGetLastError();
       ok = false;
       continue;
     }
     v_.arena[h] = (char*)p;
+    ipcMapped_[h] = true;
   }
   if (ok) ok = hipMemcpy(dView_, &v_, sizeof(MeshView), hipMemcpyHostToDevice) == hipSuccess;
   setupOk_ = ok;
@@ -715,14 +746,16 @@ void Mesh::release() noexcept {
     const bool broken = !state_ || hipMemcpy(&h, state_, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess || h.error != 0;
     if (!broken) { try { hostBarrier(2, 20.0); } catch (...) {} }
     for (int r = 0; r < v_.G; ++r)
-      if (r != v_.g && v_.arena[r]) (void)hipIpcCloseMemHandle(v_.arena[r]);
+      if (r != v_.g && v_.arena[r] && ipcMapped_[r]) (void)hipIpcCloseMemHandle(v_.arena[r]);
     if (!broken) { try { hostBarrier(3, 20.0); } catch (...) {} }
   }
   if (arena_) (void)hipFree(arena_);
   if (state_) (void)hipFree(state_);
   if (dView_) (void)hipFree(dView_);
+  if (testV_) (void)hipFree(testV_);
+  if (testP_) (void)hipFree(testP_);
   if (shm_) munmap(shm_, shmBytes_);
-  arena_ = nullptr; state_ = nullptr; dView_ = nullptr; shm_ = nullptr;
+  arena_ = nullptr; state_ = nullptr; dView_ = nullptr; shm_ = nullptr; testV_ = nullptr; testP_ = nullptr;
 }
 
 Mesh::~Mesh() { release(); }
@@ -790,10 +823,10 @@ bool Mesh::selfTest(hipStream_t s) {
   const int G = v_.G, g = v_.g;
   auto val = [](int rank, int j, int round) { return (double)((rank + 1) * 1000003 + j * 7 + round); };
   std::vector<double> host(n), got(n);
-  double* dv = nullptr;
-  double* dp = nullptr;
-  PDLP_HIP(hipMalloc((void**)&dv, sizeof(double) * (size_t)std::max(n, 4)));
-  PDLP_HIP(hipMalloc((void**)&dp, sizeof(double) * (size_t)std::max(n, 4)));  // also carries the 3 test scalars
+  // buffers allocated in construct() and freed in release(): a hipFree here would synchronise the whole
+  // device — with several ranks of one process folded onto one device it would wait for a peer's kernel
+  double* dv = testV_;
+  double* dp = testP_;  // also carries the 3 test scalars
   bool ok = true;
   try {
     for (int round = 0; round < 3 && ok; ++round) {
@@ -832,8 +865,7 @@ bool Mesh::selfTest(hipStream_t s) {
   } catch (...) {
     ok = false;
   }
-  (void)hipFree(dv);
-  (void)hipFree(dp);
+
   return ok;
 }
 

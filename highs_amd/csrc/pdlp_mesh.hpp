@@ -1,8 +1,10 @@
 // pdlp_mesh.hpp — direct xGMI exchange for the row-block sharded PDHG loop
 // ("the performance path is a direct full-mesh exchange").
 //
-// One process per GPU on one node.  Every rank owns an ARENA of uncached device
-// memory that all peers map through HIP IPC; kernels write straight into the
+// One rank per GPU on one node: either one PROCESS per GPU (a launcher, pdlp_mi355x_create_sharded) or
+// one host THREAD per GPU inside a single process (pdlp_mi355x_solve with num_devices > 1, i.e. what
+// Highs::run() reaches).  Every rank owns an ARENA of uncached device memory that all peers map —
+// through HIP IPC across processes, through peer access inside one process; kernels write straight into the
 // peers' arenas over xGMI (write-through system-scope stores), wait until those
 // stores have landed, and then announce the data by storing a monotonically
 // increasing epoch into a per-sender flag; the consumer kernel spins on its own
@@ -108,6 +110,8 @@ class Mesh {
   void* arena_ = nullptr;
   size_t arenaBytes_ = 0;
   MeshState* state_ = nullptr;
+  double* testV_ = nullptr;  // selfTest() scratch (kept for the object's lifetime)
+  double* testP_ = nullptr;
   void* shm_ = nullptr;
   size_t shmBytes_ = 0;
   std::string shmName_;
@@ -115,6 +119,7 @@ class Mesh {
   int agreeRound_ = 0;
   int32_t n_ = 0;
   bool setupOk_ = false;  // arenas exported and mapped on this rank
+  bool ipcMapped_[kMeshMaxRanks] = {};  // peer arena mapped through HIP IPC (another process), not peer access
 };
 
 // ---- hot-loop kernels (mesh flavour of enqueueTrial) -----------------------------

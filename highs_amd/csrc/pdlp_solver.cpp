@@ -152,9 +152,8 @@ void Solver::log(int level, const char* fmt, ...) const {
   if (opt_.log_level < level || rank_ != 0) return;
   va_list ap;
   va_start(ap, fmt);
-  vprintf(fmt, ap);
+  logLineV(opt_, level, fmt, ap);
   va_end(ap);
-  fflush(stdout);
 }
 
 Solver::Solver(const pdlp_problem_t& P, const pdlp_params_t& opt, int32_t rank, int32_t world, const void* id128)
@@ -454,14 +453,17 @@ void Solver::sumOverRanks(double* devBuf, int32_t count) {
 void Solver::gatherToHost(const double* devLocal, int32_t lo, int32_t hi, bool byRows, std::vector<double>& full) {
   const int32_t len = byRows ? F_.m : F_.n;
   full.assign((size_t)len, 0.0);
-  DeviceArray<double> g;
-  g.alloc((size_t)len);
+  // persistent scratch: a hipFree here would synchronise the whole device, and with several ranks of one
+  // process on one device (the folded test mode) it would wait for a peer's kernel that waits for us
+  DeviceArray<double>& g = gatherBuf_;
+  if (g.size() < (size_t)std::max(len, 1)) g.alloc((size_t)std::max(std::max(F_.n, F_.m), 1));
   g.zero(stream_);
   PDLP_HIP(hipMemcpyAsync(g.get() + lo, devLocal, sizeof(double) * (size_t)(hi - lo), hipMemcpyDeviceToDevice, stream_));
   if (meshMode_) mesh_->allGather(g.get(), byRows, stream_);
   else if (comm_) comm_->allReduceSum(g.get(), (size_t)len, stream_);
   g.download(full.data(), (size_t)len, stream_);
   PDLP_HIP(hipStreamSynchronize(stream_));
+  if (meshMode_) mesh_->checkError(stream_);  // a timed-out exchange must not return a half-gathered vector
 }
 
 // Sum per-block partials on the device, bring the scalar to the host; row
@@ -868,15 +870,14 @@ void Solver::doSolve(bool terminate, int32_t target) {
       const bool print = (it % (kCheckInterval * 100) == 0) || it == iterLim - 1 || timeUp;
       if (print) {
         if (logSinceHeader >= 50) {
-          printf("%9s  %15s  %15s   %8s  %10s  %8s %7s\n", "Iter", "Primal.Obj", "Dual.Obj", "Gap", "Primal.Inf",
+          logLine(opt_, 1, "%9s  %15s  %15s   %8s  %10s  %8s %7s\n", "Iter", "Primal.Obj", "Dual.Obj", "Gap", "Primal.Inf",
                  "Dual.Inf", "Time");
           logSinceHeader = 0;
         }
         const Residuals& r = it == 0 ? cur_ : avg_;
-        printf("%9d  %+15.8e  %+15.8e  %+8.2e  %10.2e  %8.2e %6.2fs [%c]\n", it, r.pObj, r.dObj, r.relGap,
+        logLine(opt_, 1, "%9d  %+15.8e  %+15.8e  %+8.2e  %10.2e  %8.2e %6.2fs [%c]\n", it, r.pObj, r.dObj, r.relGap,
                r.pFeas / (1.0 + F_.normRhs), r.dFeas / (1.0 + F_.normCost), t, it == 0 ? 'L' : 'A');
         ++logSinceHeader;
-        fflush(stdout);
       }
     }
     if (terminate) {
@@ -908,7 +909,7 @@ void Solver::run(pdlp_result_t* R) {
                            ? (termIterate_ ? "Optimal average solution." : "Optimal current solution.")
                            : termCode_ == PDLP_TERM_INFEASIBLE_OR_UNBOUNDED ? "Infeasible or unbounded."
                                                                             : "Time or iteration limit reached.";
-    printf("\n%-27s %s\n%27s %+15.8e\n%27s %+15.8e\n%27s %8.2e / %8.2e\n%27s %8.2e / %8.2e\n%27s %8.2e\n%27s %d\n\n",
+    logLine(opt_, 1, "\n%-27s %s\n%27s %+15.8e\n%27s %+15.8e\n%27s %8.2e / %8.2e\n%27s %8.2e / %8.2e\n%27s %8.2e\n%27s %d\n\n",
            "Solving information:", what, "Primal objective:", r.pObj, "Dual objective:", r.dObj,
            "Primal infeas (abs/rel):", r.pFeas, r.pFeas / (1.0 + F_.normRhs), "Dual infeas (abs/rel):", r.dFeas,
            r.dFeas / (1.0 + F_.normCost), "Duality gap (rel):", r.relGap, "Number of iterations:",

@@ -132,7 +132,7 @@ class Solver : public SolverBase {
   DeviceArray<double> xAvg_, yAvg_, axAvg_, atyAvg_, xSum_, ySum_, xLast_, yLast_;
   DeviceArray<double> cost_, rhs_, lower_, upper_, colScale_, rowScale_;
   DeviceArray<double> slackPos_, slackNeg_, slackPosAvg_, slackNegAvg_;
-  DeviceArray<double> partDY_, partDX_, partInter_, statPart_, statOut_, commBuf_, tmpM_;
+  DeviceArray<double> partDY_, partDX_, partInter_, statPart_, statOut_, commBuf_, tmpM_, gatherBuf_;
   // Two slots: the single-GPU loop alternates between them from trial to trial (k_decide_primal reads
   // one, writes the other); stPar_ = the slot that holds the state after everything enqueued so far.
   DeviceArray<DevState> dState_;

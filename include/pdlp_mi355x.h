@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define PDLP_MI355X_ABI_VERSION 2
+#define PDLP_MI355X_ABI_VERSION 3
 
 /* Termination codes: same numbering as cuPDLP-C's termination_code
  * (cupdlp_defs.h:61-68) so the status map of CupdlpWrapper.cpp:225-251
@@ -109,6 +109,16 @@ typedef struct pdlp_params {
   int32_t ruiz_iterations;    /* pdlp_ruiz_iterations (default 10) */
   int32_t step_size_strategy; /* pdlp_step_size_strategy: 0 fixed; anything else = PID primal weight
                                  (HiGHS default 1 -> PID, pdhg.cc:1856-1864) */
+  /* --- multi-GPU behind the one-call boundary (no reference counterpart: Ax_multi_gpu / ATy_multi_gpu
+   *     are exit(1) stubs, cupdlp_linalg.c:420-423,453-456) --- */
+  int32_t num_devices;        /* pdlp_mi355x_solve only: 0 = take PDLP_MI355X_DEVICES from the environment
+                                 (default 1); G > 1 = the constraint matrix is row-block sharded over the
+                                 devices device, device+1, ... device+G-1 of THIS process (one host thread
+                                 per device, direct xGMI exchange through peer access) */
+  int32_t reserved2;
+  /* --- log sink (HiGHS: highsLogUser).  NULL = stdout, as the reference's cuPDLP-C prints --- */
+  void (*log_callback)(void* ctx, int level, const char* text); /* level 1 = summary, 2 = verbose */
+  void* log_ctx;
 } pdlp_params_t;
 
 typedef struct pdlp_result {

@@ -80,6 +80,13 @@ HighsStatus solveLpCupdlp(const HighsOptions& options, HighsTimer& timer, const 
   // options -> pdlp_params_t (getUserParamsFromOptions)
   pdlp_params_t opt;
   pdlp_mi355x_default_params(&opt);
+  // the library's log lines go where HiGHS's own do (log file, callbacks, output_flag)
+  opt.log_callback = [](void* ctx, int /*level*/, const char* text) {
+    highsLogUser(*static_cast<const HighsLogOptions*>(ctx), HighsLogType::kInfo, "%s", text);
+  };
+  opt.log_ctx = const_cast<HighsLogOptions*>(&options.log_options);
+  // num_devices stays 0: PDLP_MI355X_DEVICES=G in the environment shards the LP over G GPUs of this process
+  // (HiGHS has no option for it; a maintainer adding one would forward it here)
   opt.iter_limit = (int32_t)std::min<int64_t>((int64_t)options.pdlp_iteration_limit,
                                               (int64_t)std::numeric_limits<int32_t>::max());
   opt.log_level = options.output_flag ? (options.log_dev_level ? 2 : 1) : 0;

@@ -52,6 +52,10 @@ HighsStatus solveLpHiPdlp(const HighsOptions& options, HighsTimer& timer, const 
   pdlp_params_t opt;
   pdlp_mi355x_default_params(&opt);
   opt.algorithm = 1;
+  opt.log_callback = [](void* ctx, int /*level*/, const char* text) {
+    highsLogUser(*static_cast<const HighsLogOptions*>(ctx), HighsLogType::kInfo, "%s", text);
+  };
+  opt.log_ctx = const_cast<HighsLogOptions*>(&options.log_options);
   opt.gap_tol = options.pdlp_optimality_tolerance;  // params_.tolerance
   if (options.kkt_tolerance != kDefaultKktTolerance) opt.gap_tol = options.kkt_tolerance;
   opt.primal_tol = opt.dual_tol = opt.gap_tol;

@@ -20,6 +20,9 @@ done
 OBJS=$(find "$REF_BUILD/highs/CMakeFiles/highs.dir" -name '*.o' | grep -v -E 'pdlp/CupdlpWrapper\.cpp\.o|pdlp/cupdlp/|pdlp/HiPdlpWrapper\.cpp\.o|pdlp/hipdlp/')
 /opt/rocm/lib/llvm/bin/clang++ -flto=thin -fuse-ld=lld -O3 -shared -o "$OUT/libhighs.so.1" -Wl,-soname,libhighs.so.1 $OBJS "$OUT/CupdlpWrapperMi355x.o" "$OUT/HiPdlpWrapperMi355x.o" \
     -L"$ROOT/highs_amd/lib" -lpdlp_mi355x -Wl,-rpath,'$ORIGIN/../../highs_amd/lib' -lz -lpthread -ldl
+# an unmodified C client of the reference's C API (Highs_create / Highs_passLp / Highs_run / ...)
+gcc -O2 -I"$REF/highs" -I"$REF_BUILD" "$HERE/capi_check.c" -o "$OUT/capi_check" -L"$OUT" -l:libhighs.so.1 -lm \
+    -Wl,-rpath,'$ORIGIN' -Wl,-rpath-link,"$ROOT/highs_amd/lib"
 cp "$REF_BUILD/bin/highs" "$OUT/highs_ref_cli"
 cp "$REF_BUILD/bin/unit_tests" "$OUT/unit_tests_ref"
 echo "built $OUT/libhighs.so.1 ; run with LD_LIBRARY_PATH=$OUT"

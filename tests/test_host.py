@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/pdlp_mi355x.h but not exported"
     assert set(solver.EXPORTS) == declared
-    assert lib.pdlp_mi355x_abi_version() == 2
+    assert lib.pdlp_mi355x_abi_version() == 3
 
 
 def test_struct_sizes_match_ctypes_mirror():
