@@ -2,7 +2,7 @@
 
 Only plain C types cross the boundary: int32/int64/double and pointers to
 caller-owned numpy buffers.  Field order and types must match the header
-exactly; tests/test_abi.py checks the struct sizes against the library.
+exactly; tests/test_host.py::test_struct_sizes_match_ctypes_mirror checks the struct sizes against the library.
 """
 import ctypes as C
 

@@ -402,7 +402,11 @@ bool HalpernSolver::check(double* x, const double* y, bool cachedSlack, Res& r) 
   PDLP_HIP(hipMemcpyAsync(hostStats_, statOut_.get(), sizeof(double) * (kHRowStats + kHColStats), hipMemcpyDeviceToHost,
                           stream_));
   PDLP_HIP(hipStreamSynchronize(stream_));
-  if (mesh_) mesh_->checkError(stream_);
+  PDLP_HIP(hipGetLastError());  // a failed kernel launch since the last check surfaces here
+  if (mesh_) {
+    mesh_->checkError(stream_);
+    mesh_->verifyReplicated(rx_.get(), F_.n, stream_);  // the reflected x is the vector every rank holds in full
+  }
   ++nChecks_;
   const double* rs = hostStats_;
   const double* cs = hostStats_ + kHRowStats;

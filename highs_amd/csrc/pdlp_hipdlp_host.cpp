@@ -14,10 +14,7 @@ const double kInf = std::numeric_limits<double>::infinity();
 }
 
 void formulateHipdlp(const pdlp_problem_t& P, StandardForm& F) {
-  if (P.num_col < 0 || P.num_row < 0) throw std::runtime_error("negative dimensions");
-  if (P.num_col > 0 && (!P.a_start || !P.col_cost || !P.col_lower || !P.col_upper))
-    throw std::runtime_error("null column arrays");
-  if (P.num_row > 0 && (!P.row_lower || !P.row_upper)) throw std::runtime_error("null row arrays");
+  validateProblem(P);
   const int32_t n0 = P.num_col, m = P.num_row;
   const int64_t nnz0 = n0 > 0 ? P.a_start[n0] : 0;
   if (nnz0 > 0 && (!P.a_index || !P.a_value)) throw std::runtime_error("null matrix arrays");

@@ -31,11 +31,26 @@ constexpr double kBoundInf = 1e20;  // CupdlpWrapper.cpp:316-317,375-378
 const double kInf = std::numeric_limits<double>::infinity();
 }  // namespace
 
-void formulate(const pdlp_problem_t& P, StandardForm& F) {
+// Structural checks of the caller's CSC arrays (shared by both formulations and the device-side setup):
+// the starts must begin at 0, never decrease and end at num_nz; row indices must be in range.
+void validateProblem(const pdlp_problem_t& P) {
   if (P.num_col < 0 || P.num_row < 0) throw std::runtime_error("negative dimensions");
   if (P.num_col > 0 && (!P.a_start || !P.col_cost || !P.col_lower || !P.col_upper))
     throw std::runtime_error("null column arrays");
   if (P.num_row > 0 && (!P.row_lower || !P.row_upper)) throw std::runtime_error("null row arrays");
+  if (P.num_col == 0) return;
+  if (P.a_start[0] != 0) throw std::runtime_error("a_start[0] must be 0");
+  for (int32_t j = 0; j < P.num_col; ++j)
+    if (P.a_start[j + 1] < P.a_start[j]) throw std::runtime_error("a_start must not decrease");
+  const int64_t nnz = P.a_start[P.num_col];
+  if (P.num_nz > 0 && nnz > P.num_nz) throw std::runtime_error("a_start[num_col] exceeds num_nz");
+  if (nnz > 0 && (!P.a_index || !P.a_value)) throw std::runtime_error("null matrix arrays");
+  for (int64_t p = 0; p < nnz; ++p)
+    if (P.a_index[p] < 0 || P.a_index[p] >= P.num_row) throw std::runtime_error("row index out of range");
+}
+
+void formulate(const pdlp_problem_t& P, StandardForm& F) {
+  validateProblem(P);
   const int32_t n0 = P.num_col, m = P.num_row;
   const int64_t nnz0 = n0 > 0 ? P.a_start[n0] : 0;
   if (nnz0 > 0 && (!P.a_index || !P.a_value)) throw std::runtime_error("null matrix arrays");

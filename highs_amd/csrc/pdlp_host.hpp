@@ -53,6 +53,7 @@ struct StandardForm {
 };
 
 // Throws std::runtime_error on malformed input.
+void validateProblem(const pdlp_problem_t& P);
 void formulate(const pdlp_problem_t& P, StandardForm& F);
 void scale(StandardForm& F, int ruizTimes = 10, double pcAlpha = 1.0);
 void finalize(StandardForm& F);  // CSR + row-sorted CSC + matNormInf

@@ -476,6 +476,31 @@ __global__ __launch_bounds__(kVecThreads) void k_mesh_barrier(const MeshArgs ma,
   if (!waitPeers(ma, kFlagBar, e)) fail(ma, nullptr);
 }
 
+// Checksum of a vector's BIT PATTERNS, independent of the summation order: every element is rotated by its
+// index and XORed (wave shuffle, then one integer atomic per wave).  *acc must be zero on entry.
+__global__ __launch_bounds__(kVecThreads) void k_mesh_checksum(const double* __restrict__ v, long long len,
+                                                               unsigned long long* acc) {
+  unsigned long long x = 0;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += stride) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v[i]);
+    const int r = (int)(i & 63);
+    x ^= (b << r) | (r ? (b >> (64 - r)) : 0ull);
+  }
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) x ^= __shfl_down(x, off, kWave);
+  if ((threadIdx.x & (kWave - 1)) == 0 && x) atomicXor(acc, x);
+}
+// buf[3*g .. 3*g+2] = the checksum in three 22-bit pieces (exact in a double), zero elsewhere
+__global__ void k_mesh_checksum_pack(const unsigned long long* acc, double* buf, int G, int g) {
+  const int t = threadIdx.x;
+  if (t < 3 * G) {
+    const unsigned long long c = *acc;
+    const int slot = t / 3, piece = t % 3;
+    buf[t] = slot == g ? (double)((c >> (22 * piece)) & (piece == 2 ? 0xfffffull : 0x3fffffull)) : 0.0;
+  }
+}
+
 __global__ __launch_bounds__(kVecThreads) void k_mesh_allreduce_scalars(double* buf, int k, const MeshArgs ma,
                                                                         long long e) {
   const MeshView* __restrict__ mv = ma.v; (void)mv;
@@ -663,8 +688,8 @@ void Mesh::construct(int32_t rank, int32_t world, const void* id128, int32_t n, 
   for (int h = 0; h < kMeshMaxRanks; ++h) v_.arena[h] = nullptr;
   v_.arena[rank] = (char*)arena_;
   PDLP_HIP(hipMalloc((void**)&dView_, sizeof(MeshView)));
-  PDLP_HIP(hipMalloc((void**)&testV_, sizeof(double) * (size_t)std::max(n, 4)));  // selfTest() scratch
-  PDLP_HIP(hipMalloc((void**)&testP_, sizeof(double) * (size_t)std::max(n, 4)));
+  PDLP_HIP(hipMalloc((void**)&testV_, sizeof(double) * (size_t)std::max(n, 64)));  // selfTest() / verifyReplicated() scratch
+  PDLP_HIP(hipMalloc((void**)&testP_, sizeof(double) * (size_t)std::max(n, 64)));
   if (world == 1) {
     PDLP_HIP(hipMemcpy(dView_, &v_, sizeof(MeshView), hipMemcpyHostToDevice));
     setupOk_ = true;
@@ -786,6 +811,29 @@ void Mesh::allReduceScalars(double* buf, int32_t k, hipStream_t s) {
   if (v_.G == 1) return;
   const long long e = ++epoch_;
   hipLaunchKernelGGL(k_mesh_allreduce_scalars, dim3(1), dim3(kVecThreads), 0, s, buf, k, args_, e);
+}
+
+// Every rank must hold the same bits in a replicated vector (x of the cuPDLP path, the reflected x of the
+// HiPDLP path): a stale or torn read in one of the exchanges would make the copies differ.  The checksums of
+// all ranks are exchanged (exact small integers through the scalar all-reduce) and compared; a mismatch is
+// an error, never a silently wrong iterate.  Called at check iterations (1 in 40).
+void Mesh::verifyReplicated(const double* vec, int64_t len, hipStream_t s) {
+  if (v_.G == 1) return;
+  unsigned long long* acc = reinterpret_cast<unsigned long long*>(testP_);
+  double* buf = testV_;  // >= 4 doubles... the pack needs 3*G <= 48: see construct()
+  PDLP_HIP(hipMemsetAsync(acc, 0, sizeof(unsigned long long), s));
+  hipLaunchKernelGGL(k_mesh_checksum, dim3(capped(len, 256)), dim3(kVecThreads), 0, s, vec, (long long)len, acc);
+  hipLaunchKernelGGL(k_mesh_checksum_pack, dim3(1), dim3(64), 0, s, acc, buf, v_.G, v_.g);
+  allReduceScalars(buf, 3 * v_.G, s);
+  double host[3 * kMeshMaxRanks];
+  PDLP_HIP(hipMemcpyAsync(host, buf, sizeof(double) * 3 * v_.G, hipMemcpyDeviceToHost, s));
+  PDLP_HIP(hipStreamSynchronize(s));
+  checkError(s);
+  for (int h = 1; h < v_.G; ++h)
+    for (int p = 0; p < 3; ++p)
+      if (host[3 * h + p] != host[p])
+        throw std::runtime_error("pdlp_mi355x mesh: the ranks hold different copies of a replicated vector (exchange "
+                                 "inconsistent); rerun with PDLP_MI355X_EXCHANGE=rccl");
 }
 
 void Mesh::checkError(hipStream_t s) {

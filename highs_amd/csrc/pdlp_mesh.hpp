@@ -92,6 +92,8 @@ class Mesh {
   void reduceScatterCols(const double* partial, double* dst, hipStream_t s);
   // buf[0:k) = sum over ranks (rank order), k <= kMeshMailDoubles; identical bits on every rank
   void allReduceScalars(double* buf, int32_t k, hipStream_t s);
+  // throws unless every rank holds bit-identical copies of vec[0:len) (collective; syncs the stream)
+  void verifyReplicated(const double* vec, int64_t len, hipStream_t s);
   // throws if a kernel reported a timed-out wait (call after a stream sync)
   void checkError(hipStream_t s);
   // exchange self-test (pattern all-gather + reduce-scatter + scalars); false = mismatch

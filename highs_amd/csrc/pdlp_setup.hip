@@ -359,10 +359,7 @@ void transposeOnDevice(const int32_t* majorIn, const int32_t* minorIn, const dou
 
 void gpuPrepare(const pdlp_problem_t& P, bool doScale, hipStream_t s, DeviceProblem& D, const HipdlpSetup* hp) {
   const bool H = hp != nullptr;  // HiPDLP form (pdhg.cc:152-357 + scaling.cc) instead of the cuPDLP-C one
-  if (P.num_col < 0 || P.num_row < 0) throw std::runtime_error("negative dimensions");
-  if (P.num_col > 0 && (!P.a_start || !P.col_cost || !P.col_lower || !P.col_upper))
-    throw std::runtime_error("null column arrays");
-  if (P.num_row > 0 && (!P.row_lower || !P.row_upper)) throw std::runtime_error("null row arrays");
+  validateProblem(P);
   const int32_t n0 = P.num_col, m = P.num_row;
   const int64_t nnz0 = n0 > 0 ? P.a_start[n0] : 0;
   if (nnz0 > 0 && (!P.a_index || !P.a_value)) throw std::runtime_error("null matrix arrays");

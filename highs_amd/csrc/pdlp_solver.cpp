@@ -391,6 +391,7 @@ void Solver::syncState() {
                  stream_, true);
   PDLP_HIP(hipMemcpyAsync(hostState_, dst(), sizeof(DevState), hipMemcpyDeviceToHost, stream_));
   PDLP_HIP(hipStreamSynchronize(stream_));
+  PDLP_HIP(hipGetLastError());  // a kernel launch that failed since the last stop (bad grid, LDS request, ...) surfaces here
   if (hostState_->commError)
     throw std::runtime_error("pdlp_mi355x mesh: a peer did not answer in time (exchange timed out)");
 }
@@ -722,7 +723,10 @@ void Solver::computeResiduals() {
   if (sharded_) sumOverRanks(statOut_.get(), meshMode_ ? kStatTotal : 2 * kRowStats);
   PDLP_HIP(hipMemcpyAsync(hostStats_, statOut_.get(), sizeof(double) * kStatTotal, hipMemcpyDeviceToHost, stream_));
   PDLP_HIP(hipStreamSynchronize(stream_));
-  if (meshMode_) mesh_->checkError(stream_);
+  if (meshMode_) {
+    mesh_->checkError(stream_);
+    mesh_->verifyReplicated(x_[c].get(), F_.n, stream_);  // every rank gathers from ITS copy of x
+  }
 
   auto fill = [&](Residuals& r, const double* rs, const double* cs) {
     r.pObj = cs[0] * F_.sense + F_.offset;

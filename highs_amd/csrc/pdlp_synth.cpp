@@ -16,8 +16,8 @@
 
 #include "../../include/pdlp_mi355x.h"
 
-extern "C" int pdlp_mi355x_gen_synthetic(int32_t m, int32_t n, int64_t nnz_target, uint64_t seed,
-                                         pdlp_problem_t* P) {
+namespace {
+int genSynthetic(int32_t m, int32_t n, int64_t nnz_target, uint64_t seed, pdlp_problem_t* P) {
   if (!P || m <= 0 || n <= 0 || nnz_target < m) return 1;
   std::mt19937_64 rng(seed);
   std::uniform_real_distribution<double> U(0.0, 1.0);
@@ -75,6 +75,17 @@ extern "C" int pdlp_mi355x_gen_synthetic(int32_t m, int32_t n, int64_t nnz_targe
   P->col_cost = cost; P->col_lower = cl; P->col_upper = cu; P->row_lower = rl; P->row_upper = ru;
   P->offset = 0.0; P->sense = 1;
   return 0;
+}
+}  // namespace
+
+// Nothing throws across the boundary: an allocation failure of the work vectors becomes return code 1.
+extern "C" int pdlp_mi355x_gen_synthetic(int32_t m, int32_t n, int64_t nnz_target, uint64_t seed,
+                                         pdlp_problem_t* P) {
+  try {
+    return genSynthetic(m, n, nnz_target, seed, P);
+  } catch (...) {
+    return 1;
+  }
 }
 
 extern "C" void pdlp_mi355x_free_problem(pdlp_problem_t* P) {

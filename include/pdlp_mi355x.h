@@ -247,8 +247,9 @@ int pdlp_mi355x_create_sharded(const pdlp_problem_t* P, const pdlp_params_t* opt
 
 /* Synthetic LP generator of SURVEY §8d / BASELINE.md §3 (std::mt19937_64(seed),
  * box 0<=x<=1, k = nnz/m draws per row, even rows equalities, odd rows <=).
- * Two-call protocol: first call with P_out==NULL to get sizes. Arrays are
- * malloc'ed by the library and released with pdlp_mi355x_free_problem. */
+ * One call: *P_out is filled with arrays malloc'ed by the library (release them with
+ * pdlp_mi355x_free_problem).  Returns 1 on bad arguments (P_out == NULL, m or n <= 0, nnz_target < m) or
+ * when memory runs out; never throws. */
 int pdlp_mi355x_gen_synthetic(int32_t m, int32_t n, int64_t nnz_target,
                               uint64_t seed, pdlp_problem_t* P_out);
 void pdlp_mi355x_free_problem(pdlp_problem_t* P);

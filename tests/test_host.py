@@ -185,3 +185,27 @@ def test_slab_layout_is_a_permutation_of_the_csr(which, long_limit):
     # inside a wave the key (slab, local major, minor) ascends
     key = (wave << 52) | ((mnr >> W) << 40) | ((maj % Rw) << 28) | (mnr & ((1 << W) - 1))
     assert np.all(np.diff(key) > 0)
+
+
+@pytest.mark.parametrize("corrupt", ["start0", "decreasing", "row_index", "overrun"])
+def test_malformed_csc_is_rejected_not_read_out_of_bounds(corrupt):
+    """formulate()/formulateHipdlp()/the device-side setup validate the caller's CSC arrays first."""
+    import ctypes as C
+    lp = L.special_lps()["distillation"]
+    H = abi.ProblemHandle(lp)
+    start = np.array(lp.a_start, dtype=np.int32).copy()
+    index = np.array(lp.a_index, dtype=np.int32).copy()
+    if corrupt == "start0":
+        start[0] = 1
+    elif corrupt == "decreasing":
+        start[1] = start[2] + 1
+    elif corrupt == "row_index":
+        index[0] = lp.num_row + 5
+    else:
+        start[-1] = len(index) + 7
+    H.struct.a_start = start.ctypes.data_as(abi.c_i32p)
+    H.struct.a_index = index.ctypes.data_as(abi.c_i32p)
+    for alg in ("pdlp", "hipdlp"):
+        F = abi.PdlpPrepared()
+        rc = solver.lib().pdlp_mi355x_host_prepare(C.byref(H.struct), C.byref(abi.default_params(solver=alg)), C.byref(F))
+        assert rc != 0 and solver.lib().pdlp_mi355x_last_error()
