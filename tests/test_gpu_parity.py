@@ -115,8 +115,20 @@ def test_trial_step_matches_oracle(which, spmv_layout):
     """One trial of cupdlp_step.c:241-257: x+, y+, A x+, A' y+ bit-identical; the three reductions
     (tree order on the GPU, left-to-right in the oracle) to 1e-12 relative."""
     for name, lp, sp_ in _problems():
-        if name != which:
-            continue
+        if name == which:
+            _trial_step_check(lp, sp_)
+
+
+def test_trial_step_matches_oracle_on_the_bench_workload(monkeypatch):
+    """The same check on BASELINE config 4 itself (1M x 1M, 8M nnz; automatic layout = slab, device-side
+    setup): the three trial sums of the GPU's reduction tree against the SERIAL oracle to 1e-12 — the guard
+    against a mistake mirrored in both the kernels and the oracle's device-order model."""
+    monkeypatch.delenv("PDLP_MI355X_SLAB", raising=False)
+    _trial_step_check(None, solver.SyntheticProblem(1000000, 1000000, 8000000, 1))
+
+
+def _trial_step_check(lp, sp_):
+    if True:
         kw = dict(problem_struct=sp_.struct) if sp_ else dict(lp=lp)
         S = solver.DeviceSolver(**kw)
         if sp_:
@@ -254,20 +266,50 @@ def test_instances_match_reference_cpu_pdlp(name):
     assert 0.25 * g["cupdlp"]["num_iter"] <= out.pdlp_iteration_count <= 4 * g["cupdlp"]["num_iter"]
 
 
-def test_synthetic_100k_matches_oracle_objective():
-    """BASELINE config 2 (100k x 100k, 1M nnz) at kkt 1e-4: both sides converge to the same optimum
-    (the oracle value is the one measured for the reference in BASELINE.md: -1.3466652515e+04)."""
-    sp_ = solver.SyntheticProblem(100000, 100000, 1000000, 1)
-    S = solver.DeviceSolver(problem_struct=sp_.struct, kkt_tolerance=1e-4)
-    R = S.run(100000, 100000)
-    assert R.term_code == abi.TERM_OPTIMAL
+SYNTH = json.load(open(os.path.join(GOLD, "reference_synth.json"))) if os.path.exists(os.path.join(GOLD, "reference_synth.json")) else {}
+
+
+def _converged_against_reference(key, m, n, nnz):
+    """BASELINE configs 2 / 4: the synthetic LP solved to the reference's DEFAULT tolerance (1e-7) on the GPU,
+    against the converged solution of the real cuPDLP-C core on the same LP (tests/golden/reference_synth.json,
+    generated by tests/golden/make_golden_synth.py): objectives to 1e-6 relative — the north_star tolerance —
+    and KKT residuals inside the termination test both sides were held to."""
+    g = SYNTH[key]
+    sp_ = solver.SyntheticProblem(m, n, nnz, 1)
+    S = solver.DeviceSolver(problem_struct=sp_.struct)  # default tolerances: 1e-7
+    assert (S.n, S.m, S.nnz) == (g["n"], g["m"], g["nnz"])
+    R = S.run(n, m)
+    assert R.term_code == abi.TERM_OPTIMAL == g["term_code"]
     lp = sp_.to_lp()
+    ref = g["objective_function_value"]
     obj = lp.objective_value(R.col_value)
-    assert abs(obj - (-1.3466652515e+04)) <= 2e-4 * 1.3466652515e+04
-    assert 900 <= R.num_iter <= 3600  # CPU reference: 1800
+    scale = 1.0 + abs(ref)
+    assert abs(obj - ref) <= 1e-6 * scale, (obj, ref)
+    assert abs(R.primal_obj - g["primal_obj"]) <= 1e-6 * scale and abs(R.dual_obj - g["dual_obj"]) <= 1e-6 * scale
+    assert R.norm_rhs == g["norm_rhs"] and R.norm_cost == g["norm_cost"]  # same formulated LP, bit for bit
+    # the reference's own termination test (cupdlp_solver.c:813-816), which its golden satisfies as well
+    assert R.primal_feas < 1e-7 * (1 + R.norm_rhs) and R.dual_feas < 1e-7 * (1 + R.norm_cost) and R.rel_gap < 1e-7
+    assert g["primal_feas"] < 1e-7 * (1 + g["norm_rhs"]) and g["rel_gap"] < 1e-7
     k = L.kkt_measures(lp, R.col_value, R.col_dual, R.row_value, R.row_dual)
-    assert k["max_primal_residual_error"] < 1e-9
+    kr = g["kkt"]
+    assert k["max_primal_residual_error"] < 1e-9 and k["max_dual_residual_error"] < 1e-9
+    assert k["max_primal_infeasibility"] <= 10 * max(kr["max_primal_infeasibility"], 1e-7)
+    assert k["max_dual_infeasibility"] <= 10 * max(kr["max_dual_infeasibility"], 1e-7)
+    assert k["primal_dual_objective_error"] <= 2e-7
+    # same ballpark of work as the CPU trajectory (not required to be equal: TestPdlp.cpp:98-113)
+    assert 0.25 * g["num_iter"] <= R.num_iter <= 4 * g["num_iter"]
     S.close()
+    return R
+
+
+@pytest.mark.skipif("a_tol1e-07" not in SYNTH, reason="golden for config 2 not generated")
+def test_synthetic_100k_converged_matches_reference():
+    _converged_against_reference("a_tol1e-07", 100000, 100000, 1000000)
+
+
+@pytest.mark.skipif("b_tol1e-07" not in SYNTH, reason="golden for config 4 not generated")
+def test_synthetic_1m_converged_matches_reference():
+    _converged_against_reference("b_tol1e-07", 1000000, 1000000, 8000000)
 
 
 def test_full_size_properties_1m():
