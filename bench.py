@@ -28,6 +28,10 @@ CONFIGS = {
     "b": dict(m=1_000_000, n=1_000_000, nnz=8_000_000, name="synthetic random sparse LP 1Mx1M, 8M nnz (seed 1)"),
     # BASELINE.json configs[1]
     "a": dict(m=100_000, n=100_000, nnz=1_000_000, name="synthetic random sparse LP 100kx100k, 1M nnz (seed 1)"),
+    # BASELINE.json configs[4]: QP prox path — the same generator at 500k x 500k (8 nnz/row) plus a random PSD
+    # diagonal Q, q_j ~ U(0,1) (numpy default_rng(1)).  No PDLP-QP exists in the reference: parity unpinned.
+    "qp": dict(m=500_000, n=500_000, nnz=4_000_000, qp=True,
+               name="synthetic random sparse QP 500kx500k, 4M nnz, diagonal Q ~ U(0,1) (seed 1)"),
 }
 PRE_ROLL = 40  # iterations of start-up excluded from every timed window
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured copy ceiling
@@ -62,6 +66,8 @@ def cpu_baseline(sp_struct, cfg, budget_iters, solver_name="pdlp"):
     R = abi.ResultHandle(sp_struct.num_col, sp_struct.num_row)
     if solver_name == "hipdlp":  # no compiled reference for this path: the oracle restatement
         kind, fn = "port", O.hipdlp_solve_fn()
+    elif sp_struct.q_dim > 0:  # no PDLP-QP in the reference: this repository's own CPU restatement
+        kind, fn = "port", O.oracle().pdlp_oracle_solve
     elif O.ref_available():
         kind, fn = "reference", O.ref().pdlp_ref_solve
     else:
@@ -126,6 +132,18 @@ def main():
         uid = (C.c_uint8 * 128)(*t.cpu().tolist())
 
     sp_ = solver.SyntheticProblem(cfg["m"], cfg["n"], cfg["nnz"], 1)
+    qkeep = None
+    if cfg.get("qp"):
+        if args.solver != "pdlp":
+            raise SystemExit("--config qp runs on the pdlp path only")
+        import numpy as np
+        ncol = sp_.struct.num_col
+        qkeep = (np.arange(ncol + 1, dtype=np.int32), np.arange(ncol, dtype=np.int32),
+                 np.random.default_rng(1).uniform(0.0, 1.0, ncol))
+        sp_.struct.q_dim = ncol
+        sp_.struct.q_start = qkeep[0].ctypes.data_as(abi.c_i32p)
+        sp_.struct.q_index = qkeep[1].ctypes.data_as(abi.c_i32p)
+        sp_.struct.q_value = qkeep[2].ctypes.data_as(abi.c_f64p)
     params = abi.default_params(kkt_tolerance=1e-4, device=local_rank, solver=args.solver)
     t_setup = time.time()
     S = solver.DeviceSolver(problem_struct=sp_.struct, params=params, rank=rank, world=world, unique_id=uid)
@@ -172,6 +190,8 @@ def main():
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         rank_consistent = bool(lo.item() == hi.item())
     b_iter, b_ax, b_aty = (algorithmic_bytes if args.solver == "pdlp" else algorithmic_bytes_hipdlp)(n, m, nnz)
+    if cfg.get("qp"):
+        b_iter += 8 * n  # the primal step also reads the diagonal of Q
     ms_step = elapsed * 1e3 / st.iters
     # long-run rate over >= 400 further iterations (whole multiples of the 40-iteration check period), so that
     # a short --steps window (which may contain no check iteration at all) can be read next to the average
@@ -240,6 +260,10 @@ def main():
                      "other_kernels_ms": {"spmv_ax_dual": k_ax, "spmv_aty_interact": k_aty},
                      "isolated_relaunch_ms": {"spmv_ax_dual": iso_ax, "spmv_aty_interact": iso_aty}},
     }
+    if cfg.get("qp"):
+        out["metric"] = "PDHG iterations/sec (QP prox path)"
+        out["parity"] = ("unpinned: the reference has no PDLP for QPs (HighsOptions.cpp:1178-1181); optimal objectives are "
+                         "pinned on the reference's QP solver for small instances (tests/golden/reference_qp.json)")
     if args.solver == "hipdlp":
         out["config"]["options"] = "presolve=off, kkt_tolerance=1e-4, Halpern restarts + PID primal weight (reference defaults)"
     if args.kernels and rank == 0 and world == 1 and args.solver == "pdlp":
@@ -249,7 +273,7 @@ def main():
         print(json.dumps({"kernels_ms": ks}), file=sys.stderr)
         out["kernels_ms"] = ks
     if rank == 0 and world == 1:
-        budget = args.cpu_iters if args.cpu_iters is not None else (120 if args.config == "b" else 3000)
+        budget = args.cpu_iters if args.cpu_iters is not None else {"b": 120, "qp": 240}.get(args.config, 3000)
         if budget > 0:
             if args.solver == "hipdlp":
                 budget = max(40, budget // 40 * 40)

@@ -45,6 +45,11 @@ class PdlpProblem(C.Structure):
         ("start_row_dual", c_f64p),
         ("start_value_valid", C.c_int32),
         ("start_dual_valid", C.c_int32),
+        ("q_dim", C.c_int32),          # HighsHessian (lower-triangular CSC); only diagonal Q is solved
+        ("reserved_q", C.c_int32),
+        ("q_start", c_i32p),
+        ("q_index", c_i32p),
+        ("q_value", c_f64p),
     ]
 
 
@@ -225,6 +230,13 @@ class ProblemHandle:
             P.start_row_dual = _ptr(self.s_rowd, c_f64p)
             P.start_value_valid = 1
             P.start_dual_valid = 1
+        hess = getattr(lp, "hessian", None)
+        if hess is not None:  # (start, index, value) of a lower-triangular column-wise HighsHessian
+            self.q_start, self.q_index, self.q_value = _i32(hess[0]), _i32(hess[1]), _f64(hess[2])
+            P.q_dim = len(self.q_start) - 1
+            P.q_start = _ptr(self.q_start, c_i32p)
+            P.q_index = _ptr(self.q_index, c_i32p)
+            P.q_value = _ptr(self.q_value, c_f64p)
         self.struct = P
 
 

@@ -15,6 +15,11 @@ const double kInf = std::numeric_limits<double>::infinity();
 
 void formulateHipdlp(const pdlp_problem_t& P, StandardForm& F) {
   validateProblem(P);
+  {
+    std::vector<double> q;
+    extractDiagonalHessian(P, 1.0, P.num_col, q);
+    if (!q.empty()) throw std::runtime_error("pdlp_mi355x: quadratic objectives are solved by the pdlp path only (algorithm = 0)");
+  }
   const int32_t n0 = P.num_col, m = P.num_row;
   const int64_t nnz0 = n0 > 0 ? P.a_start[n0] : 0;
   if (nnz0 > 0 && (!P.a_index || !P.a_value)) throw std::runtime_error("null matrix arrays");

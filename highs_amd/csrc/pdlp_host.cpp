@@ -6,6 +6,7 @@
 #include <cmath>
 #include <limits>
 #include <stdexcept>
+#include <string>
 
 namespace pdlp {
 
@@ -47,6 +48,33 @@ void validateProblem(const pdlp_problem_t& P) {
   if (nnz > 0 && (!P.a_index || !P.a_value)) throw std::runtime_error("null matrix arrays");
   for (int64_t p = 0; p < nnz; ++p)
     if (P.a_index[p] < 0 || P.a_index[p] >= P.num_row) throw std::runtime_error("row index out of range");
+}
+
+// Diagonal of the (lower-triangular, column-wise) HighsHessian times the objective sense, padded with zeros
+// for the slack columns; empty when there is no quadratic term.  Off-diagonal nonzeros are an error: the
+// primal step of this library is the closed-form proximal step of a SEPARABLE quadratic.
+void extractDiagonalHessian(const pdlp_problem_t& P, double sense, int32_t n, std::vector<double>& q) {
+  q.clear();
+  if (P.q_dim <= 0 || !P.q_start) return;
+  if (P.q_dim > P.num_col) throw std::runtime_error("Hessian dimension exceeds the number of columns");
+  const int32_t nq = P.q_start[P.q_dim];
+  if (nq > 0 && (!P.q_index || !P.q_value)) throw std::runtime_error("null Hessian arrays");
+  bool any = false;
+  std::vector<double> d((size_t)n, 0.0);
+  for (int32_t j = 0; j < P.q_dim; ++j)
+    for (int32_t p = P.q_start[j]; p < P.q_start[j + 1]; ++p) {
+      const int32_t i = P.q_index[p];
+      if (i < 0 || i >= P.q_dim) throw std::runtime_error("Hessian index out of range");
+      if (P.q_value[p] == 0.0) continue;
+      if (i != j)
+        throw std::runtime_error("pdlp_mi355x: only diagonal Hessians are supported on the PDLP path (entry (" +
+                                 std::to_string(i) + "," + std::to_string(j) + ") is off the diagonal)");
+      d[j] += P.q_value[p] * sense;
+      any = true;
+    }
+  for (double v : d)
+    if (v < 0.0) throw std::runtime_error("pdlp_mi355x: the Hessian is not positive semidefinite for this objective sense");
+  if (any) q = std::move(d);
 }
 
 void formulate(const pdlp_problem_t& P, StandardForm& F) {
@@ -111,6 +139,7 @@ void formulate(const pdlp_problem_t& P, StandardForm& F) {
     if (F.lower[j] < -kBoundInf) F.lower[j] = -kInf;
     if (F.upper[j] > kBoundInf) F.upper[j] = kInf;
   }
+  extractDiagonalHessian(P, F.sense, F.n, F.qdiag);
 
   // Matrix in the reference's entry order: per column, equality-type entries
   // first, then inequality entries (LEQ negated) (:413-436); one -1 per slack.
@@ -163,6 +192,8 @@ void applyScaling(StandardForm& F, const std::vector<double>& cs, const std::vec
     F.upper[j] *= cs[j];
     F.colScale[j] *= cs[j];
   }
+  if (!F.qdiag.empty())  // x = x'/cs  =>  1/2 q x^2 = 1/2 (q / cs^2) x'^2
+    for (int32_t j = 0; j < F.n; ++j) F.qdiag[j] = (F.qdiag[j] / cs[j]) / cs[j];
   for (int32_t i = 0; i < F.m; ++i) {
     F.rhs[i] /= rs[i];
     F.rowScale[i] *= rs[i];

@@ -41,6 +41,7 @@ struct StandardForm {
   Compressed csr;     // rows with ascending column index
   Compressed cscSorted;  // columns with ascending row index (device copy for A'y)
   std::vector<double> cost, rhs, lower, upper;
+  std::vector<double> qdiag;     // diagonal of Q (with the sense, scaled like cost twice); empty = LP
   std::vector<double> rowUpper;  // HiPDLP form only (rhs is then the row LOWER bound)
   std::vector<uint8_t> rowIsEq;  // HiPDLP form only: per PERMUTED row (is_equality_row_)
   std::vector<int32_t> rowKind;    // per ORIGINAL row
@@ -54,6 +55,7 @@ struct StandardForm {
 
 // Throws std::runtime_error on malformed input.
 void validateProblem(const pdlp_problem_t& P);
+void extractDiagonalHessian(const pdlp_problem_t& P, double sense, int32_t n, std::vector<double>& q);
 void formulate(const pdlp_problem_t& P, StandardForm& F);
 void scale(StandardForm& F, int ruizTimes = 10, double pcAlpha = 1.0);
 void finalize(StandardForm& F);  // CSR + row-sorted CSC + matNormInf

@@ -379,6 +379,7 @@ __global__ __launch_bounds__(kVecThreads) void k_primal_step(const IterVecs v, c
     double t = xv;
     t += (-tau) * ldStream(v.cost + j);
     t += tau * ldStream(aty + j);
+    if (v.qdiag) t = t / (1.0 + tau * ldStream(v.qdiag + j));
     const double u = ldStream(v.upper + j), l = ldStream(v.lower + j);
     t = t < u ? t : u;
     t = t > l ? t : l;
@@ -484,7 +485,7 @@ __global__ __launch_bounds__(kVecThreads) void k_decide_primal(const IterVecs v,
   constexpr int kPer = 2;  // elements per thread and pass, all their loads in flight together
   const int stride = gridDim.x * blockDim.x;
   const int j0 = blockIdx.x * blockDim.x + threadIdx.x;
-  double xv[kPer], av[kPer], cv[kPer], lv[kPer], uv[kPer], sv[kPer];
+  double xv[kPer], av[kPer], cv[kPer], lv[kPer], uv[kPer], sv[kPer], qv[kPer];
   auto fetchFixed = [&](int base) {
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
@@ -492,6 +493,7 @@ __global__ __launch_bounds__(kVecThreads) void k_decide_primal(const IterVecs v,
       const int jj = j < v.n ? j : v.n - 1;  // clamped, unconditional
       cv[k] = ldStream(v.cost + jj); lv[k] = ldStream(v.lower + jj); uv[k] = ldStream(v.upper + jj);
       sv[k] = ldStream(v.xSum + jj);
+      qv[k] = v.qdiag ? ldStream(v.qdiag + jj) : 0.0;
     }
   };
   auto fetchIterate = [&](int base, int par) {
@@ -535,6 +537,7 @@ __global__ __launch_bounds__(kVecThreads) void k_decide_primal(const IterVecs v,
       double t = xv[k];
       t += (-tau) * cv[k];
       t += tau * av[k];
+      if (v.qdiag) t = t / (1.0 + tau * qv[k]);  // prox of 1/2 q x^2: argmin <c - A'y, x> + q x^2/2 + (x - x_k)^2 / (2 tau)
       t = t < uv[k] ? t : uv[k];
       t = t > lv[k] ? t : lv[k];
       xn[j] = t;  // gathered by the A x+ kernel: ordinary store
@@ -620,7 +623,8 @@ __global__ __launch_bounds__(kVecThreads) void k_col_stats(const double* __restr
                                                            const double* __restrict__ cost,
                                                            const double* __restrict__ lower,
                                                            const double* __restrict__ upper,
-                                                           const double* __restrict__ colScale, int n, int scaled,
+                                                           const double* __restrict__ colScale,
+                                                           const double* __restrict__ qdiag, int n, int scaled,
                                                            double* slackPos, double* slackNeg, double* partials,
                                                            int pstride) {
   __shared__ double scratch[kVecThreads / kWave];
@@ -635,6 +639,11 @@ __global__ __launch_bounds__(kVecThreads) void k_col_stats(const double* __restr
     const double lF = l > -INFINITY ? l : 0.0, uF = u < INFINITY ? u : 0.0;
     const double atyv = aty[j];
     double r = -atyv + c;                       // c - A'y
+    if (qdiag) {                                // QP: reduced cost c + Q x - A'y, objective term 1/2 x'Qx
+      const double qj = qdiag[j];
+      r += qj * xv;
+      a[10] += (0.5 * qj * xv) * xv;
+    }
     double sp = (r > 0.0 ? r : 0.0) * hasL;     // s+ (:157-159)
     double sn = (-(r < 0.0 ? r : 0.0)) * hasU;  // s- (:171-175)
     slackPos[j] = sp;
@@ -804,10 +813,11 @@ void launchRowStats(const double* ax, const double* y, const double* rhs, const 
                      scaled, partials, stride);
 }
 void launchColStats(const double* aty, const double* x, const double* cost, const double* lower,
-                    const double* upper, const double* colScale, int32_t n, int scaled, double* slackPos,
-                    double* slackNeg, double* partials, int32_t stride, int32_t nBlocks, hipStream_t s) {
-  hipLaunchKernelGGL(k_col_stats, dim3(nBlocks), dim3(kVecThreads), 0, s, aty, x, cost, lower, upper, colScale, n,
-                     scaled, slackPos, slackNeg, partials, stride);
+                    const double* upper, const double* colScale, const double* qdiag, int32_t n, int scaled,
+                    double* slackPos, double* slackNeg, double* partials, int32_t stride, int32_t nBlocks,
+                    hipStream_t s) {
+  hipLaunchKernelGGL(k_col_stats, dim3(nBlocks), dim3(kVecThreads), 0, s, aty, x, cost, lower, upper, colScale, qdiag,
+                     n, scaled, slackPos, slackNeg, partials, stride);
 }
 void launchFinalReduce(const double* partials, int32_t stride, int32_t nBlocks, int32_t nQ, double* out,
                        hipStream_t s) {

@@ -90,6 +90,7 @@ struct IterVecs {
   const double* rhs;
   const double* lower;
   const double* upper;
+  const double* qdiag;  // diagonal of Q (QP prox step) or nullptr for an LP
   int32_t n, m;
   int32_t nEqs;       // GLOBAL count of equality rows
   int32_t rowOffset;  // global index of local row 0 (0 unless sharded)
@@ -168,10 +169,12 @@ void launchRowStats(const double* ax, const double* y, const double* rhs, const 
 //  0: sum c*x   1: sum sp*lowerF   2: sum sn*upperF   3: sum ((r-sp+sn)*colScale)^2
 //  4: sum sp^2  5: sum sn^2        6: sum ((aty+sp-sn)*colScale)^2
 //  7: sum x^2   8: sum (min(x,0)*hasLower/colScale)^2    9: sum (max(x,0)*hasUpper/colScale)^2
-constexpr int kColStats = 10;
+// 10: sum 1/2 q x^2 (QP only; the reduced cost then is c + q x - A'y)
+constexpr int kColStats = 11;
 void launchColStats(const double* aty, const double* x, const double* cost, const double* lower,
-                    const double* upper, const double* colScale, int32_t n, int scaled, double* slackPos,
-                    double* slackNeg, double* partials, int32_t stride, int32_t nBlocks, hipStream_t s);
+                    const double* upper, const double* colScale, const double* qdiag, int32_t n, int scaled,
+                    double* slackPos, double* slackNeg, double* partials, int32_t stride, int32_t nBlocks,
+                    hipStream_t s);
 // out[q] = sum_{b<nBlocks} partials[q*stride+b], q < nQ (deterministic)
 void launchFinalReduce(const double* partials, int32_t stride, int32_t nBlocks, int32_t nQ, double* out,
                        hipStream_t s);

@@ -183,6 +183,7 @@ __global__ __launch_bounds__(kVecThreads) void k_mesh_primal_step(const IterVecs
       double t = xv[q];
       t += (-tau) * cv[q];
       t += tau * av[q];
+      if (v.qdiag) t = t / (1.0 + tau * v.qdiag[j]);  // QP prox step (diagonal Q)
       t = t < uv[q] ? t : uv[q];
       t = t > lv[q] ? t : lv[q];
       xn[j] = t;

@@ -188,6 +188,7 @@ void Solver::construct(const pdlp_problem_t& P, const void* id128) {
   gpuSetup_ = nnzIn >= 200000;
   if (const char* g = getenv("PDLP_MI355X_GPU_SETUP")) gpuSetup_ = atoi(g) != 0;
   if (sharded_) gpuSetup_ = false;  // the row-block shards are cut on the host
+  if (P.q_dim > 0 && P.q_start && P.q_start[P.q_dim] > 0) gpuSetup_ = false;  // the QP form is prepared on the host
   const bool doScale = !(opt_.features_off & PDLP_FEATURE_SCALING_OFF);
   DeviceProblem devProb;
   if (gpuSetup_) {
@@ -321,6 +322,11 @@ void Solver::uploadProblem() {
   colScale_.upload(F_.colScale.data(), n, stream_);
   rhs_.upload(F_.rhs.data() + r0_, mLoc_, stream_);
   rowScale_.upload(F_.rowScale.data() + r0_, mLoc_, stream_);
+  if (!F_.qdiag.empty()) {
+    qdiag_.alloc(n);
+    qdiag_.upload(F_.qdiag.data(), n, stream_);
+    log(1, "Quadratic objective (diagonal Hessian): proximal primal step\n");
+  }
   allocIterates();
   // the big host copies are not needed any more (postsolve uses only the scale vectors and row maps)
   F_.csc = Compressed(); F_.csr = Compressed(); F_.cscSorted = Compressed();
@@ -369,10 +375,12 @@ void Solver::allocIterates() {
   }
   vecs_.xSum = xSum_.get(); vecs_.ySum = ySum_.get();
   vecs_.cost = cost_.get(); vecs_.rhs = rhs_.get(); vecs_.lower = lower_.get(); vecs_.upper = upper_.get();
+  vecs_.qdiag = qdiag_.size() ? qdiag_.get() : nullptr;
   vecs_.n = n; vecs_.m = mLoc_; vecs_.nEqs = F_.nEqs; vecs_.rowOffset = r0_;
   vecsCol_ = vecs_;
   for (int k = 0; k < 2; ++k) { vecsCol_.x[k] += c0_; vecsCol_.aty[k] += c0_; }
   vecsCol_.xSum += c0_; vecsCol_.cost += c0_; vecsCol_.lower += c0_; vecsCol_.upper += c0_;
+  if (vecsCol_.qdiag) vecsCol_.qdiag += c0_;
   vecsCol_.n = nLoc_;
   PDLP_HIP(hipStreamSynchronize(stream_));
 }
@@ -711,11 +719,12 @@ void Solver::computeResiduals() {
                  part + (size_t)kStatRowCur * statStride_, statStride_, nbM, stream_);
   launchRowStats(axAvg_.get(), yAvg_.get(), rhs_.get(), rowScale_.get(), mLoc_, F_.nEqs, r0_, sc,
                  part + (size_t)kStatRowAvg * statStride_, statStride_, nbM, stream_);
+  const double* qd = qdiag_.size() ? qdiag_.get() + co : nullptr;
   launchColStats(aty_[c].get() + co, x_[c].get() + co, cost_.get() + co, lower_.get() + co, upper_.get() + co,
-                 colScale_.get() + co, nLoc_, sc, slackPos_.get() + co, slackNeg_.get() + co,
+                 colScale_.get() + co, qd, nLoc_, sc, slackPos_.get() + co, slackNeg_.get() + co,
                  part + (size_t)kStatColCur * statStride_, statStride_, nbN, stream_);
   launchColStats(atyAvg_.get() + co, xAvg_.get() + co, cost_.get() + co, lower_.get() + co, upper_.get() + co,
-                 colScale_.get() + co, nLoc_, sc, slackPosAvg_.get() + co, slackNegAvg_.get() + co,
+                 colScale_.get() + co, qd, nLoc_, sc, slackPosAvg_.get() + co, slackNegAvg_.get() + co,
                  part + (size_t)kStatColAvg * statStride_, statStride_, nbN, stream_);
   launchFinalReduce(part, statStride_, nbM, 2 * kRowStats, statOut_.get(), stream_);
   launchFinalReduce(part + (size_t)kStatColCur * statStride_, statStride_, nbN, 2 * kColStats,
@@ -729,9 +738,10 @@ void Solver::computeResiduals() {
   }
 
   auto fill = [&](Residuals& r, const double* rs, const double* cs) {
-    r.pObj = cs[0] * F_.sense + F_.offset;
+    // QP (cs[10] = 1/2 x'Qx, zero for an LP): primal c'x + 1/2 x'Qx, dual b'y + l's+ - u's- - 1/2 x'Qx
+    r.pObj = (qdiag_.size() ? cs[0] + cs[10] : cs[0]) * F_.sense + F_.offset;
     r.pFeas = std::sqrt(rs[0]);
-    r.dObj = (rs[1] + cs[1] - cs[2]) * F_.sense + F_.offset;
+    r.dObj = (qdiag_.size() ? ((rs[1] + cs[1]) - cs[2]) - cs[10] : (rs[1] + cs[1] - cs[2])) * F_.sense + F_.offset;
     r.dFeas = std::sqrt(cs[3]);
     r.gap = r.pObj - r.dObj;
     r.relGap = std::fabs(r.pObj - r.dObj) / (1.0 + std::fabs(r.pObj) + std::fabs(r.dObj));

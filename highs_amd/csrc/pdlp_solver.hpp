@@ -130,7 +130,7 @@ class Solver : public SolverBase {
   DeviceMatrix dA_, dAt_;
   DeviceArray<double> x_[2], y_[2], ax_[2], aty_[2];
   DeviceArray<double> xAvg_, yAvg_, axAvg_, atyAvg_, xSum_, ySum_, xLast_, yLast_;
-  DeviceArray<double> cost_, rhs_, lower_, upper_, colScale_, rowScale_;
+  DeviceArray<double> cost_, rhs_, lower_, upper_, colScale_, rowScale_, qdiag_;  // qdiag_: QP only
   DeviceArray<double> slackPos_, slackNeg_, slackPosAvg_, slackNegAvg_;
   DeviceArray<double> partDY_, partDX_, partInter_, statPart_, statOut_, commBuf_, tmpM_, gatherBuf_;
   // Two slots: the single-GPU loop alternates between them from trial to trial (k_decide_primal reads

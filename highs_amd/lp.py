@@ -28,6 +28,27 @@ class HighsLp:
     sense: int = 1  # ObjSense::kMinimize = 1, kMaximize = -1
     offset: float = 0.0
     model_name: str = ""
+    # HighsModel::hessian_ (model/HighsHessian.h): (start, index, value), lower-triangular column-wise; None = LP
+    hessian: tuple = None
+
+    def set_diagonal_hessian(self, q_diag):
+        """+ 1/2 sum_j q_j x_j^2 as a HighsHessian with one entry per column."""
+        q = np.ascontiguousarray(q_diag, dtype=np.float64)
+        assert len(q) == self.num_col
+        self.hessian = (np.arange(self.num_col + 1, dtype=np.int32), np.arange(self.num_col, dtype=np.int32), q)
+        return self
+
+    def hessian_diagonal(self):
+        """Diagonal of Q as a dense vector (zeros for an LP); raises if Q has off-diagonal entries."""
+        q = np.zeros(self.num_col)
+        if self.hessian is None:
+            return q
+        st, idx, val = self.hessian
+        cols = np.repeat(np.arange(len(st) - 1), np.diff(st))
+        if np.any((idx != cols) & (val != 0)):
+            raise ValueError("off-diagonal Hessian entries")
+        np.add.at(q, cols[idx == cols], val[idx == cols])
+        return q
 
     def normalise(self):
         f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
@@ -42,8 +63,12 @@ class HighsLp:
         return int(self.a_start[self.num_col])
 
     def objective_value(self, col_value):
-        """HighsLp::objectiveValue: offset + c'x (no sense factor)."""
-        return float(self.offset + np.dot(self.col_cost, col_value))
+        """HighsModel::objectiveValue: offset + c'x + 1/2 x'Qx (no sense factor)."""
+        x = np.asarray(col_value)
+        v = float(self.offset + np.dot(self.col_cost, x))
+        if self.hessian is not None:
+            v += 0.5 * float(np.dot(self.hessian_diagonal() * x, x))
+        return v
 
     def row_activity(self, col_value):
         out = np.zeros(self.num_row)
@@ -56,14 +81,19 @@ class HighsLp:
                             col_lower=self.col_lower, col_upper=self.col_upper, row_lower=self.row_lower,
                             row_upper=self.row_upper, a_start=self.a_start, a_index=self.a_index,
                             a_value=self.a_value, sense=self.sense, offset=self.offset,
-                            model_name=np.array(self.model_name))
+                            model_name=np.array(self.model_name),
+                            **({} if self.hessian is None else {"q_start": self.hessian[0], "q_index": self.hessian[1],
+                                                                 "q_value": self.hessian[2]}))
 
     @staticmethod
     def from_npz(path):
         z = np.load(path, allow_pickle=False)
-        return HighsLp(int(z["num_col"]), int(z["num_row"]), z["col_cost"], z["col_lower"], z["col_upper"],
-                       z["row_lower"], z["row_upper"], z["a_start"], z["a_index"], z["a_value"],
-                       int(z["sense"]), float(z["offset"]), str(z["model_name"])).normalise()
+        lp = HighsLp(int(z["num_col"]), int(z["num_row"]), z["col_cost"], z["col_lower"], z["col_upper"],
+                     z["row_lower"], z["row_upper"], z["a_start"], z["a_index"], z["a_value"],
+                     int(z["sense"]), float(z["offset"]), str(z["model_name"])).normalise()
+        if "q_start" in z.files:
+            lp.hessian = (z["q_start"].astype(np.int32), z["q_index"].astype(np.int32), z["q_value"].astype(np.float64))
+        return lp
 
     @staticmethod
     def from_rowwise(num_col, num_row, r_start, r_index, r_value, **kw):
@@ -279,13 +309,14 @@ def kkt_measures(lp, col_value, col_dual, row_value, row_dual, primal_feasibilit
     dinf = np.where(meaningful & ~below, np.maximum(dual, 0.0), dinf)
     # residuals: |Ax - row_value| and |A'y + col_dual - c| (HighsSolution.cpp:196-199,263-268,400+)
     pres = np.abs(ax - rv)
-    dres = np.abs(aty + cd - lp.col_cost)
+    qx = lp.hessian_diagonal() * x  # zeros for an LP
+    dres = np.abs(aty + cd - lp.col_cost - qx)
     # dual objective: offset + sum bound * dual, bound = lower if primal < mid else upper; free -> 1
     ndual = np.concatenate([cd, rd])
     bound = np.where(free, 1.0, np.where(below, lower, upper))
     with np.errstate(invalid="ignore"):
         terms = np.where(ndual == 0.0, 0.0, bound * ndual)
-    dobj = float(lp.offset + np.sum(terms))
+    dobj = float(lp.offset + np.sum(terms) - 0.5 * np.dot(qx, x))
     return {
         "objective_function_value": obj,
         "dual_objective_value": dobj,
@@ -350,4 +381,11 @@ def write_mps(lp, path):
                     f.write(f" LO BND C{j} {float(lo)!r}\n")
                 if up < inf:
                     f.write(f" UP BND C{j} {float(up)!r}\n")
+        if lp.hessian is not None:  # lower triangle of Q: QUADOBJ (what HMpsFF.cpp reads into HighsHessian)
+            st, idx, val = lp.hessian
+            f.write("QUADOBJ\n")
+            for j in range(len(st) - 1):
+                for p in range(st[j], st[j + 1]):
+                    if val[p] != 0.0:
+                        f.write(f" C{j} C{idx[p]} {float(val[p])!r}\n")
         f.write("ENDATA\n")

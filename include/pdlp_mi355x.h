@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define PDLP_MI355X_ABI_VERSION 3
+#define PDLP_MI355X_ABI_VERSION 4
 
 /* Termination codes: same numbering as cuPDLP-C's termination_code
  * (cupdlp_defs.h:61-68) so the status map of CupdlpWrapper.cpp:225-251
@@ -86,6 +86,16 @@ typedef struct pdlp_problem {
   const double* start_row_dual;  /* [num_row] */
   int32_t start_value_valid;
   int32_t start_dual_valid;
+  /* Optional quadratic objective  + 1/2 x' Q x  (no reference counterpart on the PDLP
+   * path: HiGHS gates solver="pdlp" to LPs, lp_data/HighsOptions.cpp:1178-1181).  Q as HiGHS holds it in
+   * HighsHessian (model/HighsHessian.h:22-34): lower-triangular, column-wise, dimension q_dim <= num_col.
+   * This library solves the case of a DIAGONAL Q (closed-form proximal primal step); off-diagonal
+   * nonzeros are rejected with an error.  q_dim = 0 / NULL arrays = LP. */
+  int32_t q_dim;
+  int32_t reserved_q;
+  const int32_t* q_start; /* [q_dim+1] */
+  const int32_t* q_index; /* [q_start[q_dim]] row indices (>= column index: lower triangle) */
+  const double* q_value;
 } pdlp_problem_t;
 
 /* Options, one field per entry that getUserParamsFromOptions

@@ -87,6 +87,7 @@ typedef struct {
   int *csrBeg, *csrIdx;
   double* csrVal;
   double *cost, *rhs, *lower, *upper, *hasLower, *hasUpper, *lowerF, *upperF;
+  double* qdiag; /* QP extension (no reference counterpart on this path): diagonal of Q, NULL for an LP */
   int *rowType, *rowNewIdx;
   double offset, sense;
   /* scaling */
@@ -134,7 +135,7 @@ static void work_free(Work* w) {
   free(w->cscBeg); free(w->cscIdx); free(w->cscVal);
   free(w->csrBeg); free(w->csrIdx); free(w->csrVal);
   free(w->cost); free(w->rhs); free(w->lower); free(w->upper);
-  free(w->hasLower); free(w->hasUpper); free(w->lowerF); free(w->upperF);
+  free(w->hasLower); free(w->hasUpper); free(w->lowerF); free(w->upperF); free(w->qdiag);
   free(w->rowType); free(w->rowNewIdx); free(w->colScale); free(w->rowScale);
   for (int k = 0; k < 2; ++k) { free(w->x[k]); free(w->y[k]); free(w->ax[k]); free(w->aty[k]); }
   free(w->xAvg); free(w->yAvg); free(w->axAvg); free(w->atyAvg);
@@ -187,6 +188,21 @@ static int formulate(Work* w, const pdlp_problem_t* P) {
     if (w->lower[j] < -1e20) w->lower[j] = -INFINITY;
     if (w->upper[j] > 1e20) w->upper[j] = INFINITY;
   }
+  /* QP extension: + 1/2 x'Qx with a DIAGONAL Q given as a lower-triangular column-wise HighsHessian
+   * (model/HighsHessian.h:22-34); off-diagonal nonzeros are refused, as in the product */
+  w->qdiag = NULL;
+  if (P->q_dim > 0 && P->q_start && P->q_start[P->q_dim] > 0) {
+    int any = 0;
+    double* q = dalloc(n);
+    for (int j = 0; j < P->q_dim; ++j)
+      for (int p = P->q_start[j]; p < P->q_start[j + 1]; ++p) {
+        if (P->q_value[p] == 0.0) continue;
+        if (P->q_index[p] != j) { free(q); return 1; }
+        q[j] += P->q_value[p] * w->sense;
+        any = 1;
+      }
+    if (any) w->qdiag = q; else free(q);
+  }
   /* row permutation: EQ/BOUND first (:382-392), then LEQ (negated) / GEQ (:394-404) */
   for (int i = 0, k = 0; i < m; ++i) {
     if (w->rowType[i] == ROW_EQ) { w->rhs[k] = P->row_lower[i]; w->rowNewIdx[i] = k++; }
@@ -224,6 +240,7 @@ static int formulate(Work* w, const pdlp_problem_t* P) {
 static void scale_apply(Work* w, const double* cs, const double* rs) {
   const int n = w->n, m = w->m;
   o_ediv(n, w->cost, cs);
+  if (w->qdiag) { o_ediv(n, w->qdiag, cs); o_ediv(n, w->qdiag, cs); } /* 1/2 q x^2 with x = x'/cs */
   o_emul(n, w->lower, cs);
   o_emul(n, w->upper, cs);
   o_ediv(m, w->rhs, rs);
@@ -507,7 +524,9 @@ static double g_col_elem(const void* vc, int j) {
   const double hasL = l > -INFINITY ? 1.0 : 0.0, hasU = u < INFINITY ? 1.0 : 0.0;
   const double lF = l > -INFINITY ? l : 0.0, uF = u < INFINITY ? u : 0.0;
   const double atyv = c->aty[j];
-  const double r = -atyv + cj;
+  double r = -atyv + cj;
+  const double qj = w->qdiag ? w->qdiag[j] : 0.0;
+  if (w->qdiag) r += qj * xv; /* reduced cost c + Qx - A'y */
   const double sp = (r > 0.0 ? r : 0.0) * hasL;
   const double sn = (-(r < 0.0 ? r : 0.0)) * hasU;
   switch (c->q) {
@@ -520,6 +539,7 @@ static double g_col_elem(const void* vc, int j) {
     case 6: { double pc = (atyv + sp) - sn; pc *= cs; return pc * pc; }
     case 7: return xv * xv;
     case 8: { double lb = (xv < 0.0 ? xv : 0.0) * hasL; if (w->ifScaled) lb /= cs; return lb * lb; }
+    case 10: return (0.5 * qj * xv) * xv;
     default: { double ub = (xv > 0.0 ? xv : 0.0) * hasU; if (w->ifScaled) ub /= cs; return ub * ub; }
   }
 }
@@ -529,18 +549,21 @@ static void g_residuals(Work* w, const double* x, const double* y, const double*
                         double* gap, double* relGap, double* pInfObj, double* pInfRes, double* dInfObj,
                         double* dInfRes) {
   GStatCtx c = {w, ax, y, aty, x, 0};
-  double rs[4], cs[10];
+  double rs[4], cs[11];
   for (int q = 0; q < 4; ++q) { c.q = q; rs[q] = g_grid_sum(w->m, g_row_elem, &c, w->gStat); }
   for (int q = 0; q < 10; ++q) { c.q = q; cs[q] = g_grid_sum(w->n, g_col_elem, &c, w->gStat); }
+  cs[10] = 0.0;
+  if (w->qdiag) { c.q = 10; cs[10] = g_grid_sum(w->n, g_col_elem, &c, w->gStat); }
   for (int j = 0; j < w->n; ++j) { /* slacks as k_col_stats stores them */
     const double l = w->lower[j], u = w->upper[j];
-    const double r = -aty[j] + w->cost[j];
+    double r = -aty[j] + w->cost[j];
+    if (w->qdiag) r += w->qdiag[j] * x[j];
     sp[j] = (r > 0.0 ? r : 0.0) * (l > -INFINITY ? 1.0 : 0.0);
     sn[j] = (-(r < 0.0 ? r : 0.0)) * (u < INFINITY ? 1.0 : 0.0);
   }
-  *pObj = cs[0] * w->sense + w->offset;
+  *pObj = (w->qdiag ? cs[0] + cs[10] : cs[0]) * w->sense + w->offset;
   *pFeas = sqrt(rs[0]);
-  *dObj = (rs[1] + cs[1] - cs[2]) * w->sense + w->offset;
+  *dObj = (w->qdiag ? ((rs[1] + cs[1]) - cs[2]) - cs[10] : (rs[1] + cs[1] - cs[2])) * w->sense + w->offset;
   *dFeas = sqrt(cs[3]);
   *gap = *pObj - *dObj;
   *relGap = fabs(*pObj - *dObj) / (1.0 + fabs(*pObj) + fabs(*dObj));
@@ -562,7 +585,9 @@ static double g_dot_elem(const void* vc, int i) { const GDiffCtx* c = (const GDi
 /* ------------------------------------------------------------------ */
 static void primal_feasibility(Work* w, const double* ax, const double* x, double* feas, double* obj) {
   const int n = w->n, m = w->m;
-  *obj = o_dot(n, x, w->cost) * w->sense + w->offset;
+  double cx = o_dot(n, x, w->cost);
+  if (w->qdiag) { double h = 0.0; for (int j = 0; j < n; ++j) h += (0.5 * w->qdiag[j] * x[j]) * x[j]; cx += h; }
+  *obj = cx * w->sense + w->offset;
   double* r = w->bufM;
   memcpy(r, ax, sizeof(double) * (size_t)m);
   o_axpy(m, -1.0, w->rhs, r);
@@ -570,7 +595,7 @@ static void primal_feasibility(Work* w, const double* ax, const double* x, doubl
   if (w->ifScaled) o_emul(m, r, w->rowScale);
   *feas = o_nrm2(m, r);
 }
-static void dual_feasibility(Work* w, const double* aty, const double* y, double* feas, double* obj,
+static void dual_feasibility(Work* w, const double* aty, const double* y, const double* x, double* feas, double* obj,
                              double* sp, double* sn) {
   const int n = w->n, m = w->m;
   double d = o_dot(m, y, w->rhs);
@@ -578,6 +603,9 @@ static void dual_feasibility(Work* w, const double* aty, const double* y, double
   memcpy(r, aty, sizeof(double) * (size_t)n);
   o_scal(n, -1.0, r);
   o_axpy(n, 1.0, w->cost, r);
+  double qh = 0.0;
+  if (w->qdiag)
+    for (int j = 0; j < n; ++j) { r[j] += w->qdiag[j] * x[j]; qh += (0.5 * w->qdiag[j] * x[j]) * x[j]; }
   memcpy(sp, r, sizeof(double) * (size_t)n);
   o_proj_pos(n, sp);
   o_emul(n, sp, w->hasLower);
@@ -587,6 +615,7 @@ static void dual_feasibility(Work* w, const double* aty, const double* y, double
   o_scal(n, -1.0, sn);
   o_emul(n, sn, w->hasUpper);
   d -= o_dot(n, sn, w->upperF);
+  d -= qh;
   *obj = d * w->sense + w->offset;
   o_axpy(n, -1.0, sp, r);
   o_axpy(n, 1.0, sn, r);
@@ -605,9 +634,9 @@ static void compute_residuals(Work* w) {
     return;
   }
   primal_feasibility(w, w->ax[c], w->x[c], &w->pFeas, &w->pObj);
-  dual_feasibility(w, w->aty[c], w->y[c], &w->dFeas, &w->dObj, w->slackPos, w->slackNeg);
+  dual_feasibility(w, w->aty[c], w->y[c], w->x[c], &w->dFeas, &w->dObj, w->slackPos, w->slackNeg);
   primal_feasibility(w, w->axAvg, w->xAvg, &w->pFeasA, &w->pObjA);
-  dual_feasibility(w, w->atyAvg, w->yAvg, &w->dFeasA, &w->dObjA, w->slackPosAvg, w->slackNegAvg);
+  dual_feasibility(w, w->atyAvg, w->yAvg, w->xAvg, &w->dFeasA, &w->dObjA, w->slackPosAvg, w->slackNegAvg);
   w->gap = w->pObj - w->dObj;
   w->relGap = fabs(w->pObj - w->dObj) / (1.0 + fabs(w->pObj) + fabs(w->dObj));
   w->gapA = w->pObjA - w->dObjA;
@@ -677,6 +706,8 @@ static void primal_step(Work* w, double* xU, const double* x, const double* aty,
   memcpy(xU, x, sizeof(double) * (size_t)n);
   o_axpy(n, -tau, w->cost, xU);
   o_axpy(n, tau, aty, xU);
+  if (w->qdiag) /* prox of the separable quadratic: argmin <c - A'y, x> + 1/2 q x^2 + (x - x_k)^2 / (2 tau) */
+    for (int j = 0; j < n; ++j) xU[j] = xU[j] / (1.0 + tau * w->qdiag[j]);
   o_proj_ub_vec(n, xU, w->upper);
   o_proj_lb_vec(n, xU, w->lower);
 }

@@ -64,3 +64,12 @@ def drop_free_rows(lp):
     return L.HighsLp(lp.num_col, int(keep.sum()), lp.col_cost, lp.col_lower, lp.col_upper, lp.row_lower[keep],
                      lp.row_upper[keep], a_start, newidx[lp.a_index[sel]].astype(np.int32), lp.a_value[sel],
                      lp.sense, lp.offset).normalise()
+
+
+def random_diag_qp(seed, m=None, n=None):
+    """random_lp(seed) made a convex QP: + 1/2 sum q_j x_j^2 with q_j = 0 for about a third of the columns and
+    U(0.1, 3) for the rest (times the objective sense, so that the maximisation instances stay concave)."""
+    lp = drop_free_rows(random_lp(seed, m, n))
+    rng = np.random.default_rng(1000 + seed)
+    q = np.where(rng.random(lp.num_col) < 0.35, 0.0, rng.uniform(0.1, 3.0, lp.num_col))
+    return lp.set_diagonal_hessian(lp.sense * q)
