@@ -30,6 +30,10 @@ CONFIGS = {
     "a": dict(m=100_000, n=100_000, nnz=1_000_000, name="synthetic random sparse LP 100kx100k, 1M nnz (seed 1)"),
     # BASELINE.json configs[4]: QP prox path — the same generator at 500k x 500k (8 nnz/row) plus a random PSD
     # diagonal Q, q_j ~ U(0,1) (numpy default_rng(1)).  No PDLP-QP exists in the reference: parity unpinned.
+    # BASELINE.json configs[2] stand-in (pds-100 is not in the reference tree, no network): the block-angular
+    # multi-commodity network LP of tests/lpgen.py::structured_lp — 64 network blocks, 256 dense linking rows of
+    # 4096 nonzeros (long-major side kernel), ranged and free rows: 2.1M columns, 263k rows, 5.3M nonzeros
+    "c": dict(structured=True, name="structured block-angular network LP, 263k x 2.1M, 5.3M nnz, 256 dense linking rows (seed 1)"),
     "qp": dict(m=500_000, n=500_000, nnz=4_000_000, qp=True,
                name="synthetic random sparse QP 500kx500k, 4M nnz, diagonal Q ~ U(0,1) (seed 1)"),
 }
@@ -131,7 +135,12 @@ def main():
         dist.broadcast(t, src=0)
         uid = (C.c_uint8 * 128)(*t.cpu().tolist())
 
-    sp_ = solver.SyntheticProblem(cfg["m"], cfg["n"], cfg["nnz"], 1)
+    if cfg.get("structured"):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from lpgen import structured_lp
+        sp_ = abi.ProblemHandle(structured_lp(1))  # same attribute (.struct) as the library-generated problem
+    else:
+        sp_ = solver.SyntheticProblem(cfg["m"], cfg["n"], cfg["nnz"], 1)
     qkeep = None
     if cfg.get("qp"):
         if args.solver != "pdlp":
@@ -266,6 +275,10 @@ def main():
                          "pinned on the reference's QP solver for small instances (tests/golden/reference_qp.json)")
     if args.solver == "hipdlp":
         out["config"]["options"] = "presolve=off, kkt_tolerance=1e-4, Halpern restarts + PID primal weight (reference defaults)"
+    if cfg.get("structured") and world == 1 and args.solver == "pdlp":
+        # the dense linking rows (> 256 nonzeros) are left to the CSR side kernel: its share of the plain A x
+        side, slab = S.time_kernel("spmv_ax_plain_side", 50), S.time_kernel("spmv_ax_plain_slab", 50)
+        out["long_major_side_kernel"] = {"spmv_ax_side_ms": side, "spmv_ax_slab_ms": slab, "share": side / (side + slab)}
     if args.kernels and rank == 0 and world == 1 and args.solver == "pdlp":
         ks = {k: S.time_kernel(k, 50) for k in ("decide_primal", "primal_step", "spmv_ax", "spmv_aty", "decide", "trial",
                                                 "spmv_ax_plain", "spmv_aty_plain", "copy")}
@@ -273,7 +286,7 @@ def main():
         print(json.dumps({"kernels_ms": ks}), file=sys.stderr)
         out["kernels_ms"] = ks
     if rank == 0 and world == 1:
-        budget = args.cpu_iters if args.cpu_iters is not None else {"b": 120, "qp": 240}.get(args.config, 3000)
+        budget = args.cpu_iters if args.cpu_iters is not None else {"b": 120, "qp": 240, "c": 240}.get(args.config, 3000)
         if budget > 0:
             if args.solver == "hipdlp":
                 budget = max(40, budget // 40 * 40)

@@ -140,6 +140,9 @@ void HalpernSolver::construct(const pdlp_problem_t& P, const void* id128) {
   memset(hostState_, 0, sizeof(HalpernState));
   PDLP_HIP(hipStreamSynchronize(stream_));
   F_.csc = Compressed(); F_.csr = Compressed(); F_.cscSorted = Compressed();
+  // block -> XCD assignment of the two operands (scratch vectors: any input will do)
+  tuneXcdMap(dA_, tmpN_.get(), tmpM_.get(), stream_);
+  tuneXcdMap(dAt_, tmpM_.get(), tmpN_.get(), stream_);
   reset();
   setupSeconds_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }

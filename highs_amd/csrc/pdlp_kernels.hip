@@ -27,6 +27,7 @@ constexpr bool usesDevState(int epi) { return epi == kDualStep || epi == kAtyInt
 struct SpmvArgs {
   SpmvMat A;
   SlabMat S;
+  int32_t xcdMap;  // 1: XCD x owns a contiguous range of work blocks (see xcdContiguousBlock)
   const DevState* st;  // nullptr for kPlain
   // kPlain / kAtyPartial
   const double* in;
@@ -43,6 +44,21 @@ struct SpmvArgs {
 template <typename T>
 __device__ __forceinline__ T ldUniform(const T* p) {
   return *(const __attribute__((address_space(4))) T*)(p);
+}
+
+// XCD-aware work assignment.  Workgroup b runs on XCD b % 8 (observed dispatch order; only a speed
+// assumption), and each XCD has its own L2.  Consecutive work blocks own consecutive majors, which in a
+// structured LP (network blocks, staircases) touch neighbouring minors: giving XCD x the CONTIGUOUS range of
+// logical blocks [x*nB/8, (x+1)*nB/8) keeps the part of the gathered vector an XCD needs at 1/8 of it instead of
+// all of it (measured on the block-angular LP of bench.py --config c: A x 73 -> 50 us, L2 misses 2.5 M -> 0.9 M;
+// its transpose prefers round robin, 25 vs 39 us, and a random matrix does not care), so the mapping is chosen
+// per operand by timing both at setup (tuneXcdMap).  Results do not depend on it: partials are indexed by the
+// logical block.
+__device__ __forceinline__ int xcdContiguousBlock(int b, int nB) {
+  constexpr int kXcds = 8;
+  const int xcd = b % kXcds, i = b / kXcds;
+  const int qlo = nB / kXcds, r = nB % kXcds;
+  return xcd < r ? xcd * (qlo + 1) + i : r * (qlo + 1) + (xcd - r) * qlo + i;
 }
 
 // The major-local epilogue fused into both SpMV kernels: what happens to (A v)_r once it is known.
@@ -148,7 +164,7 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
   __shared__ double scratch[2][kSpmvThreads / kWave];
 
   const int tid = threadIdx.x;
-  const int blk = blockIdx.x;
+  const int blk = a.xcdMap ? xcdContiguousBlock(blockIdx.x, a.A.nBlocks) : (int)blockIdx.x;
   const int r0 = a.A.blockBeg[blk], r1 = a.A.blockBeg[blk + 1];
   const int p0 = a.A.beg[r0], p1 = a.A.beg[r1];
   const int32_t* __restrict__ idx = a.A.idx;
@@ -250,7 +266,7 @@ __global__ __launch_bounds__(kSlabThreads, kSlabThreads / 256) void k_spmv_slab(
 
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
-  const int blk = blockIdx.x;
+  const int blk = a.xcdMap ? xcdContiguousBlock(blockIdx.x, a.S.nBlocks) : (int)blockIdx.x;
   const int Rw = R / kWaves;
   const int mb = a.S.minorBits;
   const uint32_t mmask = (1u << mb) - 1u;
@@ -336,7 +352,12 @@ __global__ __launch_bounds__(kSlabThreads, kSlabThreads / 256) void k_spmv_slab(
       auto addRun = [&]() {
         double s = wacc[lrow];
         s += prod;
-        for (int j = lane + 1; j < end; ++j) s += stg[j];
+        int j = lane + 1;
+        for (; j + 4 <= end; j += 4) {  // long runs (clustered columns): four LDS reads in flight per step
+          const double t0 = stg[j], t1 = stg[j + 1], t2 = stg[j + 2], t3 = stg[j + 3];
+          s += t0; s += t1; s += t2; s += t3;
+        }
+        for (; j < end; ++j) s += stg[j];
         wacc[lrow] = s;
       };
       if (descs == 0) {
@@ -721,6 +742,7 @@ void launchPrimalStep(const IterVecs& v, const DevState* st, hipStream_t s) {
 namespace {
 template <int EPI>
 void launchSpmv(const MatView& M, SpmvArgs a, hipStream_t s) {
+  a.xcdMap = M.xcdMap;
   if (M.useSlab && M.slab.nBlocks > 0) {
     a.S = M.slab;
     const size_t lds = (size_t)M.slab.rowsPerBlock * 8 + kSlabThreads * 8 + 2 * (kSlabThreads / kWave) * 8;

@@ -76,6 +76,7 @@ struct MatView {
   SlabMat slab;
   int32_t useSlab;
   int32_t nPartials;  // slab.nBlocks (if used) + csr.nBlocks
+  int32_t xcdMap;     // 1: XCD x owns a contiguous range of work blocks, 0: round robin (chosen per operand at setup)
 };
 
 // Vectors of the iteration (device pointers). Pairs are double-buffered by parity.

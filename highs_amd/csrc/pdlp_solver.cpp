@@ -125,8 +125,39 @@ MatView DeviceMatrix::view() const {
                   useSlab ? majorMap.get() : nullptr, useSlab ? slab.nBlocks : 0};
   v.slab = slab;
   v.useSlab = useSlab ? 1 : 0;
+  v.xcdMap = xcdMap;
   v.nPartials = nPartials();
   return v;
+}
+
+void tuneXcdMap(DeviceMatrix& M, const double* in, double* out, hipStream_t s) {
+  if (const char* e = getenv("PDLP_MI355X_XCD_MAP")) {
+    M.xcdMap = atoi(e) != 0;
+    return;
+  }
+  if (M.nnz < 200000) {  // small operands live in every L2 anyway
+    M.xcdMap = 1;
+    return;
+  }
+  hipEvent_t e0, e1;
+  PDLP_HIP(hipEventCreate(&e0));
+  PDLP_HIP(hipEventCreate(&e1));
+  float best = 0.f;
+  int bestMap = 1;
+  for (int map = 0; map < 2; ++map) {
+    M.xcdMap = map;
+    launchSpmvPlain(M.view(), in, out, s);  // warm-up
+    PDLP_HIP(hipEventRecord(e0, s));
+    for (int r = 0; r < 3; ++r) launchSpmvPlain(M.view(), in, out, s);
+    PDLP_HIP(hipEventRecord(e1, s));
+    PDLP_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    PDLP_HIP(hipEventElapsedTime(&ms, e0, e1));
+    if (map == 0 || ms < 0.97f * best) { best = ms; bestMap = map; }  // contiguous only when clearly faster
+  }
+  M.xcdMap = bestMap;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
 }
 
 double Solver::elapsed() const {
@@ -281,6 +312,9 @@ void Solver::construct(const pdlp_problem_t& P, const void* id128) {
   mLoc_ = r1_ - r0_;
   if (gpuSetup_) uploadProblemFromDevice(devProb);
   else uploadProblem();
+  // block -> XCD assignment of the two operands (x_ / y_ are zero here: any input will do)
+  tuneXcdMap(dA_, x_[0].get(), ax_[0].get(), stream_);
+  tuneXcdMap(dAt_, y_[0].get(), sharded_ ? commBuf_.get() : aty_[0].get(), stream_);
   reset();
   // the trial-batch graph is part of the setup, not of the first iterations
   if (useGraph_ && (!sharded_ || meshMode_)) captureGraph();
@@ -1154,6 +1188,11 @@ double Solver::timeKernel(const std::string& name, int32_t reps) {
       launchDecide(dst(), partDY_.get(), dA_.nPartials(), partDX_.get(), partInter_.get(), dAt_.nPartials(), nullptr, stream_);
     else if (name == "trial") enqueueTrial();
     else if (name == "spmv_ax_plain") launchSpmvPlain(dA_.view(), x_[0].get(), tmpM_.get(), stream_);
+    else if (name == "spmv_ax_plain_slab" || name == "spmv_ax_plain_side") {  // the two launches of a slab-layout A x apart
+      MatView v = dA_.view();
+      if (name == "spmv_ax_plain_slab") v.csr.nBlocks = 0; else v.slab.nBlocks = 0;
+      launchSpmvPlain(v, x_[0].get(), tmpM_.get(), stream_);
+    }
     else if (name == "spmv_aty_plain") launchSpmvPlain(dAt_.view(), y_[0].get(), commBuf_.get(), stream_);
     else if (name == "copy")
       PDLP_HIP(hipMemcpyAsync(big.get() + bigCount, big.get(), sizeof(double) * bigCount, hipMemcpyDeviceToDevice, stream_));

@@ -26,6 +26,7 @@ struct DeviceMatrix {
   int32_t nMajor = 0, nBlocks = 0;  // nBlocks = CSR stream blocks
   int64_t nnz = 0;
   bool useSlab = false;
+  int32_t xcdMap = 1;  // block -> XCD assignment of the SpMV kernels (pdlp_kernels.hip xcdContiguousBlock), see tuneXcdMap
   SlabMat slab{};
   // mode: 0 = CSR stream only, 1 = slab layout (+ long-major side CSR), -1 = auto by nMinor
   void upload(const Compressed& c, int32_t nMajor_, int32_t nMinor_, int mode, hipStream_t s);
@@ -34,6 +35,10 @@ struct DeviceMatrix {
   MatView view() const;
   int32_t nPartials() const { return (useSlab ? slab.nBlocks : 0) + nBlocks; }
 };
+
+// Picks M.xcdMap by timing the plain SpMV out = M * in with both block -> XCD assignments (a few launches; the
+// result vector is scratch).  PDLP_MI355X_XCD_MAP=0|1 forces one.
+void tuneXcdMap(DeviceMatrix& M, const double* in, double* out, hipStream_t s);
 
 class Comm;  // RCCL wrapper (pdlp_comm.cpp)
 

@@ -7,7 +7,7 @@ Runs the REAL cuPDLP-C core compiled from the reference sources (oracle/_ref/lib
 north_star parity criterion compares: objective, cuPDLP primal / dual objective, residual norms,
 HiGHS-style KKT measures and the iteration count.
 
-    python tests/golden/make_golden_synth.py [a] [b]      (default: both; "b" takes ~1-2 h of one core)
+    python tests/golden/make_golden_synth.py [a] [b] [c_small] [c]   (default: a b; "b" takes ~1-2 h of one core)
 
 Output: tests/golden/reference_synth.json (one record per config; existing records of configs that are
 not re-run are kept).  The LP itself is regenerated on the GPU box by the library's seeded generator
@@ -27,14 +27,23 @@ import oraclelib as O  # noqa: E402
 from highs_amd import lp as L  # noqa: E402
 from highs_amd import solver  # noqa: E402
 
-CONFIGS = {"a": (100_000, 100_000, 1_000_000), "b": (1_000_000, 1_000_000, 8_000_000)}
+CONFIGS = {"a": (100_000, 100_000, 1_000_000), "b": (1_000_000, 1_000_000, 8_000_000),
+           # BASELINE config 3 stand-in (pds-100 is not in the reference tree): tests/lpgen.py::structured_lp,
+           # block-angular network LP with dense linking rows; "c" = the bench size (5.3M nnz), "c_small" = 1/16
+           "c_small": dict(commodities=16, nodes=1024, arcs=8192, link_rows=64, link_nnz=2048, extra_rows=128),
+           "c": dict()}
 OUT = os.path.join(HERE, "reference_synth.json")
 
 
 def record(key, tol):
-    m, n, nnz = CONFIGS[key]
-    sp = solver.SyntheticProblem(m, n, nnz, 1)
-    lp = sp.to_lp()
+    if isinstance(CONFIGS[key], dict):
+        from lpgen import structured_lp
+        lp = structured_lp(1, **CONFIGS[key])
+        m, n, nnz = lp.num_row, lp.num_col, lp.num_nz
+    else:
+        m, n, nnz = CONFIGS[key]
+        sp = solver.SyntheticProblem(m, n, nnz, 1)
+        lp = sp.to_lp()
     t0 = time.time()
     r = O.ref_solve(lp, kkt_tolerance=tol, pdlp_iteration_limit=2_000_000)
     wall = time.time() - t0

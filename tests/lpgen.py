@@ -73,3 +73,79 @@ def random_diag_qp(seed, m=None, n=None):
     rng = np.random.default_rng(1000 + seed)
     q = np.where(rng.random(lp.num_col) < 0.35, 0.0, rng.uniform(0.1, 3.0, lp.num_col))
     return lp.set_diagonal_hessian(lp.sense * q)
+
+
+def structured_lp(seed=1, commodities=64, nodes=4096, arcs=32768, link_rows=256, link_nnz=4096, extra_rows=512):
+    """A block-structured LP of the kind BASELINE config 3 stands for (pds-class multi-commodity / staircase
+    models; pds-100 itself is not in the reference tree): `commodities` network blocks — node-balance EQUALITY
+    rows over that block's arc columns, 2 nonzeros (+1/-1) per column, so a row block only touches its own
+    column range — tied together by `link_rows` DENSE rows of `link_nnz` nonzeros each across all blocks
+    (bundle capacities; longer than the slab kernel's 256-nonzero limit, so they exercise the long-major side
+    kernel), plus `extra_rows` RANGED and FREE rows, boxed and fixed columns, an objective offset.  Feasible and
+    bounded by construction (a primal point inside all bounds, costs = A'y0 + sign-compatible reduced costs).
+    Defaults: 2.1M columns, 263k rows, 5.3M nonzeros.  Deterministic for a given seed (numpy default_rng)."""
+    rng = np.random.default_rng(seed)
+    inf = float("inf")
+    K, N, Aa = commodities, nodes, arcs
+    n = K * Aa
+    # --- network blocks: arc (tail -> head) of block k is column k*Aa + a, rows k*N + node
+    tail = rng.integers(0, N, size=(K, Aa))
+    head = (tail + 1 + rng.integers(0, N - 1, size=(K, Aa))) % N
+    col = np.arange(n, dtype=np.int64)
+    blk = np.repeat(np.arange(K, dtype=np.int64), Aa)
+    r_net = np.concatenate([blk * N + tail.ravel(), blk * N + head.ravel()])
+    c_net = np.concatenate([col, col])
+    v_net = np.concatenate([np.ones(n), -np.ones(n)])
+    m_net = K * N
+    # --- dense linking rows
+    c_link = rng.integers(0, n, size=(link_rows, link_nnz))
+    c_link.sort(axis=1)
+    keep = np.ones_like(c_link, dtype=bool)
+    keep[:, 1:] = c_link[:, 1:] != c_link[:, :-1]
+    r_link = (m_net + np.repeat(np.arange(link_rows, dtype=np.int64), link_nnz))[keep.ravel()]
+    v_link = rng.uniform(0.5, 2.0, size=c_link.size)[keep.ravel()]
+    c_link = c_link.ravel()[keep.ravel()]
+    # --- extra rows: short random rows, alternately ranged and free
+    per = 12
+    c_ex = rng.integers(0, n, size=(extra_rows, per))
+    c_ex.sort(axis=1)
+    keep = np.ones_like(c_ex, dtype=bool)
+    keep[:, 1:] = c_ex[:, 1:] != c_ex[:, :-1]
+    r_ex = (m_net + link_rows + np.repeat(np.arange(extra_rows, dtype=np.int64), per))[keep.ravel()]
+    v_ex = rng.standard_normal(c_ex.size)[keep.ravel()]
+    c_ex = c_ex.ravel()[keep.ravel()]
+    m = m_net + link_rows + extra_rows
+    rows = np.concatenate([r_net, r_link, r_ex])
+    cols = np.concatenate([c_net, c_link, c_ex])
+    vals = np.concatenate([v_net, v_link, v_ex])
+    order = np.lexsort((rows, cols))  # column-major, rows ascending within a column
+    rows, cols, vals = rows[order], cols[order], vals[order]
+    a_start = np.zeros(n + 1, np.int64)
+    a_start[1:] = np.cumsum(np.bincount(cols, minlength=n))
+    # --- primal point, bounds
+    xs = rng.uniform(0.0, 1.0, n)
+    cl, cu = np.zeros(n), xs + rng.uniform(0.1, 1.0, n)
+    fixed = rng.random(n) < 0.01
+    cl[fixed] = cu[fixed] = xs[fixed]
+    unb = rng.random(n) < 0.2
+    cu[unb & ~fixed] = inf
+    ax = np.zeros(m)
+    np.add.at(ax, rows, vals * xs[cols])
+    rl, ru = ax.copy(), ax.copy()  # network rows: equalities
+    ru[m_net:m_net + link_rows] = ax[m_net:m_net + link_rows] + rng.uniform(0.0, 1.0, link_rows)  # capacities: <=
+    rl[m_net:m_net + link_rows] = -inf
+    ex = np.arange(m_net + link_rows, m)
+    ranged = ex[::2]
+    rl[ranged], ru[ranged] = ax[ranged] - rng.uniform(0.1, 1.0, ranged.size), ax[ranged] + rng.uniform(0.1, 1.0, ranged.size)
+    free = ex[1::2]
+    rl[free], ru[free] = -inf, inf
+    # --- a bounded objective: c = A'y0 + z with multipliers / reduced costs of admissible sign
+    y0 = rng.standard_normal(m)
+    y0[m_net:m_net + link_rows] = -np.abs(y0[m_net:m_net + link_rows])  # <= rows
+    y0[free] = 0.0
+    z = rng.standard_normal(n)
+    z = np.where(np.isinf(cu), np.abs(z), z)  # only a lower bound: z >= 0
+    c = z.copy()
+    np.add.at(c, cols, vals * y0[rows])
+    return L.HighsLp(n, m, c, cl, cu, rl, ru, a_start.astype(np.int32), rows.astype(np.int32), vals, 1, 3.0,
+                     f"structured{seed}").normalise()

@@ -307,6 +307,31 @@ def test_synthetic_100k_converged_matches_reference():
     _converged_against_reference("a_tol1e-07", 100000, 100000, 1000000)
 
 
+@pytest.mark.skipif("c_small_tol1e-07" not in SYNTH, reason="golden for the structured LP not generated")
+@pytest.mark.parametrize("key", ["c_small_tol1e-07", "c_tol1e-07"])
+def test_structured_lp_converged_matches_reference(key):
+    """BASELINE config 3 stand-in: block-angular network LP with dense linking rows (long majors -> CSR side
+    kernel next to the slab kernel), ranged and free rows; converged objectives against the real cuPDLP-C core."""
+    if key not in SYNTH:
+        pytest.skip("golden not generated")
+    from lpgen import structured_lp
+    kw = dict(commodities=16, nodes=1024, arcs=8192, link_rows=64, link_nnz=2048, extra_rows=128) if "small" in key else {}
+    lp = structured_lp(1, **kw)
+    g = SYNTH[key]
+    assert (lp.num_row, lp.num_col, lp.num_nz) == (g["m"], g["n"], g["nnz"])
+    out = solver.solveLpCupdlp(lp)
+    assert out.model_status == solver.kOptimal
+    R = out.result
+    ref = g["objective_function_value"]
+    scale = 1.0 + abs(ref)
+    assert abs(out.info["objective_function_value"] - ref) <= 1e-6 * scale
+    assert abs(R.primal_obj - g["primal_obj"]) <= 1e-6 * scale and abs(R.dual_obj - g["dual_obj"]) <= 1e-6 * scale
+    assert R.norm_rhs == g["norm_rhs"] and R.norm_cost == g["norm_cost"]
+    assert out.info["max_primal_residual_error"] <= max(10 * g["kkt"]["max_primal_residual_error"], 1e-9)
+    assert out.info["max_dual_residual_error"] <= max(10 * g["kkt"]["max_dual_residual_error"], 1e-9)
+    assert 0.25 * g["num_iter"] <= R.num_iter <= 4 * g["num_iter"]
+
+
 @pytest.mark.skipif("b_tol1e-07" not in SYNTH, reason="golden for config 4 not generated")
 def test_synthetic_1m_converged_matches_reference():
     _converged_against_reference("b_tol1e-07", 1000000, 1000000, 8000000)

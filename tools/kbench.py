@@ -16,9 +16,15 @@ ap.add_argument("--nnz", type=int, default=8_000_000)
 ap.add_argument("--reps", type=int, default=30)
 ap.add_argument("--iters", type=int, default=0, help="also run this many PDHG iterations first")
 ap.add_argument("--solver", choices=["pdlp", "hipdlp"], default="pdlp")
+ap.add_argument("--structured", action="store_true", help="the block-angular LP of bench.py --config c instead")
 ap.add_argument("--kernels", default="primal_step,spmv_ax,spmv_aty,decide,trial,spmv_ax_plain,spmv_aty_plain")
 args = ap.parse_args()
-sp_ = solver.SyntheticProblem(args.m, args.n, args.nnz, 1)
+if args.structured:
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    from lpgen import structured_lp
+    sp_ = abi.ProblemHandle(structured_lp(1))
+else:
+    sp_ = solver.SyntheticProblem(args.m, args.n, args.nnz, 1)
 S = solver.DeviceSolver(problem_struct=sp_.struct, params=abi.default_params(kkt_tolerance=1e-4, solver=args.solver))
 out = {}
 if args.iters:

@@ -9,7 +9,7 @@ cd /tmp; export TMPDIR=/tmp
 i=0
 for G in "$@"; do
   i=$((i+1))
-  timeout 100 rocprofv3 --pmc $G --kernel-trace -d "$OUT/g$i" -o p --output-format csv -- python "$R/tools/kbench.py" --reps 3 --iters ${ITERS:-0} --kernels $KERNELS > "$OUT/g$i.log" 2>&1
+  timeout 100 rocprofv3 --pmc $G --kernel-trace -d "$OUT/g$i" -o p --output-format csv -- python "$R/tools/kbench.py" --reps 3 --iters ${ITERS:-0} ${KBENCH_ARGS:-} --kernels $KERNELS > "$OUT/g$i.log" 2>&1
   echo "group $i ($G) rc=$?"
 done
 python - <<PY
