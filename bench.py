@@ -121,19 +121,23 @@ def main():
     tdev = "cuda" if backend == "nccl" else "cpu"
     torch.cuda.set_device(local_rank)
     dist = None
-    uid = None
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
+
+    def fresh_unique_id():
+        """128-byte communicator id of one solver generation, made on rank 0 and broadcast by the launcher."""
+        if world == 1:
+            return None
         idbuf = (C.c_uint8 * 128)()
         if rank == 0:
             assert solver.lib().pdlp_mi355x_comm_unique_id(idbuf) == 0, solver.lib().pdlp_mi355x_last_error()
         t = torch.tensor(list(bytes(idbuf)), dtype=torch.uint8, device=tdev)
         dist.broadcast(t, src=0)
-        uid = (C.c_uint8 * 128)(*t.cpu().tolist())
+        return (C.c_uint8 * 128)(*t.cpu().tolist())
 
     if cfg.get("structured"):
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -154,10 +158,6 @@ def main():
         sp_.struct.q_index = qkeep[1].ctypes.data_as(abi.c_i32p)
         sp_.struct.q_value = qkeep[2].ctypes.data_as(abi.c_f64p)
     params = abi.default_params(kkt_tolerance=1e-4, device=local_rank, solver=args.solver)
-    t_setup = time.time()
-    S = solver.DeviceSolver(problem_struct=sp_.struct, params=params, rank=rank, world=world, unique_id=uid)
-    t_setup = time.time() - t_setup
-    n, m, nnz = S.n, S.m, S.nnz
 
     def sync():
         torch.cuda.synchronize()
@@ -168,11 +168,43 @@ def main():
     # iterations (cupdlp_solver.c:953-962) and restarts for the first time; from iteration 40 on the
     # schedule is one check in 40.  The timed region therefore never starts before iteration 40, whatever
     # --warmup says (the hipGraph of a trial batch is captured in create(), i.e. in setup_seconds).
-    sync()
-    t0 = time.perf_counter()
-    S.iterate(PRE_ROLL)
-    sync()
-    startup_ms = (time.perf_counter() - t0) * 1e3
+    # With N > 1 the direct xGMI exchange guards itself (known-answer test at creation, checksum of the replicated
+    # iterate at every check): if it reports an inconsistency on this machine, every rank starts over with the
+    # RCCL all-reduce exchange and the line says so.
+    exchange_fallback = None
+    for attempt in ([None, "rccl"] if world > 1 and args.solver == "pdlp" else [None]):
+        if attempt:
+            os.environ["PDLP_MI355X_EXCHANGE"] = attempt
+        err, S = None, None
+        try:
+            uid = fresh_unique_id()
+            t_setup = time.time()
+            S = solver.DeviceSolver(problem_struct=sp_.struct, params=params, rank=rank, world=world, unique_id=uid)
+            t_setup = time.time() - t_setup
+            n, m, nnz = S.n, S.m, S.nnz
+            sync()
+            t0 = time.perf_counter()
+            S.iterate(PRE_ROLL)
+            sync()
+            startup_ms = (time.perf_counter() - t0) * 1e3
+        except RuntimeError as e:
+            err = str(e)
+        if dist is not None:
+            flag = torch.tensor([1.0 if err else 0.0], dtype=torch.float64, device=tdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            failed = flag.item() > 0
+        else:
+            failed = err is not None
+        if not failed:
+            break
+        if attempt == "rccl" or world == 1 or args.solver != "pdlp":
+            raise SystemExit("bench.py: the solver failed: %s" % err)
+        exchange_fallback = "direct xGMI exchange rejected on this machine (%s); rerun with the RCCL all-reduce" % (err or "error on another rank")
+        if S is not None:
+            try:
+                S.close()
+            except Exception:
+                pass
     S.iterate(args.warmup)
     sync()
     t0 = time.perf_counter()
@@ -251,6 +283,7 @@ def main():
                    "options": "presolve=off, kkt_tolerance=1e-4, adaptive step + restarts (reference defaults)"},
         "trial_steps": int(st.trials), "rejected_trials": int(st.trials - st.iters), "checks": int(st.checks),
         "restarts": int(st.restarts), "setup_seconds": t_setup, "ranks_bit_identical": rank_consistent,
+        "exchange_fallback": exchange_fallback,
         "startup_ms_first_40": startup_ms, "timed_window": "iterations %d..%d" % (PRE_ROLL + args.warmup,
                                                                                   PRE_ROLL + args.warmup + int(st.iters)),
         "steady_state": {"value": ss.iters / ss_elapsed, "unit": "it/s", "iters": int(ss.iters), "checks": int(ss.checks),
