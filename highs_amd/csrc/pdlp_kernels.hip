@@ -253,6 +253,7 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
 // stretches are applied one after the other.  Slabs ascend and minors ascend inside a slab, so every
 // major is summed in ascending minor order — the reference's order: bit-identical to the CSR path.
 constexpr int kSlabSlots = 3;  // register pipeline depth (groups of 64 entries per wave)
+constexpr int kSlabPre = 4;    // majors per thread whose epilogue operands are fetched before the stream
 template <int EPI>
 __global__ __launch_bounds__(kSlabThreads, kSlabThreads / 256) void k_spmv_slab(const SpmvArgs a) {
   if (usesDevState(EPI) && a.st->halted) return;
@@ -280,10 +281,14 @@ __global__ __launch_bounds__(kSlabThreads, kSlabThreads / 256) void k_spmv_slab(
   const double* __restrict__ in = epi.input();
 
   for (int r = lane; r < Rw; r += kWave) wacc[r] = 0.0;
-  // operands of this thread's first two majors, fetched ahead of the stream (clamped, unconditional)
-  const int rA = rBase + tid < rEnd ? rBase + tid : rEnd - 1;
-  const int rB = rBase + tid + kSlabThreads < rEnd ? rBase + tid + kSlabThreads : rEnd - 1;
-  const Pre preA = epi.prefetch(rA), preB = epi.prefetch(rB);
+  // operands of this thread's first kSlabPre majors (all of them at the bench size: 3920 majors per block),
+  // fetched ahead of the stream (clamped, unconditional) so that nothing is loaded in the kernel's tail
+  Pre pre[kSlabPre];
+#pragma unroll
+  for (int k = 0; k < kSlabPre; ++k) {
+    const int r = rBase + tid + k * kSlabThreads;
+    pre[k] = epi.prefetch(r < rEnd ? r : rEnd - 1);
+  }
 
   // ---- the stream ----
   // Register pipeline over NB slots, unrolled NB times so that a slot is a fixed register (no moves of
@@ -376,11 +381,16 @@ __global__ __launch_bounds__(kSlabThreads, kSlabThreads / 256) void k_spmv_slab(
   }
 
   const uint32_t* __restrict__ mask = a.S.longMask + (size_t)blk * (R / 32);
-  for (int lr = tid, it = 0; rBase + lr < rEnd; lr += kSlabThreads, ++it) {
-    if ((mask[lr >> 5] >> (lr & 31)) & 1u) continue;  // long major: the CSR side kernel owns it
+#pragma unroll
+  for (int k = 0; k < kSlabPre; ++k) {
+    const int lr = tid + k * kSlabThreads;
+    if (rBase + lr < rEnd && !((mask[lr >> 5] >> (lr & 31)) & 1u))  // (long major: the CSR side kernel owns it)
+      epi.apply(rBase + lr, acc[lr], pre[k]);
+  }
+  for (int lr = tid + kSlabPre * kSlabThreads; rBase + lr < rEnd; lr += kSlabThreads) {
+    if ((mask[lr >> 5] >> (lr & 31)) & 1u) continue;
     const int r = rBase + lr;
-    const Pre p = it == 0 ? preA : (it == 1 ? preB : epi.prefetch(r));
-    epi.apply(r, acc[lr], p);
+    epi.apply(r, acc[lr], epi.prefetch(r));
   }
   epi.template finish<kSlabThreads>(blk, scratch);
 }

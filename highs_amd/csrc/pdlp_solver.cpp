@@ -245,6 +245,9 @@ void Solver::construct(const pdlp_problem_t& P, const void* id128) {
     for (double v : F_.rhs) sumRhs2_ += v * v;
   }
   log(1, "Using cost norm = %9.3g and RHS norm = %9.3g\n", F_.normCost, F_.normRhs);
+  if (F_.nnz < 50000)  // DESIGN.md section 3, "Small LPs": three dependent launches of ~5 us per iteration
+    log(1, "Note: %lld nonzeros - at this size the GPU iteration is launch-latency-bound (~20-25 us) and not "
+           "faster than the reference's CPU pdlp\n", (long long)F_.nnz);
 
   // hot start in formulated+scaled space (PDHG_PreSolve, cupdlp_solver.c:1217-1279)
   if (P.start_value_valid && P.start_dual_valid && P.start_col_value && P.start_row_value && P.start_row_dual) {
