@@ -293,7 +293,7 @@ def main():
         "iter_hbm_frac_of_peak": b_iter / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS / world,
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "traffic_source": "profiles/pmc_traffic.json (static: rocprofv3 --pmc passes of tools/pmc.sh, not "
+                     "traffic_source": "profiles/pmc_traffic.json (static: rocprofv3 --pmc passes of tools/make_profiles.sh, not "
                                        "measured in this run)" if traffic is not None else None,
                      "algorithmic_bytes_per_launch": dom_bytes,
                      "measured_copy_ceiling_gbs": copy_gbs,
