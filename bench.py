@@ -218,6 +218,12 @@ def main():
 
     exchange = {0.0: "none", 1.0: "RCCL all-reduce of A'y", 2.0: "direct xGMI mesh (all-gather x+, reduce-scatter A'y+)"}[
         float(S.stage("exchange")[0])]
+    exchange_waits = None
+    if world > 1 and exchange.startswith("direct"):
+        # device-side wall-clock time a rank spent waiting for its peers' flags, per hot-loop exchange (rank 0's view)
+        ph = S.stage("mesh_phases")
+        exchange_waits = {"unit": "us per wait (rank 0, 100 MHz device clock)", "X_allgather_x": ph[0], "P_reduce_scatter_aty": ph[1],
+                          "S_scalars": ph[2], "waits": [int(ph[3]), int(ph[4]), int(ph[5])]}
     rank_consistent = None
     if dist is not None:
         # every rank must hold bit-identical iterates (same decisions everywhere): compare a checksum of x
@@ -283,7 +289,7 @@ def main():
                    "options": "presolve=off, kkt_tolerance=1e-4, adaptive step + restarts (reference defaults)"},
         "trial_steps": int(st.trials), "rejected_trials": int(st.trials - st.iters), "checks": int(st.checks),
         "restarts": int(st.restarts), "setup_seconds": t_setup, "ranks_bit_identical": rank_consistent,
-        "exchange_fallback": exchange_fallback,
+        "exchange_fallback": exchange_fallback, "exchange": exchange if world > 1 else None, "exchange_waits": exchange_waits,
         "startup_ms_first_40": startup_ms, "timed_window": "iterations %d..%d" % (PRE_ROLL + args.warmup,
                                                                                   PRE_ROLL + args.warmup + int(st.iters)),
         "steady_state": {"value": ss.iters / ss_elapsed, "unit": "it/s", "iters": int(ss.iters), "checks": int(ss.checks),

@@ -699,6 +699,10 @@ void HalpernSolver::stage(const std::string& name, double* out, int32_t cap) {
     if (k < 1 || k > kCheckInterval) throw std::runtime_error("steps: 1..40");
     pushState();
     for (int i = 1; i <= k; ++i) enqueueStep(i == 1 || i == k, i);
+  } else if (name == "mesh_phases") {  // {X, P, -} average wait in us, then the wait counts (since the last call)
+    double us[3] = {0, 0, 0}, cnt[3] = {0, 0, 0};
+    if (mesh_) mesh_->phaseStats(us, cnt, stream_);
+    for (int k = 0; k < 3; ++k) { put(k, us[k]); put(3 + k, cnt[k]); }
   } else if (name == "exchange") {
     put(0, sharded_ ? 2.0 : 0.0);
   } else if (name == "profile_on" || name == "profile_off") {

@@ -13,6 +13,8 @@
 // there is no double buffering.
 #include "pdlp_mesh.hpp"
 
+#include <cstddef>
+
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -76,6 +78,7 @@ __device__ bool waitPeers(const MeshArgs& ma, int kind, long long e) {
   const MeshView* __restrict__ mv = ma.v; (void)mv;
   __shared__ int ok;
   if (threadIdx.x == 0) ok = 1;
+  const long long tEnter = (threadIdx.x == 0 && kind < 3) ? wall_clock64() : 0;
   __syncthreads();
   if (threadIdx.x < kWave) {
     const int h = threadIdx.x, G = ma.G, g = ma.g;
@@ -97,6 +100,10 @@ __device__ bool waitPeers(const MeshArgs& ma, int kind, long long e) {
   }
   __syncthreads();
   const bool good = ok != 0;
+  if (threadIdx.x == 0 && kind < 3) {  // hot-loop exchanges: how long this block waited (integer atomics)
+    atomicAdd(&ma.ms->waitTicks[kind], (unsigned long long)(wall_clock64() - tEnter));
+    atomicAdd(&ma.ms->waitCount[kind], 1ull);
+  }
   __syncthreads();
   return good;
 }
@@ -835,6 +842,19 @@ void Mesh::verifyReplicated(const double* vec, int64_t len, hipStream_t s) {
       if (host[3 * h + p] != host[p])
         throw std::runtime_error("pdlp_mi355x mesh: the ranks hold different copies of a replicated vector (exchange "
                                  "inconsistent); rerun with PDLP_MI355X_EXCHANGE=rccl");
+}
+
+void Mesh::phaseStats(double usPerWait[3], double count[3], hipStream_t s) {
+  MeshState h{};
+  PDLP_HIP(hipMemcpyAsync(&h, state_, sizeof(h), hipMemcpyDeviceToHost, s));
+  PDLP_HIP(hipStreamSynchronize(s));
+  for (int k = 0; k < 3; ++k) {
+    count[k] = (double)h.waitCount[k];
+    usPerWait[k] = h.waitCount[k] ? (double)h.waitTicks[k] / (double)h.waitCount[k] / 100.0 : 0.0;  // 100 MHz clock
+  }
+  PDLP_HIP(hipMemsetAsync(reinterpret_cast<char*>(state_) + offsetof(MeshState, waitTicks), 0,
+                          sizeof(h.waitTicks) + sizeof(h.waitCount), s));
+  PDLP_HIP(hipStreamSynchronize(s));
 }
 
 void Mesh::checkError(hipStream_t s) {

@@ -47,6 +47,10 @@ struct MeshState {
   int32_t error;        // set by a kernel whose wait timed out (host turns it into an exception)
   int32_t pad_;
   uint32_t counter[4];  // "last block signals" tickets
+  // time spent waiting for the peers' flags in the hot loop, per exchange (X all-gather, P reduce-scatter,
+  // S scalars): 100 MHz wall-clock ticks and number of waits (measurement only; bench.py reports them)
+  unsigned long long waitTicks[3];
+  unsigned long long waitCount[3];
 };
 
 // Lives in device memory (the kernels index its arrays dynamically); the host keeps a copy.
@@ -94,6 +98,9 @@ class Mesh {
   void allReduceScalars(double* buf, int32_t k, hipStream_t s);
   // throws unless every rank holds bit-identical copies of vec[0:len) (collective; syncs the stream)
   void verifyReplicated(const double* vec, int64_t len, hipStream_t s);
+  // average microseconds a hot-loop wait for the peers took since the last call, per exchange {X, P, S}, and
+  // the number of waits (syncs the stream; resets the counters)
+  void phaseStats(double usPerWait[3], double count[3], hipStream_t s);
   // throws if a kernel reported a timed-out wait (call after a stream sync)
   void checkError(hipStream_t s);
   // exchange self-test (pattern all-gather + reduce-scatter + scalars); false = mismatch

@@ -1145,6 +1145,10 @@ void Solver::stage(const std::string& name, double* out, int32_t cap) {
     const DevState& s = *hostState_;
     put(0, s.dX2); put(1, s.dY2); put(2, s.inter); put(3, (double)s.lastAccepted);
     put(4, s.tau); put(5, s.sigma); put(6, s.eta); put(7, s.movement); put(8, s.limit);
+  } else if (name == "mesh_phases") {  // {X, P, S} average wait in us, then the three wait counts (since the last call)
+    double us[3] = {0, 0, 0}, cnt[3] = {0, 0, 0};
+    if (meshMode_) mesh_->phaseStats(us, cnt, stream_);
+    for (int k = 0; k < 3; ++k) { put(k, us[k]); put(3 + k, cnt[k]); }
   } else if (name == "exchange") {  // 0 = not sharded, 1 = RCCL all-reduce, 2 = direct xGMI mesh
     put(0, !sharded_ ? 0.0 : meshMode_ ? 2.0 : 1.0);
   } else if (name == "residuals") {
