@@ -88,7 +88,7 @@ StreamPlan planStream(const std::vector<int32_t>& beg, int32_t nMajor, int32_t c
 // Slab layout (the layout of k_spmv_slab).  The gathered vector of a random sparse LP (8 MB at
 // n = 1M) does not fit one XCD's 4 MB L2, so a plain CSR stream pays one fabric request per 8-byte
 // gather.  Here every wave sweeps the gathered vector slab by slab (slab = 2^slabWidthLog2 consecutive
-// minor indices, 512 KB by default), in step with all the others, so the slab being gathered from stays
+// minor indices, 1 MB by default), in step with all the others, so the slab being gathered from stays
 // in every XCD's L2.  The unit of ownership is the WAVE: a block of 16 waves (one block per CU) owns
 // rowsPerBlock = 16*rowsPerWave consecutive majors, wave w of it the majors [w*rowsPerWave,
 // (w+1)*rowsPerWave).  A wave's nonzeros are ONE dense stream sorted by (minor >> slabWidthLog2, local
@@ -107,7 +107,7 @@ struct SlabLayout {
   Compressed longCsr;             // compacted long majors
   std::vector<int32_t> longMap;   // compact index -> major
 };
-constexpr int32_t kSlabWidthLog2 = 16;
+constexpr int32_t kSlabWidthLog2 = 17;  // 1 MB slabs: 56.2 vs 57.0 us per A x at the bench size (15..18 within 1.5 %)
 constexpr int32_t kSlabWavesPerBlock = 16;
 constexpr int32_t kSlabTargetBlocks = 256;  // CUs of an MI355X
 // Majors per wave for an operand of this shape: even, in [16, 512], ceil(nMajor / (256*16)) when that
