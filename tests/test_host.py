@@ -25,8 +25,6 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/pdlp_mi355x.h but not exported"
     assert set(solver.EXPORTS) == declared
-    import re
-    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "pdlp_mi355x.h")).read()
     assert lib.pdlp_mi355x_abi_version() == int(re.search(r"#define PDLP_MI355X_ABI_VERSION (\d+)", hdr).group(1)) == 4
 
 
