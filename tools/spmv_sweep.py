@@ -4,7 +4,7 @@
 For every variant (environment switches read by the library at solver creation / launch) it reports the
 PDHG iteration time, the in-loop HIP-event times of the two fused SpMVs, their isolated re-launch times
 and whether the iterate after 40 iterations is bit-identical to the first variant's.
-    python tools/spmv_sweep.py [--config b] [--variants "slab=1;slab=2,w=16,depth=41;..."]
+    python tools/spmv_sweep.py [--variants "slab=1;slab=1,w=16;slab=1,xcd=0;slab=0"]
 """
 import argparse
 import hashlib
@@ -16,11 +16,9 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from highs_amd import abi, solver  # noqa: E402
 
-ENV = {"slab": "PDLP_MI355X_SLAB", "w": "PDLP_MI355X_SLAB_W", "depth": "PDLP_MI355X_WSLAB_DEPTH",
-       "pace": "PDLP_MI355X_WSLAB_PACE", "wpb": "PDLP_MI355X_WSLAB_WPB", "sync": "PDLP_MI355X_WSLAB_SYNC", "cus": "PDLP_MI355X_WSLAB_CUS", "graph": "PDLP_MI355X_GRAPH", "gpusetup": "PDLP_MI355X_GPU_SETUP"}
-DEFAULT = ("slab=1;slab=2,w=16,depth=31;slab=2,w=16,depth=41;slab=2,w=16,depth=42;slab=2,w=16,depth=52;"
-           "slab=2,w=16,depth=63;slab=2,w=16,depth=21;slab=2,w=15,depth=41;slab=2,w=15,depth=42;"
-           "slab=2,w=17,depth=41;slab=2,w=17,depth=42;slab=2,w=14,depth=42;slab=2,w=18,depth=42")
+ENV = {"slab": "PDLP_MI355X_SLAB", "w": "PDLP_MI355X_SLAB_W", "xcd": "PDLP_MI355X_XCD_MAP", "graph": "PDLP_MI355X_GRAPH",
+       "gpusetup": "PDLP_MI355X_GPU_SETUP"}
+DEFAULT = "slab=1;slab=1,w=15;slab=1,w=16;slab=1,w=18;slab=1,xcd=0;slab=1,xcd=1;slab=0"
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--m", type=int, default=1_000_000)
