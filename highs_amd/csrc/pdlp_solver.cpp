@@ -17,7 +17,11 @@ namespace pdlp {
 namespace {
 constexpr int kStatRowCur = 0, kStatRowAvg = kRowStats, kStatColCur = 2 * kRowStats,
               kStatColAvg = 2 * kRowStats + kColStats, kStatTotal = 2 * kRowStats + 2 * kColStats;
-constexpr int kGraphTrials = 10;
+// One hipGraph holds a whole check period of trials plus two spare ones for rejected trials (a trial queued after
+// the device has halted is three early-exit kernels): one graph launch per 40 iterations instead of four — the
+// gap between two graph launches is ~40 us on this runtime, which was 4 us per iteration on small LPs.
+constexpr int kGraphTrials = 42;
+constexpr int kGraphMinTodo = 30;  // fewer trials than this to the next halt: launched one by one
 constexpr int kCheckInterval = 40;  // CUPDLP_RELEASE_INTERVAL, cupdlp_defs.h:39
 }  // namespace
 
@@ -699,16 +703,16 @@ void Solver::runUntilHalt() {
     if (remaining > 4 * kCheckInterval) remaining = 4 * kCheckInterval;
     int32_t todo = (int32_t)remaining;
     const int32_t trialsBefore = hostState_->nTrials;
-    if (useGraph_ && !profile_ && (!sharded_ || meshMode_) && todo >= kGraphTrials) {
+    if (useGraph_ && !profile_ && (!sharded_ || meshMode_) && todo >= kGraphMinTodo) {
       if (!graphExec_) captureGraph();
-      while (todo >= graphTrials_) {
+      while (todo >= kGraphMinTodo) {
         if (stPar_ != graphPar_) {  // the graph starts from the state slot it was captured with
           enqueueTrial();
           --todo;
           continue;
         }
         PDLP_HIP(hipGraphLaunch(graphExec_, stream_));  // an even number of trials: the slot parity is unchanged
-        todo -= graphTrials_;
+        todo = todo > graphTrials_ ? todo - graphTrials_ : 0;
       }
     }
     for (int i = 0; i < todo; ++i) enqueueTrial();

@@ -33,3 +33,4 @@ else:
         d, g = dur[nm], gap[nm]
         print("%-50s n=%5d dur avg %6.2f us  gap-after avg %6.2f us  share %4.1f%%" % (
             nm[:50], len(d), sum(d) / len(d) / 1e3, sum(g) / len(g) / 1e3, 100.0 * (sum(d) + sum(g)) / tot))
+
