@@ -220,9 +220,24 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
       }
       double s = 0.0;
       int q = qb;
-      for (; q + 4 <= qe; q += 4) {
-        const double t0 = prod[slot(q)], t1 = prod[slot(q + 1)], t2 = prod[slot(q + 2)], t3 = prod[slot(q + 3)];
-        s += t0; s += t1; s += t2; s += t3;
+      // left to right (the reference's order): the adds are a dependent chain, so the LDS reads of the NEXT
+      // eight products are issued before the current eight are added (long majors: 25fv47 has one of 340)
+      if (q + 8 <= qe) {
+        double t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = prod[slot(q + k)];
+        q += 8;
+        for (; q + 8 <= qe; q += 8) {
+          double u[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) u[k] = prod[slot(q + k)];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) s += t[k];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) t[k] = u[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += t[k];
       }
       for (; q < qe; ++q) s += prod[slot(q)];
       epi.apply(vecIndex(r), s, pre);
