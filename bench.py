@@ -172,8 +172,10 @@ def main():
     # iterate at every check): if it reports an inconsistency on this machine, every rank starts over with the
     # RCCL all-reduce exchange and the line says so.
     exchange_fallback = None
-    for attempt in ([None, "rccl"] if world > 1 and args.solver == "pdlp" else [None]):
-        if attempt:
+    for attempt in ([None, "fences", "rccl"] if world > 1 and args.solver == "pdlp" else [None, "fences"] if world > 1 else [None]):
+        if attempt == "fences":  # the direct exchange with system-scope release / acquire fences around the flags
+            os.environ["PDLP_MI355X_MESH_FENCES"] = "1"
+        elif attempt:
             os.environ["PDLP_MI355X_EXCHANGE"] = attempt
         err, S = None, None
         try:
@@ -197,9 +199,11 @@ def main():
             failed = err is not None
         if not failed:
             break
-        if attempt == "rccl" or world == 1 or args.solver != "pdlp":
+        if attempt == "rccl" or world == 1 or (attempt == "fences" and args.solver != "pdlp"):
             raise SystemExit("bench.py: the solver failed: %s" % err)
-        exchange_fallback = "direct xGMI exchange rejected on this machine (%s); rerun with the RCCL all-reduce" % (err or "error on another rank")
+        exchange_fallback = ("direct xGMI exchange%s rejected on this machine (%s); next: %s"
+                             % (" with fences" if attempt == "fences" else "", err or "error on another rank",
+                                "the same with release/acquire fences" if attempt is None else "RCCL all-reduce"))
         if S is not None:
             try:
                 S.close()

@@ -65,6 +65,10 @@ __device__ __forceinline__ void drainStores() { asm volatile("s_waitcnt vmcnt(0)
 __device__ void signalPeers(const MeshArgs& ma, int kind, long long e) {
   const MeshView* __restrict__ mv = ma.v; (void)mv;
   const int G = ma.G, g = ma.g;
+  // Optional belt and braces (PDLP_MI355X_MESH_FENCES=1, off by default: +5..8 us per exchange kernel): a
+  // system-scope release fence in front of the flag stores, for a machine on which "the write-through payload
+  // stores have been acknowledged" should turn out not to order them before the flag at the peer.
+  if (ma.fences) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
   for (int h = 0; h < G; ++h) {
     if (h == g) continue;
     __hip_atomic_store(flagAt(ma, h, kind, g), e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -100,6 +104,7 @@ __device__ bool waitPeers(const MeshArgs& ma, int kind, long long e) {
   }
   __syncthreads();
   const bool good = ok != 0;
+  if (ma.fences) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // (payload reads are system-scope loads anyway)
   if (threadIdx.x == 0 && kind < 3) {  // hot-loop exchanges: how long this block waited (integer atomics)
     atomicAdd(&ma.ms->waitTicks[kind], (unsigned long long)(wall_clock64() - tEnter));
     atomicAdd(&ma.ms->waitCount[kind], 1ull);
@@ -624,6 +629,11 @@ uint64_t fnv64(const void* p, size_t len) {
 
 size_t alignUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+int32_t meshFences() {
+  const char* e = getenv("PDLP_MI355X_MESH_FENCES");
+  return e && atoi(e) != 0 ? 1 : 0;
+}
+
 }  // namespace
 
 void Mesh::hostBarrier(int slot, double timeoutSec) {
@@ -701,7 +711,7 @@ void Mesh::construct(int32_t rank, int32_t world, const void* id128, int32_t n, 
   if (world == 1) {
     PDLP_HIP(hipMemcpy(dView_, &v_, sizeof(MeshView), hipMemcpyHostToDevice));
     setupOk_ = true;
-    args_ = MeshArgs{dView_, state_, v_.G, v_.g, v_.waitTicks};
+    args_ = MeshArgs{dView_, state_, v_.G, v_.g, v_.waitTicks, meshFences(), 0};
     return;
   }
 
@@ -766,7 +776,7 @@ void Mesh::construct(int32_t rank, int32_t world, const void* id128, int32_t n, 
   }
   if (ok) ok = hipMemcpy(dView_, &v_, sizeof(MeshView), hipMemcpyHostToDevice) == hipSuccess;
   setupOk_ = ok;
-  args_ = MeshArgs{dView_, state_, v_.G, v_.g, v_.waitTicks};
+  args_ = MeshArgs{dView_, state_, v_.G, v_.g, v_.waitTicks, meshFences(), 0};
   hostBarrier(1, 60.0);
 }
 

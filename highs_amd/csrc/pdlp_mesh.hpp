@@ -72,6 +72,8 @@ struct MeshArgs {
   MeshState* ms;
   int32_t G, g;
   int64_t waitTicks;
+  int32_t fences;  // PDLP_MI355X_MESH_FENCES=1: system-scope release before every flag store, acquire after every wait
+  int32_t pad_;
 };
 
 // Host side: arena allocation, IPC rendezvous through a POSIX shared-memory

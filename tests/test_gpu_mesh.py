@@ -163,3 +163,13 @@ def test_sharded_hipdlp_single_rank_reproduces_single_gpu(monkeypatch):
     assert sh.pdlp_iteration_count == base.pdlp_iteration_count
     assert np.array_equal(sh.solution.col_value, base.solution.col_value)
     assert np.array_equal(sh.solution.row_dual, base.solution.row_dual)
+
+
+def test_mesh_with_release_acquire_fences_gives_the_same_bits(tmp_path):
+    """PDLP_MI355X_MESH_FENCES=1 (the belt-and-braces form of the exchange that bench.py tries before falling
+    back to RCCL) changes ordering instructions only: same iterates, bit for bit."""
+    a = _run_ranks(2, "solve:e226", tmp_path)
+    b = _run_ranks(2, "solve:e226", tmp_path, extra_env={"PDLP_MI355X_MESH_FENCES": "1"})
+    for k in ("col_value", "row_dual", "num_iter", "num_trials", "primal_obj"):
+        assert np.array_equal(a[0][k], b[0][k]) and np.array_equal(b[0][k], b[1][k]), k
+    assert b[0]["exchange"] == 2.0
