@@ -43,6 +43,8 @@ HalpernSolver::HalpernSolver(const pdlp_problem_t& P, const pdlp_params_t& opt, 
 
 void HalpernSolver::construct(const pdlp_problem_t& P, const void* id128) {
   const auto t0 = std::chrono::steady_clock::now();
+  validateProblem(P);
+  requireConstraints(P);
   int nDev = 0;
   if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0)
     throw std::runtime_error("pdlp_mi355x: no HIP device available (this library has no CPU fallback)");

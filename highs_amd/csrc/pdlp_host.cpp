@@ -77,6 +77,18 @@ void extractDiagonalHessian(const pdlp_problem_t& P, double sense, int32_t n, st
   if (any) q = std::move(d);
 }
 
+// HiGHS never hands an LP without rows or without matrix nonzeros to a solver: solveLp() answers those itself
+// (solveUnconstrainedLp, lp_data/HighsSolve.cpp:61-66).  PDHG has nothing to iterate on there (the initial step
+// size is 1/max|a_ij|), so a direct caller of the C ABI gets an error instead of a loop that never ends.
+void requireConstraints(const pdlp_problem_t& P) {
+  const int64_t nnz = P.num_col > 0 && P.a_start ? (int64_t)P.a_start[P.num_col] : 0;
+  bool anyNonzero = false;
+  for (int64_t p = 0; p < nnz && !anyNonzero; ++p) anyNonzero = P.a_value[p] != 0.0;
+  if (P.num_row == 0 || P.num_col == 0 || !anyNonzero)
+    throw std::runtime_error("pdlp_mi355x: the LP has no rows, no columns or no matrix nonzeros — HiGHS solves such "
+                             "LPs itself (solveUnconstrainedLp) before the PDLP path");
+}
+
 void formulate(const pdlp_problem_t& P, StandardForm& F) {
   validateProblem(P);
   const int32_t n0 = P.num_col, m = P.num_row;

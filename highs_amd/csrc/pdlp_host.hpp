@@ -55,6 +55,7 @@ struct StandardForm {
 
 // Throws std::runtime_error on malformed input.
 void validateProblem(const pdlp_problem_t& P);
+void requireConstraints(const pdlp_problem_t& P);  // throws for LPs without rows / columns / nonzeros
 void extractDiagonalHessian(const pdlp_problem_t& P, double sense, int32_t n, std::vector<double>& q);
 void formulate(const pdlp_problem_t& P, StandardForm& F);
 void scale(StandardForm& F, int ruizTimes = 10, double pcAlpha = 1.0);

@@ -536,7 +536,7 @@ __global__ __launch_bounds__(kVecThreads) void k_decide_primal(const IterVecs v,
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
       const int j = base + k * stride;
-      const int jj = j < v.n ? j : v.n - 1;  // clamped, unconditional
+      const int jj = j < v.n ? j : (v.n > 0 ? v.n - 1 : 0);  // clamped, unconditional (every vector has >= 1 element)
       cv[k] = ldStream(v.cost + jj); lv[k] = ldStream(v.lower + jj); uv[k] = ldStream(v.upper + jj);
       sv[k] = ldStream(v.xSum + jj);
       qv[k] = v.qdiag ? ldStream(v.qdiag + jj) : 0.0;
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(kVecThreads) void k_decide_primal(const IterVecs v,
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
       const int j = base + k * stride;
-      const int jj = j < v.n ? j : v.n - 1;
+      const int jj = j < v.n ? j : (v.n > 0 ? v.n - 1 : 0);
       xv[k] = ldStream(v.x[par] + jj); av[k] = ldStream(v.aty[par] + jj);
     }
   };

@@ -204,6 +204,8 @@ Solver::Solver(const pdlp_problem_t& P, const pdlp_params_t& opt, int32_t rank, 
 void Solver::construct(const pdlp_problem_t& P, const void* id128) {
   const auto t0 = std::chrono::steady_clock::now();
   if (world_ < 1 || rank_ < 0 || rank_ >= world_) throw std::runtime_error("bad rank/world");
+  validateProblem(P);
+  requireConstraints(P);
   int nDev = 0;
   if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0)
     throw std::runtime_error("pdlp_mi355x: no HIP device available (this library has no CPU fallback)");

@@ -633,6 +633,7 @@ static int h_solve(const pdlp_problem_t* P, const pdlp_params_t* opt, pdlp_resul
 
 int hipdlp_oracle_solve(const pdlp_problem_t* P, const pdlp_params_t* opt, pdlp_result_t* R) {
   if (!P || !opt || !R) return 1;
+  if (P->num_row == 0 || P->num_col == 0 || !P->a_start || P->a_start[P->num_col] == 0) return 1; /* HiGHS: solveUnconstrainedLp */
   return h_solve(P, opt, R, NULL);
 }
 

@@ -1071,6 +1071,14 @@ static void postsolve(Work* w, pdlp_result_t* R) {
 /* Build everything up to and including PDHG_Alloc (CupdlpWrapper.cpp:104-176). */
 static int work_setup(Work* w, const pdlp_problem_t* P, const pdlp_params_t* opt) {
   memset(w, 0, sizeof(*w));
+  /* HiGHS answers LPs without rows / columns / nonzeros itself (solveUnconstrainedLp, HighsSolve.cpp:61-66); the
+   * PDHG loop has nothing to iterate on there (1/max|a_ij| is the initial step size): refuse, like the product */
+  {
+    int any = 0;
+    const long nnz0 = (P->num_col > 0 && P->a_start) ? P->a_start[P->num_col] : 0;
+    for (long p = 0; p < nnz0 && !any; ++p) any = P->a_value[p] != 0.0;
+    if (P->num_row == 0 || P->num_col == 0 || !any) return 1;
+  }
   if (formulate(w, P)) return 1;
   const int n = w->n, m = w->m;
   /* Init_Scaling cupdlp_scaling.c:395-425: norms of the UNSCALED formulated data */

@@ -493,3 +493,15 @@ def test_bad_arguments_are_reported_not_thrown():
     R = abi.ResultHandle(32, 27)
     assert L_.pdlp_mi355x_solve(C.byref(P.struct), C.byref(prm), C.byref(R.struct)) != 0
     assert b"algorithm" in L_.pdlp_mi355x_last_error()
+
+
+def test_lp_without_constraints_is_an_error_not_a_hang():
+    inf = float("inf")
+    no_rows = L.HighsLp(2, 0, np.array([1.0, -1.0]), np.zeros(2), np.array([1.0, 2.0]), np.zeros(0), np.zeros(0),
+                        np.array([0, 0, 0], np.int32), np.zeros(0, np.int32), np.zeros(0), 1, 0.0, "norows").normalise()
+    no_cols = L.HighsLp(0, 2, np.zeros(0), np.zeros(0), np.zeros(0), np.array([-inf, -1.0]), np.array([1.0, inf]),
+                        np.array([0], np.int32), np.zeros(0, np.int32), np.zeros(0), 1, 0.0, "nocols").normalise()
+    for lp in (no_rows, no_cols):
+        for fn in (solver.solveLpCupdlp, solver.solveLpHiPdlp):
+            out = fn(lp, pdlp_iteration_limit=1000)
+            assert out.status == solver.kError and b"solveUnconstrainedLp" in solver.lib().pdlp_mi355x_last_error()

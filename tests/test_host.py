@@ -209,3 +209,12 @@ def test_malformed_csc_is_rejected_not_read_out_of_bounds(corrupt):
         F = abi.PdlpPrepared()
         rc = solver.lib().pdlp_mi355x_host_prepare(C.byref(H.struct), C.byref(abi.default_params(solver=alg)), C.byref(F))
         assert rc != 0 and solver.lib().pdlp_mi355x_last_error()
+
+
+def test_lp_without_constraints_is_refused_by_the_oracle_not_looped_on():
+    """HiGHS answers LPs without rows / nonzeros itself (solveUnconstrainedLp, HighsSolve.cpp:61-66); a direct
+    caller of the ABI must get an error, not an endless PDHG loop (1/max|a_ij| is the initial step size)."""
+    lp = L.HighsLp(2, 0, np.array([1.0, -1.0]), np.zeros(2), np.array([1.0, 2.0]), np.zeros(0), np.zeros(0),
+                   np.array([0, 0, 0], np.int32), np.zeros(0, np.int32), np.zeros(0), 1, 0.0, "norows").normalise()
+    with pytest.raises(RuntimeError):
+        O.oracle_solve(lp, kkt_tolerance=1e-6, pdlp_iteration_limit=1000)
