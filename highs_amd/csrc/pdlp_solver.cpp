@@ -718,9 +718,20 @@ void Solver::runUntilHalt() {
       }
     }
     for (int i = 0; i < todo; ++i) enqueueTrial();
+    const int32_t iterBefore = hostState_->nIter;
     syncState();
     if (profile_) profCollect(hostState_->nTrials - trialsBefore);
     if (hostState_->halted) return;
+    // The reference's step-size search is a `while (!accepted)` loop: with NaN / Inf in the data it never ends.
+    // Here every stop checks that the search still makes progress.
+    if (hostState_->nIter == iterBefore && hostState_->nTrials - trialsBefore > 0) {
+      if (++stalledRounds_ >= 50)
+        throw std::runtime_error("pdlp_mi355x: the adaptive step-size search does not terminate (no trial step accepted in " +
+                                 std::to_string(hostState_->nTrials - stalledSince_) + " trials: NaN or Inf in the problem data?)");
+    } else {
+      stalledRounds_ = 0;
+      stalledSince_ = hostState_->nTrials;
+    }
     if (timeIsUp()) return;
   }
 }

@@ -142,6 +142,7 @@ class Solver : public SolverBase {
   // one, writes the other); stPar_ = the slot that holds the state after everything enqueued so far.
   DeviceArray<DevState> dState_;
   int32_t stPar_ = 0, graphPar_ = 0;
+  int32_t stalledRounds_ = 0, stalledSince_ = 0;  // consecutive device stops without an accepted trial
   DevState* dst() const { return dState_.get() + stPar_; }
   DeviceArray<double> powRed_, powGrow_;  // host-tabulated powers of the trial counter (see DevState)
   void refreshPowTable();

@@ -505,3 +505,11 @@ def test_lp_without_constraints_is_an_error_not_a_hang():
         for fn in (solver.solveLpCupdlp, solver.solveLpHiPdlp):
             out = fn(lp, pdlp_iteration_limit=1000)
             assert out.status == solver.kError and b"solveUnconstrainedLp" in solver.lib().pdlp_mi355x_last_error()
+
+
+def test_nan_in_the_data_ends_in_an_error_not_an_endless_step_size_search():
+    lp = _lp("afiro")
+    lp.col_cost = lp.col_cost.copy()
+    lp.col_cost[3] = float("nan")
+    out = solver.solveLpCupdlp(lp, pdlp_iteration_limit=100000, time_limit=60.0)
+    assert out.status == solver.kError or out.model_status != solver.kOptimal
