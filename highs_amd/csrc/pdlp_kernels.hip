@@ -599,8 +599,9 @@ __global__ __launch_bounds__(kVecThreads) void k_flush_average(const IterVecs v,
   const int stride = gridDim.x * blockDim.x;
   const int tot = v.n + v.m;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += stride) {
-    if (i < v.n) v.xSum[i] += w * v.x[cur][i];
-    else v.ySum[i - v.n] += w * v.y[cur][i - v.n];
+    // (check-iteration kernels stream their vectors non-temporally too: the matrices stay in the Infinity Cache)
+    if (i < v.n) stStream(v.xSum + i, ldStream(v.xSum + i) + w * ldStream(v.x[cur] + i));
+    else stStream(v.ySum + (i - v.n), ldStream(v.ySum + (i - v.n)) + w * ldStream(v.y[cur] + (i - v.n)));
   }
 }
 __global__ void k_clear_avgw(DevState* st) { st->avgW = 0.0; }
@@ -608,7 +609,7 @@ __global__ void k_clear_avgw(DevState* st) { st->avgW = 0.0; }
 __global__ __launch_bounds__(kVecThreads) void k_scale_copy(double* __restrict__ dst, const double* __restrict__ src,
                                                             double a, int len) {
   const int stride = gridDim.x * blockDim.x;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += stride) dst[i] = src[i] * a;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += stride) dst[i] = ldStream(src + i) * a;
 }
 __global__ __launch_bounds__(kVecThreads) void k_fill(double* dst, double value, int len) {
   const int stride = gridDim.x * blockDim.x;
@@ -643,8 +644,8 @@ __global__ __launch_bounds__(kVecThreads) void k_row_stats(const double* __restr
   const int stride = gridDim.x * blockDim.x;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
     const bool ineq = (i + rowOffset) >= nEqs;
-    const double axv = ax[i], yv = y[i], b = rhs[i];
-    const double rs = scaled ? rowScale[i] : 1.0;
+    const double axv = ldStream(ax + i), yv = ldStream(y + i), b = ldStream(rhs + i);
+    const double rs = scaled ? ldStream(rowScale + i) : 1.0;
     double r = axv + (-1.0) * b;
     if (ineq) r = r < 0.0 ? r : 0.0;
     r *= rs;
@@ -679,11 +680,11 @@ __global__ __launch_bounds__(kVecThreads) void k_col_stats(const double* __restr
   for (int q = 0; q < kColStats; ++q) a[q] = 0.0;
   const int stride = gridDim.x * blockDim.x;
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
-    const double xv = x[j], c = cost[j], l = lower[j], u = upper[j];
-    const double cs = scaled ? colScale[j] : 1.0;
+    const double xv = ldStream(x + j), c = ldStream(cost + j), l = ldStream(lower + j), u = ldStream(upper + j);
+    const double cs = scaled ? ldStream(colScale + j) : 1.0;
     const double hasL = l > -INFINITY ? 1.0 : 0.0, hasU = u < INFINITY ? 1.0 : 0.0;
     const double lF = l > -INFINITY ? l : 0.0, uF = u < INFINITY ? u : 0.0;
-    const double atyv = aty[j];
+    const double atyv = ldStream(aty + j);
     double r = -atyv + c;                       // c - A'y
     if (qdiag) {                                // QP: reduced cost c + Q x - A'y, objective term 1/2 x'Qx
       const double qj = qdiag[j];
@@ -692,8 +693,8 @@ __global__ __launch_bounds__(kVecThreads) void k_col_stats(const double* __restr
     }
     double sp = (r > 0.0 ? r : 0.0) * hasL;     // s+ (:157-159)
     double sn = (-(r < 0.0 ? r : 0.0)) * hasU;  // s- (:171-175)
-    slackPos[j] = sp;
-    slackNeg[j] = sn;
+    stStream(slackPos + j, sp);
+    stStream(slackNeg + j, sn);
     a[0] += xv * c;
     a[1] += sp * lF;
     a[2] += sn * uF;
