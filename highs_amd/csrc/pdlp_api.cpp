@@ -266,8 +266,8 @@ int pdlp_mi355x_host_prepare(const pdlp_problem_t* P, const pdlp_params_t* opt, 
     out->col_scale = dupVec(F.colScale); out->row_scale = dupVec(F.rowScale);
     out->row_kind = dupVec(F.rowKind); out->row_new_idx = dupVec(F.rowNewIdx);
     out->norm_cost = F.normCost; out->norm_rhs = F.normRhs; out->mat_norm_inf = F.matNormInf;
-    out->spmv_blocks_ax = pdlp::planStream(F.csr.beg, F.m, pdlp::kChunk, pdlp::kMaxMajorsPerBlock).nBlocks;
-    out->spmv_blocks_aty = pdlp::planStream(F.cscSorted.beg, F.n, pdlp::kChunk, pdlp::kMaxMajorsPerBlock).nBlocks;
+    out->spmv_blocks_ax = pdlp::planStream(F.csr.beg, F.m, pdlp::spmvChunkFor(F.nnz), pdlp::kMaxMajorsPerBlock).nBlocks;
+    out->spmv_blocks_aty = pdlp::planStream(F.cscSorted.beg, F.n, pdlp::spmvChunkFor(F.nnz), pdlp::kMaxMajorsPerBlock).nBlocks;
   });
 }
 

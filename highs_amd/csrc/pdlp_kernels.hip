@@ -157,10 +157,10 @@ struct Epi {
 //            the input vector, and park the products in LDS;
 //   phase 2: one lane per major adds its products left to right (the
 //            reference's summation order) and runs the epilogue.
-template <int EPI, bool MAPPED>
+template <int EPI, bool MAPPED, int CHUNK>
 __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
   if (usesDevState(EPI) && a.st->halted) return;
-  __shared__ double prod[kChunk + kChunk / 8 + 8];
+  __shared__ double prod[CHUNK + CHUNK / 8 + 8];
   __shared__ double scratch[2][kSpmvThreads / kWave];
 
   const int tid = threadIdx.x;
@@ -173,14 +173,14 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
   const double* __restrict__ in = epi.input();
   auto vecIndex = [&](int r) { return MAPPED ? a.A.majorMap[r] : r; };
 
-  if (r1 - r0 == 1 && p1 - p0 > kChunk) {
+  if (r1 - r0 == 1 && p1 - p0 > CHUNK) {
     // long major: the whole block strides over it; tree-reduced (deterministic)
     double s = 0.0;
     for (int p = p0 + tid; p < p1; p += kSpmvThreads) s += val[p] * in[idx[p]];
     s = blockSum<kSpmvThreads>(s, scratch[0]);
     if (tid == 0) { const int r = vecIndex(r0); epi.apply(r, s, epi.prefetch(r)); }
   } else {
-    constexpr int kPer = kChunk / kSpmvThreads;
+    constexpr int kPer = CHUNK / kSpmvThreads;
     const int cnt = p1 - p0;
     // Bookkeeping of this lane's first major, issued ahead of the stream.  All
     // loads below are unconditional with clamped indices: a load inside an
@@ -776,8 +776,14 @@ void launchSpmv(const MatView& M, SpmvArgs a, hipStream_t s) {
   }
   if (M.csr.nBlocks > 0) {
     a.A = M.csr;
-    if (M.csr.majorMap) hipLaunchKernelGGL((k_spmv<EPI, true>), dim3(M.csr.nBlocks), dim3(kSpmvThreads), 0, s, a);
-    else hipLaunchKernelGGL((k_spmv<EPI, false>), dim3(M.csr.nBlocks), dim3(kSpmvThreads), 0, s, a);
+    const dim3 grid(M.csr.nBlocks), block(kSpmvThreads);
+    if (M.csr.chunk == kChunkSmall) {
+      if (M.csr.majorMap) hipLaunchKernelGGL((k_spmv<EPI, true, kChunkSmall>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((k_spmv<EPI, false, kChunkSmall>), grid, block, 0, s, a);
+    } else {
+      if (M.csr.majorMap) hipLaunchKernelGGL((k_spmv<EPI, true, kChunk>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((k_spmv<EPI, false, kChunk>), grid, block, 0, s, a);
+    }
   }
 }
 }  // namespace

@@ -13,8 +13,14 @@
 
 namespace pdlp {
 
-// Nonzeros staged through LDS per work block of the CSR-adaptive SpMV.
+// Nonzeros staged through LDS per work block of the CSR-adaptive SpMV: 2048 for big operands (8 loads in
+// flight per lane), 512 below 2^18 nonzeros — a small operand then still spreads over tens of blocks and its
+// longest majors take the block-wide path (80bau3b: 23.2 -> 18.3 us/iteration).  At 1M nonzeros the small chunk
+// is slower in the loop (A x 8.9 -> 9.5 us), hence the cut at 2^18.
 constexpr int kChunk = 2048;
+constexpr int kChunkSmall = 512;
+constexpr int64_t kChunkSmallBelowNnz = 1 << 18;
+inline int32_t spmvChunkFor(int64_t nnz) { return nnz < kChunkSmallBelowNnz ? kChunkSmall : kChunk; }
 constexpr int kSpmvThreads = 256;
 constexpr int kMaxMajorsPerBlock = 2048;
 constexpr int kVecThreads = 256;
@@ -55,6 +61,7 @@ struct SpmvMat {
   int32_t nBlocks;
   const int32_t* majorMap;  // compact major -> vector index (nullptr = identity)
   int32_t partOffset;       // first slot of this matrix in the per-block partial arrays
+  int32_t chunk;            // kChunk or kChunkSmall: the work plan's block size
 };
 
 // Slab layout (pdlp_host.hpp SlabLayout), device pointers.  One 1024-thread block = 16 waves, each

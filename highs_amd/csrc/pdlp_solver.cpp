@@ -72,7 +72,8 @@ void DeviceMatrix::upload(const Compressed& cIn, int32_t nMajor_, int32_t nMinor
   }
   const int32_t nCsrMajor = useSlab ? (int32_t)L.longMap.size() : nMajor_;
   const int64_t nnzCsr = c->beg[nCsrMajor];
-  StreamPlan plan = planStream(c->beg, nCsrMajor, kChunk, kMaxMajorsPerBlock);
+  chunk = spmvChunkFor(nnzCsr);
+  StreamPlan plan = planStream(c->beg, nCsrMajor, chunk, kMaxMajorsPerBlock);
   nBlocks = nCsrMajor > 0 ? plan.nBlocks : 0;
   beg.alloc(c->beg.size());
   idx.alloc((size_t)nnzCsr + 1);  // one pad element: the kernels clamp, never predicate, their loads
@@ -116,7 +117,8 @@ void DeviceMatrix::buildFromDevice(DeviceCsrData& M, int mode, hipStream_t s) {
     beg.download(hostBeg.data(), hostBeg.size(), s);
     PDLP_HIP(hipStreamSynchronize(s));
   }
-  StreamPlan plan = planStream(hostBeg, nCsrMajor, kChunk, kMaxMajorsPerBlock);
+  chunk = spmvChunkFor(nCsrMajor > 0 ? (int64_t)hostBeg[nCsrMajor] : 0);
+  StreamPlan plan = planStream(hostBeg, nCsrMajor, chunk, kMaxMajorsPerBlock);
   nBlocks = nCsrMajor > 0 ? plan.nBlocks : 0;
   blockBeg.alloc(plan.blockBeg.size());
   blockBeg.upload(plan.blockBeg.data(), plan.blockBeg.size(), s);
@@ -126,7 +128,7 @@ void DeviceMatrix::buildFromDevice(DeviceCsrData& M, int mode, hipStream_t s) {
 MatView DeviceMatrix::view() const {
   MatView v{};
   v.csr = SpmvMat{beg.get(), idx.get(), val.get(), blockBeg.get(), nMajor, nBlocks,
-                  useSlab ? majorMap.get() : nullptr, useSlab ? slab.nBlocks : 0};
+                  useSlab ? majorMap.get() : nullptr, useSlab ? slab.nBlocks : 0, chunk};
   v.slab = slab;
   v.useSlab = useSlab ? 1 : 0;
   v.xcdMap = xcdMap;

@@ -24,6 +24,7 @@ struct DeviceMatrix {
   DeviceArray<uint32_t> ent, longMask;
   DeviceArray<double> val, slabVal;
   int32_t nMajor = 0, nBlocks = 0;  // nBlocks = CSR stream blocks
+  int32_t chunk = kChunk;           // work-plan block size of the CSR stream (spmvChunkFor)
   int64_t nnz = 0;
   bool useSlab = false;
   int32_t xcdMap = 1;  // block -> XCD assignment of the SpMV kernels (pdlp_kernels.hip xcdContiguousBlock), see tuneXcdMap

@@ -12,7 +12,9 @@
 #define ORACLE_GPU_ORDER_H_
 #include <string.h>
 
-enum { G_T = 256, G_WAVE = 64, G_CHUNK = 2048, G_MAXMAJ = 2048, G_MAXGRID = 2048 };
+enum { G_T = 256, G_WAVE = 64, G_CHUNK = 2048, G_CHUNK_SMALL = 512, G_MAXMAJ = 2048, G_MAXGRID = 2048 };
+/* spmvChunkFor (pdlp_kernels.hpp): work-plan block size of a CSR stream with this many nonzeros */
+static inline int g_chunk_for(long nnz) { return nnz < (1L << 18) ? G_CHUNK_SMALL : G_CHUNK; }
 /* slab SpMV (k_spmv_slab): 1024-thread blocks of 16 waves, rows per wave by slabRowsPerWave (pdlp_host.cpp) */
 enum { G_SLAB_T = 1024, G_SLAB_WAVES = 16, G_SLAB_BLOCKS = 256 };
 static inline int g_slab_rows_per_wave(int nMajor, int nMinor) {
@@ -45,6 +47,34 @@ static inline double g_block_sum_n(const double* perThread, int nThreads) {
   return r;
 }
 static inline double g_block_sum(const double* perThread /* [256] */) { return g_block_sum_n(perThread, G_T); }
+/* value of one major of a CSR stream (k_spmv): left to right, except majors longer than the stream's chunk
+ * (block-strided over 256 lanes + block tree) */
+static inline double g_major_sum(const int* beg, const int* idx, const double* val, const double* in, int r, int chunk) {
+  const int p0 = beg[r], p1 = beg[r + 1];
+  if (p1 - p0 <= chunk) {
+    double s = 0.0;
+    for (int p = p0; p < p1; ++p) s += val[p] * in[idx[p]];
+    return s;
+  }
+  double lane[G_T];
+  for (int t = 0; t < G_T; ++t) {
+    double s = 0.0;
+    for (int p = p0 + t; p < p1; p += G_T) s += val[p] * in[idx[p]];
+    lane[t] = s;
+  }
+  return g_block_sum(lane);
+}
+/* chunk of the kernel that sums the long majors of one operand: the CSR stream itself (chunk by its nnz), or — slab
+ * layout — the side stream of the majors longer than 256 (chunk by THEIR nnz).  layoutMode as in pdlp_oracle.c:
+ * 0 = the product's automatic rule (slab when the gathered vector has >= 2^18 entries), 1 = CSR, 2 = slab. */
+static inline int g_long_major_chunk(const int* beg, int nMajor, int nMinor, int layoutMode) {
+  int slab = layoutMode == 2 || (layoutMode == 0 && nMinor >= (1 << 18));
+  if (slab && g_slab_rows_per_wave(nMajor, nMinor) == 0) slab = 0;
+  if (!slab) return g_chunk_for(nMajor > 0 ? beg[nMajor] : 0);
+  long longNnz = 0;
+  for (int i = 0; i < nMajor; ++i) if (beg[i + 1] - beg[i] > 256) longNnz += beg[i + 1] - beg[i];
+  return g_chunk_for(longNnz);
+}
 /* reducePartials: lane t sums p[t], p[t+256], ... in 4 independent chains */
 static inline double g_reduce_partials(const double* p, int count) {
   double lane[G_T];

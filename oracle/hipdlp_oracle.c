@@ -33,8 +33,8 @@
  * are bit-identical to the loops below; its only arithmetic difference is the ORDER in which the
  * power method's dot products, the fixed-point error sums, the check statistics and the two restart
  * norms are added (vector-kernel grid sums, gpu_order.h).  In that mode this oracle follows a whole GPU
- * solve bit for bit (tests/test_gpu_hipdlp.py).  Limitation of the mode: majors longer than 2048
- * nonzeros (summed block-strided on the GPU) are not restated.
+ * solve bit for bit (tests/test_gpu_hipdlp.py); majors longer than the SpMV chunk are summed block-strided as the
+ * GPU does (h_dev_setup, gpu_order.h g_major_sum).
  *
  * Reference behaviours reproduced on purpose (they are what a drop-in must match):
  *  - the objective sense is NOT applied to the costs (pdhg.cc:171 only stores it, :481 uses
@@ -65,6 +65,11 @@ typedef struct {
   int scaled;
   double cNorm, bNorm, offset;
   int sense;
+  /* device reduction order only (h_dev_setup): row-wise copy with ascending columns and the chunk above which
+   * the GPU sums a major block-strided (gpu_order.h g_major_sum); rBeg == NULL otherwise */
+  int *rBeg, *rIdx;
+  double* rVal;
+  int chunkA, chunkAt;
 } HLp;
 
 static void* xmalloc(size_t n) { void* p = malloc(n ? n : 1); if (!p) abort(); return p; }
@@ -72,17 +77,44 @@ static double* dvec(long n) { double* p = (double*)xmalloc(sizeof(double) * (siz
 
 /* linalg::ax, linalg.cc:36-47 (scatter over the columns) */
 static void h_ax(const HLp* L, const double* x, double* out) {
+  if (L->rBeg) { /* same left-to-right order per row; rows longer than the chunk as the GPU sums them */
+    for (int i = 0; i < L->m; ++i) out[i] = g_major_sum(L->rBeg, L->rIdx, L->rVal, x, i, L->chunkA);
+    return;
+  }
   for (int i = 0; i < L->m; ++i) out[i] = 0.0;
   for (int c = 0; c < L->n; ++c)
     for (int p = L->beg[c]; p < L->beg[c + 1]; ++p) out[L->idx[p]] += L->val[p] * x[c];
 }
 /* linalg::aTy, linalg.cc:49-61 */
 static void h_aty(const HLp* L, const double* y, double* out) {
+  if (L->rBeg) {
+    for (int c = 0; c < L->n; ++c) out[c] = g_major_sum(L->beg, L->idx, L->val, y, c, L->chunkAt);
+    return;
+  }
   for (int c = 0; c < L->n; ++c) {
     double s = 0.0;
     for (int p = L->beg[c]; p < L->beg[c + 1]; ++p) s += L->val[p] * y[L->idx[p]];
     out[c] = s;
   }
+}
+/* device reduction order: row-wise copy of the (scaled) matrix and the long-major chunks of both operands */
+static void h_dev_setup(HLp* L, int layoutMode) {
+  const int n = L->n, m = L->m;
+  const long nnz = n > 0 ? L->beg[n] : 0;
+  L->rBeg = (int*)xmalloc(sizeof(int) * (size_t)(m + 1));
+  L->rIdx = (int*)xmalloc(sizeof(int) * (size_t)(nnz > 0 ? nnz : 1));
+  L->rVal = dvec(nnz);
+  int* fill = (int*)xmalloc(sizeof(int) * (size_t)(m + 1));
+  memset(fill, 0, sizeof(int) * (size_t)(m + 1));
+  for (long p = 0; p < nnz; ++p) fill[L->idx[p]]++;
+  int acc = 0;
+  for (int i = 0; i < m; ++i) { L->rBeg[i] = acc; acc += fill[i]; fill[i] = L->rBeg[i]; }
+  L->rBeg[m] = acc;
+  for (int c = 0; c < n; ++c)
+    for (int p = L->beg[c]; p < L->beg[c + 1]; ++p) { const int q = fill[L->idx[p]]++; L->rIdx[q] = c; L->rVal[q] = L->val[p]; }
+  free(fill);
+  L->chunkA = g_long_major_chunk(L->rBeg, m, n, layoutMode);
+  L->chunkAt = g_long_major_chunk(L->beg, n, m, layoutMode);
 }
 static double h_dot(const double* a, const double* b, int n) {
   double s = 0.0;
@@ -203,6 +235,7 @@ static void h_preprocess(const pdlp_problem_t* P, HLp* L) {
 static void h_free(HLp* L) {
   free(L->beg); free(L->idx); free(L->val); free(L->cost); free(L->lower); free(L->upper); free(L->rl); free(L->ru);
   free(L->colScale); free(L->rowScale); free(L->ctype); free(L->newIdx); free(L->isEq);
+  free(L->rBeg); free(L->rIdx); free(L->rVal);
 }
 
 /* Scaling::applyScaling, scaling.cc:222-262, + the cumulative update */
@@ -509,6 +542,7 @@ static int h_solve(const pdlp_problem_t* P, const pdlp_params_t* opt, pdlp_resul
   const double eps = opt->gap_tol;
   const int pid = opt->step_size_strategy != 0;
   S.dev = opt->reserved[0] == 1;
+  if (S.dev) h_dev_setup(L, opt->reserved[1]);
   /* initializeStepSizes */
   S.omega = (L->cNorm + 1.0) / (L->bNorm + 1.0);
   S.pw = S.omega; S.bestPw = S.pw; S.beta = S.pw * S.pw;

@@ -123,7 +123,7 @@ typedef struct {
   int *planA, nPlanA, *planAt, nPlanAt; /* CSR-adaptive work plans, identical to the product's */
   /* slab layout (operands whose gathered vector has >= 2^18 entries): blocks of R consecutive majors,
    * majors longer than 256 entries go to a CSR side plan over the compacted long majors */
-  int slabA, slabAt, RA, RAt, nLongA, nLongAt;
+  int slabA, slabAt, RA, RAt, nLongA, nLongAt, chunkA, chunkAt;
   int *longMapA, *longMapAt, *longBegA, *longBegAt;
   double *gPartA, *gPartB, *gStat;
 } Work;
@@ -320,9 +320,9 @@ static void build_csr(Work* w) {
 /* AxCPU linalg.c:35-71 scatters CSC columns in ascending j, so ax[i] is the
  * left-to-right sum over ascending column index — identical to a row gather
  * over the ascending-column CSR built above. */
-static void g_spmv(const int* beg, const int* idx, const double* val, int nMajor, const double* in, double* out);
+static void g_spmv(const int* beg, const int* idx, const double* val, int nMajor, const double* in, double* out, int chunk);
 static void o_Ax(const Work* w, double* ax, const double* x) {
-  if (w->gpuOrder) { g_spmv(w->csrBeg, w->csrIdx, w->csrVal, w->m, x, ax); return; }
+  if (w->gpuOrder) { g_spmv(w->csrBeg, w->csrIdx, w->csrVal, w->m, x, ax, w->chunkA); return; }
   for (int i = 0; i < w->m; ++i) {
     double s = 0.0;
     for (int p = w->csrBeg[i]; p < w->csrBeg[i + 1]; ++p) s += w->csrVal[p] * x[w->csrIdx[p]];
@@ -333,7 +333,7 @@ static void o_Ax(const Work* w, double* ax, const double* x) {
  * over ascending (permuted) row index.  The CSC column of the formulated
  * matrix is NOT sorted by row (EQ/BOUND entries first), so do the scatter. */
 static void o_ATy(const Work* w, double* aty, const double* y) {
-  if (w->gpuOrder) { g_spmv(w->cssBeg, w->cssIdx, w->cssVal, w->n, y, aty); return; }
+  if (w->gpuOrder) { g_spmv(w->cssBeg, w->cssIdx, w->cssVal, w->n, y, aty, w->chunkAt); return; }
   memset(aty, 0, sizeof(double) * (size_t)w->n);
   for (int i = 0; i < w->m; ++i) {
     const double yi = y[i];
@@ -360,13 +360,14 @@ static void o_ATy(const Work* w, double* aty, const double* y) {
 #include "gpu_order.h"
 /* planStream (pdlp_host.cpp) */
 static int* g_plan(const int* beg, int nMajor, int* nBlocksOut) {
+  const int chunk = g_chunk_for(nMajor > 0 ? beg[nMajor] : 0);
   int* plan = ialloc((long)nMajor + 2);
   int nb = 0, start = 0;
   plan[0] = 0;
   while (start < nMajor) {
     const int base = beg[start];
     int end = start;
-    while (end < nMajor && end - start < G_MAXMAJ && beg[end + 1] - base <= G_CHUNK) ++end;
+    while (end < nMajor && end - start < G_MAXMAJ && beg[end + 1] - base <= chunk) ++end;
     if (end == start) end = start + 1;
     plan[++nb] = end;
     start = end;
@@ -374,24 +375,10 @@ static int* g_plan(const int* beg, int nMajor, int* nBlocksOut) {
   *nBlocksOut = nb;
   return plan;
 }
-/* value of one major: left to right, except majors longer than a chunk (block-strided + tree) */
-static double g_major_sum(const int* beg, const int* idx, const double* val, const double* in, int r) {
-  const int p0 = beg[r], p1 = beg[r + 1];
-  if (p1 - p0 <= G_CHUNK) {
-    double s = 0.0;
-    for (int p = p0; p < p1; ++p) s += val[p] * in[idx[p]];
-    return s;
-  }
-  double lane[G_T];
-  for (int t = 0; t < G_T; ++t) {
-    double s = 0.0;
-    for (int p = p0 + t; p < p1; p += G_T) s += val[p] * in[idx[p]];
-    lane[t] = s;
-  }
-  return g_block_sum(lane);
-}
-static void g_spmv(const int* beg, const int* idx, const double* val, int nMajor, const double* in, double* out) {
-  for (int r = 0; r < nMajor; ++r) out[r] = g_major_sum(beg, idx, val, in, r);
+/* chunk = the block size of the kernel that owns the majors which are not summed left to right by the slab kernel:
+ * the CSR stream itself, or the slab layout's side CSR of majors longer than 256 (its own, smaller nnz count) */
+static void g_spmv(const int* beg, const int* idx, const double* val, int nMajor, const double* in, double* out, int chunk) {
+  for (int r = 0; r < nMajor; ++r) out[r] = g_major_sum(beg, idx, val, in, r, chunk);
 }
 /* per-block partial of a per-major quantity: lane t accumulates majors r0+t, r0+t+256, ...;
  * a long-major block has its single value on lane 0 */
@@ -444,6 +431,8 @@ static void g_setup(Work* w, int layoutMode) {
   else w->planA = g_plan(w->csrBeg, m, &w->nPlanA);
   if (w->slabAt) g_slab_setup(w->cssBeg, n, m, &w->RAt, &w->nLongAt, &w->longMapAt, &w->longBegAt, &w->planAt, &w->nPlanAt);
   else w->planAt = g_plan(w->cssBeg, n, &w->nPlanAt);
+  w->chunkA = g_chunk_for(w->slabA ? w->longBegA[w->nLongA] : w->nnz);
+  w->chunkAt = g_chunk_for(w->slabAt ? w->longBegAt[w->nLongAt] : w->nnz);
   const long mx = (n > m ? n : m) + G_MAXGRID + 8;
   w->gPartA = dalloc(mx); w->gPartB = dalloc(mx); w->gStat = dalloc(mx);
 }
