@@ -142,6 +142,23 @@ class PdlpSlabLayout(C.Structure):
     ]
 
 
+class PdlpMpsModel(C.Structure):
+    """pdlp_mps_model_t (include/pdlp_mi355x.h): what pdlp_mi355x_read_mps fills."""
+    _fields_ = [
+        ("lp", PdlpProblem),
+        ("cost_row_location", C.c_int32), ("num_integrality", C.c_int32),
+        ("integrality", C.POINTER(C.c_uint8)),
+        ("model_name", C.c_char_p), ("objective_name", C.c_char_p),
+        ("col_name_pool", C.POINTER(C.c_char)), ("col_name_start", C.POINTER(C.c_int64)),
+        ("row_name_pool", C.POINTER(C.c_char)), ("row_name_start", C.POINTER(C.c_int64)),
+        ("hessian_dim", C.c_int32), ("warning_issued", C.c_int32),
+        ("hessian_start", c_i32p), ("hessian_index", c_i32p), ("hessian_value", c_f64p),
+        ("num_warnings", C.c_int32), ("threads", C.c_int32),
+        ("warnings", C.c_char_p),
+        ("file_bytes", C.c_int64), ("seconds", C.c_double),
+    ]
+
+
 def default_params(**kw):
     """Defaults HiGHS passes for default options (CupdlpWrapper.cpp:642-717;
     kkt_tolerance default 1e-7, HConst.h:345)."""

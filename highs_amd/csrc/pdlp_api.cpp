@@ -7,11 +7,13 @@
 #include <limits>
 #include <memory>
 #include <random>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "pdlp_halpern.hpp"
+#include "pdlp_mps.hpp"
 #include "pdlp_solver.hpp"
 
 struct pdlp_mi355x_solver {
@@ -324,8 +326,94 @@ int64_t pdlp_mi355x_sizeof(int32_t which) {
     case 3: return sizeof(pdlp_iter_stats_t);
     case 4: return sizeof(pdlp_prepared_t);
     case 5: return sizeof(pdlp_slab_layout_t);
+    case 6: return sizeof(pdlp_mps_model_t);
     default: return -1;
   }
+}
+
+// MPS ingest (pdlp_mps.cpp).  The arrays of *out are malloc'ed copies owned by the caller's struct.
+int pdlp_mi355x_read_mps(const char* path, int32_t num_threads, pdlp_mps_model_t* out) {
+  int status = 1;
+  const int rc = guarded([&] {
+    if (!path || !out) throw std::runtime_error("read_mps: NULL argument");
+    memset(out, 0, sizeof(*out));
+    pdlp::mps::Model M;
+    status = pdlp::mps::readMps(path, num_threads, M);
+    if (status != pdlp::mps::kReadOk) {
+      g_lastError = M.error;
+      return;
+    }
+    auto dupStr = [](const std::string& s) {
+      char* p = (char*)malloc(s.size() + 1);
+      memcpy(p, s.data(), s.size());
+      p[s.size()] = 0;
+      return p;
+    };
+    pdlp_problem_t& P = out->lp;
+    P.num_col = M.numCol;
+    P.num_row = M.numRow;
+    P.num_nz = (int64_t)M.aIndex.size();
+    P.a_start = dupVec(M.aStart);
+    P.a_index = dupVec(M.aIndex);
+    P.a_value = dupVec(M.aValue);
+    P.col_cost = dupVec(M.colCost);
+    P.col_lower = dupVec(M.colLower);
+    P.col_upper = dupVec(M.colUpper);
+    P.row_lower = dupVec(M.rowLower);
+    P.row_upper = dupVec(M.rowUpper);
+    P.offset = M.offset;
+    P.sense = M.sense;
+    if (M.qDim > 0) {
+      std::vector<int32_t> qs, qi;
+      std::vector<double> qv;
+      pdlp::mps::lowerTriangle(M, qs, qi, qv);
+      P.q_dim = M.qDim;
+      P.q_start = dupVec(qs);
+      P.q_index = dupVec(qi);
+      P.q_value = dupVec(qv);
+      out->hessian_dim = M.qDim;
+      out->hessian_start = dupVec(M.qStart);
+      out->hessian_index = dupVec(M.qIndex);
+      out->hessian_value = dupVec(M.qValue);
+    }
+    out->cost_row_location = M.costRowLocation;
+    if (!M.integrality.empty()) {
+      out->num_integrality = M.numCol;
+      out->integrality = dupVec(M.integrality);
+    }
+    out->model_name = dupStr(M.modelName);
+    out->objective_name = dupStr(M.objectiveName);
+    if (!M.colNameStart.empty()) {
+      char* pool = (char*)malloc(M.colNamePool.size() + 1);
+      memcpy(pool, M.colNamePool.data(), M.colNamePool.size());
+      out->col_name_pool = pool;
+      out->col_name_start = dupVec(M.colNameStart);
+    }
+    if (!M.rowNameStart.empty()) {
+      char* pool = (char*)malloc(M.rowNamePool.size() + 1);
+      memcpy(pool, M.rowNamePool.data(), M.rowNamePool.size());
+      out->row_name_pool = pool;
+      out->row_name_start = dupVec(M.rowNameStart);
+    }
+    out->num_warnings = M.numWarnings;
+    out->warning_issued = M.warningIssued ? 1 : 0;
+    out->warnings = dupStr(M.warnings);
+    out->threads = M.threads;
+    out->file_bytes = M.fileBytes;
+    out->seconds = M.seconds;
+  });
+  return rc ? 1 : status;
+}
+
+void pdlp_mi355x_free_mps_model(pdlp_mps_model_t* out) {
+  if (!out) return;
+  pdlp_problem_t& P = out->lp;
+  const void* owned[] = {P.a_start, P.a_index, P.a_value, P.col_cost, P.col_lower, P.col_upper, P.row_lower, P.row_upper,
+                         P.q_start, P.q_index, P.q_value, out->integrality, out->model_name, out->objective_name,
+                         out->col_name_pool, out->col_name_start, out->row_name_pool, out->row_name_start,
+                         out->hessian_start, out->hessian_index, out->hessian_value, out->warnings};
+  for (const void* p : owned) free((void*)p);
+  memset(out, 0, sizeof(*out));
 }
 
 int pdlp_mi355x_comm_unique_id(void* id128) {

@@ -151,8 +151,9 @@ def read_mps(path):
     """Minimal MPS reader (fixed or free format, whitespace-separated fields):
     ROWS / COLUMNS / RHS / RANGES / BOUNDS / OBJSENSE.  Semantics follow
     HiGHS' reader (io/HMpsFF.cpp): first N row is the objective, RHS on the
-    objective row is minus the offset, a negative UP bound on a column whose
-    lower bound is still 0 makes the lower bound -inf."""
+    objective row is minus the offset.  (The free-format reader has no special rule for a negative UP bound:
+    the column keeps its lower bound 0, HMpsFF.cpp:1525-1533.)  Test helper; the library's own reader is
+    csrc/pdlp_mps.cpp (solver.read_mps)."""
     import gzip
 
     op = gzip.open if str(path).endswith(".gz") else open
@@ -160,6 +161,7 @@ def read_mps(path):
     obj_name = None
     cols, col_idx = [], {}
     entries = []  # (row, col, val)
+    seen = set()
     cost = {}
     rhs, ranges = {}, {}
     bounds = []
@@ -201,9 +203,12 @@ def read_mps(path):
                 j = col_idx[cn]
                 for k in range(1, len(t) - 1, 2):
                     rn, v = t[k], float(t[k + 1])
+                    if v == 0.0:
+                        continue  # zero coefficients are dropped (HMpsFF.cpp:897)
                     if rn == obj_name:
-                        cost[j] = v
-                    elif rn in row_idx:
+                        cost.setdefault(j, v)  # the first value wins (:913-927)
+                    elif rn in row_idx and (row_idx[rn], j) not in seen:
+                        seen.add((row_idx[rn], j))
                         entries.append((row_idx[rn], j, v))
             elif section in ("RHS", "RANGES"):
                 tt = t[1:] if len(t) % 2 == 1 else t
@@ -250,8 +255,6 @@ def read_mps(path):
     for ty, j, v in bounds:
         if ty == "UP":
             cu[j] = v
-            if v < 0 and cl[j] == 0:
-                cl[j] = -inf
         elif ty == "LO":
             cl[j] = v
         elif ty == "FX":

@@ -40,6 +40,7 @@ EXPORTS = [
     "pdlp_mi355x_free_problem", "pdlp_mi355x_last_error", "pdlp_mi355x_abi_version",
     "pdlp_mi355x_host_prepare", "pdlp_mi355x_free_prepared", "pdlp_mi355x_row_partition", "pdlp_mi355x_sizeof",
     "pdlp_mi355x_host_slab_layout", "pdlp_mi355x_free_slab_layout",
+    "pdlp_mi355x_read_mps", "pdlp_mi355x_free_mps_model",
 ]
 
 
@@ -88,6 +89,10 @@ def lib():
         L.pdlp_mi355x_host_slab_layout.argtypes = [pPrep, C.c_int32, C.c_int32, pSlab]
         L.pdlp_mi355x_free_slab_layout.argtypes = [pSlab]
         L.pdlp_mi355x_free_slab_layout.restype = None
+        pMps = C.POINTER(abi.PdlpMpsModel)
+        L.pdlp_mi355x_read_mps.argtypes = [C.c_char_p, C.c_int32, pMps]
+        L.pdlp_mi355x_free_mps_model.argtypes = [pMps]
+        L.pdlp_mi355x_free_mps_model.restype = None
         L.pdlp_mi355x_sizeof.argtypes = [C.c_int32]
         L.pdlp_mi355x_sizeof.restype = C.c_int64
         L.pdlp_mi355x_last_error.restype = C.c_char_p
@@ -99,6 +104,55 @@ def lib():
 def _check(rc, what):
     if rc != 0:
         raise RuntimeError(f"{what} failed: {lib().pdlp_mi355x_last_error().decode()}")
+
+
+class MpsFixedFormat(RuntimeError):
+    """The file has names with spaces: a fixed-column reader is needed (return code 3 of pdlp_mi355x_read_mps)."""
+
+
+def read_mps(path, threads=0):
+    """Highs::readModel for an MPS file through the library's multi-threaded reader (csrc/pdlp_mps.cpp; the
+    reference: io/FilereaderMps.cpp:24-58 -> io/HMpsFF.cpp).  Returns (HighsLp, info); info carries what HighsLp
+    has no field for: integrality, names, objective name, cost row location, warnings, threads, seconds."""
+    M = abi.PdlpMpsModel()
+    L = lib()
+    rc = L.pdlp_mi355x_read_mps(os.fsencode(path), int(threads), C.byref(M))
+    if rc == 2:
+        raise FileNotFoundError(L.pdlp_mi355x_last_error().decode())
+    if rc == 3:
+        raise MpsFixedFormat(L.pdlp_mi355x_last_error().decode())
+    _check(rc, "pdlp_mi355x_read_mps")
+    try:
+        P = M.lp
+        n, m, nz = P.num_col, P.num_row, P.num_nz
+        arr = lambda p, k, dt: np.ctypeslib.as_array(p, shape=(k,)).astype(dt).copy() if k else np.zeros(0, dt)
+        lp = HighsLp(n, m, arr(P.col_cost, n, np.float64), arr(P.col_lower, n, np.float64), arr(P.col_upper, n, np.float64),
+                     arr(P.row_lower, m, np.float64), arr(P.row_upper, m, np.float64),
+                     np.ctypeslib.as_array(P.a_start, shape=(n + 1,)).astype(np.int32).copy(),
+                     arr(P.a_index, nz, np.int32), arr(P.a_value, nz, np.float64), P.sense, P.offset,
+                     (M.model_name or b"").decode())
+        if P.q_dim > 0:
+            qs = np.ctypeslib.as_array(P.q_start, shape=(P.q_dim + 1,)).astype(np.int32).copy()
+            lp.hessian = (qs, arr(P.q_index, int(qs[-1]), np.int32), arr(P.q_value, int(qs[-1]), np.float64))
+
+        def names(pool, start, k):
+            if not start or k == 0:
+                return None
+            st = np.ctypeslib.as_array(start, shape=(k + 1,))
+            raw = C.string_at(pool, int(st[k]))
+            return [raw[int(st[i]):int(st[i + 1]) - 1].decode() for i in range(k)]
+
+        info = dict(cost_row_location=M.cost_row_location, objective_name=(M.objective_name or b"").decode(),
+                    integrality=arr(M.integrality, M.num_integrality, np.uint8) if M.num_integrality else None,
+                    col_names=names(M.col_name_pool, M.col_name_start, n), row_names=names(M.row_name_pool, M.row_name_start, m),
+                    num_warnings=M.num_warnings, warning_issued=bool(M.warning_issued), warnings=(M.warnings or b"").decode().splitlines(), threads=M.threads,
+                    file_bytes=M.file_bytes, seconds=M.seconds)
+        if M.hessian_dim > 0:
+            hs = np.ctypeslib.as_array(M.hessian_start, shape=(M.hessian_dim + 1,)).astype(np.int32).copy()
+            info["hessian_square"] = (hs, arr(M.hessian_index, int(hs[-1]), np.int32), arr(M.hessian_value, int(hs[-1]), np.float64))
+        return lp, info
+    finally:
+        L.pdlp_mi355x_free_mps_model(C.byref(M))
 
 
 @dataclass

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define PDLP_MI355X_ABI_VERSION 4
+#define PDLP_MI355X_ABI_VERSION 5
 
 /* Termination codes: same numbering as cuPDLP-C's termination_code
  * (cupdlp_defs.h:61-68) so the status map of CupdlpWrapper.cpp:225-251
@@ -303,7 +303,53 @@ typedef struct pdlp_slab_layout {
 int pdlp_mi355x_host_slab_layout(const pdlp_prepared_t* prep, int32_t which,
                                  int32_t long_limit, pdlp_slab_layout_t* out);
 void pdlp_mi355x_free_slab_layout(pdlp_slab_layout_t* out);
-/* sizeof() of the ABI structs: 0 problem, 1 params, 2 result, 3 iter_stats, 4 prepared, 5 slab_layout */
+/* ---- MPS ingest (host-only, no GPU needed) --------------------------------------
+ * Multi-threaded reader of free-format MPS files (fixed-format files without spaces in names are free
+ * format too).  Replaces, for such files, the reference's single-threaded parser
+ *   io/FilereaderMps.cpp:24-58 -> free_format_parser::HMpsFF::loadProblem (io/HMpsFF.cpp:21-133)
+ * and builds the same model: first N row = objective (other N rows dropped), duplicate row / column names
+ * are distinct rows / columns and only the first occurrence can be addressed, undefined rows and repeated
+ * (column, row) pairs are ignored with a warning, zero coefficients dropped, entries of a column in file
+ * order, RHS of the cost row = -offset, RANGES by sign, integer columns of a MARKER block are [0,1] until
+ * a bound says otherwise, BOUNDS may introduce columns, QUADOBJ / QMATRIX -> Hessian, OBJSENSE either style.
+ * integration/FilereaderMpsMi355x.cpp shows the binding inside Highs::readModel.
+ * Return: 0 ok (out filled; release with pdlp_mi355x_free_mps_model), 1 malformed file / unsupported
+ * section (pdlp_mi355x_last_error), 2 file cannot be opened, 3 names contain spaces: a fixed-COLUMN reader
+ * is needed (FreeFormatParserReturnCode::kFixedFormat — the reference then falls back to io/HMPSIO.cpp),
+ * 4 the file is a gzip stream (left to the reference's zlib-backed stream, HMpsFF.cpp:253-261). */
+typedef struct pdlp_mps_model {
+  pdlp_problem_t lp;           /* HighsLp fields; lp.q_* = LOWER TRIANGLE of the Hessian (what this library's
+                                  QP path and HighsHessian::kTriangular expect), NULL / 0 for an LP */
+  int32_t cost_row_location;   /* lp.cost_row_location_ (HMpsFF.cpp:639) */
+  int32_t num_integrality;     /* 0: every column continuous (lp.integrality_ stays empty), else num_col */
+  const uint8_t* integrality;  /* HighsVarType per column: 0 continuous, 1 integer, 2 semi-continuous, 3 semi-integer */
+  const char* model_name;      /* NAME line */
+  const char* objective_name;  /* name of the cost row ("Objective" if none) */
+  /* names: one pool of NUL-terminated strings + [num+1] start offsets; NULL when the file repeats a name
+   * (the reference clears its name arrays then, HMpsFF.cpp:63-80) */
+  const char* col_name_pool;
+  const int64_t* col_name_start;
+  const char* row_name_pool;
+  const int64_t* row_name_start;
+  /* the Hessian exactly as the parser leaves it (square, column-wise, file order: fillHessian, HMpsFF.cpp:177-216) */
+  int32_t hessian_dim;
+  int32_t warning_issued;      /* HMpsFF::warning_issued_ at the end of the read: FilereaderRetcode::kWarning if set.
+                                  (The reference ASSIGNS the flag at the end of COLUMNS / RHS / BOUNDS / RANGES, so
+                                  earlier warnings may be forgotten; num_warnings below counts every class met.) */
+  const int32_t* hessian_start;
+  const int32_t* hessian_index;
+  const double* hessian_value;
+  int32_t num_warnings;        /* warning classes met */
+  int32_t threads;             /* host threads used */
+  const char* warnings;        /* one line per warning class */
+  int64_t file_bytes;
+  double seconds;              /* wall time of the call */
+} pdlp_mps_model_t;
+/* num_threads <= 0: one per hardware thread (at least 1 MB of file each, at most 64); > 0: exactly that many. */
+int pdlp_mi355x_read_mps(const char* path, int32_t num_threads, pdlp_mps_model_t* out);
+void pdlp_mi355x_free_mps_model(pdlp_mps_model_t* out);
+
+/* sizeof() of the ABI structs: 0 problem, 1 params, 2 result, 3 iter_stats, 4 prepared, 5 slab_layout, 6 mps_model */
 int64_t pdlp_mi355x_sizeof(int32_t which);
 
 const char* pdlp_mi355x_last_error(void);

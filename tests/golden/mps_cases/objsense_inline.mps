@@ -1,0 +1,10 @@
+NAME sense2
+OBJSENSE MAX
+ROWS
+ N obj
+ L r
+COLUMNS
+ x obj 1 r 1
+RHS
+ rhs r 4
+ENDATA

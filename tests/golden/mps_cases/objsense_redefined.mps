@@ -1,0 +1,12 @@
+NAME sense3
+objsense max
+   min
+   MAX
+ROWS
+ N obj
+ L r
+COLUMNS
+ x obj 1 r 1
+RHS
+ rhs r 4
+ENDATA

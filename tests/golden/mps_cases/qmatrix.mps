@@ -1,0 +1,16 @@
+NAME qm
+ROWS
+ N obj
+ G c1
+COLUMNS
+ x obj 1 c1 1
+ y obj 1 c1 1
+ z obj 1 c1 1
+RHS
+ rhs c1 1
+QMATRIX
+ x x 2.0 y 0.5
+ y x 0.5 y 3.0
+ y z -1.0
+ z y -1.0 z 4.0
+ENDATA

@@ -67,7 +67,8 @@ def test_reference_cli_presolve_on(tmp_path):
 
 @needs_build
 @pytest.mark.parametrize("case", ["pdlp-distillation-lp", "pdlp-3d-lp", "pdlp-boxed-row-lp", "pdlp-infeasible-lp",
-                                  "pdlp-unbounded-lp", "pdlp-restart-lp", "pdlp-restart-add-row"])
+                                  "pdlp-unbounded-lp", "pdlp-restart-lp", "pdlp-restart-add-row",
+                                  "test-1966"])  # check/TestIpm.cpp:92: PDLP on a primal- and dual-infeasible LP
 def test_reference_catch2_cases(tmp_path, case):
     """check/TestPdlp.cpp, unmodified binary: the asserts on iteration counts (160 / 79) are CPU-build-only
     in the reference (TestPdlp.cpp:98-113 drops them for its CUDA build); everything else must pass."""

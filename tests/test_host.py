@@ -25,12 +25,13 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/pdlp_mi355x.h but not exported"
     assert set(solver.EXPORTS) == declared
-    assert lib.pdlp_mi355x_abi_version() == int(re.search(r"#define PDLP_MI355X_ABI_VERSION (\d+)", hdr).group(1)) == 4
+    assert lib.pdlp_mi355x_abi_version() == int(re.search(r"#define PDLP_MI355X_ABI_VERSION (\d+)", hdr).group(1)) == 5
 
 
 def test_struct_sizes_match_ctypes_mirror():
     lib = solver.lib()
-    for which, ty in enumerate([abi.PdlpProblem, abi.PdlpParams, abi.PdlpResult, abi.PdlpIterStats, abi.PdlpPrepared]):
+    for which, ty in enumerate([abi.PdlpProblem, abi.PdlpParams, abi.PdlpResult, abi.PdlpIterStats, abi.PdlpPrepared,
+                              abi.PdlpSlabLayout, abi.PdlpMpsModel]):
         assert lib.pdlp_mi355x_sizeof(which) == C.sizeof(ty), ty.__name__
 
 
