@@ -226,7 +226,10 @@ void Solver::construct(const pdlp_problem_t& P, const void* id128) {
   const int64_t nnzIn = P.num_col > 0 && P.a_start ? (int64_t)P.a_start[P.num_col] : 0;
   gpuSetup_ = nnzIn >= 200000;
   if (const char* g = getenv("PDLP_MI355X_GPU_SETUP")) gpuSetup_ = atoi(g) != 0;
-  if (sharded_) gpuSetup_ = false;  // the row-block shards are cut on the host
+  // sharded: every rank still prepares the WHOLE problem (Ruiz scaling couples all rows and columns) but does it on
+  // its device and copies the result back once; only the row-block cut and the upload of its shard stay on the host
+  const bool shardedGpuSetup = sharded_ && gpuSetup_ && !(P.q_dim > 0 && P.q_start && P.q_start[P.q_dim] > 0);
+  if (sharded_) gpuSetup_ = false;
   if (P.q_dim > 0 && P.q_start && P.q_start[P.q_dim] > 0) gpuSetup_ = false;  // the QP form is prepared on the host
   const bool doScale = !(opt_.features_off & PDLP_FEATURE_SCALING_OFF);
   DeviceProblem devProb;
@@ -243,6 +246,12 @@ void Solver::construct(const pdlp_problem_t& P, const void* id128) {
     F_.rowScale = std::move(devProb.hRowScale);
     sumCost2_ = devProb.sumCost2;
     sumRhs2_ = devProb.sumRhs2;
+  } else if (shardedGpuSetup) {
+    gpuPrepare(P, doScale, stream_, devProb);
+    downloadForm(devProb, F_, stream_);
+    sumCost2_ = devProb.sumCost2;
+    sumRhs2_ = devProb.sumRhs2;
+    devProb = DeviceProblem();  // released before any exchange kernel of another rank can run on this device
   } else {
     formulate(P, F_);
     if (doScale) scale(F_);
@@ -375,6 +384,35 @@ void Solver::uploadProblem() {
   allocIterates();
   // the big host copies are not needed any more (postsolve uses only the scale vectors and row maps)
   F_.csc = Compressed(); F_.csr = Compressed(); F_.cscSorted = Compressed();
+}
+
+// The device-prepared problem as the host form the shard cut works on (bit-identical to formulate + scale +
+// finalize: tests test_gpu_setup_*).
+void Solver::downloadForm(DeviceProblem& D, StandardForm& F, hipStream_t s) {
+  F = StandardForm();
+  F.n = D.n; F.m = D.m; F.n0 = D.n0; F.nEqs = D.nEqs; F.nnz = D.nnz;
+  F.scaled = D.scaled; F.offset = D.offset; F.sense = D.sense;
+  F.normCost = D.normCost; F.normRhs = D.normRhs; F.matNormInf = D.matNormInf;
+  F.rowKind = std::move(D.rowKind);
+  F.rowNewIdx = std::move(D.rowNewIdx);
+  F.colScale = std::move(D.hColScale);
+  F.rowScale = std::move(D.hRowScale);
+  auto pull = [&](const DeviceCsrData& M, Compressed& C) {
+    C.beg.resize((size_t)M.nMajor + 1);
+    C.idx.resize((size_t)M.nnz);
+    C.val.resize((size_t)M.nnz);
+    M.beg.download(C.beg.data(), C.beg.size(), s);
+    M.idx.download(C.idx.data(), C.idx.size(), s);
+    M.val.download(C.val.data(), C.val.size(), s);
+  };
+  pull(D.A, F.csr);
+  pull(D.At, F.cscSorted);
+  F.cost.resize((size_t)D.n); F.lower.resize((size_t)D.n); F.upper.resize((size_t)D.n); F.rhs.resize((size_t)D.m);
+  D.cost.download(F.cost.data(), F.cost.size(), s);
+  D.lower.download(F.lower.data(), F.lower.size(), s);
+  D.upper.download(F.upper.data(), F.upper.size(), s);
+  D.rhs.download(F.rhs.data(), F.rhs.size(), s);
+  PDLP_HIP(hipStreamSynchronize(s));
 }
 
 void Solver::uploadProblemFromDevice(DeviceProblem& D) {

@@ -85,6 +85,7 @@ class Solver : public SolverBase {
   void release() noexcept;
   void uploadProblem();
   void uploadProblemFromDevice(DeviceProblem& D);
+  static void downloadForm(DeviceProblem& D, StandardForm& F, hipStream_t s);
   void allocIterates();
   void initStepSizes();
   void initVariables();

@@ -173,3 +173,16 @@ def test_mesh_with_release_acquire_fences_gives_the_same_bits(tmp_path):
     for k in ("col_value", "row_dual", "num_iter", "num_trials", "primal_obj"):
         assert np.array_equal(a[0][k], b[0][k]) and np.array_equal(b[0][k], b[1][k]), k
     assert b[0]["exchange"] == 2.0
+
+
+@pytest.mark.parametrize("case,world", [("solve:e226", 2), ("iterate:synth:120", 4)])
+def test_sharded_ranks_prepared_on_the_device_give_the_same_bits(case, world, tmp_path):
+    """Sharded ranks prepare the whole problem on their device (formulate + scaling + both orientations, automatic
+    from 200k nonzeros; forced here) and only cut their row block on the host: bit-identical to the host set-up."""
+    a = _run_ranks(world, case, tmp_path, extra_env={"PDLP_MI355X_GPU_SETUP": "0"})
+    b = _run_ranks(world, case, tmp_path, extra_env={"PDLP_MI355X_GPU_SETUP": "1"})
+    keys = [k for k in a[0] if k not in ("seconds",)]
+    assert keys
+    for r in range(world):
+        for k in keys:
+            assert np.array_equal(a[r][k], b[r][k]), (r, k)
