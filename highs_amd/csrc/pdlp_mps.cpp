@@ -1,10 +1,12 @@
 // pdlp_mps.cpp — see pdlp_mps.hpp.  Reference behaviour followed: io/HMpsFF.cpp (free-format MPS parser).
 #include "pdlp_mps.hpp"
 
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <zlib.h>
 
 #include <algorithm>
 #include <charconv>
@@ -456,6 +458,67 @@ void addWarning(Model& m, const std::string& s) {
   m.warnings += '\n';
 }
 
+// gzip streams (what zstr does for the reference when it is built with zlib, HMpsFF.cpp:253-261): inflated into
+// one buffer, then parsed like a mapped file.  zlib is taken from the running system with dlopen — no link-time
+// dependency; without it the caller gets kReadCompressed and falls back to its own reader.
+struct Zlib {
+  void* h = nullptr;
+  int (*inflateInit2_)(z_streamp, int, const char*, int) = nullptr;
+  int (*inflate)(z_streamp, int) = nullptr;
+  int (*inflateEnd)(z_streamp) = nullptr;
+  int (*inflateReset)(z_streamp) = nullptr;
+  Zlib() {
+    for (const char* name : {"libz.so.1", "libz.so"}) {
+      h = ::dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (h) break;
+    }
+    if (!h) return;
+    inflateInit2_ = (decltype(inflateInit2_))::dlsym(h, "inflateInit2_");
+    inflate = (decltype(inflate))::dlsym(h, "inflate");
+    inflateEnd = (decltype(inflateEnd))::dlsym(h, "inflateEnd");
+    inflateReset = (decltype(inflateReset))::dlsym(h, "inflateReset");
+    if (!inflateInit2_ || !inflate || !inflateEnd || !inflateReset) { ::dlclose(h); h = nullptr; }
+  }
+  bool ok() const { return h != nullptr; }
+};
+// 0 ok, 1 corrupt stream, 2 zlib not available
+int gunzip(const char* in, size_t inBytes, std::vector<char>& out) {
+  static const Zlib z;
+  if (!z.ok()) return 2;
+  z_stream st;
+  std::memset(&st, 0, sizeof(st));
+  if (z.inflateInit2_(&st, 16 + MAX_WBITS, ZLIB_VERSION, (int)sizeof(z_stream)) != Z_OK) return 1;
+  out.resize(std::max<size_t>(inBytes * 4, 1 << 16));
+  size_t have = 0;
+  st.next_in = (Bytef*)in;
+  size_t left = inBytes;
+  int rc = Z_OK;
+  for (;;) {
+    if (st.avail_in == 0 && left > 0) {
+      const size_t chunk = std::min<size_t>(left, 1u << 30);
+      st.avail_in = (uInt)chunk;
+      left -= chunk;
+    }
+    if (have == out.size()) out.resize(out.size() * 2);
+    const size_t room = std::min<size_t>(out.size() - have, 1u << 30);
+    st.next_out = (Bytef*)out.data() + have;
+    st.avail_out = (uInt)room;
+    rc = z.inflate(&st, Z_NO_FLUSH);
+    have += room - st.avail_out;
+    if (rc == Z_STREAM_END) {
+      if (st.avail_in == 0 && left == 0) break;
+      if (z.inflateReset(&st) != Z_OK) { rc = Z_DATA_ERROR; break; }  // concatenated members
+      continue;
+    }
+    if (rc != Z_OK && !(rc == Z_BUF_ERROR && st.avail_out == 0)) break;
+    if (rc == Z_BUF_ERROR && st.avail_in == 0 && left == 0) break;  // truncated input
+  }
+  z.inflateEnd(&st);
+  if (rc != Z_STREAM_END) return 1;
+  out.resize(have);
+  return 0;
+}
+
 }  // namespace
 
 // ==================================================================================================================
@@ -473,25 +536,33 @@ ReadStatus readMps(const std::string& path, int numThreads, Model& M) {
   ::close(fd);
   if (map == MAP_FAILED) { M.error = "cannot map " + path; return kReadNotFound; }
   ::madvise(map, bytes, MADV_WILLNEED);
-  const char* const F = (const char*)map;
-  const char* const FE = F + bytes;
-  if (bytes >= 2 && (unsigned char)F[0] == 0x1f && (unsigned char)F[1] == 0x8b) {
-    ::munmap(map, bytes);
-    M.error = "gzip-compressed file: not read by this reader";
-    return kReadCompressed;
-  }
   struct Unmap {
     void* p;
     size_t n;
-    ~Unmap() { ::munmap(p, n); }
+    ~Unmap() { if (p) ::munmap(p, n); }
   } unmap{map, bytes};
+  const char* F = (const char*)map;
+  const char* FE = F + bytes;
+  std::vector<char> inflated;
+  if (bytes >= 2 && (unsigned char)F[0] == 0x1f && (unsigned char)F[1] == 0x8b) {
+    const int zrc = gunzip(F, bytes, inflated);
+    if (zrc == 2) { M.error = "gzip stream, and zlib is not available to this reader"; return kReadCompressed; }
+    if (zrc != 0) { M.error = "corrupt gzip stream"; return kReadError; }
+    ::munmap(map, bytes);
+    unmap.p = nullptr;
+    if (inflated.empty()) { M.error = "empty file"; return kReadError; }
+    F = inflated.data();
+    FE = F + inflated.size();
+    M.fileBytes = (int64_t)inflated.size();
+  }
+  const size_t textBytes = (size_t)(FE - F);
 
   // an explicit thread count is taken literally (the tests cut small files into many pieces with it); the
   // automatic one gives every thread at least 1 MB of file
   int T = numThreads > 0 ? numThreads : (int)std::thread::hardware_concurrency();
   if (T < 1) T = 1;
   if (T > 64) T = 64;
-  if (numThreads <= 0) T = (int)std::min<int64_t>(T, std::max<int64_t>(1, (int64_t)bytes >> 20));
+  if (numThreads <= 0) T = (int)std::min<int64_t>(T, std::max<int64_t>(1, (int64_t)textBytes >> 20));
   M.threads = T;
 
   const bool timing = std::getenv("PDLP_MI355X_MPS_TIMING") != nullptr;

@@ -22,7 +22,7 @@ enum ReadStatus : int32_t {
   kReadError = 1,         // malformed file (message in Model::error)
   kReadNotFound = 2,      // cannot open / map the file
   kReadFixedFormat = 3,   // names with spaces: a fixed-column reader is needed (FreeFormatParserReturnCode::kFixedFormat)
-  kReadCompressed = 4,    // gzip stream (the reference reads those through zlib when built with it, HMpsFF.cpp:253-261)
+  kReadCompressed = 4,    // gzip stream and no zlib on this system (the reader inflates gzip files itself when it finds libz)
 };
 
 // HighsVarType (lp_data/HConst.h)

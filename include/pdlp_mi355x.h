@@ -316,7 +316,8 @@ void pdlp_mi355x_free_slab_layout(pdlp_slab_layout_t* out);
  * Return: 0 ok (out filled; release with pdlp_mi355x_free_mps_model), 1 malformed file / unsupported
  * section (pdlp_mi355x_last_error), 2 file cannot be opened, 3 names contain spaces: a fixed-COLUMN reader
  * is needed (FreeFormatParserReturnCode::kFixedFormat — the reference then falls back to io/HMPSIO.cpp),
- * 4 the file is a gzip stream (left to the reference's zlib-backed stream, HMpsFF.cpp:253-261). */
+ * 4 the file is a gzip stream and libz could not be loaded (gzip files are inflated by the reader itself otherwise,
+ * as the reference does through zstr when built with zlib, HMpsFF.cpp:253-261). */
 typedef struct pdlp_mps_model {
   pdlp_problem_t lp;           /* HighsLp fields; lp.q_* = LOWER TRIANGLE of the Hessian (what this library's
                                   QP path and HighsHessian::kTriangular expect), NULL / 0 for an LP */

@@ -4,8 +4,8 @@
 // highs/io/FilereaderMps.cpp in the build and links libpdlp_mi355x.so.  readModelFromFile hands free-format files to
 // the library's multi-threaded reader (pdlp_mi355x_read_mps, include/pdlp_mi355x.h) and fills HighsModel exactly as
 // free_format_parser::HMpsFF::loadProblem does (io/HMpsFF.cpp:82-133); everything that reader does not take on is
-// still the reference's own code: gzip streams -> HMpsFF through zstr, names with spaces / mps_parser_type_free =
-// false -> the fixed-column reader readMps (io/HMPSIO.cpp), writing -> writeModelAsMps.  Highs::readModel ->
+// still the reference's own code: names with spaces / mps_parser_type_free = false -> the fixed-column reader readMps
+// (io/HMPSIO.cpp), gzip streams on a system without libz -> HMpsFF through zstr, writing -> writeModelAsMps.  Highs::readModel ->
 // Filereader::getFilereader -> this TU -> Highs::passModel is otherwise untouched.
 #include "io/FilereaderMps.h"
 
@@ -108,7 +108,8 @@ FilereaderRetcode FilereaderMps::readModelFromFile(const HighsOptions& options, 
                      "Free format reader has detected row/col names with spaces: switching to fixed format parser\n");
         break;
       case 4: {
-        // a gzip stream: the reference's own free-format parser reads it through zlib (HMpsFF.cpp:253-261)
+        // a gzip stream and the library found no libz to inflate it with: the reference's own free-format parser
+        // reads it through zstr if it was built with zlib (HMpsFF.cpp:253-261)
         HMpsFF parser{};
         if (options.time_limit < kHighsInf && options.time_limit > 0) parser.time_limit_ = options.time_limit;
         switch (parser.loadProblem(options.log_options, filename, model)) {

@@ -229,3 +229,26 @@ def test_reference_filereader_unit_tests_pass_on_the_dropin_reader():
     out = subprocess.run([os.path.join(BUILD, "unit_tests_ref"), "[highs_filereader]"], capture_output=True, text=True,
                          timeout=900, env=_dropin_env())
     assert out.returncode == 0 and "All tests passed" in out.stdout, out.stdout[-3000:]
+
+
+def test_gzip_streams_are_inflated_by_the_reader(tmp_path):
+    """gzip files (what the Mittelmann LPs ship as) give the same model as the plain text; concatenated members and
+    a truncated stream are handled (the reference reads gzip through zstr when built with zlib, HMpsFF.cpp:253-261)."""
+    import gzip
+    src = os.path.join(GOLD, "mps_cases", "long_columns_duplicates.mps")
+    text = open(src, "rb").read()
+    plain, _ = solver.read_mps(src, 3)
+    gz = tmp_path / "m.mps.gz"
+    gz.write_bytes(gzip.compress(text))
+    got, info = solver.read_mps(str(gz), 3)
+    _same_model(got, plain)
+    assert info["file_bytes"] == len(text)
+    half = len(text) // 2
+    while text[half - 1:half] != b"\n":
+        half += 1
+    gz.write_bytes(gzip.compress(text[:half]) + gzip.compress(text[half:]))  # two members
+    got, _ = solver.read_mps(str(gz), 2)
+    _same_model(got, plain)
+    gz.write_bytes(gzip.compress(text)[:-40])
+    with pytest.raises(RuntimeError, match="gzip"):
+        solver.read_mps(str(gz))
