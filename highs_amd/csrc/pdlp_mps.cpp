@@ -519,12 +519,105 @@ int gunzip(const char* in, size_t inBytes, std::vector<char>& out) {
   return 0;
 }
 
-}  // namespace
+// One read: the state shared by the phases below.  Errors leave through Fail (caught in run()); the lambdas that run
+// on the worker threads never throw, they flag their records instead.
+class Reader {
+ public:
+  Reader(Model& model, int threads) : M(model), numThreads(threads) {}
+  ReadStatus run(const std::string& path);
 
-// ==================================================================================================================
-ReadStatus readMps(const std::string& path, int numThreads, Model& M) {
-  const auto t0 = std::chrono::steady_clock::now();
-  M = Model();
+ private:
+  struct FlagOp { const char* pos; bool assign; bool value; };
+  struct QEntry { int32_t row, col; double val; };
+
+  ReadStatus open(const std::string& path);
+  void scanSections();
+  void readRows();
+  void readColumns();
+  void mergeColumns();
+  void buildColumnState();
+  void readRhsOrRanges(const Section& S);
+  void readBounds(const Section& S);
+  void readHessian(const Section& S);
+  void finish();
+  void phase(const char* what);
+  int32_t findCol(Sv w, int32_t tableIdx) const;
+  int32_t addCol(Sv w);
+
+  Model& M;
+  const int numThreads;
+  int T = 1;
+  std::chrono::steady_clock::time_point t0, lastT;
+  bool timing = false;
+  // the text: the mapping of the file, or the inflated gzip stream
+  void* map_ = nullptr;
+  size_t mapBytes_ = 0;
+  std::vector<char> inflated_;
+  const char* F = nullptr;
+  const char* FE = nullptr;
+  // HMpsFF::warning_issued_ (what turns Highs::readModel's status into kWarning) is ASSIGNED at the end of the
+  // COLUMNS / RHS / BOUNDS / RANGES sections and only SET elsewhere, so an earlier warning can be forgotten; the
+  // flag is replayed in file order at the end to give the same return status.
+  std::vector<FlagOp> flagOps;
+  std::vector<Section> sections;
+  int nRowsSec = 0, nColsSec = 0;
+  const char *rowsLo = nullptr, *rowsHi = nullptr, *colsLo = nullptr, *colsHi = nullptr;
+  // ROWS
+  std::vector<Sv> rowKeys;          // every name of the ROWS section (cost row and other N rows included)
+  std::vector<int32_t> rowKeyVal;   // row index, kObjRow or kFreeRow
+  std::vector<uint8_t> keyIsFree;
+  std::vector<uint8_t> rowType;     // 'G','E','L' per constraint
+  std::vector<Sv> rowNames;
+  int32_t numRow = 0;
+  NameTable rowTable;
+  bool dupRowName = false;
+  // COLUMNS
+  std::vector<ColPiece> pieces;
+  std::vector<Sv> colKeys;
+  std::vector<double> colCost;
+  std::vector<uint8_t> colIntegral;
+  uint64_t ignoredRow = 0, dupCost = 0, dupNz = 0;
+  Sv firstIgnored;
+  int64_t numColFile = 0, nnz = 0;
+  NameTable colTable;
+  bool dupColName = false;
+  std::vector<uint8_t> vtype, binary;
+  std::unordered_map<std::string, int32_t> addedCols;  // columns first met in BOUNDS / Q sections (getColIdx, :491-506)
+  std::vector<std::string> addedNames;
+  int32_t numCol = 0;
+  // RHS / RANGES / Hessian
+  std::vector<uint8_t> hasRowEntry;
+  bool hasObjEntry = false;
+  std::vector<QEntry> qEntries;
+
+ public:
+  ~Reader() { if (map_) ::munmap(map_, mapBytes_); }
+};
+
+void Reader::phase(const char* what) {
+  if (!timing) return;
+  const auto now = std::chrono::steady_clock::now();
+  std::fprintf(stderr, "[mps] %-28s %8.1f ms\n", what, 1e3 * std::chrono::duration<double>(now - lastT).count());
+  lastT = now;
+}
+
+// tableIdx: result of the parallel lookup (-1 = not among the columns of the COLUMNS section)
+int32_t Reader::findCol(Sv w, int32_t tableIdx) const {
+  if (tableIdx >= 0) return tableIdx;
+  if (addedCols.empty()) return -1;
+  auto it = addedCols.find(w.str());
+  return it == addedCols.end() ? -1 : it->second;
+}
+int32_t Reader::addCol(Sv w) {
+  addedCols.emplace(w.str(), numCol);
+  addedNames.push_back(w.str());
+  M.colLower.push_back(0.0); M.colUpper.push_back(kInf); M.colCost.push_back(0.0);
+  vtype.push_back(kContinuous); binary.push_back(0);
+  M.aStart.push_back((int32_t)nnz);
+  return numCol++;
+}
+
+ReadStatus Reader::open(const std::string& path) {
   const int fd = ::open(path.c_str(), O_RDONLY);
   if (fd < 0) { M.error = "cannot open " + path; return kReadNotFound; }
   struct stat st;
@@ -536,55 +629,60 @@ ReadStatus readMps(const std::string& path, int numThreads, Model& M) {
   ::close(fd);
   if (map == MAP_FAILED) { M.error = "cannot map " + path; return kReadNotFound; }
   ::madvise(map, bytes, MADV_WILLNEED);
-  struct Unmap {
-    void* p;
-    size_t n;
-    ~Unmap() { if (p) ::munmap(p, n); }
-  } unmap{map, bytes};
-  const char* F = (const char*)map;
-  const char* FE = F + bytes;
-  std::vector<char> inflated;
+  map_ = map;
+  mapBytes_ = bytes;
+  F = (const char*)map;
+  FE = F + bytes;
   if (bytes >= 2 && (unsigned char)F[0] == 0x1f && (unsigned char)F[1] == 0x8b) {
-    const int zrc = gunzip(F, bytes, inflated);
+    const int zrc = gunzip(F, bytes, inflated_);
     if (zrc == 2) { M.error = "gzip stream, and zlib is not available to this reader"; return kReadCompressed; }
     if (zrc != 0) { M.error = "corrupt gzip stream"; return kReadError; }
-    ::munmap(map, bytes);
-    unmap.p = nullptr;
-    if (inflated.empty()) { M.error = "empty file"; return kReadError; }
-    F = inflated.data();
-    FE = F + inflated.size();
-    M.fileBytes = (int64_t)inflated.size();
+    ::munmap(map_, mapBytes_);
+    map_ = nullptr;
+    if (inflated_.empty()) { M.error = "empty file"; return kReadError; }
+    F = inflated_.data();
+    FE = F + inflated_.size();
+    M.fileBytes = (int64_t)inflated_.size();
   }
-  const size_t textBytes = (size_t)(FE - F);
-
   // an explicit thread count is taken literally (the tests cut small files into many pieces with it); the
-  // automatic one gives every thread at least 1 MB of file
-  int T = numThreads > 0 ? numThreads : (int)std::thread::hardware_concurrency();
+  // automatic one gives every thread at least 1 MB of text
+  T = numThreads > 0 ? numThreads : (int)std::thread::hardware_concurrency();
   if (T < 1) T = 1;
   if (T > 64) T = 64;
-  if (numThreads <= 0) T = (int)std::min<int64_t>(T, std::max<int64_t>(1, (int64_t)textBytes >> 20));
+  if (numThreads <= 0) T = (int)std::min<int64_t>(T, std::max<int64_t>(1, (int64_t)(FE - F) >> 20));
   M.threads = T;
+  return kReadOk;
+}
 
-  const bool timing = std::getenv("PDLP_MI355X_MPS_TIMING") != nullptr;
-  auto lastT = t0;
-  auto phase = [&](const char* what) {
-    if (!timing) return;
-    const auto now = std::chrono::steady_clock::now();
-    std::fprintf(stderr, "[mps] %-28s %8.1f ms\n", what, 1e3 * std::chrono::duration<double>(now - lastT).count());
-    lastT = now;
-  };
-  auto fail = [&](ReadStatus s, const std::string& msg) {
-    M.error = msg;
-    M.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    return s;
-  };
+ReadStatus Reader::run(const std::string& path) {
+  t0 = lastT = std::chrono::steady_clock::now();
+  timing = std::getenv("PDLP_MI355X_MPS_TIMING") != nullptr;
+  M = Model();
+  ReadStatus status = open(path);
+  if (status == kReadOk) {
+    try {
+      scanSections();
+      readRows();
+      readColumns();
+      mergeColumns();
+      buildColumnState();
+      for (const Section& S : sections) {  // the remaining sections, in file order
+        if (S.key == kRhs || S.key == kRanges) readRhsOrRanges(S);
+        else if (S.key == kBounds) readBounds(S);
+        else if (S.key == kQuadobj || S.key == kQmatrix || S.key == kQsection || S.key == kQcmatrix) readHessian(S);
+      }
+      phase("RHS/RANGES/BOUNDS/Q");
+      finish();
+    } catch (const Fail& f) {
+      M.error = f.msg;
+      status = f.status;
+    }
+  }
+  M.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return status;
+}
 
-  // HMpsFF::warning_issued_ (what turns Highs::readModel's status into kWarning) is ASSIGNED at the end of the
-  // COLUMNS / RHS / BOUNDS / RANGES sections and only SET elsewhere, so an earlier warning can be forgotten; the
-  // flag is replayed in file order at the end to give the same return status.
-  struct FlagOp { const char* pos; bool assign; bool value; };
-  std::vector<FlagOp> flagOps;
-
+void Reader::scanSections() {
   // ---- pass 1: the section headers (every thread scans its piece; a header is a context-free property of a line)
   struct Header { const char* b; const char* nl; const char* after; const char* e; Key key; };
   std::vector<std::vector<Header>> hdrPart((size_t)T);
@@ -616,7 +714,6 @@ ReadStatus readMps(const std::string& path, int numThreads, Model& M) {
   for (auto& v : hdrPart) hdr.insert(hdr.end(), v.begin(), v.end());
 
   // ---- the section sequence (HMpsFF::parse, :246-354): lines outside a section are ignored, ENDATA is required
-  std::vector<Section> sections;
   bool ended = false;
   bool inObjsense = false;
   for (size_t i = 0; i < hdr.size() && !ended; ++i) {
@@ -649,12 +746,12 @@ ReadStatus readMps(const std::string& path, int numThreads, Model& M) {
       case kMax: case kMin: break;  // outside OBJSENSE: no effect (parse() falls through to parseDefault)
       case kDelayedrows: case kModelcuts: case kUsercuts: case kIndicators: case kGencons: case kPwlobj: case kPwlnam:
       case kPwlcon:
-        return fail(kReadError, "MPS file reader cannot parse this section (DELAYEDROWS / MODELCUTS / USERCUTS / "
-                                "INDICATORS / GENCONS / PWL*)");
+        throw Fail{kReadError, "MPS file reader cannot parse this section (DELAYEDROWS / MODELCUTS / USERCUTS / "
+                                "INDICATORS / GENCONS / PWL*)"};
       default: sections.push_back({h.key, dataLo, dataHi, h.after, h.e}); break;
     }
   }
-  if (!ended) return fail(kReadError, "no ENDATA: the MPS file is truncated");
+  if (!ended) throw Fail{kReadError, "no ENDATA: the MPS file is truncated"};
 
   auto sectionRange = [&](Key k, const char*& lo, const char*& hi, int& count) {
     count = 0;
@@ -663,22 +760,23 @@ ReadStatus readMps(const std::string& path, int numThreads, Model& M) {
         if (count++ == 0) { lo = s.lo; hi = s.hi; }
       }
   };
-  int nRowsSec = 0, nColsSec = 0;
-  const char *rowsLo = F, *rowsHi = F, *colsLo = F, *colsHi = F;
   sectionRange(kRows, rowsLo, rowsHi, nRowsSec);
   sectionRange(kCols, colsLo, colsHi, nColsSec);
-  if (nRowsSec > 1 || nColsSec > 1) return fail(kReadError, "more than one ROWS or COLUMNS section");
+  if (nRowsSec > 1 || nColsSec > 1) throw Fail{kReadError, "more than one ROWS or COLUMNS section"};
   for (const Section& s : sections)
     if (s.key == kCsection || s.key == kSets || s.key == kSos) {
       // the reference parses these and then refuses the model when they hold entries (loadProblem, :37-46)
       for (const char* p = s.lo; p < s.hi;) {
         const char* nl = lineEnd(p, FE);
-        if (!trimLine(p, nl).skip) return fail(kReadError, "SOS and cones are not supported");
+        if (!trimLine(p, nl).skip) throw Fail{kReadError, "SOS and cones are not supported"};
         p = nl + 1;
       }
     }
 
   phase("section sequence");
+}
+
+void Reader::readRows() {
   // ---- ROWS (parseRows, :595-713) ------------------------------------------------------------------------------
   struct RowRec { char type; uint8_t bad; Sv name; Sv rest; };
   const auto rowParts = parseSectionLines<RowRec>(rowsLo, rowsHi, FE, T, [&](const Line& L) {
@@ -688,27 +786,21 @@ ReadStatus readMps(const std::string& path, int numThreads, Model& M) {
     if (!restIsBlank(q, L.e)) { r.bad = 1; r.rest = Sv{L.b + 1, (uint32_t)(L.e - (L.b + 1))}; }
     return r;
   });
-  std::vector<Sv> rowKeys;
-  std::vector<int32_t> rowKeyVal;
-  std::vector<uint8_t> rowType;  // 'G','E','L' per constraint
-  std::vector<Sv> rowNames;
   size_t nRowRecs = 0;
   for (const auto& v : rowParts) nRowRecs += v.size();
   rowKeys.reserve(nRowRecs + 1);
   rowKeyVal.reserve(nRowRecs + 1);
   bool hasObj = false;
   Sv objName;
-  int32_t numRow = 0;
-  std::vector<uint8_t> keyIsFree;
-  for (const auto& rowRecs : rowParts)
+  for (const auto& rowRecs : rowParts)  // pieces in file order
   for (const RowRec& r : rowRecs) {
     if (r.type != 'G' && r.type != 'E' && r.type != 'L' && r.type != 'N')
-      return fail(kReadError, "Entry \"" + std::string(1, r.type) + r.name.str() + "\" in ROWS section of MPS file is unidentified");
+      throw Fail{kReadError, "Entry \"" + std::string(1, r.type) + r.name.str() + "\" in ROWS section of MPS file is unidentified"};
     if (r.bad) {  // text after the row name: fixed format (names with spaces), :655-662
       Sv t = r.rest;
       while (t.n && isWs(*t.p)) { ++t.p; --t.n; }
-      return t.n > 8 ? fail(kReadError, "ROWS section: name with spaces longer than 8 characters")
-                     : fail(kReadFixedFormat, "ROWS section: names with spaces, fixed format");
+      if (t.n > 8) throw Fail{kReadError, "ROWS section: name with spaces longer than 8 characters"};
+      throw Fail{kReadFixedFormat, "ROWS section: names with spaces, fixed format"};
     }
     if (r.type == 'N') {
       if (!hasObj) {
@@ -725,7 +817,7 @@ ReadStatus readMps(const std::string& path, int numThreads, Model& M) {
     rowType.push_back((uint8_t)r.type);
     rowNames.push_back(r.name);
   }
-  if ((int64_t)rowKeys.size() > (int64_t)0x7fffffff) return fail(kReadError, "too many rows");
+  if ((int64_t)rowKeys.size() > (int64_t)0x7fffffff) throw Fail{kReadError, "too many rows"};
   Sv artificialObj{"artificial_empty_objective", 26};
   if (nRowsSec && !hasObj) {
     addWarning(M, "No objective row found");
@@ -733,10 +825,9 @@ ReadStatus readMps(const std::string& path, int numThreads, Model& M) {
     rowKeys.push_back(artificialObj); rowKeyVal.push_back(kObjRow); keyIsFree.push_back(0);
   }
   M.objectiveName = hasObj ? objName.str() : "Objective";
-  NameTable rowTable;
   std::vector<uint8_t> rowDup;
   rowTable.build(rowKeys, rowKeyVal, T, &rowDup);
-  bool dupRowName = false;
+  dupRowName = false;
   for (size_t i = 0; i < rowDup.size() && !dupRowName; ++i) dupRowName = rowDup[i] && !keyIsFree[i];
   M.numRow = numRow;
   M.rowLower.resize((size_t)numRow);
@@ -748,8 +839,11 @@ ReadStatus readMps(const std::string& path, int numThreads, Model& M) {
   }
 
   phase("ROWS + row table");
+}
+
+void Reader::readColumns() {
   // ---- COLUMNS -------------------------------------------------------------------------------------------------
-  std::vector<ColPiece> pieces((size_t)T);
+  pieces = std::vector<ColPiece>((size_t)T);
   if (colsLo < colsHi)
     parallelFor(T, [&](int t) {
       const char *b, *e;
@@ -757,19 +851,17 @@ ReadStatus readMps(const std::string& path, int numThreads, Model& M) {
       parseColumnsPiece(b, e, FE, rowTable, numRow, pieces[(size_t)t]);
     });
   for (ColPiece& P : pieces) {
-    if (P.failed) return fail(P.fail.status, P.fail.msg);
+    if (P.failed) throw P.fail;
     if (P.runBeg.empty()) P.runBeg.push_back(0);
   }
   phase("COLUMNS parse");
+}
+
+void Reader::mergeColumns() {
   // merge: a piece's first run continues the column of the previous piece when the names agree; MARKER lines
   // toggle the integrality of the columns CREATED after them.  Sequential over the T pieces (boundary columns,
   // marker order), parallel over the runs inside a piece.
-  std::vector<Sv> colKeys;
   std::vector<int64_t> colNnz;
-  std::vector<double> colCost;
-  std::vector<uint8_t> colIntegral;
-  uint64_t ignoredRow = 0, dupCost = 0, dupNz = 0;
-  Sv firstIgnored;
   std::vector<int64_t> colBase((size_t)T + 1, 0);   // columns created before piece t
   std::vector<uint8_t> integralAtStart((size_t)T, 0);
   {
@@ -783,7 +875,7 @@ ReadStatus readMps(const std::string& path, int numThreads, Model& M) {
       integralAtStart[(size_t)t] = integral;
       for (const ColPiece::Marker& mk : P.markers) {  // INTORG and INTEND must alternate (:793-805)
         if ((integral && mk.kind != 1) || (!integral && mk.kind != 0))
-          return fail(kReadError, "Integrality marker error in COLUMNS section of MPS file");
+          throw Fail{kReadError, "Integrality marker error in COLUMNS section of MPS file"};
         integral = !integral;
       }
       const size_t nRun = P.runName.size();
@@ -793,8 +885,8 @@ ReadStatus readMps(const std::string& path, int numThreads, Model& M) {
       if (nRun) { last = P.runName[nRun - 1]; haveLast = true; }
     }
   }
-  const int64_t numColFile = colBase[(size_t)T];
-  if (numColFile > 0x7ffffff0) return fail(kReadError, "too many columns");
+  numColFile = colBase[(size_t)T];
+  if (numColFile > 0x7ffffff0) throw Fail{kReadError, "too many columns"};
   colKeys.resize((size_t)numColFile);
   colNnz.resize((size_t)numColFile);
   colCost.resize((size_t)numColFile);
@@ -854,13 +946,13 @@ ReadStatus readMps(const std::string& path, int numThreads, Model& M) {
     }
   }
   phase("COLUMNS merge");
-  int64_t nnz = 0;
+  nnz = 0;
   M.aStart.resize((size_t)numColFile + 1);
   for (int64_t j = 0; j < numColFile; ++j) {
     M.aStart[(size_t)j] = (int32_t)std::min<int64_t>(nnz, 0x7fffffff);
     nnz += colNnz[(size_t)j];
   }
-  if (nnz > 0x7fffffff) return fail(kReadError, "more than 2^31 - 1 nonzeros");
+  if (nnz > 0x7fffffff) throw Fail{kReadError, "more than 2^31 - 1 nonzeros"};
   M.aStart[(size_t)numColFile] = (int32_t)nnz;
   M.aIndex.resize((size_t)nnz);
   M.aValue.resize((size_t)nnz);
@@ -894,6 +986,9 @@ ReadStatus readMps(const std::string& path, int numThreads, Model& M) {
     }
   });
   phase("COLUMNS copy");
+}
+
+void Reader::buildColumnState() {
   if (nColsSec) flagOps.push_back({colsLo, true, ignoredRow || dupCost || dupNz});
   if (ignoredRow || dupCost || dupNz)
     addWarning(M, "COLUMNS section: ignored " + std::to_string(ignoredRow) + " undefined rows " + std::to_string(dupCost) +
@@ -903,268 +998,247 @@ ReadStatus readMps(const std::string& path, int numThreads, Model& M) {
   // column name table; later sections may add columns (getColIdx(name, add_if_new), :491-506)
   std::vector<int32_t> colKeyVal((size_t)numColFile);
   for (int64_t j = 0; j < numColFile; ++j) colKeyVal[(size_t)j] = (int32_t)j;
-  NameTable colTable;
   std::vector<uint8_t> colDup;
   colTable.build(colKeys, colKeyVal, T, &colDup);
-  bool dupColName = false;
+  dupColName = false;
   for (uint8_t d : colDup) if (d) { dupColName = true; break; }
-  std::vector<double>& lower = M.colLower;
-  std::vector<double>& upper = M.colUpper;
-  lower.assign((size_t)numColFile, 0.0);
-  upper.assign((size_t)numColFile, kInf);
+  M.colLower.assign((size_t)numColFile, 0.0);
+  M.colUpper.assign((size_t)numColFile, kInf);
   M.colCost = std::move(colCost);
-  std::vector<uint8_t> vtype((size_t)numColFile);
-  std::vector<uint8_t> binary((size_t)numColFile);  // integer columns of the COLUMNS section are binary until a bound says otherwise (:881)
+  vtype.assign((size_t)numColFile, kContinuous);
+  binary.assign((size_t)numColFile, 0);  // integer columns of the COLUMNS section are binary until a bound says otherwise (:881)
   for (int64_t j = 0; j < numColFile; ++j) { vtype[(size_t)j] = colIntegral[(size_t)j] ? kInteger : kContinuous; binary[(size_t)j] = colIntegral[(size_t)j]; }
-  std::unordered_map<std::string, int32_t> addedCols;
-  std::vector<std::string> addedNames;
-  int32_t numCol = (int32_t)numColFile;
-  auto findCol = [&](Sv w, int32_t tableIdx) -> int32_t {  // tableIdx: result of the parallel lookup (-1 = not in the file's columns)
-    if (tableIdx >= 0) return tableIdx;
-    if (addedCols.empty()) return -1;
-    auto it = addedCols.find(w.str());
-    return it == addedCols.end() ? -1 : it->second;
-  };
-  auto addCol = [&](Sv w) -> int32_t {
-    addedCols.emplace(w.str(), numCol);
-    addedNames.push_back(w.str());
-    lower.push_back(0.0); upper.push_back(kInf); M.colCost.push_back(0.0);
-    vtype.push_back(kContinuous); binary.push_back(0);
-    M.aStart.push_back((int32_t)nnz);
-    return numCol++;
-  };
-
+  numCol = (int32_t)numColFile;
   phase("column table");
-  // ---- the remaining sections, in file order --------------------------------------------------------------------
-  std::vector<uint8_t> hasRowEntry;
-  bool hasObjEntry = false;
-  struct QEntry { int32_t row, col; double val; };
-  std::vector<QEntry> qEntries;
-  for (const Section& S : sections) {
-    if (S.key == kRhs || S.key == kRanges) {
-      const bool isRhs = S.key == kRhs;
-      const std::string& mpsName = M.modelName;
-      const auto parts = parseSectionLines<PairRec>(S.lo, S.hi, FE, T, [&](const Line& L) {
-        PairRec r;
-        r.idx[0] = r.idx[1] = -4;
-        r.val[0] = r.val[1] = 0.0;
-        r.fail = 0;
-        r.line = L.b;
-        r.len = (uint32_t)(L.e - L.b);
-        const char* q = L.b;
-        Sv w0 = nextWord(q, L.e);
-        int32_t v;
-        Sv marker;
-        // RHS only: the set name may be missing (SIF), recognised by the first word being a row name (:1120-1125)
-        if (isRhs && rowTable.find(w0, v)) marker = w0;
-        else marker = nextWord(q, L.e);
-        Sv word = nextWord(q, L.e);
-        if (word.empty()) { r.fail = 1; return r; }
-        bool found = rowTable.find(marker, v);
-        if (!found && isRhs && !mpsName.empty() && marker.n == mpsName.size() && std::memcmp(marker.p, mpsName.data(), marker.n) == 0) {
-          marker = word;  // SIF: the model name in front of the entry (:1145-1162)
-          word = nextWord(q, L.e);
-          if (word.empty()) { r.fail = 1; return r; }
-          found = rowTable.find(marker, v);
+}
+
+void Reader::readRhsOrRanges(const Section& S) {
+  const bool isRhs = S.key == kRhs;
+  const std::string& mpsName = M.modelName;
+  const auto parts = parseSectionLines<PairRec>(S.lo, S.hi, FE, T, [&](const Line& L) {
+    PairRec r;
+    r.idx[0] = r.idx[1] = -4;
+    r.val[0] = r.val[1] = 0.0;
+    r.fail = 0;
+    r.line = L.b;
+    r.len = (uint32_t)(L.e - L.b);
+    const char* q = L.b;
+    Sv w0 = nextWord(q, L.e);
+    int32_t v;
+    Sv marker;
+    // RHS only: the set name may be missing (SIF), recognised by the first word being a row name (:1120-1125)
+    if (isRhs && rowTable.find(w0, v)) marker = w0;
+    else marker = nextWord(q, L.e);
+    Sv word = nextWord(q, L.e);
+    if (word.empty()) { r.fail = 1; return r; }
+    bool found = rowTable.find(marker, v);
+    if (!found && isRhs && !mpsName.empty() && marker.n == mpsName.size() && std::memcmp(marker.p, mpsName.data(), marker.n) == 0) {
+      marker = word;  // SIF: the model name in front of the entry (:1145-1162)
+      word = nextWord(q, L.e);
+      if (word.empty()) { r.fail = 1; return r; }
+      found = rowTable.find(marker, v);
+    }
+    r.idx[0] = found ? v : -3;
+    r.val[0] = parseValue(word);
+    const Sv m2 = nextWord(q, L.e);
+    if (!m2.empty()) {
+      const Sv w2 = nextWord(q, L.e);
+      if (!isRhs && w2.empty()) { r.fail = 1; return r; }  // RANGES checks the second value (:1669-1675)
+      r.idx[1] = rowTable.find(m2, v) ? v : -3;
+      r.val[1] = parseValue(w2);
+    }
+    return r;
+  });
+  hasRowEntry.assign((size_t)std::max(numRow, 1), 0);
+  if (isRhs) hasObjEntry = false;
+  uint64_t ignored = 0, dup = 0;
+  for (const auto& recs : parts)  // pieces in file order
+  for (const PairRec& r : recs) {
+    if (r.fail) throw Fail{kReadError, std::string(isRhs ? "No bound given in RHS line \"" : "No range given in RANGES line \"") + std::string(r.line, r.len) + "\""};
+    for (int k = 0; k < 2; ++k) {
+      const int32_t idx = r.idx[k];
+      if (idx == -4) continue;
+      if (idx == -3) { ++ignored; continue; }
+      const double val = r.val[k];
+      if (isRhs) {
+        if (idx >= 0) {
+          if (hasRowEntry[(size_t)idx]) { ++dup; continue; }
+          const uint8_t ty = rowType[(size_t)idx];
+          if (ty == 'E' || ty == 'L') M.rowUpper[(size_t)idx] = val;
+          if (ty == 'E' || ty == 'G') M.rowLower[(size_t)idx] = val;
+          hasRowEntry[(size_t)idx] = 1;
+        } else {  // the cost row: objective offset (:1078-1083); other N rows take the same branch in the reference
+          if (hasObjEntry) { ++dup; continue; }
+          M.offset = -val;
+          hasObjEntry = true;
         }
-        r.idx[0] = found ? v : -3;
-        r.val[0] = parseValue(word);
-        const Sv m2 = nextWord(q, L.e);
-        if (!m2.empty()) {
-          const Sv w2 = nextWord(q, L.e);
-          if (!isRhs && w2.empty()) { r.fail = 1; return r; }  // RANGES checks the second value (:1669-1675)
-          r.idx[1] = rowTable.find(m2, v) ? v : -3;
-          r.val[1] = parseValue(w2);
-        }
-        return r;
-      });
-      hasRowEntry.assign((size_t)std::max(numRow, 1), 0);
-      if (isRhs) hasObjEntry = false;
-      uint64_t ignored = 0, dup = 0;
-      for (const auto& recs : parts)
-      for (const PairRec& r : recs) {
-        if (r.fail) return fail(kReadError, std::string(isRhs ? "No bound given in RHS line \"" : "No range given in RANGES line \"") + std::string(r.line, r.len) + "\"");
-        for (int k = 0; k < 2; ++k) {
-          const int32_t idx = r.idx[k];
-          if (idx == -4) continue;
-          if (idx == -3) { ++ignored; continue; }
-          const double val = r.val[k];
-          if (isRhs) {
-            if (idx >= 0) {
-              if (hasRowEntry[(size_t)idx]) { ++dup; continue; }
-              const uint8_t ty = rowType[(size_t)idx];
-              if (ty == 'E' || ty == 'L') M.rowUpper[(size_t)idx] = val;
-              if (ty == 'E' || ty == 'G') M.rowLower[(size_t)idx] = val;
-              hasRowEntry[(size_t)idx] = 1;
-            } else {  // the cost row: objective offset (:1078-1083); other N rows take the same branch in the reference
-              if (hasObjEntry) { ++dup; continue; }
-              M.offset = -val;
-              hasObjEntry = true;
-            }
-          } else {
-            if (idx < 0) { ++ignored; continue; }
-            if (hasRowEntry[(size_t)idx]) { ++dup; continue; }
-            const uint8_t ty = rowType[(size_t)idx];
-            if ((ty == 'E' && val < 0) || ty == 'L') M.rowLower[(size_t)idx] = M.rowUpper[(size_t)idx] - std::fabs(val);
-            else if ((ty == 'E' && val > 0) || ty == 'G') M.rowUpper[(size_t)idx] = M.rowLower[(size_t)idx] + std::fabs(val);
-            hasRowEntry[(size_t)idx] = 1;
-          }
-        }
-      }
-      flagOps.push_back({S.lo, true, ignored || dup});
-      if (ignored || dup)
-        addWarning(M, std::string(isRhs ? "RHS" : "RANGES") + " section: ignored " + std::to_string(ignored) +
-                          " undefined rows and " + std::to_string(dup) + " duplicate values");
-    } else if (S.key == kBounds) {
-      const auto parts = parseSectionLines<BoundRec>(S.lo, S.hi, FE, T, [&](const Line& L) {
-        BoundRec r;
-        r.line = L.b;
-        r.len = (uint32_t)(L.e - L.b);
-        r.col = -1;
-        r.value = 0.0;
-        r.hasValue = 0;
-        r.firstWordIsColumn = 0;
-        const char* q = L.b;
-        const Sv ty = nextWord(q, L.e);
-        r.type = 255;
-        if (ty.n == 2)
-          for (int k = 0; k < 11; ++k)
-            if (ty.p[0] == kBoundTypes[k].name[0] && ty.p[1] == kBoundTypes[k].name[1]) r.type = (uint8_t)k;
-        if (r.type == 255) return r;
-        const Sv w1 = nextWord(q, L.e);
-        const Sv w2 = nextWord(q, L.e);
-        int32_t v;
-        // the bound-set name may be missing (SIF): then the first word is a column (:1405-1415)
-        if (!w1.empty() && colTable.find(w1, v)) {
-          r.col = v;
-          r.firstWordIsColumn = 1;
-          r.hasValue = !w2.empty();
-          if (!kBoundTypes[r.type].dflt) r.value = parseValue(w2);
-        } else if (!w2.empty() && colTable.find(w2, v)) {
-          r.col = v;  // provisional: holds unless an EARLIER bounds line created a column called w1 (checked below)
-          const Sv w3 = nextWord(q, L.e);
-          r.hasValue = !w3.empty();
-          if (!kBoundTypes[r.type].dflt) r.value = parseValue(w3);
-        }
-        return r;
-      });
-      std::vector<uint8_t> hasLower((size_t)numCol, 0), hasUpper((size_t)numCol, 0);
-      uint64_t dup = 0, fractional = 0;
-      for (const auto& recs : parts)
-      for (const BoundRec& r : recs) {
-        if (r.type == 255) {
-          const char* q = r.line;
-          return fail(kReadError, "Entry in BOUNDS section of MPS file is of type \"" + nextWord(q, r.line + r.len).str() + "\"");
-        }
-        const BoundType& bt = kBoundTypes[r.type];
-        int32_t col = r.col;
-        double value = r.value;
-        bool hasValue = r.hasValue != 0;
-        Sv marker;
-        if (col < 0 || (!r.firstWordIsColumn && !addedCols.empty())) {
-          // rare: a column this section introduces, or the names of such columns have to be consulted first
-          const char* q = r.line;
-          const char* e = r.line + r.len;
-          nextWord(q, e);
-          const Sv w1 = nextWord(q, e);
-          const Sv w2 = nextWord(q, e);
-          const Sv w3 = nextWord(q, e);
-          int32_t v;
-          col = findCol(w1, colTable.find(w1, v) ? v : -1);
-          marker = w1;
-          Sv valueWord = w2;
-          if (col < 0) {
-            marker = w2;
-            valueWord = w3;
-            col = findCol(w2, !w2.empty() && colTable.find(w2, v) ? v : -1);
-            if (col < 0) {
-              col = addCol(marker);
-              hasLower.push_back(0);
-              hasUpper.push_back(0);
-            }
-          }
-          hasValue = !valueWord.empty();
-          value = parseValue(valueWord);
-        }
-        if ((bt.lb && hasLower[(size_t)col]) || (bt.ub && hasUpper[(size_t)col])) { ++dup; continue; }
-        if (bt.dflt) {
-          if (bt.integral) {  // BV
-            vtype[(size_t)col] = kInteger;
-            binary[(size_t)col] = 1;
-            upper[(size_t)col] = 1.0;
-          } else {
-            binary[(size_t)col] = 0;
-            if (bt.lb) lower[(size_t)col] = -kInf;
-            if (bt.ub) upper[(size_t)col] = kInf;
-          }
-          if (bt.lb) hasLower[(size_t)col] = 1;
-          if (bt.ub) hasUpper[(size_t)col] = 1;
-          continue;
-        }
-        if (!hasValue) return fail(kReadError, std::string("No bound given in BOUNDS line \"") + std::string(r.line, r.len) + "\"");
-        if (bt.integral) {
-          if (value - (double)(int32_t)value != 0.0) ++fractional;
-          vtype[(size_t)col] = bt.semi ? kSemiInteger : kInteger;
-        } else if (bt.semi) {
-          vtype[(size_t)col] = kSemiContinuous;
-        }
-        if (bt.lb) { lower[(size_t)col] = value; hasLower[(size_t)col] = 1; }
-        if (bt.ub) { upper[(size_t)col] = value; hasUpper[(size_t)col] = 1; }
-        binary[(size_t)col] = 0;
-      }
-      flagOps.push_back({S.lo, true, dup || fractional});
-      if (dup || fractional)
-        addWarning(M, "BOUNDS section: ignored " + std::to_string(dup) + " duplicate values and " + std::to_string(fractional) +
-                          " fractional integer bounds");
-    } else if (S.key == kQuadobj || S.key == kQmatrix || S.key == kQsection || S.key == kQcmatrix) {
-      if (S.key == kQsection || S.key == kQcmatrix) {
-        // parseQuadRows (:1745-1801): the section names a row; the cost row's section is the objective Hessian, an
-        // undefined or free row's section is skipped, a constraint's one makes the model a QCP (refused, :32-36)
-        const char* q = S.argB;
-        const Sv rn = nextWord(q, S.argE);
-        if (rn.empty()) return fail(kReadError, "No row name given in argument of QSECTION / QCMATRIX");
-        int32_t ri;
-        if (!rowTable.find(rn, ri)) {
-          addWarning(M, "Row name \"" + rn.str() + "\" in QSECTION / QCMATRIX section is not defined: ignored");
-          flagOps.push_back({S.lo, false, true});
-          continue;
-        }
-        if (ri == kFreeRow) continue;
-        if (ri >= 0) return fail(kReadError, "Quadratic rows not supported by HiGHS");
-      }
-      // parseQuadMatrix (:1803-1889): QUADOBJ / QSECTION list one triangle, every off-diagonal entry also defines its mirror
-      const bool triangular = S.key == kQuadobj || S.key == kQsection;
-      for (const char* p = S.lo; p < S.hi;) {
-        const char* nl = lineEnd(p, FE);
-        const Line L = trimLine(p, nl);
-        p = nl + 1;
-        if (L.skip) continue;
-        const char* q = L.b;
-        const Sv cn = nextWord(q, L.e);
-        int32_t v;
-        int32_t col = findCol(cn, colTable.find(cn, v) ? v : -1);
-        if (col < 0) col = addCol(cn);
-        for (int k = 0; k < 2; ++k) {
-          const Sv rn = nextWord(q, L.e);
-          if (rn.empty()) break;
-          const Sv cv = nextWord(q, L.e);
-          if (cv.empty()) return fail(kReadError, "Hessian section has no coefficient for entry \"" + rn.str() + "\" in column \"" + cn.str() + "\"");
-          int32_t row = findCol(rn, colTable.find(rn, v) ? v : -1);
-          if (row < 0) row = addCol(rn);
-          const double c = parseValue(cv);
-          if (c != 0.0 || c != c) {
-            qEntries.push_back({row, col, c});
-            if (triangular && row != col) qEntries.push_back({col, row, c});
-          }
-        }
+      } else {
+        if (idx < 0) { ++ignored; continue; }
+        if (hasRowEntry[(size_t)idx]) { ++dup; continue; }
+        const uint8_t ty = rowType[(size_t)idx];
+        if ((ty == 'E' && val < 0) || ty == 'L') M.rowLower[(size_t)idx] = M.rowUpper[(size_t)idx] - std::fabs(val);
+        else if ((ty == 'E' && val > 0) || ty == 'G') M.rowUpper[(size_t)idx] = M.rowLower[(size_t)idx] + std::fabs(val);
+        hasRowEntry[(size_t)idx] = 1;
       }
     }
   }
+  flagOps.push_back({S.lo, true, ignored || dup});
+  if (ignored || dup)
+    addWarning(M, std::string(isRhs ? "RHS" : "RANGES") + " section: ignored " + std::to_string(ignored) +
+                      " undefined rows and " + std::to_string(dup) + " duplicate values");
+}
 
-  phase("RHS/RANGES/BOUNDS/Q");
+void Reader::readBounds(const Section& S) {
+  const auto parts = parseSectionLines<BoundRec>(S.lo, S.hi, FE, T, [&](const Line& L) {
+    BoundRec r;
+    r.line = L.b;
+    r.len = (uint32_t)(L.e - L.b);
+    r.col = -1;
+    r.value = 0.0;
+    r.hasValue = 0;
+    r.firstWordIsColumn = 0;
+    const char* q = L.b;
+    const Sv ty = nextWord(q, L.e);
+    r.type = 255;
+    if (ty.n == 2)
+      for (int k = 0; k < 11; ++k)
+        if (ty.p[0] == kBoundTypes[k].name[0] && ty.p[1] == kBoundTypes[k].name[1]) r.type = (uint8_t)k;
+    if (r.type == 255) return r;
+    const Sv w1 = nextWord(q, L.e);
+    const Sv w2 = nextWord(q, L.e);
+    int32_t v;
+    // the bound-set name may be missing (SIF): then the first word is a column (:1405-1415)
+    if (!w1.empty() && colTable.find(w1, v)) {
+      r.col = v;
+      r.firstWordIsColumn = 1;
+      r.hasValue = !w2.empty();
+      if (!kBoundTypes[r.type].dflt) r.value = parseValue(w2);
+    } else if (!w2.empty() && colTable.find(w2, v)) {
+      r.col = v;  // provisional: holds unless an EARLIER bounds line created a column called w1 (checked below)
+      const Sv w3 = nextWord(q, L.e);
+      r.hasValue = !w3.empty();
+      if (!kBoundTypes[r.type].dflt) r.value = parseValue(w3);
+    }
+    return r;
+  });
+  std::vector<uint8_t> hasLower((size_t)numCol, 0), hasUpper((size_t)numCol, 0);
+  uint64_t dup = 0, fractional = 0;
+  for (const auto& recs : parts)  // pieces in file order
+  for (const BoundRec& r : recs) {
+    if (r.type == 255) {
+      const char* q = r.line;
+      throw Fail{kReadError, "Entry in BOUNDS section of MPS file is of type \"" + nextWord(q, r.line + r.len).str() + "\""};
+    }
+    const BoundType& bt = kBoundTypes[r.type];
+    int32_t col = r.col;
+    double value = r.value;
+    bool hasValue = r.hasValue != 0;
+    Sv marker;
+    if (col < 0 || (!r.firstWordIsColumn && !addedCols.empty())) {
+      // rare: a column this section introduces, or the names of such columns have to be consulted first
+      const char* q = r.line;
+      const char* e = r.line + r.len;
+      nextWord(q, e);
+      const Sv w1 = nextWord(q, e);
+      const Sv w2 = nextWord(q, e);
+      const Sv w3 = nextWord(q, e);
+      int32_t v;
+      col = findCol(w1, colTable.find(w1, v) ? v : -1);
+      marker = w1;
+      Sv valueWord = w2;
+      if (col < 0) {
+        marker = w2;
+        valueWord = w3;
+        col = findCol(w2, !w2.empty() && colTable.find(w2, v) ? v : -1);
+        if (col < 0) {
+          col = addCol(marker);
+          hasLower.push_back(0);
+          hasUpper.push_back(0);
+        }
+      }
+      hasValue = !valueWord.empty();
+      value = parseValue(valueWord);
+    }
+    if ((bt.lb && hasLower[(size_t)col]) || (bt.ub && hasUpper[(size_t)col])) { ++dup; continue; }
+    if (bt.dflt) {
+      if (bt.integral) {  // BV
+        vtype[(size_t)col] = kInteger;
+        binary[(size_t)col] = 1;
+        M.colUpper[(size_t)col] = 1.0;
+      } else {
+        binary[(size_t)col] = 0;
+        if (bt.lb) M.colLower[(size_t)col] = -kInf;
+        if (bt.ub) M.colUpper[(size_t)col] = kInf;
+      }
+      if (bt.lb) hasLower[(size_t)col] = 1;
+      if (bt.ub) hasUpper[(size_t)col] = 1;
+      continue;
+    }
+    if (!hasValue) throw Fail{kReadError, std::string("No bound given in BOUNDS line \"") + std::string(r.line, r.len) + "\""};
+    if (bt.integral) {
+      if (value - (double)(int32_t)value != 0.0) ++fractional;
+      vtype[(size_t)col] = bt.semi ? kSemiInteger : kInteger;
+    } else if (bt.semi) {
+      vtype[(size_t)col] = kSemiContinuous;
+    }
+    if (bt.lb) { M.colLower[(size_t)col] = value; hasLower[(size_t)col] = 1; }
+    if (bt.ub) { M.colUpper[(size_t)col] = value; hasUpper[(size_t)col] = 1; }
+    binary[(size_t)col] = 0;
+  }
+  flagOps.push_back({S.lo, true, dup || fractional});
+  if (dup || fractional)
+    addWarning(M, "BOUNDS section: ignored " + std::to_string(dup) + " duplicate values and " + std::to_string(fractional) +
+                      " fractional integer bounds");
+}
+
+void Reader::readHessian(const Section& S) {
+  if (S.key == kQsection || S.key == kQcmatrix) {
+    // parseQuadRows (:1745-1801): the section names a row; the cost row's section is the objective Hessian, an
+    // undefined or free row's section is skipped, a constraint's one makes the model a QCP (refused, :32-36)
+    const char* q = S.argB;
+    const Sv rn = nextWord(q, S.argE);
+    if (rn.empty()) throw Fail{kReadError, "No row name given in argument of QSECTION / QCMATRIX"};
+    int32_t ri;
+    if (!rowTable.find(rn, ri)) {
+      addWarning(M, "Row name \"" + rn.str() + "\" in QSECTION / QCMATRIX section is not defined: ignored");
+      flagOps.push_back({S.lo, false, true});
+      return;
+    }
+    if (ri == kFreeRow) return;
+    if (ri >= 0) throw Fail{kReadError, "Quadratic rows not supported by HiGHS"};
+  }
+  // parseQuadMatrix (:1803-1889): QUADOBJ / QSECTION list one triangle, every off-diagonal entry also defines its mirror
+  const bool triangular = S.key == kQuadobj || S.key == kQsection;
+  for (const char* p = S.lo; p < S.hi;) {
+    const char* nl = lineEnd(p, FE);
+    const Line L = trimLine(p, nl);
+    p = nl + 1;
+    if (L.skip) continue;
+    const char* q = L.b;
+    const Sv cn = nextWord(q, L.e);
+    int32_t v;
+    int32_t col = findCol(cn, colTable.find(cn, v) ? v : -1);
+    if (col < 0) col = addCol(cn);
+    for (int k = 0; k < 2; ++k) {
+      const Sv rn = nextWord(q, L.e);
+      if (rn.empty()) break;
+      const Sv cv = nextWord(q, L.e);
+      if (cv.empty()) throw Fail{kReadError, "Hessian section has no coefficient for entry \"" + rn.str() + "\" in column \"" + cn.str() + "\""};
+      int32_t row = findCol(rn, colTable.find(rn, v) ? v : -1);
+      if (row < 0) row = addCol(rn);
+      const double c = parseValue(cv);
+      if (c != 0.0 || c != c) {
+        qEntries.push_back({row, col, c});
+        if (triangular && row != col) qEntries.push_back({col, row, c});
+      }
+    }
+  }
+}
+
+void Reader::finish() {
   // columns that are still binary by default (parse(), :326-332)
   for (int32_t j = 0; j < numCol; ++j)
-    if (binary[(size_t)j]) { lower[(size_t)j] = 0.0; upper[(size_t)j] = 1.0; }
+    if (binary[(size_t)j]) { M.colLower[(size_t)j] = 0.0; M.colUpper[(size_t)j] = 1.0; }
   M.numCol = numCol;
   bool isMip = false;
   for (uint8_t t : vtype) if (t != kContinuous) { isMip = true; break; }
@@ -1226,8 +1300,14 @@ ReadStatus readMps(const std::string& path, int numThreads, Model& M) {
   std::stable_sort(flagOps.begin(), flagOps.end(), [](const FlagOp& x, const FlagOp& y) { return x.pos < y.pos; });
   for (const FlagOp& op : flagOps) M.warningIssued = op.assign ? op.value : (M.warningIssued || op.value);
   if (dupRowName || dupColName) M.warningIssued = true;
-  M.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-  return kReadOk;
+}
+
+}  // namespace
+
+// ==================================================================================================================
+ReadStatus readMps(const std::string& path, int numThreads, Model& M) {
+  Reader reader(M, numThreads);
+  return reader.run(path);
 }
 
 void lowerTriangle(const Model& m, std::vector<int32_t>& start, std::vector<int32_t>& index, std::vector<double>& value) {
