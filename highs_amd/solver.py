@@ -210,6 +210,16 @@ def solveLpCupdlp(lp: HighsLp, start=None, solve_fn=None, **options):
     return PdlpOutcome(status, ms, sol, int(R.num_iter), info, R)
 
 
+def run_model_file(path, solver="pdlp", threads=0, **options):
+    """Highs::readModel + Highs::run with solver="pdlp" / "hipdlp" and presolve off, on this package's side of the C
+    ABI: the library's MPS reader (read_mps), then the solve.  Returns (PdlpOutcome, HighsLp, read info)."""
+    lp, info = read_mps(path, threads)
+    if info["integrality"] is not None and info["integrality"].any():
+        raise ValueError("the model has integer columns: solver=\"pdlp\" is for LPs (and diagonal QPs)")
+    out = solveLpCupdlp(lp, **options) if solver == "pdlp" else solveLpHiPdlp(lp, **options)
+    return out, lp, info
+
+
 def solveLpHiPdlp(lp: HighsLp, solve_fn=None, **options):
     """Mirror of the reference's second PDLP entry point, solveLpHiPdlp (highs/pdlp/HiPdlpWrapper.cpp:26-141):
     restarted Halpern PDHG.  Same option names as HiGHS (kkt_tolerance / pdlp_optimality_tolerance ->

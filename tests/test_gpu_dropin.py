@@ -140,3 +140,14 @@ def test_num_devices_beyond_the_visible_devices_is_an_error(monkeypatch):
     import ctypes as C
     rc = solver.lib().pdlp_mi355x_solve(C.byref(P.struct), C.byref(abi.default_params(num_devices=64)), C.byref(R.struct))
     assert rc != 0 and b"devices" in solver.lib().pdlp_mi355x_last_error()
+
+
+@pytest.mark.parametrize("name", ["afiro", "adlittle"])
+def test_model_file_to_solution_without_highs(tmp_path, name):
+    """MPS file -> pdlp_mi355x_read_mps -> pdlp_mi355x_solve (solver.run_model_file): the reference objective."""
+    mps = os.path.join(str(tmp_path), name + ".mps")
+    L.write_mps(L.HighsLp.from_npz(os.path.join(GOLD, "instances", name + ".npz")), mps)
+    out, lp, info = solver.run_model_file(mps, threads=3)
+    ref = REF[name]["highs"]["objective_value"]
+    assert out.model_status == solver.kOptimal and info["threads"] == 3
+    assert abs(out.info["objective_function_value"] - ref) <= 1e-6 * (1 + abs(ref))
