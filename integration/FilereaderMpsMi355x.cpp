@@ -3,20 +3,25 @@
 // Same class, same two member functions (io/FilereaderMps.h:17-25); a maintainer swaps this file for
 // highs/io/FilereaderMps.cpp in the build and links libpdlp_mi355x.so.  readModelFromFile hands free-format files to
 // the library's multi-threaded reader (pdlp_mi355x_read_mps, include/pdlp_mi355x.h) and fills HighsModel exactly as
-// free_format_parser::HMpsFF::loadProblem does (io/HMpsFF.cpp:82-133); everything that reader does not take on is
-// still the reference's own code: names with spaces / mps_parser_type_free = false -> the fixed-column reader readMps
-// (io/HMPSIO.cpp), gzip streams on a system without libz -> HMpsFF through zstr, writing -> writeModelAsMps.  Highs::readModel ->
-// Filereader::getFilereader -> this TU -> Highs::passModel is otherwise untouched.
+// free_format_parser::HMpsFF::loadProblem does (io/HMpsFF.cpp:82-133).  Everything that reader does not take on stays
+// the reference's own code, literally: the original TU is kept in the build under another class name
+// (-DFilereaderMps=FilereaderMpsReference when compiling highs/io/FilereaderMps.cpp, see integration/build_dropin.sh)
+// and is called for names with spaces / mps_parser_type_free = false (fixed-column reader, io/HMPSIO.cpp), for gzip
+// streams on a system without libz (HMpsFF through zstr) and for writing (writeModelAsMps).
+// Highs::readModel -> Filereader::getFilereader -> this TU -> Highs::passModel is otherwise untouched.
 #include "io/FilereaderMps.h"
 
-#include "io/HMPSIO.h"
-#include "io/HMpsFF.h"
 #include "lp_data/HighsLp.h"
 #include "lp_data/HighsLpUtils.h"
 #include "lp_data/HighsModelUtils.h"
 #include "pdlp_mi355x.h"
 
-using free_format_parser::HMpsFF;
+// the reference's io/FilereaderMps.cpp, compiled with -DFilereaderMps=FilereaderMpsReference
+class FilereaderMpsReference : public Filereader {
+ public:
+  FilereaderRetcode readModelFromFile(const HighsOptions& options, const std::string filename, HighsModel& model);
+  HighsStatus writeModelToFile(const HighsOptions& options, const std::string filename, const HighsModel& model);
+};
 
 namespace {
 
@@ -86,68 +91,28 @@ void fillModel(const pdlp_mps_model_t& m, HighsModel& model) {
 
 FilereaderRetcode FilereaderMps::readModelFromFile(const HighsOptions& options, const std::string filename,
                                                    HighsModel& model) {
-  HighsLp& lp = model.lp_;
-  HighsHessian& hessian = model.hessian_;
   if (options.mps_parser_type_free) {
     pdlp_mps_model_t m;
     const int rc = pdlp_mi355x_read_mps(filename.c_str(), options.threads, &m);  // threads = 0: automatic
-    switch (rc) {
-      case 0: {
-        logWarnings(options.log_options, m.warnings);
-        fillModel(m, model);
-        const bool warning = m.warning_issued != 0;
-        pdlp_mi355x_free_mps_model(&m);
-        lp.ensureColwise();
-        assert(model.lp_.objective_name_ != "");
-        return warning ? FilereaderRetcode::kWarning : FilereaderRetcode::kOk;
-      }
-      case 2:
-        return FilereaderRetcode::kFileNotFound;
-      case 3:
-        highsLogUser(options.log_options, HighsLogType::kWarning,
-                     "Free format reader has detected row/col names with spaces: switching to fixed format parser\n");
-        break;
-      case 4: {
-        // a gzip stream and the library found no libz to inflate it with: the reference's own free-format parser
-        // reads it through zstr if it was built with zlib (HMpsFF.cpp:253-261)
-        HMpsFF parser{};
-        if (options.time_limit < kHighsInf && options.time_limit > 0) parser.time_limit_ = options.time_limit;
-        switch (parser.loadProblem(options.log_options, filename, model)) {
-          case FreeFormatParserReturnCode::kSuccess:
-            lp.ensureColwise();
-            return parser.warning_issued_ ? FilereaderRetcode::kWarning : FilereaderRetcode::kOk;
-          case FreeFormatParserReturnCode::kParserError:
-            return FilereaderRetcode::kParserError;
-          case FreeFormatParserReturnCode::kFileNotFound:
-            return FilereaderRetcode::kFileNotFound;
-          case FreeFormatParserReturnCode::kTimeout:
-            return FilereaderRetcode::kTimeout;
-          case FreeFormatParserReturnCode::kFixedFormat:
-            break;
-        }
-        break;
-      }
-      default:
-        highsLogUser(options.log_options, HighsLogType::kError, "%s\n", pdlp_mi355x_last_error());
-        return FilereaderRetcode::kParserError;
+    if (rc == 0) {
+      logWarnings(options.log_options, m.warnings);
+      fillModel(m, model);
+      const bool warning = m.warning_issued != 0;
+      pdlp_mi355x_free_mps_model(&m);
+      model.lp_.ensureColwise();
+      return warning ? FilereaderRetcode::kWarning : FilereaderRetcode::kOk;
     }
+    if (rc == 2) return FilereaderRetcode::kFileNotFound;
+    if (rc == 1) {
+      highsLogUser(options.log_options, HighsLogType::kError, "%s\n", pdlp_mi355x_last_error());
+      return FilereaderRetcode::kParserError;
+    }
+    // 3: names with spaces (the fixed-column format); 4: a gzip stream and no libz for the library -> the reference's TU
   }
-  // the fixed-column reader, as in the reference TU (io/FilereaderMps.cpp:60-77)
-  bool warning_issued = options.mps_parser_type_free;
-  FilereaderRetcode return_code = readMps(
-      options.log_options, filename, -1, -1, lp.num_row_, lp.num_col_, lp.sense_, lp.offset_, lp.a_matrix_.start_,
-      lp.a_matrix_.index_, lp.a_matrix_.value_, lp.col_cost_, lp.col_lower_, lp.col_upper_, lp.row_lower_, lp.row_upper_,
-      lp.integrality_, lp.objective_name_, lp.col_names_, lp.row_names_, hessian.dim_, hessian.start_, hessian.index_,
-      hessian.value_, lp.cost_row_location_, warning_issued, options.keep_n_rows);
-  if (return_code == FilereaderRetcode::kOk) lp.ensureColwise();
-  hasNamesWithSpaces(options.log_options, lp);
-  assert(model.lp_.objective_name_ != "");
-  if (return_code == FilereaderRetcode::kOk && warning_issued) return_code = FilereaderRetcode::kWarning;
-  return return_code;
+  return FilereaderMpsReference().readModelFromFile(options, filename, model);
 }
 
 HighsStatus FilereaderMps::writeModelToFile(const HighsOptions& options, const std::string filename,
                                             const HighsModel& model) {
-  assert(model.lp_.a_matrix_.isColwise());
-  return writeModelAsMps(options, filename, model, options.mps_parser_type_free);
+  return FilereaderMpsReference().writeModelToFile(options, filename, model);
 }

@@ -16,10 +16,14 @@ mkdir -p "$OUT"
 for w in CupdlpWrapperMi355x HiPdlpWrapperMi355x FilereaderMpsMi355x; do
   g++ -std=c++17 -O2 -fPIC -I"$REF/highs" -I"$REF_BUILD" -I"$ROOT/include" -c "$HERE/$w.cpp" -o "$OUT/$w.o"
 done
+# the reference's MPS reader TU stays in the build under another class name: FilereaderMpsMi355x.cpp calls it for what the
+# library's reader does not take on (fixed-column files, writing); compiled from the source where it lies
+g++ -std=c++17 -O2 -fPIC -DFilereaderMps=FilereaderMpsReference -I"$REF/highs" -I"$REF_BUILD" -I"$REF/extern" -I"$REF/extern/zstr" \
+    -c "$REF/highs/io/FilereaderMps.cpp" -o "$OUT/FilereaderMpsReference.o"
 # both reference PDLP paths are left out: cuPDLP-C (wrapper + vendored C) and HiPDLP (wrapper + hipdlp/*.cc),
 # and the MPS file reader TU (replaced by FilereaderMpsMi355x.cpp -> pdlp_mi355x_read_mps)
 OBJS=$(find "$REF_BUILD/highs/CMakeFiles/highs.dir" -name '*.o' | grep -v -E 'pdlp/CupdlpWrapper\.cpp\.o|pdlp/cupdlp/|pdlp/HiPdlpWrapper\.cpp\.o|pdlp/hipdlp/|io/FilereaderMps\.cpp\.o')
-/opt/rocm/lib/llvm/bin/clang++ -flto=thin -fuse-ld=lld -O3 -shared -o "$OUT/libhighs.so.1" -Wl,-soname,libhighs.so.1 $OBJS "$OUT/CupdlpWrapperMi355x.o" "$OUT/HiPdlpWrapperMi355x.o" "$OUT/FilereaderMpsMi355x.o" \
+/opt/rocm/lib/llvm/bin/clang++ -flto=thin -fuse-ld=lld -O3 -shared -o "$OUT/libhighs.so.1" -Wl,-soname,libhighs.so.1 $OBJS "$OUT/CupdlpWrapperMi355x.o" "$OUT/HiPdlpWrapperMi355x.o" "$OUT/FilereaderMpsMi355x.o" "$OUT/FilereaderMpsReference.o" \
     -L"$ROOT/highs_amd/lib" -lpdlp_mi355x -Wl,-rpath,'$ORIGIN/../../highs_amd/lib' -lz -lpthread -ldl
 # the same library with the REFERENCE's MPS reader TU left in: what tests/golden/make_golden_mps.py and tools/mps_bench.py
 # load to see / time the reference's own reader (io/FilereaderMps.cpp -> HMpsFF.cpp), never the product
