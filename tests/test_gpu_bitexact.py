@@ -38,7 +38,9 @@ def _csr_layout(monkeypatch):
     monkeypatch.setenv("PDLP_MI355X_SLAB", "0")  # default for this module: the CSR-stream work plan
 
 
-@pytest.mark.parametrize("name", ["afiro", "adlittle", "sctest", "e226", "shell", "25fv47"])
+@pytest.mark.parametrize("name", ["afiro", "adlittle", "sctest", "e226", "shell", "25fv47",
+                                  # LPs outside the ctest list: optimal ones and primal infeasible / unbounded ones
+                                  "qap04", "standmps", "israel", "woodinfe", "box1", "bgetam", "galenet"])
 def test_instances_bit_exact(name):
     lp = L.HighsLp.from_npz(os.path.join(GOLD, "instances", name + ".npz"))
     assert _check(lp) > 0

@@ -83,3 +83,19 @@ def test_oracle_equals_reference_core_feature_switches(features_off):
     assert (a.term_code, a.num_iter, a.num_trials) == (b.term_code, b.num_iter, b.num_trials)
     assert a.primal_obj == b.primal_obj and a.dual_obj == b.dual_obj
     assert np.array_equal(a.col_value, b.col_value) and np.array_equal(a.row_dual, b.row_dual)
+
+
+MORE = json.load(open(os.path.join(GOLD, "reference_pdlp_more.json")))
+
+
+@pytest.mark.parametrize("name", sorted(MORE))
+def test_more_instances_match_reference_binary_and_core(name):
+    """The other LPs of the reference's check/instances that its CPU pdlp finishes in minutes (five optimal, nine
+    primal infeasible or unbounded; make_golden_more.py): the restatement follows the real cuPDLP-C core bit for bit
+    and gives the reference binary's iteration count."""
+    lp = L.HighsLp.from_npz(os.path.join(GOLD, "instances", name + ".npz"))
+    r = O.oracle_solve(lp)
+    g = MORE[name]
+    for k in ("num_iter", "num_trials", "term_code", "primal_obj", "dual_obj", "primal_feas", "dual_feas"):
+        assert getattr(r, k) == g["cupdlp"][k], k
+    assert r.num_iter == g["highs"]["pdlp_iterations"]
