@@ -7,6 +7,7 @@
 #   kernel stats    : rocprofv3 --kernel-trace --stats of the headline bench command (N=1)
 #   PMC traffic     : FETCH_SIZE / WRITE_SIZE of the fused SpMV kernels, one counter per pass (never combined with
 #                     trace domains), corrected as MI355X_MICROARCH.md prescribes: bytes = (2*FETCH + WRITE) * 1024
+#   ingest / e2e    : tools/mps_bench.py on this box's host cores, tools/e2e_cli.sh (reference CLI on the drop-in, MPS -> solution)
 #   test logs       : pytest -m gpu (includes the drop-in tests: reference CLI, Catch2 cases, C API client)
 set -u
 R=$(cd "$(dirname "$0")/.." && pwd)
@@ -60,5 +61,10 @@ json.dump({"b": traffic, "raw_per_launch_means": raw,
           open("$OUT/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(traffic, indent=1))
 PY
+# host-side ingest on this box and the end-to-end run through the reference CLI (both need integration/_build)
+if [ -e $R/integration/_build/libhighs.so.1 ]; then
+  python tools/mps_bench.py --config c --threads 1,8,16,32,64,0 --reps 2 > $OUT/${RND}_mps_ingest_gpu_box_host.json 2> $OUT/mps_bench.err
+  bash tools/e2e_cli.sh b > $OUT/${RND}_e2e_reference_cli_1M.log 2>&1
+fi
 PYTEST_TIMEOUT=2400 bash tools/gpu_pytest.sh profiles_$RND/${RND}_pytest_gpu tests -m gpu -q
 echo done
