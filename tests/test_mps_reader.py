@@ -252,3 +252,21 @@ def test_gzip_streams_are_inflated_by_the_reader(tmp_path):
     gz.write_bytes(gzip.compress(text)[:-40])
     with pytest.raises(RuntimeError, match="gzip"):
         solver.read_mps(str(gz))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_lps_round_trip(seed, tmp_path):
+    """tests/lpgen.py::random_lp (every row / column kind, maximisation, offsets) written as MPS and read back by the
+    library's reader with a random number of pieces: the model the python restatement reads, and — for the LPs without
+    free rows (the writer turns those into N rows, which every reader drops) — the LP that was written."""
+    from lpgen import random_lp
+    lp = random_lp(seed)
+    path = str(tmp_path / "r.mps")
+    L.write_mps(lp, path)
+    got, info = solver.read_mps(path, 1 + seed % 7)
+    _same_model(got, L.read_mps(path))
+    free = np.isinf(lp.row_lower) & np.isinf(lp.row_upper)
+    if not free.any():
+        assert got.num_row == lp.num_row and np.array_equal(got.col_cost, lp.col_cost) and got.sense == lp.sense
+        assert np.array_equal(got.col_lower, lp.col_lower) and np.array_equal(got.col_upper, lp.col_upper)
+        assert np.array_equal(got.row_lower, lp.row_lower) and np.array_equal(got.row_upper, lp.row_upper)
