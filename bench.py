@@ -20,6 +20,9 @@ import os
 import sys
 import time
 
+# dmabuf-only hosts: HIP IPC (the direct xGMI exchange at N > 1, RCCL's own buffers) needs this before the first HIP call
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

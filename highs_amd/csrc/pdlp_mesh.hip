@@ -31,6 +31,15 @@
 #include "pdlp_devfn.hpp"
 #include "pdlp_device.hpp"
 
+// The direct exchange maps peer arenas through HIP IPC, which on dmabuf-only hosts needs HSA_ENABLE_IPC_MODE_LEGACY=0
+// when the HSA runtime starts.  Loading this library before the process's first HIP call is the common case (HiGHS
+// links it, python loads it before touching the GPU), so default the variable here without overriding the caller's.
+namespace {
+struct IpcModeDefault {
+  IpcModeDefault() { setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0); }
+} g_ipcModeDefault;
+}  // namespace
+
 namespace pdlp {
 
 namespace {
@@ -738,7 +747,14 @@ void Mesh::construct(int32_t rank, int32_t world, const void* id128, int32_t n, 
   const char* forceIpc = getenv("PDLP_MI355X_MESH_FORCE_IPC");  // diagnostic: IPC also inside one process
   const bool allLocal = !(forceIpc && atoi(forceIpc) != 0);
   const bool exported = hipIpcGetMemHandle(&mine.handle, arena_) == hipSuccess;
-  if (!exported) (void)hipGetLastError();
+  if (!exported) {
+    (void)hipGetLastError();
+    // peers in OTHER processes cannot map this arena then (same-process peers use the raw pointer): say why
+    const char* legacy = getenv("HSA_ENABLE_IPC_MODE_LEGACY");
+    fprintf(stderr, "pdlp_mi355x[rank %d]: hipIpcGetMemHandle failed (HSA_ENABLE_IPC_MODE_LEGACY=%s). Hosts whose driver only "
+                    "supports dmabuf IPC need HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment BEFORE the first HIP call of the "
+                    "process; ranks in other processes will fall back to RCCL.\n", rank, legacy ? legacy : "(unset)");
+  }
   mine.arenaBytes = arenaBytes_;
   mine.rawPtr = (uint64_t)(uintptr_t)arena_;
   mine.device = myDevice;
