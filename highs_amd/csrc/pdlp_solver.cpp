@@ -510,11 +510,13 @@ void Solver::refreshPowTable() {
   s.powGrow = powGrow_.get();
 }
 
-void Solver::pushState() {
+// wait = false: the copy stays queued in front of whatever is enqueued next.  Only for callers that do not touch
+// hostState_ again before their next stream synchronisation (the pinned buffer is the source of the queued copy).
+void Solver::pushState(bool wait) {
   refreshPowTable();
   hostState_->pending = 0;
   PDLP_HIP(hipMemcpyAsync(dst(), hostState_, sizeof(DevState), hipMemcpyHostToDevice, stream_));
-  PDLP_HIP(hipStreamSynchronize(stream_));
+  if (wait) PDLP_HIP(hipStreamSynchronize(stream_));
 }
 
 // ---- sharding-aware device linear algebra ----------------------------------
@@ -1000,7 +1002,7 @@ void Solver::doSolve(bool terminate, int32_t target) {
     if (!terminate && halt > iterLim) halt = iterLim;
     s.haltIter = (int32_t)halt;
     s.halted = 0;
-    pushState();
+    pushState(false);  // runUntilHalt only reads hostState_ until its own synchronisation: one host round trip less per check
     runUntilHalt();
   }
 }

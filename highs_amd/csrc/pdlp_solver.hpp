@@ -95,7 +95,7 @@ class Solver : public SolverBase {
   void captureGraph();
   void runUntilHalt();
   void syncState();    // device -> host_
-  void pushState();    // host_ -> device
+  void pushState(bool wait = true);    // host_ -> device
   // check iteration
   void computeAverage();
   void computeResiduals();
