@@ -693,7 +693,7 @@ void Reader::scanSections() {
       const char* nl = lineEnd(p, FE);
       // cheap reject: a header's first non-blank is a letter that starts a keyword
       const char* s = p;
-      while (s < nl && (*s == ' ' || *s == '\t')) ++s;
+      while (s < nl && isWs(*s)) ++s;
       if (s < nl && *p != '*') {
         const char c = (char)(*s | 0x20);
         if (c == 'n' || c == 'o' || c == 'm' || c == 'r' || c == 'c' || c == 'b' || c == 'q' || c == 'd' || c == 'u' ||
