@@ -151,13 +151,15 @@ __global__ void k_major_reduce(const int32_t* __restrict__ beg, const double* __
     out[r] = (s == 0.0) ? 1.0 : sqrt(s);  // sqrt(max) / sqrt(sum^(1/1)); empty or zero majors -> 1
   }
 }
+// qdiag (QP, may be null): x = x'/cs  =>  1/2 q x^2 = 1/2 (q / cs^2) x'^2, two divisions per pass as applyScaling does
 __global__ void k_apply_cols(const double* __restrict__ cs, int n, double* cost, double* lower, double* upper,
-                             double* colScale) {
+                             double* colScale, double* qdiag) {
   GSTRIDE(j, n) {
     cost[j] /= cs[j];
     lower[j] *= cs[j];
     upper[j] *= cs[j];
     colScale[j] *= cs[j];
+    if (qdiag) qdiag[j] = (qdiag[j] / cs[j]) / cs[j];
   }
 }
 __global__ void k_apply_rows(const double* __restrict__ rs, int m, double* rhs, double* rowScale) {
@@ -496,6 +498,16 @@ void gpuPrepare(const pdlp_problem_t& P, bool doScale, hipStream_t s, DeviceProb
     PDLP_HIP(hipStreamSynchronize(s));
     return;
   }
+  // QP (cuPDLP-C form): the diagonal of Q, with the objective sense, rides along with the column scaling
+  {
+    std::vector<double> q;
+    extractDiagonalHessian(P, D.sense, n, q);
+    if (!q.empty()) {
+      D.qdiag.alloc((size_t)n);
+      D.qdiag.upload(q.data(), (size_t)n, s);
+      PDLP_HIP(hipStreamSynchronize(s));  // q goes out of scope
+    }
+  }
   if (doScale) {
     DeviceArray<double> cs, rs;
     cs.alloc(n);
@@ -509,7 +521,7 @@ void gpuPrepare(const pdlp_problem_t& P, bool doScale, hipStream_t s, DeviceProb
         hipLaunchKernelGGL(k_major_reduce<false>, dim3(gridFor(m)), dim3(kT), 0, s, D.A.beg.get(), D.A.val.get(), m, rs.get());
       }
       hipLaunchKernelGGL(k_apply_cols, dim3(gridFor(n)), dim3(kT), 0, s, cs.get(), n, D.cost.get(), D.lower.get(),
-                         D.upper.get(), D.colScale.get());
+                         D.upper.get(), D.colScale.get(), D.qdiag.size() ? D.qdiag.get() : (double*)nullptr);
       hipLaunchKernelGGL(k_apply_rows, dim3(gridFor(m)), dim3(kT), 0, s, rs.get(), m, D.rhs.get(), D.rowScale.get());
       hipLaunchKernelGGL(k_scale_vals, dim3(gridFor(nnz)), dim3(kT), 0, s, cscIdx.get(), cscCol.get(), rs.get(),
                          cs.get(), nnz, cscVal.get());

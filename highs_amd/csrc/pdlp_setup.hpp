@@ -40,6 +40,7 @@ struct DeviceProblem {
   DeviceCsrData A;   // rows, ascending column
   DeviceCsrData At;  // columns, ascending row
   DeviceArray<double> cost, rhs, lower, upper, colScale, rowScale;
+  DeviceArray<double> qdiag;      // QP only (cuPDLP-C form): diagonal of Q with the sense, scaled with the columns
   DeviceArray<double> rowUpper;   // HiPDLP form only (rhs then holds the row lower bounds)
   DeviceArray<uint8_t> rowIsEq;   // HiPDLP form only, per permuted row
   // host copies of what the host side of the solver needs

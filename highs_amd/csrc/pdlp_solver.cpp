@@ -228,9 +228,8 @@ void Solver::construct(const pdlp_problem_t& P, const void* id128) {
   if (const char* g = getenv("PDLP_MI355X_GPU_SETUP")) gpuSetup_ = atoi(g) != 0;
   // sharded: every rank still prepares the WHOLE problem (Ruiz scaling couples all rows and columns) but does it on
   // its device and copies the result back once; only the row-block cut and the upload of its shard stay on the host
-  const bool shardedGpuSetup = sharded_ && gpuSetup_ && !(P.q_dim > 0 && P.q_start && P.q_start[P.q_dim] > 0);
+  const bool shardedGpuSetup = sharded_ && gpuSetup_;
   if (sharded_) gpuSetup_ = false;
-  if (P.q_dim > 0 && P.q_start && P.q_start[P.q_dim] > 0) gpuSetup_ = false;  // the QP form is prepared on the host
   const bool doScale = !(opt_.features_off & PDLP_FEATURE_SCALING_OFF);
   DeviceProblem devProb;
   if (gpuSetup_) {
@@ -412,6 +411,10 @@ void Solver::downloadForm(DeviceProblem& D, StandardForm& F, hipStream_t s) {
   D.lower.download(F.lower.data(), F.lower.size(), s);
   D.upper.download(F.upper.data(), F.upper.size(), s);
   D.rhs.download(F.rhs.data(), F.rhs.size(), s);
+  if (D.qdiag.size()) {
+    F.qdiag.resize((size_t)D.n);
+    D.qdiag.download(F.qdiag.data(), F.qdiag.size(), s);
+  }
   PDLP_HIP(hipStreamSynchronize(s));
 }
 
@@ -422,6 +425,10 @@ void Solver::uploadProblemFromDevice(DeviceProblem& D) {
   dAt_.buildFromDevice(D.At, slabMode, stream_);
   cost_ = std::move(D.cost); rhs_ = std::move(D.rhs); lower_ = std::move(D.lower); upper_ = std::move(D.upper);
   colScale_ = std::move(D.colScale); rowScale_ = std::move(D.rowScale);
+  if (D.qdiag.size()) {
+    qdiag_ = std::move(D.qdiag);
+    log(1, "Quadratic objective (diagonal Hessian): proximal primal step\n");
+  }
   allocIterates();
 }
 

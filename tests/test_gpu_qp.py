@@ -85,3 +85,18 @@ def test_qp_sharded_over_two_ranks_in_process(monkeypatch):
     env = dict(os.environ, PDLP_MI355X_FOLD_DEVICES="1", PDLP_MI355X_VERIFY_RANKS="1", GPU_MAX_HW_QUEUES="16")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0 and "qp sharded ok" in out.stdout, out.stdout[-1000:] + out.stderr[-1500:]
+
+
+@pytest.mark.parametrize("name", ["qp2", "qp6"])
+def test_qp_prepared_on_the_device_gives_the_same_bits(name, monkeypatch):
+    """QPs are prepared on the device like LPs (automatic from 200k nonzeros; forced here): the diagonal of Q is scaled
+    on the host with the scale vector that comes back — same divisions as the host path, so the same solve bit for bit."""
+    lp = _qp(name)
+    kw = dict(kkt_tolerance=1e-7, pdlp_iteration_limit=200000)
+    monkeypatch.setenv("PDLP_MI355X_GPU_SETUP", "0")
+    a = solver.solveLpCupdlp(lp, **kw)
+    monkeypatch.setenv("PDLP_MI355X_GPU_SETUP", "1")
+    b = solver.solveLpCupdlp(lp, **kw)
+    assert a.pdlp_iteration_count == b.pdlp_iteration_count and a.result.primal_obj == b.result.primal_obj
+    for k in ("col_value", "col_dual", "row_value", "row_dual"):
+        assert np.array_equal(getattr(a.solution, k), getattr(b.solution, k)), k
