@@ -58,3 +58,17 @@ def test_limits():
     big = solver.SyntheticProblem(200000, 200000, 1600000, 2).to_lp()
     out = solver.solveLpCupdlp(big, time_limit=0.0)
     assert out.model_status == solver.kTimeLimit and out.status == solver.kWarning
+
+
+@pytest.mark.skipif(not O.ref_available(), reason="oracle/_ref not built (needs /root/reference)")
+def test_oracle_equals_reference_core_on_many_more_random_lps():
+    """Seeds 100..299, two settings each (default features at 1e-6; a feature-switch combination chosen by the seed at
+    1e-4): iteration and trial counts, termination code, objectives and the solution vectors, bit for bit."""
+    for seed in range(100, 300):
+        lp = random_lp(seed)
+        for kw in (dict(kkt_tolerance=1e-6, pdlp_iteration_limit=40000),
+                   dict(kkt_tolerance=1e-4, pdlp_iteration_limit=4000, pdlp_features_off=seed % 8)):
+            a, b = O.oracle_solve(lp, **kw), O.ref_solve(lp, **kw)
+            assert (a.term_code, a.num_iter, a.num_trials, a.primal_obj, a.dual_obj) == \
+                   (b.term_code, b.num_iter, b.num_trials, b.primal_obj, b.dual_obj), (seed, kw)
+            assert np.array_equal(a.col_value, b.col_value) and np.array_equal(a.row_dual, b.row_dual), (seed, kw)
