@@ -270,3 +270,22 @@ def test_random_lps_round_trip(seed, tmp_path):
         assert got.num_row == lp.num_row and np.array_equal(got.col_cost, lp.col_cost) and got.sense == lp.sense
         assert np.array_equal(got.col_lower, lp.col_lower) and np.array_equal(got.col_upper, lp.col_upper)
         assert np.array_equal(got.row_lower, lp.row_lower) and np.array_equal(got.row_upper, lp.row_upper)
+
+
+@needs_build
+def test_reference_cli_reads_a_gzip_file_through_the_reader(tmp_path):
+    """afiro.mps.gz through the reference's unmodified CLI on the drop-in (Filereader::getFilereader strips ".gz" and
+    dispatches to the MPS reader TU, which hands the gzip stream to pdlp_mi355x_read_mps)."""
+    import gzip
+    import re
+    import subprocess
+    ref = json.load(open(os.path.join(GOLD, "reference_pdlp.json")))["afiro"]["highs"]["objective_value"]
+    mps = str(tmp_path / "afiro.mps")
+    L.write_mps(L.HighsLp.from_npz(os.path.join(GOLD, "instances", "afiro.npz")), mps)
+    gz = mps + ".gz"
+    open(gz, "wb").write(gzip.compress(open(mps, "rb").read()))
+    out = subprocess.run([os.path.join(BUILD, "highs_ref_cli"), "--solver=simplex", gz], capture_output=True, text=True,
+                         timeout=300, env=_dropin_env(), cwd=str(tmp_path))
+    txt = out.stdout + out.stderr
+    assert out.returncode == 0 and "Optimal" in txt, txt[-1500:]
+    assert abs(float(re.search(r"Objective value\s*:\s*(\S+)", txt)[1]) - ref) <= 1e-6 * (1 + abs(ref))
