@@ -65,6 +65,12 @@ void HalpernSolver::construct(const pdlp_problem_t& P, const void* id128) {
     origVal_.assign(P.a_value, P.a_value + origBeg_[P.num_col]);
     origCost_.assign(P.col_cost, P.col_cost + P.num_col);
   }
+  // quadratic objectives belong to the pdlp path (algorithm 0): refused here, before either set-up path is chosen
+  // (the device-side set-up never looks at q_*)
+  if (P.q_dim > 0 && P.q_start && P.q_value)
+    for (int32_t p = 0; p < P.q_start[P.q_dim]; ++p)
+      if (P.q_value[p] != 0.0)
+        throw std::runtime_error("pdlp_mi355x: quadratic objectives are solved by the pdlp path only (algorithm = 0)");
   const bool doScale = !(opt_.features_off & PDLP_FEATURE_SCALING_OFF);
   int slabMode = -1;
   if (const char* g = getenv("PDLP_MI355X_SLAB")) slabMode = atoi(g);

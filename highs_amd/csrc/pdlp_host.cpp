@@ -317,22 +317,47 @@ void extractSlab(const StandardForm& F, int32_t r0, int32_t r1, Compressed& csrS
 
 StreamPlan planStream(const std::vector<int32_t>& beg, int32_t nMajor, int32_t chunk, int32_t maxMajorsPerBlock) {
   StreamPlan plan;
-  plan.blockBeg.push_back(0);
   int32_t start = 0;
   while (start < nMajor) {
+    if (beg[start + 1] - beg[start] > chunk) {  // a long major: segment tasks, no block
+      plan.longMajors.push_back(start);
+      ++start;
+      continue;
+    }
     const int32_t base = beg[start];
     int32_t end = start;
     // extend while the block stays within `chunk` nonzeros and the major cap
     while (end < nMajor && end - start < maxMajorsPerBlock && beg[end + 1] - base <= chunk) ++end;
-    if (end == start) {  // a single major longer than chunk
-      end = start + 1;
-      ++plan.nLong;
-    }
+    plan.blockBeg.push_back(start);
     plan.blockBeg.push_back(end);
     start = end;
   }
-  plan.nBlocks = (int32_t)plan.blockBeg.size() - 1;
+  plan.nBlocks = (int32_t)plan.blockBeg.size() / 2;
   return plan;
+}
+
+LongPlan planLong(const std::vector<int32_t>& beg, const std::vector<int32_t>& longMajors, const int32_t* vecIndex,
+                  int32_t W) {
+  constexpr int32_t kSeg = 512, kMaxSeg = 64;  // pdlp_kernels.hpp kLongSegment, kLongMaxSegments
+  LongPlan L;
+  L.nLong = (int32_t)longMajors.size();
+  for (int32_t c = 0; c < L.nLong; ++c) {
+    const int32_t r = longMajors[c];
+    const int32_t p0 = beg[r], len = beg[r + 1] - beg[r];
+    int64_t seg = kSeg;
+    while ((len + seg - 1) / seg > kMaxSeg) seg *= 2;
+    const int32_t nSeg = (int32_t)((len + seg - 1) / seg);
+    const bool contained = nSeg <= W;
+    if (contained)
+      while ((int32_t)(L.tasks.size() % W) + nSeg > W) L.tasks.push_back(LongTaskHost{0, 0, -1, (int32_t)L.tasks.size(), 1, 0, 1, 0});
+    const int32_t first = (int32_t)L.tasks.size();
+    for (int32_t k = 0; k < nSeg; ++k) {
+      const int64_t a = p0 + (int64_t)k * seg, b = std::min<int64_t>(p0 + len, a + seg);
+      L.tasks.push_back(LongTaskHost{(int32_t)a, (int32_t)b, c, first, nSeg, vecIndex ? vecIndex[c] : r, contained ? 1 : 0, 0});
+    }
+  }
+  L.nTasks = (int32_t)L.tasks.size();
+  return L;
 }
 
 namespace {

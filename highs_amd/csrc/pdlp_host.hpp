@@ -77,14 +77,28 @@ std::vector<int32_t> rowPartition(const Compressed& csr, int32_t m, int32_t worl
 // Row slab [r0,r1) of F as (csr slab, csc-of-slab with local row indices).
 void extractSlab(const StandardForm& F, int32_t r0, int32_t r1, Compressed& csrSlab, Compressed& cscSlab);
 
-// CSR-adaptive launch plan: consecutive majors are grouped into work blocks of
-// at most `chunk` nonzeros; a major longer than `chunk` gets a block of its own.
+// CSR-adaptive launch plan: consecutive majors are grouped into work blocks of at most `chunk` nonzeros (whole
+// majors, summed left to right by one lane each); a major longer than `chunk` belongs to no block — it is cut
+// into segment tasks (LongPlan).
 struct StreamPlan {
-  std::vector<int32_t> blockBeg;  // [nBlocks+1] first major of each block
+  std::vector<int32_t> blockBeg;    // [2*nBlocks] first and end major of each block
   int32_t nBlocks = 0;
-  int32_t nLong = 0;              // blocks that hold a single over-long major
+  std::vector<int32_t> longMajors;  // majors longer than chunk, ascending
 };
 StreamPlan planStream(const std::vector<int32_t>& beg, int32_t nMajor, int32_t chunk, int32_t maxMajorsPerBlock);
+
+// Segment tasks of the long majors of one operand (the device view is pdlp_kernels.hpp LongMat / LongTask).  A long
+// major is cut into segments of 512 * 2^k nonzeros (smallest k with at most 64 segments), one task each; tasks are
+// handed to workgroups of wavesPerBlock waves, W consecutive tasks each, and a major with at most W segments never
+// straddles two workgroups (idle tasks pad the list).
+struct LongTaskHost { int32_t pBeg, pEnd, c, first, nSeg, major, contained, pad_; };  // = LongTask
+struct LongPlan {
+  std::vector<LongTaskHost> tasks;
+  int32_t nLong = 0, nTasks = 0;
+};
+// longMajors: indices into beg; vecIndex: result-vector index of each of them (nullptr: the index itself)
+LongPlan planLong(const std::vector<int32_t>& beg, const std::vector<int32_t>& longMajors, const int32_t* vecIndex,
+                  int32_t wavesPerBlock);
 
 // Slab layout (the layout of k_spmv_slab).  The gathered vector of a random sparse LP (8 MB at
 // n = 1M) does not fit one XCD's 4 MB L2, so a plain CSR stream pays one fabric request per 8-byte

@@ -14,6 +14,7 @@
 #include "pdlp_kernels.hpp"
 
 #include <cmath>
+#include <cstdlib>
 
 #include "pdlp_devfn.hpp"
 
@@ -27,6 +28,7 @@ constexpr bool usesDevState(int epi) { return epi == kDualStep || epi == kAtyInt
 struct SpmvArgs {
   SpmvMat A;
   SlabMat S;
+  LongMat L;
   int32_t xcdMap;  // 1: XCD x owns a contiguous range of work blocks (see xcdContiguousBlock)
   const DevState* st;  // nullptr for kPlain
   // kPlain / kAtyPartial
@@ -151,35 +153,136 @@ struct Epi {
   }
 };
 
-// CSR-adaptive SpMV (stream + long-row paths) with the fused epilogue.
+// The segment tasks of the long majors (pdlp_kernels.hpp LongMat): workgroup lb of the extra blocks runs the tasks
+// [lb*W, (lb+1)*W), one per wave.  Lane l adds the products of the entries l, l+64, ... of the segment in ascending
+// order (8 unit-stride loads of idx/val per lane and pass, all issued before the 8 dependent gathers), 64-lane
+// shuffle tree.  A major whose segments all sit in this workgroup is finished through LDS; a spanning one through
+// HBM: segment sum stored, ticket taken, the wave with the last ticket adds the segment sums left to right.
+// Cross-workgroup visibility: every shared word (segSum, ticket) is only touched with agent-scope relaxed atomics
+// (sc1: write-through stores, L1-bypassing loads), and the segment sum has landed (s_waitcnt vmcnt(0)) before the
+// ticket is taken.  The epilogue operands of the major are fetched with the first loads, not after the reduction.
+template <int EPI, int W>
+__device__ __forceinline__ void longBlock(const SpmvArgs& a, Epi<EPI>& epi, int lb, double* lds /* [W] */) {
+  const LongMat& L = a.L;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x / kWave);
+  const int t = lb * W + wave;
+  LongTask T;
+  T.c = -1; T.pBeg = T.pEnd = 0; T.first = t; T.nSeg = 1; T.major = 0; T.contained = 1; T.pad_ = 0;
+  if (t < L.nTasks) {  // (one 32-byte scalar load)
+    const int32_t* q = reinterpret_cast<const int32_t*>(L.tasks + t);
+    T.pBeg = ldUniform(q); T.pEnd = ldUniform(q + 1); T.c = ldUniform(q + 2); T.first = ldUniform(q + 3);
+    T.nSeg = ldUniform(q + 4); T.major = ldUniform(q + 5); T.contained = ldUniform(q + 6);
+  }
+  const bool active = T.c >= 0;
+  const int seg = t - T.first;
+  Pre pre{0.0, 0.0, 0.0, 0.0, 0.0};
+  if (active && (seg == 0 || !T.contained)) pre = epi.prefetch(T.major);
+  const int32_t* __restrict__ idx = L.idx;
+  const double* __restrict__ val = L.val;
+  const double* __restrict__ in = epi.input();
+  constexpr int kPer = kLongSegment / kWave;
+  double s = 0.0;
+  for (int base = T.pBeg; base < T.pEnd; base += kLongSegment) {
+    int32_t ci[kPer];
+    double va[kPer], xg[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {  // unconditional, clamped (a load in an exec-masked branch drains vmcnt)
+      const int q = base + k * kWave + lane;
+      const int qq = q < T.pEnd ? q : T.pEnd - 1;
+      ci[k] = idx[qq];
+      va[k] = val[qq];
+    }
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) xg[k] = in[ci[k]];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k)
+      if (base + k * kWave + lane < T.pEnd) s += va[k] * xg[k];
+  }
+  s = waveSum(s);
+  int last = 0;
+  if (lane == 0) {
+    lds[wave] = s;
+    if (active && !T.contained) {
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(L.segSum + t), (unsigned long long)__double_as_longlong(s),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the segment sum has landed before the ticket is taken
+      const unsigned old = __hip_atomic_fetch_add(L.ticket + T.c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = old == (unsigned)(T.nSeg - 1) ? 1 : 0;
+    }
+  }
+  last = __builtin_amdgcn_readfirstlane(last);
+  __syncthreads();
+  double total = 0.0;
+  bool finish = false;
+  if (active && T.contained && seg == 0) {
+    for (int k = 0; k < T.nSeg; ++k) total += lds[wave + k];  // left to right
+    finish = true;
+  } else if (last) {  // last ticket of a spanning major: every segment sum is in HBM
+    if (lane == 0) __hip_atomic_store(L.ticket + T.c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
+    double v = 0.0;
+    if (lane < T.nSeg)
+      v = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(L.segSum + T.first + lane),
+                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    for (int k = 0; k < T.nSeg; ++k) total += __shfl(v, k, kWave);  // left to right
+    finish = true;
+  }
+  if (finish && lane == 0) {
+    const double keep0 = epi.acc0, keep1 = epi.acc1;
+    epi.acc0 = 0.0; epi.acc1 = 0.0;
+    epi.apply(T.major, total, pre);
+    if (EPI == kDualStep || EPI == kAtyInteract) {  // the major's own slot (or, beyond kLongSlotCap, its entry for k_long_groups)
+      double* o0 = L.contrib ? L.contrib + T.c : a.part0 + L.slotBase + T.c;
+      *o0 = epi.acc0;
+      if (EPI == kAtyInteract) {
+        double* o1 = L.contrib ? L.contrib + L.nLong + T.c : a.part1 + L.slotBase + T.c;
+        *o1 = epi.acc1;
+      }
+    }
+    epi.acc0 = keep0; epi.acc1 = keep1;
+  }
+}
+
+// More long majors than kLongSlotCap: slot g of the partial arrays = contributions of the majors [g*G, (g+1)*G),
+// added left to right.
+__global__ __launch_bounds__(kVecThreads) void k_long_groups(const LongMat L, const DevState* st, double* part0, double* part1) {
+  if (st && st->halted) return;
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= L.nSlots) return;
+  const int c0 = g * L.groupSize, c1 = c0 + L.groupSize < L.nLong ? c0 + L.groupSize : L.nLong;
+  double s0 = 0.0, s1 = 0.0;
+  for (int c = c0; c < c1; ++c) { s0 += L.contrib[c]; if (part1) s1 += L.contrib[L.nLong + c]; }
+  part0[L.slotBase + g] = s0;
+  if (part1) part1[L.slotBase + g] = s1;
+}
+
+// CSR-adaptive SpMV with the fused epilogue (long majors: segment tasks in the extra blocks at the end of the grid).
 // One work block = up to kChunk consecutive nonzeros belonging to whole majors.
 //   phase 1: all lanes stream val[]/idx[] with unit stride (coalesced), gather
 //            the input vector, and park the products in LDS;
 //   phase 2: one lane per major adds its products left to right (the
 //            reference's summation order) and runs the epilogue.
-template <int EPI, bool MAPPED, int CHUNK>
+template <int EPI, int CHUNK>
 __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
   if (usesDevState(EPI) && a.st->halted) return;
   __shared__ double prod[CHUNK + CHUNK / 8 + 8];
   __shared__ double scratch[2][kSpmvThreads / kWave];
 
   const int tid = threadIdx.x;
+  Epi<EPI> epi(a);
+  if ((int)blockIdx.x >= a.A.nBlocks) {  // the extra blocks: one segment task of a long major per wave
+    longBlock<EPI, kSpmvThreads / kWave>(a, epi, (int)blockIdx.x - a.A.nBlocks, scratch[0]);
+    return;
+  }
   const int blk = a.xcdMap ? xcdContiguousBlock(blockIdx.x, a.A.nBlocks) : (int)blockIdx.x;
-  const int r0 = a.A.blockBeg[blk], r1 = a.A.blockBeg[blk + 1];
+  const int r0 = a.A.blockBeg[2 * blk], r1 = a.A.blockBeg[2 * blk + 1];
   const int p0 = a.A.beg[r0], p1 = a.A.beg[r1];
   const int32_t* __restrict__ idx = a.A.idx;
   const double* __restrict__ val = a.A.val;
-  Epi<EPI> epi(a);
   const double* __restrict__ in = epi.input();
-  auto vecIndex = [&](int r) { return MAPPED ? a.A.majorMap[r] : r; };
+  auto vecIndex = [&](int r) { return r; };
 
-  if (r1 - r0 == 1 && p1 - p0 > CHUNK) {
-    // long major: the whole block strides over it; tree-reduced (deterministic)
-    double s = 0.0;
-    for (int p = p0 + tid; p < p1; p += kSpmvThreads) s += val[p] * in[idx[p]];
-    s = blockSum<kSpmvThreads>(s, scratch[0]);
-    if (tid == 0) { const int r = vecIndex(r0); epi.apply(r, s, epi.prefetch(r)); }
-  } else {
+  {
     constexpr int kPer = CHUNK / kSpmvThreads;
     const int cnt = p1 - p0;
     // Bookkeeping of this lane's first major, issued ahead of the stream.  All
@@ -268,13 +371,20 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
 // stretches are applied one after the other.  Slabs ascend and minors ascend inside a slab, so every
 // major is summed in ascending minor order — the reference's order: bit-identical to the CSR path.
 constexpr int kSlabSlots = 3;  // register pipeline depth (groups of 64 entries per wave)
-constexpr int kSlabPre = 4;    // majors per thread whose epilogue operands are fetched before the stream
-template <int EPI>
-__global__ __launch_bounds__(kSlabThreads, kSlabThreads / 256) void k_spmv_slab(const SpmvArgs a) {
+// TWO: register budget for two resident blocks per CU (8 waves per SIMD) — the extra blocks with the segment
+// tasks of the long majors then run NEXT to the streaming blocks instead of after them.
+template <int EPI, bool TWO>
+__global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabThreads / 256) void k_spmv_slab(const SpmvArgs a) {
   if (usesDevState(EPI) && a.st->halted) return;
   constexpr int NB = kSlabSlots, kWaves = kSlabThreads / kWave;
-  // dynamic LDS: acc[R] f64 | stg[16][64] f64 | scratch[2][16] f64
+  constexpr int kSlabPre = TWO ? 2 : 4;  // majors per thread whose epilogue operands are fetched before the stream
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if ((int)blockIdx.x >= a.S.nBlocks) {  // the extra blocks: one segment task of a long major per wave
+    Epi<EPI> epiL(a);
+    longBlock<EPI, kWaves>(a, epiL, (int)blockIdx.x - a.S.nBlocks, reinterpret_cast<double*>(smem));
+    return;
+  }
+  // dynamic LDS: acc[R] f64 | stg[16][64] f64 | scratch[2][16] f64
   const int R = a.S.rowsPerBlock;
   double* acc = reinterpret_cast<double*>(smem);
   double* stgAll = acc + R;
@@ -766,25 +876,31 @@ void launchPrimalStep(const IterVecs& v, const DevState* st, hipStream_t s) {
 }
 
 namespace {
+// PDLP_MI355X_SLAB_OCC2=0|1: register budget of the slab kernel for one / two resident blocks per CU
+bool slabTwoPerCu() {
+  static const int v = [] { const char* e = getenv("PDLP_MI355X_SLAB_OCC2"); return e ? atoi(e) : 1; }();
+  return v != 0;
+}
 template <int EPI>
 void launchSpmv(const MatView& M, SpmvArgs a, hipStream_t s) {
   a.xcdMap = M.xcdMap;
+  a.L = M.lng;
+  a.A = M.csr;
+  const int nTasks = M.lng.nTasks;
   if (M.useSlab && M.slab.nBlocks > 0) {
     a.S = M.slab;
     const size_t lds = (size_t)M.slab.rowsPerBlock * 8 + kSlabThreads * 8 + 2 * (kSlabThreads / kWave) * 8;
-    hipLaunchKernelGGL((k_spmv_slab<EPI>), dim3(M.slab.nBlocks), dim3(kSlabThreads), lds, s, a);
+    const dim3 grid(M.slab.nBlocks + (nTasks + kSlabThreads / kWave - 1) / (kSlabThreads / kWave));
+    if (nTasks > 0 && slabTwoPerCu()) hipLaunchKernelGGL((k_spmv_slab<EPI, true>), grid, dim3(kSlabThreads), lds, s, a);
+    else hipLaunchKernelGGL((k_spmv_slab<EPI, false>), grid, dim3(kSlabThreads), lds, s, a);
+  } else if (M.csr.nBlocks > 0 || nTasks > 0) {
+    const dim3 grid(M.csr.nBlocks + (nTasks + kSpmvThreads / kWave - 1) / (kSpmvThreads / kWave)), block(kSpmvThreads);
+    if (M.csr.chunk == kChunkSmall) hipLaunchKernelGGL((k_spmv<EPI, kChunkSmall>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_spmv<EPI, kChunk>), grid, block, 0, s, a);
   }
-  if (M.csr.nBlocks > 0) {
-    a.A = M.csr;
-    const dim3 grid(M.csr.nBlocks), block(kSpmvThreads);
-    if (M.csr.chunk == kChunkSmall) {
-      if (M.csr.majorMap) hipLaunchKernelGGL((k_spmv<EPI, true, kChunkSmall>), grid, block, 0, s, a);
-      else hipLaunchKernelGGL((k_spmv<EPI, false, kChunkSmall>), grid, block, 0, s, a);
-    } else {
-      if (M.csr.majorMap) hipLaunchKernelGGL((k_spmv<EPI, true, kChunk>), grid, block, 0, s, a);
-      else hipLaunchKernelGGL((k_spmv<EPI, false, kChunk>), grid, block, 0, s, a);
-    }
-  }
+  if (nTasks > 0 && M.lng.contrib && (EPI == kDualStep || EPI == kAtyInteract))
+    hipLaunchKernelGGL(k_long_groups, dim3((M.lng.nSlots + kVecThreads - 1) / kVecThreads), dim3(kVecThreads), 0, s, M.lng,
+                       a.st, a.part0, EPI == kAtyInteract ? a.part1 : nullptr);
 }
 }  // namespace
 

@@ -56,12 +56,47 @@ struct SpmvMat {
   const int32_t* beg;       // [nMajor+1]
   const int32_t* idx;       // [nnz]
   const double* val;        // [nnz]
-  const int32_t* blockBeg;  // [nBlocks+1] stream plan
+  const int32_t* blockBeg;  // [2*nBlocks] stream plan: first major and end major of each work block
   int32_t nMajor;
   int32_t nBlocks;
-  const int32_t* majorMap;  // compact major -> vector index (nullptr = identity)
   int32_t partOffset;       // first slot of this matrix in the per-block partial arrays
   int32_t chunk;            // kChunk or kChunkSmall: the work plan's block size
+};
+
+// Long majors (pdlp_host.hpp LongPlan), device pointers.  A major that is too long for the left-to-right
+// lanes (more than the stream plan's chunk; more than 256 nonzeros in the slab layout) is cut into SEGMENT
+// TASKS of segLen nonzeros (512, doubled until a major has at most 64 of them).  One wave per task: lane l
+// accumulates the entries l, l+64, ... of the segment in ascending order, then the 64-lane shuffle tree; the
+// segment sums of a major are added left to right and its epilogue runs once.  The tasks are extra workgroups
+// at the end of the SpMV grid (W = 4 waves per 256-thread block, 16 per 1024-thread block), so they run next to
+// the streams instead of behind them.  A major with at most W segments never straddles two workgroups (the task
+// list is padded with idle tasks): its segment sums meet in LDS.  A longer one spans workgroups: segment sums go
+// to HBM, every wave takes a ticket of the major, the wave with the LAST ticket finishes it.  The reduction
+// contributions of long major c go to their own slot of the partial arrays (slotBase + c): which wave finishes
+// last does not matter, results are deterministic.
+constexpr int kLongSegment = 512;   // nonzeros per segment task (8 per lane)
+constexpr int kLongMaxSegments = 64;
+constexpr int kLongSlotCap = 2048;  // more long majors than this: contributions are summed in fixed groups (k_long_groups)
+struct LongTask {      // 32 bytes: one scalar load per wave
+  int32_t pBeg, pEnd;  // entries of the segment
+  int32_t c;           // long-major index (-1: idle task, padding)
+  int32_t first;       // first task of the major (segment = task - first)
+  int32_t nSeg;        // segments of the major
+  int32_t major;       // index of the major in the result vector
+  int32_t contained;   // 1: all segments in this workgroup (LDS), 0: spanning (tickets)
+  int32_t pad_;
+};
+struct LongMat {
+  const int32_t* idx;        // the CSR arrays the long majors live in (the operand's, or the slab layout's side copy)
+  const double* val;
+  const LongTask* tasks;     // [nTasks]
+  double* segSum;            // [nTasks] (spanning majors)
+  uint32_t* ticket;          // [nLong] zero between launches
+  double* contrib;           // [2*nLong] when nLong > kLongSlotCap (then k_long_groups fills the slots), else nullptr
+  int32_t nLong, nTasks;
+  int32_t slotBase;          // first slot of the long majors in the partial arrays
+  int32_t nSlots;            // nLong, or the number of groups
+  int32_t groupSize;         // long majors per slot (1 unless nLong > kLongSlotCap)
 };
 
 // Slab layout (pdlp_host.hpp SlabLayout), device pointers.  One 1024-thread block = 16 waves, each
@@ -76,13 +111,14 @@ struct SlabMat {
   int32_t nMajor, nBlocks, rowsPerBlock, minorBits;
 };
 
-// One operand matrix of the iteration: either a plain CSR stream, or the slab
-// layout for the short majors plus a CSR side matrix for the long ones.
+// One operand matrix of the iteration: a plain CSR stream or the slab layout for the majors that are summed
+// left to right, plus the segment tasks of the long ones.
 struct MatView {
   SpmvMat csr;
   SlabMat slab;
+  LongMat lng;
   int32_t useSlab;
-  int32_t nPartials;  // slab.nBlocks (if used) + csr.nBlocks
+  int32_t nPartials;  // slab.nBlocks (if used) + csr.nBlocks + lng.nSlots
   int32_t xcdMap;     // 1: XCD x owns a contiguous range of work blocks, 0: round robin (chosen per operand at setup)
 };
 

@@ -46,6 +46,41 @@ bool chooseSlab(int mode, int32_t nMajor, int32_t nMinor) {
 }
 }  // namespace
 
+// Stream plan (blocks of whole short majors) and segment tasks (long majors) of the CSR arrays in beg/idx/val.
+// Slab layout: those arrays hold only the majors longer than kSlabLongLimit, so chunk = that limit and every one
+// of them becomes segment tasks (longVecIndex = compact index -> major).
+void DeviceMatrix::uploadPlans(const std::vector<int32_t>& hostBeg, int32_t nCsrMajor, const int32_t* longVecIndex,
+                               hipStream_t s) {
+  const int64_t nnzCsr = nCsrMajor > 0 ? (int64_t)hostBeg[nCsrMajor] : 0;
+  chunk = spmvChunkFor(nnzCsr);
+  StreamPlan plan = planStream(hostBeg, nCsrMajor, useSlab ? kSlabLongLimit : chunk, kMaxMajorsPerBlock);
+  if (useSlab && plan.nBlocks != 0) throw std::runtime_error("slab layout: a short major in the side matrix");
+  nBlocks = plan.nBlocks;
+  blockBeg.alloc(plan.blockBeg.size());
+  blockBeg.upload(plan.blockBeg.data(), plan.blockBeg.size(), s);
+  std::vector<int32_t> vecIdx;
+  if (longVecIndex)
+    for (int32_t c : plan.longMajors) vecIdx.push_back(longVecIndex[c]);
+  static_assert(sizeof(LongTask) == sizeof(LongTaskHost) && sizeof(LongTask) == 32, "task record layout");
+  LongPlan L = planLong(hostBeg, plan.longMajors, longVecIndex ? vecIdx.data() : nullptr,
+                        (useSlab ? kSlabThreads : kSpmvThreads) / 64);
+  nLong = L.nLong;
+  nTasks = L.nTasks;
+  longGroup = nLong > kLongSlotCap ? (nLong + kLongSlotCap - 1) / kLongSlotCap : 1;
+  longSlots = (nLong + longGroup - 1) / longGroup;
+  lTasks.alloc((size_t)nTasks);
+  lTasks.upload(reinterpret_cast<const LongTask*>(L.tasks.data()), (size_t)nTasks, s);
+  lSegSum.alloc((size_t)nTasks);
+  lSegSum.zero(s);
+  lTicket.alloc((size_t)nLong);
+  lTicket.zero(s);
+  if (longGroup > 1) {
+    lContrib.alloc((size_t)2 * nLong);
+    lContrib.zero(s);
+  }
+  PDLP_HIP(hipStreamSynchronize(s));  // host vectors go out of scope
+}
+
 void DeviceMatrix::upload(const Compressed& cIn, int32_t nMajor_, int32_t nMinor_, int mode, hipStream_t s) {
   nMajor = nMajor_;
   nnz = cIn.beg.empty() ? 0 : cIn.beg[nMajor_];
@@ -67,24 +102,18 @@ void DeviceMatrix::upload(const Compressed& cIn, int32_t nMajor_, int32_t nMinor
     longMask.upload(L.longMask.data(), L.longMask.size(), s);
     slab = SlabMat{wavePtr.get(), ent.get(), slabVal.get(), longMask.get(), nMajor_, L.nBlocks, L.rowsPerBlock, L.minorBits};
     c = &L.longCsr;
-    majorMap.alloc(L.longMap.size());
-    majorMap.upload(L.longMap.data(), L.longMap.size(), s);
   }
   const int32_t nCsrMajor = useSlab ? (int32_t)L.longMap.size() : nMajor_;
   const int64_t nnzCsr = c->beg[nCsrMajor];
-  chunk = spmvChunkFor(nnzCsr);
-  StreamPlan plan = planStream(c->beg, nCsrMajor, chunk, kMaxMajorsPerBlock);
-  nBlocks = nCsrMajor > 0 ? plan.nBlocks : 0;
   beg.alloc(c->beg.size());
   idx.alloc((size_t)nnzCsr + 1);  // one pad element: the kernels clamp, never predicate, their loads
   val.alloc((size_t)nnzCsr + 1);
   idx.zero(s);
   val.zero(s);
-  blockBeg.alloc(plan.blockBeg.size());
   beg.upload(c->beg.data(), c->beg.size(), s);
   idx.upload(c->idx.data(), (size_t)nnzCsr, s);
   val.upload(c->val.data(), (size_t)nnzCsr, s);
-  blockBeg.upload(plan.blockBeg.data(), plan.blockBeg.size(), s);
+  uploadPlans(c->beg, nCsrMajor, useSlab ? L.longMap.data() : nullptr, s);
   PDLP_HIP(hipStreamSynchronize(s));  // host vectors may go out of scope
 }
 
@@ -92,7 +121,7 @@ void DeviceMatrix::buildFromDevice(DeviceCsrData& M, int mode, hipStream_t s) {
   nMajor = M.nMajor;
   nnz = M.nnz;
   useSlab = chooseSlab(mode, M.nMajor, M.nMinor);
-  std::vector<int32_t> hostBeg;
+  std::vector<int32_t> hostBeg, hostLongMap;
   int32_t nCsrMajor = nMajor;
   if (useSlab) {
     DeviceSlabLayout L;
@@ -106,9 +135,11 @@ void DeviceMatrix::buildFromDevice(DeviceCsrData& M, int mode, hipStream_t s) {
     beg = std::move(L.longCsr.beg);
     idx = std::move(L.longCsr.idx);
     val = std::move(L.longCsr.val);
-    majorMap = std::move(L.longMap);
     hostBeg = L.hostLongBeg;
     nCsrMajor = L.nLong;
+    hostLongMap.resize((size_t)L.nLong);
+    L.longMap.download(hostLongMap.data(), (size_t)L.nLong, s);
+    PDLP_HIP(hipStreamSynchronize(s));
   } else {
     beg = std::move(M.beg);
     idx = std::move(M.idx);  // allocated with one pad element
@@ -117,19 +148,16 @@ void DeviceMatrix::buildFromDevice(DeviceCsrData& M, int mode, hipStream_t s) {
     beg.download(hostBeg.data(), hostBeg.size(), s);
     PDLP_HIP(hipStreamSynchronize(s));
   }
-  chunk = spmvChunkFor(nCsrMajor > 0 ? (int64_t)hostBeg[nCsrMajor] : 0);
-  StreamPlan plan = planStream(hostBeg, nCsrMajor, chunk, kMaxMajorsPerBlock);
-  nBlocks = nCsrMajor > 0 ? plan.nBlocks : 0;
-  blockBeg.alloc(plan.blockBeg.size());
-  blockBeg.upload(plan.blockBeg.data(), plan.blockBeg.size(), s);
-  PDLP_HIP(hipStreamSynchronize(s));
+  uploadPlans(hostBeg, nCsrMajor, useSlab ? hostLongMap.data() : nullptr, s);
 }
 
 MatView DeviceMatrix::view() const {
   MatView v{};
-  v.csr = SpmvMat{beg.get(), idx.get(), val.get(), blockBeg.get(), nMajor, nBlocks,
-                  useSlab ? majorMap.get() : nullptr, useSlab ? slab.nBlocks : 0, chunk};
+  const int32_t slabBlocks = useSlab ? slab.nBlocks : 0;
+  v.csr = SpmvMat{beg.get(), idx.get(), val.get(), blockBeg.get(), nMajor, nBlocks, slabBlocks, chunk};
   v.slab = slab;
+  v.lng = LongMat{idx.get(), val.get(), lTasks.get(), lSegSum.get(), lTicket.get(), longGroup > 1 ? lContrib.get() : nullptr,
+                  nLong, nTasks, slabBlocks + nBlocks, longSlots, longGroup};
   v.useSlab = useSlab ? 1 : 0;
   v.xcdMap = xcdMap;
   v.nPartials = nPartials();
@@ -1261,9 +1289,9 @@ double Solver::timeKernel(const std::string& name, int32_t reps) {
       launchDecide(dst(), partDY_.get(), dA_.nPartials(), partDX_.get(), partInter_.get(), dAt_.nPartials(), nullptr, stream_);
     else if (name == "trial") enqueueTrial();
     else if (name == "spmv_ax_plain") launchSpmvPlain(dA_.view(), x_[0].get(), tmpM_.get(), stream_);
-    else if (name == "spmv_ax_plain_slab" || name == "spmv_ax_plain_side") {  // the two launches of a slab-layout A x apart
+    else if (name == "spmv_ax_plain_nolong") {  // A x without the segment tasks of its long majors
       MatView v = dA_.view();
-      if (name == "spmv_ax_plain_slab") v.csr.nBlocks = 0; else v.slab.nBlocks = 0;
+      v.lng.nTasks = 0;
       launchSpmvPlain(v, x_[0].get(), tmpM_.get(), stream_);
     }
     else if (name == "spmv_aty_plain") launchSpmvPlain(dAt_.view(), y_[0].get(), commBuf_.get(), stream_);

@@ -18,23 +18,32 @@
 
 namespace pdlp {
 
-// One operand matrix in HBM: CSR stream plan, or slab layout + CSR side matrix of long majors.
+// One operand matrix in HBM: CSR stream plan or slab layout for the majors that are summed left to right,
+// segment tasks for the long ones (pdlp_host.hpp LongPlan).
 struct DeviceMatrix {
-  DeviceArray<int32_t> beg, idx, blockBeg, majorMap, wavePtr;
+  DeviceArray<int32_t> beg, idx, blockBeg, wavePtr;
   DeviceArray<uint32_t> ent, longMask;
   DeviceArray<double> val, slabVal;
+  // long majors
+  DeviceArray<LongTask> lTasks;
+  DeviceArray<double> lSegSum, lContrib;
+  DeviceArray<uint32_t> lTicket;
+  int32_t nLong = 0, nTasks = 0, longSlots = 0, longGroup = 1;
   int32_t nMajor = 0, nBlocks = 0;  // nBlocks = CSR stream blocks
   int32_t chunk = kChunk;           // work-plan block size of the CSR stream (spmvChunkFor)
   int64_t nnz = 0;
   bool useSlab = false;
   int32_t xcdMap = 1;  // block -> XCD assignment of the SpMV kernels (pdlp_kernels.hip xcdContiguousBlock), see tuneXcdMap
   SlabMat slab{};
-  // mode: 0 = CSR stream only, 1 = slab layout (+ long-major side CSR), -1 = auto by nMinor
+  // mode: 0 = CSR stream only, 1 = slab layout, -1 = auto by nMinor
   void upload(const Compressed& c, int32_t nMajor_, int32_t nMinor_, int mode, hipStream_t s);
   // same, from a matrix that is already in HBM (GPU-side setup); takes M's arrays
   void buildFromDevice(DeviceCsrData& M, int mode, hipStream_t s);
   MatView view() const;
-  int32_t nPartials() const { return (useSlab ? slab.nBlocks : 0) + nBlocks; }
+  int32_t nPartials() const { return (useSlab ? slab.nBlocks : 0) + nBlocks + longSlots; }
+
+ private:
+  void uploadPlans(const std::vector<int32_t>& hostBeg, int32_t nCsrMajor, const int32_t* longVecIndex, hipStream_t s);
 };
 
 // Picks M.xcdMap by timing the plain SpMV out = M * in with both block -> XCD assignments (a few launches; the

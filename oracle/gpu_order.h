@@ -47,33 +47,44 @@ static inline double g_block_sum_n(const double* perThread, int nThreads) {
   return r;
 }
 static inline double g_block_sum(const double* perThread /* [256] */) { return g_block_sum_n(perThread, G_T); }
-/* value of one major of a CSR stream (k_spmv): left to right, except majors longer than the stream's chunk
- * (block-strided over 256 lanes + block tree) */
-static inline double g_major_sum(const int* beg, const int* idx, const double* val, const double* in, int r, int chunk) {
+/* A long major (pdlp_kernels.hip longTask): segments of 512 * 2^k entries (smallest k with at most 64 segments);
+ * within a segment lane l adds the products of the entries l, l+64, ... in ascending order, then the 64-lane
+ * shuffle tree; the segment sums are added left to right. */
+enum { G_LONG_SEG = 512, G_LONG_MAXSEG = 64, G_LONG_SLOT_CAP = 2048, G_SLAB_LONG = 256 };
+static inline double g_long_major_sum(const int* idx, const double* val, const double* in, int p0, int len) {
+  long seg = G_LONG_SEG;
+  while ((len + seg - 1) / seg > G_LONG_MAXSEG) seg *= 2;
+  double total = 0.0;
+  for (long sb = 0; sb < len; sb += seg) {
+    const long se = sb + seg < len ? sb + seg : len;
+    double lane[G_WAVE];
+    for (int l = 0; l < G_WAVE; ++l) {
+      double s = 0.0;
+      for (long q = sb + l; q < se; q += G_WAVE) s += val[p0 + q] * in[idx[p0 + q]];
+      lane[l] = s;
+    }
+    total += g_wave_tree(lane);
+  }
+  return total;
+}
+/* value of one major: left to right up to longLimit entries, segment tasks beyond */
+static inline double g_major_sum(const int* beg, const int* idx, const double* val, const double* in, int r, int longLimit) {
   const int p0 = beg[r], p1 = beg[r + 1];
-  if (p1 - p0 <= chunk) {
+  if (p1 - p0 <= longLimit) {
     double s = 0.0;
     for (int p = p0; p < p1; ++p) s += val[p] * in[idx[p]];
     return s;
   }
-  double lane[G_T];
-  for (int t = 0; t < G_T; ++t) {
-    double s = 0.0;
-    for (int p = p0 + t; p < p1; p += G_T) s += val[p] * in[idx[p]];
-    lane[t] = s;
-  }
-  return g_block_sum(lane);
+  return g_long_major_sum(idx, val, in, p0, p1 - p0);
 }
-/* chunk of the kernel that sums the long majors of one operand: the CSR stream itself (chunk by its nnz), or — slab
- * layout — the side stream of the majors longer than 256 (chunk by THEIR nnz).  layoutMode as in pdlp_oracle.c:
- * 0 = the product's automatic rule (slab when the gathered vector has >= 2^18 entries), 1 = CSR, 2 = slab. */
+/* the longest major that is still summed left to right: the CSR stream's chunk (by its nnz), or 256 in the slab
+ * layout.  layoutMode as in pdlp_oracle.c: 0 = the product's automatic rule (slab when the gathered vector has
+ * >= 2^18 entries), 1 = CSR, 2 = slab. */
 static inline int g_long_major_chunk(const int* beg, int nMajor, int nMinor, int layoutMode) {
   int slab = layoutMode == 2 || (layoutMode == 0 && nMinor >= (1 << 18));
   if (slab && g_slab_rows_per_wave(nMajor, nMinor) == 0) slab = 0;
   if (!slab) return g_chunk_for(nMajor > 0 ? beg[nMajor] : 0);
-  long longNnz = 0;
-  for (int i = 0; i < nMajor; ++i) if (beg[i + 1] - beg[i] > 256) longNnz += beg[i + 1] - beg[i];
-  return g_chunk_for(longNnz);
+  return G_SLAB_LONG;
 }
 /* reducePartials: lane t sums p[t], p[t+256], ... in 4 independent chains */
 static inline double g_reduce_partials(const double* p, int count) {

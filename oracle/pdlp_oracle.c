@@ -358,33 +358,29 @@ static void o_ATy(const Work* w, double* aty, const double* y) {
 /* nonzeros / 2048 majors per work block, vector grids capped at 2048. */
 /* ------------------------------------------------------------------ */
 #include "gpu_order.h"
-/* planStream (pdlp_host.cpp) */
-static int* g_plan(const int* beg, int nMajor, int* nBlocksOut) {
-  const int chunk = g_chunk_for(nMajor > 0 ? beg[nMajor] : 0);
-  int* plan = ialloc((long)nMajor + 2);
+/* planStream (pdlp_host.cpp): blocks of whole majors with at most `chunk` entries in total; a major longer than
+ * chunk belongs to no block.  Returns [2*nBlocks] (first, end) pairs. */
+static int* g_plan(const int* beg, int nMajor, int chunk, int* nBlocksOut) {
+  int* plan = ialloc(2 * (long)nMajor + 2);
   int nb = 0, start = 0;
-  plan[0] = 0;
   while (start < nMajor) {
+    if (beg[start + 1] - beg[start] > chunk) { ++start; continue; }
     const int base = beg[start];
     int end = start;
     while (end < nMajor && end - start < G_MAXMAJ && beg[end + 1] - base <= chunk) ++end;
-    if (end == start) end = start + 1;
-    plan[++nb] = end;
+    plan[2 * nb] = start; plan[2 * nb + 1] = end; ++nb;
     start = end;
   }
   *nBlocksOut = nb;
   return plan;
 }
-/* chunk = the block size of the kernel that owns the majors which are not summed left to right by the slab kernel:
- * the CSR stream itself, or the slab layout's side CSR of majors longer than 256 (its own, smaller nnz count) */
-static void g_spmv(const int* beg, const int* idx, const double* val, int nMajor, const double* in, double* out, int chunk) {
-  for (int r = 0; r < nMajor; ++r) out[r] = g_major_sum(beg, idx, val, in, r, chunk);
+static void g_spmv(const int* beg, const int* idx, const double* val, int nMajor, const double* in, double* out, int longLimit) {
+  for (int r = 0; r < nMajor; ++r) out[r] = g_major_sum(beg, idx, val, in, r, longLimit);
 }
-/* per-block partial of a per-major quantity: lane t accumulates majors r0+t, r0+t+256, ...;
- * a long-major block has its single value on lane 0 */
+/* per-block partial of a per-major quantity: lane t accumulates majors r0+t, r0+t+256, ... */
 static double g_block_partial(const int* plan, int blk, const double* perMajor) {
   double lane[G_T];
-  const int r0 = plan[blk], r1 = plan[blk + 1];
+  const int r0 = plan[2 * blk], r1 = plan[2 * blk + 1];
   for (int t = 0; t < G_T; ++t) {
     double a = 0.0;
     for (int r = r0 + t; r < r1; r += G_T) a += perMajor[r];
@@ -392,23 +388,7 @@ static double g_block_partial(const int* plan, int blk, const double* perMajor) 
   }
   return g_block_sum(lane);
 }
-enum { G_SLAB_LONG = 256, G_SLAB_AUTO_MINOR = 1 << 18 };
-/* slab layout parameters of one operand (pdlp_host.cpp buildSlabLayout) */
-static void g_slab_setup(const int* beg, int nMajor, int nMinor, int* R, int* nLong, int** longMap, int** longBeg,
-                         int** sidePlan, int* nSidePlan) {
-  *R = g_slab_rows_per_wave(nMajor, nMinor) * G_SLAB_WAVES;
-  int nl = 0;
-  for (int i = 0; i < nMajor; ++i) if (beg[i + 1] - beg[i] > G_SLAB_LONG) ++nl;
-  *nLong = nl;
-  *longMap = ialloc(nl + 1);
-  *longBeg = ialloc(nl + 2);
-  int k = 0;
-  (*longBeg)[0] = 0;
-  for (int i = 0; i < nMajor; ++i)
-    if (beg[i + 1] - beg[i] > G_SLAB_LONG) { (*longMap)[k] = i; (*longBeg)[k + 1] = (*longBeg)[k] + (beg[i + 1] - beg[i]); ++k; }
-  *sidePlan = g_plan(*longBeg, nl, nSidePlan);
-  if (nl == 0) *nSidePlan = 0;
-}
+enum { G_SLAB_AUTO_MINOR = 1 << 18 };
 
 static void g_setup(Work* w, int layoutMode) {
   const int n = w->n, m = w->m;
@@ -427,56 +407,61 @@ static void g_setup(Work* w, int layoutMode) {
   w->slabAt = layoutMode == 2 || (layoutMode == 0 && m >= G_SLAB_AUTO_MINOR);  /* A' gathers y (m) */
   if (w->slabA && g_slab_rows_per_wave(m, n) == 0) w->slabA = 0;   /* minors do not fit the entry packing */
   if (w->slabAt && g_slab_rows_per_wave(n, m) == 0) w->slabAt = 0;
-  if (w->slabA) g_slab_setup(w->csrBeg, m, n, &w->RA, &w->nLongA, &w->longMapA, &w->longBegA, &w->planA, &w->nPlanA);
-  else w->planA = g_plan(w->csrBeg, m, &w->nPlanA);
-  if (w->slabAt) g_slab_setup(w->cssBeg, n, m, &w->RAt, &w->nLongAt, &w->longMapAt, &w->longBegAt, &w->planAt, &w->nPlanAt);
-  else w->planAt = g_plan(w->cssBeg, n, &w->nPlanAt);
-  w->chunkA = g_chunk_for(w->slabA ? w->longBegA[w->nLongA] : w->nnz);
-  w->chunkAt = g_chunk_for(w->slabAt ? w->longBegAt[w->nLongAt] : w->nnz);
-  const long mx = (n > m ? n : m) + G_MAXGRID + 8;
+  /* the longest major that is summed left to right (longer ones: segment tasks, gpu_order.h g_long_major_sum) */
+  w->chunkA = w->slabA ? G_SLAB_LONG : g_chunk_for(w->nnz);
+  w->chunkAt = w->slabAt ? G_SLAB_LONG : g_chunk_for(w->nnz);
+  if (w->slabA) { w->RA = g_slab_rows_per_wave(m, n) * G_SLAB_WAVES; w->planA = ialloc(2); w->nPlanA = 0; }
+  else w->planA = g_plan(w->csrBeg, m, w->chunkA, &w->nPlanA);
+  if (w->slabAt) { w->RAt = g_slab_rows_per_wave(n, m) * G_SLAB_WAVES; w->planAt = ialloc(2); w->nPlanAt = 0; }
+  else w->planAt = g_plan(w->cssBeg, n, w->chunkAt, &w->nPlanAt);
+  const long mx = 2L * (n > m ? n : m) + G_MAXGRID + 8;
   w->gPartA = dalloc(mx); w->gPartB = dalloc(mx); w->gStat = dalloc(mx);
 }
 
-/* Fixed-order total of a per-major quantity exactly as the SpMV epilogues + k_decide add it up.
- * CSR stream: one partial per work block.  Slab: one partial per 1024-thread block of R majors (long majors
- * skipped), then one per work block of the CSR side kernel over the compacted long majors. */
+/* Fixed-order total of a per-major quantity exactly as the SpMV epilogues + k_decide add it up.  Partial slots:
+ * one per work block of the stream (CSR layout) or per 1024-thread block of R majors (slab layout; long majors
+ * skipped), then the long majors in ascending order — one slot each, or, beyond 2048 of them, one slot per group
+ * of G consecutive ones added left to right (k_long_groups). */
 static double g_epilogue_total(Work* w, int isAt, const double* perMajor) {
   const int nMajor = isAt ? w->n : w->m;
   const int slab = isAt ? w->slabAt : w->slabA;
   const int* plan = isAt ? w->planAt : w->planA;
   const int nPlan = isAt ? w->nPlanAt : w->nPlanA;
+  const int limit = isAt ? w->chunkAt : w->chunkA;
+  const int* beg = isAt ? w->cssBeg : w->csrBeg;
   double* part = w->gPartA;
   int np = 0;
   if (!slab) {
     for (int b = 0; b < nPlan; ++b) part[np++] = g_block_partial(plan, b, perMajor);
-    return g_reduce_partials(part, np);
-  }
-  const int R = isAt ? w->RAt : w->RA, nLong = isAt ? w->nLongAt : w->nLongA;
-  const int* beg = isAt ? w->cssBeg : w->csrBeg;
-  const int* longMap = isAt ? w->longMapAt : w->longMapA;
-  const int nBlocks = (nMajor + R - 1) / R;
-  for (int b = 0; b < nBlocks; ++b) { /* k_spmv_slab: 1024 threads, thread t owns majors b*R + t, + 1024, ... */
-    double lane[G_SLAB_T];
-    const int rEnd = (b + 1) * R < nMajor ? (b + 1) * R : nMajor;
-    for (int t = 0; t < G_SLAB_T; ++t) {
-      double a = 0.0;
-      for (int r = b * R + t; r < rEnd; r += G_SLAB_T)
-        if (beg[r + 1] - beg[r] <= G_SLAB_LONG) a += perMajor[r];
-      lane[t] = a;
+  } else {
+    const int R = isAt ? w->RAt : w->RA;
+    const int nBlocks = (nMajor + R - 1) / R;
+    for (int b = 0; b < nBlocks; ++b) { /* k_spmv_slab: 1024 threads, thread t owns majors b*R + t, + 1024, ... */
+      double lane[G_SLAB_T];
+      const int rEnd = (b + 1) * R < nMajor ? (b + 1) * R : nMajor;
+      for (int t = 0; t < G_SLAB_T; ++t) {
+        double a = 0.0;
+        for (int r = b * R + t; r < rEnd; r += G_SLAB_T)
+          if (beg[r + 1] - beg[r] <= limit) a += perMajor[r];
+        lane[t] = a;
+      }
+      part[np++] = g_block_sum_n(lane, G_SLAB_T);
     }
-    part[np++] = g_block_sum_n(lane, G_SLAB_T);
   }
-  for (int b = 0; b < nPlan; ++b) { /* side kernel: compact major c stands for major longMap[c] */
-    double lane[G_T];
-    const int c0 = plan[b], c1 = plan[b + 1];
-    for (int t = 0; t < G_T; ++t) {
-      double a = 0.0;
-      for (int c = c0 + t; c < c1; c += G_T) a += perMajor[longMap[c]];
-      lane[t] = a;
+  int nLong = 0;
+  for (int r = 0; r < nMajor; ++r) if (beg[r + 1] - beg[r] > limit) ++nLong;
+  if (nLong > 0) {
+    const int G = nLong > G_LONG_SLOT_CAP ? (nLong + G_LONG_SLOT_CAP - 1) / G_LONG_SLOT_CAP : 1;
+    int c = 0;
+    double acc = 0.0;
+    for (int r = 0; r < nMajor; ++r) {
+      if (beg[r + 1] - beg[r] <= limit) continue;
+      if (c % G == 0) acc = 0.0;
+      acc += perMajor[r];
+      ++c;
+      if (c % G == 0 || c == nLong) part[np++] = acc;
     }
-    part[np++] = g_block_sum(lane);
   }
-  (void)nLong;
   return g_reduce_partials(part, np);
 }
 
@@ -1187,6 +1172,14 @@ void pdlp_oracle_spmv_csr(int m, const int* beg, const int* idx, const double* v
     for (int p = beg[i]; p < beg[i + 1]; ++p) s += val[p] * x[idx[p]];
     out[i] = s;
   }
+}
+
+/* the same in the product's summation order: majors with more than long_limit entries are cut into segment tasks
+ * (gpu_order.h g_long_major_sum); long_limit = the stream's chunk (512 below 2^18 nonzeros, else 2048) or 256 in
+ * the slab layout */
+void pdlp_oracle_spmv_csr_device_order(int m, const int* beg, const int* idx, const double* val,
+                                       const double* x, double* out, int long_limit) {
+  for (int i = 0; i < m; ++i) out[i] = g_major_sum(beg, idx, val, x, i, long_limit);
 }
 
 /* One trial step of cupdlp_step.c:241-257 + linalg.c:772-801 on caller vectors

@@ -47,6 +47,8 @@ void pdlp_oracle_free_formulated(pdlp_oracle_formulated_t* F);
 
 void pdlp_oracle_spmv_csr(int m, const int* beg, const int* idx, const double* val,
                           const double* x, double* out);
+void pdlp_oracle_spmv_csr_device_order(int m, const int* beg, const int* idx, const double* val,
+                                       const double* x, double* out, int long_limit);
 void pdlp_oracle_trial_step(const pdlp_oracle_formulated_t* F, double tau, double sigma,
                             const double* x, const double* y, const double* ax, const double* aty,
                             double* xU, double* yU, double* axU, double* atyU, double* out3);

@@ -56,6 +56,7 @@ def oracle():
         lib.pdlp_oracle_formulate_scale.restype = C.c_int
         lib.pdlp_oracle_free_formulated.argtypes = [C.POINTER(Formulated)]
         lib.pdlp_oracle_spmv_csr.argtypes = [C.c_int, abi.c_i32p, abi.c_i32p, abi.c_f64p, abi.c_f64p, abi.c_f64p]
+        lib.pdlp_oracle_spmv_csr_device_order.argtypes = lib.pdlp_oracle_spmv_csr.argtypes + [C.c_int]
         lib.pdlp_oracle_trial_step.argtypes = [C.POINTER(Formulated), C.c_double, C.c_double] + [abi.c_f64p] * 9
         _oracle = lib
     return _oracle

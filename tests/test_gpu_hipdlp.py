@@ -31,10 +31,11 @@ def test_halpern_steps_bit_exact(name, steps, spmv_layout):
     """The fused step kernels (A'y + primal projection/reflection/blend, A x + dual ones) reproduce the
     oracle's x, y, x_next, y_next bit for bit over a block of Halpern steps with the same step sizes
     (element-wise arithmetic in the reference's order, majors summed left to right).  standgub has rows longer
-    than the 512-entry SpMV block of small operands, which the GPU sums block-strided: there the oracle runs in
-    its device reduction order (oracle/gpu_order.h g_major_sum)."""
+    than the 512-entry SpMV block of small operands, 25fv47 rows longer than the slab layout's 256: the GPU sums
+    those as segment tasks, and there the oracle runs in its device reduction order (oracle/gpu_order.h
+    g_major_sum)."""
     lp = _lp(name)
-    long_majors = name == "standgub"
+    long_majors = name == "standgub" or (name == "25fv47" and spmv_layout == "slab")
     ref = O.hipdlp_probe(lp, steps, **(dict(device_reduction_order=True, device_layout=spmv_layout) if long_majors else {}))
     S = solver.DeviceSolver(lp=lp, solver="hipdlp")
     st = S.get("steps", 8)

@@ -19,11 +19,17 @@ def _lp(name):
     return L.HighsLp.from_npz(os.path.join(GOLD, "instances", name + ".npz"))
 
 
-def _spmv(beg, idx, val, x, m):
+def _spmv(beg, idx, val, x, m, long_limit=None):
+    """Left-to-right row sums (the reference's order); with long_limit, majors longer than that in the product's
+    segment-task order (oracle/gpu_order.h g_long_major_sum)."""
     out = np.zeros(m)
     p = lambda a, t: np.ascontiguousarray(a).ctypes.data_as(t)
-    O.oracle().pdlp_oracle_spmv_csr(m, p(beg, abi.c_i32p), p(idx, abi.c_i32p), p(val, abi.c_f64p),
-                                    np.ascontiguousarray(x).ctypes.data_as(abi.c_f64p), out.ctypes.data_as(abi.c_f64p))
+    args = (m, p(beg, abi.c_i32p), p(idx, abi.c_i32p), p(val, abi.c_f64p),
+            np.ascontiguousarray(x).ctypes.data_as(abi.c_f64p), out.ctypes.data_as(abi.c_f64p))
+    if long_limit is None:
+        O.oracle().pdlp_oracle_spmv_csr(*args)
+    else:
+        O.oracle().pdlp_oracle_spmv_csr_device_order(*args, long_limit)
     return out
 
 
@@ -44,7 +50,8 @@ def spmv_layout(request, monkeypatch):
 @pytest.mark.parametrize("which", ["25fv47", "shell", "synthetic"])
 def test_spmv_bit_exact(which, spmv_layout):
     """A x (CSR) and A' y (CSC) — integer-exact placement and, because every major is summed left to
-    right like AxCPU/ATyCPU (cupdlp_linalg.c:35-109), bit-identical values."""
+    right like AxCPU/ATyCPU (cupdlp_linalg.c:35-109), bit-identical values.  (Slab layout: majors longer than 256
+    — 25fv47 has some — are segment tasks; those follow the modelled order of oracle/gpu_order.h.)"""
     for name, lp, sp_ in _problems():
         if name != which:
             continue
@@ -58,8 +65,11 @@ def test_spmv_bit_exact(which, spmv_layout):
         S.set("y", y)
         S.stage("ax")
         S.stage("aty")
-        assert np.array_equal(S.get("ax", P.m), _spmv(P.csr_beg, P.csr_idx, P.csr_val, x, P.m))
-        assert np.array_equal(S.get("aty", P.n), _spmv(P.csc_beg, P.csc_idx, P.csc_val, y, P.n))
+        limit = 256 if spmv_layout == "slab" else None
+        if limit is None:
+            assert max(np.diff(P.csr_beg).max(), np.diff(P.csc_beg).max()) <= (512 if P.nnz < 2**18 else 2048)
+        assert np.array_equal(S.get("ax", P.m), _spmv(P.csr_beg, P.csr_idx, P.csr_val, x, P.m, limit))
+        assert np.array_equal(S.get("aty", P.n), _spmv(P.csc_beg, P.csc_idx, P.csc_val, y, P.n, limit))
         S.close()
 
 
@@ -78,8 +88,8 @@ def test_spmv_wide_matrix_many_slabs(spmv_layout):
 
 
 def test_spmv_long_and_empty_majors(spmv_layout):
-    """Rows longer than one LDS chunk (512 nnz for operands below 2^18 nonzeros, 2048 above: spmvChunkFor) take
-    the block-per-row path; empty rows/cols give 0."""
+    """Rows longer than one LDS chunk (512 nnz for operands below 2^18 nonzeros, 2048 above: spmvChunkFor; 256 in
+    the slab layout) are cut into segment tasks; empty rows/cols give 0."""
     rng = np.random.default_rng(1)
     n, m = 6000, 40
     rows, cols, vals = [], [], []
@@ -102,11 +112,14 @@ def test_spmv_long_and_empty_majors(spmv_layout):
     ax_o = _spmv(P.csr_beg, P.csr_idx, P.csr_val, x, P.m)
     ax_g = S.get("ax", P.m)
     lens = np.diff(P.csr_beg)
-    short = lens <= 512  # this operand is small: chunk 512
+    limit = 256 if spmv_layout == "slab" else 512  # this operand is small: chunk 512
+    short = lens <= limit
+    assert (~short).sum() == 2
     assert np.array_equal(ax_g[short], ax_o[short])
     assert ax_g[lens == 0].tolist() == [0.0] * int((lens == 0).sum())
     scale = _spmv(P.csr_beg, P.csr_idx, np.abs(P.csr_val), np.abs(x), P.m)
-    assert np.all(np.abs(ax_g - ax_o) <= 1e-14 * (scale + 1))  # tree-summed long rows
+    assert np.all(np.abs(ax_g - ax_o) <= 1e-14 * (scale + 1))  # long rows: segment sums
+    assert np.array_equal(ax_g, _spmv(P.csr_beg, P.csr_idx, P.csr_val, x, P.m, limit))  # ... in exactly the modelled order
     assert np.array_equal(S.get("aty", P.n), _spmv(P.csc_beg, P.csc_idx, P.csc_val, y, P.n))
     S.close()
 
@@ -160,8 +173,14 @@ def _trial_step_check(lp, sp_):
         O.oracle().pdlp_oracle_trial_step(C.byref(F), tau, sigma, d(x), d(y), d(ax), d(aty), d(xo), d(yo), d(axo),
                                           d(atyo), d(o3))
         O.oracle().pdlp_oracle_free_formulated(C.byref(F))
-        assert np.array_equal(xg, xo) and np.array_equal(axg, axo)
-        assert np.array_equal(yg, yo) and np.array_equal(atyg, atyo)
+        slab = os.environ.get("PDLP_MI355X_SLAB") == "1" or (os.environ.get("PDLP_MI355X_SLAB") is None and max(n, m) >= 2**18)
+        longest = max(np.diff(Fv.csr_beg).max(), np.bincount(Fv.csr_idx, minlength=n).max())
+        if longest <= (256 if slab else 512 if Fv.nnz < 2**18 else 2048):
+            assert np.array_equal(xg, xo) and np.array_equal(axg, axo)
+            assert np.array_equal(yg, yo) and np.array_equal(atyg, atyo)
+        else:  # long majors are summed as segment tasks (bit-exactness in THAT order: test_gpu_bitexact.py)
+            assert np.array_equal(xg, xo) and np.allclose(axg, axo, rtol=1e-12, atol=1e-13)
+            assert np.allclose(yg, yo, rtol=1e-12, atol=1e-13) and np.allclose(atyg, atyo, rtol=1e-11, atol=1e-12)
         assert np.allclose(out[:3], o3, rtol=1e-12, atol=0)
         # the decision itself (cupdlp_step.c:266-285)
         sb = np.sqrt(beta)
@@ -448,7 +467,7 @@ def test_gpu_setup_gives_identical_solve(layout, monkeypatch):
 
 
 def test_gpu_setup_long_rows_slab_layout(monkeypatch):
-    """Device-built slab layout with long majors (> 256 nnz) routed to the CSR side kernel."""
+    """Device-built slab layout with long majors (> 256 nnz) cut into segment tasks."""
     monkeypatch.setenv("PDLP_MI355X_SLAB", "1")
     monkeypatch.setenv("PDLP_MI355X_GPU_SETUP", "1")
     rng = np.random.default_rng(1)
@@ -469,8 +488,10 @@ def test_gpu_setup_long_rows_slab_layout(monkeypatch):
     ax_o = _spmv(P.csr_beg, P.csr_idx, P.csr_val, x, P.m)
     lens = np.diff(P.csr_beg)
     ax_g = S.get("ax", P.m)
-    assert np.array_equal(ax_g[lens <= 512], ax_o[lens <= 512])  # (the side CSR of the long majors is small: chunk 512)
+    assert (lens > 256).sum() == 3
+    assert np.array_equal(ax_g[lens <= 256], ax_o[lens <= 256])
     assert np.allclose(ax_g, ax_o, rtol=1e-13, atol=1e-13)
+    assert np.array_equal(ax_g, _spmv(P.csr_beg, P.csr_idx, P.csr_val, x, P.m, 256))  # segment tasks, modelled order
     assert np.array_equal(S.get("aty", P.n), _spmv(P.csc_beg, P.csc_idx, P.csc_val, y, P.n))
     S.close()
 

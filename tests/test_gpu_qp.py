@@ -61,9 +61,12 @@ def test_synthetic_qp_iterates_and_improves():
     assert abs(lin.info["objective_function_value"] - k["objective_function_value"]) > 1e-3
 
 
-def test_off_diagonal_hessian_and_hipdlp_are_refused():
+def test_off_diagonal_hessian_and_hipdlp_are_refused(monkeypatch):
     lp = _qp("qp0")
     assert solver.solveLpHiPdlp(lp).status == solver.kError
+    monkeypatch.setenv("PDLP_MI355X_GPU_SETUP", "1")  # the device-side set-up never reads q_*: refused before it is chosen
+    assert solver.solveLpHiPdlp(lp).status == solver.kError and b"quadratic" in solver.lib().pdlp_mi355x_last_error()
+    monkeypatch.delenv("PDLP_MI355X_GPU_SETUP")
     st = np.arange(lp.num_col + 1, dtype=np.int32)
     idx = np.arange(lp.num_col, dtype=np.int32)
     idx[0] = 1

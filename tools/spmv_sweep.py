@@ -27,9 +27,15 @@ ap.add_argument("--nnz", type=int, default=8_000_000)
 ap.add_argument("--iters", type=int, default=600)
 ap.add_argument("--solver", choices=["pdlp", "hipdlp"], default="pdlp")
 ap.add_argument("--variants", default=DEFAULT)
+ap.add_argument("--structured", action="store_true", help="the block-angular LP of bench.py --config c instead")
 args = ap.parse_args()
 
-sp_ = solver.SyntheticProblem(args.m, args.n, args.nnz, 1)
+if args.structured:
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    from lpgen import structured_lp
+    sp_ = abi.ProblemHandle(structured_lp(1))
+else:
+    sp_ = solver.SyntheticProblem(args.m, args.n, args.nnz, 1)
 ref_hash = None
 for spec in args.variants.split(";"):
     for k in ENV.values():
