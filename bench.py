@@ -35,7 +35,7 @@ CONFIGS = {
     # diagonal Q, q_j ~ U(0,1) (numpy default_rng(1)).  No PDLP-QP exists in the reference: parity unpinned.
     # BASELINE.json configs[2] stand-in (pds-100 is not in the reference tree, no network): the block-angular
     # multi-commodity network LP of tests/lpgen.py::structured_lp — 64 network blocks, 256 dense linking rows of
-    # 4096 nonzeros (long-major side kernel), ranged and free rows: 2.1M columns, 263k rows, 5.3M nonzeros
+    # 4096 nonzeros (segment tasks), ranged and free rows: 2.1M columns, 263k rows, 5.3M nonzeros
     "c": dict(structured=True, name="structured block-angular network LP, 263k x 2.1M, 5.3M nnz, 256 dense linking rows (seed 1)"),
     "qp": dict(m=500_000, n=500_000, nnz=4_000_000, qp=True,
                name="synthetic random sparse QP 500kx500k, 4M nnz, diagonal Q ~ U(0,1) (seed 1)"),
@@ -313,6 +313,7 @@ def main():
                    "parallelism": "single GPU" if world == 1 else "row-block x%d, %s" % (world, exchange),
                    "options": "presolve=off, kkt_tolerance=1e-4, adaptive step + restarts (reference defaults)"},
         "trial_steps": int(st.trials), "rejected_trials": int(st.trials - st.iters), "checks": int(st.checks),
+        "trial_launches": int(S.stage("trial_launches")[0]) if args.solver == "pdlp" else 2,
         "restarts": int(st.restarts), "setup_seconds": t_setup, "ranks_bit_identical": rank_consistent,
         "exchange_fallback": exchange_fallback, "exchange": exchange if world > 1 else None, "exchange_waits": exchange_waits,
         "startup_ms_first_40": startup_ms,
@@ -340,9 +341,11 @@ def main():
     if args.solver == "hipdlp":
         out["config"]["options"] = "presolve=off, kkt_tolerance=1e-4, Halpern restarts + PID primal weight (reference defaults)"
     if cfg.get("structured") and world == 1 and args.solver == "pdlp":
-        # the dense linking rows (> 256 nonzeros) are left to the CSR side kernel: its share of the plain A x
-        side, slab = S.time_kernel("spmv_ax_plain_side", 50), S.time_kernel("spmv_ax_plain_slab", 50)
-        out["long_major_side_kernel"] = {"spmv_ax_side_ms": side, "spmv_ax_slab_ms": slab, "share": side / (side + slab)}
+        # the dense linking rows (> 256 nonzeros) are cut into segment tasks that run as extra workgroups of the SAME
+        # launch: what they add to the plain A x (they hold 20 % of the nonzeros of this LP)
+        full, nolong = S.time_kernel("spmv_ax_plain", 50), S.time_kernel("spmv_ax_plain_nolong", 50)
+        out["long_majors"] = {"spmv_ax_plain_ms": full, "without_the_long_majors_ms": nolong, "share": (full - nolong) / full,
+                              "share_of_nonzeros": 256 * 4096 / nnz}
     if args.kernels and rank == 0 and world == 1 and args.solver == "pdlp":
         ks = {k: S.time_kernel(k, 50) for k in ("decide_primal", "primal_step", "spmv_ax", "spmv_aty", "decide", "trial",
                                                 "spmv_ax_plain", "spmv_aty_plain", "copy")}

@@ -66,8 +66,14 @@ __device__ __attribute__((unused)) double reducePartials(const double* __restric
 // Accept/reject and step-size update of PDHG_Update_Iterate_Adaptive_Step_Size
 // (cupdlp_step.c:237-306), the bookkeeping of PDHG_Update_Average (:433-441)
 // and the parity flip that the reference gets from ++nIter.  One thread.
-__device__ __attribute__((unused)) void decideUpdate(DevState* st, double dX2, double dY2, double inter) {
-  DevState s = *st;
+// TABLE_ONLY (the fused trial kernel, which has no registers to spare for an inlined pow): the host-tabulated powers
+// must cover the trial counter — Solver::refreshPowTable keeps >= 1024 entries ahead at every stop; if they ever
+// do not, the state is flagged (commError) instead of silently taking the device's own pow.
+// QP with off-diagonal Hessian entries (no reference counterpart): the explicit N x term of the primal step is a
+// forward step on a smooth function, so the trial must also satisfy tau <= |dx|^2 / |dx . N dx|; with tau = eta/w the
+// two conditions combine to eta <= movement / (|interaction| + |dx . N dx| / 2), which is the LP rule for qint = 0.
+template <bool TABLE_ONLY>
+__device__ __forceinline__ void decideCore(DevState& s, double dX2, double dY2, double inter, double qint) {
   const double sb = sqrt(s.beta);
   const double movement = dX2 * 0.5 * sb + dY2 / (2.0 * sb);
   s.nTrials += 1;
@@ -75,18 +81,26 @@ __device__ __attribute__((unused)) void decideUpdate(DevState* st, double dX2, d
   double etaNew = s.eta;
   double limit = INFINITY;
   if (s.adaptive) {
-    limit = (inter != 0.0) ? movement / fabs(inter) : INFINITY;
+    const double den = fabs(inter) + 0.5 * fabs(qint);
+    limit = (den != 0.0) ? movement / den : INFINITY;
     accept = s.eta <= limit;
     const double k1 = (double)s.nTrials + 1.0;
     const int ti = s.nTrials - s.powBase;
     const bool tab = s.powRed != nullptr && ti >= 0 && ti < s.powCount;
-    const double pRed = tab ? s.powRed[ti] : pow(k1, -0.3);    // PDHG_STEPSIZE_REDUCTION_EXP
-    const double pGrow = tab ? s.powGrow[ti] : pow(k1, -0.6);  // PDHG_STEPSIZE_GROWTH_EXP
+    double pRed, pGrow;
+    if (TABLE_ONLY) {
+      pRed = tab ? s.powRed[ti] : 0.0;
+      pGrow = tab ? s.powGrow[ti] : 0.0;
+      if (!tab) s.commError = 1;
+    } else {
+      pRed = tab ? s.powRed[ti] : pow(k1, -0.3);    // PDHG_STEPSIZE_REDUCTION_EXP
+      pGrow = tab ? s.powGrow[ti] : pow(k1, -0.6);  // PDHG_STEPSIZE_GROWTH_EXP
+    }
     const double first = (1.0 - pRed) * limit;
     const double second = (1.0 + pGrow) * s.eta;
     etaNew = fmin(first, second);
   }
-  s.dX2 = dX2; s.dY2 = dY2; s.inter = inter; s.movement = movement; s.limit = limit;
+  s.dX2 = dX2; s.dY2 = dY2; s.inter = inter; s.movement = movement; s.limit = limit; s.qint = qint;
   s.lastAccepted = accept ? 1 : 0;
   s.pending = 0;
   if (accept) {
@@ -98,6 +112,7 @@ __device__ __attribute__((unused)) void decideUpdate(DevState* st, double dX2, d
     s.sumPrimalStep += w;
     s.sumDualStep += w;
     s.avgW = w;
+    s.avgWx = w;
     s.cur ^= 1;
     s.nIter += 1;
     s.eta = w;  // next iteration starts from sqrt(primalStep*dualStep) (step.c:231)
@@ -105,12 +120,22 @@ __device__ __attribute__((unused)) void decideUpdate(DevState* st, double dX2, d
   } else {
     s.eta = etaNew;
     s.avgW = 0.0;
+    s.avgWx = 0.0;
   }
   if (s.adaptive) {
     s.tau = s.eta / sqrt(s.beta);
     s.sigma = s.eta * sqrt(s.beta);
   }
-  *st = s;
+}
+template <bool TABLE_ONLY = false>
+__device__ __attribute__((unused)) void decideUpdate(DevState* st, double dX2, double dY2, double inter, double qint = 0.0) {
+  if (TABLE_ONLY) {  // the state sits in LDS: updated in place (a register copy of the record costs 50 VGPRs)
+    decideCore<true>(*st, dX2, dY2, inter, qint);
+  } else {
+    DevState s = *st;
+    decideCore<false>(s, dX2, dY2, inter, qint);
+    *st = s;
+  }
 }
 
 // Epilogue operands that do not depend on the SpMV result.

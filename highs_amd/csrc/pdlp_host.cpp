@@ -54,27 +54,88 @@ void validateProblem(const pdlp_problem_t& P) {
 // for the slack columns; empty when there is no quadratic term.  Off-diagonal nonzeros are an error: the
 // primal step of this library is the closed-form proximal step of a SEPARABLE quadratic.
 void extractDiagonalHessian(const pdlp_problem_t& P, double sense, int32_t n, std::vector<double>& q) {
+  Compressed off;
+  extractHessian(P, sense, n, q, off);
+  if (!off.beg.empty())
+    throw std::runtime_error("pdlp_mi355x: this set-up path takes diagonal Hessians only (off-diagonal entries present)");
+}
+
+bool hessianHasOffDiagonal(const pdlp_problem_t& P) {
+  if (P.q_dim <= 0 || !P.q_start || !P.q_index || !P.q_value) return false;
+  for (int32_t j = 0; j < P.q_dim; ++j)
+    for (int32_t p = P.q_start[j]; p < P.q_start[j + 1]; ++p)
+      if (P.q_index[p] != j && P.q_value[p] != 0.0) return true;
+  return false;
+}
+
+void extractHessian(const pdlp_problem_t& P, double sense, int32_t n, std::vector<double>& q, Compressed& off) {
   q.clear();
+  off = Compressed();
   if (P.q_dim <= 0 || !P.q_start) return;
   if (P.q_dim > P.num_col) throw std::runtime_error("Hessian dimension exceeds the number of columns");
   const int32_t nq = P.q_start[P.q_dim];
   if (nq > 0 && (!P.q_index || !P.q_value)) throw std::runtime_error("null Hessian arrays");
   bool any = false;
   std::vector<double> d((size_t)n, 0.0);
+  std::vector<int32_t> cnt((size_t)n + 1, 0);
+  int64_t nOff = 0;
   for (int32_t j = 0; j < P.q_dim; ++j)
     for (int32_t p = P.q_start[j]; p < P.q_start[j + 1]; ++p) {
       const int32_t i = P.q_index[p];
       if (i < 0 || i >= P.q_dim) throw std::runtime_error("Hessian index out of range");
       if (P.q_value[p] == 0.0) continue;
-      if (i != j)
-        throw std::runtime_error("pdlp_mi355x: only diagonal Hessians are supported on the PDLP path (entry (" +
-                                 std::to_string(i) + "," + std::to_string(j) + ") is off the diagonal)");
-      d[j] += P.q_value[p] * sense;
       any = true;
+      if (i == j) { d[j] += P.q_value[p] * sense; continue; }
+      if (i < j)
+        throw std::runtime_error("pdlp_mi355x: the Hessian must be given by its lower triangle (entry (" + std::to_string(i) + "," +
+                                 std::to_string(j) + ") lies above the diagonal)");
+      ++cnt[i + 1]; ++cnt[j + 1];
+      nOff += 2;
     }
   for (double v : d)
     if (v < 0.0) throw std::runtime_error("pdlp_mi355x: the Hessian is not positive semidefinite for this objective sense");
   if (any) q = std::move(d);
+  if (nOff == 0) return;
+  if (nOff > 0x7fffffff) throw std::runtime_error("Hessian too large");
+  // both triangles by rows; columns visited in ascending order, so row i receives its entries (i, j < i) in ascending
+  // j from the first pass and (i, j > i) in ascending j from the second: sorted without a sort
+  for (int32_t r = 0; r < n; ++r) cnt[r + 1] += cnt[r];
+  std::vector<int32_t> pos(cnt.begin(), cnt.end() - 1);
+  std::vector<int32_t> idx((size_t)nOff);
+  std::vector<double> val((size_t)nOff);
+  for (int32_t j = 0; j < P.q_dim; ++j)  // lower entries (i > j) into row i: column j ascending over the outer loop
+    for (int32_t p = P.q_start[j]; p < P.q_start[j + 1]; ++p) {
+      const int32_t i = P.q_index[p];
+      if (i == j || P.q_value[p] == 0.0) continue;
+      idx[pos[i]] = j; val[pos[i]++] = P.q_value[p] * sense;
+    }
+  // mirrored entries (j, i) into row j: within column j the caller's order of i; sort each row's tail by column
+  std::vector<int32_t> tailBeg(pos);
+  for (int32_t j = 0; j < P.q_dim; ++j)
+    for (int32_t p = P.q_start[j]; p < P.q_start[j + 1]; ++p) {
+      const int32_t i = P.q_index[p];
+      if (i == j || P.q_value[p] == 0.0) continue;
+      idx[pos[j]] = i; val[pos[j]++] = P.q_value[p] * sense;
+    }
+  for (int32_t r = 0; r < n; ++r) {  // (stable insertion sort: the rows of a column usually come ascending already)
+    for (int32_t a = tailBeg[r] + 1; a < cnt[r + 1]; ++a) {
+      const int32_t ci = idx[a];
+      const double cv = val[a];
+      int32_t b = a - 1;
+      while (b >= tailBeg[r] && idx[b] > ci) { idx[b + 1] = idx[b]; val[b + 1] = val[b]; --b; }
+      idx[b + 1] = ci; val[b + 1] = cv;
+    }
+  }
+  // repeated (row, column) pairs are added up, left to right
+  off.beg.assign((size_t)n + 1, 0);
+  for (int32_t r = 0; r < n; ++r) {
+    off.beg[r] = (int32_t)off.idx.size();
+    for (int32_t a = cnt[r]; a < cnt[r + 1]; ++a) {
+      if (a > cnt[r] && idx[a] == off.idx.back()) off.val.back() += val[a];
+      else { off.idx.push_back(idx[a]); off.val.push_back(val[a]); }
+    }
+  }
+  off.beg[n] = (int32_t)off.idx.size();
 }
 
 // HiGHS never hands an LP without rows or without matrix nonzeros to a solver: solveLp() answers those itself
@@ -151,7 +212,7 @@ void formulate(const pdlp_problem_t& P, StandardForm& F) {
     if (F.lower[j] < -kBoundInf) F.lower[j] = -kInf;
     if (F.upper[j] > kBoundInf) F.upper[j] = kInf;
   }
-  extractDiagonalHessian(P, F.sense, F.n, F.qdiag);
+  extractHessian(P, F.sense, F.n, F.qdiag, F.qoff);
 
   // Matrix in the reference's entry order: per column, equality-type entries
   // first, then inequality entries (LEQ negated) (:413-436); one -1 per slack.
@@ -206,6 +267,9 @@ void applyScaling(StandardForm& F, const std::vector<double>& cs, const std::vec
   }
   if (!F.qdiag.empty())  // x = x'/cs  =>  1/2 q x^2 = 1/2 (q / cs^2) x'^2
     for (int32_t j = 0; j < F.n; ++j) F.qdiag[j] = (F.qdiag[j] / cs[j]) / cs[j];
+  if (!F.qoff.beg.empty())
+    for (int32_t r = 0; r < F.n; ++r)
+      for (int32_t p = F.qoff.beg[r]; p < F.qoff.beg[r + 1]; ++p) F.qoff.val[p] = (F.qoff.val[p] / cs[r]) / cs[F.qoff.idx[p]];
   for (int32_t i = 0; i < F.m; ++i) {
     F.rhs[i] /= rs[i];
     F.rowScale[i] *= rs[i];
@@ -373,7 +437,7 @@ int32_t slabRowsPerWave(int32_t nMajor, int32_t nMinor) {
   int64_t Rw = ((int64_t)nMajor + waves - 1) / waves;
   Rw = (Rw + 1) / 2 * 2;  // even: rowsPerBlock is then a multiple of 32 (longMask words)
   if (Rw < 16) Rw = 16;
-  if (Rw > 512) Rw = 512;
+  if (Rw > 1024) Rw = 1024;  // 16384 majors per block: 128 KB of LDS accumulators (gfx950 has 160 KB per CU)
   // (localMajor << minorBits | minor) must fit 32 bits: shrink the waves until it does
   while (Rw > 16 && ((int64_t)1 << (32 - bitsForRows((int32_t)Rw))) < (int64_t)nMinor) Rw = (Rw / 2 + 1) / 2 * 2;
   if (((int64_t)1 << (32 - bitsForRows((int32_t)Rw))) < (int64_t)nMinor) return 0;

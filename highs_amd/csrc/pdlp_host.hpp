@@ -42,6 +42,8 @@ struct StandardForm {
   Compressed cscSorted;  // columns with ascending row index (device copy for A'y)
   std::vector<double> cost, rhs, lower, upper;
   std::vector<double> qdiag;     // diagonal of Q (with the sense, scaled like cost twice); empty = LP
+  Compressed qoff;               // off-diagonal part of Q: symmetric, both triangles, by rows with ascending column
+                                 // (with the sense, q_ij / (cs_i cs_j)); beg empty = none
   std::vector<double> rowUpper;  // HiPDLP form only (rhs is then the row LOWER bound)
   std::vector<uint8_t> rowIsEq;  // HiPDLP form only: per PERMUTED row (is_equality_row_)
   std::vector<int32_t> rowKind;    // per ORIGINAL row
@@ -57,6 +59,12 @@ struct StandardForm {
 void validateProblem(const pdlp_problem_t& P);
 void requireConstraints(const pdlp_problem_t& P);  // throws for LPs without rows / columns / nonzeros
 void extractDiagonalHessian(const pdlp_problem_t& P, double sense, int32_t n, std::vector<double>& q);
+// The Hessian of a QP, given as HiGHS gives it (model/HighsHessian.h:22-34: lower triangle, column-wise), split into
+// its diagonal (prox step) and its off-diagonal part N (explicit N x term): qoff = N with both triangles, by rows with
+// ascending column, repeated entries added up; empty when Q is diagonal.  Entries above the diagonal and a negative
+// diagonal (for this objective sense) are errors.
+void extractHessian(const pdlp_problem_t& P, double sense, int32_t n, std::vector<double>& qdiag, Compressed& qoff);
+bool hessianHasOffDiagonal(const pdlp_problem_t& P);
 void formulate(const pdlp_problem_t& P, StandardForm& F);
 void scale(StandardForm& F, int ruizTimes = 10, double pcAlpha = 1.0);
 void finalize(StandardForm& F);  // CSR + row-sorted CSC + matNormInf
@@ -125,7 +133,7 @@ struct SlabLayout {
 constexpr int32_t kSlabWidthLog2 = 17;  // 1 MB slabs: 56.2 vs 57.0 us per A x at the bench size (15..18 within 1.5 %)
 constexpr int32_t kSlabWavesPerBlock = 16;
 constexpr int32_t kSlabTargetBlocks = 256;  // CUs of an MI355X
-// Majors per wave for an operand of this shape: even, in [16, 512], ceil(nMajor / (256*16)) when that
+// Majors per wave for an operand of this shape: even, in [16, 1024], ceil(nMajor / (256*16)) when that
 // fits; halved until the minor index fits the entry packing; 0 when it cannot (nMinor > 2^28: the
 // caller then uses the CSR stream kernel).
 int32_t slabRowsPerWave(int32_t nMajor, int32_t nMinor);

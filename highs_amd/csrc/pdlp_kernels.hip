@@ -14,6 +14,7 @@
 #include "pdlp_kernels.hpp"
 
 #include <cmath>
+#include <cstddef>
 #include <cstdlib>
 
 #include "pdlp_devfn.hpp"
@@ -22,8 +23,14 @@ namespace pdlp {
 
 namespace {
 
-enum Epilogue { kPlain = 0, kDualStep = 1, kAtyInteract = 2, kAtyPartial = 3, kHalpernPrimal = 4, kHalpernDual = 5 };
-constexpr bool usesDevState(int epi) { return epi == kDualStep || epi == kAtyInteract || epi == kAtyPartial; }
+// kAtyFused = kAtyInteract + grid barrier + decision + the next trial's primal step (slab kernel only)
+// kQxInteract: N x+ for the off-diagonal part N of a QP's Hessian, with the partials of dx . N dx
+enum Epilogue { kPlain = 0, kDualStep = 1, kAtyInteract = 2, kAtyPartial = 3, kHalpernPrimal = 4, kHalpernDual = 5, kAtyFused = 6,
+                kQxInteract = 7 };
+constexpr bool usesDevState(int epi) {
+  return epi == kDualStep || epi == kAtyInteract || epi == kAtyPartial || epi == kAtyFused || epi == kQxInteract;
+}
+constexpr bool isInteract(int epi) { return epi == kAtyInteract || epi == kAtyFused; }
 
 struct SpmvArgs {
   SpmvMat A;
@@ -39,6 +46,11 @@ struct SpmvArgs {
   double* part0;  // dY^2 (dual) | dX^2 (aty)
   double* part1;  // interaction (aty)
   HalpernVecs h;  // kHalpernPrimal / kHalpernDual
+  // kAtyFused
+  DevState* stOut;
+  const double* partDY;
+  int32_t nDY, nDX;
+  unsigned long long* bar;
 };
 
 // Block-uniform read through the scalar (constant) path: s_load counts on lgkmcnt,
@@ -61,6 +73,43 @@ __device__ __forceinline__ int xcdContiguousBlock(int b, int nB) {
   const int xcd = b % kXcds, i = b / kXcds;
   const int qlo = nB / kXcds, r = nB % kXcds;
   return xcd < r ? xcd * (qlo + 1) + i : r * (qlo + 1) + (xcd - r) * qlo + i;
+}
+
+// Agent-scope relaxed accesses (global_load/store ... sc1): write-through stores, L1-bypassing loads — the only
+// way data crosses workgroups INSIDE a launch on this part (eight XCDs with private L2s, per-CU L1s that are never
+// refreshed by other CUs' stores).
+__device__ __forceinline__ void stAgent(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ldAgent(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// Grid barrier for a grid whose blocks are ALL resident.  Called by wave 0 of every block after lane 0's agent-scope
+// stores of the block's published words.  Every block owns one 8-byte arrival word; arriving = storing the launch's
+// epoch there (after the published words have landed); waiting = sweeping all arrival words with relaxed agent-scope
+// loads, nBlocks / 64 per lane, until every one carries the epoch.  One store and one sweep: no atomic round trips,
+// no counter to reset — measured 64.0 -> see DESIGN.md against the XCD-hierarchical counter barrier it replaced.  The epoch is the
+// trial counter + 1 (unique per executed trial; the words are zeroed when a solve starts).  A wait that does not
+// end (a block that is not resident) gives up after ~1 s and raises the flag word instead of hanging the device.
+__device__ __forceinline__ void gridBarrier(unsigned long long* bar, int blk, int nBlocks, unsigned long long epoch, int lane) {
+  if (lane == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this block's published words have landed
+    __hip_atomic_store(bar + blk, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  for (uint32_t spins = 0;; ++spins) {
+    bool ok = true;
+    for (int i = lane; i < nBlocks; i += kWave)
+      ok = ok && __hip_atomic_load(bar + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+    if (__all(ok)) break;
+    __builtin_amdgcn_s_sleep(4);
+    if (spins > (1u << 21)) {
+      if (lane == 0) __hip_atomic_store(bar + nBlocks, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+  }
 }
 
 // The major-local epilogue fused into both SpMV kernels: what happens to (A v)_r once it is known.
@@ -91,7 +140,7 @@ struct Epi {
   // the gathered vector
   __device__ __forceinline__ const double* input() const {
     if (EPI == kPlain) return a.in;
-    if (EPI == kDualStep) return a.v.x[nxt];
+    if (EPI == kDualStep || EPI == kQxInteract) return a.v.x[nxt];
     if (EPI == kHalpernPrimal) return a.h.yc;
     if (EPI == kHalpernDual) return a.h.rx;
     return a.v.y[nxt];
@@ -101,8 +150,10 @@ struct Epi {
     Pre p{0.0, 0.0, 0.0, 0.0, 0.0};
     if (EPI == kDualStep) {
       p.a = ldStream(a.v.y[cur] + r); p.b = ldStream(a.v.rhs + r); p.c = ldStream(a.v.ax[cur] + r);
-    } else if (EPI == kAtyInteract) {
+    } else if (isInteract(EPI)) {
       p.a = ldStream(a.v.x[cur] + r); p.b = ldStream(a.v.x[nxt] + r); p.c = ldStream(a.v.aty[cur] + r);
+    } else if (EPI == kQxInteract) {
+      p.a = ldStream(a.v.x[cur] + r); p.b = ldStream(a.v.x[nxt] + r); p.c = ldStream(a.v.nx[cur] + r);
     } else if (EPI == kHalpernPrimal) {
       p.a = ldStream(a.h.xc + r); p.b = ldStream(a.h.cost + r); p.c = ldStream(a.h.xa + r);
       p.d = ldStream(a.h.lower + r); p.e = ldStream(a.h.upper + r);
@@ -119,6 +170,11 @@ struct Epi {
       halpernPrimal(a.h, r, s, p, hTau, hRho, hW);
     } else if (EPI == kHalpernDual) {
       halpernDual(a.h, r, s, p, sigma, hRho, hW);
+    } else if (EPI == kQxInteract) {
+      const double dx = p.a - p.b;
+      const double dq = p.c - s;
+      stStream(a.v.nx[nxt] + r, s);
+      acc0 += dx * dq;
     } else if (EPI == kDualStep) {
       const double yv = p.a;
       if (avgW != 0.0) stStream(a.v.ySum + r, ldStream(a.v.ySum + r) + avgW * yv);  // deferred PDHG_Update_Average (step.c:438)
@@ -131,7 +187,7 @@ struct Epi {
       a.v.y[nxt][r] = t;  // gathered by the next kernel: ordinary store
       const double d = yv - t;
       acc0 += d * d;
-    } else {  // kAtyInteract
+    } else {  // kAtyInteract, kAtyFused
       const double dx = p.a - p.b;
       const double da = p.c - s;
       stStream(a.v.aty[nxt] + r, s);
@@ -142,16 +198,68 @@ struct Epi {
   // per-block partials of the reductions (deterministic: wave shuffle tree -> fixed-order sum of the waves)
   template <int NT>
   __device__ __forceinline__ void finish(int slot, double (*scratch)[NT / 64]) {
-    if (EPI == kDualStep) {
+    if (EPI == kDualStep || EPI == kQxInteract) {
       const double t = blockSum<NT>(acc0, scratch[0]);
       if (threadIdx.x == 0) a.part0[slot] = t;
     } else if (EPI == kAtyInteract) {
       const double t0 = blockSum<NT>(acc0, scratch[0]);
       const double t1 = blockSum<NT>(acc1, scratch[1]);
       if (threadIdx.x == 0) { a.part0[slot] = t0; a.part1[slot] = t1; }
+    } else if (EPI == kAtyFused) {  // read by every other block after the grid barrier: write-through stores
+      const double t0 = blockSum<NT>(acc0, scratch[0]);
+      const double t1 = blockSum<NT>(acc1, scratch[1]);
+      if (threadIdx.x == 0) { stAgent(a.part0 + slot, t0); stAgent(a.part1 + slot, t1); }
     }
   }
 };
+
+// Fixed-order sums of the three per-block partial arrays by 256 threads: lane t sums elements t, t+256, ...
+// (4 independent chains), then wave shuffle tree, then the 4 wave results in order.  Results valid in thread 0.
+// Shared by k_decide, k_decide_primal and the fused trial kernel, so all take identical decisions.  AGENT: the
+// partials were written by other workgroups of the SAME launch (agent-scope loads); threads >= 256 of a larger
+// block only take part in the barrier.
+template <bool AGENT>
+__device__ __forceinline__ void trialSumsT(const double* __restrict__ partDY, int nDY, const double* __restrict__ partDX,
+                                           const double* __restrict__ partInter, int nDX, double (*scratch)[kVecThreads / kWave],
+                                           double& dY2, double& dX2, double& inter, const double* __restrict__ partQ = nullptr,
+                                           int nQ = 0, double* qint = nullptr) {
+  const int tid = threadIdx.x;
+  auto ld = [&](const double* q) { return AGENT ? ldAgent(q) : *q; };
+  auto laneSum = [&](const double* __restrict__ p, int count) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int i = tid;
+    for (; i + 3 * kVecThreads < count; i += 4 * kVecThreads) {
+      const double a0 = ld(p + i), a1 = ld(p + i + kVecThreads), a2 = ld(p + i + 2 * kVecThreads), a3 = ld(p + i + 3 * kVecThreads);
+      s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+    }
+    for (; i < count; i += kVecThreads) s0 += ld(p + i);
+    return (s0 + s1) + (s2 + s3);
+  };
+  if (tid < kVecThreads) {
+    double vY = partDY ? laneSum(partDY, nDY) : 0.0;
+    double vX = laneSum(partDX, nDX);
+    double vI = laneSum(partInter, nDX);
+    double vQ = partQ ? laneSum(partQ, nQ) : 0.0;  // (QP with off-diagonal Hessian entries: dx . N dx)
+    vY = waveSum(vY); vX = waveSum(vX); vI = waveSum(vI);
+    if (partQ) vQ = waveSum(vQ);
+    const int lane = tid & (kWave - 1), w = tid / kWave;
+    if (lane == 0) { scratch[0][w] = vY; scratch[1][w] = vX; scratch[2][w] = vI; scratch[3][w] = vQ; }
+  }
+  __syncthreads();
+  dY2 = dX2 = inter = 0.0;
+  if (tid == 0) {
+    double q = 0.0;
+#pragma unroll
+    for (int i = 0; i < kVecThreads / kWave; ++i) { dY2 += scratch[0][i]; dX2 += scratch[1][i]; inter += scratch[2][i]; q += scratch[3][i]; }
+    if (qint) *qint = q;
+  }
+}
+__device__ __forceinline__ void trialSums(const double* __restrict__ partDY, int nDY, const double* __restrict__ partDX,
+                                          const double* __restrict__ partInter, int nDX, double (*scratch)[kVecThreads / kWave],
+                                          double& dY2, double& dX2, double& inter, const double* __restrict__ partQ = nullptr,
+                                          int nQ = 0, double* qint = nullptr) {
+  trialSumsT<false>(partDY, nDY, partDX, partInter, nDX, scratch, dY2, dX2, inter, partQ, nQ, qint);
+}
 
 // The segment tasks of the long majors (pdlp_kernels.hpp LongMat): workgroup lb of the extra blocks runs the tasks
 // [lb*W, (lb+1)*W), one per wave.  Lane l adds the products of the entries l, l+64, ... of the segment in ascending
@@ -231,10 +339,10 @@ __device__ __forceinline__ void longBlock(const SpmvArgs& a, Epi<EPI>& epi, int 
     const double keep0 = epi.acc0, keep1 = epi.acc1;
     epi.acc0 = 0.0; epi.acc1 = 0.0;
     epi.apply(T.major, total, pre);
-    if (EPI == kDualStep || EPI == kAtyInteract) {  // the major's own slot (or, beyond kLongSlotCap, its entry for k_long_groups)
+    if (EPI == kDualStep || EPI == kQxInteract || isInteract(EPI)) {  // the major's own slot (or, beyond kLongSlotCap, its entry for k_long_groups)
       double* o0 = L.contrib ? L.contrib + T.c : a.part0 + L.slotBase + T.c;
       *o0 = epi.acc0;
-      if (EPI == kAtyInteract) {
+      if (isInteract(EPI)) {
         double* o1 = L.contrib ? L.contrib + L.nLong + T.c : a.part1 + L.slotBase + T.c;
         *o1 = epi.acc1;
       }
@@ -373,10 +481,16 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
 constexpr int kSlabSlots = 3;  // register pipeline depth (groups of 64 entries per wave)
 // TWO: register budget for two resident blocks per CU (8 waves per SIMD) — the extra blocks with the segment
 // tasks of the long majors then run NEXT to the streaming blocks instead of after them.
-template <int EPI, bool TWO>
+template <int EPI, bool TWO, int NB, int GD>
 __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabThreads / 256) void k_spmv_slab(const SpmvArgs a) {
+  if (EPI == kAtyFused && a.st->halted) {  // keep the two state slots identical while the queue drains
+    if (blockIdx.x == 0 && threadIdx.x < sizeof(DevState) / 4)
+      reinterpret_cast<uint32_t*>(a.stOut)[threadIdx.x] = reinterpret_cast<const uint32_t*>(a.st)[threadIdx.x];
+    return;
+  }
   if (usesDevState(EPI) && a.st->halted) return;
-  constexpr int NB = kSlabSlots, kWaves = kSlabThreads / kWave;
+  static_assert(GD >= 1 && NB >= GD + 2, "entry loads need two steps, gathers GD steps");
+  constexpr int kWaves = kSlabThreads / kWave;
   constexpr int kSlabPre = TWO ? 2 : 4;  // majors per thread whose epilogue operands are fetched before the stream
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if ((int)blockIdx.x >= a.S.nBlocks) {  // the extra blocks: one segment task of a long major per wave
@@ -384,7 +498,7 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
     longBlock<EPI, kWaves>(a, epiL, (int)blockIdx.x - a.S.nBlocks, reinterpret_cast<double*>(smem));
     return;
   }
-  // dynamic LDS: acc[R] f64 | stg[16][64] f64 | scratch[2][16] f64
+  // dynamic LDS: acc[R] f64 | stg[16][64] f64 | scratch[2][16] f64 | (kAtyFused) trial scratch[4][4] f64, DevState
   const int R = a.S.rowsPerBlock;
   double* acc = reinterpret_cast<double*>(smem);
   double* stgAll = acc + R;
@@ -414,6 +528,17 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
     const int r = rBase + tid + k * kSlabThreads;
     pre[k] = epi.prefetch(r < rEnd ? r : rEnd - 1);
   }
+  // kAtyFused: the operands of the NEXT primal step that no decision can change (c, l, u, xSum) travel with the stream
+  Pre fix[EPI == kAtyFused ? kSlabPre : 1];
+  if (EPI == kAtyFused) {
+#pragma unroll
+    for (int k = 0; k < kSlabPre; ++k) {
+      const int r0_ = rBase + tid + k * kSlabThreads;
+      const int r = r0_ < rEnd ? r0_ : rEnd - 1;
+      fix[k].a = ldStream(a.v.cost + r); fix[k].b = ldStream(a.v.lower + r); fix[k].c = ldStream(a.v.upper + r);
+      fix[k].d = 0.0; fix[k].e = 0.0;
+    }
+  }
 
   // ---- the stream ----
   // Register pipeline over NB slots, unrolled NB times so that a slot is a fixed register (no moves of
@@ -436,7 +561,7 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
   // compiler's vmcnt bookkeeping at the loop header does not have to assume the worst)
 #pragma unroll
   for (int k = 0; k < NB; ++k) {
-    if (k + 1 >= NB) X[(k + 1) % NB] = gather(E[(k + 1) % NB]);
+    if (k + GD >= NB) X[(k + GD) % NB] = gather(E[(k + GD) % NB]);
     const int q = entryIndex(k);
     E[k] = ent[q];
     V[k] = val[q];
@@ -456,7 +581,7 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
       const int g = o * NB + u;
-      X[(u + 1) % NB] = gather(E[(u + 1) % NB]);  // group g+1
+      X[(u + GD) % NB] = gather(E[(u + GD) % NB]);  // group g+GD
       // consume group g
       const int nValid = cnt - g * kWave;  // lanes >= nValid hold nothing of this wave (<= 0: phantom group)
       const bool valid = lane < nValid;
@@ -517,14 +642,77 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
     const int r = rBase + lr;
     epi.apply(r, acc[lr], epi.prefetch(r));
   }
+  if (EPI == kAtyFused) {  // xSum of the own columns: in flight across the barrier and the decision
+#pragma unroll
+    for (int k = 0; k < kSlabPre; ++k) {
+      const int r0_ = rBase + tid + k * kSlabThreads;
+      fix[k].d = ldStream(a.v.xSum + (r0_ < rEnd ? r0_ : rEnd - 1));
+    }
+  }
   epi.template finish<kSlabThreads>(blk, scratch);
+  if (EPI == kAtyFused) {
+    // ---- every block's partials in HBM -> decision (identical in every block) -> the next trial's primal step ----
+    double(*tscr)[kVecThreads / kWave] = reinterpret_cast<double(*)[kVecThreads / kWave]>(&scratch[2][0]);
+    DevState* sh = reinterpret_cast<DevState*>(&tscr[4][0]);
+    if (wave == 0) gridBarrier(a.bar, (int)blockIdx.x, a.S.nBlocks, (unsigned long long)a.st->nTrials + 1ull, lane);
+    {  // the state record -> LDS, one word per thread (no register copy of the 50-word record)
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(a.st);
+      uint32_t* dstw = reinterpret_cast<uint32_t*>(sh);
+      if (tid >= kVecThreads && tid - kVecThreads < (int)(sizeof(DevState) / 4)) dstw[tid - kVecThreads] = src[tid - kVecThreads];
+    }
+    __syncthreads();
+    double dY2, dX2, inter;
+    trialSumsT<true>(a.partDY, a.nDY, a.part0, a.part1, a.nDX, tscr, dY2, dX2, inter);
+    if (tid == 0) {
+      decideUpdate<true>(sh, dX2, dY2, inter);
+      if (__hip_atomic_load(a.bar + a.S.nBlocks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) sh->commError = 1;
+    }
+    __syncthreads();
+    const int halted = sh->halted, curN = sh->cur, accepted = sh->lastAccepted;
+    const double tau = sh->tau, avgWx = sh->avgWx;
+    if (blockIdx.x == 0 && tid < (int)(sizeof(DevState) / 4)) {  // pending = 0 (decideCore); avgWx: added to xSum below
+      uint32_t w = reinterpret_cast<const uint32_t*>(sh)[tid];
+      constexpr int kAvgWxWord = offsetof(DevState, avgWx) / 4;
+      if (!halted && (tid == kAvgWxWord || tid == kAvgWxWord + 1)) w = 0u;
+      reinterpret_cast<uint32_t*>(a.stOut)[tid] = w;
+    }
+    if (halted) return;
+    // the iterate the step starts from: the trial's (x+, A'y+) when it was accepted, else (x, A'y) again
+    const double* __restrict__ xBase = a.v.x[curN];
+    const double* __restrict__ atyBase = a.v.aty[curN];
+    double* __restrict__ xOut = a.v.x[curN ^ 1];
+    auto step = [&](int r, double xb, double ab, double c, double l, double u, double xs) {
+      if (avgWx != 0.0) stStream(a.v.xSum + r, xs + avgWx * xb);  // deferred PDHG_Update_Average (step.c:437)
+      double t = xb;
+      t += (-tau) * c;
+      t += tau * ab;
+      if (a.v.qdiag) t = t / (1.0 + tau * ldStream(a.v.qdiag + r));
+      t = t < u ? t : u;
+      t = t > l ? t : l;
+      xOut[r] = t;  // gathered by the A x+ kernel: ordinary store
+    };
+#pragma unroll
+    for (int k = 0; k < kSlabPre; ++k) {
+      const int lr = tid + k * kSlabThreads;
+      if (rBase + lr < rEnd) {  // (a rejected trial, 3 %, fetches x and A'y again)
+        const int r = rBase + lr;
+        step(r, accepted ? pre[k].b : ldStream(xBase + r), accepted ? acc[lr] : ldStream(atyBase + r), fix[k].a, fix[k].b, fix[k].c,
+             fix[k].d);
+      }
+    }
+    for (int lr = tid + kSlabPre * kSlabThreads; rBase + lr < rEnd; lr += kSlabThreads) {  // (more than 4096 majors per block)
+      const int r = rBase + lr;
+      step(r, ldStream(xBase + r), accepted ? acc[lr] : ldStream(atyBase + r), ldStream(a.v.cost + r), ldStream(a.v.lower + r),
+           ldStream(a.v.upper + r), ldStream(a.v.xSum + r));
+    }
+  }
 }
 
 // x+ = clamp(x - tau (c - A'y), l, u): cupdlp_step.c:16-40, rounding as the CPU branch.
 __global__ __launch_bounds__(kVecThreads) void k_primal_step(const IterVecs v, const DevState* st) {
   if (st->halted) return;
   const int cur = st->cur, nxt = cur ^ 1;
-  const double tau = st->tau, avgW = st->avgW;
+  const double tau = st->tau, avgW = st->avgWx;
   const double* __restrict__ x = v.x[cur];
   const double* __restrict__ aty = v.aty[cur];
   double* __restrict__ xn = v.x[nxt];
@@ -535,6 +723,7 @@ __global__ __launch_bounds__(kVecThreads) void k_primal_step(const IterVecs v, c
     double t = xv;
     t += (-tau) * ldStream(v.cost + j);
     t += tau * ldStream(aty + j);
+    if (v.nx[0]) t += (-tau) * ldStream(v.nx[cur] + j);  // explicit gradient term of the off-diagonal part of Q
     if (v.qdiag) t = t / (1.0 + tau * ldStream(v.qdiag + j));
     const double u = ldStream(v.upper + j), l = ldStream(v.lower + j);
     t = t < u ? t : u;
@@ -573,50 +762,20 @@ __global__ __launch_bounds__(kVecThreads) void k_reduce_to(const double* partial
   if (threadIdx.x == 0) *out = s;
 }
 
-// Fixed-order sums of the three per-block partial arrays by one 256-thread block: lane t sums elements
-// t, t+256, ... (4 independent chains), then wave shuffle tree, then the 4 wave results in order.
-// Results valid in thread 0.  Shared by k_decide and k_decide_primal, so both take identical decisions.
-__device__ __forceinline__ void trialSums(const double* __restrict__ partDY, int nDY, const double* __restrict__ partDX,
-                                          const double* __restrict__ partInter, int nDX, double (*scratch)[kVecThreads / kWave],
-                                          double& dY2, double& dX2, double& inter) {
-  const int tid = threadIdx.x;
-  auto laneSum = [&](const double* __restrict__ p, int count) {
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int i = tid;
-    for (; i + 3 * kVecThreads < count; i += 4 * kVecThreads) {
-      const double a0 = p[i], a1 = p[i + kVecThreads], a2 = p[i + 2 * kVecThreads], a3 = p[i + 3 * kVecThreads];
-      s0 += a0; s1 += a1; s2 += a2; s3 += a3;
-    }
-    for (; i < count; i += kVecThreads) s0 += p[i];
-    return (s0 + s1) + (s2 + s3);
-  };
-  double vY = partDY ? laneSum(partDY, nDY) : 0.0;
-  double vX = laneSum(partDX, nDX);
-  double vI = laneSum(partInter, nDX);
-  vY = waveSum(vY); vX = waveSum(vX); vI = waveSum(vI);
-  const int lane = tid & (kWave - 1), w = tid / kWave;
-  if (lane == 0) { scratch[0][w] = vY; scratch[1][w] = vX; scratch[2][w] = vI; }
-  __syncthreads();
-  dY2 = dX2 = inter = 0.0;
-  if (tid == 0) {
-#pragma unroll
-    for (int i = 0; i < kVecThreads / kWave; ++i) { dY2 += scratch[0][i]; dX2 += scratch[1][i]; inter += scratch[2][i]; }
-  }
-}
-
 // k_decide: the decision kernel (one block).  All partial loads of the three sums are issued
 // together and reduced in one pass — the kernel is pure latency (it sits between two trials).
 __global__ __launch_bounds__(kVecThreads) void k_decide(DevState* st, const double* __restrict__ partDY, int nDY,
                                                         const double* __restrict__ partDX,
                                                         const double* __restrict__ partInter, int nDX,
-                                                        const double* dyGlobal, int onlyIfPending) {
+                                                        const double* dyGlobal, int onlyIfPending,
+                                                        const double* __restrict__ partQ, int nQ) {
   if (st->halted) return;
   if (onlyIfPending && !st->pending) return;
-  __shared__ double scratch[3][kVecThreads / kWave];
-  double dY2, dX2, inter;
-  trialSums(dyGlobal ? nullptr : partDY, nDY, partDX, partInter, nDX, scratch, dY2, dX2, inter);
+  __shared__ double scratch[4][kVecThreads / kWave];
+  double dY2, dX2, inter, qint = 0.0;
+  trialSums(dyGlobal ? nullptr : partDY, nDY, partDX, partInter, nDX, scratch, dY2, dX2, inter, partQ, nQ, &qint);
   if (threadIdx.x != 0) return;
-  decideUpdate(st, dX2, dyGlobal ? *dyGlobal : dY2, inter);
+  decideUpdate(st, dX2, dyGlobal ? *dyGlobal : dY2, inter, qint);
 }
 
 // Single-GPU loop: decision of the previous trial + primal step of this one in ONE launch (see
@@ -628,20 +787,21 @@ __global__ __launch_bounds__(kVecThreads) void k_decide_primal(const IterVecs v,
                                                                DevState* __restrict__ stOut,
                                                                const double* __restrict__ partDY, int nDY,
                                                                const double* __restrict__ partDX,
-                                                               const double* __restrict__ partInter, int nDX) {
+                                                               const double* __restrict__ partInter, int nDX,
+                                                               const double* __restrict__ partQ, int nQ) {
   const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
   if (stIn->halted) {  // keep the two slots identical while the queue drains
     if (writer) *stOut = *stIn;
     return;
   }
-  __shared__ double scratch[3][kVecThreads / kWave];
+  __shared__ double scratch[4][kVecThreads / kWave];
   __shared__ DevState sh;
   const int pending = stIn->pending;
   const int guess = pending ? (stIn->cur ^ 1) : stIn->cur;  // parity of the iterate if the pending trial is accepted
   constexpr int kPer = 2;  // elements per thread and pass, all their loads in flight together
   const int stride = gridDim.x * blockDim.x;
   const int j0 = blockIdx.x * blockDim.x + threadIdx.x;
-  double xv[kPer], av[kPer], cv[kPer], lv[kPer], uv[kPer], sv[kPer], qv[kPer];
+  double xv[kPer], av[kPer], cv[kPer], lv[kPer], uv[kPer], sv[kPer], qv[kPer], nv[kPer];
   auto fetchFixed = [&](int base) {
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
@@ -658,26 +818,28 @@ __global__ __launch_bounds__(kVecThreads) void k_decide_primal(const IterVecs v,
       const int j = base + k * stride;
       const int jj = j < v.n ? j : (v.n > 0 ? v.n - 1 : 0);
       xv[k] = ldStream(v.x[par] + jj); av[k] = ldStream(v.aty[par] + jj);
+      nv[k] = v.nx[0] ? ldStream(v.nx[par] + jj) : 0.0;
     }
   };
   fetchIterate(j0, guess);
   fetchFixed(j0);
   if (pending) {
-    double dY2, dX2, inter;
-    trialSums(partDY, nDY, partDX, partInter, nDX, scratch, dY2, dX2, inter);
+    double dY2, dX2, inter, qint = 0.0;
+    trialSums(partDY, nDY, partDX, partInter, nDX, scratch, dY2, dX2, inter, partQ, nQ, &qint);
     if (threadIdx.x == 0) {
       sh = *stIn;
-      decideUpdate(&sh, dX2, dY2, inter);
+      decideUpdate(&sh, dX2, dY2, inter, qint);
     }
   } else if (threadIdx.x == 0) {
     sh = *stIn;
   }
   __syncthreads();
   const int halted = sh.halted, cur = sh.cur, nxt = cur ^ 1;
-  const double tau = sh.tau, avgW = sh.avgW;
+  const double tau = sh.tau, avgW = sh.avgWx;
   if (writer) {
     DevState t = sh;
     t.pending = halted ? 0 : 1;
+    if (!halted) t.avgWx = 0.0;  // added to xSum below
     *stOut = t;
   }
   if (halted) return;
@@ -693,6 +855,7 @@ __global__ __launch_bounds__(kVecThreads) void k_decide_primal(const IterVecs v,
       double t = xv[k];
       t += (-tau) * cv[k];
       t += tau * av[k];
+      if (v.nx[0]) t += (-tau) * nv[k];          // explicit gradient term of the off-diagonal part of Q
       if (v.qdiag) t = t / (1.0 + tau * qv[k]);  // prox of 1/2 q x^2: argmin <c - A'y, x> + q x^2/2 + (x - x_k)^2 / (2 tau)
       t = t < uv[k] ? t : uv[k];
       t = t > lv[k] ? t : lv[k];
@@ -703,18 +866,18 @@ __global__ __launch_bounds__(kVecThreads) void k_decide_primal(const IterVecs v,
 
 // Apply a pending average update (before a check iteration reads xSum/ySum).
 __global__ __launch_bounds__(kVecThreads) void k_flush_average(const IterVecs v, const DevState* st) {
-  const double w = st->avgW;
-  if (w == 0.0) return;
+  const double w = st->avgW, wx = st->avgWx;  // (the two sides are consumed by different kernels of a trial)
+  if (w == 0.0 && wx == 0.0) return;
   const int cur = st->cur;
   const int stride = gridDim.x * blockDim.x;
   const int tot = v.n + v.m;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += stride) {
     // (check-iteration kernels stream their vectors non-temporally too: the matrices stay in the Infinity Cache)
-    if (i < v.n) stStream(v.xSum + i, ldStream(v.xSum + i) + w * ldStream(v.x[cur] + i));
-    else stStream(v.ySum + (i - v.n), ldStream(v.ySum + (i - v.n)) + w * ldStream(v.y[cur] + (i - v.n)));
+    if (i < v.n) { if (wx != 0.0) stStream(v.xSum + i, ldStream(v.xSum + i) + wx * ldStream(v.x[cur] + i)); }
+    else if (w != 0.0) stStream(v.ySum + (i - v.n), ldStream(v.ySum + (i - v.n)) + w * ldStream(v.y[cur] + (i - v.n)));
   }
 }
-__global__ void k_clear_avgw(DevState* st) { st->avgW = 0.0; }
+__global__ void k_clear_avgw(DevState* st) { st->avgW = 0.0; st->avgWx = 0.0; }
 
 __global__ __launch_bounds__(kVecThreads) void k_scale_copy(double* __restrict__ dst, const double* __restrict__ src,
                                                             double a, int len) {
@@ -781,7 +944,8 @@ __global__ __launch_bounds__(kVecThreads) void k_col_stats(const double* __restr
                                                            const double* __restrict__ lower,
                                                            const double* __restrict__ upper,
                                                            const double* __restrict__ colScale,
-                                                           const double* __restrict__ qdiag, int n, int scaled,
+                                                           const double* __restrict__ qdiag,
+                                                           const double* __restrict__ nx, int n, int scaled,
                                                            double* slackPos, double* slackNeg, double* partials,
                                                            int pstride) {
   __shared__ double scratch[kVecThreads / kWave];
@@ -796,11 +960,18 @@ __global__ __launch_bounds__(kVecThreads) void k_col_stats(const double* __restr
     const double lF = l > -INFINITY ? l : 0.0, uF = u < INFINITY ? u : 0.0;
     const double atyv = ldStream(aty + j);
     double r = -atyv + c;                       // c - A'y
+    double half = 0.0;                          // QP: 1/2 x_j (Q x)_j
     if (qdiag) {                                // QP: reduced cost c + Q x - A'y, objective term 1/2 x'Qx
       const double qj = qdiag[j];
       r += qj * xv;
-      a[10] += (0.5 * qj * xv) * xv;
+      half = (0.5 * qj * xv) * xv;
     }
+    if (nx) {                                   // off-diagonal part: (N x)_j
+      const double nj = ldStream(nx + j);
+      r += nj;
+      half += (0.5 * nj) * xv;
+    }
+    a[10] += half;
     double sp = (r > 0.0 ? r : 0.0) * hasL;     // s+ (:157-159)
     double sn = (-(r < 0.0 ? r : 0.0)) * hasU;  // s- (:171-175)
     stStream(slackPos + j, sp);
@@ -878,8 +1049,8 @@ void launchPrimalStep(const IterVecs& v, const DevState* st, hipStream_t s) {
 namespace {
 // PDLP_MI355X_SLAB_OCC2=0|1: register budget of the slab kernel for one / two resident blocks per CU
 bool slabTwoPerCu() {
-  static const int v = [] { const char* e = getenv("PDLP_MI355X_SLAB_OCC2"); return e ? atoi(e) : 1; }();
-  return v != 0;
+  const char* e = getenv("PDLP_MI355X_SLAB_OCC2");  // (development switch, read per launch; a captured graph keeps its choice)
+  return e ? atoi(e) != 0 : true;
 }
 template <int EPI>
 void launchSpmv(const MatView& M, SpmvArgs a, hipStream_t s) {
@@ -891,14 +1062,15 @@ void launchSpmv(const MatView& M, SpmvArgs a, hipStream_t s) {
     a.S = M.slab;
     const size_t lds = (size_t)M.slab.rowsPerBlock * 8 + kSlabThreads * 8 + 2 * (kSlabThreads / kWave) * 8;
     const dim3 grid(M.slab.nBlocks + (nTasks + kSlabThreads / kWave - 1) / (kSlabThreads / kWave));
-    if (nTasks > 0 && slabTwoPerCu()) hipLaunchKernelGGL((k_spmv_slab<EPI, true>), grid, dim3(kSlabThreads), lds, s, a);
-    else hipLaunchKernelGGL((k_spmv_slab<EPI, false>), grid, dim3(kSlabThreads), lds, s, a);
+    // (gather distance 2 / 3 with 4 / 6 slots measured the same as (3, 1) on the random and on the structured LP, round 3)
+    if (nTasks > 0 && slabTwoPerCu()) hipLaunchKernelGGL((k_spmv_slab<EPI, true, kSlabSlots, 1>), grid, dim3(kSlabThreads), lds, s, a);
+    else hipLaunchKernelGGL((k_spmv_slab<EPI, false, kSlabSlots, 1>), grid, dim3(kSlabThreads), lds, s, a);
   } else if (M.csr.nBlocks > 0 || nTasks > 0) {
     const dim3 grid(M.csr.nBlocks + (nTasks + kSpmvThreads / kWave - 1) / (kSpmvThreads / kWave)), block(kSpmvThreads);
     if (M.csr.chunk == kChunkSmall) hipLaunchKernelGGL((k_spmv<EPI, kChunkSmall>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((k_spmv<EPI, kChunk>), grid, block, 0, s, a);
   }
-  if (nTasks > 0 && M.lng.contrib && (EPI == kDualStep || EPI == kAtyInteract))
+  if (nTasks > 0 && M.lng.contrib && (EPI == kDualStep || EPI == kAtyInteract || EPI == kQxInteract))
     hipLaunchKernelGGL(k_long_groups, dim3((M.lng.nSlots + kVecThreads - 1) / kVecThreads), dim3(kVecThreads), 0, s, M.lng,
                        a.st, a.part0, EPI == kAtyInteract ? a.part1 : nullptr);
 }
@@ -914,6 +1086,29 @@ void launchSpmvAtyInteract(const MatView& At, const IterVecs& v, const DevState*
   SpmvArgs a{};
   a.st = st; a.v = v; a.part0 = partDX; a.part1 = partInter;
   launchSpmv<kAtyInteract>(At, a, s);
+}
+namespace {
+size_t fusedLds(const MatView& At) {
+  return (size_t)At.slab.rowsPerBlock * 8 + kSlabThreads * 8 + 2 * (kSlabThreads / kWave) * 8 + 4 * (kVecThreads / kWave) * 8 +
+         sizeof(DevState) + 16;
+}
+}  // namespace
+int fusedAtyBlocksResident(const MatView& At, int device) {
+  if (!At.useSlab || At.slab.nBlocks <= 0 || At.lng.nTasks > 0) return 0;  // (long majors run in extra blocks that take no part in the barrier)
+  int perCu = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_spmv_slab<kAtyFused, false, kSlabSlots, 1>, kSlabThreads, fusedLds(At)) != hipSuccess)
+    return 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
+  return perCu * cus;
+}
+void launchSpmvAtyFusedPrimal(const MatView& At, const IterVecs& v, const DevState* stIn, DevState* stOut,
+                              const double* partDY, int32_t nDY, double* partDX, double* partInter, unsigned long long* bar,
+                              hipStream_t s) {
+  SpmvArgs a{};
+  a.st = stIn; a.v = v; a.part0 = partDX; a.part1 = partInter;
+  a.stOut = stOut; a.partDY = partDY; a.nDY = nDY; a.nDX = At.nPartials; a.bar = bar;
+  a.xcdMap = At.xcdMap; a.L = At.lng; a.A = At.csr; a.S = At.slab;
+  hipLaunchKernelGGL((k_spmv_slab<kAtyFused, false, kSlabSlots, 1>), dim3(At.slab.nBlocks), dim3(kSlabThreads), fusedLds(At), s, a);
 }
 void launchSpmvAtyPartial(const MatView& At, const IterVecs& v, const DevState* st, double* out, hipStream_t s) {
   SpmvArgs a{};
@@ -943,18 +1138,24 @@ void launchReduceTo(const double* partials, int32_t count, double* out, const De
   hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(kVecThreads), 0, s, partials, count, out, st);
 }
 void launchDecide(DevState* st, const double* partDY, int32_t nDY, const double* partDX, const double* partInter,
-                  int32_t nDX, const double* dyGlobal, hipStream_t s, bool onlyIfPending) {
+                  int32_t nDX, const double* dyGlobal, hipStream_t s, bool onlyIfPending, const double* partQ, int32_t nQ) {
   hipLaunchKernelGGL(k_decide, dim3(1), dim3(kVecThreads), 0, s, st, partDY, nDY, partDX, partInter, nDX, dyGlobal,
-                     onlyIfPending ? 1 : 0);
+                     onlyIfPending ? 1 : 0, partQ, nQ);
+}
+void launchSpmvQxInteract(const MatView& N, const IterVecs& v, const DevState* st, double* partQ, hipStream_t s) {
+  SpmvArgs a{};
+  a.st = st; a.v = v; a.part0 = partQ;
+  launchSpmv<kQxInteract>(N, a, s);
 }
 void launchDecidePrimal(const IterVecs& v, const DevState* stIn, DevState* stOut, const double* partDY, int32_t nDY,
-                        const double* partDX, const double* partInter, int32_t nDX, hipStream_t s) {
+                        const double* partDX, const double* partInter, int32_t nDX, hipStream_t s, const double* partQ,
+                        int32_t nQ) {
   // 4 blocks per CU, several passes per thread: 14.1 us against 17.0 us with one pass per thread (2048 blocks) at
   // n = 1M — the loads of the next pass overlap the stores of the current one
   int nb = vecBlocks(v.n);
   if (nb > 1024) nb = 1024;
   hipLaunchKernelGGL(k_decide_primal, dim3(nb), dim3(kVecThreads), 0, s, v, stIn, stOut, partDY, nDY, partDX,
-                     partInter, nDX);
+                     partInter, nDX, partQ, nQ);
 }
 void launchFlushAverage(const IterVecs& v, DevState* st, hipStream_t s) {
   hipLaunchKernelGGL(k_flush_average, dim3(vecBlocks(v.n + v.m)), dim3(kVecThreads), 0, s, v, st);
@@ -987,10 +1188,10 @@ void launchRowStats(const double* ax, const double* y, const double* rhs, const 
                      scaled, partials, stride);
 }
 void launchColStats(const double* aty, const double* x, const double* cost, const double* lower,
-                    const double* upper, const double* colScale, const double* qdiag, int32_t n, int scaled,
+                    const double* upper, const double* colScale, const double* qdiag, const double* nx, int32_t n, int scaled,
                     double* slackPos, double* slackNeg, double* partials, int32_t stride, int32_t nBlocks,
                     hipStream_t s) {
-  hipLaunchKernelGGL(k_col_stats, dim3(nBlocks), dim3(kVecThreads), 0, s, aty, x, cost, lower, upper, colScale, qdiag,
+  hipLaunchKernelGGL(k_col_stats, dim3(nBlocks), dim3(kVecThreads), 0, s, aty, x, cost, lower, upper, colScale, qdiag, nx,
                      n, scaled, slackPos, slackNeg, partials, stride);
 }
 void launchFinalReduce(const double* partials, int32_t stride, int32_t nBlocks, int32_t nQ, double* out,

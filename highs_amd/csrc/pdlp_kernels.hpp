@@ -32,8 +32,10 @@ struct DevState {
   double tau, sigma;     // step sizes of the next trial
   double primalStep, dualStep;        // stepsize->dPrimalStep / dDualStep
   double sumPrimalStep, sumDualStep;  // stepsize->dSum*Step
-  double avgW;           // weight of the accepted iterate not yet added to xSum/ySum
+  double avgW;           // weight of the accepted iterate not yet added to ySum (the dual-step epilogue adds it)
+  double avgWx;          // ... not yet added to xSum (the next primal step adds it)
   double dX2, dY2, inter, movement, limit;  // last trial (diagnostics / tests)
+  double qint;           // QP with off-diagonal Hessian entries: dx . N dx of the last trial
   int32_t nIter;         // timers->nIter
   int32_t nTrials;       // stepsize->nStepSizeIter
   int32_t cur;           // parity of the current iterate buffers (nIter % 2 in the reference)
@@ -102,7 +104,7 @@ struct LongMat {
 // Slab layout (pdlp_host.hpp SlabLayout), device pointers.  One 1024-thread block = 16 waves, each
 // owning rowsPerBlock/16 consecutive majors and its own sorted entry list.
 constexpr int kSlabThreads = 1024;
-constexpr int kSlabMaxRows = 8192;  // majors per block (LDS accumulators: 64 KB)
+constexpr int kSlabMaxRows = 16384;  // majors per block (LDS accumulators: 128 KB of the 160 KB)
 struct SlabMat {
   const int32_t* wavePtr;    // [16*nBlocks+1] entry offsets per wave
   const uint32_t* ent;       // [nnz] (localMajor << minorBits | minor)
@@ -135,6 +137,7 @@ struct IterVecs {
   const double* lower;
   const double* upper;
   const double* qdiag;  // diagonal of Q (QP prox step) or nullptr for an LP
+  double* nx[2];        // N x for the off-diagonal part N of Q (explicit gradient term), by parity; nullptr without one
   int32_t n, m;
   int32_t nEqs;       // GLOBAL count of equality rows
   int32_t rowOffset;  // global index of local row 0 (0 unless sharded)
@@ -172,7 +175,10 @@ void launchHalpernDual(const MatView& A, const HalpernVecs& h, hipStream_t s);
 // result), then the primal step of this trial with the new step sizes.  Reads *stIn, block 0 writes *stOut
 // (the two slots alternate from trial to trial, so no block can read a half-written state).
 void launchDecidePrimal(const IterVecs& v, const DevState* stIn, DevState* stOut, const double* partDY, int32_t nDY,
-                        const double* partDX, const double* partInter, int32_t nDX, hipStream_t s);
+                        const double* partDX, const double* partInter, int32_t nDX, hipStream_t s,
+                        const double* partQ = nullptr, int32_t nQ = 0);
+// QP with off-diagonal Hessian entries: nx_next = N x_next fused with the partials of dx . N dx (the third SpMV of a trial)
+void launchSpmvQxInteract(const MatView& N, const IterVecs& v, const DevState* st, double* partQ, hipStream_t s);
 void launchPrimalStep(const IterVecs& v, const DevState* st, hipStream_t s);
 // ax_next = A x_next fused with the dual step; writes per-block sum (dy)^2 to partDY[block]
 void launchSpmvAxDual(const MatView& A, const IterVecs& v, const DevState* st, double* partDY, hipStream_t s);
@@ -189,7 +195,23 @@ void launchReduceTo(const double* partials, int32_t count, double* out, const De
 // accept/reject + step-size update; dyGlobal != nullptr -> use *dyGlobal instead of partDY;
 // onlyIfPending: the flush of the single-GPU loop (no-op unless st->pending)
 void launchDecide(DevState* st, const double* partDY, int32_t nDY, const double* partDX, const double* partInter,
-                  int32_t nDX, const double* dyGlobal, hipStream_t s, bool onlyIfPending = false);
+                  int32_t nDX, const double* dyGlobal, hipStream_t s, bool onlyIfPending = false,
+                  const double* partQ = nullptr, int32_t nQ = 0);
+
+// ---- fused trial (single GPU, slab layout): 2 launches ------------------------------------------------------
+// aty_next = A' y_next with the movement / interaction partials as above, then — inside the same launch — a grid
+// barrier, the accept/reject decision (every block re-reduces the partials in the fixed order of k_decide), and
+// the NEXT trial's primal step on the columns the block owns: x, x+, A'y are still in registers, A'y+ in LDS, and
+// c, l, u, xSum were fetched while the matrix streamed.  Reads *stIn, block 0 writes *stOut (the other slot).
+// Needs every block of the grid resident at once (one 1024-thread block per CU): fusedAtyBlocksResident() tells
+// how many the device takes; the solver falls back to the 3-launch trial otherwise.  bar: one zeroed 8-byte
+// arrival word per block + one timeout flag (a wait that does not end within ~1 s sets commError instead of
+// hanging the device); the words must be zeroed whenever the trial counter starts again (Solver::reset).
+inline size_t gridBarWords(int nBlocks) { return (size_t)nBlocks + 8; }
+int fusedAtyBlocksResident(const MatView& At, int device);
+void launchSpmvAtyFusedPrimal(const MatView& At, const IterVecs& v, const DevState* stIn, DevState* stOut,
+                              const double* partDY, int32_t nDY, double* partDX, double* partInter,
+                              unsigned long long* bar, hipStream_t s);
 
 // ---- check-iteration kernels (host knows the parity here) -------------------
 void launchFlushAverage(const IterVecs& v, DevState* st, hipStream_t s);
@@ -213,10 +235,10 @@ void launchRowStats(const double* ax, const double* y, const double* rhs, const 
 //  0: sum c*x   1: sum sp*lowerF   2: sum sn*upperF   3: sum ((r-sp+sn)*colScale)^2
 //  4: sum sp^2  5: sum sn^2        6: sum ((aty+sp-sn)*colScale)^2
 //  7: sum x^2   8: sum (min(x,0)*hasLower/colScale)^2    9: sum (max(x,0)*hasUpper/colScale)^2
-// 10: sum 1/2 q x^2 (QP only; the reduced cost then is c + q x - A'y)
+// 10: sum 1/2 x (Qx) (QP only; the reduced cost then is c + Q x - A'y; nx = N x for the off-diagonal part, or nullptr)
 constexpr int kColStats = 11;
 void launchColStats(const double* aty, const double* x, const double* cost, const double* lower,
-                    const double* upper, const double* colScale, const double* qdiag, int32_t n, int scaled,
+                    const double* upper, const double* colScale, const double* qdiag, const double* nx, int32_t n, int scaled,
                     double* slackPos, double* slackNeg, double* partials, int32_t stride, int32_t nBlocks,
                     hipStream_t s);
 // out[q] = sum_{b<nBlocks} partials[q*stride+b], q < nQ (deterministic)

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(kVecThreads) void k_mesh_primal_step(const IterVecs
   if (st->halted || dead(ma)) return;
   const long long e = ma.ms->seq + 1;
   const int cur = st->cur, nxt = cur ^ 1;
-  const double tau = st->tau, avgW = st->avgW;
+  const double tau = st->tau, avgW = st->avgWx;
   const double* __restrict__ x = v.x[cur];
   const double* __restrict__ aty = v.aty[cur];
   double* __restrict__ xn = v.x[nxt];

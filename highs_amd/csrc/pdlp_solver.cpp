@@ -254,6 +254,11 @@ void Solver::construct(const pdlp_problem_t& P, const void* id128) {
   const int64_t nnzIn = P.num_col > 0 && P.a_start ? (int64_t)P.a_start[P.num_col] : 0;
   gpuSetup_ = nnzIn >= 200000;
   if (const char* g = getenv("PDLP_MI355X_GPU_SETUP")) gpuSetup_ = atoi(g) != 0;
+  hasQoff_ = hessianHasOffDiagonal(P);
+  if (hasQoff_) {
+    gpuSetup_ = false;  // the off-diagonal part of Q is scaled with the columns on the host (pdlp_host.cpp applyScaling)
+    if (sharded_) throw std::runtime_error("pdlp_mi355x: a Hessian with off-diagonal entries is solved on one GPU (num_devices = 1)");
+  }
   // sharded: every rank still prepares the WHOLE problem (Ruiz scaling couples all rows and columns) but does it on
   // its device and copies the result back once; only the row-block cut and the upload of its shard stay on the host
   const bool shardedGpuSetup = sharded_ && gpuSetup_;
@@ -362,6 +367,14 @@ void Solver::construct(const pdlp_problem_t& P, const void* id128) {
   // block -> XCD assignment of the two operands (x_ / y_ are zero here: any input will do)
   tuneXcdMap(dA_, x_[0].get(), ax_[0].get(), stream_);
   tuneXcdMap(dAt_, y_[0].get(), sharded_ ? commBuf_.get() : aty_[0].get(), stream_);
+  if (hasQoff_) tuneXcdMap(dQ_, x_[0].get(), nx_[0].get(), stream_);
+  // 2-launch trial where the A' y grid is resident all at once (grid barrier inside the kernel); PDLP_MI355X_FUSED=0 forces 3 launches
+  if (!sharded_) {
+    const char* fe = getenv("PDLP_MI355X_FUSED");
+    const MatView at = dAt_.view();
+    fused_ = !(fe && atoi(fe) == 0) && !hasQoff_ && at.useSlab && fusedAtyBlocksResident(at, opt_.device) >= at.slab.nBlocks;
+    if (fused_) gridBar_.alloc(gridBarWords(at.slab.nBlocks));
+  }
   reset();
   // the trial-batch graph is part of the setup, not of the first iterations
   if (useGraph_ && (!sharded_ || meshMode_)) captureGraph();
@@ -406,7 +419,13 @@ void Solver::uploadProblem() {
   if (!F_.qdiag.empty()) {
     qdiag_.alloc(n);
     qdiag_.upload(F_.qdiag.data(), n, stream_);
-    log(1, "Quadratic objective (diagonal Hessian): proximal primal step\n");
+    if (F_.qoff.beg.empty()) log(1, "Quadratic objective (diagonal Hessian): proximal primal step\n");
+  }
+  if (!F_.qoff.beg.empty()) {
+    dQ_.upload(F_.qoff, n, n, slabMode, stream_);
+    log(1, "Quadratic objective (%lld off-diagonal Hessian entries): proximal step on the diagonal, explicit Q x term for the rest\n",
+        (long long)F_.qoff.beg[n]);
+    F_.qoff = Compressed();
   }
   allocIterates();
   // the big host copies are not needed any more (postsolve uses only the scale vectors and row maps)
@@ -466,6 +485,12 @@ void Solver::allocIterates() {
     x_[k].alloc(n); y_[k].alloc(mLoc_); ax_[k].alloc(mLoc_); aty_[k].alloc(n);
     x_[k].zero(stream_); y_[k].zero(stream_); ax_[k].zero(stream_); aty_[k].zero(stream_);
   }
+  if (hasQoff_) {
+    for (int k = 0; k < 2; ++k) { nx_[k].alloc(n); nx_[k].zero(stream_); }
+    nxAvg_.alloc(n);
+    nxAvg_.zero(stream_);
+    partQ_.alloc(std::max(dQ_.nPartials(), 1));
+  }
   xAvg_.alloc(n); yAvg_.alloc(mLoc_); axAvg_.alloc(mLoc_); atyAvg_.alloc(n);
   xSum_.alloc(n); ySum_.alloc(mLoc_); xLast_.alloc(n); yLast_.alloc(mLoc_);
   slackPos_.alloc(n); slackNeg_.alloc(n); slackPosAvg_.alloc(n); slackNegAvg_.alloc(n);
@@ -494,6 +519,7 @@ void Solver::allocIterates() {
   vecs_.xSum = xSum_.get(); vecs_.ySum = ySum_.get();
   vecs_.cost = cost_.get(); vecs_.rhs = rhs_.get(); vecs_.lower = lower_.get(); vecs_.upper = upper_.get();
   vecs_.qdiag = qdiag_.size() ? qdiag_.get() : nullptr;
+  if (hasQoff_) { vecs_.nx[0] = nx_[0].get(); vecs_.nx[1] = nx_[1].get(); }
   vecs_.n = n; vecs_.m = mLoc_; vecs_.nEqs = F_.nEqs; vecs_.rowOffset = r0_;
   vecsCol_ = vecs_;
   for (int k = 0; k < 2; ++k) { vecsCol_.x[k] += c0_; vecsCol_.aty[k] += c0_; }
@@ -514,7 +540,7 @@ void Solver::syncState() {
   // the decision of the last enqueued trial is still pending in the single-GPU loop: take it now
   if (!sharded_)
     launchDecide(dst(), partDY_.get(), dA_.nPartials(), partDX_.get(), partInter_.get(), dAt_.nPartials(), nullptr,
-                 stream_, true);
+                 stream_, true, hasQoff_ ? partQ_.get() : nullptr, hasQoff_ ? dQ_.nPartials() : 0);
   PDLP_HIP(hipMemcpyAsync(hostState_, dst(), sizeof(DevState), hipMemcpyDeviceToHost, stream_));
   PDLP_HIP(hipStreamSynchronize(stream_));
   PDLP_HIP(hipGetLastError());  // a kernel launch that failed since the last stop (bad grid, LDS request, ...) surfaces here
@@ -550,6 +576,7 @@ void Solver::refreshPowTable() {
 void Solver::pushState(bool wait) {
   refreshPowTable();
   hostState_->pending = 0;
+  needPrimal_ = true;
   PDLP_HIP(hipMemcpyAsync(dst(), hostState_, sizeof(DevState), hipMemcpyHostToDevice, stream_));
   if (wait) PDLP_HIP(hipStreamSynchronize(stream_));
 }
@@ -657,6 +684,7 @@ void Solver::initVariables() {
   launchProjectBounds(x_[0].get(), lower_.get(), upper_.get(), n, stream_);
   deviceAx(x_[0].get(), ax_[0].get());
   deviceATy(y_[0].get(), aty_[0].get());
+  if (hasQoff_) launchSpmvPlain(dQ_.view(), x_[0].get(), nx_[0].get(), stream_);
   xSum_.zero(stream_); ySum_.zero(stream_); xAvg_.zero(stream_); yAvg_.zero(stream_);
   launchProjectBounds(xSum_.get(), lower_.get(), upper_.get(), n, stream_);  // :583-584
   launchProjectBounds(xAvg_.get(), lower_.get(), upper_.get(), n, stream_);
@@ -666,6 +694,7 @@ void Solver::initVariables() {
 void Solver::reset() {
   DevState& s = *hostState_;
   memset(&s, 0, sizeof(s));
+  if (fused_) gridBar_.zero(stream_);  // arrival epochs follow the trial counter, which starts again
   s.adaptive = adaptive_ ? 1 : 0;
   initStepSizes();
   initVariables();
@@ -719,6 +748,37 @@ void Solver::enqueueTrial() {
     launchMeshDecide(dst(), mv, partDY_.get(), dA_.nPartials(), partDX_.get(), partInter_.get(), nb, stream_);
     return;
   }
+  if (!sharded_ && fused_) {
+    // single GPU, 2 launches per trial: A x+ (+ dual step), then A' y+ (+ movement / interaction partials, grid
+    // barrier, decision, the NEXT trial's primal step); after a host push of the state, a stand-alone primal step first
+    if (needPrimal_) {
+      const DevState* in = dst();
+      stPar_ ^= 1;
+      launchDecidePrimal(vecs_, in, dst(), partDY_.get(), dA_.nPartials(), partDX_.get(), partInter_.get(), dAt_.nPartials(), stream_);
+      needPrimal_ = false;
+    }
+    const DevState* st = dst();
+    hipEvent_t* ev = nullptr;
+    if (profile_) {
+      while ((int32_t)profEvents_.size() < 4 * (profTrialsQueued_ + 1)) {
+        hipEvent_t e;
+        PDLP_HIP(hipEventCreate(&e));
+        profEvents_.push_back(e);
+      }
+      ev = &profEvents_[4 * profTrialsQueued_++];
+      PDLP_HIP(hipEventRecord(ev[0], stream_));
+    }
+    launchSpmvAxDual(dA_.view(), vecs_, st, partDY_.get(), stream_);
+    if (ev) PDLP_HIP(hipEventRecord(ev[1], stream_));
+    stPar_ ^= 1;
+    launchSpmvAtyFusedPrimal(dAt_.view(), vecs_, st, dst(), partDY_.get(), dA_.nPartials(), partDX_.get(), partInter_.get(),
+                             gridBar_.get(), stream_);
+    if (ev) {
+      PDLP_HIP(hipEventRecord(ev[2], stream_));
+      PDLP_HIP(hipEventRecord(ev[3], stream_));
+    }
+    return;
+  }
   if (!sharded_) {
     // single GPU: 3 launches per trial — [decision of the previous trial + primal step], A x+ (+ dual step),
     // A' y+ (+ movement / interaction partials); the state alternates between the two slots
@@ -726,7 +786,7 @@ void Solver::enqueueTrial() {
     stPar_ ^= 1;
     DevState* st = dst();
     launchDecidePrimal(vecs_, stIn, st, partDY_.get(), dA_.nPartials(), partDX_.get(), partInter_.get(),
-                       dAt_.nPartials(), stream_);
+                       dAt_.nPartials(), stream_, hasQoff_ ? partQ_.get() : nullptr, hasQoff_ ? dQ_.nPartials() : 0);
     hipEvent_t* ev = nullptr;
     if (profile_) {
       while ((int32_t)profEvents_.size() < 4 * (profTrialsQueued_ + 1)) {
@@ -744,6 +804,7 @@ void Solver::enqueueTrial() {
       PDLP_HIP(hipEventRecord(ev[2], stream_));
       PDLP_HIP(hipEventRecord(ev[3], stream_));
     }
+    if (hasQoff_) launchSpmvQxInteract(dQ_.view(), vecs_, st, partQ_.get(), stream_);  // N x+ and dx . N dx: the fourth launch of a QP trial
     return;
   }
   // row-block sharded, RCCL exchange: A_g' y_g partials are summed over the ranks together
@@ -766,9 +827,12 @@ void Solver::captureGraph() {
   static_assert(kGraphTrials % 2 == 0, "the graph must leave the state-slot parity unchanged");
   hipGraph_t graph = nullptr;
   graphPar_ = stPar_;
+  const bool savedNeed = needPrimal_;
+  needPrimal_ = false;  // (the stand-alone primal step after a host push is never part of the graph)
   PDLP_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
   for (int i = 0; i < kGraphTrials; ++i) enqueueTrial();
   PDLP_HIP(hipStreamEndCapture(stream_, &graph));
+  needPrimal_ = savedNeed;
   PDLP_HIP(hipGraphInstantiate(&graphExec_, graph, nullptr, nullptr, 0));
   (void)hipGraphDestroy(graph);
   graphTrials_ = kGraphTrials;
@@ -785,7 +849,7 @@ void Solver::runUntilHalt() {
     if (useGraph_ && !profile_ && (!sharded_ || meshMode_) && todo >= kGraphMinTodo) {
       if (!graphExec_) captureGraph();
       while (todo >= kGraphMinTodo) {
-        if (stPar_ != graphPar_) {  // the graph starts from the state slot it was captured with
+        if (stPar_ != graphPar_ || (fused_ && needPrimal_)) {  // the graph starts from the state slot it was captured with, after a primal step
           enqueueTrial();
           --todo;
           continue;
@@ -829,6 +893,7 @@ int32_t Solver::nextCheckIter(int32_t it) const {
 void Solver::computeAverage() {
   launchFlushAverage(vecsCol_, dst(), stream_);
   hostState_->avgW = 0.0;
+  hostState_->avgWx = 0.0;
   const double ps = hostState_->sumPrimalStep > 0.0 ? 1.0 / hostState_->sumPrimalStep : 1.0;
   const double ds = hostState_->sumDualStep > 0.0 ? 1.0 / hostState_->sumDualStep : 1.0;
   launchScaleCopy(xAvg_.get() + c0_, xSum_.get() + c0_, ps, nLoc_, stream_);
@@ -836,6 +901,7 @@ void Solver::computeAverage() {
   launchScaleCopy(yAvg_.get(), ySum_.get(), ds, mLoc_, stream_);
   deviceAx(xAvg_.get(), axAvg_.get());
   deviceATy(yAvg_.get(), atyAvg_.get());
+  if (hasQoff_) launchSpmvPlain(dQ_.view(), xAvg_.get(), nxAvg_.get(), stream_);
 }
 
 // PDHG_Compute_Residuals + PDHG_Compute_Infeas_Residuals (cupdlp_solver.c:433-529)
@@ -852,10 +918,10 @@ void Solver::computeResiduals() {
                  part + (size_t)kStatRowAvg * statStride_, statStride_, nbM, stream_);
   const double* qd = qdiag_.size() ? qdiag_.get() + co : nullptr;
   launchColStats(aty_[c].get() + co, x_[c].get() + co, cost_.get() + co, lower_.get() + co, upper_.get() + co,
-                 colScale_.get() + co, qd, nLoc_, sc, slackPos_.get() + co, slackNeg_.get() + co,
+                 colScale_.get() + co, qd, hasQoff_ ? nx_[c].get() : nullptr, nLoc_, sc, slackPos_.get() + co, slackNeg_.get() + co,
                  part + (size_t)kStatColCur * statStride_, statStride_, nbN, stream_);
   launchColStats(atyAvg_.get() + co, xAvg_.get() + co, cost_.get() + co, lower_.get() + co, upper_.get() + co,
-                 colScale_.get() + co, qd, nLoc_, sc, slackPosAvg_.get() + co, slackNegAvg_.get() + co,
+                 colScale_.get() + co, qd, hasQoff_ ? nxAvg_.get() : nullptr, nLoc_, sc, slackPosAvg_.get() + co, slackNegAvg_.get() + co,
                  part + (size_t)kStatColAvg * statStride_, statStride_, nbN, stream_);
   launchFinalReduce(part, statStride_, nbM, 2 * kRowStats, statOut_.get(), stream_);
   launchFinalReduce(part + (size_t)kStatColCur * statStride_, statStride_, nbN, 2 * kColStats,
@@ -949,6 +1015,7 @@ void Solver::restartIterate() {
     PDLP_HIP(hipMemcpyAsync(y_[c].get(), yAvg_.get(), sizeof(double) * mLoc_, hipMemcpyDeviceToDevice, stream_));
     PDLP_HIP(hipMemcpyAsync(ax_[c].get(), axAvg_.get(), sizeof(double) * mLoc_, hipMemcpyDeviceToDevice, stream_));
     PDLP_HIP(hipMemcpyAsync(aty_[c].get(), atyAvg_.get(), sizeof(double) * n, hipMemcpyDeviceToDevice, stream_));
+    if (hasQoff_) PDLP_HIP(hipMemcpyAsync(nx_[c].get(), nxAvg_.get(), sizeof(double) * n, hipMemcpyDeviceToDevice, stream_));
   } else {
     pFeasLR_ = cur_.pFeas; dFeasLR_ = cur_.dFeas; gapLR_ = cur_.gap;
   }
@@ -1186,6 +1253,8 @@ std::pair<double*, int64_t> Solver::lookup(const std::string& name) {
   if (name == "row_scale") return {rowScale_.get(), m};
   if (name == "slack_pos") return {slackPos_.get(), n};
   if (name == "slack_neg") return {slackNeg_.get(), n};
+  if (hasQoff_ && name == "nx") return {nx_[c].get(), n};
+  if (hasQoff_ && name == "nx_next") return {nx_[u].get(), n};
   throw std::runtime_error("unknown vector name: " + name);
 }
 
@@ -1238,11 +1307,13 @@ void Solver::stage(const std::string& name, double* out, int32_t cap) {
     syncState();
     const DevState& s = *hostState_;
     put(0, s.dX2); put(1, s.dY2); put(2, s.inter); put(3, (double)s.lastAccepted);
-    put(4, s.tau); put(5, s.sigma); put(6, s.eta); put(7, s.movement); put(8, s.limit);
+    put(4, s.tau); put(5, s.sigma); put(6, s.eta); put(7, s.movement); put(8, s.limit); put(9, s.qint);
   } else if (name == "mesh_phases") {  // {X, P, S} average wait in us, then the three wait counts (since the last call)
     double us[3] = {0, 0, 0}, cnt[3] = {0, 0, 0};
     if (meshMode_) mesh_->phaseStats(us, cnt, stream_);
     for (int k = 0; k < 3; ++k) { put(k, us[k]); put(3 + k, cnt[k]); }
+  } else if (name == "trial_launches") {  // kernels per trial step of the hot loop (2 = fused decision + primal step)
+    put(0, meshMode_ ? 9.0 : sharded_ ? 7.0 : fused_ ? 2.0 : 3.0);
   } else if (name == "exchange") {  // 0 = not sharded, 1 = RCCL all-reduce, 2 = direct xGMI mesh
     put(0, !sharded_ ? 0.0 : meshMode_ ? 2.0 : 1.0);
   } else if (name == "residuals") {
@@ -1262,6 +1333,7 @@ double Solver::timeKernel(const std::string& name, int32_t reps) {
   if (reps < 1) reps = 1;
   launchFlushAverage(vecsCol_, dst(), stream_);
   hostState_->avgW = 0.0;
+  hostState_->avgWx = 0.0;
   const int32_t savedHalt = hostState_->haltIter;
   hostState_->haltIter = INT_MAX;
   hostState_->halted = 0;

@@ -144,6 +144,11 @@ class Solver : public SolverBase {
   // device
   hipStream_t stream_ = nullptr;
   DeviceMatrix dA_, dAt_;
+  // QP whose Hessian has off-diagonal entries: N = the off-diagonal part (symmetric, scaled with the
+  // columns), N x by parity like A'y, N xAvg at checks, the partials of dx . N dx
+  DeviceMatrix dQ_;
+  bool hasQoff_ = false;
+  DeviceArray<double> nx_[2], nxAvg_, partQ_;
   DeviceArray<double> x_[2], y_[2], ax_[2], aty_[2];
   DeviceArray<double> xAvg_, yAvg_, axAvg_, atyAvg_, xSum_, ySum_, xLast_, yLast_;
   DeviceArray<double> cost_, rhs_, lower_, upper_, colScale_, rowScale_, qdiag_;  // qdiag_: QP only
@@ -153,6 +158,11 @@ class Solver : public SolverBase {
   // one, writes the other); stPar_ = the slot that holds the state after everything enqueued so far.
   DeviceArray<DevState> dState_;
   int32_t stPar_ = 0, graphPar_ = 0;
+  // Fused trial (2 launches, pdlp_kernels.hpp launchSpmvAtyFusedPrimal): the A'y kernel also takes the decision and
+  // does the next primal step.  needPrimal_: the host has pushed a state since the last trial, so the next trial
+  // starts with a stand-alone primal step.
+  bool fused_ = false, needPrimal_ = true;
+  DeviceArray<unsigned long long> gridBar_;
   int32_t stalledRounds_ = 0, stalledSince_ = 0;  // consecutive device stops without an accepted trial
   DevState* dst() const { return dState_.get() + stPar_; }
   DeviceArray<double> powRed_, powGrow_;  // host-tabulated powers of the trial counter (see DevState)

@@ -22,7 +22,7 @@ static inline int g_slab_rows_per_wave(int nMajor, int nMinor) {
   long rw = ((long)nMajor + waves - 1) / waves;
   rw = (rw + 1) / 2 * 2;
   if (rw < 16) rw = 16;
-  if (rw > 512) rw = 512;
+  if (rw > 1024) rw = 1024;
   for (;;) {
     int rb = 0;
     while ((1L << rb) < rw) ++rb;

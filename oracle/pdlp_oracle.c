@@ -88,6 +88,12 @@ typedef struct {
   double* csrVal;
   double *cost, *rhs, *lower, *upper, *hasLower, *hasUpper, *lowerF, *upperF;
   double* qdiag; /* QP extension (no reference counterpart on this path): diagonal of Q, NULL for an LP */
+  /* ... and its off-diagonal part N (symmetric, both triangles, by rows with ascending column; NULL when Q is
+   * diagonal): the diagonal goes into the proximal step, N x is an explicit gradient term (a third SpMV per trial) */
+  int *qnBeg, *qnIdx;
+  double* qnVal;
+  double *nx[2], *nxAvg; /* N x by parity (like A'y), N xAvg at checks */
+  int slabQ, RQ, chunkQ, *planQ, nPlanQ; /* device-order layout of N (g_setup) */
   int *rowType, *rowNewIdx;
   double offset, sense;
   /* scaling */
@@ -136,6 +142,7 @@ static void work_free(Work* w) {
   free(w->csrBeg); free(w->csrIdx); free(w->csrVal);
   free(w->cost); free(w->rhs); free(w->lower); free(w->upper);
   free(w->hasLower); free(w->hasUpper); free(w->lowerF); free(w->upperF); free(w->qdiag);
+  free(w->qnBeg); free(w->qnIdx); free(w->qnVal); free(w->nx[0]); free(w->nx[1]); free(w->nxAvg); free(w->planQ);
   free(w->rowType); free(w->rowNewIdx); free(w->colScale); free(w->rowScale);
   for (int k = 0; k < 2; ++k) { free(w->x[k]); free(w->y[k]); free(w->ax[k]); free(w->aty[k]); }
   free(w->xAvg); free(w->yAvg); free(w->axAvg); free(w->atyAvg);
@@ -188,20 +195,69 @@ static int formulate(Work* w, const pdlp_problem_t* P) {
     if (w->lower[j] < -1e20) w->lower[j] = -INFINITY;
     if (w->upper[j] > 1e20) w->upper[j] = INFINITY;
   }
-  /* QP extension: + 1/2 x'Qx with a DIAGONAL Q given as a lower-triangular column-wise HighsHessian
-   * (model/HighsHessian.h:22-34); off-diagonal nonzeros are refused, as in the product */
+  /* QP extension: + 1/2 x'Qx with Q given as a lower-triangular column-wise HighsHessian (model/HighsHessian.h:22-34),
+   * split into its diagonal and its off-diagonal part N exactly as the product does (pdlp_host.cpp extractHessian):
+   * both triangles of N by rows with ascending column, repeated entries added up left to right */
   w->qdiag = NULL;
+  w->qnBeg = NULL; w->qnIdx = NULL; w->qnVal = NULL;
   if (P->q_dim > 0 && P->q_start && P->q_start[P->q_dim] > 0) {
     int any = 0;
+    long nOff = 0;
     double* q = dalloc(n);
+    int* cnt = ialloc(n + 1);
     for (int j = 0; j < P->q_dim; ++j)
       for (int p = P->q_start[j]; p < P->q_start[j + 1]; ++p) {
+        const int i = P->q_index[p];
         if (P->q_value[p] == 0.0) continue;
-        if (P->q_index[p] != j) { free(q); return 1; }
-        q[j] += P->q_value[p] * w->sense;
         any = 1;
+        if (i == j) { q[j] += P->q_value[p] * w->sense; continue; }
+        if (i < j || i >= P->q_dim) { free(q); free(cnt); return 1; }
+        ++cnt[i + 1]; ++cnt[j + 1];
+        nOff += 2;
       }
     if (any) w->qdiag = q; else free(q);
+    if (nOff > 0) {
+      for (int r = 0; r < n; ++r) cnt[r + 1] += cnt[r];
+      int* pos = ialloc(n);
+      int* tailBeg = ialloc(n);
+      int* idx = ialloc(nOff);
+      double* val = dalloc(nOff);
+      for (int r = 0; r < n; ++r) pos[r] = cnt[r];
+      for (int j = 0; j < P->q_dim; ++j)
+        for (int p = P->q_start[j]; p < P->q_start[j + 1]; ++p) {
+          const int i = P->q_index[p];
+          if (i == j || P->q_value[p] == 0.0) continue;
+          idx[pos[i]] = j; val[pos[i]++] = P->q_value[p] * w->sense;
+        }
+      for (int r = 0; r < n; ++r) tailBeg[r] = pos[r];
+      for (int j = 0; j < P->q_dim; ++j)
+        for (int p = P->q_start[j]; p < P->q_start[j + 1]; ++p) {
+          const int i = P->q_index[p];
+          if (i == j || P->q_value[p] == 0.0) continue;
+          idx[pos[j]] = i; val[pos[j]++] = P->q_value[p] * w->sense;
+        }
+      for (int r = 0; r < n; ++r)
+        for (int a = tailBeg[r] + 1; a < cnt[r + 1]; ++a) {
+          const int ci = idx[a];
+          const double cv = val[a];
+          int b = a - 1;
+          while (b >= tailBeg[r] && idx[b] > ci) { idx[b + 1] = idx[b]; val[b + 1] = val[b]; --b; }
+          idx[b + 1] = ci; val[b + 1] = cv;
+        }
+      w->qnBeg = ialloc(n + 1); w->qnIdx = ialloc(nOff); w->qnVal = dalloc(nOff);
+      long k = 0;
+      for (int r = 0; r < n; ++r) {
+        w->qnBeg[r] = (int)k;
+        for (int a = cnt[r]; a < cnt[r + 1]; ++a) {
+          if (a > cnt[r] && idx[a] == w->qnIdx[k - 1]) w->qnVal[k - 1] += val[a];
+          else { w->qnIdx[k] = idx[a]; w->qnVal[k] = val[a]; ++k; }
+        }
+      }
+      w->qnBeg[n] = (int)k;
+      free(pos); free(tailBeg); free(idx); free(val);
+      w->nx[0] = dalloc(n); w->nx[1] = dalloc(n); w->nxAvg = dalloc(n);
+    }
+    free(cnt);
   }
   /* row permutation: EQ/BOUND first (:382-392), then LEQ (negated) / GEQ (:394-404) */
   for (int i = 0, k = 0; i < m; ++i) {
@@ -241,6 +297,9 @@ static void scale_apply(Work* w, const double* cs, const double* rs) {
   const int n = w->n, m = w->m;
   o_ediv(n, w->cost, cs);
   if (w->qdiag) { o_ediv(n, w->qdiag, cs); o_ediv(n, w->qdiag, cs); } /* 1/2 q x^2 with x = x'/cs */
+  if (w->qnBeg)
+    for (int r = 0; r < n; ++r)
+      for (int p = w->qnBeg[r]; p < w->qnBeg[r + 1]; ++p) w->qnVal[p] = (w->qnVal[p] / cs[r]) / cs[w->qnIdx[p]];
   o_emul(n, w->lower, cs);
   o_emul(n, w->upper, cs);
   o_ediv(m, w->rhs, rs);
@@ -342,6 +401,17 @@ static void o_ATy(const Work* w, double* aty, const double* y) {
 }
 
 
+/* N x for the off-diagonal part of a QP's Hessian (rows summed left to right, like A x on the device) */
+static void g_spmv(const int* beg, const int* idx, const double* val, int nMajor, const double* in, double* out, int longLimit);
+static void o_Nx(const Work* w, double* nx, const double* x) {
+  if (w->gpuOrder) { g_spmv(w->qnBeg, w->qnIdx, w->qnVal, w->n, x, nx, w->chunkQ); return; }
+  for (int r = 0; r < w->n; ++r) {
+    double s = 0.0;
+    for (int p = w->qnBeg[r]; p < w->qnBeg[r + 1]; ++p) s += w->qnVal[p] * x[w->qnIdx[p]];
+    nx[r] = s;
+  }
+}
+
 /* ------------------------------------------------------------------ */
 /* GPU-ORDER mode (opt->reserved[0] == 1)                              */
 /*                                                                    */
@@ -414,6 +484,13 @@ static void g_setup(Work* w, int layoutMode) {
   else w->planA = g_plan(w->csrBeg, m, w->chunkA, &w->nPlanA);
   if (w->slabAt) { w->RAt = g_slab_rows_per_wave(n, m) * G_SLAB_WAVES; w->planAt = ialloc(2); w->nPlanAt = 0; }
   else w->planAt = g_plan(w->cssBeg, n, w->chunkAt, &w->nPlanAt);
+  if (w->qnBeg) { /* N gathers x (n), majors = n */
+    w->slabQ = layoutMode == 2 || (layoutMode == 0 && n >= G_SLAB_AUTO_MINOR);
+    if (w->slabQ && g_slab_rows_per_wave(n, n) == 0) w->slabQ = 0;
+    w->chunkQ = w->slabQ ? G_SLAB_LONG : g_chunk_for(w->qnBeg[n]);
+    if (w->slabQ) { w->RQ = g_slab_rows_per_wave(n, n) * G_SLAB_WAVES; w->planQ = ialloc(2); w->nPlanQ = 0; }
+    else w->planQ = g_plan(w->qnBeg, n, w->chunkQ, &w->nPlanQ);
+  }
   const long mx = 2L * (n > m ? n : m) + G_MAXGRID + 8;
   w->gPartA = dalloc(mx); w->gPartB = dalloc(mx); w->gStat = dalloc(mx);
 }
@@ -422,19 +499,19 @@ static void g_setup(Work* w, int layoutMode) {
  * one per work block of the stream (CSR layout) or per 1024-thread block of R majors (slab layout; long majors
  * skipped), then the long majors in ascending order — one slot each, or, beyond 2048 of them, one slot per group
  * of G consecutive ones added left to right (k_long_groups). */
-static double g_epilogue_total(Work* w, int isAt, const double* perMajor) {
+static double g_epilogue_total(Work* w, int isAt /* 0: A, 1: A', 2: N (off-diagonal Hessian) */, const double* perMajor) {
   const int nMajor = isAt ? w->n : w->m;
-  const int slab = isAt ? w->slabAt : w->slabA;
-  const int* plan = isAt ? w->planAt : w->planA;
-  const int nPlan = isAt ? w->nPlanAt : w->nPlanA;
-  const int limit = isAt ? w->chunkAt : w->chunkA;
-  const int* beg = isAt ? w->cssBeg : w->csrBeg;
+  const int slab = isAt == 2 ? w->slabQ : isAt ? w->slabAt : w->slabA;
+  const int* plan = isAt == 2 ? w->planQ : isAt ? w->planAt : w->planA;
+  const int nPlan = isAt == 2 ? w->nPlanQ : isAt ? w->nPlanAt : w->nPlanA;
+  const int limit = isAt == 2 ? w->chunkQ : isAt ? w->chunkAt : w->chunkA;
+  const int* beg = isAt == 2 ? w->qnBeg : isAt ? w->cssBeg : w->csrBeg;
   double* part = w->gPartA;
   int np = 0;
   if (!slab) {
     for (int b = 0; b < nPlan; ++b) part[np++] = g_block_partial(plan, b, perMajor);
   } else {
-    const int R = isAt ? w->RAt : w->RA;
+    const int R = isAt == 2 ? w->RQ : isAt ? w->RAt : w->RA;
     const int nBlocks = (nMajor + R - 1) / R;
     for (int b = 0; b < nBlocks; ++b) { /* k_spmv_slab: 1024 threads, thread t owns majors b*R + t, + 1024, ... */
       double lane[G_SLAB_T];
@@ -466,7 +543,7 @@ static double g_epilogue_total(Work* w, int isAt, const double* perMajor) {
 }
 
 /* movement / interaction sums of one trial in device order */
-static void g_trial_sums(Work* w, double* dX2, double* dY2, double* inter) {
+static void g_trial_sums(Work* w, double* dX2, double* dY2, double* inter, double* qint) {
   const int n = w->n, m = w->m, c = w->nIter % 2, u = (w->nIter + 1) % 2;
   double* perM = w->bufMax2;
   double* perN = w->bufMax3;
@@ -476,10 +553,15 @@ static void g_trial_sums(Work* w, double* dX2, double* dY2, double* inter) {
   *dX2 = g_epilogue_total(w, 1, perN);
   for (int j = 0; j < n; ++j) { const double dx = w->x[c][j] - w->x[u][j]; const double da = w->aty[c][j] - w->aty[u][j]; perN[j] = dx * da; }
   *inter = g_epilogue_total(w, 1, perN);
+  *qint = 0.0;
+  if (w->qnBeg) {
+    for (int j = 0; j < n; ++j) { const double dx = w->x[c][j] - w->x[u][j]; const double dq = w->nx[c][j] - w->nx[u][j]; perN[j] = dx * dq; }
+    *qint = g_epilogue_total(w, 2, perN);
+  }
 }
 
 /* k_row_stats / k_col_stats element functions */
-typedef struct { const Work* w; const double *ax, *y, *aty, *x; int q; } GStatCtx;
+typedef struct { const Work* w; const double *ax, *y, *aty, *x; int q; const double* nx; } GStatCtx;
 static double g_row_elem(const void* vc, int i) {
   const GStatCtx* c = (const GStatCtx*)vc;
   const Work* w = c->w;
@@ -501,6 +583,8 @@ static double g_col_elem(const void* vc, int j) {
   double r = -atyv + cj;
   const double qj = w->qdiag ? w->qdiag[j] : 0.0;
   if (w->qdiag) r += qj * xv; /* reduced cost c + Qx - A'y */
+  const double nj = c->nx ? c->nx[j] : 0.0;
+  if (c->nx) r += nj;
   const double sp = (r > 0.0 ? r : 0.0) * hasL;
   const double sn = (-(r < 0.0 ? r : 0.0)) * hasU;
   switch (c->q) {
@@ -513,16 +597,16 @@ static double g_col_elem(const void* vc, int j) {
     case 6: { double pc = (atyv + sp) - sn; pc *= cs; return pc * pc; }
     case 7: return xv * xv;
     case 8: { double lb = (xv < 0.0 ? xv : 0.0) * hasL; if (w->ifScaled) lb /= cs; return lb * lb; }
-    case 10: return (0.5 * qj * xv) * xv;
+    case 10: { double h = (0.5 * qj * xv) * xv; if (c->nx) h += (0.5 * nj) * xv; return h; }
     default: { double ub = (xv > 0.0 ? xv : 0.0) * hasU; if (w->ifScaled) ub /= cs; return ub * ub; }
   }
 }
 /* residuals + infeasibility numbers of one iterate, as Solver::computeResiduals derives them */
-static void g_residuals(Work* w, const double* x, const double* y, const double* ax, const double* aty,
+static void g_residuals(Work* w, const double* x, const double* y, const double* ax, const double* aty, const double* nx,
                         double* sp, double* sn, double* pObj, double* dObj, double* pFeas, double* dFeas,
                         double* gap, double* relGap, double* pInfObj, double* pInfRes, double* dInfObj,
                         double* dInfRes) {
-  GStatCtx c = {w, ax, y, aty, x, 0};
+  GStatCtx c = {w, ax, y, aty, x, 0, nx};
   double rs[4], cs[11];
   for (int q = 0; q < 4; ++q) { c.q = q; rs[q] = g_grid_sum(w->m, g_row_elem, &c, w->gStat); }
   for (int q = 0; q < 10; ++q) { c.q = q; cs[q] = g_grid_sum(w->n, g_col_elem, &c, w->gStat); }
@@ -532,6 +616,7 @@ static void g_residuals(Work* w, const double* x, const double* y, const double*
     const double l = w->lower[j], u = w->upper[j];
     double r = -aty[j] + w->cost[j];
     if (w->qdiag) r += w->qdiag[j] * x[j];
+    if (nx) r += nx[j];
     sp[j] = (r > 0.0 ? r : 0.0) * (l > -INFINITY ? 1.0 : 0.0);
     sn[j] = (-(r < 0.0 ? r : 0.0)) * (u < INFINITY ? 1.0 : 0.0);
   }
@@ -557,10 +642,14 @@ static double g_dot_elem(const void* vc, int i) { const GDiffCtx* c = (const GDi
 /* ------------------------------------------------------------------ */
 /* residuals — cupdlp_solver.c:12-204 (CPU branches)                   */
 /* ------------------------------------------------------------------ */
-static void primal_feasibility(Work* w, const double* ax, const double* x, double* feas, double* obj) {
+static void primal_feasibility(Work* w, const double* ax, const double* x, const double* nx, double* feas, double* obj) {
   const int n = w->n, m = w->m;
   double cx = o_dot(n, x, w->cost);
-  if (w->qdiag) { double h = 0.0; for (int j = 0; j < n; ++j) h += (0.5 * w->qdiag[j] * x[j]) * x[j]; cx += h; }
+  if (w->qdiag) {
+    double h = 0.0;
+    for (int j = 0; j < n; ++j) { double t = (0.5 * w->qdiag[j] * x[j]) * x[j]; if (nx) t += (0.5 * nx[j]) * x[j]; h += t; }
+    cx += h;
+  }
   *obj = cx * w->sense + w->offset;
   double* r = w->bufM;
   memcpy(r, ax, sizeof(double) * (size_t)m);
@@ -569,8 +658,8 @@ static void primal_feasibility(Work* w, const double* ax, const double* x, doubl
   if (w->ifScaled) o_emul(m, r, w->rowScale);
   *feas = o_nrm2(m, r);
 }
-static void dual_feasibility(Work* w, const double* aty, const double* y, const double* x, double* feas, double* obj,
-                             double* sp, double* sn) {
+static void dual_feasibility(Work* w, const double* aty, const double* y, const double* x, const double* nx, double* feas,
+                             double* obj, double* sp, double* sn) {
   const int n = w->n, m = w->m;
   double d = o_dot(m, y, w->rhs);
   double* r = w->bufN;
@@ -579,7 +668,12 @@ static void dual_feasibility(Work* w, const double* aty, const double* y, const 
   o_axpy(n, 1.0, w->cost, r);
   double qh = 0.0;
   if (w->qdiag)
-    for (int j = 0; j < n; ++j) { r[j] += w->qdiag[j] * x[j]; qh += (0.5 * w->qdiag[j] * x[j]) * x[j]; }
+    for (int j = 0; j < n; ++j) {
+      r[j] += w->qdiag[j] * x[j];
+      double t = (0.5 * w->qdiag[j] * x[j]) * x[j];
+      if (nx) { r[j] += nx[j]; t += (0.5 * nx[j]) * x[j]; }
+      qh += t;
+    }
   memcpy(sp, r, sizeof(double) * (size_t)n);
   o_proj_pos(n, sp);
   o_emul(n, sp, w->hasLower);
@@ -600,17 +694,19 @@ static void dual_feasibility(Work* w, const double* aty, const double* y, const 
 static void compute_residuals(Work* w) {
   const int c = w->nIter % 2;
   if (w->gpuOrder) {
-    g_residuals(w, w->x[c], w->y[c], w->ax[c], w->aty[c], w->slackPos, w->slackNeg, &w->pObj, &w->dObj, &w->pFeas,
+    g_residuals(w, w->x[c], w->y[c], w->ax[c], w->aty[c], w->qnBeg ? w->nx[c] : NULL, w->slackPos, w->slackNeg, &w->pObj, &w->dObj, &w->pFeas,
                 &w->dFeas, &w->gap, &w->relGap, &w->pInfObj, &w->pInfRes, &w->dInfObj, &w->dInfRes);
-    g_residuals(w, w->xAvg, w->yAvg, w->axAvg, w->atyAvg, w->slackPosAvg, w->slackNegAvg, &w->pObjA, &w->dObjA,
+    g_residuals(w, w->xAvg, w->yAvg, w->axAvg, w->atyAvg, w->qnBeg ? w->nxAvg : NULL, w->slackPosAvg, w->slackNegAvg, &w->pObjA, &w->dObjA,
                 &w->pFeasA, &w->dFeasA, &w->gapA, &w->relGapA, &w->pInfObjA, &w->pInfResA, &w->dInfObjA,
                 &w->dInfResA);
     return;
   }
-  primal_feasibility(w, w->ax[c], w->x[c], &w->pFeas, &w->pObj);
-  dual_feasibility(w, w->aty[c], w->y[c], w->x[c], &w->dFeas, &w->dObj, w->slackPos, w->slackNeg);
-  primal_feasibility(w, w->axAvg, w->xAvg, &w->pFeasA, &w->pObjA);
-  dual_feasibility(w, w->atyAvg, w->yAvg, w->xAvg, &w->dFeasA, &w->dObjA, w->slackPosAvg, w->slackNegAvg);
+  const double* nxc = w->qnBeg ? w->nx[c] : NULL;
+  const double* nxa = w->qnBeg ? w->nxAvg : NULL;
+  primal_feasibility(w, w->ax[c], w->x[c], nxc, &w->pFeas, &w->pObj);
+  dual_feasibility(w, w->aty[c], w->y[c], w->x[c], nxc, &w->dFeas, &w->dObj, w->slackPos, w->slackNeg);
+  primal_feasibility(w, w->axAvg, w->xAvg, nxa, &w->pFeasA, &w->pObjA);
+  dual_feasibility(w, w->atyAvg, w->yAvg, w->xAvg, nxa, &w->dFeasA, &w->dObjA, w->slackPosAvg, w->slackNegAvg);
   w->gap = w->pObj - w->dObj;
   w->relGap = fabs(w->pObj - w->dObj) / (1.0 + fabs(w->pObj) + fabs(w->dObj));
   w->gapA = w->pObjA - w->dObjA;
@@ -675,11 +771,12 @@ static void compute_infeas_residuals(Work* w) {
 /* steps — cupdlp_step.c                                               */
 /* ------------------------------------------------------------------ */
 /* PDHG_primalGradientStep :16-40 (CPU branch: copy, 2 axpy, projub, projlb) */
-static void primal_step(Work* w, double* xU, const double* x, const double* aty, double tau) {
+static void primal_step(Work* w, double* xU, const double* x, const double* aty, const double* nx, double tau) {
   const int n = w->n;
   memcpy(xU, x, sizeof(double) * (size_t)n);
   o_axpy(n, -tau, w->cost, xU);
   o_axpy(n, tau, aty, xU);
+  if (nx) o_axpy(n, -tau, nx, xU); /* explicit gradient term of the off-diagonal part of Q */
   if (w->qdiag) /* prox of the separable quadratic: argmin <c - A'y, x> + 1/2 q x^2 + (x - x_k)^2 / (2 tau) */
     for (int j = 0; j < n; ++j) xU[j] = xU[j] / (1.0 + tau * w->qdiag[j]);
   o_proj_ub_vec(n, xU, w->upper);
@@ -695,12 +792,13 @@ static void dual_step(Work* w, double* yU, const double* y, const double* ax, co
   o_proj_pos(m - w->nEqs, yU + w->nEqs);
 }
 /* cupdlp_compute_interaction_and_movement linalg.c:772-801 (CPU branch) */
-static void movement_interaction(Work* w, double* movement, double* interaction) {
+static void movement_interaction(Work* w, double* movement, double* interaction, double* qint) {
   const int n = w->n, m = w->m, c = w->nIter % 2, u = (w->nIter + 1) % 2;
   const double sb = sqrt(w->beta);
+  *qint = 0.0;
   if (w->gpuOrder) {
     double dX2, dY2;
-    g_trial_sums(w, &dX2, &dY2, interaction);
+    g_trial_sums(w, &dX2, &dY2, interaction, qint);
     *movement = dX2 * 0.5 * sb + dY2 / (2.0 * sb);
     return;
   }
@@ -714,6 +812,10 @@ static void movement_interaction(Work* w, double* movement, double* interaction)
   memcpy(d3, w->aty[c], sizeof(double) * (size_t)n); o_axpy(n, -1.0, w->aty[u], d3);
   *interaction = o_dot(n, d2, d3);
   *movement = dX * 0.5 * sb + dY / (2.0 * sb);
+  if (w->qnBeg) { /* dx . N dx (d2 still holds x - x+) */
+    memcpy(d3, w->nx[c], sizeof(double) * (size_t)n); o_axpy(n, -1.0, w->nx[u], d3);
+    *qint = o_dot(n, d2, d3);
+  }
 }
 /* PDHG_Update_Iterate_Adaptive_Step_Size :215-310; returns 1 on time-out */
 static int update_adaptive(Work* w) {
@@ -723,13 +825,16 @@ static int update_adaptive(Work* w) {
   while (!done) {
     ++w->nStepSizeIter;
     const double tau = eta / sqrt(w->beta), sigma = eta * sqrt(w->beta);
-    primal_step(w, w->x[u], w->x[c], w->aty[c], tau);
+    primal_step(w, w->x[u], w->x[c], w->aty[c], w->qnBeg ? w->nx[c] : NULL, tau);
     o_Ax(w, w->ax[u], w->x[u]);
     dual_step(w, w->y[u], w->y[c], w->ax[c], w->ax[u], sigma);
     o_ATy(w, w->aty[u], w->y[u]);
-    double mov = 0.0, inter = 0.0;
-    movement_interaction(w, &mov, &inter);
-    const double limit = (inter != 0.0) ? mov / fabs(inter) : INFINITY;
+    if (w->qnBeg) o_Nx(w, w->nx[u], w->x[u]);
+    double mov = 0.0, inter = 0.0, qint = 0.0;
+    movement_interaction(w, &mov, &inter, &qint);
+    /* QP with off-diagonal Hessian entries: the forward step on N also needs tau <= |dx|^2 / |dx . N dx| (pdlp_devfn.hpp decideCore) */
+    const double den = fabs(inter) + 0.5 * fabs(qint);
+    const double limit = (den != 0.0) ? mov / den : INFINITY;
     if (eta <= limit) {
       done = 1;
     } else {
@@ -749,10 +854,12 @@ static void update_constant(Work* w) {
   const int c = w->nIter % 2, u = (w->nIter + 1) % 2;
   o_Ax(w, w->ax[c], w->x[c]);
   o_ATy(w, w->aty[c], w->y[c]);
-  primal_step(w, w->x[u], w->x[c], w->aty[c], w->primalStep);
+  if (w->qnBeg) o_Nx(w, w->nx[c], w->x[c]);
+  primal_step(w, w->x[u], w->x[c], w->aty[c], w->qnBeg ? w->nx[c] : NULL, w->primalStep);
   o_Ax(w, w->ax[u], w->x[u]);
   dual_step(w, w->y[u], w->y[c], w->ax[c], w->ax[u], w->dualStep);
   o_ATy(w, w->aty[u], w->y[u]);
+  if (w->qnBeg) o_Nx(w, w->nx[u], w->x[u]);
 }
 /* PDHG_Update_Average :422-442 — uses the step sizes ALREADY overwritten with the next eta */
 static void update_average(Work* w) {
@@ -773,6 +880,7 @@ static void compute_average(Work* w) {
   o_scal(w->m, ds, w->yAvg);
   o_Ax(w, w->axAvg, w->xAvg);
   o_ATy(w, w->atyAvg, w->yAvg);
+  if (w->qnBeg) o_Nx(w, w->nxAvg, w->xAvg);
 }
 /* PDHG_Power_Method :71-145 (20 iterations; the logged residual is not restated) */
 static double power_method(Work* w) {
@@ -823,6 +931,7 @@ static void init_variables(Work* w, int hasStart) {
   if (!hasStart) memset(w->y[c], 0, sizeof(double) * (size_t)m);
   o_Ax(w, w->ax[c], w->x[c]);
   o_ATy(w, w->aty[c], w->y[c]);
+  if (w->qnBeg) o_Nx(w, w->nx[c], w->x[c]);
   memset(w->xSum, 0, sizeof(double) * (size_t)n);
   memset(w->ySum, 0, sizeof(double) * (size_t)m);
   memset(w->xAvg, 0, sizeof(double) * (size_t)n);
@@ -910,6 +1019,7 @@ static void restart_iterate(Work* w) {
     memcpy(w->y[c], w->yAvg, sizeof(double) * (size_t)m);
     memcpy(w->ax[c], w->axAvg, sizeof(double) * (size_t)m);
     memcpy(w->aty[c], w->atyAvg, sizeof(double) * (size_t)n);
+    if (w->qnBeg) memcpy(w->nx[c], w->nxAvg, sizeof(double) * (size_t)n);
   } else {
     w->pFeasLR = w->pFeas; w->dFeasLR = w->dFeas; w->gapLR = w->gap;
   }
