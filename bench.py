@@ -39,6 +39,10 @@ CONFIGS = {
     "c": dict(structured=True, name="structured block-angular network LP, 263k x 2.1M, 5.3M nnz, 256 dense linking rows (seed 1)"),
     "qp": dict(m=500_000, n=500_000, nnz=4_000_000, qp=True,
                name="synthetic random sparse QP 500kx500k, 4M nnz, diagonal Q ~ U(0,1) (seed 1)"),
+    # the same with a NON-diagonal Hessian (the Q x SpMV of the general-Q path, a fourth launch per trial): tridiagonal,
+    # diagonally dominant (PSD), off-diagonal entries ~ U(-0.5, 0.5), diagonal = their absolute row sums + U(0,1)
+    "qpn": dict(m=500_000, n=500_000, nnz=4_000_000, qp=True, banded=True,
+                name="synthetic random sparse QP 500kx500k, 4M nnz, tridiagonal PSD Q (seed 1)"),
 }
 PRE_ROLL = 40  # iterations of start-up excluded from every timed window
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured copy ceiling
@@ -162,8 +166,20 @@ def main():
             raise SystemExit("--config qp runs on the pdlp path only")
         import numpy as np
         ncol = sp_.struct.num_col
-        qkeep = (np.arange(ncol + 1, dtype=np.int32), np.arange(ncol, dtype=np.int32),
-                 np.random.default_rng(1).uniform(0.0, 1.0, ncol))
+        if cfg.get("banded"):
+            rng = np.random.default_rng(1)
+            off = rng.uniform(-0.5, 0.5, ncol - 1)
+            diag = np.abs(np.concatenate([off, [0.0]])) + np.abs(np.concatenate([[0.0], off])) + rng.uniform(0.0, 1.0, ncol)
+            st = np.zeros(ncol + 1, np.int32)
+            st[1:] = np.cumsum(np.concatenate([np.full(ncol - 1, 2), [1]]))
+            qi = np.empty(2 * ncol - 1, np.int32)
+            qv = np.empty(2 * ncol - 1)
+            qi[0::2], qv[0::2] = np.arange(ncol), diag
+            qi[1::2], qv[1::2] = np.arange(1, ncol), off
+            qkeep = (st, qi, qv)
+        else:
+            qkeep = (np.arange(ncol + 1, dtype=np.int32), np.arange(ncol, dtype=np.int32),
+                     np.random.default_rng(1).uniform(0.0, 1.0, ncol))
         sp_.struct.q_dim = ncol
         sp_.struct.q_start = qkeep[0].ctypes.data_as(abi.c_i32p)
         sp_.struct.q_index = qkeep[1].ctypes.data_as(abi.c_i32p)
@@ -275,6 +291,8 @@ def main():
     b_iter, b_ax, b_aty = (algorithmic_bytes if args.solver == "pdlp" else algorithmic_bytes_hipdlp)(n, m, nnz)
     if cfg.get("qp"):
         b_iter += 8 * n  # the primal step also reads the diagonal of Q
+    if cfg.get("banded"):  # N x+ SpMV: 12 B per off-diagonal entry (both triangles) + row pointers + x, x+, N x in, N x+ out; + N x in the primal step
+        b_iter += 12 * 2 * (n - 1) + 4 * (n + 1) + 8 * 5 * n
     ms_step = elapsed * 1e3 / st.iters
     # dominant kernel, timed live with HIP events on the solver's own stream, IN the loop (same
     # kernel sequence and cache state as the timed region; what rocprofv3 --kernel-trace reports)

@@ -50,6 +50,29 @@ class HighsLp:
         np.add.at(q, cols[idx == cols], val[idx == cols])
         return q
 
+    def hessian_times(self, x):
+        """Q x for the symmetric Q whose lower triangle is stored (zeros for an LP)."""
+        q = np.zeros(self.num_col)
+        if self.hessian is None:
+            return q
+        x = np.asarray(x, dtype=np.float64)
+        st, idx, val = self.hessian
+        cols = np.repeat(np.arange(len(st) - 1), np.diff(st))
+        np.add.at(q, idx, val * x[cols])
+        off = idx != cols
+        np.add.at(q, cols[off], val[off] * x[idx[off]])
+        return q
+
+    def set_hessian_from_dense(self, Q):
+        """Lower triangle (column-wise) of a dense symmetric matrix."""
+        Q = np.asarray(Q, dtype=np.float64)
+        st, idx, val = [0], [], []
+        for j in range(self.num_col):
+            rows = np.nonzero(Q[j:, j])[0] + j
+            idx += list(rows); val += list(Q[rows, j]); st.append(len(idx))
+        self.hessian = (np.array(st, np.int32), np.array(idx, np.int32), np.array(val, np.float64))
+        return self
+
     def normalise(self):
         f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
         self.col_cost, self.col_lower, self.col_upper = f(self.col_cost), f(self.col_lower), f(self.col_upper)
@@ -67,7 +90,7 @@ class HighsLp:
         x = np.asarray(col_value)
         v = float(self.offset + np.dot(self.col_cost, x))
         if self.hessian is not None:
-            v += 0.5 * float(np.dot(self.hessian_diagonal() * x, x))
+            v += 0.5 * float(np.dot(self.hessian_times(x), x))
         return v
 
     def row_activity(self, col_value):
@@ -312,7 +335,7 @@ def kkt_measures(lp, col_value, col_dual, row_value, row_dual, primal_feasibilit
     dinf = np.where(meaningful & ~below, np.maximum(dual, 0.0), dinf)
     # residuals: |Ax - row_value| and |A'y + col_dual - c| (HighsSolution.cpp:196-199,263-268,400+)
     pres = np.abs(ax - rv)
-    qx = lp.hessian_diagonal() * x  # zeros for an LP
+    qx = lp.hessian_times(x)  # zeros for an LP
     dres = np.abs(aty + cd - lp.col_cost - qx)
     # dual objective: offset + sum bound * dual, bound = lower if primal < mid else upper; free -> 1
     ndual = np.concatenate([cd, rd])

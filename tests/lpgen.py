@@ -75,6 +75,21 @@ def random_diag_qp(seed, m=None, n=None):
     return lp.set_diagonal_hessian(lp.sense * q)
 
 
+def random_sparse_qp(seed, m=None, n=None, density=None):
+    """random_lp(seed) made a convex QP with a SPARSE NON-DIAGONAL Hessian: Q = G'G + diag(d) for a sparse random G
+    (so Q is PSD by construction, with off-diagonal entries where two columns share a row of G) and d = 0 for about
+    a third of the columns; times the objective sense, so that the maximisation instances stay concave."""
+    lp = drop_free_rows(random_lp(seed, m, n))
+    rng = np.random.default_rng(2000 + seed)
+    nc = lp.num_col
+    k = max(2, nc // 2)
+    dens = density if density is not None else min(0.5, 3.0 / nc)
+    G = rng.standard_normal((k, nc)) * (rng.random((k, nc)) < dens)
+    d = np.where(rng.random(nc) < 0.35, 0.0, rng.uniform(0.1, 2.0, nc))
+    Q = G.T @ G + np.diag(d)
+    return lp.set_hessian_from_dense(lp.sense * Q)
+
+
 def structured_lp(seed=1, commodities=64, nodes=4096, arcs=32768, link_rows=256, link_nnz=4096, extra_rows=512):
     """A block-structured LP of the kind BASELINE config 3 stands for (pds-class multi-commodity / staircase
     models; pds-100 itself is not in the reference tree): `commodities` network blocks — node-balance EQUALITY
