@@ -1,7 +1,8 @@
 """The drop-in boundary on the driver's box: the REFERENCE's own unmodified CLI, Catch2 `[pdlp]` unit tests and
 a plain C client of its C API, all running on a libhighs.so whose PDLP wrapper TUs are replaced by
-integration/*Mi355x.cpp -> libpdlp_mi355x.so (built in the build container by integration/build_dropin.sh;
-integration/_build travels with the repo snapshot).  Skipped where that build is absent."""
+integration/*Mi355x.cpp -> libpdlp_mi355x.so (built by `make -C integration` — a CMake-free recipe that compiles the
+reference's TUs from where they lie; __graft_entry__.build() runs it wherever the reference tree exists — and
+integration/_build travels with the repo snapshot).  A missing build FAILS where the reference tree is present."""
 import json
 import os
 import re
@@ -17,8 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BUILD = os.path.join(ROOT, "integration", "_build")
 GOLD = os.path.join(ROOT, "tests", "golden")
 REF = json.load(open(os.path.join(GOLD, "reference_pdlp.json")))
-needs_build = pytest.mark.skipif(not os.path.exists(os.path.join(BUILD, "libhighs.so.1")),
-                                 reason="integration/_build not present (build container only)")
+needs_build = pytest.mark.usefixtures("dropin_build")  # tests/conftest.py: FAILS where the reference tree is present and the build is not
 
 
 def _env(**extra):

@@ -191,8 +191,7 @@ def test_reader_errors(tmp_path):
 # ---- the reader behind Highs::readModel (integration/FilereaderMpsMi355x.cpp in the drop-in libhighs) ------------------
 ROOT = os.path.dirname(HERE)
 BUILD = os.path.join(ROOT, "integration", "_build")
-needs_build = pytest.mark.skipif(not os.path.exists(os.path.join(BUILD, "libhighs.so.1")),
-                                 reason="integration/_build not present (made in the build container by integration/build_dropin.sh)")
+needs_build = pytest.mark.usefixtures("dropin_build")  # tests/conftest.py: FAILS where the reference tree is present and the build is not
 
 
 def _dropin_env():
