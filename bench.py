@@ -67,6 +67,26 @@ def algorithmic_bytes_hipdlp(n, m, nnz):
     return b_ax + b_aty, b_ax, b_aty
 
 
+def scaling_model(n, m, nnz, G, ax_us_1gpu, aty_us_1gpu, vec_us_1gpu):
+    """Predicted microseconds per phase of one trial on G GPUs with the two-all-gathers layout, from
+    the single-GPU kernel times and the node's link figures: xGMI 76.8 GB/s per direction and link (153.6 GB/s
+    bidirectional, 7 links per GPU: MI355X_MICROARCH.md / the task statement), every rank sends its slice to the G-1
+    peers over G-1 separate links, a flag hop ~3 us, a kernel ~3 us at least, a kernel boundary ~1.7 us.  The
+    measured `exchange_waits` of an N > 1 run are printed next to it."""
+    link_gbs, hop_us, floor_us, boundary_us = 76.8, 3.0, 3.0, 1.7
+    x_us = 8.0 * n / G / (link_gbs * 1e3) + hop_us   # the own slice to each peer, one link per peer
+    y_us = 8.0 * m / G / (link_gbs * 1e3) + hop_us
+    phases = {"primal_step_own_columns": max(floor_us, vec_us_1gpu / G), "X_allgather_x": x_us,
+              "spmv_ax_dual_own_rows": max(floor_us, ax_us_1gpu / G), "Y_allgather_y": y_us,
+              "spmv_aty_interact_own_columns": max(floor_us, aty_us_1gpu / G), "S_scalars_and_decision": hop_us + 1.0,
+              "kernel_boundaries": 9 * boundary_us}
+    total = sum(phases.values())
+    return {"ranks": G, "us_per_phase": phases, "us_per_trial": total,
+            "bytes_sent_per_rank_and_trial": 8 * (n + m) * (G - 1) // G,
+            "assumptions": "xGMI %.1f GB/s per direction and link, flag hop %.0f us, kernel floor %.0f us, boundary %.1f us"
+                           % (link_gbs, hop_us, floor_us, boundary_us)}
+
+
 def cpu_baseline(sp_struct, cfg, limits, solver_name="pdlp"):
     """Reference CPU pdlp (single thread) on a bounded sample of the same LP, as SURVEY §8(d) prescribes: the same
     solve at TWO iteration limits, iterations/s = the slope between them — set-up and the start-up phase (a check at
@@ -268,13 +288,15 @@ def main():
         st, elapsed = timed(max(400, (args.steps + 39) // 40 * 40))
         val_start = pos
 
-    exchange = {0.0: "none", 1.0: "RCCL all-reduce of A'y", 2.0: "direct xGMI mesh (all-gather x+, reduce-scatter A'y+)"}[
+    exchange = {0.0: "none", 1.0: "RCCL all-reduce of A'y", 2.0: "direct xGMI mesh (all-gather x+, reduce-scatter A'y+)",
+                3.0: "direct xGMI mesh, two all-gathers (x+ column slices, y+ row blocks; A'y from the rank's column block)"}[
         float(S.stage("exchange")[0])]
     exchange_waits = None
     if world > 1 and exchange.startswith("direct"):
         # device-side wall-clock time a rank spent waiting for its peers' flags, per hot-loop exchange (rank 0's view)
         ph = S.stage("mesh_phases")
-        exchange_waits = {"unit": "us per wait (rank 0, 100 MHz device clock)", "X_allgather_x": ph[0], "P_reduce_scatter_aty": ph[1],
+        exchange_waits = {"unit": "us per wait (rank 0, 100 MHz device clock)", "X_allgather_x": ph[0],
+                          "P_reduce_scatter_aty": ph[1],  # (two-all-gathers layout: the wait for the y+ row blocks)
                           "S_scalars": ph[2], "waits": [int(ph[3]), int(ph[4]), int(ph[5])]}
     rank_consistent = None
     if dist is not None:
@@ -305,7 +327,14 @@ def main():
         S.stage("profile_off")
         if ps.reserved[0] > 0:
             k_ax, k_aty, prof_launches = ps.spmv_ax_ms, ps.spmv_aty_ms, int(ps.reserved[0])
-    dom_name, dom_ms, dom_bytes = ("spmv_ax_dual", k_ax, b_ax) if k_ax >= k_aty else ("spmv_aty_interact", k_aty, b_aty)
+    fused = args.solver == "pdlp" and world == 1 and int(S.stage("trial_launches")[0]) == 2
+    if fused:
+        # the A'y launch of the 2-launch trial also holds the grid barrier, the decision and the NEXT primal step: its
+        # algorithmic bytes are SURVEY §8(d)'s terms for that work — SpMV A'y + movement/interaction (b_aty), the
+        # primal step R5W1 (6n words) and the x half of the running average R2W1 (3n words)
+        b_aty = b_aty + 8 * 9 * n + (8 * n if cfg.get("qp") else 0)
+    dom_name, dom_ms, dom_bytes = ("spmv_ax_dual", k_ax, b_ax) if k_ax >= k_aty else (
+        "spmv_aty_interact_decide_primal" if fused else "spmv_aty_interact", k_aty, b_aty)
     if world > 1:  # each rank streams 1/world of the matrix
         dom_bytes = dom_bytes / world
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
@@ -316,7 +345,7 @@ def main():
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if args.solver == "hipdlp":  # same SpMV kernels with the Halpern epilogues
-        dom_name = {"spmv_ax_dual": "spmv_ax_halpern_dual", "spmv_aty_interact": "spmv_aty_halpern_primal"}[dom_name]
+        dom_name = {"spmv_ax_dual": "spmv_ax_halpern_dual", "spmv_aty_interact": "spmv_aty_halpern_primal"}.get(dom_name, dom_name)
     if os.path.exists(tpath):
         try:
             traffic = json.load(open(tpath)).get(args.config, {}).get(dom_name)
@@ -350,8 +379,17 @@ def main():
                      "frac_of_copy_ceiling": (achieved / copy_gbs) if copy_gbs else None,
                      "avg_launch_ms": dom_ms, "timed_launches_in_loop": prof_launches,
                      "other_kernels_ms": {"spmv_ax_dual": k_ax, "spmv_aty_interact": k_aty},
+                     "per_kernel": {"spmv_ax_dual": {"ms": k_ax, "algorithmic_bytes": b_ax / world, "frac": b_ax / world / (k_ax * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                                    ("spmv_aty_interact_decide_primal" if fused else "spmv_aty_interact"):
+                                        {"ms": k_aty, "algorithmic_bytes": b_aty / world, "frac": b_aty / world / (k_aty * 1e-3) / 1e9 / HBM_PEAK_GBS}},
                      "isolated_relaunch_ms": {"spmv_ax_dual": iso_ax, "spmv_aty_interact": iso_aty}},
     }
+    if args.solver == "pdlp" and not cfg.get("qp"):
+        # the model of DESIGN.md §6 for this LP: single-GPU kernel times of the round-3 profiles (us), scaled by 1/G
+        base = {"b": (56.0, 53.0, 15.5), "a": (8.9, 8.2, 4.0), "c": (41.0, 33.0, 25.6)}[args.config]
+        out["scaling_model"] = {("G=%d" % G): scaling_model(n, m, nnz, G, *base) for G in ((world,) if world > 1 else (2, 4, 8))}
+        if world > 1:
+            out["scaling_model"]["measured_us_per_trial"] = ms_step * 1e3 * st.iters / max(int(st.trials), 1)
     if cfg.get("qp"):
         out["metric"] = "PDHG iterations/sec (QP prox path)"
         out["parity"] = ("unpinned: the reference has no PDLP for QPs (HighsOptions.cpp:1178-1181); optimal objectives are "

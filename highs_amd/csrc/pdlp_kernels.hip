@@ -372,9 +372,17 @@ __global__ __launch_bounds__(kVecThreads) void k_long_groups(const LongMat L, co
 //            reference's summation order) and runs the epilogue.
 template <int EPI, int CHUNK>
 __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
+  if (EPI == kAtyFused && a.st->halted) {  // keep the two state slots identical while the queue drains
+    if (blockIdx.x == 0 && threadIdx.x < sizeof(DevState) / 4)
+      reinterpret_cast<uint32_t*>(a.stOut)[threadIdx.x] = reinterpret_cast<const uint32_t*>(a.st)[threadIdx.x];
+    return;
+  }
   if (usesDevState(EPI) && a.st->halted) return;
   __shared__ double prod[CHUNK + CHUNK / 8 + 8];
   __shared__ double scratch[2][kSpmvThreads / kWave];
+  // kAtyFused (the 2-launch trial on the stream layout): reduction scratch of the decision and the state record
+  __shared__ double tscr[EPI == kAtyFused ? 4 : 1][kVecThreads / kWave];
+  __shared__ uint32_t shWords[EPI == kAtyFused ? (sizeof(DevState) + 3) / 4 : 1];
 
   const int tid = threadIdx.x;
   Epi<EPI> epi(a);
@@ -402,6 +410,10 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
     int qb = a.A.beg[rr] - p0;
     int qe = a.A.beg[rr + 1] - p0;
     Pre pre = epi.prefetch(vecIndex(rr));
+    // kAtyFused: what the NEXT primal step needs of this lane's first major and no decision can change (c, l, u)
+    Pre fix{0.0, 0.0, 0.0, 0.0, 0.0};
+    double keepX = 0.0, keepS = 0.0;  // x+ and (A'y+) of that major, for the step after an accepted trial
+    if (EPI == kAtyFused) { fix.a = ldStream(a.v.cost + rr); fix.b = ldStream(a.v.lower + rr); fix.c = ldStream(a.v.upper + rr); }
     // phase 1: kPer unit-stride loads of idx/val per lane, all issued before the
     // dependent gathers, so a wave keeps 3*kPer memory operations in flight
     const int last = cnt > 0 ? cnt - 1 : 0;  // idx/val carry one pad element
@@ -452,9 +464,58 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
       }
       for (; q < qe; ++q) s += prod[slot(q)];
       epi.apply(vecIndex(r), s, pre);
+      if (EPI == kAtyFused && r == rFirst) { keepX = pre.b; keepS = s; }
     }
+    if (EPI == kAtyFused) fix.d = ldStream(a.v.xSum + rr);  // in flight across the barrier and the decision
+    epi.template finish<kSpmvThreads>(a.A.partOffset + blk, scratch);
+    if (EPI == kAtyFused) {
+      // ---- every block's partials in HBM -> decision (identical in every block) -> the next trial's primal step on the
+      // block's majors (pdlp_kernels.hip k_spmv_slab has the same tail) ----
+      DevState* sh = reinterpret_cast<DevState*>(shWords);
+      if (tid < kWave) gridBarrier(a.bar, (int)blockIdx.x, a.A.nBlocks, (unsigned long long)a.st->nTrials + 1ull, tid);
+      if (tid >= kWave && tid - kWave < (int)(sizeof(DevState) / 4)) shWords[tid - kWave] = reinterpret_cast<const uint32_t*>(a.st)[tid - kWave];
+      __syncthreads();
+      double dY2, dX2, inter;
+      trialSumsT<true>(a.partDY, a.nDY, a.part0, a.part1, a.nDX, tscr, dY2, dX2, inter);
+      if (tid == 0) {
+        decideUpdate<true>(sh, dX2, dY2, inter);
+        if (__hip_atomic_load(a.bar + a.A.nBlocks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) sh->commError = 1;
+      }
+      __syncthreads();
+      const int halted = sh->halted, curN = sh->cur, accepted = sh->lastAccepted;
+      const double tau = sh->tau, avgWx = sh->avgWx;
+      if (blockIdx.x == 0 && tid < (int)(sizeof(DevState) / 4)) {  // pending = 0 (decideCore); avgWx: added to xSum below
+        uint32_t w = shWords[tid];
+        constexpr int kAvgWxWord = offsetof(DevState, avgWx) / 4;
+        if (!halted && (tid == kAvgWxWord || tid == kAvgWxWord + 1)) w = 0u;
+        reinterpret_cast<uint32_t*>(a.stOut)[tid] = w;
+      }
+      if (halted) return;
+      const double* __restrict__ xBase = a.v.x[curN];
+      const double* __restrict__ atyBase = a.v.aty[curN];
+      double* __restrict__ xOut = a.v.x[curN ^ 1];
+      for (int r = rFirst; r < r1; r += kSpmvThreads) {
+        double xb, ab, c, l, u, xs;
+        if (r == rFirst) {  // from registers (a rejected trial, 3 %, fetches x and A'y again)
+          xb = accepted ? keepX : ldStream(xBase + r); ab = accepted ? keepS : ldStream(atyBase + r);
+          c = fix.a; l = fix.b; u = fix.c; xs = fix.d;
+        } else {            // (more than 256 majors in the block: short columns)
+          xb = ldStream(xBase + r); ab = ldStream(atyBase + r);
+          c = ldStream(a.v.cost + r); l = ldStream(a.v.lower + r); u = ldStream(a.v.upper + r); xs = ldStream(a.v.xSum + r);
+        }
+        if (avgWx != 0.0) stStream(a.v.xSum + r, xs + avgWx * xb);  // deferred PDHG_Update_Average (step.c:437)
+        double t = xb;
+        t += (-tau) * c;
+        t += tau * ab;
+        if (a.v.qdiag) t = t / (1.0 + tau * ldStream(a.v.qdiag + r));
+        t = t < u ? t : u;
+        t = t > l ? t : l;
+        xOut[r] = t;  // gathered by the A x+ kernel: ordinary store
+      }
+      return;
+    }
+    return;
   }
-  epi.template finish<kSpmvThreads>(a.A.partOffset + blk, scratch);
 }
 
 // Slab SpMV (layout: pdlp_host.hpp SlabLayout) — for operands whose gathered vector does not fit an
@@ -879,6 +940,48 @@ __global__ __launch_bounds__(kVecThreads) void k_flush_average(const IterVecs v,
 }
 __global__ void k_clear_avgw(DevState* st) { st->avgW = 0.0; st->avgWx = 0.0; }
 
+// Check iteration, one pass instead of three (k_flush_average, k_clear_avgw, 2 x k_scale_copy): the pending average
+// update and the average itself, xAvg = xSum / sum(tau), yAvg = ySum / sum(sigma) (PDHG_Compute_Average_Iterate,
+// cupdlp_step.c:377-420).  The pending weights come from the host's copy of the state (synchronised before every
+// check), which the host clears and pushes back before the loop resumes: no device-side clear.  Same operations,
+// in the same order, as the separate kernels: bit-identical.
+__global__ __launch_bounds__(kVecThreads) void k_flush_scale(const IterVecs v, int cur, double w, double wx, double ps, double ds,
+                                                             double* __restrict__ xAvg, double* __restrict__ yAvg) {
+  const int stride = gridDim.x * blockDim.x;
+  const int tot = v.n + v.m;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += stride) {
+    if (i < v.n) {
+      double sx = ldStream(v.xSum + i);
+      if (wx != 0.0) { sx = sx + wx * ldStream(v.x[cur] + i); stStream(v.xSum + i, sx); }
+      xAvg[i] = sx * ps;  // (gathered by the A xAvg kernel: ordinary store)
+    } else {
+      const int k = i - v.n;
+      double sy = ldStream(v.ySum + k);
+      if (w != 0.0) { sy = sy + w * ldStream(v.y[cur] + k); stStream(v.ySum + k, sy); }
+      yAvg[k] = sy * ds;
+    }
+  }
+}
+
+// NQ block sums with ONE barrier: every wave shuffles its NQ values down, lane 0 parks them, thread q adds the wave
+// results of quantity q in order — the same tree as blockSum per quantity (bit-identical), without 2 NQ barriers.
+template <int NQ>
+__device__ __forceinline__ void blockSumMany(double (&a)[NQ], double (*scratch)[kVecThreads / kWave], double* partials, int pstride) {
+  const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const double t = waveSum(a[q]);
+    if (lane == 0) scratch[q][w] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < NQ) {
+    double r = 0.0;
+#pragma unroll
+    for (int i = 0; i < kVecThreads / kWave; ++i) r += scratch[threadIdx.x][i];
+    partials[threadIdx.x * pstride + blockIdx.x] = r;
+  }
+}
+
 __global__ __launch_bounds__(kVecThreads) void k_scale_copy(double* __restrict__ dst, const double* __restrict__ src,
                                                             double a, int len) {
   const int stride = gridDim.x * blockDim.x;
@@ -935,6 +1038,41 @@ __global__ __launch_bounds__(kVecThreads) void k_row_stats(const double* __restr
     const double t = blockSum<kVecThreads>(a[q], scratch);
     if (threadIdx.x == 0) partials[q * pstride + blockIdx.x] = t;
   }
+}
+
+// The same for the current AND the average iterate in one pass (rhs and rowScale are read once; one barrier for the
+// eight block sums): quantities 0..3 = current, 4..7 = average.  Per quantity the same additions in the same order
+// as k_row_stats: bit-identical.
+__global__ __launch_bounds__(kVecThreads) void k_row_stats2(const double* __restrict__ axC, const double* __restrict__ yC,
+                                                            const double* __restrict__ axA, const double* __restrict__ yA,
+                                                            const double* __restrict__ rhs, const double* __restrict__ rowScale,
+                                                            int m, int nEqs, int rowOffset, int scaled, double* partials,
+                                                            int pstride) {
+  __shared__ double scratch[2 * kRowStats][kVecThreads / kWave];
+  double a[2 * kRowStats];
+#pragma unroll
+  for (int q = 0; q < 2 * kRowStats; ++q) a[q] = 0.0;
+  const int stride = gridDim.x * blockDim.x;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
+    const bool ineq = (i + rowOffset) >= nEqs;
+    const double b = ldStream(rhs + i);
+    const double rs = scaled ? ldStream(rowScale + i) : 1.0;
+    const double axv[2] = {ldStream(axC + i), ldStream(axA + i)}, yv[2] = {ldStream(yC + i), ldStream(yA + i)};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      double r = axv[k] + (-1.0) * b;
+      if (ineq) r = r < 0.0 ? r : 0.0;
+      r *= rs;
+      a[4 * k + 0] += r * r;
+      a[4 * k + 1] += yv[k] * b;
+      a[4 * k + 2] += yv[k] * yv[k];
+      double c = axv[k];
+      if (ineq) c = c < 0.0 ? c : 0.0;
+      c *= rs;
+      a[4 * k + 3] += c * c;
+    }
+  }
+  blockSumMany<2 * kRowStats>(a, scratch, partials, pstride);
 }
 
 // Column pass of PDHG_Compute_Dual_Feasibility and the x-side certificates
@@ -1000,6 +1138,72 @@ __global__ __launch_bounds__(kVecThreads) void k_col_stats(const double* __restr
     const double t = blockSum<kVecThreads>(a[q], scratch);
     if (threadIdx.x == 0) partials[q * pstride + blockIdx.x] = t;
   }
+}
+
+// The same for the current AND the average iterate in one pass (cost, bounds and colScale are read once; one barrier
+// for the 22 block sums): quantities 0..10 = current, 11..21 = average; bit-identical per quantity to k_col_stats.
+__global__ __launch_bounds__(kVecThreads) void k_col_stats2(const double* __restrict__ atyC, const double* __restrict__ xC,
+                                                            const double* __restrict__ atyA, const double* __restrict__ xA,
+                                                            const double* __restrict__ cost, const double* __restrict__ lower,
+                                                            const double* __restrict__ upper, const double* __restrict__ colScale,
+                                                            const double* __restrict__ qdiag, const double* __restrict__ nxC,
+                                                            const double* __restrict__ nxA, int n, int scaled, double* spC,
+                                                            double* snC, double* spA, double* snA, double* partials, int pstride) {
+  __shared__ double scratch[2 * kColStats][kVecThreads / kWave];
+  double a[2 * kColStats];
+#pragma unroll
+  for (int q = 0; q < 2 * kColStats; ++q) a[q] = 0.0;
+  const int stride = gridDim.x * blockDim.x;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+    const double c = ldStream(cost + j), l = ldStream(lower + j), u = ldStream(upper + j);
+    const double cs = scaled ? ldStream(colScale + j) : 1.0;
+    const double hasL = l > -INFINITY ? 1.0 : 0.0, hasU = u < INFINITY ? 1.0 : 0.0;
+    const double lF = l > -INFINITY ? l : 0.0, uF = u < INFINITY ? u : 0.0;
+    const double qj = qdiag ? qdiag[j] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const double xv = ldStream((k ? xA : xC) + j), atyv = ldStream((k ? atyA : atyC) + j);
+      const double* __restrict__ nx = k ? nxA : nxC;
+      double* a_ = a + kColStats * k;
+      double r = -atyv + c;
+      double half = 0.0;
+      if (qdiag) { r += qj * xv; half = (0.5 * qj * xv) * xv; }
+      if (nx) { const double nj = ldStream(nx + j); r += nj; half += (0.5 * nj) * xv; }
+      a_[10] += half;
+      const double sp = (r > 0.0 ? r : 0.0) * hasL;
+      const double sn = (-(r < 0.0 ? r : 0.0)) * hasU;
+      stStream((k ? spA : spC) + j, sp);
+      stStream((k ? snA : snC) + j, sn);
+      a_[0] += xv * c;
+      a_[1] += sp * lF;
+      a_[2] += sn * uF;
+      double rd = r + (-1.0) * sp;
+      rd += sn;
+      rd *= cs;
+      a_[3] += rd * rd;
+      a_[4] += sp * sp;
+      a_[5] += sn * sn;
+      double pc = (atyv + sp) - sn;
+      pc *= cs;
+      a_[6] += pc * pc;
+      a_[7] += xv * xv;
+      double lb = (xv < 0.0 ? xv : 0.0) * hasL;
+      double ub = (xv > 0.0 ? xv : 0.0) * hasU;
+      if (scaled) { lb /= cs; ub /= cs; }
+      a_[8] += lb * lb;
+      a_[9] += ub * ub;
+    }
+  }
+  blockSumMany<2 * kColStats>(a, scratch, partials, pstride);
+}
+
+// out[q] = fixed-order sum of quantity q's per-block partials; the first nQ0 quantities have nBlocks0 partials each,
+// the others nBlocks1 (row and column statistics of a check in one launch)
+__global__ __launch_bounds__(kVecThreads) void k_final_reduce2(const double* partials, int pstride, int nQ0, int nBlocks0,
+                                                               int nBlocks1, double* out) {
+  __shared__ double scratch[kVecThreads / kWave];
+  const double s = reducePartials(partials + (size_t)blockIdx.x * pstride, (int)blockIdx.x < nQ0 ? nBlocks0 : nBlocks1, scratch);
+  if (threadIdx.x == 0) out[blockIdx.x] = s;
 }
 
 __global__ __launch_bounds__(kVecThreads) void k_final_reduce(const double* partials, int pstride, int nBlocks,
@@ -1094,13 +1298,22 @@ size_t fusedLds(const MatView& At) {
 }
 }  // namespace
 int fusedAtyBlocksResident(const MatView& At, int device) {
-  if (!At.useSlab || At.slab.nBlocks <= 0 || At.lng.nTasks > 0) return 0;  // (long majors run in extra blocks that take no part in the barrier)
+  if (At.lng.nTasks > 0) return 0;  // (long majors run in extra blocks that take no part in the barrier)
   int perCu = 0, cus = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_spmv_slab<kAtyFused, false, kSlabSlots, 1>, kSlabThreads, fusedLds(At)) != hipSuccess)
-    return 0;
+  hipError_t e;
+  if (At.useSlab) {
+    if (At.slab.nBlocks <= 0) return 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_spmv_slab<kAtyFused, false, kSlabSlots, 1>, kSlabThreads, fusedLds(At));
+  } else {
+    if (At.csr.nBlocks <= 0) return 0;
+    e = At.csr.chunk == kChunkSmall ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_spmv<kAtyFused, kChunkSmall>, kSpmvThreads, 0)
+                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_spmv<kAtyFused, kChunk>, kSpmvThreads, 0);
+  }
+  if (e != hipSuccess) return 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
   return perCu * cus;
 }
+int fusedAtyBlocks(const MatView& At) { return At.useSlab ? At.slab.nBlocks : At.csr.nBlocks; }
 void launchSpmvAtyFusedPrimal(const MatView& At, const IterVecs& v, const DevState* stIn, DevState* stOut,
                               const double* partDY, int32_t nDY, double* partDX, double* partInter, unsigned long long* bar,
                               hipStream_t s) {
@@ -1108,7 +1321,12 @@ void launchSpmvAtyFusedPrimal(const MatView& At, const IterVecs& v, const DevSta
   a.st = stIn; a.v = v; a.part0 = partDX; a.part1 = partInter;
   a.stOut = stOut; a.partDY = partDY; a.nDY = nDY; a.nDX = At.nPartials; a.bar = bar;
   a.xcdMap = At.xcdMap; a.L = At.lng; a.A = At.csr; a.S = At.slab;
-  hipLaunchKernelGGL((k_spmv_slab<kAtyFused, false, kSlabSlots, 1>), dim3(At.slab.nBlocks), dim3(kSlabThreads), fusedLds(At), s, a);
+  if (At.useSlab)
+    hipLaunchKernelGGL((k_spmv_slab<kAtyFused, false, kSlabSlots, 1>), dim3(At.slab.nBlocks), dim3(kSlabThreads), fusedLds(At), s, a);
+  else if (At.csr.chunk == kChunkSmall)
+    hipLaunchKernelGGL((k_spmv<kAtyFused, kChunkSmall>), dim3(At.csr.nBlocks), dim3(kSpmvThreads), 0, s, a);
+  else
+    hipLaunchKernelGGL((k_spmv<kAtyFused, kChunk>), dim3(At.csr.nBlocks), dim3(kSpmvThreads), 0, s, a);
 }
 void launchSpmvAtyPartial(const MatView& At, const IterVecs& v, const DevState* st, double* out, hipStream_t s) {
   SpmvArgs a{};
@@ -1160,6 +1378,27 @@ void launchDecidePrimal(const IterVecs& v, const DevState* stIn, DevState* stOut
 void launchFlushAverage(const IterVecs& v, DevState* st, hipStream_t s) {
   hipLaunchKernelGGL(k_flush_average, dim3(vecBlocks(v.n + v.m)), dim3(kVecThreads), 0, s, v, st);
   hipLaunchKernelGGL(k_clear_avgw, dim3(1), dim3(1), 0, s, st);
+}
+void launchFlushScale(const IterVecs& v, int cur, double w, double wx, double ps, double ds, double* xAvg, double* yAvg,
+                      hipStream_t s) {
+  hipLaunchKernelGGL(k_flush_scale, dim3(vecBlocks(v.n + v.m)), dim3(kVecThreads), 0, s, v, cur, w, wx, ps, ds, xAvg, yAvg);
+}
+void launchRowStats2(const double* axC, const double* yC, const double* axA, const double* yA, const double* rhs,
+                     const double* rowScale, int32_t m, int32_t nEqs, int32_t rowOffset, int scaled, double* partials,
+                     int32_t stride, int32_t nBlocks, hipStream_t s) {
+  hipLaunchKernelGGL(k_row_stats2, dim3(nBlocks), dim3(kVecThreads), 0, s, axC, yC, axA, yA, rhs, rowScale, m, nEqs, rowOffset,
+                     scaled, partials, stride);
+}
+void launchColStats2(const double* atyC, const double* xC, const double* atyA, const double* xA, const double* cost,
+                     const double* lower, const double* upper, const double* colScale, const double* qdiag, const double* nxC,
+                     const double* nxA, int32_t n, int scaled, double* spC, double* snC, double* spA, double* snA,
+                     double* partials, int32_t stride, int32_t nBlocks, hipStream_t s) {
+  hipLaunchKernelGGL(k_col_stats2, dim3(nBlocks), dim3(kVecThreads), 0, s, atyC, xC, atyA, xA, cost, lower, upper, colScale, qdiag,
+                     nxC, nxA, n, scaled, spC, snC, spA, snA, partials, stride);
+}
+void launchFinalReduce2(const double* partials, int32_t stride, int32_t nQ0, int32_t nBlocks0, int32_t nQ1, int32_t nBlocks1,
+                        double* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_final_reduce2, dim3(nQ0 + nQ1), dim3(kVecThreads), 0, s, partials, stride, nQ0, nBlocks0, nBlocks1, out);
 }
 void launchScaleCopy(double* dst, const double* src, double a, int32_t len, hipStream_t s) {
   if (len <= 0) return;

@@ -198,7 +198,7 @@ void launchDecide(DevState* st, const double* partDY, int32_t nDY, const double*
                   int32_t nDX, const double* dyGlobal, hipStream_t s, bool onlyIfPending = false,
                   const double* partQ = nullptr, int32_t nQ = 0);
 
-// ---- fused trial (single GPU, slab layout): 2 launches ------------------------------------------------------
+// ---- fused trial (single GPU, either layout): 2 launches ------------------------------------------------------
 // aty_next = A' y_next with the movement / interaction partials as above, then — inside the same launch — a grid
 // barrier, the accept/reject decision (every block re-reduces the partials in the fixed order of k_decide), and
 // the NEXT trial's primal step on the columns the block owns: x, x+, A'y are still in registers, A'y+ in LDS, and
@@ -209,6 +209,7 @@ void launchDecide(DevState* st, const double* partDY, int32_t nDY, const double*
 // hanging the device); the words must be zeroed whenever the trial counter starts again (Solver::reset).
 inline size_t gridBarWords(int nBlocks) { return (size_t)nBlocks + 8; }
 int fusedAtyBlocksResident(const MatView& At, int device);
+int fusedAtyBlocks(const MatView& At);  // blocks of the fused launch (= arrival words of the barrier)
 void launchSpmvAtyFusedPrimal(const MatView& At, const IterVecs& v, const DevState* stIn, DevState* stOut,
                               const double* partDY, int32_t nDY, double* partDX, double* partInter,
                               unsigned long long* bar, hipStream_t s);
@@ -216,6 +217,21 @@ void launchSpmvAtyFusedPrimal(const MatView& At, const IterVecs& v, const DevSta
 // ---- check-iteration kernels (host knows the parity here) -------------------
 void launchFlushAverage(const IterVecs& v, DevState* st, hipStream_t s);
 void launchScaleCopy(double* dst, const double* src, double a, int32_t len, hipStream_t s);  // dst = a*src
+// one pass: pending average update (weights w for y, wx for x, from the host's copy of the state) and the averages
+// xAvg = xSum * ps, yAvg = ySum * ds; bit-identical to launchFlushAverage + 2 x launchScaleCopy
+void launchFlushScale(const IterVecs& v, int cur, double w, double wx, double ps, double ds, double* xAvg, double* yAvg,
+                      hipStream_t s);
+// row / column statistics of the current AND the average iterate in one pass each (quantities: current first), and
+// the final reduction of both in one launch; per quantity bit-identical to the single-iterate kernels
+void launchRowStats2(const double* axC, const double* yC, const double* axA, const double* yA, const double* rhs,
+                     const double* rowScale, int32_t m, int32_t nEqs, int32_t rowOffset, int scaled, double* partials,
+                     int32_t stride, int32_t nBlocks, hipStream_t s);
+void launchColStats2(const double* atyC, const double* xC, const double* atyA, const double* xA, const double* cost,
+                     const double* lower, const double* upper, const double* colScale, const double* qdiag, const double* nxC,
+                     const double* nxA, int32_t n, int scaled, double* spC, double* snC, double* spA, double* snA,
+                     double* partials, int32_t stride, int32_t nBlocks, hipStream_t s);
+void launchFinalReduce2(const double* partials, int32_t stride, int32_t nQ0, int32_t nBlocks0, int32_t nQ1, int32_t nBlocks1,
+                        double* out, hipStream_t s);
 void launchSpmvPlain(const MatView& A, const double* in, double* out, hipStream_t s);
 void launchFill(double* dst, double value, int32_t len, hipStream_t s);
 void launchProjectBounds(double* x, const double* lower, const double* upper, int32_t n, hipStream_t s);

@@ -56,6 +56,8 @@ __device__ __forceinline__ double* recvP(const MeshArgs& ma, int rank, int src) 
   const MeshView* __restrict__ mv = ma.v; (void)mv;
   return (double*)(mv->arena[rank] + mv->offRecvP) + (size_t)src * mv->sliceMax;
 }
+__device__ __forceinline__ double* recvY(const MeshArgs& ma, int rank) {
+  const MeshView* __restrict__ mv = ma.v; (void)mv; return (double*)(mv->arena[rank] + mv->offRecvY); }
 __device__ __forceinline__ double* mailAt(const MeshArgs& ma, int rank, bool hot, int src) {
   const MeshView* __restrict__ mv = ma.v; (void)mv;
   return (double*)(mv->arena[rank] + (hot ? mv->offMailHot : mv->offMailGen)) + (size_t)src * kMeshMailDoubles;
@@ -236,6 +238,60 @@ __global__ __launch_bounds__(kVecThreads) void k_mesh_wait_copy_x(const IterVecs
     for (int u = 0; u < 4; ++u) {  // four independent system-scope loads in flight
       const int q = min(q0 + u * stride, lastQ);
       jj[u] = q < c0 ? q : q + (c1 - c0);
+      t[u] = sysLoad(src + jj[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (q0 + u * stride <= lastQ) dst[jj[u]] = t[u];
+  }
+}
+
+// ---- "two all-gathers" layout: all-gather of y+ (rows) --------------------------------------------------
+// y+[r0:r1) (just written by the dual-step epilogue of A_g x+) -> every peer's recvY; flag P.
+__global__ __launch_bounds__(kVecThreads) void k_mesh_push_y(const double* __restrict__ y0, const double* __restrict__ y1,
+                                                             const DevState* st, const MeshArgs ma) {
+  const MeshView* __restrict__ mv = ma.v; (void)mv;
+  if (st->halted || dead(ma)) return;
+  const long long e = ma.ms->seq + 1;
+  const double* __restrict__ yn = (st->cur ^ 1) ? y1 : y0;
+  const int r0 = mv->rowOff[ma.g], r1 = mv->rowOff[ma.g + 1];
+  const int G = ma.G, g = ma.g;
+  PeerPtrs peer;
+#pragma unroll
+  for (int h = 0; h < kMeshMaxRanks; ++h) peer.p[h] = (h < G && h != g) ? recvY(ma, h) : nullptr;
+  const int stride = gridDim.x * blockDim.x, len = r1 - r0;
+  for (int i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < len; i0 += 4 * stride) {
+    double t[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) t[u] = yn[r0 + min(i0 + u * stride, len - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * stride;
+      if (i >= len) break;
+#pragma unroll
+      for (int h = 0; h < kMeshMaxRanks; ++h)
+        if (peer.p[h]) sysStore(peer.p[h] + r0 + i, t[u]);
+    }
+  }
+  lastBlockSignal(ma, kFlagP, e, 1);
+}
+// y+ of the other row blocks: recvY -> y[nxt] (ordinary memory, so that the A'y gathers hit L2).
+__global__ __launch_bounds__(kVecThreads) void k_mesh_wait_copy_y(double* __restrict__ y0, double* __restrict__ y1, int m,
+                                                                  const DevState* st, const MeshArgs ma) {
+  const MeshView* __restrict__ mv = ma.v; (void)mv;
+  if (st->halted || dead(ma)) return;  // (k_mesh_wait ran before: flag P has arrived, or the exchange is dead)
+  double* __restrict__ dst = (st->cur ^ 1) ? y1 : y0;
+  const int r0 = mv->rowOff[ma.g], r1 = mv->rowOff[ma.g + 1];
+  const double* __restrict__ src = recvY(ma, ma.g);
+  const int stride = gridDim.x * blockDim.x;
+  const int other = m - (r1 - r0), lastQ = other - 1;
+  for (int q0 = blockIdx.x * blockDim.x + threadIdx.x; q0 < other; q0 += 4 * stride) {
+    double t[4];
+    int jj[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {  // four independent system-scope loads in flight
+      const int q = min(q0 + u * stride, lastQ);
+      jj[u] = q < r0 ? q : q + (r1 - r0);
       t[u] = sysLoad(src + jj[u]);
     }
 #pragma unroll
@@ -594,6 +650,15 @@ void launchMeshDecide(DevState* st, const MeshArgs& dmv, const double* partDY, i
   hipLaunchKernelGGL(k_mesh_decide, dim3(1), dim3(kVecThreads), 0, s, st, dmv, partDY, nDY, partDX, partInter, nDX);
 }
 
+void launchMeshPushY(const IterVecs& vf, const double* const yFull[2], const DevState* st, const MeshArgs& dmv, hipStream_t s) {
+  hipLaunchKernelGGL(k_mesh_push_y, dim3(meshBlocks(std::max(vf.m, 1))), dim3(kVecThreads), 0, s, yFull[0], yFull[1], st, dmv);
+}
+void launchMeshWaitCopyY(double* const yFull[2], int32_t m, const DevState* st, const MeshArgs& dmv, hipStream_t s) {
+  hipLaunchKernelGGL(k_mesh_wait, dim3(1), dim3(kWave), 0, s, const_cast<DevState*>(st), dmv, (int)kFlagP, 0LL);
+  hipLaunchKernelGGL(k_mesh_wait_copy_y, dim3(meshConsumerBlocks(std::max(m, 1))), dim3(kVecThreads), 0, s, yFull[0], yFull[1], m,
+                     st, dmv);
+}
+
 void launchMeshHalpernStep(const MatView& A, const MatView& At, const HalpernVecs& hFull, const HalpernVecs& hCol,
                            int32_t n, int32_t nLoc, double* partial, const MeshArgs& ma, hipStream_t s) {
   // 1. partial A_g' y_current, pushed to the slice owners (flag P)
@@ -692,6 +757,7 @@ void Mesh::construct(int32_t rank, int32_t world, const void* id128, int32_t n, 
   v_.offMailGen = (int64_t)off; off += alignUp((size_t)kMeshMaxRanks * kMeshMailDoubles * 8, 4096);
   v_.offRecvX = (int64_t)off;   off += alignUp((size_t)std::max(n, m) * 8 + 8, 4096);
   v_.offRecvP = (int64_t)off;   off += alignUp((size_t)world * sliceMax * 8, 4096);
+  v_.offRecvY = (int64_t)off;   off += alignUp((size_t)std::max(m, 1) * 8 + 8, 4096);
   arenaBytes_ = off;
 
   // memory that is coherent between agents inside a kernel (PDLP_MI355X_MESH_MEM=finegrained|coarse are

@@ -59,7 +59,7 @@ struct MeshView {
   int32_t G, g;
   int32_t colOff[kMeshMaxRanks + 1];
   int32_t rowOff[kMeshMaxRanks + 1];
-  int64_t offFlags, offMailHot, offMailGen, offRecvX, offRecvP;
+  int64_t offFlags, offMailHot, offMailGen, offRecvX, offRecvP, offRecvY;
   int64_t sliceMax;  // doubles per recvP slot
   int64_t waitTicks; // wall-clock (100 MHz) budget of one wait
   MeshState* ms;
@@ -144,6 +144,11 @@ void launchMeshReduceInteract(const IterVecs& vc, const DevState* st, const Mesh
                               double* partDX, double* partInter, int32_t nBlocks, hipStream_t s);
 void launchMeshDecide(DevState* st, const MeshArgs& dmv, const double* partDY, int32_t nDY, const double* partDX,
                       const double* partInter, int32_t nDX, hipStream_t s);
+// "Two all-gathers" layout (row block for A x, column block for A'y): the dual step's y+[r0:r1) is pushed into
+// every peer's recvY (flag P stands for "Y" there), then recvY -> yNext outside the own rows.  yNextFull = the
+// full-length y of the next parity on this rank.
+void launchMeshPushY(const IterVecs& vf, const double* const yFull[2], const DevState* st, const MeshArgs& dmv, hipStream_t s);
+void launchMeshWaitCopyY(double* const yFull[2], int32_t m, const DevState* st, const MeshArgs& dmv, hipStream_t s);
 
 // One sharded HiPDLP step (pdhg.cc:961-1018 over row-block shards): hFull = full-length / local-row
 // pointers, hCol = the same with the column vectors offset to the own slice (rx stays full-length).

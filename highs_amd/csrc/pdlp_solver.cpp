@@ -345,6 +345,8 @@ void Solver::construct(const pdlp_problem_t& P, const void* id128) {
     }
     meshMode_ = mesh_ != nullptr;
     if (meshMode_) {
+      const char* ml = getenv("PDLP_MI355X_MESH_LAYOUT");
+      colblock_ = !(ml && !strcmp(ml, "partial"));
       c0_ = mesh_->c0();
       c1_ = mesh_->c1();
       nLoc_ = c1_ - c0_;
@@ -356,7 +358,9 @@ void Solver::construct(const pdlp_problem_t& P, const void* id128) {
       }
       comm_ = new Comm(rank_, world_, id128);
     }
-    log(1, "Row-block sharded over %d GPUs, exchange: %s\n", world_, meshMode_ ? "direct xGMI mesh" : "RCCL all-reduce");
+    log(1, "Row-block sharded over %d GPUs, exchange: %s\n", world_,
+        !meshMode_ ? "RCCL all-reduce" : colblock_ ? "direct xGMI mesh, two all-gathers (x+ slices, y+ row blocks)"
+                                                   : "direct xGMI mesh, all-gather of x+ and reduce-scatter of the A'y partials");
   } else {
     r0_ = 0;
     r1_ = F_.m;
@@ -368,12 +372,17 @@ void Solver::construct(const pdlp_problem_t& P, const void* id128) {
   tuneXcdMap(dA_, x_[0].get(), ax_[0].get(), stream_);
   tuneXcdMap(dAt_, y_[0].get(), sharded_ ? commBuf_.get() : aty_[0].get(), stream_);
   if (hasQoff_) tuneXcdMap(dQ_, x_[0].get(), nx_[0].get(), stream_);
-  // 2-launch trial where the A' y grid is resident all at once (grid barrier inside the kernel); PDLP_MI355X_FUSED=0 forces 3 launches
+  // 2-launch trial where the A' y grid is resident all at once (grid barrier inside the kernel); PDLP_MI355X_FUSED=0 forces
+  // 3 launches.  Slab layout (one block per CU): on by default, 140.0 -> 135.0 us per iteration at 1M x 1M.  Stream
+  // layout: off by default — measured in round 3 the barrier + decision tail costs what the separate launch did
+  // (100k x 100k: 33.1 us fused vs 32.1; 25fv47: 19.5 vs 20.2); PDLP_MI355X_FUSED_STREAM=1 turns it on.
   if (!sharded_) {
     const char* fe = getenv("PDLP_MI355X_FUSED");
+    const char* fs = getenv("PDLP_MI355X_FUSED_STREAM");
     const MatView at = dAt_.view();
-    fused_ = !(fe && atoi(fe) == 0) && !hasQoff_ && at.useSlab && fusedAtyBlocksResident(at, opt_.device) >= at.slab.nBlocks;
-    if (fused_) gridBar_.alloc(gridBarWords(at.slab.nBlocks));
+    const bool allowed = at.useSlab ? !(fe && atoi(fe) == 0) : (fs && atoi(fs) != 0);
+    fused_ = allowed && !hasQoff_ && fusedAtyBlocks(at) > 0 && fusedAtyBlocksResident(at, opt_.device) >= fusedAtyBlocks(at);
+    if (fused_) gridBar_.alloc(gridBarWords(fusedAtyBlocks(at)));
   }
   reset();
   // the trial-batch graph is part of the setup, not of the first iterations
@@ -407,7 +416,17 @@ void Solver::uploadProblem() {
     Compressed csrSlab, cscSlab;
     extractSlab(F_, r0_, r1_, csrSlab, cscSlab);
     dA_.upload(csrSlab, mLoc_, n, slabMode, stream_);
-    dAt_.upload(cscSlab, n, mLoc_, slabMode, stream_);
+    if (colblock_) {  // A'y operand: the columns this rank owns, over ALL rows (rows ascending, as on one GPU)
+      Compressed cb;
+      const int32_t b = F_.cscSorted.beg[c0_], e = F_.cscSorted.beg[c1_];
+      cb.beg.resize((size_t)nLoc_ + 1);
+      for (int32_t j = 0; j <= nLoc_; ++j) cb.beg[j] = F_.cscSorted.beg[c0_ + j] - b;
+      cb.idx.assign(F_.cscSorted.idx.begin() + b, F_.cscSorted.idx.begin() + e);
+      cb.val.assign(F_.cscSorted.val.begin() + b, F_.cscSorted.val.begin() + e);
+      dAt_.upload(cb, nLoc_, F_.m, slabMode, stream_);
+    } else {
+      dAt_.upload(cscSlab, n, mLoc_, slabMode, stream_);
+    }
   }
   cost_.alloc(n); rhs_.alloc(mLoc_); lower_.alloc(n); upper_.alloc(n); colScale_.alloc(n); rowScale_.alloc(mLoc_);
   cost_.upload(F_.cost.data(), n, stream_);
@@ -481,8 +500,10 @@ void Solver::uploadProblemFromDevice(DeviceProblem& D) {
 
 void Solver::allocIterates() {
   const int32_t n = F_.n;
+  yLen_ = colblock_ ? F_.m : mLoc_;
+  yOff_ = colblock_ ? r0_ : 0;
   for (int k = 0; k < 2; ++k) {
-    x_[k].alloc(n); y_[k].alloc(mLoc_); ax_[k].alloc(mLoc_); aty_[k].alloc(n);
+    x_[k].alloc(n); y_[k].alloc(yLen_); ax_[k].alloc(mLoc_); aty_[k].alloc(n);
     x_[k].zero(stream_); y_[k].zero(stream_); ax_[k].zero(stream_); aty_[k].zero(stream_);
   }
   if (hasQoff_) {
@@ -491,11 +512,12 @@ void Solver::allocIterates() {
     nxAvg_.zero(stream_);
     partQ_.alloc(std::max(dQ_.nPartials(), 1));
   }
-  xAvg_.alloc(n); yAvg_.alloc(mLoc_); axAvg_.alloc(mLoc_); atyAvg_.alloc(n);
+  xAvg_.alloc(n); yAvg_.alloc(yLen_); axAvg_.alloc(mLoc_); atyAvg_.alloc(n);
   xSum_.alloc(n); ySum_.alloc(mLoc_); xLast_.alloc(n); yLast_.alloc(mLoc_);
   slackPos_.alloc(n); slackNeg_.alloc(n); slackPosAvg_.alloc(n); slackNegAvg_.alloc(n);
   slackPos_.zero(stream_); slackNeg_.zero(stream_); slackPosAvg_.zero(stream_); slackNegAvg_.zero(stream_);
-  tmpM_.alloc(mLoc_);
+  tmpM_.alloc(yLen_);
+  tmpM_.zero(stream_);
 
   const int32_t nbV = std::max(vecBlocks(n), vecBlocks(std::max(mLoc_, 1)));
   partDY_.alloc(std::max(dA_.nPartials(), 1));
@@ -514,7 +536,7 @@ void Solver::allocIterates() {
 
   vecs_ = IterVecs{};
   for (int k = 0; k < 2; ++k) {
-    vecs_.x[k] = x_[k].get(); vecs_.y[k] = y_[k].get(); vecs_.ax[k] = ax_[k].get(); vecs_.aty[k] = aty_[k].get();
+    vecs_.x[k] = x_[k].get(); vecs_.y[k] = yl(k); vecs_.ax[k] = ax_[k].get(); vecs_.aty[k] = aty_[k].get();
   }
   vecs_.xSum = xSum_.get(); vecs_.ySum = ySum_.get();
   vecs_.cost = cost_.get(); vecs_.rhs = rhs_.get(); vecs_.lower = lower_.get(); vecs_.upper = upper_.get();
@@ -526,6 +548,9 @@ void Solver::allocIterates() {
   vecsCol_.xSum += c0_; vecsCol_.cost += c0_; vecsCol_.lower += c0_; vecsCol_.upper += c0_;
   if (vecsCol_.qdiag) vecsCol_.qdiag += c0_;
   vecsCol_.n = nLoc_;
+  vecsAty_ = vecsCol_;
+  if (colblock_)  // the column-block A'y kernel gathers from the FULL y of the next parity
+    for (int k = 0; k < 2; ++k) vecsAty_.y[k] = y_[k].get();
   PDLP_HIP(hipStreamSynchronize(stream_));
 }
 
@@ -587,6 +612,13 @@ void Solver::deviceAx(const double* x, double* axLocal) { launchSpmvPlain(dA_.vi
 void Solver::deviceATy(const double* yLocal, double* aty) {
   if (!sharded_) {
     launchSpmvPlain(dAt_.view(), yLocal, aty, stream_);
+  } else if (meshMode_ && colblock_) {
+    // yLocal is this rank's rows inside a full-length vector: all-gather the rows, own columns of A'y from the
+    // column block, all-gather of the slices (full vector everywhere, as the other layouts leave it)
+    double* full = const_cast<double*>(yLocal) - yOff_;
+    mesh_->allGather(full, true, stream_);
+    launchSpmvPlain(dAt_.view(), full, aty + c0_, stream_);
+    mesh_->allGather(aty, false, stream_);
   } else if (meshMode_) {
     // reduce-scatter of the partials to the column owners, then all-gather: full vector everywhere
     launchSpmvPlain(dAt_.view(), yLocal, commBuf_.get(), stream_);
@@ -647,15 +679,15 @@ void Solver::initStepSizes() {
     // PDHG_Power_Method, cupdlp_step.c:71-145: 20 iterations on A A'
     const int32_t n = F_.n;
     double lambda = 0.0;
-    launchFill(tmpM_.get(), 1.0, mLoc_, stream_);
+    launchFill(tmpMl(), 1.0, mLoc_, stream_);
     const int32_t nbM = vecBlocks(std::max(mLoc_, 1)), nbN = vecBlocks(n);
     for (int it = 0; it < 20; ++it) {
-      deviceATy(tmpM_.get(), aty_[0].get());
+      deviceATy(tmpMl(), aty_[0].get());
       deviceAx(aty_[0].get(), ax_[0].get());
       launchDot(ax_[0].get(), ax_[0].get(), mLoc_, partDX_.get(), nbM, stream_);
       const double qn = std::sqrt(reduceScalar(partDX_.get(), nbM, true));
-      launchScaleCopy(tmpM_.get(), ax_[0].get(), 1.0 / qn, mLoc_, stream_);
-      deviceATy(tmpM_.get(), aty_[0].get());
+      launchScaleCopy(tmpMl(), ax_[0].get(), 1.0 / qn, mLoc_, stream_);
+      deviceATy(tmpMl(), aty_[0].get());
       launchDot(aty_[0].get(), aty_[0].get(), n, partDX_.get(), nbN, stream_);
       lambda = reduceScalar(partDX_.get(), nbN, false);
     }
@@ -676,14 +708,14 @@ void Solver::initVariables() {
   const int32_t n = F_.n;
   if (hasStart_) {
     x_[0].upload(startX_.data(), n, stream_);
-    y_[0].upload(startY_.data() + r0_, mLoc_, stream_);
+    y_[0].upload(startY_.data() + (r0_ - yOff_), yLen_, stream_);
   } else {
     x_[0].zero(stream_);
     y_[0].zero(stream_);
   }
   launchProjectBounds(x_[0].get(), lower_.get(), upper_.get(), n, stream_);
   deviceAx(x_[0].get(), ax_[0].get());
-  deviceATy(y_[0].get(), aty_[0].get());
+  deviceATy(yl(0), aty_[0].get());
   if (hasQoff_) launchSpmvPlain(dQ_.view(), x_[0].get(), nx_[0].get(), stream_);
   xSum_.zero(stream_); ySum_.zero(stream_); xAvg_.zero(stream_); yAvg_.zero(stream_);
   launchProjectBounds(xSum_.get(), lower_.get(), upper_.get(), n, stream_);  // :583-584
@@ -742,6 +774,16 @@ void Solver::enqueueTrial() {
     launchMeshPrimalStep(vecsCol_, dst(), mv, stream_);
     launchMeshWaitCopyX(vecs_, dst(), mv, stream_);
     launchSpmvAxDual(dA_.view(), vecs_, dst(), partDY_.get(), stream_);
+    if (colblock_) {
+      // Y all-gather of the dual step's rows, then A'y+ on the own COLUMNS from the column block: every column is
+      // summed over all rows in the single-GPU order; no n-length partial is written, pushed and re-reduced
+      double* yFull[2] = {y_[0].get(), y_[1].get()};
+      launchMeshPushY(vecs_, yFull, dst(), mv, stream_);
+      launchMeshWaitCopyY(yFull, F_.m, dst(), mv, stream_);
+      launchSpmvAtyInteract(dAt_.view(), vecsAty_, dst(), partDX_.get(), partInter_.get(), stream_);
+      launchMeshDecide(dst(), mv, partDY_.get(), dA_.nPartials(), partDX_.get(), partInter_.get(), dAt_.nPartials(), stream_);
+      return;
+    }
     launchSpmvAtyPartial(dAt_.view(), vecs_, dst(), buf, stream_);
     launchMeshPushPartial(buf, F_.n, dst(), mv, stream_);
     launchMeshReduceInteract(vecsCol_, dst(), mv, buf, partDX_.get(), partInter_.get(), nb, stream_);
@@ -891,16 +933,16 @@ int32_t Solver::nextCheckIter(int32_t it) const {
 // ---- check iteration -----------------------------------------------------------
 // PDHG_Compute_Average_Iterate, cupdlp_step.c:377-420
 void Solver::computeAverage() {
-  launchFlushAverage(vecsCol_, dst(), stream_);
-  hostState_->avgW = 0.0;
-  hostState_->avgWx = 0.0;
   const double ps = hostState_->sumPrimalStep > 0.0 ? 1.0 / hostState_->sumPrimalStep : 1.0;
   const double ds = hostState_->sumDualStep > 0.0 ? 1.0 / hostState_->sumDualStep : 1.0;
-  launchScaleCopy(xAvg_.get() + c0_, xSum_.get() + c0_, ps, nLoc_, stream_);
+  // pending average update + the averages of the own columns / rows in one pass; the pending weights come from the
+  // host's copy of the state (every caller has synchronised it) and are cleared here: the next pushState carries that
+  launchFlushScale(vecsCol_, hostState_->cur, hostState_->avgW, hostState_->avgWx, ps, ds, xAvg_.get() + c0_, yAvgl(), stream_);
+  hostState_->avgW = 0.0;
+  hostState_->avgWx = 0.0;
   if (meshMode_) mesh_->allGather(xAvg_.get(), false, stream_);
-  launchScaleCopy(yAvg_.get(), ySum_.get(), ds, mLoc_, stream_);
   deviceAx(xAvg_.get(), axAvg_.get());
-  deviceATy(yAvg_.get(), atyAvg_.get());
+  deviceATy(yAvgl(), atyAvg_.get());
   if (hasQoff_) launchSpmvPlain(dQ_.view(), xAvg_.get(), nxAvg_.get(), stream_);
 }
 
@@ -912,26 +954,23 @@ void Solver::computeResiduals() {
   double* part = statPart_.get();
   const size_t co = (size_t)c0_;  // column statistics run on the own column slice (everything unless mesh-sharded)
   const int sc = F_.scaled ? 1 : 0;
-  launchRowStats(ax_[c].get(), y_[c].get(), rhs_.get(), rowScale_.get(), mLoc_, F_.nEqs, r0_, sc,
-                 part + (size_t)kStatRowCur * statStride_, statStride_, nbM, stream_);
-  launchRowStats(axAvg_.get(), yAvg_.get(), rhs_.get(), rowScale_.get(), mLoc_, F_.nEqs, r0_, sc,
-                 part + (size_t)kStatRowAvg * statStride_, statStride_, nbM, stream_);
+  static_assert(kStatRowAvg == kStatRowCur + kRowStats && kStatColAvg == kStatColCur + kColStats, "current first, then average");
   const double* qd = qdiag_.size() ? qdiag_.get() + co : nullptr;
-  launchColStats(aty_[c].get() + co, x_[c].get() + co, cost_.get() + co, lower_.get() + co, upper_.get() + co,
-                 colScale_.get() + co, qd, hasQoff_ ? nx_[c].get() : nullptr, nLoc_, sc, slackPos_.get() + co, slackNeg_.get() + co,
-                 part + (size_t)kStatColCur * statStride_, statStride_, nbN, stream_);
-  launchColStats(atyAvg_.get() + co, xAvg_.get() + co, cost_.get() + co, lower_.get() + co, upper_.get() + co,
-                 colScale_.get() + co, qd, hasQoff_ ? nxAvg_.get() : nullptr, nLoc_, sc, slackPosAvg_.get() + co, slackNegAvg_.get() + co,
-                 part + (size_t)kStatColAvg * statStride_, statStride_, nbN, stream_);
-  launchFinalReduce(part, statStride_, nbM, 2 * kRowStats, statOut_.get(), stream_);
-  launchFinalReduce(part + (size_t)kStatColCur * statStride_, statStride_, nbN, 2 * kColStats,
-                    statOut_.get() + kStatColCur, stream_);
+  // both iterates per pass (shared vectors read once), one reduction launch for all 30 quantities
+  launchRowStats2(ax_[c].get(), yl(c), axAvg_.get(), yAvgl(), rhs_.get(), rowScale_.get(), mLoc_, F_.nEqs, r0_, sc,
+                  part + (size_t)kStatRowCur * statStride_, statStride_, nbM, stream_);
+  launchColStats2(aty_[c].get() + co, x_[c].get() + co, atyAvg_.get() + co, xAvg_.get() + co, cost_.get() + co, lower_.get() + co,
+                  upper_.get() + co, colScale_.get() + co, qd, hasQoff_ ? nx_[c].get() : nullptr, hasQoff_ ? nxAvg_.get() : nullptr,
+                  nLoc_, sc, slackPos_.get() + co, slackNeg_.get() + co, slackPosAvg_.get() + co, slackNegAvg_.get() + co,
+                  part + (size_t)kStatColCur * statStride_, statStride_, nbN, stream_);
+  launchFinalReduce2(part, statStride_, 2 * kRowStats, nbM, 2 * kColStats, nbN, statOut_.get(), stream_);
   if (sharded_) sumOverRanks(statOut_.get(), meshMode_ ? kStatTotal : 2 * kRowStats);
   PDLP_HIP(hipMemcpyAsync(hostStats_, statOut_.get(), sizeof(double) * kStatTotal, hipMemcpyDeviceToHost, stream_));
   PDLP_HIP(hipStreamSynchronize(stream_));
   if (meshMode_) {
     mesh_->checkError(stream_);
     mesh_->verifyReplicated(x_[c].get(), F_.n, stream_);  // every rank gathers from ITS copy of x
+    if (colblock_) mesh_->verifyReplicated(y_[c].get(), F_.m, stream_);  // ... and, in this layout, from its copy of y
   }
 
   auto fill = [&](Residuals& r, const double* rs, const double* cs) {
@@ -1012,7 +1051,7 @@ void Solver::restartIterate() {
   if (!toCurrent) {
     pFeasLR_ = avg_.pFeas; dFeasLR_ = avg_.dFeas; gapLR_ = avg_.gap;
     PDLP_HIP(hipMemcpyAsync(x_[c].get(), xAvg_.get(), sizeof(double) * n, hipMemcpyDeviceToDevice, stream_));
-    PDLP_HIP(hipMemcpyAsync(y_[c].get(), yAvg_.get(), sizeof(double) * mLoc_, hipMemcpyDeviceToDevice, stream_));
+    PDLP_HIP(hipMemcpyAsync(y_[c].get(), yAvg_.get(), sizeof(double) * yLen_, hipMemcpyDeviceToDevice, stream_));  // (colblock: the full, all-gathered average)
     PDLP_HIP(hipMemcpyAsync(ax_[c].get(), axAvg_.get(), sizeof(double) * mLoc_, hipMemcpyDeviceToDevice, stream_));
     PDLP_HIP(hipMemcpyAsync(aty_[c].get(), atyAvg_.get(), sizeof(double) * n, hipMemcpyDeviceToDevice, stream_));
     if (hasQoff_) PDLP_HIP(hipMemcpyAsync(nx_[c].get(), nxAvg_.get(), sizeof(double) * n, hipMemcpyDeviceToDevice, stream_));
@@ -1024,7 +1063,7 @@ void Solver::restartIterate() {
   const int32_t nbN = vecBlocks(std::max(nLoc_, 1)), nbM = vecBlocks(std::max(mLoc_, 1));
   launchDiffNorm2(x_[c].get() + c0_, xLast_.get() + c0_, nLoc_, partDX_.get(), nbN, stream_);
   const double dP = std::sqrt(reduceScalar(partDX_.get(), nbN, meshMode_));
-  launchDiffNorm2(y_[c].get(), yLast_.get(), mLoc_, partDX_.get(), nbM, stream_);
+  launchDiffNorm2(yl(c), yLast_.get(), mLoc_, partDX_.get(), nbM, stream_);
   const double dD = std::sqrt(reduceScalar(partDX_.get(), nbM, true));
   if (std::fmin(dP, dD) > 1e-10) {
     const double lg = 0.5 * std::log(dD / dP) + 0.5 * std::log(std::sqrt(s.beta));
@@ -1041,7 +1080,7 @@ void Solver::restartIterate() {
     s.sigma = s.dualStep;
   }
   PDLP_HIP(hipMemcpyAsync(xLast_.get(), x_[c].get(), sizeof(double) * n, hipMemcpyDeviceToDevice, stream_));
-  PDLP_HIP(hipMemcpyAsync(yLast_.get(), y_[c].get(), sizeof(double) * mLoc_, hipMemcpyDeviceToDevice, stream_));
+  PDLP_HIP(hipMemcpyAsync(yLast_.get(), yl(c), sizeof(double) * mLoc_, hipMemcpyDeviceToDevice, stream_));
   iLastRestartIter_ = it;
   ++nRestarts_;
   log(2, "Restart at iter %d to %s: beta = %g\n", it, toCurrent ? "current" : "average", s.beta);
@@ -1175,11 +1214,11 @@ void Solver::postsolve(pdlp_result_t* R) {
   (useAvg ? xAvg_ : x_[c]).download(x.data(), n, stream_);
   (useAvg ? slackPosAvg_ : slackPos_).download(sp.data(), n, stream_);
   (useAvg ? slackNegAvg_ : slackNeg_).download(sn.data(), n, stream_);
-  (useAvg ? yAvg_ : y_[c]).download(y.data() + r0_, mLoc_, stream_);
+  PDLP_HIP(hipMemcpyAsync(y.data() + r0_, useAvg ? yAvgl() : yl(c), sizeof(double) * mLoc_, hipMemcpyDeviceToHost, stream_));
   (useAvg ? axAvg_ : ax_[c]).download(ax.data() + r0_, mLoc_, stream_);
   PDLP_HIP(hipStreamSynchronize(stream_));
   if (sharded_) {  // assemble the row-sharded (and, with the mesh, column-sliced) vectors on every rank
-    gatherToHost((useAvg ? yAvg_ : y_[c]).get(), r0_, r1_, true, y);
+    gatherToHost(useAvg ? yAvgl() : yl(c), r0_, r1_, true, y);
     gatherToHost((useAvg ? axAvg_ : ax_[c]).get(), r0_, r1_, true, ax);
     if (meshMode_) {
       gatherToHost((useAvg ? slackPosAvg_ : slackPos_).get() + c0_, c0_, c1_, false, sp);
@@ -1232,15 +1271,15 @@ std::pair<double*, int64_t> Solver::lookup(const std::string& name) {
   const int c = hostState_->cur, u = c ^ 1;
   const int64_t n = F_.n, m = mLoc_;
   if (name == "x") return {x_[c].get(), n};
-  if (name == "y") return {y_[c].get(), m};
+  if (name == "y") return {yl(c), m};
   if (name == "ax") return {ax_[c].get(), m};
   if (name == "aty") return {aty_[c].get(), n};
   if (name == "x_next") return {x_[u].get(), n};
-  if (name == "y_next") return {y_[u].get(), m};
+  if (name == "y_next") return {yl(u), m};
   if (name == "ax_next") return {ax_[u].get(), m};
   if (name == "aty_next") return {aty_[u].get(), n};
   if (name == "x_avg") return {xAvg_.get(), n};
-  if (name == "y_avg") return {yAvg_.get(), m};
+  if (name == "y_avg") return {yAvgl(), m};
   if (name == "ax_avg") return {axAvg_.get(), m};
   if (name == "aty_avg") return {atyAvg_.get(), n};
   if (name == "x_sum") return {xSum_.get(), n};
@@ -1298,7 +1337,7 @@ void Solver::stage(const std::string& name, double* out, int32_t cap) {
   } else if (name == "ax") {
     deviceAx(x_[c].get(), ax_[c].get());
   } else if (name == "aty") {
-    deviceATy(y_[c].get(), aty_[c].get());
+    deviceATy(yl(c), aty_[c].get());
   } else if (name == "trial") {
     hostState_->haltIter = INT_MAX;
     hostState_->halted = 0;
@@ -1313,12 +1352,13 @@ void Solver::stage(const std::string& name, double* out, int32_t cap) {
     if (meshMode_) mesh_->phaseStats(us, cnt, stream_);
     for (int k = 0; k < 3; ++k) { put(k, us[k]); put(3 + k, cnt[k]); }
   } else if (name == "trial_launches") {  // kernels per trial step of the hot loop (2 = fused decision + primal step)
-    put(0, meshMode_ ? 9.0 : sharded_ ? 7.0 : fused_ ? 2.0 : 3.0);
-  } else if (name == "exchange") {  // 0 = not sharded, 1 = RCCL all-reduce, 2 = direct xGMI mesh
-    put(0, !sharded_ ? 0.0 : meshMode_ ? 2.0 : 1.0);
+    put(0, meshMode_ ? (colblock_ ? 10.0 : 9.0) : sharded_ ? 7.0 : fused_ ? 2.0 : 3.0);
+  } else if (name == "exchange") {  // 0 = not sharded, 1 = RCCL all-reduce, 2 = direct xGMI mesh (partials), 3 = mesh, two all-gathers
+    put(0, !sharded_ ? 0.0 : !meshMode_ ? 1.0 : colblock_ ? 3.0 : 2.0);
   } else if (name == "residuals") {
     computeAverage();
     computeResiduals();
+    pushState();  // (computeAverage consumed the pending average weights in the host's copy of the state only)
     put(0, cur_.pObj); put(1, cur_.dObj); put(2, cur_.pFeas); put(3, cur_.dFeas);
     put(4, avg_.pObj); put(5, avg_.dObj); put(6, avg_.pFeas); put(7, avg_.dFeas);
     put(8, cur_.pInfObj); put(9, cur_.pInfRes); put(10, cur_.dInfObj); put(11, cur_.dInfRes);
@@ -1349,6 +1389,7 @@ double Solver::timeKernel(const std::string& name, int32_t reps) {
     if (name == "spmv_ax") launchSpmvAxDual(dA_.view(), vecs_, dst(), partDY_.get(), stream_);
     else if (name == "spmv_aty") {
       if (!sharded_) launchSpmvAtyInteract(dAt_.view(), vecs_, dst(), partDX_.get(), partInter_.get(), stream_);
+      else if (colblock_) launchSpmvAtyInteract(dAt_.view(), vecsAty_, dst(), partDX_.get(), partInter_.get(), stream_);
       else launchSpmvAtyPartial(dAt_.view(), vecs_, dst(), commBuf_.get(), stream_);
     } else if (name == "primal_step") launchPrimalStep(vecs_, dst(), stream_);
     else if (name == "decide_primal") {  // (pending is set by the kernel itself: from the second launch on it decides too)

@@ -139,8 +139,18 @@ class Solver : public SolverBase {
   // well, [c0_, c1_)) or, as the fallback, RCCL all-reduce with replicated column work
   Mesh* mesh_ = nullptr;
   bool meshMode_ = false;
+  // Mesh layouts (PDLP_MI355X_MESH_LAYOUT): "colblock" (default) = row block for A x, column block A[:, c0:c1) for
+  // A'y, two all-gathers per trial (x+ slices, y+ row blocks), no n-length partial; "partial" = the round-1 layout
+  // (transpose of the row block, all-gather of x+ and reduce-scatter of the A_g'y partials).  With colblock every
+  // rank keeps y, yAvg (and the power method's work vector) at FULL length m; yOff_ = r0_ is where its rows sit.
+  bool colblock_ = false;
+  int32_t yOff_ = 0, yLen_ = 0;
+  double* yl(int k) const { return y_[k].get() + yOff_; }
+  double* yAvgl() const { return yAvg_.get() + yOff_; }
+  double* tmpMl() const { return tmpM_.get() + yOff_; }
   int32_t c0_ = 0, c1_ = 0, nLoc_ = 0;
   IterVecs vecsCol_{};  // vecs_ restricted to the own column slice
+  IterVecs vecsAty_{};  // colblock layout: vecsCol_ with the FULL-length y (what the column-block A'y kernel gathers from)
   // device
   hipStream_t stream_ = nullptr;
   DeviceMatrix dA_, dAt_;

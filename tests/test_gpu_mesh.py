@@ -46,7 +46,7 @@ def test_mesh_sharded_solve(world, name, tmp_path):
     base = solver.solveLpCupdlp(lp)
     res = _run_ranks(world, f"solve:{name}", tmp_path)
     for r in res:
-        assert r["exchange"] == 2.0, "the direct mesh exchange must be the one in use"
+        assert r["exchange"] in (2.0, 3.0), "the direct mesh exchange must be the one in use"
     # identical control flow and identical bits on every rank
     for r in res[1:]:
         for k in ("col_value", "col_dual", "row_value", "row_dual", "num_iter", "num_trials", "primal_obj", "dual_obj"):
@@ -172,7 +172,7 @@ def test_mesh_with_release_acquire_fences_gives_the_same_bits(tmp_path):
     b = _run_ranks(2, "solve:e226", tmp_path, extra_env={"PDLP_MI355X_MESH_FENCES": "1"})
     for k in ("col_value", "row_dual", "num_iter", "num_trials", "primal_obj"):
         assert np.array_equal(a[0][k], b[0][k]) and np.array_equal(b[0][k], b[1][k]), k
-    assert b[0]["exchange"] == 2.0
+    assert b[0]["exchange"] in (2.0, 3.0)
 
 
 @pytest.mark.parametrize("case,world", [("solve:e226", 2), ("iterate:synth:120", 4)])
