@@ -542,7 +542,7 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
 constexpr int kSlabSlots = 3;  // register pipeline depth (groups of 64 entries per wave)
 // TWO: register budget for two resident blocks per CU (8 waves per SIMD) — the extra blocks with the segment
 // tasks of the long majors then run NEXT to the streaming blocks instead of after them.
-template <int EPI, bool TWO, int NB, int GD>
+template <int EPI, bool TWO, int NB, int GD, bool STAGE = false>
 __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabThreads / 256) void k_spmv_slab(const SpmvArgs a) {
   if (EPI == kAtyFused && a.st->halted) {  // keep the two state slots identical while the queue drains
     if (blockIdx.x == 0 && threadIdx.x < sizeof(DevState) / 4)
@@ -560,10 +560,12 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
     return;
   }
   // dynamic LDS: acc[R] f64 | stg[16][64] f64 | scratch[2][16] f64 | (kAtyFused) trial scratch[4][4] f64, DevState
+  //              | (STAGE) the tile of the gathered vector
   const int R = a.S.rowsPerBlock;
   double* acc = reinterpret_cast<double*>(smem);
   double* stgAll = acc + R;
   double(*scratch)[kWaves] = reinterpret_cast<double(*)[kWaves]>(stgAll + kSlabThreads);
+  double* xt = reinterpret_cast<double*>(&scratch[2][0]);
 
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
@@ -601,6 +603,100 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
     }
   }
 
+  // Consume one 64-entry group of this wave: products to the wave's LDS strip, the first lane of each run of equal
+  // local majors adds the run, left to right, onto the major's accumulator (ascending stretches one after the other
+  // when the group straddles slabs).
+  auto consumeGroup = [&](uint32_t e, double prod, int nValid) {
+    const bool valid = lane < nValid;
+    const uint32_t lrow = valid ? (e >> mb) : 0xffffffffu;
+    stg[lane] = prod;
+    const uint32_t prev = (uint32_t)__shfl_up((int)lrow, 1, kWave);
+    const bool isHead = valid && (lane == 0 || lrow != prev);
+    const bool desc = valid && lane != 0 && lrow < prev;
+    const uint64_t heads = __ballot(isHead);
+    const uint64_t descs = __ballot(desc);
+    // end of this lane's run = next head above it (or the end of the group)
+    const uint64_t above = (heads >> lane) >> 1;
+    const int vEnd = nValid < kWave ? nValid : kWave;
+    const int end = above ? lane + __ffsll((unsigned long long)above) : vEnd;
+    __builtin_amdgcn_wave_barrier();
+    auto addRun = [&]() {
+      double s = wacc[lrow];
+      s += prod;
+      int j = lane + 1;
+      for (; j + 4 <= end; j += 4) {  // long runs (clustered columns): four LDS reads in flight per step
+        const double t0 = stg[j], t1 = stg[j + 1], t2 = stg[j + 2], t3 = stg[j + 3];
+        s += t0; s += t1; s += t2; s += t3;
+      }
+      for (; j < end; ++j) s += stg[j];
+      wacc[lrow] = s;
+    };
+    if (descs == 0) {
+      if (isHead) addRun();
+    } else {
+      // the group straddles slabs: ascending stretches one after the other (a major may own a run in each)
+      const int seg = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(descs >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)descs, 0u)) + (desc ? 1 : 0);
+      const int nSeg = __popcll(descs) + 1;
+      for (int sg = 0; sg < nSeg; ++sg) {
+        if (isHead && seg == sg) addRun();
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  };
+  // (a block without tiles — its majors are spread over too many — streams the plain way)
+  const int t0 = STAGE ? ldUniform(a.S.blkTilePtr + blk) : 0, t1 = STAGE ? ldUniform(a.S.blkTilePtr + blk + 1) : 0;
+  if (STAGE && t1 > t0) {
+    // ---- the stream, tile by tile, gathering from LDS ----
+    const int tl = a.S.tileLog2;
+    const int32_t* __restrict__ twb = a.S.tileWaveBeg + (size_t)(t0 + blk) * kWaves + wave;
+    const uint32_t* __restrict__ entAll = a.S.ent;
+    const double* __restrict__ valAll = a.S.val;
+    constexpr int NBS = 8;  // groups of a wave part whose entries are in flight together (a part rarely has more)
+    for (int t = t0; t < t1; ++t) {
+      const int slabIdx = ldUniform(a.S.tileSlab + t), nG = ldUniform(a.S.tileGroups + t);
+      const int eb = ldUniform(twb + (size_t)(t - t0) * kWaves), ee = ldUniform(twb + (size_t)(t - t0 + 1) * kWaves);
+      const int base = slabIdx << tl;
+      const int width = (a.S.nMinor - base) < (1 << tl) ? (a.S.nMinor - base) : (1 << tl);
+      const int cnt = ee - eb;
+      const int last = cnt > 0 ? cnt - 1 : 0;
+      const uint32_t* __restrict__ ent = entAll + eb;  // (an empty part re-reads the entry at eb: exists, the arrays carry one pad element)
+      const double* __restrict__ val = valAll + eb;
+      auto entryIndex = [&](int g) { const int q = g * kWave + lane; return q < last ? q : last; };
+      uint32_t E[NBS];
+      double V[NBS];
+#pragma unroll
+      for (int k = 0; k < NBS; ++k) { const int q = entryIndex(k); E[k] = ent[q]; V[k] = val[q]; }  // in flight across the staging
+      __syncthreads();  // every wave is done with the previous tile
+      {  // the tile: 2^tl doubles with unit-stride loads, all of a thread's 16 in flight
+        const double* __restrict__ src = in + base;
+        constexpr int kU = 16;
+        for (int i0 = tid; i0 < width; i0 += kU * kSlabThreads) {
+          double tmp[kU];
+#pragma unroll
+          for (int u = 0; u < kU; ++u) { const int i = i0 + u * kSlabThreads; tmp[u] = src[i < width ? i : width - 1]; }
+#pragma unroll
+          for (int u = 0; u < kU; ++u) { const int i = i0 + u * kSlabThreads; if (i < width) xt[i] = tmp[u]; }
+        }
+      }
+      __syncthreads();
+      for (int g0 = 0; g0 < nG; g0 += NBS) {
+        if (g0 > 0) {  // (a wave part of more than NBS groups: the next NBS)
+#pragma unroll
+          for (int k = 0; k < NBS; ++k) { const int q = entryIndex(g0 + k); E[k] = ent[q]; V[k] = val[q]; }
+        }
+#pragma unroll
+        for (int u = 0; u < NBS; ++u) {
+          const int nValid = cnt - (g0 + u) * kWave;
+          if (nValid > 0) {  // (wave-uniform)
+            const int off = (int)(E[u] & mmask) - base;
+            const double x = xt[(off >= 0 && off < width) ? off : 0];
+            consumeGroup(E[u], V[u] * x, nValid);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  } else {
   // ---- the stream ----
   // Register pipeline over NB slots, unrolled NB times so that a slot is a fixed register (no moves of
   // values still in flight, which would drain vmcnt): step g gathers for group g+1, then consumes
@@ -645,8 +741,7 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
       X[(u + GD) % NB] = gather(E[(u + GD) % NB]);  // group g+GD
       // consume group g
       const int nValid = cnt - g * kWave;  // lanes >= nValid hold nothing of this wave (<= 0: phantom group)
-      const bool valid = lane < nValid;
-      const uint32_t lrow = valid ? (E[u] >> mb) : 0xffffffffu;
+      const uint32_t eCur = E[u];
       const double prod = V[u] * X[u];
       {  // slot u is free: refill it with group g+NB
         const int q = entryIndex(g + NB);
@@ -654,43 +749,12 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
         V[u] = val[q];
       }
       __builtin_amdgcn_sched_barrier(0);  // gather, then refill, then the LDS work: in this order
-      stg[lane] = prod;
-      const uint32_t prev = (uint32_t)__shfl_up((int)lrow, 1, kWave);
-      const bool isHead = valid && (lane == 0 || lrow != prev);
-      const bool desc = valid && lane != 0 && lrow < prev;
-      const uint64_t heads = __ballot(isHead);
-      const uint64_t descs = __ballot(desc);
-      // end of this lane's run = next head above it (or the end of the group)
-      const uint64_t above = (heads >> lane) >> 1;
-      const int vEnd = nValid < kWave ? nValid : kWave;
-      const int end = above ? lane + __ffsll((unsigned long long)above) : vEnd;
-      __builtin_amdgcn_wave_barrier();
-      auto addRun = [&]() {
-        double s = wacc[lrow];
-        s += prod;
-        int j = lane + 1;
-        for (; j + 4 <= end; j += 4) {  // long runs (clustered columns): four LDS reads in flight per step
-          const double t0 = stg[j], t1 = stg[j + 1], t2 = stg[j + 2], t3 = stg[j + 3];
-          s += t0; s += t1; s += t2; s += t3;
-        }
-        for (; j < end; ++j) s += stg[j];
-        wacc[lrow] = s;
-      };
-      if (descs == 0) {
-        if (isHead) addRun();
-      } else {
-        // the group straddles slabs: ascending stretches one after the other (a major may own a run in each)
-        const int seg = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(descs >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)descs, 0u)) + (desc ? 1 : 0);
-        const int nSeg = __popcll(descs) + 1;
-        for (int sg = 0; sg < nSeg; ++sg) {
-          if (isHead && seg == sg) addRun();
-          __builtin_amdgcn_wave_barrier();
-        }
-      }
+      consumeGroup(eCur, prod, nValid);
       __syncthreads();  // pacing: the CU's waves stay on the same slab (and order this step's LDS traffic)
     }
   }
 
+  }
   const uint32_t* __restrict__ mask = a.S.longMask + (size_t)blk * (R / 32);
 #pragma unroll
   for (int k = 0; k < kSlabPre; ++k) {
@@ -1267,7 +1331,9 @@ void launchSpmv(const MatView& M, SpmvArgs a, hipStream_t s) {
     const size_t lds = (size_t)M.slab.rowsPerBlock * 8 + kSlabThreads * 8 + 2 * (kSlabThreads / kWave) * 8;
     const dim3 grid(M.slab.nBlocks + (nTasks + kSlabThreads / kWave - 1) / (kSlabThreads / kWave));
     // (gather distance 2 / 3 with 4 / 6 slots measured the same as (3, 1) on the random and on the structured LP, round 3)
-    if (nTasks > 0 && slabTwoPerCu()) hipLaunchKernelGGL((k_spmv_slab<EPI, true, kSlabSlots, 1>), grid, dim3(kSlabThreads), lds, s, a);
+    if (M.slab.tileLog2 > 0)  // structured operand: the gathered vector goes through LDS tile by tile (one block per CU)
+      hipLaunchKernelGGL((k_spmv_slab<EPI, false, kSlabSlots, 1, true>), grid, dim3(kSlabThreads), lds + ((size_t)8 << M.slab.tileLog2), s, a);
+    else if (nTasks > 0 && slabTwoPerCu()) hipLaunchKernelGGL((k_spmv_slab<EPI, true, kSlabSlots, 1>), grid, dim3(kSlabThreads), lds, s, a);
     else hipLaunchKernelGGL((k_spmv_slab<EPI, false, kSlabSlots, 1>), grid, dim3(kSlabThreads), lds, s, a);
   } else if (M.csr.nBlocks > 0 || nTasks > 0) {
     const dim3 grid(M.csr.nBlocks + (nTasks + kSpmvThreads / kWave - 1) / (kSpmvThreads / kWave)), block(kSpmvThreads);
@@ -1440,6 +1506,57 @@ void launchFinalReduce(const double* partials, int32_t stride, int32_t nBlocks, 
 void launchDiffNorm2(const double* a, const double* b, int32_t len, double* partials, int32_t nBlocks,
                      hipStream_t s) {
   hipLaunchKernelGGL(k_diff_norm2, dim3(nBlocks), dim3(kVecThreads), 0, s, a, b, len, partials);
+}
+namespace {
+// Per block of R consecutive majors: smallest and largest minor index over its majors of at most `longLimit` entries
+// (CSR with ascending minors: the first and the last entry of a major) and their entry count.
+__global__ __launch_bounds__(kVecThreads) void k_block_span(const int32_t* __restrict__ beg, const int32_t* __restrict__ idx, int nMajor,
+                                                            int R, int longLimit, int32_t* lo, int32_t* hi, int32_t* cnt) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nMajor) return;
+  const int p0 = beg[r], p1 = beg[r + 1];
+  if (p1 <= p0 || p1 - p0 > longLimit) return;
+  const int b = r / R;
+  atomicMin(lo + b, idx[p0]);
+  atomicMax(hi + b, idx[p1 - 1]);
+  atomicAdd(cnt + b, p1 - p0);
+}
+// One wave per slab wave: the positions in its entry list where the slab (minor >> tileLog2) changes, in order
+// (at most cap of them are kept; outCnt says how many there were).
+__global__ __launch_bounds__(kWave) void k_slab_tile_scan(const int32_t* __restrict__ wavePtr, const uint32_t* __restrict__ ent, int nWaves,
+                                                          uint32_t mmask, int tileLog2, int cap, int32_t* outSlab, int32_t* outPos,
+                                                          int32_t* outCnt) {
+  const int gw = blockIdx.x, lane = threadIdx.x;
+  if (gw >= nWaves) return;
+  const int e0 = wavePtr[gw], e1 = wavePtr[gw + 1];
+  int n = 0;
+  for (int i0 = e0; i0 < e1; i0 += kWave) {
+    const int i = i0 + lane;
+    const bool in = i < e1;
+    const int sl = in ? (int)((ent[i] & mmask) >> tileLog2) : -1;
+    const int pv = (in && i > e0) ? (int)((ent[i - 1] & mmask) >> tileLog2) : -1;
+    const bool isB = in && sl != pv;
+    const uint64_t bal = __ballot(isB);
+    if (isB) {
+      const int k = n + __popcll(bal & ((1ull << lane) - 1ull));
+      if (k < cap) { outSlab[(size_t)gw * cap + k] = sl; outPos[(size_t)gw * cap + k] = i; }
+    }
+    n += __popcll(bal);
+  }
+  if (lane == 0) outCnt[gw] = n;
+}
+}  // namespace
+void launchBlockSpan(const int32_t* beg, const int32_t* idx, int32_t nMajor, int32_t R, int32_t longLimit, int32_t* lo, int32_t* hi,
+                     int32_t* cnt, hipStream_t s) {
+  if (nMajor <= 0) return;
+  hipLaunchKernelGGL(k_block_span, dim3((nMajor + kVecThreads - 1) / kVecThreads), dim3(kVecThreads), 0, s, beg, idx, nMajor, R, longLimit,
+                     lo, hi, cnt);
+}
+void launchSlabTileScan(const SlabMat& S, int32_t tileLog2, int32_t cap, int32_t* outSlab, int32_t* outPos, int32_t* outCnt, hipStream_t s) {
+  const int nWaves = S.nBlocks * (kSlabThreads / kWave);
+  if (nWaves <= 0) return;
+  hipLaunchKernelGGL(k_slab_tile_scan, dim3(nWaves), dim3(kWave), 0, s, S.wavePtr, S.ent, nWaves, (1u << S.minorBits) - 1u, tileLog2, cap,
+                     outSlab, outPos, outCnt);
 }
 void launchDot(const double* a, const double* b, int32_t len, double* partials, int32_t nBlocks, hipStream_t s) {
   hipLaunchKernelGGL(k_dot, dim3(nBlocks), dim3(kVecThreads), 0, s, a, b, len, partials);

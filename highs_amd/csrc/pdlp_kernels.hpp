@@ -111,7 +111,19 @@ struct SlabMat {
   const double* val;         // [nnz]
   const uint32_t* longMask;  // [nBlocks*rowsPerBlock/32]
   int32_t nMajor, nBlocks, rowsPerBlock, minorBits;
+  // LDS staging of the gathered vector (structured operands: the majors of a block touch a few slabs of the gathered
+  // vector densely — network blocks, staircases).  The block walks ITS slabs ("tiles") one after the other: the tile
+  // (2^tileLog2 entries of the gathered vector, 128 KB) is copied into LDS with coalesced loads, then every wave runs
+  // the part of its entry list that falls into the tile, gathering from LDS — the gathers then cost no slot of the
+  // CU's vector-memory miss queue, which is what bounds the kernel otherwise.  Entry order, hence every sum, is
+  // unchanged.  tileLog2 == 0: not staged.
+  int32_t tileLog2, nMinor;
+  const int32_t* blkTilePtr;  // [nBlocks+1] first tile of each block
+  const int32_t* tileSlab;    // [nTiles] slab index of the tile
+  const int32_t* tileGroups;  // [nTiles] 64-entry groups of the longest wave part in the tile
+  const int32_t* tileWaveBeg; // [(nTiles + nBlocks) * 16] entry offset of each wave's part per tile; one closing row per block
 };
+constexpr int kSlabTileLog2 = 14;
 
 // One operand matrix of the iteration: a plain CSR stream or the slab layout for the majors that are summed
 // left to right, plus the segment tasks of the long ones.
@@ -267,5 +279,12 @@ void launchDiffNorm2(const double* a, const double* b, int32_t len, double* part
 void launchDot(const double* a, const double* b, int32_t len, double* partials, int32_t nBlocks, hipStream_t s);
 
 int32_t vecBlocks(int32_t len);  // grid size used by the vector/statistics kernels
+
+// ---- set-up of the LDS-staged slab layout (SlabMat::tileLog2) ----
+// lo/hi/cnt [ceil(nMajor/R)], pre-set to INT_MAX / -1 / 0: column span and entry count of each block's short majors
+void launchBlockSpan(const int32_t* beg, const int32_t* idx, int32_t nMajor, int32_t R, int32_t longLimit, int32_t* lo, int32_t* hi,
+                     int32_t* cnt, hipStream_t s);
+// per slab wave: where in its entry list the tile (minor >> tileLog2) changes: outSlab/outPos [nWaves*cap], outCnt [nWaves]
+void launchSlabTileScan(const SlabMat& S, int32_t tileLog2, int32_t cap, int32_t* outSlab, int32_t* outPos, int32_t* outCnt, hipStream_t s);
 
 }  // namespace pdlp

@@ -81,14 +81,106 @@ void DeviceMatrix::uploadPlans(const std::vector<int32_t>& hostBeg, int32_t nCsr
   PDLP_HIP(hipStreamSynchronize(s));  // host vectors go out of scope
 }
 
+// LDS staging (pdlp_kernels.hpp SlabMat::tileLog2) is meant for operands whose blocks touch FEW tiles of the gathered
+// vector DENSELY (at most 8 tiles per block, at least one gather per 8 staged elements, accumulators + tile within the
+// 160 KB of LDS).  MEASURED in round 3 on the block-angular LP of bench.py --config c (248 of 249 blocks staged, 2.5
+// tiles per block): A x without its long rows 46.7 us staged against 33.2 us plain (31.5 with 16384-column slabs) —
+// bit-identical, but two block barriers and a dependent chain scalar loads -> tile + entry loads -> LDS per tile cost
+// more than the gathers they replace.  It therefore stays OFF unless PDLP_MI355X_SLAB_STAGE=1 asks for it.
+namespace { constexpr int32_t kStageMaxTiles = 8; }
+bool DeviceMatrix::wantStaging(const std::vector<int32_t>& lo, const std::vector<int32_t>& hi, const std::vector<int32_t>& cnt, int32_t R) {
+  const size_t lds = (size_t)R * 8 + kSlabThreads * 8 + 2 * 16 * 8 + ((size_t)8 << kSlabTileLog2) + 64;
+  if (lds > 160 * 1024) return false;
+  int force = -1;
+  if (const char* e = getenv("PDLP_MI355X_SLAB_STAGE")) force = atoi(e);
+  if (force == 0) return false;
+  // blocks worth staging: at most kStageMaxTiles tiles, at least one gather per 8 staged elements; the operand is staged
+  // when they hold most of its entries (the others stream the plain way inside the same launch)
+  int64_t good = 0, all = 0;
+  for (size_t b = 0; b < lo.size(); ++b) {
+    if (cnt[b] <= 0) continue;
+    const int64_t t = (hi[b] >> kSlabTileLog2) - (lo[b] >> kSlabTileLog2) + 1;  // (an upper bound: tiles in between may be untouched)
+    all += cnt[b];
+    if (t <= kStageMaxTiles && (int64_t)cnt[b] * 8 >= t * ((int64_t)1 << kSlabTileLog2)) good += cnt[b];
+  }
+  (void)good;
+  return all > 0 && force == 1;
+}
+
+// Tile tables of a built slab layout: where each wave's entry list changes tile (device scan), merged per block on the host.
+void DeviceMatrix::buildTileTables(int32_t nMinor, hipStream_t s) {
+  constexpr int32_t kCap = 64;
+  const int32_t nWaves = slab.nBlocks * (kSlabThreads / 64);
+  DeviceArray<int32_t> dSlab, dPos, dCnt;
+  dSlab.alloc((size_t)nWaves * kCap); dPos.alloc((size_t)nWaves * kCap); dCnt.alloc((size_t)nWaves);
+  launchSlabTileScan(slab, kSlabTileLog2, kCap, dSlab.get(), dPos.get(), dCnt.get(), s);
+  std::vector<int32_t> hSlab((size_t)nWaves * kCap), hPos((size_t)nWaves * kCap), hCnt((size_t)nWaves), hWave((size_t)nWaves + 1);
+  dSlab.download(hSlab.data(), hSlab.size(), s); dPos.download(hPos.data(), hPos.size(), s); dCnt.download(hCnt.data(), hCnt.size(), s);
+  wavePtr.download(hWave.data(), hWave.size(), s);
+  PDLP_HIP(hipStreamSynchronize(s));
+  std::vector<int32_t> blkPtr((size_t)slab.nBlocks + 1, 0), tsl, tgr, twb;
+  for (int32_t b = 0; b < slab.nBlocks; ++b) {
+    std::vector<int32_t> tiles;
+    for (int32_t w = 0; w < 16; ++w) {
+      const int32_t gw = b * 16 + w;
+      for (int32_t k = 0; k < std::min(hCnt[gw], kCap); ++k) tiles.push_back(hSlab[(size_t)gw * kCap + k]);
+    }
+    std::sort(tiles.begin(), tiles.end());
+    tiles.erase(std::unique(tiles.begin(), tiles.end()), tiles.end());
+    bool overflow = false;
+    for (int32_t w = 0; w < 16; ++w) overflow = overflow || hCnt[b * 16 + w] > kCap;
+    if (overflow || (int32_t)tiles.size() > kStageMaxTiles) tiles.clear();  // this block streams the plain way
+    const size_t row0 = twb.size();
+    twb.resize(row0 + (tiles.size() + 1) * 16);
+    for (int32_t w = 0; w < 16; ++w) {
+      const int32_t gw = b * 16 + w;
+      int32_t k = 0;
+      for (size_t t = 0; t < tiles.size(); ++t) {  // first entry of the wave whose tile is >= tiles[t]
+        while (k < hCnt[gw] && hSlab[(size_t)gw * kCap + k] < tiles[t]) ++k;
+        twb[row0 + t * 16 + w] = k < hCnt[gw] ? hPos[(size_t)gw * kCap + k] : hWave[gw + 1];
+      }
+      twb[row0 + tiles.size() * 16 + w] = hWave[gw + 1];
+    }
+    for (size_t t = 0; t < tiles.size(); ++t) {
+      int32_t g = 0;
+      for (int32_t w = 0; w < 16; ++w) g = std::max(g, (twb[row0 + (t + 1) * 16 + w] - twb[row0 + t * 16 + w] + 63) / 64);
+      tsl.push_back(tiles[t]);
+      tgr.push_back(g);
+    }
+    blkPtr[b + 1] = (int32_t)tsl.size();
+  }
+  if (getenv("PDLP_MI355X_DEBUG_TILES")) {
+    int64_t g = 0; int32_t mx = 0, staged = 0;
+    for (int32_t v : tgr) g += v;
+    for (int32_t b = 0; b < slab.nBlocks; ++b) { mx = std::max(mx, blkPtr[b + 1] - blkPtr[b]); staged += blkPtr[b + 1] > blkPtr[b]; }
+    fprintf(stderr, "tile tables: %d blocks (%d staged), %zu tiles (max %d per block), %lld group steps in total\n", slab.nBlocks, staged,
+            tsl.size(), mx, (long long)g);
+  }
+  auto up = [&](DeviceArray<int32_t>& d, const std::vector<int32_t>& h) { d.alloc(h.size()); d.upload(h.data(), h.size(), s); };
+  up(tBlkPtr, blkPtr); up(tSlab, tsl); up(tGroups, tgr); up(tWaveBeg, twb);
+  PDLP_HIP(hipStreamSynchronize(s));
+  tileLog2 = kSlabTileLog2;
+  slab.tileLog2 = tileLog2; slab.nMinor = nMinor;
+  slab.blkTilePtr = tBlkPtr.get(); slab.tileSlab = tSlab.get(); slab.tileGroups = tGroups.get(); slab.tileWaveBeg = tWaveBeg.get();
+}
+
 void DeviceMatrix::upload(const Compressed& cIn, int32_t nMajor_, int32_t nMinor_, int mode, hipStream_t s) {
   nMajor = nMajor_;
   nnz = cIn.beg.empty() ? 0 : cIn.beg[nMajor_];
   useSlab = chooseSlab(mode, nMajor_, nMinor_);
   const Compressed* c = &cIn;
   SlabLayout L;
+  bool stage = false;
   if (useSlab) {
-    buildSlabLayout(cIn, nMajor_, nMinor_, kSlabLongLimit, slabWidthLog2(), L);
+    const int32_t R = slabRowsPerWave(nMajor_, nMinor_) * 16, nB = (nMajor_ + R - 1) / R;
+    std::vector<int32_t> lo((size_t)nB, INT_MAX), hi((size_t)nB, -1), cnt((size_t)nB, 0);
+    for (int32_t r = 0; r < nMajor_; ++r) {
+      const int32_t p0 = cIn.beg[r], p1 = cIn.beg[r + 1];
+      if (p1 <= p0 || p1 - p0 > kSlabLongLimit) continue;
+      lo[r / R] = std::min(lo[r / R], cIn.idx[p0]); hi[r / R] = std::max(hi[r / R], cIn.idx[p1 - 1]); cnt[r / R] += p1 - p0;
+    }
+    stage = wantStaging(lo, hi, cnt, R);
+    buildSlabLayout(cIn, nMajor_, nMinor_, kSlabLongLimit, stage ? kSlabTileLog2 : slabWidthLog2(), L);
     if (L.rowsPerBlock > kSlabMaxRows) throw std::runtime_error("slab layout: too many majors per block");
     wavePtr.alloc(L.wavePtr.size());
     wavePtr.upload(L.wavePtr.data(), L.wavePtr.size(), s);
@@ -115,6 +207,7 @@ void DeviceMatrix::upload(const Compressed& cIn, int32_t nMajor_, int32_t nMinor
   val.upload(c->val.data(), (size_t)nnzCsr, s);
   uploadPlans(c->beg, nCsrMajor, useSlab ? L.longMap.data() : nullptr, s);
   PDLP_HIP(hipStreamSynchronize(s));  // host vectors may go out of scope
+  if (stage) buildTileTables(nMinor_, s);
 }
 
 void DeviceMatrix::buildFromDevice(DeviceCsrData& M, int mode, hipStream_t s) {
@@ -123,9 +216,22 @@ void DeviceMatrix::buildFromDevice(DeviceCsrData& M, int mode, hipStream_t s) {
   useSlab = chooseSlab(mode, M.nMajor, M.nMinor);
   std::vector<int32_t> hostBeg, hostLongMap;
   int32_t nCsrMajor = nMajor;
+  bool stage = false;
+  const int32_t nMinorM = M.nMinor;
   if (useSlab) {
+    const int32_t R = slabRowsPerWave(M.nMajor, M.nMinor) * 16, nB = (M.nMajor + R - 1) / R;
+    {  // per-block span of the short majors, from the CSR that is already in HBM
+      std::vector<int32_t> lo((size_t)nB, INT_MAX), hi((size_t)nB, -1), cnt((size_t)nB, 0);
+      DeviceArray<int32_t> dLo, dHi, dCn;
+      dLo.alloc(nB); dHi.alloc(nB); dCn.alloc(nB);
+      dLo.upload(lo.data(), nB, s); dHi.upload(hi.data(), nB, s); dCn.upload(cnt.data(), nB, s);
+      launchBlockSpan(M.beg.get(), M.idx.get(), M.nMajor, R, kSlabLongLimit, dLo.get(), dHi.get(), dCn.get(), s);
+      dLo.download(lo.data(), nB, s); dHi.download(hi.data(), nB, s); dCn.download(cnt.data(), nB, s);
+      PDLP_HIP(hipStreamSynchronize(s));
+      stage = wantStaging(lo, hi, cnt, R);
+    }
     DeviceSlabLayout L;
-    gpuBuildSlabLayout(M, kSlabLongLimit, slabWidthLog2(), s, L);
+    gpuBuildSlabLayout(M, kSlabLongLimit, stage ? kSlabTileLog2 : slabWidthLog2(), s, L);
     if (L.rowsPerBlock > kSlabMaxRows) throw std::runtime_error("slab layout: too many majors per block");
     wavePtr = std::move(L.wavePtr);
     ent = std::move(L.ent);
@@ -149,6 +255,7 @@ void DeviceMatrix::buildFromDevice(DeviceCsrData& M, int mode, hipStream_t s) {
     PDLP_HIP(hipStreamSynchronize(s));
   }
   uploadPlans(hostBeg, nCsrMajor, useSlab ? hostLongMap.data() : nullptr, s);
+  if (stage) buildTileTables(nMinorM, s);
 }
 
 MatView DeviceMatrix::view() const {

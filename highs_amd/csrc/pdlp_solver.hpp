@@ -26,6 +26,9 @@ struct DeviceMatrix {
   DeviceArray<double> val, slabVal;
   // long majors
   DeviceArray<LongTask> lTasks;
+  // LDS staging of the gathered vector (SlabMat::tileLog2 and its tables)
+  DeviceArray<int32_t> tBlkPtr, tSlab, tGroups, tWaveBeg;
+  int32_t tileLog2 = 0;
   DeviceArray<double> lSegSum, lContrib;
   DeviceArray<uint32_t> lTicket;
   int32_t nLong = 0, nTasks = 0, longSlots = 0, longGroup = 1;
@@ -44,6 +47,9 @@ struct DeviceMatrix {
 
  private:
   void uploadPlans(const std::vector<int32_t>& hostBeg, int32_t nCsrMajor, const int32_t* longVecIndex, hipStream_t s);
+  // should the operand be staged through LDS (per-block span / entry count of its short majors)? -> slab width to build with
+  static bool wantStaging(const std::vector<int32_t>& lo, const std::vector<int32_t>& hi, const std::vector<int32_t>& cnt, int32_t R);
+  void buildTileTables(int32_t nMinor, hipStream_t s);
 };
 
 // Picks M.xcdMap by timing the plain SpMV out = M * in with both block -> XCD assignments (a few launches; the

@@ -496,6 +496,34 @@ def test_gpu_setup_long_rows_slab_layout(monkeypatch):
     S.close()
 
 
+def test_lds_staged_slab_layout_bit_identical(monkeypatch):
+    """Structured operand (block-angular network LP in small): the slab kernel that stages the gathered vector through
+    LDS tile by tile (SlabMat::tileLog2) must give the bits of the plain slab kernel — entry order and every sum are
+    unchanged —, for the plain SpMVs (also against the oracle's device order) and for the iterates after 120
+    iterations with every fused epilogue in the loop."""
+    from lpgen import structured_lp
+    lp = structured_lp(seed=2, commodities=12, nodes=1024, arcs=8192, link_rows=24, link_nnz=700, extra_rows=40)
+    monkeypatch.setenv("PDLP_MI355X_SLAB", "1")
+    out = {}
+    for stage in ("0", "1"):
+        monkeypatch.setenv("PDLP_MI355X_SLAB_STAGE", stage)
+        P = solver.Prepared(lp)
+        S = solver.DeviceSolver(lp)
+        rng = np.random.default_rng(4)
+        x, y = rng.standard_normal(P.n), rng.standard_normal(P.m)
+        S.set("x", x); S.set("y", y); S.stage("ax"); S.stage("aty")
+        ax, aty = S.get("ax", P.m), S.get("aty", P.n)
+        assert np.array_equal(ax, _spmv(P.csr_beg, P.csr_idx, P.csr_val, x, P.m, 256))
+        assert np.array_equal(aty, _spmv(P.csc_beg, P.csc_idx, P.csc_val, y, P.n, 256))
+        S.close()
+        S = solver.DeviceSolver(lp)
+        S.iterate(120)
+        out[stage] = (ax, aty, S.get("x", P.n), S.get("y", P.m), S.get("steps", 8))
+        S.close()
+    for a, b in zip(out["0"], out["1"]):
+        assert np.array_equal(a, b)
+
+
 def test_concurrent_solver_contexts_on_two_threads():
     """SURVEY §8b threading contract: several Highs instances may call the path concurrently from different
     threads, so a context holds no process-global mutable state.  Two threads solve different LPs (both
