@@ -138,8 +138,124 @@ __device__ __attribute__((unused)) void decideUpdate(DevState* st, double dX2, d
   }
 }
 
+// Block-uniform read through the scalar (constant) path: s_load counts on lgkmcnt,
+// so it never forces a wait on the vector-memory prefetches in flight.
+template <typename T>
+__device__ __forceinline__ T ldUniform(const T* p) {
+  return *(const __attribute__((address_space(4))) T*)(p);
+}
+
+// XCD-aware work assignment.  Workgroup b runs on XCD b % 8 (observed dispatch order; only a speed
+// assumption), and each XCD has its own L2.  Consecutive work blocks own consecutive majors, which in a
+// structured LP (network blocks, staircases) touch neighbouring minors: giving XCD x the CONTIGUOUS range of
+// logical blocks [x*nB/8, (x+1)*nB/8) keeps the part of the gathered vector an XCD needs at 1/8 of it instead of
+// all of it (measured on the block-angular LP of bench.py --config c: A x 73 -> 50 us, L2 misses 2.5 M -> 0.9 M;
+// its transpose prefers round robin, 25 vs 39 us, and a random matrix does not care), so the mapping is chosen
+// per operand by timing both at setup (tuneXcdMap).  Results do not depend on it: partials are indexed by the
+// logical block.
+__device__ __forceinline__ int xcdContiguousBlock(int b, int nB) {
+  constexpr int kXcds = 8;
+  const int xcd = b % kXcds, i = b / kXcds;
+  const int qlo = nB / kXcds, r = nB % kXcds;
+  return xcd < r ? xcd * (qlo + 1) + i : r * (qlo + 1) + (xcd - r) * qlo + i;
+}
+
+// Agent-scope relaxed accesses (global_load/store ... sc1): write-through stores, L1-bypassing loads — the only
+// way data crosses workgroups INSIDE a launch on this part (eight XCDs with private L2s, per-CU L1s that are never
+// refreshed by other CUs' stores).
+__device__ __forceinline__ void stAgent(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ldAgent(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// Grid barrier for a grid whose blocks are ALL resident.  Called by wave 0 of every block after lane 0's stores of the
+// block's published words.  Every block owns one 8-byte arrival word; arriving = storing the epoch there (after the
+// published words have landed); waiting = sweeping all arrival words, nBlocks / 64 per lane, until every one carries
+// at least the epoch (a fast block may already stand at the launch's next barrier).  One store and one sweep: no
+// atomic round trips, no counter to reset (measured the same as the XCD-hierarchical counter barrier it replaced in
+// the fused trial: 64.0 us per launch either way).  Epochs grow with the trial counter (the words are zeroed when a
+// solve starts).  A wait that does not end (a block that is not resident) gives up after ~1 s and raises the flag
+// word instead of hanging the device.  LOCAL: every block sits on ONE XCD (the caller has checked it): the words go
+// through that XCD's L2 — ordinary stores, non-temporal (L1-bypassing) loads — instead of through memory.
+template <bool LOCAL = false>
+__device__ __forceinline__ void gridBarrier(unsigned long long* bar, int blk, int nBlocks, unsigned long long epoch, int lane) {
+  auto ld = [&](const unsigned long long* p) -> unsigned long long {
+    if (!LOCAL) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long v;
+    asm volatile("global_load_dwordx2 %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+  };
+  if (lane == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this block's published words have landed
+    if (LOCAL) { *reinterpret_cast<volatile unsigned long long*>(bar + blk) = epoch; }
+    else __hip_atomic_store(bar + blk, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  for (uint32_t spins = 0;; ++spins) {
+    bool ok = true;
+    for (int i = lane; i < nBlocks; i += kWave) ok = ok && ld(bar + i) >= epoch;
+    if (__all(ok)) break;
+    __builtin_amdgcn_s_sleep(1);
+    if (spins > (1u << 23)) {
+      if (lane == 0) __hip_atomic_store(bar + nBlocks, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+  }
+}
+
 // Epilogue operands that do not depend on the SpMV result.
 struct Pre { double a, b, c, d, e; };
+
+// Fixed-order sums of the three per-block partial arrays by 256 threads: lane t sums elements t, t+256, ...
+// (4 independent chains), then wave shuffle tree, then the 4 wave results in order.  Results valid in thread 0.
+// Shared by k_decide, k_decide_primal and the fused trial kernel, so all take identical decisions.  AGENT: the
+// partials were written by other workgroups of the SAME launch (agent-scope loads); threads >= 256 of a larger
+// block only take part in the barrier.
+template <bool AGENT>
+__device__ __forceinline__ void trialSumsT(const double* __restrict__ partDY, int nDY, const double* __restrict__ partDX,
+                                           const double* __restrict__ partInter, int nDX, double (*scratch)[kVecThreads / kWave],
+                                           double& dY2, double& dX2, double& inter, const double* __restrict__ partQ = nullptr,
+                                           int nQ = 0, double* qint = nullptr) {
+  const int tid = threadIdx.x;
+  auto ld = [&](const double* q) { return AGENT ? ldAgent(q) : *q; };
+  auto laneSum = [&](const double* __restrict__ p, int count) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int i = tid;
+    for (; i + 3 * kVecThreads < count; i += 4 * kVecThreads) {
+      const double a0 = ld(p + i), a1 = ld(p + i + kVecThreads), a2 = ld(p + i + 2 * kVecThreads), a3 = ld(p + i + 3 * kVecThreads);
+      s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+    }
+    for (; i < count; i += kVecThreads) s0 += ld(p + i);
+    return (s0 + s1) + (s2 + s3);
+  };
+  if (tid < kVecThreads) {
+    double vY = partDY ? laneSum(partDY, nDY) : 0.0;
+    double vX = laneSum(partDX, nDX);
+    double vI = laneSum(partInter, nDX);
+    double vQ = partQ ? laneSum(partQ, nQ) : 0.0;  // (QP with off-diagonal Hessian entries: dx . N dx)
+    vY = waveSum(vY); vX = waveSum(vX); vI = waveSum(vI);
+    if (partQ) vQ = waveSum(vQ);
+    const int lane = tid & (kWave - 1), w = tid / kWave;
+    if (lane == 0) { scratch[0][w] = vY; scratch[1][w] = vX; scratch[2][w] = vI; scratch[3][w] = vQ; }
+  }
+  __syncthreads();
+  dY2 = dX2 = inter = 0.0;
+  if (tid == 0) {
+    double q = 0.0;
+#pragma unroll
+    for (int i = 0; i < kVecThreads / kWave; ++i) { dY2 += scratch[0][i]; dX2 += scratch[1][i]; inter += scratch[2][i]; q += scratch[3][i]; }
+    if (qint) *qint = q;
+  }
+}
+__device__ __forceinline__ void trialSums(const double* __restrict__ partDY, int nDY, const double* __restrict__ partDX,
+                                          const double* __restrict__ partInter, int nDX, double (*scratch)[kVecThreads / kWave],
+                                          double& dY2, double& dX2, double& inter, const double* __restrict__ partQ = nullptr,
+                                          int nQ = 0, double* qint = nullptr) {
+  trialSumsT<false>(partDY, nDY, partDX, partInter, nDX, scratch, dY2, dX2, inter, partQ, nQ, qint);
+}
 
 // HiPDLP step, column side (pdhg.cc:975-990 and :1008-1011): s = (A'y)_j.
 __device__ __forceinline__ __attribute__((unused)) void halpernPrimal(const HalpernVecs& h, int j, double s, const Pre& p, double tau,

@@ -394,9 +394,11 @@ StreamPlan planStream(const std::vector<int32_t>& beg, int32_t nMajor, int32_t c
     while (end < nMajor && end - start < maxMajorsPerBlock && beg[end + 1] - base <= chunk) ++end;
     plan.blockBeg.push_back(start);
     plan.blockBeg.push_back(end);
+    plan.blockBeg.push_back(beg[start]);  // (first and end entry ride along: one dependent load less in the kernels)
+    plan.blockBeg.push_back(beg[end]);
     start = end;
   }
-  plan.nBlocks = (int32_t)plan.blockBeg.size() / 2;
+  plan.nBlocks = (int32_t)plan.blockBeg.size() / 4;
   return plan;
 }
 

@@ -89,7 +89,7 @@ void extractSlab(const StandardForm& F, int32_t r0, int32_t r1, Compressed& csrS
 // majors, summed left to right by one lane each); a major longer than `chunk` belongs to no block — it is cut
 // into segment tasks (LongPlan).
 struct StreamPlan {
-  std::vector<int32_t> blockBeg;    // [2*nBlocks] first and end major of each block
+  std::vector<int32_t> blockBeg;    // [4*nBlocks] first and end major, first and end entry of each block
   int32_t nBlocks = 0;
   std::vector<int32_t> longMajors;  // majors longer than chunk, ascending
 };

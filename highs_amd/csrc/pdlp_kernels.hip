@@ -53,65 +53,6 @@ struct SpmvArgs {
   unsigned long long* bar;
 };
 
-// Block-uniform read through the scalar (constant) path: s_load counts on lgkmcnt,
-// so it never forces a wait on the vector-memory prefetches in flight.
-template <typename T>
-__device__ __forceinline__ T ldUniform(const T* p) {
-  return *(const __attribute__((address_space(4))) T*)(p);
-}
-
-// XCD-aware work assignment.  Workgroup b runs on XCD b % 8 (observed dispatch order; only a speed
-// assumption), and each XCD has its own L2.  Consecutive work blocks own consecutive majors, which in a
-// structured LP (network blocks, staircases) touch neighbouring minors: giving XCD x the CONTIGUOUS range of
-// logical blocks [x*nB/8, (x+1)*nB/8) keeps the part of the gathered vector an XCD needs at 1/8 of it instead of
-// all of it (measured on the block-angular LP of bench.py --config c: A x 73 -> 50 us, L2 misses 2.5 M -> 0.9 M;
-// its transpose prefers round robin, 25 vs 39 us, and a random matrix does not care), so the mapping is chosen
-// per operand by timing both at setup (tuneXcdMap).  Results do not depend on it: partials are indexed by the
-// logical block.
-__device__ __forceinline__ int xcdContiguousBlock(int b, int nB) {
-  constexpr int kXcds = 8;
-  const int xcd = b % kXcds, i = b / kXcds;
-  const int qlo = nB / kXcds, r = nB % kXcds;
-  return xcd < r ? xcd * (qlo + 1) + i : r * (qlo + 1) + (xcd - r) * qlo + i;
-}
-
-// Agent-scope relaxed accesses (global_load/store ... sc1): write-through stores, L1-bypassing loads — the only
-// way data crosses workgroups INSIDE a launch on this part (eight XCDs with private L2s, per-CU L1s that are never
-// refreshed by other CUs' stores).
-__device__ __forceinline__ void stAgent(double* p, double v) {
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double ldAgent(const double* p) {
-  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
-                                                          __HIP_MEMORY_SCOPE_AGENT));
-}
-
-// Grid barrier for a grid whose blocks are ALL resident.  Called by wave 0 of every block after lane 0's agent-scope
-// stores of the block's published words.  Every block owns one 8-byte arrival word; arriving = storing the launch's
-// epoch there (after the published words have landed); waiting = sweeping all arrival words with relaxed agent-scope
-// loads, nBlocks / 64 per lane, until every one carries the epoch.  One store and one sweep: no atomic round trips,
-// no counter to reset — measured 64.0 -> see DESIGN.md against the XCD-hierarchical counter barrier it replaced.  The epoch is the
-// trial counter + 1 (unique per executed trial; the words are zeroed when a solve starts).  A wait that does not
-// end (a block that is not resident) gives up after ~1 s and raises the flag word instead of hanging the device.
-__device__ __forceinline__ void gridBarrier(unsigned long long* bar, int blk, int nBlocks, unsigned long long epoch, int lane) {
-  if (lane == 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this block's published words have landed
-    __hip_atomic_store(bar + blk, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  for (uint32_t spins = 0;; ++spins) {
-    bool ok = true;
-    for (int i = lane; i < nBlocks; i += kWave)
-      ok = ok && __hip_atomic_load(bar + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
-    if (__all(ok)) break;
-    __builtin_amdgcn_s_sleep(4);
-    if (spins > (1u << 21)) {
-      if (lane == 0) __hip_atomic_store(bar + nBlocks, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      break;
-    }
-  }
-}
-
 // The major-local epilogue fused into both SpMV kernels: what happens to (A v)_r once it is known.
 //   kDualStep     y+ = proj(y + sigma (b - 2 A x+ + A x)), sum (dy)^2        cupdlp_step.c:43-69
 //   kAtyInteract  sum (dx)^2, sum dx . d(A'y)                                cupdlp_linalg.c:772-801
@@ -212,54 +153,6 @@ struct Epi {
     }
   }
 };
-
-// Fixed-order sums of the three per-block partial arrays by 256 threads: lane t sums elements t, t+256, ...
-// (4 independent chains), then wave shuffle tree, then the 4 wave results in order.  Results valid in thread 0.
-// Shared by k_decide, k_decide_primal and the fused trial kernel, so all take identical decisions.  AGENT: the
-// partials were written by other workgroups of the SAME launch (agent-scope loads); threads >= 256 of a larger
-// block only take part in the barrier.
-template <bool AGENT>
-__device__ __forceinline__ void trialSumsT(const double* __restrict__ partDY, int nDY, const double* __restrict__ partDX,
-                                           const double* __restrict__ partInter, int nDX, double (*scratch)[kVecThreads / kWave],
-                                           double& dY2, double& dX2, double& inter, const double* __restrict__ partQ = nullptr,
-                                           int nQ = 0, double* qint = nullptr) {
-  const int tid = threadIdx.x;
-  auto ld = [&](const double* q) { return AGENT ? ldAgent(q) : *q; };
-  auto laneSum = [&](const double* __restrict__ p, int count) {
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int i = tid;
-    for (; i + 3 * kVecThreads < count; i += 4 * kVecThreads) {
-      const double a0 = ld(p + i), a1 = ld(p + i + kVecThreads), a2 = ld(p + i + 2 * kVecThreads), a3 = ld(p + i + 3 * kVecThreads);
-      s0 += a0; s1 += a1; s2 += a2; s3 += a3;
-    }
-    for (; i < count; i += kVecThreads) s0 += ld(p + i);
-    return (s0 + s1) + (s2 + s3);
-  };
-  if (tid < kVecThreads) {
-    double vY = partDY ? laneSum(partDY, nDY) : 0.0;
-    double vX = laneSum(partDX, nDX);
-    double vI = laneSum(partInter, nDX);
-    double vQ = partQ ? laneSum(partQ, nQ) : 0.0;  // (QP with off-diagonal Hessian entries: dx . N dx)
-    vY = waveSum(vY); vX = waveSum(vX); vI = waveSum(vI);
-    if (partQ) vQ = waveSum(vQ);
-    const int lane = tid & (kWave - 1), w = tid / kWave;
-    if (lane == 0) { scratch[0][w] = vY; scratch[1][w] = vX; scratch[2][w] = vI; scratch[3][w] = vQ; }
-  }
-  __syncthreads();
-  dY2 = dX2 = inter = 0.0;
-  if (tid == 0) {
-    double q = 0.0;
-#pragma unroll
-    for (int i = 0; i < kVecThreads / kWave; ++i) { dY2 += scratch[0][i]; dX2 += scratch[1][i]; inter += scratch[2][i]; q += scratch[3][i]; }
-    if (qint) *qint = q;
-  }
-}
-__device__ __forceinline__ void trialSums(const double* __restrict__ partDY, int nDY, const double* __restrict__ partDX,
-                                          const double* __restrict__ partInter, int nDX, double (*scratch)[kVecThreads / kWave],
-                                          double& dY2, double& dX2, double& inter, const double* __restrict__ partQ = nullptr,
-                                          int nQ = 0, double* qint = nullptr) {
-  trialSumsT<false>(partDY, nDY, partDX, partInter, nDX, scratch, dY2, dX2, inter, partQ, nQ, qint);
-}
 
 // The segment tasks of the long majors (pdlp_kernels.hpp LongMat): workgroup lb of the extra blocks runs the tasks
 // [lb*W, (lb+1)*W), one per wave.  Lane l adds the products of the entries l, l+64, ... of the segment in ascending
@@ -391,8 +284,8 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
     return;
   }
   const int blk = a.xcdMap ? xcdContiguousBlock(blockIdx.x, a.A.nBlocks) : (int)blockIdx.x;
-  const int r0 = a.A.blockBeg[2 * blk], r1 = a.A.blockBeg[2 * blk + 1];
-  const int p0 = a.A.beg[r0], p1 = a.A.beg[r1];
+  const int4 bb = *reinterpret_cast<const int4*>(a.A.blockBeg + 4 * blk);  // (first major, end major, first entry, end entry)
+  const int r0 = bb.x, r1 = bb.y, p0 = bb.z, p1 = bb.w;
   const int32_t* __restrict__ idx = a.A.idx;
   const double* __restrict__ val = a.A.val;
   const double* __restrict__ in = epi.input();
@@ -750,9 +643,10 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
       }
       __builtin_amdgcn_sched_barrier(0);  // gather, then refill, then the LDS work: in this order
       consumeGroup(eCur, prod, nValid);
-      __syncthreads();  // pacing: the CU's waves stay on the same slab (and order this step's LDS traffic)
+      if (!a.S.noPace) __syncthreads();  // pacing: the CU's waves stay on the same slab
     }
   }
+  if (a.S.noPace) __syncthreads();  // (free-running waves: every wave's accumulators are final before the epilogue reads them)
 
   }
   const uint32_t* __restrict__ mask = a.S.longMask + (size_t)blk * (R / 32);

@@ -58,7 +58,7 @@ struct SpmvMat {
   const int32_t* beg;       // [nMajor+1]
   const int32_t* idx;       // [nnz]
   const double* val;        // [nnz]
-  const int32_t* blockBeg;  // [2*nBlocks] stream plan: first major and end major of each work block
+  const int32_t* blockBeg;  // [4*nBlocks] stream plan: first and end major, first and end entry of each work block
   int32_t nMajor;
   int32_t nBlocks;
   int32_t partOffset;       // first slot of this matrix in the per-block partial arrays
@@ -118,6 +118,11 @@ struct SlabMat {
   // CU's vector-memory miss queue, which is what bounds the kernel otherwise.  Entry order, hence every sum, is
   // unchanged.  tileLog2 == 0: not staged.
   int32_t tileLog2, nMinor;
+  // 1: no block barrier per 64-entry group.  The barrier keeps the CU's waves on the same slab of the gathered vector
+  // (a random matrix needs that: 50 -> 58 us at 1M x 1M without); an operand whose blocks touch little of the gathered
+  // vector anyway runs faster free (block-angular LP of bench.py --config c: 31.8 -> 29.0 us).  Chosen per operand by
+  // timing both at set-up (tuneXcdMap).
+  int32_t noPace;
   const int32_t* blkTilePtr;  // [nBlocks+1] first tile of each block
   const int32_t* tileSlab;    // [nTiles] slab index of the tile
   const int32_t* tileGroups;  // [nTiles] 64-entry groups of the longest wave part in the tile
@@ -225,6 +230,18 @@ int fusedAtyBlocks(const MatView& At);  // blocks of the fused launch (= arrival
 void launchSpmvAtyFusedPrimal(const MatView& At, const IterVecs& v, const DevState* stIn, DevState* stOut,
                               const double* partDY, int32_t nDY, double* partDX, double* partInter,
                               unsigned long long* bar, hipStream_t s);
+
+// ---- small LPs: a batch of trials as ONE persistent launch (pdlp_small.hip) -------------------------------------
+// Both operands in the stream layout with 512-entry work blocks, no long majors.  smallTrialsGrid: workgroups of the
+// launch (0: does not qualify) and, in *resident, how many the device holds at once (the grid barrier needs all of
+// them resident).  bar: gridBarWords(grid) zeroed words.  The launch runs at most maxTrials trials and stops early
+// when the device halts; the state record is read from and written back to *st.  xcdLocal: only every eighth of
+// 8 * grid workgroups works (one XCD, one coherent L2: no agent-scope traffic); the launch checks that placement and,
+// if it does not hold, changes nothing and sets commError = 2 in *st — the caller then goes on with xcdLocal = false.
+int smallTrialsGrid(const MatView& A, const MatView& At, int32_t n, int device, int* resident);
+void launchSmallTrials(const MatView& A, const MatView& At, const IterVecs& v, DevState* st, double* partDY, double* partDX,
+                       double* partInter, unsigned long long* bar, int32_t grid, int32_t maxTrials, bool xcdLocal, hipStream_t s);
+inline size_t smallBarWords(int grid) { return 2 * (size_t)grid + 16; }  // arrival words, timeout flag, XCC ids of the placement check
 
 // ---- check-iteration kernels (host knows the parity here) -------------------
 void launchFlushAverage(const IterVecs& v, DevState* st, hipStream_t s);

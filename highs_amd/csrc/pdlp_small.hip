@@ -1,0 +1,330 @@
+// pdlp_small.hip — the PDHG trial loop of SMALL LPs (Netlib class) as ONE persistent launch.
+//
+// Below ~10^5 nonzeros a trial step is latency, not bandwidth: three dependent launches of ~6 us each, of which
+// ~2 us is the kernel boundary and the rest a chain of three or four dependent memory round trips.  Here a batch
+// of trials runs inside one launch of a few dozen resident workgroups: the phases of a trial
+//     P  x+ = clamp(x - tau (c - A'y), l, u) on a share of the columns        cupdlp_step.c:16-40
+//     A  A x+ with the dual step and the (dy)^2 partials                       cupdlp_step.c:43-69
+//     T  A'y+ with the (dx)^2 and dx.d(A'y) partials                           cupdlp_linalg.c:772-801
+//     D  accept / reject and the step-size update, in EVERY workgroup          cupdlp_step.c:215-310
+// are separated by grid barriers (one arrival word per workgroup, a sweep by one wave: pdlp_devfn.hpp gridBarrier)
+// instead of kernel boundaries.  Work blocks, lane assignments and reduction trees are EXACTLY those of k_spmv /
+// k_decide_primal (pdlp_kernels.hip), so iterates and decisions are bit-identical to the 3-launch loop and the
+// oracle's device-order mode follows them unchanged.
+//   Visibility inside a launch: per-CU L1s are never refreshed by other CUs' stores and the eight XCD L2s are not
+// coherent with each other, so EVERY access to a vector that changes during the launch (iterates, sums, partials)
+// is an agent-scope relaxed atomic (global_load/store sc1: write-through, L1-bypassing); a workgroup's stores have
+// landed (s_waitcnt vmcnt(0) in every wave, then the block barrier) before its arrival word is written.  Matrix,
+// plans, costs, bounds and right-hand sides never change: ordinary loads.
+//   XCD-LOCAL mode (the default): only every eighth workgroup of the launch works — under the dispatch order observed
+// on this part those share ONE XCD, i.e. one coherent L2 — and then ordinary stores (the L1 is write-through) with
+// non-temporal loads (served by the L2, never by a stale L1 line) are coherent without a trip to memory: a dependent
+// round trip costs an L2 hit instead of an HBM access.  The placement is CHECKED, never assumed: every worker
+// publishes the XCC id it runs on before the first trial; unless all agree the launch changes nothing and reports it,
+// and the solver continues with agent-scope accesses on all XCDs (the mode above) from then on.
+//   The state record lives in LDS of every workgroup (identical copies: every workgroup takes the same decision
+// from the same partials); workgroup 0 writes it back when the batch ends or the device halts.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+
+#include "pdlp_devfn.hpp"
+#include "pdlp_kernels.hpp"
+
+namespace pdlp {
+
+namespace {
+
+struct SmallArgs {
+  SpmvMat A, At;
+  IterVecs v;
+  DevState* st;
+  double* partDY;
+  double* partDX;
+  double* partInter;
+  unsigned long long* bar;
+  int32_t xcdA, xcdAt;
+  int32_t maxTrials;
+  int32_t pad_;
+  unsigned long long* prof;  // development: 100 MHz ticks per phase {P, barrier, A, barrier, T, barrier, D}, accumulated by workgroup 0
+};
+
+template <bool LOCAL>
+__device__ __forceinline__ void arrive(unsigned long long* bar, int lb, int nBlocks, unsigned long long epoch) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores (write-through, or into the shared L2) ...
+  __syncthreads();                                    // ... before the block's arrival word is written
+  if (threadIdx.x < kWave) gridBarrier<LOCAL>(bar, lb, nBlocks, epoch, (int)threadIdx.x);
+  __syncthreads();
+}
+// accesses to the vectors that change during the launch: agent scope on all XCDs, or L2-coherent on one XCD
+template <bool LOCAL>
+__device__ __forceinline__ double ldM(const double* p) { return LOCAL ? ldStream(p) : ldAgent(p); }
+template <bool LOCAL>
+__device__ __forceinline__ void stM(double* p, double v) { if (LOCAL) *p = v; else stAgent(p, v); }
+__device__ __forceinline__ int xccId() {
+  int id;
+  asm volatile("s_getreg_b32 %0, hwreg(20, 0, 4)" : "=s"(id));  // HW_REG_XCC_ID[3:0]
+  return id;
+}
+
+// The work block a workgroup owns in one operand, loaded ONCE per launch: a persistent workgroup runs the same
+// block of A and of A' in every trial, and the matrix never changes — entries, values and the bookkeeping of the
+// lane's first major stay in registers; a trial then only gathers, adds and stores.
+template <int CHUNK>
+struct OwnBlock {
+  static constexpr int kPer = CHUNK / kSpmvThreads;
+  int r0 = 0, r1 = 0, p0 = 0, cnt = 0, qb = 0, qe = 0, slot_ = 0;
+  int32_t ci[kPer];
+  double va[kPer];
+  double fixed = 0.0;  // rhs of the lane's first row (phase A)
+  bool have = false;
+  __device__ __forceinline__ void load(const SpmvMat& M, int blk, bool dual, const double* rhs) {
+    have = true;
+    slot_ = M.partOffset + blk;
+    const int4 bb = *reinterpret_cast<const int4*>(M.blockBeg + 4 * blk);  // (first major, end major, first entry, end entry)
+    r0 = bb.x; r1 = bb.y; p0 = bb.z; cnt = bb.w - bb.z;
+    const int tid = threadIdx.x;
+    const int rFirst = r0 + tid;
+    const int rr = rFirst < r1 ? rFirst : r1 - 1;
+    qb = M.beg[rr] - p0;
+    qe = M.beg[rr + 1] - p0;
+    if (dual) fixed = rhs[rr];
+    const int last = cnt > 0 ? cnt - 1 : 0;  // idx/val carry one pad element
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int q = tid + k * kSpmvThreads;
+      const int qq = q < last ? q : last;
+      ci[k] = M.idx[p0 + qq];
+      va[k] = M.val[p0 + qq];
+    }
+  }
+};
+
+// One trial's pass over the owned block (same plan, lanes and sums as k_spmv's stream path) with the epilogue of
+// phase A (DUAL) or T.  Per-thread reduction partials are added to acc0 / acc1.
+template <int CHUNK, bool DUAL, bool LOCAL>
+__device__ __forceinline__ void smallSpmvBlock(const SmallArgs& a, const SpmvMat& M, const OwnBlock<CHUNK>& B, int cur, double sigma,
+                                               double avgW, double* prod, double& acc0, double& acc1) {
+  const int tid = threadIdx.x, nxt = cur ^ 1;
+  const double* in = DUAL ? a.v.x[nxt] : a.v.y[nxt];
+  constexpr int kPer = CHUNK / kSpmvThreads;
+  const int r0 = B.r0, r1 = B.r1, p0 = B.p0, cnt = B.cnt;
+  const int rFirst = r0 + tid;
+  const int rr = rFirst < r1 ? rFirst : r1 - 1;
+  int qb = B.qb, qe = B.qe;
+  auto prefetch = [&](int r, bool first) {
+    Pre p{0.0, 0.0, 0.0, 0.0, 0.0};
+    if (DUAL) { p.a = ldM<LOCAL>(a.v.y[cur] + r); p.b = first ? B.fixed : a.v.rhs[r]; p.c = ldM<LOCAL>(a.v.ax[cur] + r); }
+    else { p.a = ldM<LOCAL>(a.v.x[cur] + r); p.b = ldM<LOCAL>(a.v.x[nxt] + r); p.c = ldM<LOCAL>(a.v.aty[cur] + r); }
+    return p;
+  };
+  double xg[kPer];
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) xg[k] = ldM<LOCAL>(in + B.ci[k]);
+  Pre pre = prefetch(rr, true);
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    const int q = tid + k * kSpmvThreads;
+    if (q < cnt) prod[slot(q)] = B.va[k] * xg[k];
+  }
+  __syncthreads();
+  for (int r = rFirst; r < r1; r += kSpmvThreads) {
+    if (r != rFirst) {
+      qb = M.beg[r] - p0;
+      qe = M.beg[r + 1] - p0;
+      pre = prefetch(r, false);
+    }
+    double s = 0.0;
+    int q = qb;
+    // left to right (the reference's order): the adds are a dependent chain, so the LDS reads of the NEXT eight
+    // products are issued before the current eight are added (25fv47 has a major of 340 entries)
+    if (q + 8 <= qe) {
+      double t[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t[k] = prod[slot(q + k)];
+      q += 8;
+      for (; q + 8 <= qe; q += 8) {
+        double u[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) u[k] = prod[slot(q + k)];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += t[k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = u[k];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += t[k];
+    }
+    for (; q < qe; ++q) s += prod[slot(q)];
+    if (DUAL) {
+      const double yv = pre.a;
+      if (avgW != 0.0) stM<LOCAL>(a.v.ySum + r, ldM<LOCAL>(a.v.ySum + r) + avgW * yv);  // deferred PDHG_Update_Average (step.c:438)
+      double t = yv;
+      t += sigma * pre.b;
+      t += (-2.0 * sigma) * s;
+      t += sigma * pre.c;
+      if (r + a.v.rowOffset >= a.v.nEqs) t = t > 0.0 ? t : 0.0;
+      stM<LOCAL>(a.v.ax[nxt] + r, s);
+      stM<LOCAL>(a.v.y[nxt] + r, t);
+      const double d = yv - t;
+      acc0 += d * d;
+    } else {
+      const double dx = pre.a - pre.b;
+      const double da = pre.c - s;
+      stM<LOCAL>(a.v.aty[nxt] + r, s);
+      acc0 += dx * dx;
+      acc1 += dx * da;
+    }
+  }
+}
+
+template <int CHUNK_A, int CHUNK_AT, bool LOCAL>
+__global__ __launch_bounds__(kSpmvThreads) void k_trials_small(const SmallArgs a) {
+  constexpr int kMaxChunk = CHUNK_A > CHUNK_AT ? CHUNK_A : CHUNK_AT;
+  __shared__ double prod[kMaxChunk + kMaxChunk / 8 + 8];
+  __shared__ double scratch[2][kSpmvThreads / kWave];
+  __shared__ double tscr[4][kVecThreads / kWave];
+  __shared__ DevState sh;
+  __shared__ int placementOk;
+  const int tid = threadIdx.x;
+  if (LOCAL && (blockIdx.x & 7) != 0) return;  // XCD-local: every eighth workgroup works
+  const int lb = LOCAL ? (int)blockIdx.x >> 3 : (int)blockIdx.x;      // logical workgroup
+  const int G = LOCAL ? (int)gridDim.x >> 3 : (int)gridDim.x;
+  if (tid < (int)(sizeof(DevState) / 4)) reinterpret_cast<uint32_t*>(&sh)[tid] = reinterpret_cast<const uint32_t*>(a.st)[tid];
+  __syncthreads();
+  if (sh.halted) return;
+  // the blocks this workgroup owns (the grid has at least as many workgroups as either operand has blocks)
+  const int nA = a.A.nBlocks, nAt = a.At.nBlocks;
+  OwnBlock<CHUNK_A> bA;
+  OwnBlock<CHUNK_AT> bAt;
+  if (lb < nA) bA.load(a.A, a.xcdA ? xcdContiguousBlock(lb, nA) : lb, true, a.v.rhs);
+  if (lb < nAt) bAt.load(a.At, a.xcdAt ? xcdContiguousBlock(lb, nAt) : lb, false, nullptr);
+  if (LOCAL) {
+    // the placement check: XCC ids of all workers (words behind the arrival words and the timeout flag)
+    unsigned long long* ids = a.bar + G + 8;
+    if (tid == 0) __hip_atomic_store(ids + lb, (unsigned long long)xccId() + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    arrive<false>(a.bar, lb, G, 4ull * (unsigned long long)sh.nTrials + 1ull);
+    if (tid == 0) {
+      const unsigned long long mine = __hip_atomic_load(ids + lb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int ok = 1;
+      for (int i = 0; i < G; ++i) ok &= __hip_atomic_load(ids + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mine;
+      placementOk = ok;
+    }
+    __syncthreads();
+    if (!placementOk) {  // nothing has been touched: report, and let the host continue on all XCDs
+      if (lb == 0 && tid == 0) a.st->commError = 2;
+      return;
+    }
+  }
+  unsigned long long tPrev = a.prof ? wall_clock64() : 0ull;
+  auto stamp = [&](int k) {
+    if (a.prof && lb == 0 && tid == 0) { const unsigned long long t = wall_clock64(); a.prof[k] += t - tPrev; tPrev = t; }
+  };
+  for (int trial = 0; trial < a.maxTrials; ++trial) {
+    if (sh.halted) break;
+    const int cur = sh.cur, nxt = cur ^ 1;
+    const double tau = sh.tau, sigma = sh.sigma, avgW = sh.avgW, avgWx = sh.avgWx;
+    const unsigned long long e0 = 4ull * (unsigned long long)sh.nTrials + 1ull;  // (+1: the placement check used 4 nTrials + 1 of the first trial)
+    // ---- P: primal step on a share of the columns ----
+    for (int j = lb * kSpmvThreads + tid; j < a.v.n; j += G * kSpmvThreads) {
+      const double xv = ldM<LOCAL>(a.v.x[cur] + j);
+      if (avgWx != 0.0) stM<LOCAL>(a.v.xSum + j, ldM<LOCAL>(a.v.xSum + j) + avgWx * xv);  // deferred PDHG_Update_Average (step.c:437)
+      double t = xv;
+      t += (-tau) * a.v.cost[j];
+      t += tau * ldM<LOCAL>(a.v.aty[cur] + j);
+      if (a.v.qdiag) t = t / (1.0 + tau * a.v.qdiag[j]);
+      const double u = a.v.upper[j], l = a.v.lower[j];
+      t = t < u ? t : u;
+      t = t > l ? t : l;
+      stM<LOCAL>(a.v.x[nxt] + j, t);
+    }
+    stamp(0);
+    arrive<LOCAL>(a.bar, lb, G, e0 + 1);
+    stamp(1);
+    // ---- A: A x+ and the dual step ----
+    if (bA.have) {
+      double acc0 = 0.0, acc1 = 0.0;
+      smallSpmvBlock<CHUNK_A, true, LOCAL>(a, a.A, bA, cur, sigma, avgW, prod, acc0, acc1);
+      const double t = blockSum<kSpmvThreads>(acc0, scratch[0]);
+      if (tid == 0) stM<LOCAL>(a.partDY + bA.slot_, t);
+    }
+    stamp(2);
+    arrive<LOCAL>(a.bar, lb, G, e0 + 2);
+    stamp(3);
+    // ---- T: A'y+ with the movement / interaction partials ----
+    if (bAt.have) {
+      double acc0 = 0.0, acc1 = 0.0;
+      smallSpmvBlock<CHUNK_AT, false, LOCAL>(a, a.At, bAt, cur, sigma, avgW, prod, acc0, acc1);
+      const double t0 = blockSum<kSpmvThreads>(acc0, scratch[0]);
+      const double t1 = blockSum<kSpmvThreads>(acc1, scratch[1]);
+      if (tid == 0) { stM<LOCAL>(a.partDX + bAt.slot_, t0); stM<LOCAL>(a.partInter + bAt.slot_, t1); }
+    }
+    stamp(4);
+    arrive<LOCAL>(a.bar, lb, G, e0 + 3);
+    stamp(5);
+    // ---- D: the decision, identical in every workgroup ----
+    double dY2, dX2, inter;
+    trialSumsT<true>(a.partDY, nA, a.partDX, a.partInter, nAt, tscr, dY2, dX2, inter);
+    if (tid == 0) {
+      decideUpdate<true>(&sh, dX2, dY2, inter);
+      if (__hip_atomic_load(a.bar + G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { sh.commError = 1; sh.halted = 1; }
+    }
+    __syncthreads();
+    stamp(6);
+    if (a.prof && lb == 0 && tid == 0) a.prof[7] += 1;
+  }
+  if (lb == 0 && tid < (int)(sizeof(DevState) / 4)) reinterpret_cast<uint32_t*>(a.st)[tid] = reinterpret_cast<const uint32_t*>(&sh)[tid];
+}
+
+using SmallKernel = void (*)(const SmallArgs);
+SmallKernel pick(int chunkA, int chunkAt, bool local) {
+  if (chunkA == kChunkSmall && chunkAt == kChunkSmall)
+    return local ? k_trials_small<kChunkSmall, kChunkSmall, true> : k_trials_small<kChunkSmall, kChunkSmall, false>;
+  return nullptr;
+}
+
+}  // namespace
+
+// Workgroups the persistent launch would use (0: this pair of operands does not qualify) and how many the device
+// keeps resident at once.
+int smallTrialsGrid(const MatView& A, const MatView& At, int32_t n, int device, int* residentOut) {
+  *residentOut = 0;
+  if (A.useSlab || At.useSlab || A.lng.nTasks > 0 || At.lng.nTasks > 0) return 0;
+  SmallKernel k = pick(A.csr.chunk, At.csr.chunk, false);
+  if (!k || A.csr.nBlocks <= 0 || At.csr.nBlocks <= 0) return 0;
+  int perCu = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k, kSpmvThreads, 0) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
+  // (blocks of >= 82 SGPRs: the hardware admits fewer per CU than the occupancy query says — MI355X_MICROARCH.md; stay far below)
+  *residentOut = (perCu < 4 ? perCu : 4) * cus;
+  int g = A.csr.nBlocks > At.csr.nBlocks ? A.csr.nBlocks : At.csr.nBlocks;
+  const int gv = (n + kSpmvThreads - 1) / kSpmvThreads;
+  if (gv > g) g = gv < 64 ? gv : (g > 64 ? g : 64);  // the primal step alone never asks for more than 64 workgroups
+  return g;
+}
+
+void launchSmallTrials(const MatView& A, const MatView& At, const IterVecs& v, DevState* st, double* partDY, double* partDX,
+                       double* partInter, unsigned long long* bar, int32_t grid, int32_t maxTrials, bool xcdLocal, hipStream_t s) {
+  SmallArgs a{};
+  a.A = A.csr; a.At = At.csr; a.v = v; a.st = st; a.partDY = partDY; a.partDX = partDX; a.partInter = partInter; a.bar = bar;
+  a.xcdA = A.xcdMap; a.xcdAt = At.xcdMap; a.maxTrials = maxTrials;
+  static unsigned long long* prof = [] {  // PDLP_MI355X_SMALL_PROF=1: per-phase ticks, printed at exit (development)
+    unsigned long long* p = nullptr;
+    if (getenv("PDLP_MI355X_SMALL_PROF") && hipMalloc((void**)&p, 64) == hipSuccess) {
+      (void)hipMemset(p, 0, 64);
+      static unsigned long long* keep = p;
+      atexit([] {
+        unsigned long long h[8];
+        if (hipMemcpy(h, keep, 64, hipMemcpyDeviceToHost) == hipSuccess && h[7])
+          fprintf(stderr, "small-LP phases, us per trial over %llu trials: P %.2f | bar %.2f | A %.2f | bar %.2f | T %.2f | bar %.2f | D %.2f\n", h[7],
+                  h[0] * 0.01 / h[7], h[1] * 0.01 / h[7], h[2] * 0.01 / h[7], h[3] * 0.01 / h[7], h[4] * 0.01 / h[7], h[5] * 0.01 / h[7], h[6] * 0.01 / h[7]);
+      });
+    }
+    return p;
+  }();
+  a.prof = prof;
+  hipLaunchKernelGGL(pick(A.csr.chunk, At.csr.chunk, xcdLocal), dim3(xcdLocal ? 8 * grid : grid), dim3(kSpmvThreads), 0, s, a);
+}
+
+}  // namespace pdlp

@@ -263,6 +263,7 @@ MatView DeviceMatrix::view() const {
   const int32_t slabBlocks = useSlab ? slab.nBlocks : 0;
   v.csr = SpmvMat{beg.get(), idx.get(), val.get(), blockBeg.get(), nMajor, nBlocks, slabBlocks, chunk};
   v.slab = slab;
+  v.slab.noPace = noPace;
   v.lng = LongMat{idx.get(), val.get(), lTasks.get(), lSegSum.get(), lTicket.get(), longGroup > 1 ? lContrib.get() : nullptr,
                   nLong, nTasks, slabBlocks + nBlocks, longSlots, longGroup};
   v.useSlab = useSlab ? 1 : 0;
@@ -272,31 +273,37 @@ MatView DeviceMatrix::view() const {
 }
 
 void tuneXcdMap(DeviceMatrix& M, const double* in, double* out, hipStream_t s) {
-  if (const char* e = getenv("PDLP_MI355X_XCD_MAP")) {
-    M.xcdMap = atoi(e) != 0;
-    return;
-  }
+  const char* em = getenv("PDLP_MI355X_XCD_MAP");
+  const char* ep = getenv("PDLP_MI355X_SLAB_PACE");  // 1 = barrier per group (random operands), 0 = free-running waves
+  if (em) M.xcdMap = atoi(em) != 0;
+  if (ep) M.noPace = atoi(ep) == 0;
   if (M.nnz < 200000) {  // small operands live in every L2 anyway
-    M.xcdMap = 1;
+    if (!em) M.xcdMap = 1;
     return;
   }
+  if (em && (ep || !M.useSlab)) return;
   hipEvent_t e0, e1;
   PDLP_HIP(hipEventCreate(&e0));
   PDLP_HIP(hipEventCreate(&e1));
   float best = 0.f;
-  int bestMap = 1;
-  for (int map = 0; map < 2; ++map) {
-    M.xcdMap = map;
-    launchSpmvPlain(M.view(), in, out, s);  // warm-up
-    PDLP_HIP(hipEventRecord(e0, s));
-    for (int r = 0; r < 3; ++r) launchSpmvPlain(M.view(), in, out, s);
-    PDLP_HIP(hipEventRecord(e1, s));
-    PDLP_HIP(hipEventSynchronize(e1));
-    float ms = 0.f;
-    PDLP_HIP(hipEventElapsedTime(&ms, e0, e1));
-    if (map == 0 || ms < 0.97f * best) { best = ms; bestMap = map; }  // contiguous only when clearly faster
+  int bestMap = M.xcdMap, bestFree = M.noPace;
+  bool first = true;
+  for (int fr = 0; fr < (M.useSlab && !ep ? 2 : 1); ++fr) {
+    for (int map = 0; map < (em ? 1 : 2); ++map) {
+      if (!em) M.xcdMap = map;
+      if (!ep) M.noPace = fr;
+      launchSpmvPlain(M.view(), in, out, s);  // warm-up
+      PDLP_HIP(hipEventRecord(e0, s));
+      for (int r = 0; r < 3; ++r) launchSpmvPlain(M.view(), in, out, s);
+      PDLP_HIP(hipEventRecord(e1, s));
+      PDLP_HIP(hipEventSynchronize(e1));
+      float ms = 0.f;
+      PDLP_HIP(hipEventElapsedTime(&ms, e0, e1));
+      if (first || ms < 0.97f * best) { best = ms; bestMap = M.xcdMap; bestFree = M.noPace; first = false; }  // a change only when clearly faster
+    }
   }
   M.xcdMap = bestMap;
+  M.noPace = bestFree;
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
 }
@@ -489,11 +496,27 @@ void Solver::construct(const pdlp_problem_t& P, const void* id128) {
     const MatView at = dAt_.view();
     const bool allowed = at.useSlab ? !(fe && atoi(fe) == 0) : (fs && atoi(fs) != 0);
     fused_ = allowed && !hasQoff_ && fusedAtyBlocks(at) > 0 && fusedAtyBlocksResident(at, opt_.device) >= fusedAtyBlocks(at);
+    // Netlib-class LPs (both operands below 2^18 nonzeros, stream layout, no long majors): the whole trial batch is one
+    // persistent launch with grid barriers between the phases (pdlp_small.hip); PDLP_MI355X_PERSISTENT=0 turns it off
+    const char* pe = getenv("PDLP_MI355X_PERSISTENT");
+    int resident = 0;
+    const int g = (pe && atoi(pe) == 0) || hasQoff_ ? 0 : smallTrialsGrid(dA_.view(), at, F_.n, opt_.device, &resident);
+    if (g > 0 && g <= resident) {
+      persistent_ = true;
+      smallGrid_ = g;
+      fused_ = false;
+      const char* xl = getenv("PDLP_MI355X_XCD_LOCAL");
+      // one XCD has 32 CUs: up to one workgroup per CU the XCD-local mode wins (25fv47, 21 workgroups: 17.6 us per
+      // iteration against 19.4 with agent-scope accesses on all XCDs and 20.3 with launches), beyond it the single L2 and
+      // the shared CUs cost more than the memory round trips they save (80bau3b, 48 workgroups: 19.7 / 16.8 / 17.4)
+      xcdLocal_ = g <= 32 && !(xl && atoi(xl) == 0);
+    }
     if (fused_) gridBar_.alloc(gridBarWords(fusedAtyBlocks(at)));
+    if (persistent_) gridBar_.alloc(smallBarWords(smallGrid_));
   }
   reset();
   // the trial-batch graph is part of the setup, not of the first iterations
-  if (useGraph_ && (!sharded_ || meshMode_)) captureGraph();
+  if (useGraph_ && !persistent_ && (!sharded_ || meshMode_)) captureGraph();
   PDLP_HIP(hipStreamSynchronize(stream_));
   setupSeconds_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
@@ -676,8 +699,16 @@ void Solver::syncState() {
   PDLP_HIP(hipMemcpyAsync(hostState_, dst(), sizeof(DevState), hipMemcpyDeviceToHost, stream_));
   PDLP_HIP(hipStreamSynchronize(stream_));
   PDLP_HIP(hipGetLastError());  // a kernel launch that failed since the last stop (bad grid, LDS request, ...) surfaces here
+  if (hostState_->commError == 2 && persistent_ && xcdLocal_) {
+    // the persistent launch found its workers on more than one XCD and touched nothing: agent-scope accesses from now on
+    xcdLocal_ = false;
+    hostState_->commError = 0;
+    PDLP_HIP(hipMemcpyAsync(dst(), hostState_, sizeof(DevState), hipMemcpyHostToDevice, stream_));
+    PDLP_HIP(hipStreamSynchronize(stream_));
+    log(1, "Note: the XCD-local trial loop is not placed on one XCD on this device; continuing with agent-scope accesses\n");
+  }
   if (hostState_->commError)
-    throw std::runtime_error("pdlp_mi355x mesh: a peer did not answer in time (exchange timed out)");
+    throw std::runtime_error("pdlp_mi355x: a grid barrier or a peer did not answer in time (exchange timed out)");
 }
 // (k+1)^-0.3 and (k+1)^-0.6 of the adaptive step rule (cupdlp_step.c:279-284) for the next
 // kPowWindow trial counters, computed with the host's pow so that the device takes exactly the
@@ -833,7 +864,7 @@ void Solver::initVariables() {
 void Solver::reset() {
   DevState& s = *hostState_;
   memset(&s, 0, sizeof(s));
-  if (fused_) gridBar_.zero(stream_);  // arrival epochs follow the trial counter, which starts again
+  if (fused_ || persistent_) gridBar_.zero(stream_);  // arrival epochs follow the trial counter, which starts again
   s.adaptive = adaptive_ ? 1 : 0;
   initStepSizes();
   initVariables();
@@ -895,6 +926,11 @@ void Solver::enqueueTrial() {
     launchMeshPushPartial(buf, F_.n, dst(), mv, stream_);
     launchMeshReduceInteract(vecsCol_, dst(), mv, buf, partDX_.get(), partInter_.get(), nb, stream_);
     launchMeshDecide(dst(), mv, partDY_.get(), dA_.nPartials(), partDX_.get(), partInter_.get(), nb, stream_);
+    return;
+  }
+  if (persistent_) {
+    launchSmallTrials(dA_.view(), dAt_.view(), vecs_, dst(), partDY_.get(), partDX_.get(), partInter_.get(), gridBar_.get(), smallGrid_, 1,
+                      xcdLocal_, stream_);
     return;
   }
   if (!sharded_ && fused_) {
@@ -995,7 +1031,12 @@ void Solver::runUntilHalt() {
     if (remaining > 4 * kCheckInterval) remaining = 4 * kCheckInterval;
     int32_t todo = (int32_t)remaining;
     const int32_t trialsBefore = hostState_->nTrials;
-    if (useGraph_ && !profile_ && (!sharded_ || meshMode_) && todo >= kGraphMinTodo) {
+    if (persistent_ && !profile_) {  // the whole stretch to the next check (plus spare trials for rejections) in one launch
+      launchSmallTrials(dA_.view(), dAt_.view(), vecs_, dst(), partDY_.get(), partDX_.get(), partInter_.get(), gridBar_.get(),
+                        smallGrid_, todo + 8, xcdLocal_, stream_);
+      todo = 0;
+    }
+    if (useGraph_ && !persistent_ && !profile_ && (!sharded_ || meshMode_) && todo >= kGraphMinTodo) {
       if (!graphExec_) captureGraph();
       while (todo >= kGraphMinTodo) {
         if (stPar_ != graphPar_ || (fused_ && needPrimal_)) {  // the graph starts from the state slot it was captured with, after a primal step
@@ -1023,6 +1064,9 @@ void Solver::runUntilHalt() {
       stalledSince_ = hostState_->nTrials;
     }
     if (timeIsUp()) return;
+    // a stretch without check iterations (check_interval beyond the host's 160-iteration rounds): keep the tabulated
+    // powers of the step rule ahead of the trial counter (the fused / persistent kernels take no other)
+    if (hostState_->powRed && hostState_->nTrials + 1024 >= hostState_->powBase + hostState_->powCount) pushState();
   }
 }
 
@@ -1459,7 +1503,7 @@ void Solver::stage(const std::string& name, double* out, int32_t cap) {
     if (meshMode_) mesh_->phaseStats(us, cnt, stream_);
     for (int k = 0; k < 3; ++k) { put(k, us[k]); put(3 + k, cnt[k]); }
   } else if (name == "trial_launches") {  // kernels per trial step of the hot loop (2 = fused decision + primal step)
-    put(0, meshMode_ ? (colblock_ ? 10.0 : 9.0) : sharded_ ? 7.0 : fused_ ? 2.0 : 3.0);
+    put(0, meshMode_ ? (colblock_ ? 10.0 : 9.0) : sharded_ ? 7.0 : persistent_ ? 0.0 : fused_ ? 2.0 : 3.0);  // 0: one persistent launch per batch
   } else if (name == "exchange") {  // 0 = not sharded, 1 = RCCL all-reduce, 2 = direct xGMI mesh (partials), 3 = mesh, two all-gathers
     put(0, !sharded_ ? 0.0 : !meshMode_ ? 1.0 : colblock_ ? 3.0 : 2.0);
   } else if (name == "residuals") {

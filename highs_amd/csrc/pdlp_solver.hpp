@@ -36,6 +36,7 @@ struct DeviceMatrix {
   int32_t chunk = kChunk;           // work-plan block size of the CSR stream (spmvChunkFor)
   int64_t nnz = 0;
   bool useSlab = false;
+  int32_t noPace = 0;  // slab kernel without the per-group block barrier (SlabMat::noPace), see tuneXcdMap
   int32_t xcdMap = 1;  // block -> XCD assignment of the SpMV kernels (pdlp_kernels.hip xcdContiguousBlock), see tuneXcdMap
   SlabMat slab{};
   // mode: 0 = CSR stream only, 1 = slab layout, -1 = auto by nMinor
@@ -178,6 +179,9 @@ class Solver : public SolverBase {
   // does the next primal step.  needPrimal_: the host has pushed a state since the last trial, so the next trial
   // starts with a stand-alone primal step.
   bool fused_ = false, needPrimal_ = true;
+  // Small LPs: a batch of trials is ONE persistent launch (pdlp_small.hip); smallGrid_ = its workgroups
+  bool persistent_ = false, xcdLocal_ = false;
+  int32_t smallGrid_ = 0;
   DeviceArray<unsigned long long> gridBar_;
   int32_t stalledRounds_ = 0, stalledSince_ = 0;  // consecutive device stops without an accepted trial
   DevState* dst() const { return dState_.get() + stPar_; }
