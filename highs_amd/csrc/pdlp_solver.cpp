@@ -88,12 +88,13 @@ void DeviceMatrix::uploadPlans(const std::vector<int32_t>& hostBeg, int32_t nCsr
 // bit-identical, but two block barriers and a dependent chain scalar loads -> tile + entry loads -> LDS per tile cost
 // more than the gathers they replace.  It therefore stays OFF unless PDLP_MI355X_SLAB_STAGE=1 asks for it.
 namespace { constexpr int32_t kStageMaxTiles = 8; }
-bool DeviceMatrix::wantStaging(const std::vector<int32_t>& lo, const std::vector<int32_t>& hi, const std::vector<int32_t>& cnt, int32_t R) {
+bool DeviceMatrix::wantStaging(const std::vector<int32_t>& lo, const std::vector<int32_t>& hi, const std::vector<int32_t>& cnt, int32_t R,
+                               bool* local) {
+  if (local) *local = false;
   const size_t lds = (size_t)R * 8 + kSlabThreads * 8 + 2 * 16 * 8 + ((size_t)8 << kSlabTileLog2) + 64;
-  if (lds > 160 * 1024) return false;
   int force = -1;
   if (const char* e = getenv("PDLP_MI355X_SLAB_STAGE")) force = atoi(e);
-  if (force == 0) return false;
+  if (lds > 160 * 1024) force = 0;
   // blocks worth staging: at most kStageMaxTiles tiles, at least one gather per 8 staged elements; the operand is staged
   // when they hold most of its entries (the others stream the plain way inside the same launch)
   int64_t good = 0, all = 0;
@@ -103,7 +104,7 @@ bool DeviceMatrix::wantStaging(const std::vector<int32_t>& lo, const std::vector
     all += cnt[b];
     if (t <= kStageMaxTiles && (int64_t)cnt[b] * 8 >= t * ((int64_t)1 << kSlabTileLog2)) good += cnt[b];
   }
-  (void)good;
+  if (local) *local = all > 0 && good * 5 >= all * 4;
   return all > 0 && force == 1;
 }
 
@@ -179,8 +180,9 @@ void DeviceMatrix::upload(const Compressed& cIn, int32_t nMajor_, int32_t nMinor
       if (p1 <= p0 || p1 - p0 > kSlabLongLimit) continue;
       lo[r / R] = std::min(lo[r / R], cIn.idx[p0]); hi[r / R] = std::max(hi[r / R], cIn.idx[p1 - 1]); cnt[r / R] += p1 - p0;
     }
-    stage = wantStaging(lo, hi, cnt, R);
-    buildSlabLayout(cIn, nMajor_, nMinor_, kSlabLongLimit, stage ? kSlabTileLog2 : slabWidthLog2(), L);
+    bool local = false;
+    stage = wantStaging(lo, hi, cnt, R, &local);
+    buildSlabLayout(cIn, nMajor_, nMinor_, kSlabLongLimit, stage || (local && !getenv("PDLP_MI355X_SLAB_W")) ? kSlabTileLog2 : slabWidthLog2(), L);
     if (L.rowsPerBlock > kSlabMaxRows) throw std::runtime_error("slab layout: too many majors per block");
     wavePtr.alloc(L.wavePtr.size());
     wavePtr.upload(L.wavePtr.data(), L.wavePtr.size(), s);
@@ -216,7 +218,7 @@ void DeviceMatrix::buildFromDevice(DeviceCsrData& M, int mode, hipStream_t s) {
   useSlab = chooseSlab(mode, M.nMajor, M.nMinor);
   std::vector<int32_t> hostBeg, hostLongMap;
   int32_t nCsrMajor = nMajor;
-  bool stage = false;
+  bool stage = false, localM = false;
   const int32_t nMinorM = M.nMinor;
   if (useSlab) {
     const int32_t R = slabRowsPerWave(M.nMajor, M.nMinor) * 16, nB = (M.nMajor + R - 1) / R;
@@ -228,10 +230,12 @@ void DeviceMatrix::buildFromDevice(DeviceCsrData& M, int mode, hipStream_t s) {
       launchBlockSpan(M.beg.get(), M.idx.get(), M.nMajor, R, kSlabLongLimit, dLo.get(), dHi.get(), dCn.get(), s);
       dLo.download(lo.data(), nB, s); dHi.download(hi.data(), nB, s); dCn.download(cnt.data(), nB, s);
       PDLP_HIP(hipStreamSynchronize(s));
-      stage = wantStaging(lo, hi, cnt, R);
+      stage = wantStaging(lo, hi, cnt, R, &localM);
     }
     DeviceSlabLayout L;
-    gpuBuildSlabLayout(M, kSlabLongLimit, stage ? kSlabTileLog2 : slabWidthLog2(), s, L);
+    // (an operand whose blocks touch few 16384-entry tiles of the gathered vector densely gets slabs of that width: its
+    // runs of equal majors are shorter, more lanes add in parallel — bench.py --config c, A x: 44.0 -> 41.1 us)
+    gpuBuildSlabLayout(M, kSlabLongLimit, stage || (localM && !getenv("PDLP_MI355X_SLAB_W")) ? kSlabTileLog2 : slabWidthLog2(), s, L);
     if (L.rowsPerBlock > kSlabMaxRows) throw std::runtime_error("slab layout: too many majors per block");
     wavePtr = std::move(L.wavePtr);
     ent = std::move(L.ent);

@@ -49,7 +49,8 @@ struct DeviceMatrix {
  private:
   void uploadPlans(const std::vector<int32_t>& hostBeg, int32_t nCsrMajor, const int32_t* longVecIndex, hipStream_t s);
   // should the operand be staged through LDS (per-block span / entry count of its short majors)? -> slab width to build with
-  static bool wantStaging(const std::vector<int32_t>& lo, const std::vector<int32_t>& hi, const std::vector<int32_t>& cnt, int32_t R);
+  static bool wantStaging(const std::vector<int32_t>& lo, const std::vector<int32_t>& hi, const std::vector<int32_t>& cnt, int32_t R,
+                          bool* local);  // *local: blocks touch few tiles of the gathered vector densely
   void buildTileTables(int32_t nMinor, hipStream_t s);
 };
 
