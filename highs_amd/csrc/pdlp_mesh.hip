@@ -31,15 +31,11 @@
 #include "pdlp_devfn.hpp"
 #include "pdlp_device.hpp"
 
-// The direct exchange maps peer arenas through HIP IPC, which on dmabuf-only hosts needs HSA_ENABLE_IPC_MODE_LEGACY=0
-// when the HSA runtime starts.  Loading this library before the process's first HIP call is the common case (HiGHS
-// links it, python loads it before touching the GPU), so default the variable here without overriding the caller's.
-namespace {
-struct IpcModeDefault {
-  IpcModeDefault() { setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0); }
-} g_ipcModeDefault;
-}  // namespace
-
+// The direct exchange maps the arenas of ranks in OTHER processes through HIP IPC, which on dmabuf-only hosts needs
+// HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment when the HSA runtime starts.  That is the LAUNCHER's business (bench.py
+// and the test launchers set it; the hipIpcGetMemHandle error message names it): a library must not change the
+// environment of the process that loads it.  Ranks inside one process (pdlp_mi355x_solve with num_devices > 1, what
+// Highs::run() reaches) map each other through peer access and need nothing.
 namespace pdlp {
 
 namespace {

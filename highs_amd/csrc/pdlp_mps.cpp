@@ -17,6 +17,8 @@
 #include <cstring>
 #include <limits>
 #include <new>
+#include <exception>
+#include <mutex>
 #include <thread>
 #include <unordered_map>
 
@@ -100,14 +102,32 @@ inline const char* alignToLine(const char* lo, const char* hi, const char* pos) 
   return q ? (const char*)q + 1 : hi;
 }
 
+// An exception inside a worker (bad_alloc from a table, a Fail from the parser) must not reach std::terminate — the
+// host process is HiGHS: the first one is kept, every thread is joined, then it is thrown again on the calling thread.
 template <class Fn>
 void parallelFor(int T, Fn&& fn) {
   if (T <= 1) { fn(0); return; }
+  std::exception_ptr first;
+  std::mutex mu;
+  auto guarded = [&](int t) {
+    try {
+      fn(t);
+    } catch (...) {
+      std::lock_guard<std::mutex> lock(mu);
+      if (!first) first = std::current_exception();
+    }
+  };
   std::vector<std::thread> th;
   th.reserve((size_t)T - 1);
-  for (int t = 1; t < T; ++t) th.emplace_back([&fn, t] { fn(t); });
-  fn(0);
+  try {
+    for (int t = 1; t < T; ++t) th.emplace_back(guarded, t);
+  } catch (...) {  // (thread creation failed: run what is left on this thread)
+    std::lock_guard<std::mutex> lock(mu);
+    if (!first) first = std::current_exception();
+  }
+  guarded(0);
   for (auto& x : th) x.join();
+  if (first) std::rethrow_exception(first);
 }
 // Zero-filled array for the randomly accessed tables (name slots, per-thread row stamps): anonymous mapping with
 // transparent huge pages requested, so that a lookup in a 64 MB table does not also miss the TLB.

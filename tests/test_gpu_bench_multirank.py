@@ -46,11 +46,11 @@ def test_bench_rccl_exchange_when_two_devices_are_visible():
     ctypes.CDLL("libamdhip64.so").hipGetDeviceCount(ctypes.byref(n))
     if n.value < 2:
         pytest.skip("one GPU visible: RCCL needs one device per rank")
-    for ex in ("rccl", ""):
+    for k, ex in enumerate(("rccl", "")):
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
         if ex:
             env["PDLP_MI355X_EXCHANGE"] = ex
-        port = 29900 + os.getpid() % 90
+        port = 29900 + os.getpid() % 45 + 45 * k  # (a port of its own per launch)
         cmd = ["timeout", "400", sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2",
                "--config", "a", "--steps", "400", "--warmup", "80"]

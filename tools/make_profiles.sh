@@ -11,7 +11,7 @@
 #   test logs       : pytest -m gpu (includes the drop-in tests: reference CLI, Catch2 cases, C API client)
 set -u
 R=$(cd "$(dirname "$0")/.." && pwd)
-RND=${1:-r02}
+RND=${1:-r03}
 if [ "${2:-}" = "collect" ]; then
   S=$R/gpurun_out/profiles_$RND
   cp $S/r*.json $S/r*.csv $S/r*.log $R/profiles/ 2>/dev/null
@@ -27,11 +27,13 @@ python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${RND}_bench_1M_driver_fla
 python bench.py --config a > $OUT/${RND}_bench_100k.json 2>> $OUT/bench_1M.err
 python bench.py --config c > $OUT/${RND}_bench_structured.json 2>> $OUT/bench_1M.err
 python bench.py --config qp > $OUT/${RND}_bench_qp.json 2>> $OUT/bench_1M.err
+python bench.py --config qpn > $OUT/${RND}_bench_qp_sparse_hessian.json 2>> $OUT/bench_1M.err
 python bench.py --solver hipdlp > $OUT/${RND}_bench_hipdlp_1M.json 2>> $OUT/bench_1M.err
 python tools/solve_times.py > $OUT/${RND}_small_lp_times.log 2>&1
 ( cd /tmp; export TMPDIR=/tmp
   rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- python $R/bench.py --steps 2000 --warmup 200 --cpu-iters 0 > /dev/null 2>&1
   cp $OUT/trace/t_kernel_stats.csv $OUT/${RND}_bench_1M_kernel_stats.csv
+  cp $OUT/trace/t_kernel_trace.csv $OUT/kernel_trace_1M.csv 2>/dev/null
   rocprofv3 --kernel-trace --stats -d $OUT/trace_h -o t --output-format csv -- python $R/bench.py --solver hipdlp --cpu-iters 0 > /dev/null 2>&1
   cp $OUT/trace_h/t_kernel_stats.csv $OUT/${RND}_bench_hipdlp_1M_kernel_stats.csv
   for SOLVER in pdlp hipdlp; do for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
@@ -43,10 +45,11 @@ import csv, collections, glob, json, re
 agg = collections.defaultdict(list)
 for f in glob.glob("$OUT/pmc_*/p_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        m = re.search(r"k_spmv_slab<(\d)>", r["Kernel_Name"])
+        m = re.search(r"k_spmv_slab<(\d)", r["Kernel_Name"])
         if m:
             agg[(int(m.group(1)), r["Counter_Name"])].append(float(r["Counter_Value"]))
-names = {1: "spmv_ax_dual", 2: "spmv_aty_interact", 4: "spmv_aty_halpern_primal", 5: "spmv_ax_halpern_dual"}
+names = {1: "spmv_ax_dual", 2: "spmv_aty_interact", 4: "spmv_aty_halpern_primal", 5: "spmv_ax_halpern_dual",
+         6: "spmv_aty_interact_decide_primal"}
 raw, traffic = {}, {}
 for (k, c), v in sorted(agg.items()):
     if k in names:
@@ -60,6 +63,25 @@ json.dump({"b": traffic, "raw_per_launch_means": raw,
                    "FETCH_SIZE counts coalesced streams at half their size (MI355X_MICROARCH.md), so it is doubled."},
           open("$OUT/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(traffic, indent=1))
+# per-kernel averages over WORKING launches only: launches queued after the device halted return at once (a few hundred ns)
+# and must not dilute the averages rocprofv3 --stats prints
+try:
+    rows = list(csv.DictReader(open("$OUT/kernel_trace_1M.csv")))
+    per = collections.defaultdict(list)
+    for r in rows:
+        per[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    out = {}
+    for k, v in per.items():
+        if "pdlp" not in k or len(v) < 20:
+            continue
+        v.sort()
+        med = v[len(v) // 2]
+        w = [x for x in v if x >= 0.2 * med]
+        short = re.sub(r"pdlp::\(anonymous namespace\)::", "", k)[:80]
+        out[short] = {"launches": len(v), "working_launches": len(w), "avg_ns_all": sum(v) / len(v), "avg_ns_working": sum(w) / len(w)}
+    json.dump(out, open("$OUT/${RND}_bench_1M_kernel_stats_working_launches.json", "w"), indent=1)
+except Exception as e:
+    print("kernel trace post-processing skipped:", e)
 PY
 # host-side ingest on this box and the end-to-end run through the reference CLI (both need integration/_build)
 if [ -e $R/integration/_build/libhighs.so.1 ]; then
