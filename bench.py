@@ -335,6 +335,13 @@ def main():
         b_aty = b_aty + 8 * 9 * n + (8 * n if cfg.get("qp") else 0)
     dom_name, dom_ms, dom_bytes = ("spmv_ax_dual", k_ax, b_ax) if k_ax >= k_aty else (
         "spmv_aty_interact_decide_primal" if fused else "spmv_aty_interact", k_aty, b_aty)
+    persistent = args.solver == "pdlp" and world == 1 and int(S.stage("trial_launches")[0]) == 0
+    if persistent:
+        # the whole trial batch is ONE launch (pdlp_small.hip): there is no per-SpMV launch to time in the loop; the
+        # launch's algorithmic bytes per trial are the iteration's, its duration per trial the loop's (check iterations
+        # included, so this understates the kernel a little).  k_ax / k_aty below are the stand-alone SpMV kernels
+        # re-launched in isolation — what the 3-launch loop would run.
+        dom_name, dom_ms, dom_bytes = "trials_persistent(per trial)", ms_step * st.iters / max(int(st.trials), 1), b_iter
     if world > 1:  # each rank streams 1/world of the matrix
         dom_bytes = dom_bytes / world
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9

@@ -232,16 +232,20 @@ void launchSpmvAtyFusedPrimal(const MatView& At, const IterVecs& v, const DevSta
                               unsigned long long* bar, hipStream_t s);
 
 // ---- small LPs: a batch of trials as ONE persistent launch (pdlp_small.hip) -------------------------------------
-// Both operands in the stream layout with 512-entry work blocks, no long majors.  smallTrialsGrid: workgroups of the
-// launch (0: does not qualify) and, in *resident, how many the device holds at once (the grid barrier needs all of
-// them resident).  bar: gridBarWords(grid) zeroed words.  The launch runs at most maxTrials trials and stops early
-// when the device halts; the state record is read from and written back to *st.  xcdLocal: only every eighth of
+// Both operands in the stream layout, no long majors.  smallTrialsGrid: workgroups of the launch (0: does not
+// qualify) and, in *resident, how many the device holds at once (the grid barrier needs all of them resident).
+// bar: smallBarWords(grid) zeroed words.  The launch runs at most maxTrials trials and stops early when the device
+// halts; the state record is read from and written back to *st.  mode 0: agent-scope accesses on all XCDs, every
+// workgroup sweeps the arrival words (512-entry blocks only).  mode 1 (512-entry blocks only): only every eighth of
 // 8 * grid workgroups works (one XCD, one coherent L2: no agent-scope traffic); the launch checks that placement and,
-// if it does not hold, changes nothing and sets commError = 2 in *st — the caller then goes on with xcdLocal = false.
+// if it does not hold, changes nothing and sets commError = 2 in *st — the caller then goes on with another mode.
+// mode 2: all XCDs, XCD-hierarchical barrier (pdlp_devfn.hpp hierBarrier) — what hundreds of workgroups need.
 int smallTrialsGrid(const MatView& A, const MatView& At, int32_t n, int device, int* resident);
 void launchSmallTrials(const MatView& A, const MatView& At, const IterVecs& v, DevState* st, double* partDY, double* partDX,
-                       double* partInter, unsigned long long* bar, int32_t grid, int32_t maxTrials, bool xcdLocal, hipStream_t s);
-inline size_t smallBarWords(int grid) { return 2 * (size_t)grid + 16; }  // arrival words, timeout flag, XCC ids of the placement check
+                       double* partInter, unsigned long long* bar, int32_t grid, int32_t maxTrials, int mode, hipStream_t s);
+constexpr int kSmallHierWords = 4 * 16 * 32;  // the XCD-hierarchical barrier's words (pdlp_devfn.hpp HierBar)
+// arrival words, timeout flag, XCC ids of the placement check; behind them (256-byte aligned) the hierarchical barrier's words
+inline size_t smallBarWords(int grid) { return ((2 * (size_t)grid + 16 + 31) / 32) * 32 + kSmallHierWords; }
 
 // ---- check-iteration kernels (host knows the parity here) -------------------
 void launchFlushAverage(const IterVecs& v, DevState* st, hipStream_t s);

@@ -57,16 +57,18 @@ __device__ __forceinline__ void arrive(unsigned long long* bar, int lb, int nBlo
   if (threadIdx.x < kWave) gridBarrier<LOCAL>(bar, lb, nBlocks, epoch, (int)threadIdx.x);
   __syncthreads();
 }
+// the same through the XCD-hierarchical barrier (k-th barrier of the launch)
+__device__ __forceinline__ void arriveHier(const HierBar& h, unsigned long long k) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x < kWave) hierBarrier(h, k, (int)threadIdx.x);
+  __syncthreads();
+}
 // accesses to the vectors that change during the launch: agent scope on all XCDs, or L2-coherent on one XCD
 template <bool LOCAL>
 __device__ __forceinline__ double ldM(const double* p) { return LOCAL ? ldStream(p) : ldAgent(p); }
 template <bool LOCAL>
 __device__ __forceinline__ void stM(double* p, double v) { if (LOCAL) *p = v; else stAgent(p, v); }
-__device__ __forceinline__ int xccId() {
-  int id;
-  asm volatile("s_getreg_b32 %0, hwreg(20, 0, 4)" : "=s"(id));  // HW_REG_XCC_ID[3:0]
-  return id;
-}
 
 // The work block a workgroup owns in one operand, loaded ONCE per launch: a persistent workgroup runs the same
 // block of A and of A' in every trial, and the matrix never changes — entries, values and the bookkeeping of the
@@ -179,14 +181,18 @@ __device__ __forceinline__ void smallSpmvBlock(const SmallArgs& a, const SpmvMat
   }
 }
 
-template <int CHUNK_A, int CHUNK_AT, bool LOCAL>
+// MODE 0: agent-scope accesses, sweep barrier; 1: XCD-local; 2: agent-scope accesses, XCD-hierarchical barrier
+template <int CHUNK_A, int CHUNK_AT, int MODE>
 __global__ __launch_bounds__(kSpmvThreads) void k_trials_small(const SmallArgs a) {
+  constexpr bool LOCAL = MODE == 1;
   constexpr int kMaxChunk = CHUNK_A > CHUNK_AT ? CHUNK_A : CHUNK_AT;
   __shared__ double prod[kMaxChunk + kMaxChunk / 8 + 8];
   __shared__ double scratch[2][kSpmvThreads / kWave];
   __shared__ double tscr[4][kVecThreads / kWave];
   __shared__ DevState sh;
   __shared__ int placementOk;
+  __shared__ int hierN;
+  __shared__ uint32_t hierActive;
   const int tid = threadIdx.x;
   if (LOCAL && (blockIdx.x & 7) != 0) return;  // XCD-local: every eighth workgroup works
   const int lb = LOCAL ? (int)blockIdx.x >> 3 : (int)blockIdx.x;      // logical workgroup
@@ -217,6 +223,29 @@ __global__ __launch_bounds__(kSpmvThreads) void k_trials_small(const SmallArgs a
       return;
     }
   }
+  HierBar hb{};
+  unsigned long long kbar = 0;
+  if (MODE == 2) {
+    // registration: how many workgroups sit on which XCD (the barrier words were zeroed by the host before this launch)
+    hb.base = a.bar + ((2 * G + 16 + kXccStride - 1) / kXccStride) * kXccStride;
+    hb.flag = a.bar + G;
+    hb.xcc = xccId();
+    if (tid == 0) __hip_atomic_fetch_add(hb.reg(hb.xcc), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    arrive<false>(a.bar, lb, G, 1ull);
+    if (tid < kWave) {
+      const unsigned long long c = tid < kXccSlots ? __hip_atomic_load(hb.reg(tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+      const unsigned long long act = __ballot(c > 0);
+      const unsigned long long mine = __shfl(c, hb.xcc);
+      if (tid == 0) { hierN = (int)mine; hierActive = (uint32_t)act; }
+    }
+    __syncthreads();
+    hb.nLocal = hierN;
+    hb.active = hierActive;
+  }
+  auto meet = [&](unsigned long long epoch) {
+    if (MODE == 2) arriveHier(hb, ++kbar);
+    else arrive<LOCAL>(a.bar, lb, G, epoch);
+  };
   unsigned long long tPrev = a.prof ? wall_clock64() : 0ull;
   auto stamp = [&](int k) {
     if (a.prof && lb == 0 && tid == 0) { const unsigned long long t = wall_clock64(); a.prof[k] += t - tPrev; tPrev = t; }
@@ -240,7 +269,7 @@ __global__ __launch_bounds__(kSpmvThreads) void k_trials_small(const SmallArgs a
       stM<LOCAL>(a.v.x[nxt] + j, t);
     }
     stamp(0);
-    arrive<LOCAL>(a.bar, lb, G, e0 + 1);
+    meet(e0 + 1);
     stamp(1);
     // ---- A: A x+ and the dual step ----
     if (bA.have) {
@@ -250,7 +279,7 @@ __global__ __launch_bounds__(kSpmvThreads) void k_trials_small(const SmallArgs a
       if (tid == 0) stM<LOCAL>(a.partDY + bA.slot_, t);
     }
     stamp(2);
-    arrive<LOCAL>(a.bar, lb, G, e0 + 2);
+    meet(e0 + 2);
     stamp(3);
     // ---- T: A'y+ with the movement / interaction partials ----
     if (bAt.have) {
@@ -261,7 +290,7 @@ __global__ __launch_bounds__(kSpmvThreads) void k_trials_small(const SmallArgs a
       if (tid == 0) { stM<LOCAL>(a.partDX + bAt.slot_, t0); stM<LOCAL>(a.partInter + bAt.slot_, t1); }
     }
     stamp(4);
-    arrive<LOCAL>(a.bar, lb, G, e0 + 3);
+    meet(e0 + 3);
     stamp(5);
     // ---- D: the decision, identical in every workgroup ----
     double dY2, dX2, inter;
@@ -278,9 +307,15 @@ __global__ __launch_bounds__(kSpmvThreads) void k_trials_small(const SmallArgs a
 }
 
 using SmallKernel = void (*)(const SmallArgs);
-SmallKernel pick(int chunkA, int chunkAt, bool local) {
+SmallKernel pick(int chunkA, int chunkAt, int mode) {
   if (chunkA == kChunkSmall && chunkAt == kChunkSmall)
-    return local ? k_trials_small<kChunkSmall, kChunkSmall, true> : k_trials_small<kChunkSmall, kChunkSmall, false>;
+    return mode == 1 ? k_trials_small<kChunkSmall, kChunkSmall, 1> : mode == 2 ? k_trials_small<kChunkSmall, kChunkSmall, 2>
+                                                                               : k_trials_small<kChunkSmall, kChunkSmall, 0>;
+  // mid-size operands (2048-entry blocks): hundreds of workgroups, always the hierarchical barrier
+  if (mode != 2) return nullptr;
+  if (chunkA == kChunk && chunkAt == kChunk) return k_trials_small<kChunk, kChunk, 2>;
+  if (chunkA == kChunk && chunkAt == kChunkSmall) return k_trials_small<kChunk, kChunkSmall, 2>;
+  if (chunkA == kChunkSmall && chunkAt == kChunk) return k_trials_small<kChunkSmall, kChunk, 2>;
   return nullptr;
 }
 
@@ -291,7 +326,7 @@ SmallKernel pick(int chunkA, int chunkAt, bool local) {
 int smallTrialsGrid(const MatView& A, const MatView& At, int32_t n, int device, int* residentOut) {
   *residentOut = 0;
   if (A.useSlab || At.useSlab || A.lng.nTasks > 0 || At.lng.nTasks > 0) return 0;
-  SmallKernel k = pick(A.csr.chunk, At.csr.chunk, false);
+  SmallKernel k = pick(A.csr.chunk, At.csr.chunk, 2);
   if (!k || A.csr.nBlocks <= 0 || At.csr.nBlocks <= 0) return 0;
   int perCu = 0, cus = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k, kSpmvThreads, 0) != hipSuccess) return 0;
@@ -305,7 +340,10 @@ int smallTrialsGrid(const MatView& A, const MatView& At, int32_t n, int device, 
 }
 
 void launchSmallTrials(const MatView& A, const MatView& At, const IterVecs& v, DevState* st, double* partDY, double* partDX,
-                       double* partInter, unsigned long long* bar, int32_t grid, int32_t maxTrials, bool xcdLocal, hipStream_t s) {
+                       double* partInter, unsigned long long* bar, int32_t grid, int32_t maxTrials, int mode, hipStream_t s) {
+  const bool xcdLocal = mode == 1;
+  static_assert(kHierBarWords == kSmallHierWords, "barrier buffer layout");
+  if (mode == 2) (void)hipMemsetAsync(bar, 0, smallBarWords(grid) * sizeof(unsigned long long), s);  // launch-local barrier counters
   SmallArgs a{};
   a.A = A.csr; a.At = At.csr; a.v = v; a.st = st; a.partDY = partDY; a.partDX = partDX; a.partInter = partInter; a.bar = bar;
   a.xcdA = A.xcdMap; a.xcdAt = At.xcdMap; a.maxTrials = maxTrials;
@@ -324,7 +362,7 @@ void launchSmallTrials(const MatView& A, const MatView& At, const IterVecs& v, D
     return p;
   }();
   a.prof = prof;
-  hipLaunchKernelGGL(pick(A.csr.chunk, At.csr.chunk, xcdLocal), dim3(xcdLocal ? 8 * grid : grid), dim3(kSpmvThreads), 0, s, a);
+  hipLaunchKernelGGL(pick(A.csr.chunk, At.csr.chunk, mode), dim3(xcdLocal ? 8 * grid : grid), dim3(kSpmvThreads), 0, s, a);
 }
 
 }  // namespace pdlp

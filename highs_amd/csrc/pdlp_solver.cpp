@@ -514,6 +514,11 @@ void Solver::construct(const pdlp_problem_t& P, const void* id128) {
       // iteration against 19.4 with agent-scope accesses on all XCDs and 20.3 with launches), beyond it the single L2 and
       // the shared CUs cost more than the memory round trips they save (80bau3b, 48 workgroups: 19.7 / 16.8 / 17.4)
       xcdLocal_ = g <= 32 && !(xl && atoi(xl) == 0);
+      // beyond a few dozen workgroups the all-poll-all barrier is what a trial waits for (490 workgroups: 4.8 us per
+      // barrier): meet per XCD in its L2 first (PDLP_MI355X_HIER_BARRIER=0/1 forces either)
+      const char* hbEnv = getenv("PDLP_MI355X_HIER_BARRIER");
+      const bool smallChunks = dA_.view().csr.chunk == kChunkSmall && at.csr.chunk == kChunkSmall;
+      hierBar_ = !smallChunks || (hbEnv ? atoi(hbEnv) != 0 : g > 64);
     }
     if (fused_) gridBar_.alloc(gridBarWords(fusedAtyBlocks(at)));
     if (persistent_) gridBar_.alloc(smallBarWords(smallGrid_));
@@ -934,7 +939,7 @@ void Solver::enqueueTrial() {
   }
   if (persistent_) {
     launchSmallTrials(dA_.view(), dAt_.view(), vecs_, dst(), partDY_.get(), partDX_.get(), partInter_.get(), gridBar_.get(), smallGrid_, 1,
-                      xcdLocal_, stream_);
+                      smallMode(), stream_);
     return;
   }
   if (!sharded_ && fused_) {
@@ -1037,7 +1042,7 @@ void Solver::runUntilHalt() {
     const int32_t trialsBefore = hostState_->nTrials;
     if (persistent_ && !profile_) {  // the whole stretch to the next check (plus spare trials for rejections) in one launch
       launchSmallTrials(dA_.view(), dAt_.view(), vecs_, dst(), partDY_.get(), partDX_.get(), partInter_.get(), gridBar_.get(),
-                        smallGrid_, todo + 8, xcdLocal_, stream_);
+                        smallGrid_, todo + 8, smallMode(), stream_);
       todo = 0;
     }
     if (useGraph_ && !persistent_ && !profile_ && (!sharded_ || meshMode_) && todo >= kGraphMinTodo) {

@@ -181,7 +181,8 @@ class Solver : public SolverBase {
   // starts with a stand-alone primal step.
   bool fused_ = false, needPrimal_ = true;
   // Small LPs: a batch of trials is ONE persistent launch (pdlp_small.hip); smallGrid_ = its workgroups
-  bool persistent_ = false, xcdLocal_ = false;
+  bool persistent_ = false, xcdLocal_ = false, hierBar_ = false;
+  int smallMode() const { return xcdLocal_ ? 1 : hierBar_ ? 2 : 0; }
   int32_t smallGrid_ = 0;
   DeviceArray<unsigned long long> gridBar_;
   int32_t stalledRounds_ = 0, stalledSince_ = 0;  // consecutive device stops without an accepted trial
