@@ -51,6 +51,58 @@ __device__ __forceinline__ double blockSum(double v, double* scratch /* [NT/64] 
 // off a single bank pair.
 __device__ __forceinline__ int slot(int q) { return q + (q >> 3); }
 
+// Sum of the products q = qb .. qe-1 of one major in the padded LDS strip, left to right (the reference's order).
+// The adds are a dependent chain (25fv47 has a major of 340 entries), so nothing but the adds may sit in the loop.
+// Eight products occupy nine consecutive slots, one of which is a pad slot (slot(q) = q + q / 8) that holds -0.0 —
+// adding it changes no sum (x + -0.0 == x for every x) — so the nine reads use immediate offsets from ONE address that
+// advances by 72 bytes: no per-element index arithmetic (which cost more than the adds: phase A of the small-LP
+// loop 6.3 -> 3.9 us on 25fv47).  The reads of the next window are issued before the current one is added.  The
+// caller has filled the pad slots (padSlots) before the products were written.
+__device__ __forceinline__ void padSlots(double* prod, int nSlots, int tid, int nThreads) {
+  for (int i = 8 + 9 * tid; i < nSlots; i += 9 * nThreads) prod[i] = -0.0;
+}
+__device__ __forceinline__ double majorSum(const double* prod, int qb, int qe) {
+  double s = 0.0;
+  int q = qb;
+  if (q + 8 <= qe) {
+    const double* w = prod + slot(q);
+    double t[9], u[9];
+    auto load = [&](double (&d)[9], const double* p) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) d[k] = p[k];
+    };
+    auto add = [&](const double (&d)[9]) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) s += d[k];
+    };
+    load(t, w);
+    q += 8;
+    w += 9;
+    while (q + 16 <= qe) {  // two windows per turn: no register rotation; the scheduler must not sink the reads to their uses
+      load(u, w);
+      __builtin_amdgcn_sched_barrier(0);
+      add(t);
+      __builtin_amdgcn_sched_barrier(0);
+      load(t, w + 9);
+      __builtin_amdgcn_sched_barrier(0);
+      add(u);
+      q += 16;
+      w += 18;
+    }
+    if (q + 8 <= qe) {
+      load(u, w);
+      __builtin_amdgcn_sched_barrier(0);
+      add(t);
+      add(u);
+      q += 8;
+    } else {
+      add(t);
+    }
+  }
+  for (; q < qe; ++q) s += prod[slot(q)];
+  return s;
+}
+
 // Fixed-order sum of `count` partials by one block of 256 threads (4 loads in flight per lane).
 __device__ __attribute__((unused)) double reducePartials(const double* __restrict__ p, int count, double* scratch) {
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;

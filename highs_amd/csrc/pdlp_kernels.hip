@@ -286,6 +286,7 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
   const int blk = a.xcdMap ? xcdContiguousBlock(blockIdx.x, a.A.nBlocks) : (int)blockIdx.x;
   const int4 bb = *reinterpret_cast<const int4*>(a.A.blockBeg + 4 * blk);  // (first major, end major, first entry, end entry)
   const int r0 = bb.x, r1 = bb.y, p0 = bb.z, p1 = bb.w;
+  padSlots(prod, CHUNK + CHUNK / 8 + 8, tid, kSpmvThreads);  // the pad slots of the strip: -0.0 (majorSum adds them)
   const int32_t* __restrict__ idx = a.A.idx;
   const double* __restrict__ val = a.A.val;
   const double* __restrict__ in = epi.input();
@@ -334,28 +335,7 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
         qe = a.A.beg[r + 1] - p0;
         pre = epi.prefetch(vecIndex(r));
       }
-      double s = 0.0;
-      int q = qb;
-      // left to right (the reference's order): the adds are a dependent chain, so the LDS reads of the NEXT
-      // eight products are issued before the current eight are added (long majors: 25fv47 has one of 340)
-      if (q + 8 <= qe) {
-        double t[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t[k] = prod[slot(q + k)];
-        q += 8;
-        for (; q + 8 <= qe; q += 8) {
-          double u[8];
-#pragma unroll
-          for (int k = 0; k < 8; ++k) u[k] = prod[slot(q + k)];
-#pragma unroll
-          for (int k = 0; k < 8; ++k) s += t[k];
-#pragma unroll
-          for (int k = 0; k < 8; ++k) t[k] = u[k];
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s += t[k];
-      }
-      for (; q < qe; ++q) s += prod[slot(q)];
+      const double s = majorSum(prod, qb, qe);
       epi.apply(vecIndex(r), s, pre);
       if (EPI == kAtyFused && r == rFirst) { keepX = pre.b; keepS = s; }
     }

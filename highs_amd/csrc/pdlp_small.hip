@@ -137,50 +137,7 @@ __device__ __forceinline__ void smallSpmvBlock(const SmallArgs& a, const SpmvMat
       qe = M.beg[r + 1] - p0;
       pre = prefetch(r, false);
     }
-    double s = 0.0;
-    int q = qb;
-    // left to right (the reference's order): the adds are a dependent chain (25fv47 has a major of 340 entries), so
-    // nothing but the adds may sit in the loop.  Eight products occupy nine consecutive LDS slots, one of which is a
-    // pad slot (slot(q) = q + q / 8) holding -0.0: adding it changes no sum (x + -0.0 == x for every x), and the nine
-    // reads use immediate offsets from ONE address that advances by 72 bytes — no per-element index arithmetic
-    // (which cost more than the adds).  The reads of the NEXT window are issued before the
-    // current one is added.
-    if (q + 8 <= qe) {
-      const double* w = prod + slot(q);
-      double t[9], u[9];
-      auto load = [&](double (&d)[9], const double* p) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) d[k] = p[k];
-      };
-      auto add = [&](const double (&d)[9]) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) s += d[k];
-      };
-      load(t, w);
-      q += 8;
-      w += 9;
-      while (q + 16 <= qe) {  // two windows per turn: no register rotation; the scheduler must not sink the reads to their uses
-        load(u, w);
-        __builtin_amdgcn_sched_barrier(0);
-        add(t);
-        __builtin_amdgcn_sched_barrier(0);
-        load(t, w + 9);
-        __builtin_amdgcn_sched_barrier(0);
-        add(u);
-        q += 16;
-        w += 18;
-      }
-      if (q + 8 <= qe) {
-        load(u, w);
-        __builtin_amdgcn_sched_barrier(0);
-        add(t);
-        add(u);
-        q += 8;
-      } else {
-        add(t);
-      }
-    }
-    for (; q < qe; ++q) s += prod[slot(q)];
+    const double s = majorSum(prod, qb, qe);
     if (DUAL) {
       const double yv = pre.a;
       if (avgW != 0.0) stM<LOCAL>(a.v.ySum + r, ldM<LOCAL>(a.v.ySum + r) + avgW * yv);  // deferred PDHG_Update_Average (step.c:438)
@@ -220,7 +177,7 @@ __global__ __launch_bounds__(kSpmvThreads) void k_trials_small(const SmallArgs a
   const int lb = LOCAL ? (int)blockIdx.x >> 3 : (int)blockIdx.x;      // logical workgroup
   const int G = LOCAL ? (int)gridDim.x >> 3 : (int)gridDim.x;
   if (tid < (int)(sizeof(DevState) / 4)) reinterpret_cast<uint32_t*>(&sh)[tid] = reinterpret_cast<const uint32_t*>(a.st)[tid];
-  for (int i = 8 + 9 * tid; i < kMaxChunk + kMaxChunk / 8 + 8; i += 9 * kSpmvThreads) prod[i] = -0.0;  // the pad slots (never written again)
+  padSlots(prod, kMaxChunk + kMaxChunk / 8 + 8, tid, kSpmvThreads);  // (never written again)
   __syncthreads();
   if (sh.halted) return;
   // the blocks this workgroup owns (the grid has at least as many workgroups as either operand has blocks)
