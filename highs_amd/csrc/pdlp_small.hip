@@ -16,6 +16,9 @@
 // is an agent-scope relaxed atomic (global_load/store sc1: write-through, L1-bypassing); a workgroup's stores have
 // landed (s_waitcnt vmcnt(0) in every wave, then the block barrier) before its arrival word is written.  Matrix,
 // plans, costs, bounds and right-hand sides never change: ordinary loads.
+//   (Measured alternative for the gathers: ordinary cached loads behind an agent-scope acquire — buffer_inv sc1 — after
+// every barrier.  The invalidate empties the XCD's L2 for EVERYTHING, three times per trial: phase A 5.8 -> 8.9 us,
+// the decision 3.3 -> 6.2 us at 100k x 100k.  The per-access agent-scope loads stay.)
 //   XCD-LOCAL mode (the default): only every eighth workgroup of the launch works — under the dispatch order observed
 // on this part those share ONE XCD, i.e. one coherent L2 — and then ordinary stores (the L1 is write-through) with
 // non-temporal loads (served by the L2, never by a stale L1 line) are coherent without a trip to memory: a dependent
