@@ -524,6 +524,44 @@ def test_lds_staged_slab_layout_bit_identical(monkeypatch):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("name,iters", [("25fv47", 400), ("80bau3b", 400), ("synthetic", 240)])
+def test_trial_loop_variants_give_the_same_bits(name, iters, monkeypatch):
+    """The trial loop exists as separate launches and as ONE persistent launch (pdlp_small.hip) — on one XCD, on all
+    XCDs with every workgroup sweeping the arrival words, on all XCDs with the XCD-hierarchical barrier; mid-size LPs
+    (2048-entry work blocks, hundreds of workgroups) only take the last.  Work blocks, lanes and sums are the same in
+    all of them: iterates, step sizes and trial counts after a few hundred iterations (several check iterations and
+    restarts among them) must agree bit for bit."""
+    sp_ = None
+    if name == "synthetic":
+        sp_ = solver.SyntheticProblem(40000, 35000, 400000, 9)  # above 2^18 nonzeros: ~200 work blocks of 2048 entries per operand
+        kw = dict(problem_struct=sp_.struct)
+    else:
+        kw = dict(lp=_lp(name))
+    variants = {"launches": {"PDLP_MI355X_PERSISTENT": "0"},
+                "persistent": {},
+                "all-xcds-sweep": {"PDLP_MI355X_XCD_LOCAL": "0", "PDLP_MI355X_HIER_BARRIER": "0"},
+                "all-xcds-hierarchical": {"PDLP_MI355X_XCD_LOCAL": "0", "PDLP_MI355X_HIER_BARRIER": "1"}}
+    out = {}
+    for vname, env in variants.items():
+        for k in ("PDLP_MI355X_PERSISTENT", "PDLP_MI355X_XCD_LOCAL", "PDLP_MI355X_HIER_BARRIER"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        S = solver.DeviceSolver(**kw)
+        st = S.iterate(iters)
+        launches = int(S.stage("trial_launches")[0])
+        out[vname] = (S.get("x", S.n), S.get("y", S.m), S.get("steps", 8), int(st.trials), int(st.iters), launches)
+        S.close()
+    if sp_ is not None:
+        sp_.close()
+    assert out["launches"][5] in (2, 3) and out["persistent"][5] == 0 and out["all-xcds-hierarchical"][5] == 0
+    ref = out["launches"]
+    for vname, o in out.items():
+        for a, b in zip(ref[:3], o[:3]):
+            assert np.array_equal(a, b), vname
+        assert ref[3:5] == o[3:5], vname
+
+
 def test_concurrent_solver_contexts_on_two_threads():
     """SURVEY §8b threading contract: several Highs instances may call the path concurrently from different
     threads, so a context holds no process-global mutable state.  Two threads solve different LPs (both
