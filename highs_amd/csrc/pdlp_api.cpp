@@ -333,12 +333,16 @@ int64_t pdlp_mi355x_sizeof(int32_t which) {
 
 // MPS ingest (pdlp_mps.cpp).  The arrays of *out are malloc'ed copies owned by the caller's struct.
 int pdlp_mi355x_read_mps(const char* path, int32_t num_threads, pdlp_mps_model_t* out) {
+  return pdlp_mi355x_read_mps_timed(path, num_threads, 0.0, out);
+}
+
+int pdlp_mi355x_read_mps_timed(const char* path, int32_t num_threads, double time_limit, pdlp_mps_model_t* out) {
   int status = 1;
   const int rc = guarded([&] {
     if (!path || !out) throw std::runtime_error("read_mps: NULL argument");
     memset(out, 0, sizeof(*out));
     pdlp::mps::Model M;
-    status = pdlp::mps::readMps(path, num_threads, M);
+    status = pdlp::mps::readMps(path, num_threads, M, time_limit);
     if (status != pdlp::mps::kReadOk) {
       g_lastError = M.error;
       return;

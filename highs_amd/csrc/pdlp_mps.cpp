@@ -543,7 +543,7 @@ int gunzip(const char* in, size_t inBytes, std::vector<char>& out) {
 // on the worker threads never throw, they flag their records instead.
 class Reader {
  public:
-  Reader(Model& model, int threads) : M(model), numThreads(threads) {}
+  Reader(Model& model, int threads, double timeLimit) : M(model), numThreads(threads), timeLimit_(timeLimit) {}
   ReadStatus run(const std::string& path);
 
  private:
@@ -611,12 +611,16 @@ class Reader {
   std::vector<QEntry> qEntries;
 
  public:
+  double timeLimit_ = 0.0;
   ~Reader() { if (map_) ::munmap(map_, mapBytes_); }
 };
 
 void Reader::phase(const char* what) {
-  if (!timing) return;
   const auto now = std::chrono::steady_clock::now();
+  // the reference checks its clock line by line (HMpsFF::timeout); the phases here take a fraction of a second each
+  if (timeLimit_ > 0.0 && std::isfinite(timeLimit_) && std::chrono::duration<double>(now - t0).count() > timeLimit_)
+    throw Fail{kReadTimeout, "time limit reached while reading the file"};
+  if (!timing) return;
   std::fprintf(stderr, "[mps] %-28s %8.1f ms\n", what, 1e3 * std::chrono::duration<double>(now - lastT).count());
   lastT = now;
 }
@@ -1325,8 +1329,8 @@ void Reader::finish() {
 }  // namespace
 
 // ==================================================================================================================
-ReadStatus readMps(const std::string& path, int numThreads, Model& M) {
-  Reader reader(M, numThreads);
+ReadStatus readMps(const std::string& path, int numThreads, Model& M, double timeLimit) {
+  Reader reader(M, numThreads, timeLimit);
   return reader.run(path);
 }
 

@@ -23,6 +23,7 @@ enum ReadStatus : int32_t {
   kReadNotFound = 2,      // cannot open / map the file
   kReadFixedFormat = 3,   // names with spaces: a fixed-column reader is needed (FreeFormatParserReturnCode::kFixedFormat)
   kReadCompressed = 4,    // gzip stream and no zlib on this system (the reader inflates gzip files itself when it finds libz)
+  kReadTimeout = 5,       // the time limit passed between two phases of the read (FreeFormatParserReturnCode::kTimeout)
 };
 
 // HighsVarType (lp_data/HConst.h)
@@ -55,7 +56,8 @@ struct Model {
 };
 
 // numThreads <= 0: one per hardware thread (at least 1 MB of file each, at most 64); > 0: exactly that many pieces.
-ReadStatus readMps(const std::string& path, int numThreads, Model& out);
+// timeLimit <= 0 or infinite: none (HMpsFF::timeout(), io/HMpsFF.cpp:218-220: checked between the phases here, line by line there)
+ReadStatus readMps(const std::string& path, int numThreads, Model& out, double timeLimit = 0.0);
 
 // Lower triangle (column-wise, rows ascending, duplicates summed, (q_ij + q_ji)/2 for a square input) of the
 // parser's Hessian — what normaliseHessian (model/HighsHessianUtils.cpp:320) leaves and what pdlp_problem_t wants.

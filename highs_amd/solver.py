@@ -40,7 +40,7 @@ EXPORTS = [
     "pdlp_mi355x_free_problem", "pdlp_mi355x_last_error", "pdlp_mi355x_abi_version",
     "pdlp_mi355x_host_prepare", "pdlp_mi355x_free_prepared", "pdlp_mi355x_row_partition", "pdlp_mi355x_sizeof",
     "pdlp_mi355x_host_slab_layout", "pdlp_mi355x_free_slab_layout",
-    "pdlp_mi355x_read_mps", "pdlp_mi355x_free_mps_model",
+    "pdlp_mi355x_read_mps", "pdlp_mi355x_read_mps_timed", "pdlp_mi355x_free_mps_model",
 ]
 
 
@@ -91,6 +91,7 @@ def lib():
         L.pdlp_mi355x_free_slab_layout.restype = None
         pMps = C.POINTER(abi.PdlpMpsModel)
         L.pdlp_mi355x_read_mps.argtypes = [C.c_char_p, C.c_int32, pMps]
+        L.pdlp_mi355x_read_mps_timed.argtypes = [C.c_char_p, C.c_int32, C.c_double, pMps]
         L.pdlp_mi355x_free_mps_model.argtypes = [pMps]
         L.pdlp_mi355x_free_mps_model.restype = None
         L.pdlp_mi355x_sizeof.argtypes = [C.c_int32]
@@ -110,17 +111,24 @@ class MpsFixedFormat(RuntimeError):
     """The file has names with spaces: a fixed-column reader is needed (return code 3 of pdlp_mi355x_read_mps)."""
 
 
-def read_mps(path, threads=0):
+class MpsTimeout(RuntimeError):
+    """options.time_limit passed while the file was read (return code 5: FilereaderRetcode::kTimeout)."""
+
+
+def read_mps(path, threads=0, time_limit=0.0):
     """Highs::readModel for an MPS file through the library's multi-threaded reader (csrc/pdlp_mps.cpp; the
     reference: io/FilereaderMps.cpp:24-58 -> io/HMpsFF.cpp).  Returns (HighsLp, info); info carries what HighsLp
-    has no field for: integrality, names, objective name, cost row location, warnings, threads, seconds."""
+    has no field for: integrality, names, objective name, cost row location, warnings, threads, seconds.
+    time_limit: HMpsFF::time_limit_ (seconds; <= 0: none)."""
     M = abi.PdlpMpsModel()
     L = lib()
-    rc = L.pdlp_mi355x_read_mps(os.fsencode(path), int(threads), C.byref(M))
+    rc = L.pdlp_mi355x_read_mps_timed(os.fsencode(path), int(threads), float(time_limit), C.byref(M))
     if rc == 2:
         raise FileNotFoundError(L.pdlp_mi355x_last_error().decode())
     if rc == 3:
         raise MpsFixedFormat(L.pdlp_mi355x_last_error().decode())
+    if rc == 5:
+        raise MpsTimeout(L.pdlp_mi355x_last_error().decode())
     _check(rc, "pdlp_mi355x_read_mps")
     try:
         P = M.lp

@@ -348,6 +348,10 @@ typedef struct pdlp_mps_model {
 } pdlp_mps_model_t;
 /* num_threads <= 0: one per hardware thread (at least 1 MB of file each, at most 64); > 0: exactly that many. */
 int pdlp_mi355x_read_mps(const char* path, int32_t num_threads, pdlp_mps_model_t* out);
+/* The same with HMpsFF::time_limit_ (io/FilereaderMps.cpp:30-31, io/HMpsFF.cpp:218-220): seconds from the start of
+   the call, checked between the phases of the read; <= 0 or infinite: none.  Returns 5 when it has passed
+   (FreeFormatParserReturnCode::kTimeout -> FilereaderRetcode::kTimeout). */
+int pdlp_mi355x_read_mps_timed(const char* path, int32_t num_threads, double time_limit, pdlp_mps_model_t* out);
 void pdlp_mi355x_free_mps_model(pdlp_mps_model_t* out);
 
 /* sizeof() of the ABI structs: 0 problem, 1 params, 2 result, 3 iter_stats, 4 prepared, 5 slab_layout, 6 mps_model */

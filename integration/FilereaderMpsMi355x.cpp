@@ -93,7 +93,8 @@ FilereaderRetcode FilereaderMps::readModelFromFile(const HighsOptions& options, 
                                                    HighsModel& model) {
   if (options.mps_parser_type_free) {
     pdlp_mps_model_t m;
-    const int rc = pdlp_mi355x_read_mps(filename.c_str(), options.threads, &m);  // threads = 0: automatic
+    const double limit = options.time_limit < kHighsInf && options.time_limit > 0 ? options.time_limit : 0.0;  // io/FilereaderMps.cpp:30-31
+    const int rc = pdlp_mi355x_read_mps_timed(filename.c_str(), options.threads, limit, &m);  // threads = 0: automatic
     if (rc == 0) {
       logWarnings(options.log_options, m.warnings);
       fillModel(m, model);
@@ -107,7 +108,23 @@ FilereaderRetcode FilereaderMps::readModelFromFile(const HighsOptions& options, 
       highsLogUser(options.log_options, HighsLogType::kError, "%s\n", pdlp_mi355x_last_error());
       return FilereaderRetcode::kParserError;
     }
-    // 3: names with spaces (the fixed-column format); 4: a gzip stream and no libz for the library -> the reference's TU
+    if (rc == 5) {
+      highsLogUser(options.log_options, HighsLogType::kWarning,
+                   "Free format reader reached time_limit while parsing the input file\n");
+      return FilereaderRetcode::kTimeout;
+    }
+    if (rc == 3) {
+      // names with spaces: the reference's free-format reader would find the same and hand over to the fixed-column
+      // reader (io/FilereaderMps.cpp:45-49) — go there directly instead of parsing the file a second time
+      highsLogUser(options.log_options, HighsLogType::kWarning,
+                   "Free format reader has detected row/col names with spaces: switching to fixed format parser\n");
+      HighsOptions fixed = options;
+      fixed.mps_parser_type_free = false;
+      const FilereaderRetcode rcFixed = FilereaderMpsReference().readModelFromFile(fixed, filename, model);
+      // (the reference marks the read as one that issued a warning in this case)
+      return rcFixed == FilereaderRetcode::kOk ? FilereaderRetcode::kWarning : rcFixed;
+    }
+    // 4: a gzip stream and no libz for the library -> the reference's TU
   }
   return FilereaderMpsReference().readModelFromFile(options, filename, model);
 }

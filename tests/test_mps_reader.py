@@ -188,6 +188,20 @@ def test_reader_errors(tmp_path):
         solver.read_mps(str(p))
 
 
+def test_reader_time_limit(tmp_path):
+    """HMpsFF::time_limit_ (io/FilereaderMps.cpp:30-31, HMpsFF::timeout :218-220): a limit that has already passed
+    when the first phase ends gives return code 5 (FilereaderRetcode::kTimeout in the drop-in's reader TU), a
+    generous one and 'none' (<= 0, infinite) read the file."""
+    mps = str(tmp_path / "a.mps")
+    lp = L.HighsLp.from_npz(os.path.join(GOLD, "instances", "25fv47.npz"))
+    L.write_mps(lp, mps)
+    with pytest.raises(solver.MpsTimeout):
+        solver.read_mps(mps, time_limit=1e-9)
+    for limit in (0.0, -1.0, float("inf"), 3600.0):
+        got, _ = solver.read_mps(mps, time_limit=limit)
+        assert got.num_col == lp.num_col and got.num_row == lp.num_row
+
+
 # ---- the reader behind Highs::readModel (integration/FilereaderMpsMi355x.cpp in the drop-in libhighs) ------------------
 ROOT = os.path.dirname(HERE)
 BUILD = os.path.join(ROOT, "integration", "_build")
@@ -288,3 +302,24 @@ def test_reference_cli_reads_a_gzip_file_through_the_reader(tmp_path):
     txt = out.stdout + out.stderr
     assert out.returncode == 0 and "Optimal" in txt, txt[-1500:]
     assert abs(float(re.search(r"Objective value\s*:\s*(\S+)", txt)[1]) - ref) <= 1e-6 * (1 + abs(ref))
+
+
+@needs_build
+def test_reference_cli_names_with_spaces_go_to_the_fixed_format_reader_once(tmp_path):
+    """A fixed-column file whose names contain spaces: the drop-in's reader TU sees return code 3 and calls the
+    reference's fixed-format reader directly (one warning, as the reference prints it: io/FilereaderMps.cpp:45-49);
+    a time limit that has passed is reported the reference's way."""
+    import subprocess
+    mps = tmp_path / "sp.mps"
+    # fields at the fixed columns 2-3, 5-12, 15-22, 25-36 (io/HMPSIO.cpp)
+    mps.write_text("NAME          spaces\nROWS\n N  obj\n G  my row\nCOLUMNS\n"
+                   "    col one   obj                1.0   my row             1.0\n"
+                   "    col two   obj                2.0   my row             1.0\n"
+                   "RHS\n    rhs       my row             1.0\nENDATA\n")
+    out = subprocess.run([os.path.join(BUILD, "highs_ref_cli"), "--solver=simplex", str(mps)], capture_output=True, text=True,
+                         timeout=300, env=_dropin_env(), cwd=str(tmp_path))
+    txt = out.stdout + out.stderr
+    assert out.returncode == 0 and "Optimal" in txt, txt[-1500:]
+    assert txt.count("switching to fixed format parser") == 1, txt[-1500:]
+    import re
+    assert abs(float(re.search(r"Objective value\s*:\s*(\S+)", txt)[1]) - 1.0) < 1e-9
