@@ -286,9 +286,14 @@ def test_instances_match_reference_cpu_pdlp(name):
     # sensitive to the summation order: 80bau3b took 289 600 iterations with 2048-entry SpMV blocks and 93 360
     # with 512-entry ones (reference CPU: 374 520), hence the wide band
     assert 0.2 * g["cupdlp"]["num_iter"] <= out.pdlp_iteration_count <= 5 * g["cupdlp"]["num_iter"]
+    assert out.pdlp_iteration_count == GPU_PINS[name]["pdlp_iteration_count"]  # exact: the device's sums have a fixed order
 
 
 MORE = json.load(open(os.path.join(GOLD, "reference_pdlp_more.json")))
+# The GPU path's own iteration counts (tools/make_gpu_iteration_pins.py, run on an MI355X): every sum on the device has
+# a fixed order, so they are reproducible exactly — a different count means a summation order or a decision changed.
+# Regenerate the file then, and say in the commit which change moved them.
+GPU_PINS = json.load(open(os.path.join(GOLD, "gpu_iteration_counts.json")))
 
 
 @pytest.mark.parametrize("name", sorted(MORE))
@@ -317,6 +322,7 @@ def test_more_instances_match_reference_cpu_pdlp(name):
         assert out.model_status == solver.kUnboundedOrInfeasible
         assert g["highs"]["model_status"] == "Primal infeasible or unbounded"
     assert 0.2 * g["cupdlp"]["num_iter"] <= out.pdlp_iteration_count <= max(5 * g["cupdlp"]["num_iter"], 40)
+    assert out.pdlp_iteration_count == GPU_PINS[name]["pdlp_iteration_count"]
 
 
 SYNTH = json.load(open(os.path.join(GOLD, "reference_synth.json"))) if os.path.exists(os.path.join(GOLD, "reference_synth.json")) else {}
@@ -633,4 +639,5 @@ def test_nan_in_the_data_ends_in_an_error_not_an_endless_step_size_search():
     lp.col_cost = lp.col_cost.copy()
     lp.col_cost[3] = float("nan")
     out = solver.solveLpCupdlp(lp, pdlp_iteration_limit=100000, time_limit=60.0)
-    assert out.status == solver.kError or out.model_status != solver.kOptimal
+    # the library reports the search that cannot end (RETCODE != OK -> HighsStatus::kError + kSolveError, CupdlpWrapper.cpp:225-251)
+    assert out.status == solver.kError and out.model_status == solver.kSolveError
