@@ -1,4 +1,5 @@
-// pdlp_small.hip — the PDHG trial loop of SMALL LPs (Netlib class) as ONE persistent launch.
+// pdlp_small.hip — the PDHG trial loop of SMALL and MID-SIZE LPs (every work block of both operands resident at once)
+// as ONE persistent launch.
 //
 // Below ~10^5 nonzeros a trial step is latency, not bandwidth: three dependent launches of ~6 us each, of which
 // ~2 us is the kernel boundary and the rest a chain of three or four dependent memory round trips.  Here a batch
@@ -7,8 +8,9 @@
 //     A  A x+ with the dual step and the (dy)^2 partials                       cupdlp_step.c:43-69
 //     T  A'y+ with the (dx)^2 and dx.d(A'y) partials                           cupdlp_linalg.c:772-801
 //     D  accept / reject and the step-size update, in EVERY workgroup          cupdlp_step.c:215-310
-// are separated by grid barriers (one arrival word per workgroup, a sweep by one wave: pdlp_devfn.hpp gridBarrier)
-// instead of kernel boundaries.  Work blocks, lane assignments and reduction trees are EXACTLY those of k_spmv /
+// are separated by grid barriers instead of kernel boundaries — one arrival word per workgroup and a sweep by one wave
+// (pdlp_devfn.hpp gridBarrier) for a few dozen workgroups; per XCD first, then between the XCDs (hierBarrier) for the
+// hundreds of workgroups of a mid-size LP (100k x 100k / 1M nonzeros: 490), where the sweep costs 4.8 us per barrier.  Work blocks, lane assignments and reduction trees are EXACTLY those of k_spmv /
 // k_decide_primal (pdlp_kernels.hip), so iterates and decisions are bit-identical to the 3-launch loop and the
 // oracle's device-order mode follows them unchanged.
 //   Visibility inside a launch: per-CU L1s are never refreshed by other CUs' stores and the eight XCD L2s are not
