@@ -203,3 +203,109 @@ def test_mesh_exchange_pattern_matches_unsharded_oracle(world):
     assert len(ret) == world and all(v[0] for v in ret.values())
     sl = sorted((v[1], v[2]) for v in ret.values())
     assert sl[0][0] == 0 and all(sl[i][1] == sl[i + 1][0] for i in range(world - 1))
+
+
+def _colblock_worker(rank, world, port, ret):
+    """The DEFAULT mesh layout of round 3 (pdlp_solver.cpp colblock_): rank g owns the row block [r0,r1) for A x and the
+    column block [c0,c1) of the WHOLE matrix for A'y.  A trial = primal step on the own columns, all-gather of x+, dual
+    step on the own rows, all-gather of y+, A'y+ of the own columns over ALL rows (every column summed as one GPU sums
+    it: rows ascending — no partial sums, no reduce-scatter), three scalars added in rank order.  Same data and same
+    acceptance as the unsharded oracle; here A'y+ must agree with it to the last bit."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sp_ = solver.SyntheticProblem(3000, 2500, 24000, 11)
+        lp = sp_.to_lp()
+        P = solver.Prepared(problem_struct=sp_.struct)
+        n, m = P.n, P.m
+        off = P.row_partition(world)
+        r0, r1 = int(off[rank]), int(off[rank + 1])
+        col = [n * h // world for h in range(world + 1)]
+        c0, c1 = col[rank], col[rank + 1]
+        rng = np.random.default_rng(3)
+        x = np.clip(rng.standard_normal(n), P.lower, P.upper)
+        y = rng.standard_normal(m)
+        y[P.n_eqs:] = np.maximum(y[P.n_eqs:], 0)
+        tau, sigma, beta = 0.31, 0.23, 0.23 / 0.31
+
+        def all_gather_blocks(mine, bounds, total):  # every rank contributes its block of a vector
+            pad = np.zeros(total); pad[bounds[rank]:bounds[rank + 1]] = mine
+            t = torch.from_numpy(pad)
+            outs = [torch.zeros(total, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(outs, t)
+            full = np.zeros(total)
+            for h in range(world):
+                full[bounds[h]:bounds[h + 1]] = outs[h].numpy()[bounds[h]:bounds[h + 1]]
+            return full
+
+        def rows_times(v):  # (A v) on the own rows, entries left to right (the oracle's order)
+            out = np.zeros(r1 - r0)
+            for i in range(r0, r1):
+                s = 0.0
+                for p in range(P.csr_beg[i], P.csr_beg[i + 1]):
+                    s += P.csr_val[p] * v[P.csr_idx[p]]
+                out[i - r0] = s
+            return out
+
+        def cols_times(w):  # (A' w) on the own columns over ALL rows, rows ascending
+            out = np.zeros(c1 - c0)
+            for j in range(c0, c1):
+                s = 0.0
+                for p in range(P.csc_beg[j], P.csc_beg[j + 1]):
+                    s += P.csc_val[p] * w[P.csc_idx[p]]
+                out[j - c0] = s
+            return out
+
+        ax_g = rows_times(x)
+        aty_c = cols_times(y)
+        # 1. primal step on the own columns, all-gather of x+
+        v = x[c0:c1].copy(); v += (-tau) * P.cost[c0:c1]; v += tau * aty_c
+        v = np.where(v < P.upper[c0:c1], v, P.upper[c0:c1]); v = np.where(v > P.lower[c0:c1], v, P.lower[c0:c1])
+        xU = all_gather_blocks(v, col, n)
+        # 2. dual step on the own rows, all-gather of y+
+        axU_g = rows_times(xU)
+        yg = y[r0:r1]
+        w = yg.copy(); w += sigma * P.rhs[r0:r1]; w += (-2.0 * sigma) * axU_g; w += sigma * ax_g
+        ineq = (np.arange(r0, r1) >= P.n_eqs)
+        yU_g = np.where(ineq, np.where(w > 0, w, 0.0), w)
+        yU = all_gather_blocks(yU_g, [int(o) for o in off], m)
+        # 3. A'y+ of the own columns from the column block, partials on the own rows / columns
+        atyU_c = cols_times(yU)
+        dx = x[c0:c1] - xU[c0:c1]
+        mine = np.array([float(np.sum(dx * dx)), float(np.sum((yg - yU_g) ** 2)), float(np.sum(dx * (aty_c - atyU_c)))])
+        t = torch.from_numpy(mine.copy())
+        outs = [torch.zeros(3, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(outs, t)
+        tot = np.zeros(3)
+        for o in outs:
+            tot = tot + o.numpy()
+        # unsharded oracle on the assembled vectors
+        ax = all_gather_blocks(ax_g, [int(o) for o in off], m)
+        aty = all_gather_blocks(aty_c, col, n)
+        Ph = abi.ProblemHandle(lp)
+        F = O.Formulated()
+        prm = abi.default_params()
+        assert O.oracle().pdlp_oracle_formulate_scale(C.byref(Ph.struct), C.byref(prm), C.byref(F)) == 0
+        xo, yo, axo, atyo, o3 = np.zeros(n), np.zeros(m), np.zeros(m), np.zeros(n), np.zeros(3)
+        d = lambda a: np.ascontiguousarray(a).ctypes.data_as(abi.c_f64p)
+        xc, yc, axc, atyc = map(np.ascontiguousarray, (x, y, ax, aty))
+        O.oracle().pdlp_oracle_trial_step(C.byref(F), tau, sigma, d(xc), d(yc), d(axc), d(atyc), d(xo), d(yo), d(axo), d(atyo), d(o3))
+        O.oracle().pdlp_oracle_free_formulated(C.byref(F))
+        ok = (np.array_equal(xU, xo) and np.array_equal(yU, yo) and np.array_equal(axU_g, axo[r0:r1])
+              and np.array_equal(atyU_c, atyo[c0:c1]) and np.allclose(tot, o3, rtol=1e-10))
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_all_gathers_layout_matches_unsharded_oracle_bit_for_bit(world):
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 33500 + (os.getpid() % 2000) + world
+    mp.spawn(_colblock_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert len(ret) == world and all(ret.values())
