@@ -235,15 +235,41 @@ __global__ __launch_bounds__(kSpmvThreads) void k_trials_small(const SmallArgs a
   auto stamp = [&](int k) {
     if (a.prof && lb == 0 && tid == 0) { const unsigned long long t = wall_clock64(); a.prof[k] += t - tPrev; tPrev = t; }
   };
+  // The primal step of this thread's FIRST column: what no decision changes (cost, bounds, diagonal of Q) stays in
+  // registers for the whole launch, and what the decision selects between — both parities of x and A'y, the running
+  // sum — is fetched BEFORE the decision is computed (the values exist once the third barrier of the previous trial
+  // has passed), so that the step behind the decision is arithmetic and one store.  Same operations, same order.
+  const int j0 = lb * kSpmvThreads + tid;
+  const bool own0 = j0 < a.v.n;
+  const int jc = own0 ? j0 : 0;
+  const double c0 = a.v.cost[jc], u0 = a.v.upper[jc], l0 = a.v.lower[jc], q0 = a.v.qdiag ? a.v.qdiag[jc] : 0.0;
+  double px[2], pa[2], pxs;
+  auto prefetchPrimal = [&]() {
+    px[0] = ldM<LOCAL>(a.v.x[0] + jc); px[1] = ldM<LOCAL>(a.v.x[1] + jc);
+    pa[0] = ldM<LOCAL>(a.v.aty[0] + jc); pa[1] = ldM<LOCAL>(a.v.aty[1] + jc);
+    pxs = ldM<LOCAL>(a.v.xSum + jc);
+  };
+  prefetchPrimal();
   for (int trial = 0; trial < a.maxTrials; ++trial) {
     if (sh.halted) break;
     const int cur = sh.cur, nxt = cur ^ 1;
     const double tau = sh.tau, sigma = sh.sigma, avgW = sh.avgW, avgWx = sh.avgWx;
     const unsigned long long e0 = 4ull * (unsigned long long)sh.nTrials + 1ull;  // (+1: the placement check used 4 nTrials + 1 of the first trial)
     // ---- P: primal step on a share of the columns ----
-    for (int j = lb * kSpmvThreads + tid; j < a.v.n; j += G * kSpmvThreads) {
+    if (own0) {
+      const double xv = cur ? px[1] : px[0];
+      if (avgWx != 0.0) stM<LOCAL>(a.v.xSum + j0, pxs + avgWx * xv);  // deferred PDHG_Update_Average (step.c:437)
+      double t = xv;
+      t += (-tau) * c0;
+      t += tau * (cur ? pa[1] : pa[0]);
+      if (a.v.qdiag) t = t / (1.0 + tau * q0);
+      t = t < u0 ? t : u0;
+      t = t > l0 ? t : l0;
+      stM<LOCAL>(a.v.x[nxt] + j0, t);
+    }
+    for (int j = j0 + G * kSpmvThreads; j < a.v.n; j += G * kSpmvThreads) {
       const double xv = ldM<LOCAL>(a.v.x[cur] + j);
-      if (avgWx != 0.0) stM<LOCAL>(a.v.xSum + j, ldM<LOCAL>(a.v.xSum + j) + avgWx * xv);  // deferred PDHG_Update_Average (step.c:437)
+      if (avgWx != 0.0) stM<LOCAL>(a.v.xSum + j, ldM<LOCAL>(a.v.xSum + j) + avgWx * xv);
       double t = xv;
       t += (-tau) * a.v.cost[j];
       t += tau * ldM<LOCAL>(a.v.aty[cur] + j);
@@ -277,6 +303,7 @@ __global__ __launch_bounds__(kSpmvThreads) void k_trials_small(const SmallArgs a
     stamp(4);
     meet(e0 + 3);
     stamp(5);
+    prefetchPrimal();  // for the next trial's primal step: in flight while the decision is computed
     // ---- D: the decision, identical in every workgroup ----
     double dY2, dX2, inter;
     trialSumsT<true>(a.partDY, nA, a.partDX, a.partInter, nAt, tscr, dY2, dX2, inter);
