@@ -530,7 +530,7 @@ def test_lds_staged_slab_layout_bit_identical(monkeypatch):
         assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("name,iters", [("25fv47", 400), ("80bau3b", 400), ("synthetic", 240)])
+@pytest.mark.parametrize("name,iters", [("afiro", 160), ("25fv47", 400), ("80bau3b", 400), ("synthetic", 240)])
 def test_trial_loop_variants_give_the_same_bits(name, iters, monkeypatch):
     """The trial loop exists as separate launches and as ONE persistent launch (pdlp_small.hip) — on one XCD, on all
     XCDs with every workgroup sweeping the arrival words, on all XCDs with the XCD-hierarchical barrier; mid-size LPs
