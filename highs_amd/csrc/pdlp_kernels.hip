@@ -402,10 +402,11 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
 // the bench size, of which 0.5 M are the fill of x into 8 L2s and 0.75 M the matrix stream); free-running
 // waves (no barrier, 8 blocks/CU) drift apart — the SIMDs issue oldest-first once the vector-memory
 // queue is full — and miss 3.9 M times.
-//   What bounds the kernel: a CU keeps ~128 cache-line requests in flight (the vector L1's miss queue;
-// the same ~16 KB per CU that limits a streaming copy to ~6 TB/s), and every gathered double is its own
-// line request: 8 M gathers x ~300 cycles L2-hit latency / (256 CUs x 128) = 36 us, plus the matrix and
-// vector streams through the same queue.
+//   What bounds the kernel: every gathered double is its own L2 request.  Round-3 counters at the bench size
+// (profiles/r03_development_measurements.md §13): TCC_REQ 8.98 M per launch over the 128 L2 channels = 0.67
+// requests per channel per clock for the whole launch, mean L2 latency 331 cycles, VALU busy 25 %, waves at
+// vector-memory wait counters half of their life; a deeper gather pipeline or 32 instead of 16 waves per CU
+// change nothing.  The request rate of the L2, not latency, issue slots or bytes (0.35 of the HBM peak).
 //   Accumulation: the 64 products go to a wave-private LDS strip; the first lane of each run of equal
 // local majors adds the run, left to right, onto the major's LDS accumulator.  A 64-entry group may
 // straddle slabs, so the same major can own two runs in it: those are in different ASCENDING stretches
