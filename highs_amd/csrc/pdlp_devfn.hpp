@@ -6,12 +6,24 @@
 
 #include <cmath>
 
+#include "pdlp_detmath.h"
 #include "pdlp_kernels.hpp"
 
 namespace pdlp {
 namespace {
 
 constexpr int kWave = 64;
+
+// Is a check iteration due?  Asked by every kernel of a device-driven check (pdlp_kernels.hpp CheckCtl): the device
+// has halted, at an iteration of the reference's schedule (nIter < 10, nIter % interval == 0, the last iteration:
+// cupdlp_solver.c:953-962), and the solve has not ended.  The fixed-work loop stops AT its target without a check.
+__device__ __forceinline__ bool checkDue(const DevState* st, const CheckCtl* cc) {
+  if (!st->halted || st->commError || cc->terminated) return false;
+  const int it = st->nIter;
+  if (!cc->terminate && it >= cc->iterLimit) return false;
+  return it < 10 || it % cc->interval == 0 || (cc->terminate && it == cc->optIterLimit - 1);
+}
+__device__ __forceinline__ bool gateOpen(const CheckGate& g) { return g.st == nullptr || checkDue(g.st, g.cc); }
 
 // Streamed vector traffic (iterates, costs, bounds, sums: everything that is touched once per kernel)
 // is loaded and stored NON-TEMPORALLY: it then does not displace the two matrix copies (192 MB at the

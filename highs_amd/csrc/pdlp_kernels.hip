@@ -51,6 +51,7 @@ struct SpmvArgs {
   const double* partDY;
   int32_t nDY, nDX;
   unsigned long long* bar;
+  CheckGate gate;  // kPlain inside a device-driven check: the launch is a no-op unless the check is due
 };
 
 // The major-local epilogue fused into both SpMV kernels: what happens to (A v)_r once it is known.
@@ -271,6 +272,7 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
     return;
   }
   if (usesDevState(EPI) && a.st->halted) return;
+  if (EPI == kPlain && !gateOpen(a.gate)) return;
   __shared__ double prod[CHUNK + CHUNK / 8 + 8];
   __shared__ double scratch[2][kSpmvThreads / kWave];
   // kAtyFused (the 2-launch trial on the stream layout): reduction scratch of the decision and the state record
@@ -424,6 +426,7 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
     return;
   }
   if (usesDevState(EPI) && a.st->halted) return;
+  if (EPI == kPlain && !gateOpen(a.gate)) return;
   static_assert(GD >= 1 && NB >= GD + 2, "entry loads need two steps, gathers GD steps");
   constexpr int kWaves = kSlabThreads / kWave;
   constexpr int kSlabPre = TWO ? 2 : 4;  // majors per thread whose epilogue operands are fetched before the stream
@@ -881,11 +884,17 @@ __global__ void k_clear_avgw(DevState* st) { st->avgW = 0.0; st->avgWx = 0.0; }
 
 // Check iteration, one pass instead of three (k_flush_average, k_clear_avgw, 2 x k_scale_copy): the pending average
 // update and the average itself, xAvg = xSum / sum(tau), yAvg = ySum / sum(sigma) (PDHG_Compute_Average_Iterate,
-// cupdlp_step.c:377-420).  The pending weights come from the host's copy of the state (synchronised before every
-// check), which the host clears and pushes back before the loop resumes: no device-side clear.  Same operations,
-// in the same order, as the separate kernels: bit-identical.
-__global__ __launch_bounds__(kVecThreads) void k_flush_scale(const IterVecs v, int cur, double w, double wx, double ps, double ds,
-                                                             double* __restrict__ xAvg, double* __restrict__ yAvg) {
+// cupdlp_step.c:377-420).  Same operations, in the same order, as the separate kernels: bit-identical.  The pending
+// weights come from the host's copy of the state (host-driven check: the host clears them there and pushes the state
+// back before the loop resumes) or, in a device-driven check, from the state record itself (k_check_decide clears them).
+__global__ __launch_bounds__(kVecThreads) void k_flush_scale(const IterVecs v, const CheckGate g, int cur, double w, double wx, double ps,
+                                                             double ds, double* __restrict__ xAvg, double* __restrict__ yAvg) {
+  if (g.st) {
+    if (!checkDue(g.st, g.cc)) return;
+    cur = g.st->cur; w = g.st->avgW; wx = g.st->avgWx;
+    ps = g.st->sumPrimalStep > 0.0 ? 1.0 / g.st->sumPrimalStep : 1.0;
+    ds = g.st->sumDualStep > 0.0 ? 1.0 / g.st->sumDualStep : 1.0;
+  }
   const int stride = gridDim.x * blockDim.x;
   const int tot = v.n + v.m;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += stride) {
@@ -948,46 +957,21 @@ __global__ __launch_bounds__(kVecThreads) void k_div(double* x, const double* y,
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += stride) x[i] /= y[i];
 }
 
-// Row pass of PDHG_Compute_Primal_Feasibility / the y-side of the dual
-// objective and of the infeasibility certificates (cupdlp_solver.c:12-67,80,230,339-345).
-__global__ __launch_bounds__(kVecThreads) void k_row_stats(const double* __restrict__ ax, const double* __restrict__ y,
-                                                           const double* __restrict__ rhs,
-                                                           const double* __restrict__ rowScale, int m, int nEqs,
-                                                           int rowOffset, int scaled, double* partials, int pstride) {
-  __shared__ double scratch[kVecThreads / kWave];
-  double a[kRowStats] = {0.0, 0.0, 0.0, 0.0};
-  const int stride = gridDim.x * blockDim.x;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
-    const bool ineq = (i + rowOffset) >= nEqs;
-    const double axv = ldStream(ax + i), yv = ldStream(y + i), b = ldStream(rhs + i);
-    const double rs = scaled ? ldStream(rowScale + i) : 1.0;
-    double r = axv + (-1.0) * b;
-    if (ineq) r = r < 0.0 ? r : 0.0;
-    r *= rs;
-    a[0] += r * r;
-    a[1] += yv * b;
-    a[2] += yv * yv;
-    double c = axv;
-    if (ineq) c = c < 0.0 ? c : 0.0;
-    c *= rs;
-    a[3] += c * c;
+// Row pass of PDHG_Compute_Primal_Feasibility / the y-side of the dual objective and of the infeasibility
+// certificates (cupdlp_solver.c:12-67,80,230,339-345) for the current AND the average iterate in one pass (rhs and
+// rowScale are read once; one barrier for the eight block sums): quantities 0..3 = current, 4..7 = average.
+__global__ __launch_bounds__(kVecThreads) void k_row_stats2(const IterVecs v, const CheckGate g, int cur, const double* __restrict__ axA,
+                                                            const double* __restrict__ yA, const double* __restrict__ rowScale,
+                                                            int scaled, double* partials, int pstride) {
+  if (g.st) {
+    if (!checkDue(g.st, g.cc)) return;
+    cur = g.st->cur;
   }
-#pragma unroll
-  for (int q = 0; q < kRowStats; ++q) {
-    const double t = blockSum<kVecThreads>(a[q], scratch);
-    if (threadIdx.x == 0) partials[q * pstride + blockIdx.x] = t;
-  }
-}
-
-// The same for the current AND the average iterate in one pass (rhs and rowScale are read once; one barrier for the
-// eight block sums): quantities 0..3 = current, 4..7 = average.  Per quantity the same additions in the same order
-// as k_row_stats: bit-identical.
-__global__ __launch_bounds__(kVecThreads) void k_row_stats2(const double* __restrict__ axC, const double* __restrict__ yC,
-                                                            const double* __restrict__ axA, const double* __restrict__ yA,
-                                                            const double* __restrict__ rhs, const double* __restrict__ rowScale,
-                                                            int m, int nEqs, int rowOffset, int scaled, double* partials,
-                                                            int pstride) {
   __shared__ double scratch[2 * kRowStats][kVecThreads / kWave];
+  const double* __restrict__ axC = v.ax[cur];
+  const double* __restrict__ yC = v.y[cur];
+  const double* __restrict__ rhs = v.rhs;
+  const int m = v.m, nEqs = v.nEqs, rowOffset = v.rowOffset;
   double a[2 * kRowStats];
 #pragma unroll
   for (int q = 0; q < 2 * kRowStats; ++q) a[q] = 0.0;
@@ -1014,80 +998,25 @@ __global__ __launch_bounds__(kVecThreads) void k_row_stats2(const double* __rest
   blockSumMany<2 * kRowStats>(a, scratch, partials, pstride);
 }
 
-// Column pass of PDHG_Compute_Dual_Feasibility and the x-side certificates
-// (cupdlp_solver.c:69-204, 229-256, 326-366); also stores the slacks s+, s-.
-__global__ __launch_bounds__(kVecThreads) void k_col_stats(const double* __restrict__ aty, const double* __restrict__ x,
-                                                           const double* __restrict__ cost,
-                                                           const double* __restrict__ lower,
-                                                           const double* __restrict__ upper,
-                                                           const double* __restrict__ colScale,
-                                                           const double* __restrict__ qdiag,
-                                                           const double* __restrict__ nx, int n, int scaled,
-                                                           double* slackPos, double* slackNeg, double* partials,
-                                                           int pstride) {
-  __shared__ double scratch[kVecThreads / kWave];
-  double a[kColStats];
-#pragma unroll
-  for (int q = 0; q < kColStats; ++q) a[q] = 0.0;
-  const int stride = gridDim.x * blockDim.x;
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
-    const double xv = ldStream(x + j), c = ldStream(cost + j), l = ldStream(lower + j), u = ldStream(upper + j);
-    const double cs = scaled ? ldStream(colScale + j) : 1.0;
-    const double hasL = l > -INFINITY ? 1.0 : 0.0, hasU = u < INFINITY ? 1.0 : 0.0;
-    const double lF = l > -INFINITY ? l : 0.0, uF = u < INFINITY ? u : 0.0;
-    const double atyv = ldStream(aty + j);
-    double r = -atyv + c;                       // c - A'y
-    double half = 0.0;                          // QP: 1/2 x_j (Q x)_j
-    if (qdiag) {                                // QP: reduced cost c + Q x - A'y, objective term 1/2 x'Qx
-      const double qj = qdiag[j];
-      r += qj * xv;
-      half = (0.5 * qj * xv) * xv;
-    }
-    if (nx) {                                   // off-diagonal part: (N x)_j
-      const double nj = ldStream(nx + j);
-      r += nj;
-      half += (0.5 * nj) * xv;
-    }
-    a[10] += half;
-    double sp = (r > 0.0 ? r : 0.0) * hasL;     // s+ (:157-159)
-    double sn = (-(r < 0.0 ? r : 0.0)) * hasU;  // s- (:171-175)
-    stStream(slackPos + j, sp);
-    stStream(slackNeg + j, sn);
-    a[0] += xv * c;
-    a[1] += sp * lF;
-    a[2] += sn * uF;
-    double rd = r + (-1.0) * sp;
-    rd += sn;
-    rd *= cs;
-    a[3] += rd * rd;
-    a[4] += sp * sp;
-    a[5] += sn * sn;
-    double pc = (atyv + sp) - sn;
-    pc *= cs;
-    a[6] += pc * pc;
-    a[7] += xv * xv;
-    double lb = (xv < 0.0 ? xv : 0.0) * hasL;
-    double ub = (xv > 0.0 ? xv : 0.0) * hasU;
-    if (scaled) { lb /= cs; ub /= cs; }
-    a[8] += lb * lb;
-    a[9] += ub * ub;
+// Column pass of PDHG_Compute_Dual_Feasibility and the x-side certificates (cupdlp_solver.c:69-204, 229-256,
+// 326-366) for the current AND the average iterate in one pass (cost, bounds and colScale are read once; one barrier
+// for the 22 block sums): quantities 0..10 = current, 11..21 = average; also stores the slacks s+, s- of both.
+__global__ __launch_bounds__(kVecThreads) void k_col_stats2(const IterVecs v, const CheckGate g, int cur, const double* __restrict__ atyA,
+                                                            const double* __restrict__ xA, const double* __restrict__ colScale,
+                                                            const double* __restrict__ nxA, int scaled, double* spC, double* snC,
+                                                            double* spA, double* snA, double* partials, int pstride) {
+  if (g.st) {
+    if (!checkDue(g.st, g.cc)) return;
+    cur = g.st->cur;
   }
-#pragma unroll
-  for (int q = 0; q < kColStats; ++q) {
-    const double t = blockSum<kVecThreads>(a[q], scratch);
-    if (threadIdx.x == 0) partials[q * pstride + blockIdx.x] = t;
-  }
-}
-
-// The same for the current AND the average iterate in one pass (cost, bounds and colScale are read once; one barrier
-// for the 22 block sums): quantities 0..10 = current, 11..21 = average; bit-identical per quantity to k_col_stats.
-__global__ __launch_bounds__(kVecThreads) void k_col_stats2(const double* __restrict__ atyC, const double* __restrict__ xC,
-                                                            const double* __restrict__ atyA, const double* __restrict__ xA,
-                                                            const double* __restrict__ cost, const double* __restrict__ lower,
-                                                            const double* __restrict__ upper, const double* __restrict__ colScale,
-                                                            const double* __restrict__ qdiag, const double* __restrict__ nxC,
-                                                            const double* __restrict__ nxA, int n, int scaled, double* spC,
-                                                            double* snC, double* spA, double* snA, double* partials, int pstride) {
+  const double* __restrict__ atyC = v.aty[cur];
+  const double* __restrict__ xC = v.x[cur];
+  const double* __restrict__ cost = v.cost;
+  const double* __restrict__ lower = v.lower;
+  const double* __restrict__ upper = v.upper;
+  const double* __restrict__ qdiag = v.qdiag;
+  const double* __restrict__ nxC = v.nx[0] ? v.nx[cur] : nullptr;
+  const int n = v.n;
   __shared__ double scratch[2 * kColStats][kVecThreads / kWave];
   double a[2 * kColStats];
 #pragma unroll
@@ -1139,7 +1068,8 @@ __global__ __launch_bounds__(kVecThreads) void k_col_stats2(const double* __rest
 // out[q] = fixed-order sum of quantity q's per-block partials; the first nQ0 quantities have nBlocks0 partials each,
 // the others nBlocks1 (row and column statistics of a check in one launch)
 __global__ __launch_bounds__(kVecThreads) void k_final_reduce2(const double* partials, int pstride, int nQ0, int nBlocks0,
-                                                               int nBlocks1, double* out) {
+                                                               int nBlocks1, double* out, const CheckGate g) {
+  if (!gateOpen(g)) return;
   __shared__ double scratch[kVecThreads / kWave];
   const double s = reducePartials(partials + (size_t)blockIdx.x * pstride, (int)blockIdx.x < nQ0 ? nBlocks0 : nBlocks1, scratch);
   if (threadIdx.x == 0) out[blockIdx.x] = s;
@@ -1284,9 +1214,9 @@ void launchHalpernDual(const MatView& A, const HalpernVecs& h, hipStream_t s) {
   a.h = h;
   launchSpmv<kHalpernDual>(A, a, s);
 }
-void launchSpmvPlain(const MatView& A, const double* in, double* out, hipStream_t s) {
+void launchSpmvPlain(const MatView& A, const double* in, double* out, hipStream_t s, CheckGate g) {
   SpmvArgs a{};
-  a.st = nullptr; a.in = in; a.out = out;
+  a.st = nullptr; a.in = in; a.out = out; a.gate = g;
   launchSpmv<kPlain>(A, a, s);
 }
 void launchInteract(const IterVecs& v, const DevState* st, const double* atyReduced, double* partDX,
@@ -1320,26 +1250,24 @@ void launchFlushAverage(const IterVecs& v, DevState* st, hipStream_t s) {
   hipLaunchKernelGGL(k_flush_average, dim3(vecBlocks(v.n + v.m)), dim3(kVecThreads), 0, s, v, st);
   hipLaunchKernelGGL(k_clear_avgw, dim3(1), dim3(1), 0, s, st);
 }
-void launchFlushScale(const IterVecs& v, int cur, double w, double wx, double ps, double ds, double* xAvg, double* yAvg,
+void launchClearAvgW(DevState* st, hipStream_t s) { hipLaunchKernelGGL(k_clear_avgw, dim3(1), dim3(1), 0, s, st); }
+void launchFlushScale(const IterVecs& v, CheckGate g, int cur, double w, double wx, double ps, double ds, double* xAvg, double* yAvg,
                       hipStream_t s) {
-  hipLaunchKernelGGL(k_flush_scale, dim3(vecBlocks(v.n + v.m)), dim3(kVecThreads), 0, s, v, cur, w, wx, ps, ds, xAvg, yAvg);
+  hipLaunchKernelGGL(k_flush_scale, dim3(vecBlocks(v.n + v.m)), dim3(kVecThreads), 0, s, v, g, cur, w, wx, ps, ds, xAvg, yAvg);
 }
-void launchRowStats2(const double* axC, const double* yC, const double* axA, const double* yA, const double* rhs,
-                     const double* rowScale, int32_t m, int32_t nEqs, int32_t rowOffset, int scaled, double* partials,
-                     int32_t stride, int32_t nBlocks, hipStream_t s) {
-  hipLaunchKernelGGL(k_row_stats2, dim3(nBlocks), dim3(kVecThreads), 0, s, axC, yC, axA, yA, rhs, rowScale, m, nEqs, rowOffset,
-                     scaled, partials, stride);
-}
-void launchColStats2(const double* atyC, const double* xC, const double* atyA, const double* xA, const double* cost,
-                     const double* lower, const double* upper, const double* colScale, const double* qdiag, const double* nxC,
-                     const double* nxA, int32_t n, int scaled, double* spC, double* snC, double* spA, double* snA,
+void launchRowStats2(const IterVecs& v, CheckGate g, int cur, const double* axA, const double* yA, const double* rowScale, int scaled,
                      double* partials, int32_t stride, int32_t nBlocks, hipStream_t s) {
-  hipLaunchKernelGGL(k_col_stats2, dim3(nBlocks), dim3(kVecThreads), 0, s, atyC, xC, atyA, xA, cost, lower, upper, colScale, qdiag,
-                     nxC, nxA, n, scaled, spC, snC, spA, snA, partials, stride);
+  hipLaunchKernelGGL(k_row_stats2, dim3(nBlocks), dim3(kVecThreads), 0, s, v, g, cur, axA, yA, rowScale, scaled, partials, stride);
+}
+void launchColStats2(const IterVecs& v, CheckGate g, int cur, const double* atyA, const double* xA, const double* colScale,
+                     const double* nxA, int scaled, double* spC, double* snC, double* spA, double* snA, double* partials,
+                     int32_t stride, int32_t nBlocks, hipStream_t s) {
+  hipLaunchKernelGGL(k_col_stats2, dim3(nBlocks), dim3(kVecThreads), 0, s, v, g, cur, atyA, xA, colScale, nxA, scaled, spC, snC, spA,
+                     snA, partials, stride);
 }
 void launchFinalReduce2(const double* partials, int32_t stride, int32_t nQ0, int32_t nBlocks0, int32_t nQ1, int32_t nBlocks1,
-                        double* out, hipStream_t s) {
-  hipLaunchKernelGGL(k_final_reduce2, dim3(nQ0 + nQ1), dim3(kVecThreads), 0, s, partials, stride, nQ0, nBlocks0, nBlocks1, out);
+                        double* out, CheckGate g, hipStream_t s) {
+  hipLaunchKernelGGL(k_final_reduce2, dim3(nQ0 + nQ1), dim3(kVecThreads), 0, s, partials, stride, nQ0, nBlocks0, nBlocks1, out, g);
 }
 void launchScaleCopy(double* dst, const double* src, double a, int32_t len, hipStream_t s) {
   if (len <= 0) return;
@@ -1360,19 +1288,6 @@ void launchMulInPlace(double* x, const double* y, int32_t len, hipStream_t s) {
 void launchDivInPlace(double* x, const double* y, int32_t len, hipStream_t s) {
   if (len <= 0) return;
   hipLaunchKernelGGL(k_div, dim3(vecBlocks(len)), dim3(kVecThreads), 0, s, x, y, len);
-}
-void launchRowStats(const double* ax, const double* y, const double* rhs, const double* rowScale, int32_t m,
-                    int32_t nEqs, int32_t rowOffset, int scaled, double* partials, int32_t stride, int32_t nBlocks,
-                    hipStream_t s) {
-  hipLaunchKernelGGL(k_row_stats, dim3(nBlocks), dim3(kVecThreads), 0, s, ax, y, rhs, rowScale, m, nEqs, rowOffset,
-                     scaled, partials, stride);
-}
-void launchColStats(const double* aty, const double* x, const double* cost, const double* lower,
-                    const double* upper, const double* colScale, const double* qdiag, const double* nx, int32_t n, int scaled,
-                    double* slackPos, double* slackNeg, double* partials, int32_t stride, int32_t nBlocks,
-                    hipStream_t s) {
-  hipLaunchKernelGGL(k_col_stats, dim3(nBlocks), dim3(kVecThreads), 0, s, aty, x, cost, lower, upper, colScale, qdiag, nx,
-                     n, scaled, slackPos, slackNeg, partials, stride);
 }
 void launchFinalReduce(const double* partials, int32_t stride, int32_t nBlocks, int32_t nQ, double* out,
                        hipStream_t s) {

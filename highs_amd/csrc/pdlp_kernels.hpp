@@ -54,6 +54,47 @@ struct DevState {
   const double* powGrow;
 };
 
+// ---- check / restart control on the device (round 4) -----------------------------------------------------------
+// The reference's check iteration (PDHG_Solve, cupdlp_solver.c:975-1069: residuals of both iterates, termination
+// tests, PDHG_Check_Restart_GPU cupdlp_restart.c:3-124, PDHG_Compute_Step_Size_Ratio cupdlp_step.c:147-176) used to
+// come back to the host every 40 iterations: 30 statistics down, the decision on the host, a state record up, a
+// stand-alone primal step — ~240 us of idle queue per check at 1M x 1M next to 173 us of kernels.  Now the whole
+// check is a sequence of kernels BEHIND the trial batch: every kernel of it first asks checkDue() (the device has
+// halted at a scheduled iteration and the solve is not over), k_check_decide holds the scalar logic, and the host
+// enqueues several [batch][check] units before it looks at the pinned CheckRecords.  A check that is not due
+// (a period that needed more spare trials than were queued; the queue behind a termination) costs early-exit
+// kernels and changes nothing.
+struct ResidualsDev {  // = Residuals (pdlp_solver.hpp)
+  double pObj, dObj, gap, relGap, pFeas, dFeas, pInfObj, pInfRes, dInfObj, dInfRes;
+};
+struct CheckCtl {
+  // parameters of the running loop (host, before the first unit)
+  double primalTolAbs, dualTolAbs;  // tol * (1 + ||b||), tol * (1 + ||c||)   cupdlp_solver.c:797-841
+  double gapTol, feasTol, sense, offset;
+  int32_t terminate;     // 1: Solver::run (termination tests), 0: fixed-work loop of Solver::iterate
+  int32_t restartOn;
+  int32_t interval;      // check interval (CUPDLP_RELEASE_INTERVAL 40 unless the caller asked otherwise)
+  int32_t iterLimit;     // terminate: opt.iter_limit, else the target iteration of the fixed-work loop
+  int32_t optIterLimit;  // opt.iter_limit (the schedule's "last iteration" rule uses it in both modes)
+  int32_t qp;            // the objective has a 1/2 x'Qx term (statistic 10 of the column pass)
+  int32_t adaptive;
+  int32_t pad_;
+  // state (host mirrors: Solver::cur_, avg_, pFeasLR_ ...; uploaded before, downloaded after a device-driven loop)
+  ResidualsDev cur, avg;
+  double pFeasLR, dFeasLR, gapLR, pFeasLC, dFeasLC, gapLC;
+  int32_t iLastRestartIter, nRestarts, nChecks;
+  int32_t termCode, termIterate;
+  int32_t terminated;    // the solve is over: everything still queued is a no-op
+  int32_t restartKind;   // of the check in flight: 0 none, 1 to the current, 2 to the average iterate
+  int32_t lastCheckIter;
+};
+// What the host reads of an executed check (pinned host memory, written by the check's scalar kernels)
+struct CheckRecord {
+  int32_t ran, it, terminated, termCode, termIterate, restartKind, nRestarts, nChecks, nTrials, pad_;
+  double beta;
+  ResidualsDev cur, avg;
+};
+
 struct SpmvMat {
   const int32_t* beg;       // [nMajor+1]
   const int32_t* idx;       // [nnz]
@@ -247,49 +288,45 @@ constexpr int kSmallHierWords = 4 * 16 * 32;  // the XCD-hierarchical barrier's 
 // arrival words, timeout flag, XCC ids of the placement check; behind them (256-byte aligned) the hierarchical barrier's words
 inline size_t smallBarWords(int grid) { return ((2 * (size_t)grid + 16 + 31) / 32) * 32 + kSmallHierWords; }
 
-// ---- check-iteration kernels (host knows the parity here) -------------------
+// ---- check-iteration kernels --------------------------------------------------------------------------------------
+// Every launcher takes a CheckGate.  {nullptr, nullptr}: host-driven check (sharded paths, stage("residuals"),
+// profile mode) — the kernel always runs and takes the buffer parity / weights from its arguments.  Otherwise the
+// kernel runs only if checkDue(st, cc) (pdlp_devfn.hpp) and reads parity, weights and step sums from *st.
+struct CheckGate {
+  const DevState* st = nullptr;
+  const CheckCtl* cc = nullptr;
+};
 void launchFlushAverage(const IterVecs& v, DevState* st, hipStream_t s);
+void launchClearAvgW(DevState* st, hipStream_t s);  // the pending average weights of *st have been consumed
 void launchScaleCopy(double* dst, const double* src, double a, int32_t len, hipStream_t s);  // dst = a*src
-// one pass: pending average update (weights w for y, wx for x, from the host's copy of the state) and the averages
-// xAvg = xSum * ps, yAvg = ySum * ds; bit-identical to launchFlushAverage + 2 x launchScaleCopy
-void launchFlushScale(const IterVecs& v, int cur, double w, double wx, double ps, double ds, double* xAvg, double* yAvg,
+// one pass: pending average update (weights w for y, wx for x) and the averages xAvg = xSum * ps, yAvg = ySum * ds
+// (PDHG_Compute_Average_Iterate, cupdlp_step.c:377-420)
+void launchFlushScale(const IterVecs& v, CheckGate g, int cur, double w, double wx, double ps, double ds, double* xAvg, double* yAvg,
                       hipStream_t s);
-// row / column statistics of the current AND the average iterate in one pass each (quantities: current first), and
-// the final reduction of both in one launch; per quantity bit-identical to the single-iterate kernels
-void launchRowStats2(const double* axC, const double* yC, const double* axA, const double* yA, const double* rhs,
-                     const double* rowScale, int32_t m, int32_t nEqs, int32_t rowOffset, int scaled, double* partials,
-                     int32_t stride, int32_t nBlocks, hipStream_t s);
-void launchColStats2(const double* atyC, const double* xC, const double* atyA, const double* xA, const double* cost,
-                     const double* lower, const double* upper, const double* colScale, const double* qdiag, const double* nxC,
-                     const double* nxA, int32_t n, int scaled, double* spC, double* snC, double* spA, double* snA,
+// Row / column statistics of the current AND the average iterate in one pass each (quantities: current first), and
+// the final reduction of both in one launch.  v: the iterate vectors of the rows / of the own column slice.
+//  row  0: sum ((ax-b) projected) * rowScale)^2   primal residual^2   (cupdlp_solver.c:12-67)
+//       1: sum y*b                                dual objective part (:80)
+//       2: sum y^2                                ray norm part       (:230)
+//       3: sum ((ax projected)*rowScale)^2        dual-infeasibility constraint part (:339-345)
+//  col  0: sum c*x   1: sum sp*lowerF   2: sum sn*upperF   3: sum ((r-sp+sn)*colScale)^2
+//       4: sum sp^2  5: sum sn^2        6: sum ((aty+sp-sn)*colScale)^2
+//       7: sum x^2   8: sum (min(x,0)*hasLower/colScale)^2    9: sum (max(x,0)*hasUpper/colScale)^2
+//      10: sum 1/2 x (Qx) (QP only; the reduced cost then is c + Q x - A'y; nx = N x for the off-diagonal part)
+constexpr int kRowStats = 4;
+constexpr int kColStats = 11;
+void launchRowStats2(const IterVecs& v, CheckGate g, int cur, const double* axA, const double* yA, const double* rowScale, int scaled,
                      double* partials, int32_t stride, int32_t nBlocks, hipStream_t s);
+void launchColStats2(const IterVecs& v, CheckGate g, int cur, const double* atyA, const double* xA, const double* colScale,
+                     const double* nxA, int scaled, double* spC, double* snC, double* spA, double* snA, double* partials,
+                     int32_t stride, int32_t nBlocks, hipStream_t s);
 void launchFinalReduce2(const double* partials, int32_t stride, int32_t nQ0, int32_t nBlocks0, int32_t nQ1, int32_t nBlocks1,
-                        double* out, hipStream_t s);
-void launchSpmvPlain(const MatView& A, const double* in, double* out, hipStream_t s);
+                        double* out, CheckGate g, hipStream_t s);
+void launchSpmvPlain(const MatView& A, const double* in, double* out, hipStream_t s, CheckGate g = CheckGate());
 void launchFill(double* dst, double value, int32_t len, hipStream_t s);
 void launchProjectBounds(double* x, const double* lower, const double* upper, int32_t n, hipStream_t s);
 void launchMulInPlace(double* x, const double* y, int32_t len, hipStream_t s);   // x *= y
 void launchDivInPlace(double* x, const double* y, int32_t len, hipStream_t s);   // x /= y
-
-// Row statistics of one iterate: out[0..kRowStats) (after launchFinalReduce)
-//  0: sum ((ax-b) projected) * rowScale)^2   primal residual^2   (cupdlp_solver.c:12-67)
-//  1: sum y*b                                dual objective part (:80)
-//  2: sum y^2                                ray norm part       (:230)
-//  3: sum ((ax projected)*rowScale)^2        dual-infeasibility constraint part (:339-345)
-constexpr int kRowStats = 4;
-void launchRowStats(const double* ax, const double* y, const double* rhs, const double* rowScale, int32_t m,
-                    int32_t nEqs, int32_t rowOffset, int scaled, double* partials, int32_t stride, int32_t nBlocks,
-                    hipStream_t s);
-// Column statistics: out[0..kColStats)
-//  0: sum c*x   1: sum sp*lowerF   2: sum sn*upperF   3: sum ((r-sp+sn)*colScale)^2
-//  4: sum sp^2  5: sum sn^2        6: sum ((aty+sp-sn)*colScale)^2
-//  7: sum x^2   8: sum (min(x,0)*hasLower/colScale)^2    9: sum (max(x,0)*hasUpper/colScale)^2
-// 10: sum 1/2 x (Qx) (QP only; the reduced cost then is c + Q x - A'y; nx = N x for the off-diagonal part, or nullptr)
-constexpr int kColStats = 11;
-void launchColStats(const double* aty, const double* x, const double* cost, const double* lower,
-                    const double* upper, const double* colScale, const double* qdiag, const double* nx, int32_t n, int scaled,
-                    double* slackPos, double* slackNeg, double* partials, int32_t stride, int32_t nBlocks,
-                    hipStream_t s);
 // out[q] = sum_{b<nBlocks} partials[q*stride+b], q < nQ (deterministic)
 void launchFinalReduce(const double* partials, int32_t stride, int32_t nBlocks, int32_t nQ, double* out,
                        hipStream_t s);
@@ -298,6 +335,24 @@ void launchDiffNorm2(const double* a, const double* b, int32_t len, double* part
                      hipStream_t s);
 // partials of a.b
 void launchDot(const double* a, const double* b, int32_t len, double* partials, int32_t nBlocks, hipStream_t s);
+
+// ---- the scalar side of a device-driven check (pdlp_check.hip) ------------------------------------------------------
+// stat: the 2*kRowStats + 2*kColStats statistics (launchFinalReduce2).  Residuals of both iterates, termination
+// tests, the restart decision (-> cc->restartKind); rec: pinned host record of this check.
+void launchCheckDecide(DevState* st, CheckCtl* cc, const double* stat, CheckRecord* rec, hipStream_t s);
+// If the check decided to restart: running sums cleared, average -> current iterate (restartKind 2), the partials of
+// ||x - xLast||^2 (nbX blocks, partX) and ||y - yLast||^2 (nbY blocks, partY) in the grids of launchDiffNorm2, and
+// xLast / yLast <- the restarted iterate (PDHG_Restart_Iterate_GPU, cupdlp_proj.c:88-148).  v / vCol: rows / own columns.
+struct RestartVecs {
+  const double* xAvg; const double* yAvg; const double* axAvg; const double* atyAvg; const double* nxAvg;
+  double* xLast; double* yLast;
+};
+void launchRestartVec(const IterVecs& v, const DevState* st, const CheckCtl* cc, const RestartVecs& r, double* partX, int32_t nbX,
+                      double* partY, int32_t nbY, hipStream_t s);
+// Primal-weight update after a restart (PDHG_Compute_Step_Size_Ratio, cupdlp_step.c:147-176) from the two partial
+// arrays, then — restart or not — the next halt iteration of the reference's check schedule and the device runs on.
+void launchRestartFinish(DevState* st, CheckCtl* cc, const double* partX, int32_t nbX, const double* partY, int32_t nbY,
+                         CheckRecord* rec, hipStream_t s);
 
 int32_t vecBlocks(int32_t len);  // grid size used by the vector/statistics kernels
 

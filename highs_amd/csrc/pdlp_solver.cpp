@@ -3,6 +3,7 @@
 // decision is taken on the device, so the host only synchronises at the
 // reference's check iterations (nIter < 10, nIter % 40 == 0, last iteration).
 #include "pdlp_solver.hpp"
+#include "pdlp_detmath.h"
 
 #include <algorithm>
 #include <climits>
@@ -523,6 +524,11 @@ void Solver::construct(const pdlp_problem_t& P, const void* id128) {
     if (fused_) gridBar_.alloc(gridBarWords(fusedAtyBlocks(at)));
     if (persistent_) gridBar_.alloc(smallBarWords(smallGrid_));
   }
+  // check iterations on the device (single GPU; the sharded paths issue their check collectives from the host)
+  {
+    const char* dc = getenv("PDLP_MI355X_DEVICE_CHECK");
+    devCheck_ = !sharded_ && !(dc && atoi(dc) == 0);
+  }
   reset();
   // the trial-batch graph is part of the setup, not of the first iterations
   if (useGraph_ && !persistent_ && (!sharded_ || meshMode_)) captureGraph();
@@ -536,6 +542,9 @@ void Solver::release() noexcept {
   profEvents_.clear();
   if (hostState_) (void)hipHostFree(hostState_);
   if (hostStats_) (void)hipHostFree(hostStats_);
+  if (hostCtl_) (void)hipHostFree(hostCtl_);
+  if (hostRing_) (void)hipHostFree(hostRing_);
+  hostCtl_ = nullptr; hostRing_ = nullptr;
   delete comm_;
   delete mesh_;
   if (stream_) (void)hipStreamDestroy(stream_);
@@ -672,6 +681,13 @@ void Solver::allocIterates() {
   PDLP_HIP(hipHostMalloc((void**)&hostState_, sizeof(DevState), hipHostMallocDefault));
   PDLP_HIP(hipHostMalloc((void**)&hostStats_, sizeof(double) * (kStatTotal + 8), hipHostMallocDefault));
   memset(hostState_, 0, sizeof(DevState));
+  dCtl_.alloc(1);
+  dCtl_.zero(stream_);
+  PDLP_HIP(hipHostMalloc((void**)&hostCtl_, sizeof(CheckCtl), hipHostMallocDefault));
+  PDLP_HIP(hipHostMalloc((void**)&hostRing_, sizeof(CheckRecord) * kRingSlots, hipHostMallocDefault));
+  memset(hostCtl_, 0, sizeof(CheckCtl));
+  memset(hostRing_, 0, sizeof(CheckRecord) * kRingSlots);
+  partRestartY_.alloc((size_t)std::max(vecBlocks(std::max(mLoc_, 1)), 1));
 
   vecs_ = IterVecs{};
   for (int k = 0; k < 2; ++k) {
@@ -1033,6 +1049,30 @@ void Solver::captureGraph() {
   stPar_ = graphPar_;
 }
 
+// `todo` trials towards the next halt.  Trials queued behind the halt are early-exit kernels, so every form carries a
+// few spare ones for rejected trials: the persistent launch runs up to todo + 8, the captured graph holds 42 for a
+// period of 40; single launches (the first ten iterations, profile mode) carry none — the caller looks at the state.
+void Solver::enqueueBatch(int32_t todo) {
+  if (persistent_ && !profile_) {  // the whole stretch to the next check (plus spare trials for rejections) in one launch
+    launchSmallTrials(dA_.view(), dAt_.view(), vecs_, dst(), partDY_.get(), partDX_.get(), partInter_.get(), gridBar_.get(),
+                      smallGrid_, todo + 8, smallMode(), stream_);
+    return;
+  }
+  if (useGraph_ && !persistent_ && !profile_ && (!sharded_ || meshMode_) && todo >= kGraphMinTodo) {
+    if (!graphExec_) captureGraph();
+    while (todo >= kGraphMinTodo) {
+      if (stPar_ != graphPar_ || (fused_ && needPrimal_)) {  // the graph starts from the state slot it was captured with, after a primal step
+        enqueueTrial();
+        --todo;
+        continue;
+      }
+      PDLP_HIP(hipGraphLaunch(graphExec_, stream_));  // an even number of trials: the slot parity is unchanged
+      todo = todo > graphTrials_ ? todo - graphTrials_ : 0;
+    }
+  }
+  for (int i = 0; i < todo; ++i) enqueueTrial();
+}
+
 void Solver::runUntilHalt() {
   for (;;) {
     int64_t remaining = (int64_t)hostState_->haltIter - hostState_->nIter;
@@ -1040,24 +1080,7 @@ void Solver::runUntilHalt() {
     if (remaining > 4 * kCheckInterval) remaining = 4 * kCheckInterval;
     int32_t todo = (int32_t)remaining;
     const int32_t trialsBefore = hostState_->nTrials;
-    if (persistent_ && !profile_) {  // the whole stretch to the next check (plus spare trials for rejections) in one launch
-      launchSmallTrials(dA_.view(), dAt_.view(), vecs_, dst(), partDY_.get(), partDX_.get(), partInter_.get(), gridBar_.get(),
-                        smallGrid_, todo + 8, smallMode(), stream_);
-      todo = 0;
-    }
-    if (useGraph_ && !persistent_ && !profile_ && (!sharded_ || meshMode_) && todo >= kGraphMinTodo) {
-      if (!graphExec_) captureGraph();
-      while (todo >= kGraphMinTodo) {
-        if (stPar_ != graphPar_ || (fused_ && needPrimal_)) {  // the graph starts from the state slot it was captured with, after a primal step
-          enqueueTrial();
-          --todo;
-          continue;
-        }
-        PDLP_HIP(hipGraphLaunch(graphExec_, stream_));  // an even number of trials: the slot parity is unchanged
-        todo = todo > graphTrials_ ? todo - graphTrials_ : 0;
-      }
-    }
-    for (int i = 0; i < todo; ++i) enqueueTrial();
+    enqueueBatch(todo);
     const int32_t iterBefore = hostState_->nIter;
     syncState();
     if (profile_) profCollect(hostState_->nTrials - trialsBefore);
@@ -1097,9 +1120,10 @@ void Solver::computeAverage() {
   const double ds = hostState_->sumDualStep > 0.0 ? 1.0 / hostState_->sumDualStep : 1.0;
   // pending average update + the averages of the own columns / rows in one pass; the pending weights come from the
   // host's copy of the state (every caller has synchronised it) and are cleared here: the next pushState carries that
-  launchFlushScale(vecsCol_, hostState_->cur, hostState_->avgW, hostState_->avgWx, ps, ds, xAvg_.get() + c0_, yAvgl(), stream_);
+  launchFlushScale(vecsCol_, CheckGate(), hostState_->cur, hostState_->avgW, hostState_->avgWx, ps, ds, xAvg_.get() + c0_, yAvgl(), stream_);
   hostState_->avgW = 0.0;
   hostState_->avgWx = 0.0;
+  launchClearAvgW(dst(), stream_);  // the device's record too: a caller that stops here (terminate, stage) leaves host and device agreeing
   if (meshMode_) mesh_->allGather(xAvg_.get(), false, stream_);
   deviceAx(xAvg_.get(), axAvg_.get());
   deviceATy(yAvgl(), atyAvg_.get());
@@ -1115,15 +1139,13 @@ void Solver::computeResiduals() {
   const size_t co = (size_t)c0_;  // column statistics run on the own column slice (everything unless mesh-sharded)
   const int sc = F_.scaled ? 1 : 0;
   static_assert(kStatRowAvg == kStatRowCur + kRowStats && kStatColAvg == kStatColCur + kColStats, "current first, then average");
-  const double* qd = qdiag_.size() ? qdiag_.get() + co : nullptr;
   // both iterates per pass (shared vectors read once), one reduction launch for all 30 quantities
-  launchRowStats2(ax_[c].get(), yl(c), axAvg_.get(), yAvgl(), rhs_.get(), rowScale_.get(), mLoc_, F_.nEqs, r0_, sc,
-                  part + (size_t)kStatRowCur * statStride_, statStride_, nbM, stream_);
-  launchColStats2(aty_[c].get() + co, x_[c].get() + co, atyAvg_.get() + co, xAvg_.get() + co, cost_.get() + co, lower_.get() + co,
-                  upper_.get() + co, colScale_.get() + co, qd, hasQoff_ ? nx_[c].get() : nullptr, hasQoff_ ? nxAvg_.get() : nullptr,
-                  nLoc_, sc, slackPos_.get() + co, slackNeg_.get() + co, slackPosAvg_.get() + co, slackNegAvg_.get() + co,
+  launchRowStats2(vecs_, CheckGate(), c, axAvg_.get(), yAvgl(), rowScale_.get(), sc, part + (size_t)kStatRowCur * statStride_, statStride_,
+                  nbM, stream_);
+  launchColStats2(vecsCol_, CheckGate(), c, atyAvg_.get() + co, xAvg_.get() + co, colScale_.get() + co, hasQoff_ ? nxAvg_.get() : nullptr,
+                  sc, slackPos_.get() + co, slackNeg_.get() + co, slackPosAvg_.get() + co, slackNegAvg_.get() + co,
                   part + (size_t)kStatColCur * statStride_, statStride_, nbN, stream_);
-  launchFinalReduce2(part, statStride_, 2 * kRowStats, nbM, 2 * kColStats, nbN, statOut_.get(), stream_);
+  launchFinalReduce2(part, statStride_, 2 * kRowStats, nbM, 2 * kColStats, nbN, statOut_.get(), CheckGate(), stream_);
   if (sharded_) sumOverRanks(statOut_.get(), meshMode_ ? kStatTotal : 2 * kRowStats);
   PDLP_HIP(hipMemcpyAsync(hostStats_, statOut_.get(), sizeof(double) * kStatTotal, hipMemcpyDeviceToHost, stream_));
   PDLP_HIP(hipStreamSynchronize(stream_));
@@ -1226,8 +1248,9 @@ void Solver::restartIterate() {
   launchDiffNorm2(yl(c), yLast_.get(), mLoc_, partDX_.get(), nbM, stream_);
   const double dD = std::sqrt(reduceScalar(partDX_.get(), nbM, true));
   if (std::fmin(dP, dD) > 1e-10) {
-    const double lg = 0.5 * std::log(dD / dP) + 0.5 * std::log(std::sqrt(s.beta));
-    s.beta = std::exp(lg) * std::exp(lg);
+    // (pdlp_detmath.h: the same bits as the device-driven restart, pdlp_check.hip k_restart_finish)
+    const double lg = 0.5 * pdlp_det_log(dD / dP) + 0.5 * pdlp_det_log(std::sqrt(s.beta));
+    s.beta = pdlp_det_exp(lg) * pdlp_det_exp(lg);
   }
   s.primalStep = mean / std::sqrt(s.beta);
   s.dualStep = s.primalStep * s.beta;
@@ -1246,6 +1269,205 @@ void Solver::restartIterate() {
   log(2, "Restart at iter %d to %s: beta = %g\n", it, toCurrent ? "current" : "average", s.beta);
   // The reference recomputes the residuals here (cupdlp_proj.c:145); the values
   // are overwritten by the next check before anything reads them, so we don't.
+}
+
+// One line of the iteration log (the reference prints every 100th check, the last iteration and at the time limit).
+void Solver::logCheckLine(int32_t it, const Residuals& cur, const Residuals& avg, double t, int& logSinceHeader) const {
+  if (opt_.log_level <= 0 || rank_ != 0) return;
+  if (logSinceHeader >= 50) {
+    logLine(opt_, 1, "%9s  %15s  %15s   %8s  %10s  %8s %7s\n", "Iter", "Primal.Obj", "Dual.Obj", "Gap", "Primal.Inf",
+           "Dual.Inf", "Time");
+    logSinceHeader = 0;
+  }
+  const Residuals& r = it == 0 ? cur : avg;
+  logLine(opt_, 1, "%9d  %+15.8e  %+15.8e  %+8.2e  %10.2e  %8.2e %6.2fs [%c]\n", it, r.pObj, r.dObj, r.relGap,
+         r.pFeas / (1.0 + F_.normRhs), r.dFeas / (1.0 + F_.normCost), t, it == 0 ? 'L' : 'A');
+  ++logSinceHeader;
+}
+
+// ---- check iterations on the device (pdlp_kernels.hpp CheckCtl, pdlp_check.hip) -------------------------------------
+static_assert(sizeof(ResidualsDev) == sizeof(Residuals), "Residuals is mirrored on the device");
+
+// parameters of the loop + the host's mirrors of the restart bookkeeping -> device
+void Solver::uploadCtl(bool terminate, int64_t iterLim) {
+  CheckCtl& c = *hostCtl_;
+  memset(&c, 0, sizeof(c));
+  c.primalTolAbs = opt_.primal_tol * (1.0 + F_.normRhs);
+  c.dualTolAbs = opt_.dual_tol * (1.0 + F_.normCost);
+  c.gapTol = opt_.gap_tol;
+  c.feasTol = feasTol_;
+  c.sense = F_.sense;
+  c.offset = F_.offset;
+  c.terminate = terminate ? 1 : 0;
+  c.restartOn = restartOn_ ? 1 : 0;
+  c.interval = opt_.check_interval > 0 ? opt_.check_interval : kCheckInterval;
+  c.iterLimit = (int32_t)std::min<int64_t>(iterLim, INT_MAX);
+  c.optIterLimit = opt_.iter_limit;
+  c.qp = qdiag_.size() ? 1 : 0;
+  c.adaptive = adaptive_ ? 1 : 0;
+  memcpy(&c.cur, &cur_, sizeof(Residuals));
+  memcpy(&c.avg, &avg_, sizeof(Residuals));
+  c.pFeasLR = pFeasLR_; c.dFeasLR = dFeasLR_; c.gapLR = gapLR_;
+  c.pFeasLC = pFeasLC_; c.dFeasLC = dFeasLC_; c.gapLC = gapLC_;
+  c.iLastRestartIter = iLastRestartIter_; c.nRestarts = nRestarts_; c.nChecks = nChecks_;
+  c.termCode = termCode_; c.termIterate = termIterate_;
+  c.lastCheckIter = -1;
+  PDLP_HIP(hipMemcpyAsync(dCtl_.get(), hostCtl_, sizeof(CheckCtl), hipMemcpyHostToDevice, stream_));
+}
+
+// device -> the host's mirrors (the stream is idle)
+void Solver::downloadCtl() {
+  PDLP_HIP(hipMemcpyAsync(hostCtl_, dCtl_.get(), sizeof(CheckCtl), hipMemcpyDeviceToHost, stream_));
+  PDLP_HIP(hipStreamSynchronize(stream_));
+  const CheckCtl& c = *hostCtl_;
+  memcpy(&cur_, &c.cur, sizeof(Residuals));
+  memcpy(&avg_, &c.avg, sizeof(Residuals));
+  pFeasLR_ = c.pFeasLR; dFeasLR_ = c.dFeasLR; gapLR_ = c.gapLR;
+  pFeasLC_ = c.pFeasLC; dFeasLC_ = c.dFeasLC; gapLC_ = c.gapLC;
+  iLastRestartIter_ = c.iLastRestartIter; nRestarts_ = c.nRestarts; nChecks_ = c.nChecks;
+  if (c.terminated) { termCode_ = c.termCode; termIterate_ = c.termIterate; }
+}
+
+// One check iteration behind whatever is queued: flush + averages, A xAvg, A'yAvg, the two statistics passes, their
+// reduction, then the scalar logic and the restart — every kernel a no-op unless the device has halted at a scheduled
+// iteration (checkDue).  10 launches, no host synchronisation.
+void Solver::enqueueCheckDevice() {
+  DevState* st = dst();
+  const CheckGate g{st, dCtl_.get()};
+  if (!persistent_ && !fused_)  // 3-launch loop: the decision of the last trial may still be pending
+    launchDecide(st, partDY_.get(), dA_.nPartials(), partDX_.get(), partInter_.get(), dAt_.nPartials(), nullptr, stream_, true,
+                 hasQoff_ ? partQ_.get() : nullptr, hasQoff_ ? dQ_.nPartials() : 0);
+  launchFlushScale(vecs_, g, 0, 0.0, 0.0, 1.0, 1.0, xAvg_.get(), yAvg_.get(), stream_);
+  launchSpmvPlain(dA_.view(), xAvg_.get(), axAvg_.get(), stream_, g);
+  launchSpmvPlain(dAt_.view(), yAvg_.get(), atyAvg_.get(), stream_, g);
+  if (hasQoff_) launchSpmvPlain(dQ_.view(), xAvg_.get(), nxAvg_.get(), stream_, g);
+  const int32_t nbM = vecBlocks(std::max(mLoc_, 1)), nbN = vecBlocks(std::max(nLoc_, 1));
+  double* part = statPart_.get();
+  const int sc = F_.scaled ? 1 : 0;
+  launchRowStats2(vecs_, g, 0, axAvg_.get(), yAvg_.get(), rowScale_.get(), sc, part + (size_t)kStatRowCur * statStride_, statStride_, nbM,
+                  stream_);
+  launchColStats2(vecs_, g, 0, atyAvg_.get(), xAvg_.get(), colScale_.get(), hasQoff_ ? nxAvg_.get() : nullptr, sc, slackPos_.get(),
+                  slackNeg_.get(), slackPosAvg_.get(), slackNegAvg_.get(), part + (size_t)kStatColCur * statStride_, statStride_, nbN,
+                  stream_);
+  launchFinalReduce2(part, statStride_, 2 * kRowStats, nbM, 2 * kColStats, nbN, statOut_.get(), g, stream_);
+  CheckRecord* rec = hostRing_ + (checkSeq_ % kRingSlots);
+  rec->ran = 0;
+  ++checkSeq_;
+  launchCheckDecide(st, dCtl_.get(), statOut_.get(), rec, stream_);
+  const RestartVecs rv{xAvg_.get(), yAvg_.get(), axAvg_.get(), atyAvg_.get(), hasQoff_ ? nxAvg_.get() : nullptr, xLast_.get(), yLast_.get()};
+  launchRestartVec(vecs_, st, dCtl_.get(), rv, partDX_.get(), nbN, partRestartY_.get(), nbM, stream_);
+  launchRestartFinish(st, dCtl_.get(), partDX_.get(), nbN, partRestartY_.get(), nbM, rec, stream_);
+  needPrimal_ = true;  // (2-launch trial: the next batch starts with a stand-alone primal step, as after a host push)
+}
+
+// The records of the checks that have run since the last look: iteration log, restart notes.
+void Solver::processRecords(bool terminate, int64_t iterLim, int& logSinceHeader) {
+  for (; checkSeen_ < checkSeq_; ++checkSeen_) {
+    const CheckRecord& r = hostRing_[checkSeen_ % kRingSlots];
+    if (!r.ran) continue;  // the check was not due (a period that needed another batch; the queue behind a termination)
+    if (opt_.log_level > 0 && rank_ == 0) {
+      Residuals cur, avg;
+      memcpy(&cur, &r.cur, sizeof(cur));
+      memcpy(&avg, &r.avg, sizeof(avg));
+      if ((r.it % (kCheckInterval * 100) == 0) || (terminate && r.it == iterLim - 1)) logCheckLine(r.it, cur, avg, elapsed(), logSinceHeader);
+      if (r.restartKind) log(2, "Restart at iter %d to %s: beta = %g\n", r.it, r.restartKind == 1 ? "current" : "average", r.beta);
+    }
+  }
+}
+
+// PDHG_Solve (cupdlp_solver.c:899-1215) with the check iterations on the device.  The host enqueues units of
+// [trial batch to the next scheduled check][check] — `ahead` of them, doubling from 1 up to ~25 ms of queued work —
+// and only then synchronises: termination, time limit, the log and the tabulated powers of the step rule are looked
+// after once per round instead of once per check.  What the device does between two looks is exactly what the
+// host-driven loop (doSolve) does: same kernels for the trials, same statistics, the same scalar arithmetic.
+void Solver::doSolveDevice(bool terminate, int32_t target) {
+  DevState& s = *hostState_;
+  const int64_t iterLim = terminate ? (int64_t)opt_.iter_limit : (int64_t)target;
+  const int32_t interval = opt_.check_interval > 0 ? opt_.check_interval : kCheckInterval;
+  if (s.nIter >= iterLim) return;
+  uploadCtl(terminate, iterLim);
+  checkSeen_ = checkSeq_;
+  auto onSchedule = [&](int64_t it) { return it < 10 || it % interval == 0 || (terminate && it == (int64_t)opt_.iter_limit - 1); };
+  auto haltAfter = [&](int64_t it) {
+    int64_t h = nextCheckIter((int32_t)it);
+    if (!terminate && h > iterLim) h = iterLim;
+    return h;
+  };
+  // entry: a check is due right here (the device "halts" at the current iteration), or the device runs on to the next one
+  if (onSchedule(s.nIter)) {
+    s.haltIter = s.nIter;
+    s.halted = 1;
+  } else {
+    s.haltIter = (int32_t)haltAfter(s.nIter);
+    s.halted = 0;
+  }
+  pushState(false);
+  int logSinceHeader = 50;
+  int32_t ahead = 1, aheadMax = 16;
+  bool timeUp = false;
+  for (;;) {
+    const auto roundBeg = std::chrono::steady_clock::now();
+    const int32_t iterBefore = s.nIter, trialsBefore = s.nTrials;
+    const int64_t seq0 = checkSeq_;
+    int64_t itExp = s.nIter, haltExp = s.haltIter;
+    if (s.halted) {  // (entry only: every batch below is followed by its check)
+      enqueueCheckDevice();
+      haltExp = haltAfter(itExp);
+    }
+    int32_t units = 0;
+    for (int32_t u = 0; u < ahead; ++u) {
+      int64_t todo = haltExp - itExp;
+      if (todo < 1) todo = 1;
+      if (todo > 4 * kCheckInterval) todo = 4 * kCheckInterval;
+      // single launches carry their own spare trials (a rejected trial must not cost a host round trip)
+      const bool batched = persistent_ || (useGraph_ && todo >= kGraphMinTodo);
+      enqueueBatch((int32_t)todo + (batched ? 0 : todo >= 8 ? 2 : 1));
+      enqueueCheckDevice();
+      ++units;
+      itExp = std::min(itExp + todo, haltExp);
+      if (itExp >= iterLim || (terminate && itExp >= iterLim - 1)) break;  // the target / the check that ends the solve
+      if (itExp == haltExp) haltExp = haltAfter(itExp);
+    }
+    syncState();
+    processRecords(terminate, iterLim, logSinceHeader);
+    bool over = false;  // a check of this round has ended the solve (everything queued behind it was a no-op)
+    for (int64_t q = seq0; q < checkSeq_; ++q) over = over || (hostRing_[q % kRingSlots].ran && hostRing_[q % kRingSlots].terminated);
+    if (over) break;
+    if (!terminate && s.nIter >= iterLim) break;
+    // The reference's step-size search is a `while (!accepted)` loop: with NaN / Inf in the data it never ends.
+    if (s.nIter == iterBefore && s.nTrials - trialsBefore > 0) {
+      if (++stalledRounds_ >= 50)
+        throw std::runtime_error("pdlp_mi355x: the adaptive step-size search does not terminate (no trial step accepted in " +
+                                 std::to_string(s.nTrials - stalledSince_) + " trials: NaN or Inf in the problem data?)");
+    } else {
+      stalledRounds_ = 0;
+      stalledSince_ = s.nTrials;
+    }
+    if (timeIsUp()) { timeUp = true; break; }
+    // tabulated powers of the step rule: kept ahead of the trial counter while the stream is idle
+    if (s.powRed && s.nTrials + 1024 >= s.powBase + s.powCount) pushState(false);
+    // queue depth: ~25 ms of work, at most 16 units
+    const double roundMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - roundBeg).count();
+    if (units > 0 && roundMs > 0.0) aheadMax = std::max(1, std::min(16, (int32_t)(25.0 * units / roundMs)));
+    ahead = std::min(ahead * 2, aheadMax);
+  }
+  downloadCtl();
+  if (timeUp) {
+    // The time limit: the reference checks at once and stops (cupdlp_solver.c:953-962).  The device stands right behind
+    // a check (fresh residuals) unless a period was cut short by rejected trials — then one host-driven check.
+    if (s.nIter != hostCtl_->lastCheckIter) {
+      computeAverage();
+      computeResiduals();
+      ++nChecks_;
+    }
+    logCheckLine(s.nIter, cur_, avg_, elapsed(), logSinceHeader);
+    if (terminate) {
+      if (checkTermination(cur_)) { termIterate_ = 0; termCode_ = PDLP_TERM_OPTIMAL; }
+      else if (checkTermination(avg_)) { termIterate_ = 1; termCode_ = PDLP_TERM_OPTIMAL; }
+      else if (checkInfeasibility()) termCode_ = PDLP_TERM_INFEASIBLE_OR_UNBOUNDED;
+      else termCode_ = PDLP_TERM_TIMELIMIT_OR_ITERLIMIT;
+    }
+  }
 }
 
 // PDHG_Solve, cupdlp_solver.c:899-1215.  `terminate` false = fixed-work timing loop.
@@ -1277,20 +1499,7 @@ void Solver::doSolve(bool terminate, int32_t target) {
     computeAverage();
     computeResiduals();
     ++nChecks_;
-    if (opt_.log_level > 0 && rank_ == 0) {
-      const bool print = (it % (kCheckInterval * 100) == 0) || it == iterLim - 1 || timeUp;
-      if (print) {
-        if (logSinceHeader >= 50) {
-          logLine(opt_, 1, "%9s  %15s  %15s   %8s  %10s  %8s %7s\n", "Iter", "Primal.Obj", "Dual.Obj", "Gap", "Primal.Inf",
-                 "Dual.Inf", "Time");
-          logSinceHeader = 0;
-        }
-        const Residuals& r = it == 0 ? cur_ : avg_;
-        logLine(opt_, 1, "%9d  %+15.8e  %+15.8e  %+8.2e  %10.2e  %8.2e %6.2fs [%c]\n", it, r.pObj, r.dObj, r.relGap,
-               r.pFeas / (1.0 + F_.normRhs), r.dFeas / (1.0 + F_.normCost), t, it == 0 ? 'L' : 'A');
-        ++logSinceHeader;
-      }
-    }
+    if ((it % (kCheckInterval * 100) == 0) || it == iterLim - 1 || timeUp) logCheckLine(it, cur_, avg_, t, logSinceHeader);
     if (terminate) {
       if (checkTermination(cur_)) { termIterate_ = 0; termCode_ = PDLP_TERM_OPTIMAL; break; }
       if (checkTermination(avg_)) { termIterate_ = 1; termCode_ = PDLP_TERM_OPTIMAL; break; }
@@ -1312,7 +1521,8 @@ void Solver::run(pdlp_result_t* R) {
   reset();
   solveBeg_ = std::chrono::steady_clock::now();
   if (hasStart_) log(1, "Hot starting with given column primal values and row dual values\n");
-  doSolve(true, 0);
+  if (devCheck_ && !profile_) doSolveDevice(true, 0);
+  else doSolve(true, 0);
   solveSeconds_ = elapsed();
   if (opt_.log_level > 0 && rank_ == 0) {
     const Residuals& r = (termCode_ == PDLP_TERM_OPTIMAL && termIterate_ == 1) ? avg_ : cur_;
@@ -1341,7 +1551,8 @@ void Solver::iterate(int32_t nIters, pdlp_iter_stats_t* st) {
   PDLP_HIP(hipEventCreate(&e0));
   PDLP_HIP(hipEventCreate(&e1));
   PDLP_HIP(hipEventRecord(e0, stream_));
-  doSolve(false, it0 + nIters);
+  if (devCheck_ && !profile_) doSolveDevice(false, it0 + nIters);
+  else doSolve(false, it0 + nIters);
   PDLP_HIP(hipEventRecord(e1, stream_));
   PDLP_HIP(hipEventSynchronize(e1));
   float ms = 0.f;

@@ -109,6 +109,7 @@ class Solver : public SolverBase {
   void applyHotStart();
   // hot loop
   void enqueueTrial();
+  void enqueueBatch(int32_t todo);  // trials up to the next halt: one persistent launch / the captured graph / single trials
   void captureGraph();
   void runUntilHalt();
   void syncState();    // device -> host_
@@ -120,7 +121,13 @@ class Solver : public SolverBase {
   bool checkInfeasibility();
   void restartIterate();
   int32_t nextCheckIter(int32_t it) const;
-  void doSolve(bool terminate, int32_t iterBudget);
+  void doSolve(bool terminate, int32_t iterBudget);        // check iterations driven by the host (sharded paths, profile mode)
+  void doSolveDevice(bool terminate, int32_t iterBudget);  // check iterations on the device, several periods queued ahead
+  void enqueueCheckDevice();
+  void uploadCtl(bool terminate, int64_t iterLim);
+  void downloadCtl();
+  void processRecords(bool terminate, int64_t iterLim, int& logSinceHeader);
+  void logCheckLine(int32_t it, const Residuals& cur, const Residuals& avg, double t, int& logSinceHeader) const;
   void postsolve(pdlp_result_t* R);
   // linear algebra on device (sharding-aware)
   void deviceAx(const double* x, double* axLocal);
@@ -186,6 +193,14 @@ class Solver : public SolverBase {
   int32_t smallGrid_ = 0;
   DeviceArray<unsigned long long> gridBar_;
   int32_t stalledRounds_ = 0, stalledSince_ = 0;  // consecutive device stops without an accepted trial
+  // Device-driven check iterations (pdlp_kernels.hpp CheckCtl; PDLP_MI355X_DEVICE_CHECK=0 gives the host-driven loop back)
+  bool devCheck_ = true;
+  DeviceArray<CheckCtl> dCtl_;
+  CheckCtl* hostCtl_ = nullptr;      // pinned staging copy
+  CheckRecord* hostRing_ = nullptr;  // pinned: one record per queued check, written by the device
+  static constexpr int32_t kRingSlots = 64;
+  int64_t checkSeq_ = 0, checkSeen_ = 0;  // checks enqueued / records looked at
+  DeviceArray<double> partRestartY_;
   DevState* dst() const { return dState_.get() + stPar_; }
   DeviceArray<double> powRed_, powGrow_;  // host-tabulated powers of the trial counter (see DevState)
   void refreshPowTable();

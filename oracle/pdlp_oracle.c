@@ -419,7 +419,11 @@ static void o_Nx(const Work* w, double* nx, const double* x) {
 /* serial loops above; the ONLY arithmetic difference is the summation */
 /* order of its reductions (per-lane strided accumulation, 64-lane     */
 /* shuffle tree, fixed-order sum of 4 wave results, 4-chain sum of     */
-/* per-block partials).  This section restates those orders exactly   */
+/* per-block partials) — and, since round 4, the exp / log of the      */
+/* restart's primal-weight update, which the device computes with the  */
+/* product's own plain-arithmetic functions (pdlp_detmath.h, < 1 ulp   */
+/* from libm) instead of the host's libm.                              */
+/* This section restates those orders exactly                          */
 /* (highs_amd/csrc/pdlp_kernels.hip: waveSum, blockSum, reducePartials,*/
 /* k_spmv epilogues, k_row_stats, k_col_stats, k_diff_norm2, k_dot)    */
 /* for the CSR-stream layout, so that a whole GPU solve can be checked */
@@ -428,6 +432,7 @@ static void o_Nx(const Work* w, double* nx, const double* x) {
 /* nonzeros / 2048 majors per work block, vector grids capped at 2048. */
 /* ------------------------------------------------------------------ */
 #include "gpu_order.h"
+#include "../highs_amd/csrc/pdlp_detmath.h" /* (test infrastructure may read a product header, never the other way round) */
 /* planStream (pdlp_host.cpp): blocks of whole majors with at most `chunk` entries in total; a major longer than
  * chunk belongs to no block.  Returns [2*nBlocks] (first, end) pairs. */
 static int* g_plan(const int* beg, int nMajor, int chunk, int* nBlocksOut) {
@@ -998,8 +1003,13 @@ static void step_size_ratio(Work* w) {
     dD = o_nrm2(m, d);
   }
   if (fmin(dP, dD) > 1e-10) {
-    const double lg = 0.5 * log(dD / dP) + 0.5 * log(sqrt(w->beta));
-    w->beta = exp(lg) * exp(lg);
+    if (w->gpuOrder) { /* the product's exp / log (pdlp_detmath.h: plain IEEE arithmetic, the same bits on host and device) */
+      const double lg = 0.5 * pdlp_det_log(dD / dP) + 0.5 * pdlp_det_log(sqrt(w->beta));
+      w->beta = pdlp_det_exp(lg) * pdlp_det_exp(lg);
+    } else { /* the reference: libm (cupdlp_step.c:165-170) */
+      const double lg = 0.5 * log(dD / dP) + 0.5 * log(sqrt(w->beta));
+      w->beta = exp(lg) * exp(lg);
+    }
   }
   w->primalStep = mean / sqrt(w->beta);
   w->dualStep = w->primalStep * w->beta;
@@ -1282,6 +1292,11 @@ void pdlp_oracle_spmv_csr(int m, const int* beg, const int* idx, const double* v
     for (int p = beg[i]; p < beg[i + 1]; ++p) s += val[p] * x[idx[p]];
     out[i] = s;
   }
+}
+
+/* exp and log as the product computes them (highs_amd/csrc/pdlp_detmath.h), for the accuracy test against libm */
+void pdlp_oracle_det_exp_log(int n, const double* x, double* expOut, double* logOut) {
+  for (int i = 0; i < n; ++i) { expOut[i] = pdlp_det_exp(x[i]); logOut[i] = pdlp_det_log(x[i]); }
 }
 
 /* the same in the product's summation order: majors with more than long_limit entries are cut into segment tasks

@@ -44,7 +44,8 @@ def oracle():
     global _oracle
     if _oracle is None:
         path = os.path.join(ORACLE_DIR, "liboracle.so")
-        srcs = [os.path.join(ORACLE_DIR, f) for f in ("pdlp_oracle.c", "hipdlp_oracle.c")]
+        srcs = [os.path.join(ORACLE_DIR, f) for f in ("pdlp_oracle.c", "hipdlp_oracle.c", "gpu_order.h",
+                                                       "../highs_amd/csrc/pdlp_detmath.h")]
         if not os.path.exists(path) or os.path.getmtime(path) < max(os.path.getmtime(f) for f in srcs):
             build_oracle()
         lib = C.CDLL(path)
@@ -57,6 +58,7 @@ def oracle():
         lib.pdlp_oracle_free_formulated.argtypes = [C.POINTER(Formulated)]
         lib.pdlp_oracle_spmv_csr.argtypes = [C.c_int, abi.c_i32p, abi.c_i32p, abi.c_f64p, abi.c_f64p, abi.c_f64p]
         lib.pdlp_oracle_spmv_csr_device_order.argtypes = lib.pdlp_oracle_spmv_csr.argtypes + [C.c_int]
+        lib.pdlp_oracle_det_exp_log.argtypes = [C.c_int, abi.c_f64p, abi.c_f64p, abi.c_f64p]
         lib.pdlp_oracle_trial_step.argtypes = [C.POINTER(Formulated), C.c_double, C.c_double] + [abi.c_f64p] * 9
         _oracle = lib
     return _oracle

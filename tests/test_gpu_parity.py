@@ -568,6 +568,38 @@ def test_trial_loop_variants_give_the_same_bits(name, iters, monkeypatch):
         assert ref[3:5] == o[3:5], vname
 
 
+@pytest.mark.parametrize("name", ["afiro", "25fv47", "standata", "synthetic-stream", "synthetic-slab", "qp"])
+def test_device_driven_checks_give_the_bits_of_host_driven_checks(name, monkeypatch):
+    """Since round 4 the check iteration (residuals, termination, restart, primal-weight update) runs on the device
+    behind the trial batch, several periods queued ahead of the host (pdlp_check.hip, Solver::doSolveDevice);
+    PDLP_MI355X_DEVICE_CHECK=0 gives the host-driven loop back (what the sharded paths run).  Same kernels for the
+    statistics, the same scalar arithmetic: complete solves must agree bit for bit — status, iteration / trial /
+    restart counts, residuals, every solution vector."""
+    sp_ = None
+    if name == "synthetic-stream":
+        sp_ = solver.SyntheticProblem(30000, 25000, 200000, 3)
+        lp, kw = sp_.to_lp(), dict(kkt_tolerance=1e-5)
+    elif name == "synthetic-slab":  # gathered vectors beyond 2^18 entries: slab layout, 2-launch fused trial, hipGraph batches
+        sp_ = solver.SyntheticProblem(300000, 280000, 2000000, 5)
+        lp, kw = sp_.to_lp(), dict(kkt_tolerance=1e-4, pdlp_iteration_limit=2500)
+    elif name == "qp":
+        lp, kw = L.HighsLp.from_npz(os.path.join(GOLD, "qp", "qp0.npz")), dict(kkt_tolerance=1e-8)
+    else:
+        lp, kw = _lp(name), {}
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("PDLP_MI355X_DEVICE_CHECK", mode)
+        out[mode] = solver.solveLpCupdlp(lp, **kw)
+    if sp_ is not None:
+        sp_.close()
+    a, b = out["0"].result, out["1"].result
+    assert (a.term_code, a.term_iterate, a.num_iter, a.num_trials, a.num_restarts) == (b.term_code, b.term_iterate, b.num_iter, b.num_trials, b.num_restarts)
+    assert (a.primal_obj, a.dual_obj, a.primal_feas, a.dual_feas, a.rel_gap) == (b.primal_obj, b.dual_obj, b.primal_feas, b.dual_feas, b.rel_gap)
+    for v in ("col_value", "col_dual", "row_value", "row_dual"):
+        assert np.array_equal(getattr(out["0"].solution, v), getattr(out["1"].solution, v)), v
+    assert b.num_iter > 0
+
+
 def test_concurrent_solver_contexts_on_two_threads():
     """SURVEY §8b threading contract: several Highs instances may call the path concurrently from different
     threads, so a context holds no process-global mutable state.  Two threads solve different LPs (both

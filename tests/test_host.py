@@ -219,3 +219,21 @@ def test_lp_without_constraints_is_refused_by_the_oracle_not_looped_on():
                    np.array([0, 0, 0], np.int32), np.zeros(0, np.int32), np.zeros(0), 1, 0.0, "norows").normalise()
     with pytest.raises(RuntimeError):
         O.oracle_solve(lp, kkt_tolerance=1e-6, pdlp_iteration_limit=1000)
+
+
+def test_plain_arithmetic_exp_log_within_one_ulp_of_libm():
+    """pdlp_detmath.h (the primal-weight update of a device-driven restart): exp and log in plain IEEE arithmetic, the
+    same bits on host and device; here the gcc build against numpy's libm results, error in units of the last place."""
+    rng = np.random.default_rng(7)
+    x = np.concatenate([rng.uniform(-700, 700, 200000), rng.uniform(-10, 10, 200000), rng.uniform(-1, 1, 200000),
+                        rng.uniform(-1e-3, 1e-3, 100000), [0.0, 1.0, -1.0, 709.0, -745.0]])
+    y = np.concatenate([np.exp(rng.uniform(-700, 700, 300000)), np.exp(rng.uniform(-2, 2, 300000)), [1.0, 2.0, 0.5, 5e-324, 1e308]])
+    e, l = np.zeros(len(x)), np.zeros(len(x))
+    O.oracle().pdlp_oracle_det_exp_log(len(x), x.ctypes.data_as(abi.c_f64p), e.ctypes.data_as(abi.c_f64p), l.ctypes.data_as(abi.c_f64p))
+    ref = np.exp(x.astype(np.longdouble))
+    assert np.max(np.abs(e - ref) / np.spacing(np.abs(ref.astype(np.float64)))) < 1.0
+    e2, l2 = np.zeros(len(y)), np.zeros(len(y))
+    O.oracle().pdlp_oracle_det_exp_log(len(y), y.ctypes.data_as(abi.c_f64p), e2.ctypes.data_as(abi.c_f64p), l2.ctypes.data_as(abi.c_f64p))
+    refl = np.log(y.astype(np.longdouble))
+    err = np.abs(l2 - refl) / np.maximum(np.spacing(np.abs(refl.astype(np.float64))), 5e-324)
+    assert np.max(err[refl != 0]) < 1.0 and l2[len(y) - 5] == 0.0
