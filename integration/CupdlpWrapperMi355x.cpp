@@ -25,11 +25,21 @@
 
 #include "lp_data/HighsLpSolverObject.h"
 #include "lp_data/HighsSolution.h"
+#include "model/HighsHessian.h"
 #include "pdlp_mi355x.h"
 
 HighsStatus solveLpCupdlp(const HighsOptions& options, HighsTimer& timer, const HighsLp& lp,
                           HighsBasis& highs_basis, HighsSolution& highs_solution,
                           HighsModelStatus& model_status, HighsInfo& highs_info, HighsCallback& callback);
+// QPs on the same path.  The reference gates solver="pdlp" to LPs (lp_data/HighsOptions.cpp:1178-1181
+// solverValidForQp, lp_data/Highs.cpp:4139 callSolveQp); integration/qp_gate_patch.py lifts that gate in build-time
+// COPIES of those two TUs (libhighs_qp.so.1), whose callSolveQp then calls this function when solver == "pdlp".
+HighsStatus solveQpPdlpMi355x(const HighsOptions& options, HighsTimer& timer, const HighsLp& lp, const HighsHessian& hessian,
+                              HighsBasis& highs_basis, HighsSolution& highs_solution, HighsModelStatus& model_status,
+                              HighsInfo& highs_info, HighsCallback& callback);
+static HighsStatus solveOnMi355x(const HighsOptions& options, const HighsLp& lp, const HighsHessian* hessian,
+                                 HighsBasis& highs_basis, HighsSolution& highs_solution, HighsModelStatus& model_status,
+                                 HighsInfo& highs_info);
 
 HighsStatus solveLpCupdlp(HighsLpSolverObject& solver_object) {
   return solveLpCupdlp(solver_object.options_, solver_object.timer_, solver_object.lp_, solver_object.basis_,
@@ -42,6 +52,20 @@ HighsStatus solveLpCupdlp(const HighsOptions& options, HighsTimer& timer, const 
                           HighsModelStatus& model_status, HighsInfo& highs_info, HighsCallback& callback) {
   (void)timer;
   (void)callback;  // accepted but unused, as in the reference
+  return solveOnMi355x(options, lp, nullptr, highs_basis, highs_solution, model_status, highs_info);
+}
+
+HighsStatus solveQpPdlpMi355x(const HighsOptions& options, HighsTimer& timer, const HighsLp& lp, const HighsHessian& hessian,
+                              HighsBasis& highs_basis, HighsSolution& highs_solution, HighsModelStatus& model_status,
+                              HighsInfo& highs_info, HighsCallback& callback) {
+  (void)timer;
+  (void)callback;
+  return solveOnMi355x(options, lp, &hessian, highs_basis, highs_solution, model_status, highs_info);
+}
+
+static HighsStatus solveOnMi355x(const HighsOptions& options, const HighsLp& lp, const HighsHessian* hessian,
+                                 HighsBasis& highs_basis, HighsSolution& highs_solution, HighsModelStatus& model_status,
+                                 HighsInfo& highs_info) {
   resetModelStatusAndHighsInfo(model_status, highs_info);
 
   // HighsLp -> pdlp_problem_t: zero-copy views of HiGHS' own storage (column-wise matrix)
@@ -59,6 +83,13 @@ HighsStatus solveLpCupdlp(const HighsOptions& options, HighsTimer& timer, const 
   P.row_upper = lp.row_upper_.data();
   P.offset = lp.offset_;
   P.sense = lp.sense_ == ObjSense::kMaximize ? -1 : 1;
+  if (hessian && hessian->dim_ > 0) {
+    // HighsHessian as HiGHS holds it (model/HighsHessian.h:22-34): lower triangle, column-wise — what pdlp_problem_t takes
+    P.q_dim = hessian->dim_;
+    P.q_start = hessian->start_.data();
+    P.q_index = hessian->index_.data();
+    P.q_value = hessian->value_.data();
+  }
 
   // hot start: the incumbent HighsSolution, used only when both parts are valid
   // (PDHG_PreSolve semantics; tests pdlp-restart*, check/TestPdlp.cpp:241-327)

@@ -4,9 +4,13 @@
  * unmodified C client of HiGHS does.  LP = the "distillation" LP of the reference's own PDLP unit test
  * (check/TestPdlp.cpp:22-61, check/SpecialLps.h:278-296; optimal objective 31.2).
  * Usage: capi_check [solver]     solver = pdlp (default) | hipdlp
+ *        capi_check solver model-file [kkt_tolerance]     Highs_readModel + Highs_run on a model file (LP or QP: the
+ *                                         QP case needs libhighs_qp.so.1, see integration/Makefile) — prints the line
+ *                                         the tests parse, exit code 0 = model status optimal
  * Exit code 0 = optimal with the expected objective and a primal-feasible solution. */
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "interfaces/highs_c_api.h"
@@ -23,6 +27,24 @@ int main(int argc, char** argv) {
   const HighsInt a_index[6] = {0, 1, 2, 0, 1, 2};
   const double a_value[6] = {2.0, 3.0, 2.0, 2.0, 4.0, 1.0};
 
+  if (argc > 2) { /* a model file through the reference's reader entry point */
+    void* h = Highs_create();
+    if (!h) return 2;
+    Highs_setBoolOptionValue(h, "output_flag", 1);
+    if (Highs_setStringOptionValue(h, "solver", solver) != kHighsStatusOk) return 3;
+    Highs_setStringOptionValue(h, "presolve", "off");
+    Highs_setDoubleOptionValue(h, "kkt_tolerance", argc > 3 ? atof(argv[3]) : 1e-6);
+    if (Highs_readModel(h, argv[2]) == kHighsStatusError) return 4;
+    const HighsInt rs = Highs_run(h);
+    const HighsInt ms = Highs_getModelStatus(h);
+    HighsInt it = -1, qn = -1;
+    Highs_getIntInfoValue(h, "pdlp_iteration_count", &it);
+    Highs_getIntInfoValue(h, "qp_iteration_count", &qn);
+    printf("capi_check: solver=%s file=%s run_status=%d model_status=%d objective=%.12g pdlp_iteration_count=%d qp_iteration_count=%d hessian_nz=%d\n",
+           solver, argv[2], (int)rs, (int)ms, Highs_getObjectiveValue(h), (int)it, (int)qn, (int)Highs_getHessianNumNz(h));
+    Highs_destroy(h);
+    return ms == kHighsModelStatusOptimal ? 0 : 10;
+  }
   void* highs = Highs_create();
   if (!highs) return 2;
   Highs_setBoolOptionValue(highs, "output_flag", 1);

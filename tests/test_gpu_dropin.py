@@ -89,6 +89,49 @@ def test_c_api_client(tmp_path, which):
     assert "model_status=7" in out.stdout
 
 
+REF_QP = dict(json.load(open(os.path.join(GOLD, "reference_qp.json"))), **json.load(open(os.path.join(GOLD, "reference_qp_sparse.json"))))
+
+
+@needs_build
+@pytest.mark.parametrize("name", ["qjh_mps", "qjh_qmatrix_mps", "qptestnw_lp", "qp3", "qp7", "sq5", "sq100"])
+def test_qp_through_highs_run_with_the_gate_lifted(tmp_path, name):
+    """SURVEY §8(f)-3 through the reference's own entry point: libhighs_qp.so.1 = the drop-in libhighs with the two gate
+    TUs (lp_data/HighsOptions.cpp:1178-1181 solverValidForQp, lp_data/Highs.cpp:4139 callSolveQp) replaced by build-time
+    copies carrying two edits (integration/qp_gate_patch.py).  A plain C client (capi_check.c: Highs_readModel,
+    solver=pdlp, Highs_run) then solves the reference's own QP instances and random convex QPs on the MI355X path and
+    must reach the optimum of the reference's QP solver (tests/golden/reference_qp*.json) — check/TestQpSolver.cpp's
+    objective asserts, at 1e-6 relative."""
+    assert os.path.exists(os.path.join(BUILD, "capi_check_qp")), "make -C integration (libhighs_qp.so.1, capi_check_qp)"
+    lp = L.HighsLp.from_npz(os.path.join(GOLD, "qp", name + ".npz"))
+    mps = os.path.join(str(tmp_path), name + ".mps")
+    L.write_mps(lp, mps)
+    out = subprocess.run([os.path.join(BUILD, "capi_check_qp"), "pdlp", mps, "1e-8"], capture_output=True, text=True, timeout=300,
+                         env=_env(), cwd=str(tmp_path))
+    txt = out.stdout + out.stderr
+    m = re.search(r"capi_check: .*model_status=(\d+) objective=(\S+) pdlp_iteration_count=(-?\d+) qp_iteration_count=(-?\d+) hessian_nz=(\d+)", txt)
+    assert m, txt[-2000:]
+    status, obj, it, qit, hnz = int(m[1]), float(m[2]), int(m[3]), int(m[4]), int(m[5])
+    ref = REF_QP[name]["objective_value"]
+    assert "MI355X" in txt and "Quadratic objective" in txt  # the library's banner: the QP went down the PDLP path ...
+    assert it > 0 and qit <= 0 and hnz > 0                    # ... not to the active-set solver
+    assert status == 7, txt[-1500:]                           # kHighsModelStatusOptimal
+    assert abs(obj - ref) <= 1e-6 * (1 + abs(ref)), (obj, ref)
+
+
+@needs_build
+def test_unpatched_libhighs_keeps_the_reference_gate(tmp_path):
+    """The plain drop-in (libhighs.so.1) leaves the gate where the reference has it: solver=pdlp on a QP warns and runs the
+    reference's own QP solver (lp_data/Highs.cpp:1367)."""
+    lp = L.HighsLp.from_npz(os.path.join(GOLD, "qp", "qjh_mps.npz"))
+    mps = os.path.join(str(tmp_path), "qjh.mps")
+    L.write_mps(lp, mps)
+    out = subprocess.run([os.path.join(BUILD, "capi_check"), "pdlp", mps], capture_output=True, text=True, timeout=300, env=_env(),
+                         cwd=str(tmp_path))
+    txt = out.stdout + out.stderr
+    assert "not available for QP" in txt and re.search(r"qp_iteration_count=[1-9]", txt), txt[-1500:]
+    assert abs(float(re.search(r"objective=(\S+)", txt)[1]) + 5.25) < 1e-6
+
+
 @needs_build
 def test_reference_cli_sharded_over_two_ranks(tmp_path):
     """Multi-GPU BEHIND the boundary: PDLP_MI355X_DEVICES=2 makes pdlp_mi355x_solve (what Highs::run reaches)
