@@ -242,32 +242,94 @@ __device__ __forceinline__ double ldAgent(const double* p) {
 // at least the epoch (a fast block may already stand at the launch's next barrier).  One store and one sweep: no
 // atomic round trips, no counter to reset (measured the same as the XCD-hierarchical counter barrier it replaced in
 // the fused trial: 64.0 us per launch either way).  Epochs grow with the trial counter (the words are zeroed when a
-// solve starts).  A wait that does not end (a block that is not resident) gives up after ~1 s and raises the flag
-// word instead of hanging the device.  LOCAL: every block sits on ONE XCD (the caller has checked it): the words go
-// through that XCD's L2 — ordinary stores, non-temporal (L1-bypassing) loads — instead of through memory.
+// solve starts).  LOCAL: every block sits on ONE XCD (the caller has checked it): the words go through that XCD's L2
+// — ordinary stores, non-temporal (L1-bypassing) loads — instead of through memory.
+//   Not every block may be resident: plain launches promise nothing about co-residency, and a second tenant of the
+// device (another process, another stream) can hold the CUs a block of this grid needs.  A wait that has not ended
+// after limitTicks (100 MHz wall clock; Solver: PDLP_MI355X_BARRIER_TIMEOUT_MS, 1 s) gives up: the block POISONS its
+// own arrival word (bit 62: still >= every epoch, so nobody waits for it any more) and raises the flag word behind
+// the arrival words; every sweep that meets a poisoned word fails too — the blocks that time out, the ones that sweep
+// later and the stragglers that only start once the others have left all return false, so a barrier either holds for
+// every block or for none (the poison is set before any straggler arrives, i.e. before any sweep can complete; a
+// sweep pass that straddles the two events by a microsecond would be the exception — the poison is sticky, so the
+// NEXT barrier of any block then meets a poisoned word of an older epoch and reports kBarBroken: an error, never a
+// silently wrong iterate).  On kBarFailed the caller leaves the trial undecided and the host falls back to plain
+// launches (Solver::syncState).
+constexpr unsigned long long kBarPoison = 1ull << 62;
+enum : int { kBarOk = 0, kBarFailed = 1, kBarBroken = 2 };
 template <bool LOCAL = false>
-__device__ __forceinline__ void gridBarrier(unsigned long long* bar, int blk, int nBlocks, unsigned long long epoch, int lane) {
+__device__ __forceinline__ int gridBarrier(unsigned long long* bar, int blk, int nBlocks, unsigned long long epoch, int lane,
+                                            unsigned long long limitTicks) {
   auto ld = [&](const unsigned long long* p) -> unsigned long long {
     if (!LOCAL) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned long long v;
     asm volatile("global_load_dwordx2 %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
     return v;
   };
+  auto st = [&](unsigned long long* p, unsigned long long v) {
+    if (LOCAL) *reinterpret_cast<volatile unsigned long long*>(p) = v;
+    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
   if (lane == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this block's published words have landed
-    if (LOCAL) { *reinterpret_cast<volatile unsigned long long*>(bar + blk) = epoch; }
-    else __hip_atomic_store(bar + blk, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    st(bar + blk, epoch);
   }
+  const unsigned long long t0 = wall_clock64();
   for (uint32_t spins = 0;; ++spins) {
-    bool ok = true;
-    for (int i = lane; i < nBlocks; i += kWave) ok = ok && ld(bar + i) >= epoch;
-    if (__all(ok)) break;
+    bool ok = true, bad = false, stale = false;
+    for (int i = lane; i < nBlocks; i += kWave) {
+      const unsigned long long v = ld(bar + i);
+      ok = ok && v >= epoch;
+      bad = bad || (v & kBarPoison) != 0;
+      stale = stale || ((v & kBarPoison) != 0 && (v & ~kBarPoison) < epoch);
+    }
+    if (__any(stale)) return kBarBroken;
+    if (__any(bad)) return kBarFailed;
+    if (__all(ok)) return kBarOk;
     __builtin_amdgcn_s_sleep(1);
-    if (spins > (1u << 23)) {
-      if (lane == 0) __hip_atomic_store(bar + nBlocks, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      break;
+    if ((spins & 31u) == 31u && wall_clock64() - t0 > limitTicks) {
+      if (lane == 0) {
+        st(bar + blk, epoch | kBarPoison);
+        __hip_atomic_store(bar + nBlocks, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      return kBarFailed;
     }
   }
+}
+
+// Roll call at the START of a launch whose workgroups will meet at grid barriers: before it has written anything,
+// every workgroup adds itself to one counter word (zeroed by the host in front of the launch) and waits until all G
+// have.  If they do not within limitTicks — the device is shared and not all of them fit next to the other tenant's
+// work — the launch must change NOTHING and say so, and that verdict has to be the same in every workgroup, also in
+// one that only starts after the others have given up.  Hence one word decides: a workgroup that gives up sets the
+// poison bit with a compare-and-swap that fails once the count is complete; an arrival that finds the poison bit (its
+// own fetch-add returns it) leaves at once; a waiter that reads the complete count without the bit has won for good —
+// the count never drops and the bit can no longer be set.  Called by wave 0; the verdict is returned in every lane.
+__device__ __forceinline__ bool rollCall(unsigned long long* word, int G, unsigned long long limitTicks, int lane) {
+  int verdict = 0;  // 1: everybody is here, 2: not this time
+  if (lane == 0) {
+    unsigned long long v = __hip_atomic_fetch_add(word, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
+    const unsigned long long t0 = wall_clock64();
+    for (uint32_t spins = 0;; ++spins) {
+      if (v & kBarPoison) { verdict = 2; break; }
+      if ((long long)(v & 0xffffffffull) >= (long long)G) { verdict = 1; break; }
+      __builtin_amdgcn_s_sleep(2);
+      if ((spins & 15u) == 15u && wall_clock64() - t0 > limitTicks) {
+        unsigned long long cur = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (;;) {
+          if (cur & kBarPoison) { verdict = 2; break; }
+          if ((long long)(cur & 0xffffffffull) >= (long long)G) { verdict = 1; break; }
+          if (__hip_atomic_compare_exchange_strong(word, &cur, cur | kBarPoison, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            verdict = 2;
+            break;
+          }
+        }
+        break;
+      }
+      v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  return __shfl(verdict, 0) == 1;
 }
 
 // XCD-hierarchical grid barrier for HUNDREDS of resident blocks on all XCDs.  With the sweep above every block polls
@@ -286,6 +348,7 @@ __device__ __forceinline__ void gridBarrier(unsigned long long* bar, int blk, in
 constexpr int kXccSlots = 16;   // XCC_ID has four bits
 constexpr int kXccStride = 32;  // words between two XCDs' words: 256 bytes
 struct HierBar {
+  unsigned long long limit;  // 100 MHz ticks a wait may last
   unsigned long long* base;  // 4 arrays of kXccSlots * kXccStride words: registration counts, arrival counters, L2 release words, agent-scope XCD words
   unsigned long long* flag;  // timeout flag
   int xcc, nLocal;
@@ -312,6 +375,7 @@ __device__ __forceinline__ void hierBarrier(const HierBar& h, unsigned long long
     if (lane == 0) __hip_atomic_store(h.flag, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   unsigned long long old = 0;
+  const unsigned long long t0 = wall_clock64();
   if (lane == 0) old = __hip_atomic_fetch_add(h.cnt(h.xcc), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   old = __shfl(old, 0);
   if (old + 1 == k * (unsigned long long)h.nLocal) {  // the last block of this XCD
@@ -320,14 +384,14 @@ __device__ __forceinline__ void hierBarrier(const HierBar& h, unsigned long long
       bool ok = true;
       if (lane < kXccSlots && ((h.active >> lane) & 1u)) ok = __hip_atomic_load(h.glob(lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= k;
       if (__all(ok)) break;
-      if (spins > (1u << 22)) { giveUp(); break; }
+      if ((spins & 63u) == 63u && wall_clock64() - t0 > h.limit) { giveUp(); break; }
     }
     if (lane == 0) *reinterpret_cast<volatile unsigned long long*>(h.rel(h.xcc)) = k;
   } else {
     for (uint32_t spins = 0;; ++spins) {
       if (ldL2(h.rel(h.xcc)) >= k) break;
       __builtin_amdgcn_s_sleep(1);
-      if (spins > (1u << 23)) { giveUp(); break; }
+      if ((spins & 63u) == 63u && wall_clock64() - t0 > h.limit) { giveUp(); break; }
     }
   }
 }

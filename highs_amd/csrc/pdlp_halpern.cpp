@@ -50,10 +50,10 @@ void HalpernSolver::construct(const pdlp_problem_t& P, const void* id128) {
     throw std::runtime_error("pdlp_mi355x: no HIP device available (this library has no CPU fallback)");
   PDLP_HIP(hipSetDevice(opt_.device));
   PDLP_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-  if (const char* g = getenv("PDLP_MI355X_GRAPH")) useGraph_ = atoi(g) != 0;
+  const DevSwitches sw = DevSwitches::fromEnv();  // the environment, once per solver
+  if (sw.graph >= 0) useGraph_ = sw.graph != 0;
   if (world_ < 1 || rank_ < 0 || rank_ >= world_) throw std::runtime_error("bad rank/world");
-  const char* fc = getenv("PDLP_MI355X_FORCE_COMM");
-  sharded_ = world_ > 1 || (fc && atoi(fc) != 0);
+  sharded_ = world_ > 1 || sw.forceComm != 0;
   if (rank_ == 0) log(1, "Solving with HiPDLP (restarted Halpern PDHG) on MI355X (gfx950, HIP)\n");
   if ((opt_.features_off & PDLP_FEATURE_RESTART_OFF) != 0)
     log(1, "HiPDLP uses Halpern restart only; ignoring the restart-off feature flag.\n");  // pdhg.cc:1846-1852
@@ -72,13 +72,11 @@ void HalpernSolver::construct(const pdlp_problem_t& P, const void* id128) {
       if (P.q_value[p] != 0.0)
         throw std::runtime_error("pdlp_mi355x: quadratic objectives are solved by the pdlp path only (algorithm = 0)");
   const bool doScale = !(opt_.features_off & PDLP_FEATURE_SCALING_OFF);
-  int slabMode = -1;
-  if (const char* g = getenv("PDLP_MI355X_SLAB")) slabMode = atoi(g);
   // preprocessing + scaling + both orientations (+ slab layouts) on the device for big LPs, on the host
   // for small ones: same bits either way (tests)
   const int64_t nnzIn = P.num_col > 0 && P.a_start ? (int64_t)P.a_start[P.num_col] : 0;
   bool gpuSetup = nnzIn >= 200000;
-  if (const char* g = getenv("PDLP_MI355X_GPU_SETUP")) gpuSetup = atoi(g) != 0;
+  if (sw.gpuSetup >= 0) gpuSetup = sw.gpuSetup != 0;
   if (sharded_) gpuSetup = false;  // the row-block shards are cut on the host
   if (gpuSetup) {
     HipdlpSetup hs;
@@ -92,8 +90,8 @@ void HalpernSolver::construct(const pdlp_problem_t& P, const void* id128) {
     F_.normCost = D.normCost; F_.normRhs = D.normRhs;
     F_.rowKind = std::move(D.rowKind); F_.rowNewIdx = std::move(D.rowNewIdx);
     F_.colScale = std::move(D.hColScale); F_.rowScale = std::move(D.hRowScale);
-    dA_.buildFromDevice(D.A, slabMode, stream_);
-    dAt_.buildFromDevice(D.At, slabMode, stream_);
+    dA_.buildFromDevice(D.A, sw, stream_);
+    dAt_.buildFromDevice(D.At, sw, stream_);
     cost_ = std::move(D.cost); lower_ = std::move(D.lower); upper_ = std::move(D.upper); rl_ = std::move(D.rhs);
     ru_ = std::move(D.rowUpper); colScale_ = std::move(D.colScale); rowScale_ = std::move(D.rowScale);
     isEq_ = std::move(D.rowIsEq);
@@ -112,13 +110,13 @@ void HalpernSolver::construct(const pdlp_problem_t& P, const void* id128) {
       c0_ = mesh_->c0(); c1_ = mesh_->c1();
       Compressed csrSlab, cscSlab;
       extractSlab(F_, r0_, r1_, csrSlab, cscSlab);
-      dA_.upload(csrSlab, r1_ - r0_, F_.n, slabMode, stream_);
-      dAt_.upload(cscSlab, F_.n, r1_ - r0_, slabMode, stream_);
+      dA_.upload(csrSlab, r1_ - r0_, F_.n, sw, stream_);
+      dAt_.upload(cscSlab, F_.n, r1_ - r0_, sw, stream_);
       commBuf_.alloc((size_t)F_.n + 8);
       commBuf_.zero(stream_);
     } else {
-      dA_.upload(F_.csr, F_.m, F_.n, slabMode, stream_);
-      dAt_.upload(F_.cscSorted, F_.n, F_.m, slabMode, stream_);
+      dA_.upload(F_.csr, F_.m, F_.n, sw, stream_);
+      dAt_.upload(F_.cscSorted, F_.n, F_.m, sw, stream_);
     }
     auto up = [&](DeviceArray<double>& d, const double* h, size_t count) {
       d.alloc(count);
@@ -149,8 +147,8 @@ void HalpernSolver::construct(const pdlp_problem_t& P, const void* id128) {
   PDLP_HIP(hipStreamSynchronize(stream_));
   F_.csc = Compressed(); F_.csr = Compressed(); F_.cscSorted = Compressed();
   // block -> XCD assignment of the two operands (scratch vectors: any input will do)
-  tuneXcdMap(dA_, tmpN_.get(), tmpM_.get(), stream_);
-  tuneXcdMap(dAt_, tmpM_.get(), tmpN_.get(), stream_);
+  tuneXcdMap(dA_, sw, tmpN_.get(), tmpM_.get(), stream_);
+  tuneXcdMap(dAt_, sw, tmpM_.get(), tmpN_.get(), stream_);
   reset();
   setupSeconds_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }

@@ -15,7 +15,6 @@
 
 #include <cmath>
 #include <cstddef>
-#include <cstdlib>
 
 #include "pdlp_devfn.hpp"
 
@@ -51,6 +50,8 @@ struct SpmvArgs {
   const double* partDY;
   int32_t nDY, nDX;
   unsigned long long* bar;
+  unsigned long long barLimit;  // 100 MHz ticks the grid barrier may wait for a missing block
+  int32_t faultTrial;           // tests: the barrier of the trial that raises the trial counter to this value expects one block too many
   CheckGate gate;  // kPlain inside a device-driven check: the launch is a no-op unless the check is due
 };
 
@@ -245,6 +246,20 @@ __device__ __forceinline__ void longBlock(const SpmvArgs& a, Epi<EPI>& epi, int 
   }
 }
 
+// The grid barrier of a fused trial did not hold (pdlp_devfn.hpp gridBarrier: a block of the launch was not resident in
+// time — the device is shared — or, kBarBroken, an earlier barrier was split).  No block takes the decision or does the
+// primal step: the iterate buffers of the CURRENT parity and the state record are as they were before the trial, apart
+// from the pending average weight of y, which the A x+ launch of this trial has already added to ySum (the host clears
+// it).  Block 0 hands the record on with commError = 3 (fall back to plain launches) or 1 (error) and halted = 1, so
+// that whatever is queued behind is a no-op.  words: the state record, in LDS.
+__device__ __forceinline__ void fusedBarrierFailed(DevState* stOut, const uint32_t* words, int verdict, bool writer, int tid) {
+  if (!writer || tid >= (int)(sizeof(DevState) / 4)) return;
+  uint32_t w = words[tid];
+  if (tid == (int)(offsetof(DevState, commError) / 4)) w = verdict == kBarFailed ? 3u : 1u;
+  if (tid == (int)(offsetof(DevState, halted) / 4)) w = 1u;
+  reinterpret_cast<uint32_t*>(stOut)[tid] = w;
+}
+
 // More long majors than kLongSlotCap: slot g of the partial arrays = contributions of the majors [g*G, (g+1)*G),
 // added left to right.
 __global__ __launch_bounds__(kVecThreads) void k_long_groups(const LongMat L, const DevState* st, double* part0, double* part1) {
@@ -278,6 +293,7 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
   // kAtyFused (the 2-launch trial on the stream layout): reduction scratch of the decision and the state record
   __shared__ double tscr[EPI == kAtyFused ? 4 : 1][kVecThreads / kWave];
   __shared__ uint32_t shWords[EPI == kAtyFused ? (sizeof(DevState) + 3) / 4 : 1];
+  __shared__ int barVerdict;
 
   const int tid = threadIdx.x;
   Epi<EPI> epi(a);
@@ -347,9 +363,17 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
       // ---- every block's partials in HBM -> decision (identical in every block) -> the next trial's primal step on the
       // block's majors (pdlp_kernels.hip k_spmv_slab has the same tail) ----
       DevState* sh = reinterpret_cast<DevState*>(shWords);
-      if (tid < kWave) gridBarrier(a.bar, (int)blockIdx.x, a.A.nBlocks, (unsigned long long)a.st->nTrials + 1ull, tid);
+      if (tid < kWave) {
+        const int nExp = a.A.nBlocks + (a.st->nTrials + 1 == a.faultTrial ? 1 : 0);
+        const int verdict = gridBarrier(a.bar, (int)blockIdx.x, nExp, (unsigned long long)a.st->nTrials + 1ull, tid, a.barLimit);
+        if (tid == 0) barVerdict = verdict;
+      }
       if (tid >= kWave && tid - kWave < (int)(sizeof(DevState) / 4)) shWords[tid - kWave] = reinterpret_cast<const uint32_t*>(a.st)[tid - kWave];
       __syncthreads();
+      if (barVerdict != kBarOk) {  // not every block of this launch was resident in time: the trial stays undecided (fusedBarrierFailed)
+        fusedBarrierFailed(a.stOut, shWords, barVerdict, blockIdx.x == 0, tid);
+        return;
+      }
       double dY2, dX2, inter;
       trialSumsT<true>(a.partDY, a.nDY, a.part0, a.part1, a.nDX, tscr, dY2, dX2, inter);
       if (tid == 0) {
@@ -418,7 +442,7 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
 constexpr int kSlabSlots = 3;  // register pipeline depth (groups of 64 entries per wave)
 // TWO: register budget for two resident blocks per CU (8 waves per SIMD) — the extra blocks with the segment
 // tasks of the long majors then run NEXT to the streaming blocks instead of after them.
-template <int EPI, bool TWO, int NB, int GD, bool STAGE = false>
+template <int EPI, bool TWO, int NB, int GD>
 __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabThreads / 256) void k_spmv_slab(const SpmvArgs a) {
   if (EPI == kAtyFused && a.st->halted) {  // keep the two state slots identical while the queue drains
     if (blockIdx.x == 0 && threadIdx.x < sizeof(DevState) / 4)
@@ -437,12 +461,10 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
     return;
   }
   // dynamic LDS: acc[R] f64 | stg[16][64] f64 | scratch[2][16] f64 | (kAtyFused) trial scratch[4][4] f64, DevState
-  //              | (STAGE) the tile of the gathered vector
   const int R = a.S.rowsPerBlock;
   double* acc = reinterpret_cast<double*>(smem);
   double* stgAll = acc + R;
   double(*scratch)[kWaves] = reinterpret_cast<double(*)[kWaves]>(stgAll + kSlabThreads);
-  double* xt = reinterpret_cast<double*>(&scratch[2][0]);
 
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
@@ -520,60 +542,6 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
       }
     }
   };
-  // (a block without tiles — its majors are spread over too many — streams the plain way)
-  const int t0 = STAGE ? ldUniform(a.S.blkTilePtr + blk) : 0, t1 = STAGE ? ldUniform(a.S.blkTilePtr + blk + 1) : 0;
-  if (STAGE && t1 > t0) {
-    // ---- the stream, tile by tile, gathering from LDS ----
-    const int tl = a.S.tileLog2;
-    const int32_t* __restrict__ twb = a.S.tileWaveBeg + (size_t)(t0 + blk) * kWaves + wave;
-    const uint32_t* __restrict__ entAll = a.S.ent;
-    const double* __restrict__ valAll = a.S.val;
-    constexpr int NBS = 8;  // groups of a wave part whose entries are in flight together (a part rarely has more)
-    for (int t = t0; t < t1; ++t) {
-      const int slabIdx = ldUniform(a.S.tileSlab + t), nG = ldUniform(a.S.tileGroups + t);
-      const int eb = ldUniform(twb + (size_t)(t - t0) * kWaves), ee = ldUniform(twb + (size_t)(t - t0 + 1) * kWaves);
-      const int base = slabIdx << tl;
-      const int width = (a.S.nMinor - base) < (1 << tl) ? (a.S.nMinor - base) : (1 << tl);
-      const int cnt = ee - eb;
-      const int last = cnt > 0 ? cnt - 1 : 0;
-      const uint32_t* __restrict__ ent = entAll + eb;  // (an empty part re-reads the entry at eb: exists, the arrays carry one pad element)
-      const double* __restrict__ val = valAll + eb;
-      auto entryIndex = [&](int g) { const int q = g * kWave + lane; return q < last ? q : last; };
-      uint32_t E[NBS];
-      double V[NBS];
-#pragma unroll
-      for (int k = 0; k < NBS; ++k) { const int q = entryIndex(k); E[k] = ent[q]; V[k] = val[q]; }  // in flight across the staging
-      __syncthreads();  // every wave is done with the previous tile
-      {  // the tile: 2^tl doubles with unit-stride loads, all of a thread's 16 in flight
-        const double* __restrict__ src = in + base;
-        constexpr int kU = 16;
-        for (int i0 = tid; i0 < width; i0 += kU * kSlabThreads) {
-          double tmp[kU];
-#pragma unroll
-          for (int u = 0; u < kU; ++u) { const int i = i0 + u * kSlabThreads; tmp[u] = src[i < width ? i : width - 1]; }
-#pragma unroll
-          for (int u = 0; u < kU; ++u) { const int i = i0 + u * kSlabThreads; if (i < width) xt[i] = tmp[u]; }
-        }
-      }
-      __syncthreads();
-      for (int g0 = 0; g0 < nG; g0 += NBS) {
-        if (g0 > 0) {  // (a wave part of more than NBS groups: the next NBS)
-#pragma unroll
-          for (int k = 0; k < NBS; ++k) { const int q = entryIndex(g0 + k); E[k] = ent[q]; V[k] = val[q]; }
-        }
-#pragma unroll
-        for (int u = 0; u < NBS; ++u) {
-          const int nValid = cnt - (g0 + u) * kWave;
-          if (nValid > 0) {  // (wave-uniform)
-            const int off = (int)(E[u] & mmask) - base;
-            const double x = xt[(off >= 0 && off < width) ? off : 0];
-            consumeGroup(E[u], V[u] * x, nValid);
-          }
-        }
-      }
-    }
-    __syncthreads();
-  } else {
   // ---- the stream ----
   // Register pipeline over NB slots, unrolled NB times so that a slot is a fixed register (no moves of
   // values still in flight, which would drain vmcnt): step g gathers for group g+1, then consumes
@@ -632,7 +600,6 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
   }
   if (a.S.noPace) __syncthreads();  // (free-running waves: every wave's accumulators are final before the epilogue reads them)
 
-  }
   const uint32_t* __restrict__ mask = a.S.longMask + (size_t)blk * (R / 32);
 #pragma unroll
   for (int k = 0; k < kSlabPre; ++k) {
@@ -657,13 +624,22 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
     // ---- every block's partials in HBM -> decision (identical in every block) -> the next trial's primal step ----
     double(*tscr)[kVecThreads / kWave] = reinterpret_cast<double(*)[kVecThreads / kWave]>(&scratch[2][0]);
     DevState* sh = reinterpret_cast<DevState*>(&tscr[4][0]);
-    if (wave == 0) gridBarrier(a.bar, (int)blockIdx.x, a.S.nBlocks, (unsigned long long)a.st->nTrials + 1ull, lane);
+    int* barVerdict = reinterpret_cast<int*>(reinterpret_cast<char*>(sh) + ((sizeof(DevState) + 7) / 8) * 8);
+    if (wave == 0) {
+      const int nExp = a.S.nBlocks + (a.st->nTrials + 1 == a.faultTrial ? 1 : 0);
+      const int verdict = gridBarrier(a.bar, (int)blockIdx.x, nExp, (unsigned long long)a.st->nTrials + 1ull, lane, a.barLimit);
+      if (lane == 0) *barVerdict = verdict;
+    }
     {  // the state record -> LDS, one word per thread (no register copy of the 50-word record)
       const uint32_t* src = reinterpret_cast<const uint32_t*>(a.st);
       uint32_t* dstw = reinterpret_cast<uint32_t*>(sh);
       if (tid >= kVecThreads && tid - kVecThreads < (int)(sizeof(DevState) / 4)) dstw[tid - kVecThreads] = src[tid - kVecThreads];
     }
     __syncthreads();
+    if (*barVerdict != kBarOk) {  // not every block of this launch was resident in time: the trial stays undecided (fusedBarrierFailed)
+      fusedBarrierFailed(a.stOut, reinterpret_cast<const uint32_t*>(sh), *barVerdict, blockIdx.x == 0, tid);
+      return;
+    }
     double dY2, dX2, inter;
     trialSumsT<true>(a.partDY, a.nDY, a.part0, a.part1, a.nDX, tscr, dY2, dX2, inter);
     if (tid == 0) {
@@ -1120,11 +1096,6 @@ void launchPrimalStep(const IterVecs& v, const DevState* st, hipStream_t s) {
 }
 
 namespace {
-// PDLP_MI355X_SLAB_OCC2=0|1: register budget of the slab kernel for one / two resident blocks per CU
-bool slabTwoPerCu() {
-  const char* e = getenv("PDLP_MI355X_SLAB_OCC2");  // (development switch, read per launch; a captured graph keeps its choice)
-  return e ? atoi(e) != 0 : true;
-}
 template <int EPI>
 void launchSpmv(const MatView& M, SpmvArgs a, hipStream_t s) {
   a.xcdMap = M.xcdMap;
@@ -1136,9 +1107,8 @@ void launchSpmv(const MatView& M, SpmvArgs a, hipStream_t s) {
     const size_t lds = (size_t)M.slab.rowsPerBlock * 8 + kSlabThreads * 8 + 2 * (kSlabThreads / kWave) * 8;
     const dim3 grid(M.slab.nBlocks + (nTasks + kSlabThreads / kWave - 1) / (kSlabThreads / kWave));
     // (gather distance 2 / 3 with 4 / 6 slots measured the same as (3, 1) on the random and on the structured LP, round 3)
-    if (M.slab.tileLog2 > 0)  // structured operand: the gathered vector goes through LDS tile by tile (one block per CU)
-      hipLaunchKernelGGL((k_spmv_slab<EPI, false, kSlabSlots, 1, true>), grid, dim3(kSlabThreads), lds + ((size_t)8 << M.slab.tileLog2), s, a);
-    else if (nTasks > 0 && slabTwoPerCu()) hipLaunchKernelGGL((k_spmv_slab<EPI, true, kSlabSlots, 1>), grid, dim3(kSlabThreads), lds, s, a);
+    // segment tasks ride along: register budget for two resident blocks per CU, so that a task block runs NEXT to a streaming one
+    if (nTasks > 0) hipLaunchKernelGGL((k_spmv_slab<EPI, true, kSlabSlots, 1>), grid, dim3(kSlabThreads), lds, s, a);
     else hipLaunchKernelGGL((k_spmv_slab<EPI, false, kSlabSlots, 1>), grid, dim3(kSlabThreads), lds, s, a);
   } else if (M.csr.nBlocks > 0 || nTasks > 0) {
     const dim3 grid(M.csr.nBlocks + (nTasks + kSpmvThreads / kWave - 1) / (kSpmvThreads / kWave)), block(kSpmvThreads);
@@ -1187,8 +1157,10 @@ int fusedAtyBlocksResident(const MatView& At, int device) {
 int fusedAtyBlocks(const MatView& At) { return At.useSlab ? At.slab.nBlocks : At.csr.nBlocks; }
 void launchSpmvAtyFusedPrimal(const MatView& At, const IterVecs& v, const DevState* stIn, DevState* stOut,
                               const double* partDY, int32_t nDY, double* partDX, double* partInter, unsigned long long* bar,
-                              hipStream_t s) {
+                              hipStream_t s, int32_t timeoutMs, int32_t faultTrial) {
   SpmvArgs a{};
+  a.barLimit = (unsigned long long)(timeoutMs > 0 ? timeoutMs : 1000) * 100000ull;
+  a.faultTrial = faultTrial;
   a.st = stIn; a.v = v; a.part0 = partDX; a.part1 = partInter;
   a.stOut = stOut; a.partDY = partDY; a.nDY = nDY; a.nDX = At.nPartials; a.bar = bar;
   a.xcdMap = At.xcdMap; a.L = At.lng; a.A = At.csr; a.S = At.slab;
@@ -1311,42 +1283,12 @@ __global__ __launch_bounds__(kVecThreads) void k_block_span(const int32_t* __res
   atomicMax(hi + b, idx[p1 - 1]);
   atomicAdd(cnt + b, p1 - p0);
 }
-// One wave per slab wave: the positions in its entry list where the slab (minor >> tileLog2) changes, in order
-// (at most cap of them are kept; outCnt says how many there were).
-__global__ __launch_bounds__(kWave) void k_slab_tile_scan(const int32_t* __restrict__ wavePtr, const uint32_t* __restrict__ ent, int nWaves,
-                                                          uint32_t mmask, int tileLog2, int cap, int32_t* outSlab, int32_t* outPos,
-                                                          int32_t* outCnt) {
-  const int gw = blockIdx.x, lane = threadIdx.x;
-  if (gw >= nWaves) return;
-  const int e0 = wavePtr[gw], e1 = wavePtr[gw + 1];
-  int n = 0;
-  for (int i0 = e0; i0 < e1; i0 += kWave) {
-    const int i = i0 + lane;
-    const bool in = i < e1;
-    const int sl = in ? (int)((ent[i] & mmask) >> tileLog2) : -1;
-    const int pv = (in && i > e0) ? (int)((ent[i - 1] & mmask) >> tileLog2) : -1;
-    const bool isB = in && sl != pv;
-    const uint64_t bal = __ballot(isB);
-    if (isB) {
-      const int k = n + __popcll(bal & ((1ull << lane) - 1ull));
-      if (k < cap) { outSlab[(size_t)gw * cap + k] = sl; outPos[(size_t)gw * cap + k] = i; }
-    }
-    n += __popcll(bal);
-  }
-  if (lane == 0) outCnt[gw] = n;
-}
 }  // namespace
 void launchBlockSpan(const int32_t* beg, const int32_t* idx, int32_t nMajor, int32_t R, int32_t longLimit, int32_t* lo, int32_t* hi,
                      int32_t* cnt, hipStream_t s) {
   if (nMajor <= 0) return;
   hipLaunchKernelGGL(k_block_span, dim3((nMajor + kVecThreads - 1) / kVecThreads), dim3(kVecThreads), 0, s, beg, idx, nMajor, R, longLimit,
                      lo, hi, cnt);
-}
-void launchSlabTileScan(const SlabMat& S, int32_t tileLog2, int32_t cap, int32_t* outSlab, int32_t* outPos, int32_t* outCnt, hipStream_t s) {
-  const int nWaves = S.nBlocks * (kSlabThreads / kWave);
-  if (nWaves <= 0) return;
-  hipLaunchKernelGGL(k_slab_tile_scan, dim3(nWaves), dim3(kWave), 0, s, S.wavePtr, S.ent, nWaves, (1u << S.minorBits) - 1u, tileLog2, cap,
-                     outSlab, outPos, outCnt);
 }
 void launchDot(const double* a, const double* b, int32_t len, double* partials, int32_t nBlocks, hipStream_t s) {
   hipLaunchKernelGGL(k_dot, dim3(nBlocks), dim3(kVecThreads), 0, s, a, b, len, partials);

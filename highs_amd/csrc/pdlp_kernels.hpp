@@ -152,23 +152,17 @@ struct SlabMat {
   const double* val;         // [nnz]
   const uint32_t* longMask;  // [nBlocks*rowsPerBlock/32]
   int32_t nMajor, nBlocks, rowsPerBlock, minorBits;
-  // LDS staging of the gathered vector (structured operands: the majors of a block touch a few slabs of the gathered
-  // vector densely — network blocks, staircases).  The block walks ITS slabs ("tiles") one after the other: the tile
-  // (2^tileLog2 entries of the gathered vector, 128 KB) is copied into LDS with coalesced loads, then every wave runs
-  // the part of its entry list that falls into the tile, gathering from LDS — the gathers then cost no slot of the
-  // CU's vector-memory miss queue, which is what bounds the kernel otherwise.  Entry order, hence every sum, is
-  // unchanged.  tileLog2 == 0: not staged.
-  int32_t tileLog2, nMinor;
   // 1: no block barrier per 64-entry group.  The barrier keeps the CU's waves on the same slab of the gathered vector
   // (a random matrix needs that: 50 -> 58 us at 1M x 1M without); an operand whose blocks touch little of the gathered
   // vector anyway runs faster free (block-angular LP of bench.py --config c: 31.8 -> 29.0 us).  Chosen per operand by
   // timing both at set-up (tuneXcdMap).
   int32_t noPace;
-  const int32_t* blkTilePtr;  // [nBlocks+1] first tile of each block
-  const int32_t* tileSlab;    // [nTiles] slab index of the tile
-  const int32_t* tileGroups;  // [nTiles] 64-entry groups of the longest wave part in the tile
-  const int32_t* tileWaveBeg; // [(nTiles + nBlocks) * 16] entry offset of each wave's part per tile; one closing row per block
 };
+// Slab width for operands whose row blocks touch few 2^14-entry stretches of the gathered vector densely (network
+// blocks, staircases): shorter runs of equal majors per 64-entry group, more lanes adding (bench.py --config c, A x:
+// 44.0 -> 41.1 us).  (Round 3 also built LDS staging of those stretches — bit-identical, measured SLOWER, 46.7 vs
+// 33.2 us on config c: two block barriers and a dependent load chain per tile cost more than the L2 gathers they
+// replace; removed in round 4, the code is in the history at commit 22b5412.)
 constexpr int kSlabTileLog2 = 14;
 
 // One operand matrix of the iteration: a plain CSR stream or the slab layout for the majors that are summed
@@ -268,9 +262,12 @@ void launchDecide(DevState* st, const double* partDY, int32_t nDY, const double*
 inline size_t gridBarWords(int nBlocks) { return (size_t)nBlocks + 8; }
 int fusedAtyBlocksResident(const MatView& At, int device);
 int fusedAtyBlocks(const MatView& At);  // blocks of the fused launch (= arrival words of the barrier)
+// timeoutMs: how long the barrier waits for a block that is not resident (a shared device); then the trial stays
+// undecided, *stOut carries commError = 3 and the caller falls back to the 3-launch trial.  faultTrial (tests): the
+// trial that raises the trial counter to this value expects one block too many (0: none).
 void launchSpmvAtyFusedPrimal(const MatView& At, const IterVecs& v, const DevState* stIn, DevState* stOut,
                               const double* partDY, int32_t nDY, double* partDX, double* partInter,
-                              unsigned long long* bar, hipStream_t s);
+                              unsigned long long* bar, hipStream_t s, int32_t timeoutMs = 1000, int32_t faultTrial = 0);
 
 // ---- small LPs: a batch of trials as ONE persistent launch (pdlp_small.hip) -------------------------------------
 // Both operands in the stream layout, no long majors.  smallTrialsGrid: workgroups of the launch (0: does not
@@ -282,8 +279,11 @@ void launchSpmvAtyFusedPrimal(const MatView& At, const IterVecs& v, const DevSta
 // if it does not hold, changes nothing and sets commError = 2 in *st — the caller then goes on with another mode.
 // mode 2: all XCDs, XCD-hierarchical barrier (pdlp_devfn.hpp hierBarrier) — what hundreds of workgroups need.
 int smallTrialsGrid(const MatView& A, const MatView& At, int32_t n, int device, int* resident);
+// Every launch begins with a roll call of its working workgroups (pdlp_devfn.hpp rollCall): if they are not all resident
+// within timeoutMs, the launch changes nothing but commError = 3 in *st (failRollCall: a test asks for exactly that).
 void launchSmallTrials(const MatView& A, const MatView& At, const IterVecs& v, DevState* st, double* partDY, double* partDX,
-                       double* partInter, unsigned long long* bar, int32_t grid, int32_t maxTrials, int mode, hipStream_t s);
+                       double* partInter, unsigned long long* bar, int32_t grid, int32_t maxTrials, int mode, hipStream_t s,
+                       int32_t timeoutMs = 1000, bool failRollCall = false);
 constexpr int kSmallHierWords = 4 * 16 * 32;  // the XCD-hierarchical barrier's words (pdlp_devfn.hpp HierBar)
 // arrival words, timeout flag, XCC ids of the placement check; behind them (256-byte aligned) the hierarchical barrier's words
 inline size_t smallBarWords(int grid) { return ((2 * (size_t)grid + 16 + 31) / 32) * 32 + kSmallHierWords; }
@@ -356,11 +356,9 @@ void launchRestartFinish(DevState* st, CheckCtl* cc, const double* partX, int32_
 
 int32_t vecBlocks(int32_t len);  // grid size used by the vector/statistics kernels
 
-// ---- set-up of the LDS-staged slab layout (SlabMat::tileLog2) ----
+// ---- set-up: which slab width suits an operand ----
 // lo/hi/cnt [ceil(nMajor/R)], pre-set to INT_MAX / -1 / 0: column span and entry count of each block's short majors
 void launchBlockSpan(const int32_t* beg, const int32_t* idx, int32_t nMajor, int32_t R, int32_t longLimit, int32_t* lo, int32_t* hi,
                      int32_t* cnt, hipStream_t s);
-// per slab wave: where in its entry list the tile (minor >> tileLog2) changes: outSlab/outPos [nWaves*cap], outCnt [nWaves]
-void launchSlabTileScan(const SlabMat& S, int32_t tileLog2, int32_t cap, int32_t* outSlab, int32_t* outPos, int32_t* outCnt, hipStream_t s);
 
 }  // namespace pdlp

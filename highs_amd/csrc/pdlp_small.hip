@@ -51,15 +51,18 @@ struct SmallArgs {
   unsigned long long* bar;
   int32_t xcdA, xcdAt;
   int32_t maxTrials;
-  int32_t pad_;
+  int32_t expect;            // workgroups the roll call waits for (= the working workgroups of the launch, unless a test asks for a failure)
+  unsigned long long limit;  // 100 MHz ticks a roll call or barrier wait may last
   unsigned long long* prof;  // development: 100 MHz ticks per phase {P, barrier, A, barrier, T, barrier, D}, accumulated by workgroup 0
 };
 
+// (inside a launch that has passed its roll call a wait can only fail on a defect: the timeout raises the flag word,
+// which the decision phase turns into commError = 1)
 template <bool LOCAL>
-__device__ __forceinline__ void arrive(unsigned long long* bar, int lb, int nBlocks, unsigned long long epoch) {
+__device__ __forceinline__ void arrive(unsigned long long* bar, int lb, int nBlocks, unsigned long long epoch, unsigned long long limit) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores (write-through, or into the shared L2) ...
   __syncthreads();                                    // ... before the block's arrival word is written
-  if (threadIdx.x < kWave) gridBarrier<LOCAL>(bar, lb, nBlocks, epoch, (int)threadIdx.x);
+  if (threadIdx.x < kWave) (void)gridBarrier<LOCAL>(bar, lb, nBlocks, epoch, (int)threadIdx.x, limit);
   __syncthreads();
 }
 // the same through the XCD-hierarchical barrier (k-th barrier of the launch)
@@ -185,6 +188,19 @@ __global__ __launch_bounds__(kSpmvThreads) void k_trials_small(const SmallArgs a
   padSlots(prod, kMaxChunk + kMaxChunk / 8 + 8, tid, kSpmvThreads);  // (never written again)
   __syncthreads();
   if (sh.halted) return;
+  // Roll call (pdlp_devfn.hpp rollCall): nothing is written before every working workgroup of the launch is known to be
+  // resident.  If they are not all there in time (another tenant holds CUs), the launch changes nothing but commError = 3
+  // and the solver goes on with plain launches.
+  if (tid < kWave) {
+    const bool here = rollCall(a.bar + G + 1, a.expect, a.limit, tid);
+    if (tid == 0) placementOk = here ? 1 : 0;
+  }
+  __syncthreads();
+  if (!placementOk) {
+    if (tid == 0) __hip_atomic_store(&a.st->commError, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  __syncthreads();
   // the blocks this workgroup owns (the grid has at least as many workgroups as either operand has blocks)
   const int nA = a.A.nBlocks, nAt = a.At.nBlocks;
   OwnBlock<CHUNK_A> bA;
@@ -195,7 +211,7 @@ __global__ __launch_bounds__(kSpmvThreads) void k_trials_small(const SmallArgs a
     // the placement check: XCC ids of all workers (words behind the arrival words and the timeout flag)
     unsigned long long* ids = a.bar + G + 8;
     if (tid == 0) __hip_atomic_store(ids + lb, (unsigned long long)xccId() + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    arrive<false>(a.bar, lb, G, 4ull * (unsigned long long)sh.nTrials + 1ull);
+    arrive<false>(a.bar, lb, G, 4ull * (unsigned long long)sh.nTrials + 1ull, a.limit);
     if (tid == 0) {
       const unsigned long long mine = __hip_atomic_load(ids + lb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       int ok = 1;
@@ -214,9 +230,10 @@ __global__ __launch_bounds__(kSpmvThreads) void k_trials_small(const SmallArgs a
     // registration: how many workgroups sit on which XCD (the barrier words were zeroed by the host before this launch)
     hb.base = a.bar + ((2 * G + 16 + kXccStride - 1) / kXccStride) * kXccStride;
     hb.flag = a.bar + G;
+    hb.limit = a.limit;
     hb.xcc = xccId();
     if (tid == 0) __hip_atomic_fetch_add(hb.reg(hb.xcc), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    arrive<false>(a.bar, lb, G, 1ull);
+    arrive<false>(a.bar, lb, G, 1ull, a.limit);
     if (tid < kWave) {
       const unsigned long long c = tid < kXccSlots ? __hip_atomic_load(hb.reg(tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
       const unsigned long long act = __ballot(c > 0);
@@ -229,7 +246,7 @@ __global__ __launch_bounds__(kSpmvThreads) void k_trials_small(const SmallArgs a
   }
   auto meet = [&](unsigned long long epoch) {
     if (MODE == 2) arriveHier(hb, ++kbar);
-    else arrive<LOCAL>(a.bar, lb, G, epoch);
+    else arrive<LOCAL>(a.bar, lb, G, epoch, a.limit);
   };
   unsigned long long tPrev = a.prof ? wall_clock64() : 0ull;
   auto stamp = [&](int k) {
@@ -352,11 +369,15 @@ int smallTrialsGrid(const MatView& A, const MatView& At, int32_t n, int device, 
 }
 
 void launchSmallTrials(const MatView& A, const MatView& At, const IterVecs& v, DevState* st, double* partDY, double* partDX,
-                       double* partInter, unsigned long long* bar, int32_t grid, int32_t maxTrials, int mode, hipStream_t s) {
+                       double* partInter, unsigned long long* bar, int32_t grid, int32_t maxTrials, int mode, hipStream_t s,
+                       int32_t timeoutMs, bool failRollCall) {
   const bool xcdLocal = mode == 1;
   static_assert(kHierBarWords == kSmallHierWords, "barrier buffer layout");
   if (mode == 2) (void)hipMemsetAsync(bar, 0, smallBarWords(grid) * sizeof(unsigned long long), s);  // launch-local barrier counters
+  else (void)hipMemsetAsync(bar + grid + 1, 0, sizeof(unsigned long long), s);                    // the roll-call word
   SmallArgs a{};
+  a.expect = grid + (failRollCall ? 1 : 0);
+  a.limit = (unsigned long long)(timeoutMs > 0 ? timeoutMs : 1000) * 100000ull;
   a.A = A.csr; a.At = At.csr; a.v = v; a.st = st; a.partDY = partDY; a.partDX = partDX; a.partInter = partInter; a.bar = bar;
   a.xcdA = A.xcdMap; a.xcdAt = At.xcdMap; a.maxTrials = maxTrials;
   static unsigned long long* prof = [] {  // PDLP_MI355X_SMALL_PROF=1: per-phase ticks, printed at exit (development)

@@ -36,9 +36,11 @@ constexpr int32_t kSlabAutoMinor = 1 << 18;
 }  // namespace
 
 namespace {
-int32_t slabWidthLog2() {
-  if (const char* e = getenv("PDLP_MI355X_SLAB_W")) return atoi(e);  // development switch
-  return kSlabWidthLog2;
+// slab width (log2 of the minors per slab) of an operand: PDLP_MI355X_SLAB_W if given, 2^14 for operands whose blocks
+// touch few stretches of the gathered vector densely, else 2^17 (1 MB of the gathered vector)
+int32_t slabWidthFor(const DevSwitches& sw, bool fewTiles) {
+  if (sw.slabW > 0) return sw.slabW;
+  return fewTiles ? kSlabTileLog2 : kSlabWidthLog2;
 }
 // mode (PDLP_MI355X_SLAB or auto) -> is the slab layout used for an operand of this shape
 bool chooseSlab(int mode, int32_t nMajor, int32_t nMinor) {
@@ -82,97 +84,27 @@ void DeviceMatrix::uploadPlans(const std::vector<int32_t>& hostBeg, int32_t nCsr
   PDLP_HIP(hipStreamSynchronize(s));  // host vectors go out of scope
 }
 
-// LDS staging (pdlp_kernels.hpp SlabMat::tileLog2) is meant for operands whose blocks touch FEW tiles of the gathered
-// vector DENSELY (at most 8 tiles per block, at least one gather per 8 staged elements, accumulators + tile within the
-// 160 KB of LDS).  MEASURED in round 3 on the block-angular LP of bench.py --config c (248 of 249 blocks staged, 2.5
-// tiles per block): A x without its long rows 46.7 us staged against 33.2 us plain (31.5 with 16384-column slabs) —
-// bit-identical, but two block barriers and a dependent chain scalar loads -> tile + entry loads -> LDS per tile cost
-// more than the gathers they replace.  It therefore stays OFF unless PDLP_MI355X_SLAB_STAGE=1 asks for it.
-namespace { constexpr int32_t kStageMaxTiles = 8; }
-bool DeviceMatrix::wantStaging(const std::vector<int32_t>& lo, const std::vector<int32_t>& hi, const std::vector<int32_t>& cnt, int32_t R,
-                               bool* local) {
-  if (local) *local = false;
-  const size_t lds = (size_t)R * 8 + kSlabThreads * 8 + 2 * 16 * 8 + ((size_t)8 << kSlabTileLog2) + 64;
-  int force = -1;
-  if (const char* e = getenv("PDLP_MI355X_SLAB_STAGE")) force = atoi(e);
-  if (lds > 160 * 1024) force = 0;
-  // blocks worth staging: at most kStageMaxTiles tiles, at least one gather per 8 staged elements; the operand is staged
-  // when they hold most of its entries (the others stream the plain way inside the same launch)
+// Do the row blocks of this operand touch few 2^14-entry stretches of the gathered vector, densely (at most 8 per block,
+// at least one gather per 8 of their elements, for blocks holding most of the entries)?  Then the slab layout is built
+// with slabs of that width (pdlp_kernels.hpp kSlabTileLog2).
+namespace { constexpr int32_t kLocalMaxTiles = 8; }
+bool DeviceMatrix::touchesFewTiles(const std::vector<int32_t>& lo, const std::vector<int32_t>& hi, const std::vector<int32_t>& cnt) {
   int64_t good = 0, all = 0;
   for (size_t b = 0; b < lo.size(); ++b) {
     if (cnt[b] <= 0) continue;
     const int64_t t = (hi[b] >> kSlabTileLog2) - (lo[b] >> kSlabTileLog2) + 1;  // (an upper bound: tiles in between may be untouched)
     all += cnt[b];
-    if (t <= kStageMaxTiles && (int64_t)cnt[b] * 8 >= t * ((int64_t)1 << kSlabTileLog2)) good += cnt[b];
+    if (t <= kLocalMaxTiles && (int64_t)cnt[b] * 8 >= t * ((int64_t)1 << kSlabTileLog2)) good += cnt[b];
   }
-  if (local) *local = all > 0 && good * 5 >= all * 4;
-  return all > 0 && force == 1;
+  return all > 0 && good * 5 >= all * 4;
 }
 
-// Tile tables of a built slab layout: where each wave's entry list changes tile (device scan), merged per block on the host.
-void DeviceMatrix::buildTileTables(int32_t nMinor, hipStream_t s) {
-  constexpr int32_t kCap = 64;
-  const int32_t nWaves = slab.nBlocks * (kSlabThreads / 64);
-  DeviceArray<int32_t> dSlab, dPos, dCnt;
-  dSlab.alloc((size_t)nWaves * kCap); dPos.alloc((size_t)nWaves * kCap); dCnt.alloc((size_t)nWaves);
-  launchSlabTileScan(slab, kSlabTileLog2, kCap, dSlab.get(), dPos.get(), dCnt.get(), s);
-  std::vector<int32_t> hSlab((size_t)nWaves * kCap), hPos((size_t)nWaves * kCap), hCnt((size_t)nWaves), hWave((size_t)nWaves + 1);
-  dSlab.download(hSlab.data(), hSlab.size(), s); dPos.download(hPos.data(), hPos.size(), s); dCnt.download(hCnt.data(), hCnt.size(), s);
-  wavePtr.download(hWave.data(), hWave.size(), s);
-  PDLP_HIP(hipStreamSynchronize(s));
-  std::vector<int32_t> blkPtr((size_t)slab.nBlocks + 1, 0), tsl, tgr, twb;
-  for (int32_t b = 0; b < slab.nBlocks; ++b) {
-    std::vector<int32_t> tiles;
-    for (int32_t w = 0; w < 16; ++w) {
-      const int32_t gw = b * 16 + w;
-      for (int32_t k = 0; k < std::min(hCnt[gw], kCap); ++k) tiles.push_back(hSlab[(size_t)gw * kCap + k]);
-    }
-    std::sort(tiles.begin(), tiles.end());
-    tiles.erase(std::unique(tiles.begin(), tiles.end()), tiles.end());
-    bool overflow = false;
-    for (int32_t w = 0; w < 16; ++w) overflow = overflow || hCnt[b * 16 + w] > kCap;
-    if (overflow || (int32_t)tiles.size() > kStageMaxTiles) tiles.clear();  // this block streams the plain way
-    const size_t row0 = twb.size();
-    twb.resize(row0 + (tiles.size() + 1) * 16);
-    for (int32_t w = 0; w < 16; ++w) {
-      const int32_t gw = b * 16 + w;
-      int32_t k = 0;
-      for (size_t t = 0; t < tiles.size(); ++t) {  // first entry of the wave whose tile is >= tiles[t]
-        while (k < hCnt[gw] && hSlab[(size_t)gw * kCap + k] < tiles[t]) ++k;
-        twb[row0 + t * 16 + w] = k < hCnt[gw] ? hPos[(size_t)gw * kCap + k] : hWave[gw + 1];
-      }
-      twb[row0 + tiles.size() * 16 + w] = hWave[gw + 1];
-    }
-    for (size_t t = 0; t < tiles.size(); ++t) {
-      int32_t g = 0;
-      for (int32_t w = 0; w < 16; ++w) g = std::max(g, (twb[row0 + (t + 1) * 16 + w] - twb[row0 + t * 16 + w] + 63) / 64);
-      tsl.push_back(tiles[t]);
-      tgr.push_back(g);
-    }
-    blkPtr[b + 1] = (int32_t)tsl.size();
-  }
-  if (getenv("PDLP_MI355X_DEBUG_TILES")) {
-    int64_t g = 0; int32_t mx = 0, staged = 0;
-    for (int32_t v : tgr) g += v;
-    for (int32_t b = 0; b < slab.nBlocks; ++b) { mx = std::max(mx, blkPtr[b + 1] - blkPtr[b]); staged += blkPtr[b + 1] > blkPtr[b]; }
-    fprintf(stderr, "tile tables: %d blocks (%d staged), %zu tiles (max %d per block), %lld group steps in total\n", slab.nBlocks, staged,
-            tsl.size(), mx, (long long)g);
-  }
-  auto up = [&](DeviceArray<int32_t>& d, const std::vector<int32_t>& h) { d.alloc(h.size()); d.upload(h.data(), h.size(), s); };
-  up(tBlkPtr, blkPtr); up(tSlab, tsl); up(tGroups, tgr); up(tWaveBeg, twb);
-  PDLP_HIP(hipStreamSynchronize(s));
-  tileLog2 = kSlabTileLog2;
-  slab.tileLog2 = tileLog2; slab.nMinor = nMinor;
-  slab.blkTilePtr = tBlkPtr.get(); slab.tileSlab = tSlab.get(); slab.tileGroups = tGroups.get(); slab.tileWaveBeg = tWaveBeg.get();
-}
-
-void DeviceMatrix::upload(const Compressed& cIn, int32_t nMajor_, int32_t nMinor_, int mode, hipStream_t s) {
+void DeviceMatrix::upload(const Compressed& cIn, int32_t nMajor_, int32_t nMinor_, const DevSwitches& sw, hipStream_t s) {
   nMajor = nMajor_;
   nnz = cIn.beg.empty() ? 0 : cIn.beg[nMajor_];
-  useSlab = chooseSlab(mode, nMajor_, nMinor_);
+  useSlab = chooseSlab(sw.slab, nMajor_, nMinor_);
   const Compressed* c = &cIn;
   SlabLayout L;
-  bool stage = false;
   if (useSlab) {
     const int32_t R = slabRowsPerWave(nMajor_, nMinor_) * 16, nB = (nMajor_ + R - 1) / R;
     std::vector<int32_t> lo((size_t)nB, INT_MAX), hi((size_t)nB, -1), cnt((size_t)nB, 0);
@@ -181,9 +113,7 @@ void DeviceMatrix::upload(const Compressed& cIn, int32_t nMajor_, int32_t nMinor
       if (p1 <= p0 || p1 - p0 > kSlabLongLimit) continue;
       lo[r / R] = std::min(lo[r / R], cIn.idx[p0]); hi[r / R] = std::max(hi[r / R], cIn.idx[p1 - 1]); cnt[r / R] += p1 - p0;
     }
-    bool local = false;
-    stage = wantStaging(lo, hi, cnt, R, &local);
-    buildSlabLayout(cIn, nMajor_, nMinor_, kSlabLongLimit, stage || (local && !getenv("PDLP_MI355X_SLAB_W")) ? kSlabTileLog2 : slabWidthLog2(), L);
+    buildSlabLayout(cIn, nMajor_, nMinor_, kSlabLongLimit, slabWidthFor(sw, touchesFewTiles(lo, hi, cnt)), L);
     if (L.rowsPerBlock > kSlabMaxRows) throw std::runtime_error("slab layout: too many majors per block");
     wavePtr.alloc(L.wavePtr.size());
     wavePtr.upload(L.wavePtr.data(), L.wavePtr.size(), s);
@@ -210,17 +140,15 @@ void DeviceMatrix::upload(const Compressed& cIn, int32_t nMajor_, int32_t nMinor
   val.upload(c->val.data(), (size_t)nnzCsr, s);
   uploadPlans(c->beg, nCsrMajor, useSlab ? L.longMap.data() : nullptr, s);
   PDLP_HIP(hipStreamSynchronize(s));  // host vectors may go out of scope
-  if (stage) buildTileTables(nMinor_, s);
 }
 
-void DeviceMatrix::buildFromDevice(DeviceCsrData& M, int mode, hipStream_t s) {
+void DeviceMatrix::buildFromDevice(DeviceCsrData& M, const DevSwitches& sw, hipStream_t s) {
   nMajor = M.nMajor;
   nnz = M.nnz;
-  useSlab = chooseSlab(mode, M.nMajor, M.nMinor);
+  useSlab = chooseSlab(sw.slab, M.nMajor, M.nMinor);
   std::vector<int32_t> hostBeg, hostLongMap;
   int32_t nCsrMajor = nMajor;
-  bool stage = false, localM = false;
-  const int32_t nMinorM = M.nMinor;
+  bool localM = false;
   if (useSlab) {
     const int32_t R = slabRowsPerWave(M.nMajor, M.nMinor) * 16, nB = (M.nMajor + R - 1) / R;
     {  // per-block span of the short majors, from the CSR that is already in HBM
@@ -231,12 +159,12 @@ void DeviceMatrix::buildFromDevice(DeviceCsrData& M, int mode, hipStream_t s) {
       launchBlockSpan(M.beg.get(), M.idx.get(), M.nMajor, R, kSlabLongLimit, dLo.get(), dHi.get(), dCn.get(), s);
       dLo.download(lo.data(), nB, s); dHi.download(hi.data(), nB, s); dCn.download(cnt.data(), nB, s);
       PDLP_HIP(hipStreamSynchronize(s));
-      stage = wantStaging(lo, hi, cnt, R, &localM);
+      localM = touchesFewTiles(lo, hi, cnt);
     }
     DeviceSlabLayout L;
     // (an operand whose blocks touch few 16384-entry tiles of the gathered vector densely gets slabs of that width: its
     // runs of equal majors are shorter, more lanes add in parallel — bench.py --config c, A x: 44.0 -> 41.1 us)
-    gpuBuildSlabLayout(M, kSlabLongLimit, stage || (localM && !getenv("PDLP_MI355X_SLAB_W")) ? kSlabTileLog2 : slabWidthLog2(), s, L);
+    gpuBuildSlabLayout(M, kSlabLongLimit, slabWidthFor(sw, localM), s, L);
     if (L.rowsPerBlock > kSlabMaxRows) throw std::runtime_error("slab layout: too many majors per block");
     wavePtr = std::move(L.wavePtr);
     ent = std::move(L.ent);
@@ -260,7 +188,6 @@ void DeviceMatrix::buildFromDevice(DeviceCsrData& M, int mode, hipStream_t s) {
     PDLP_HIP(hipStreamSynchronize(s));
   }
   uploadPlans(hostBeg, nCsrMajor, useSlab ? hostLongMap.data() : nullptr, s);
-  if (stage) buildTileTables(nMinorM, s);
 }
 
 MatView DeviceMatrix::view() const {
@@ -277,11 +204,11 @@ MatView DeviceMatrix::view() const {
   return v;
 }
 
-void tuneXcdMap(DeviceMatrix& M, const double* in, double* out, hipStream_t s) {
-  const char* em = getenv("PDLP_MI355X_XCD_MAP");
-  const char* ep = getenv("PDLP_MI355X_SLAB_PACE");  // 1 = barrier per group (random operands), 0 = free-running waves
-  if (em) M.xcdMap = atoi(em) != 0;
-  if (ep) M.noPace = atoi(ep) == 0;
+void tuneXcdMap(DeviceMatrix& M, const DevSwitches& sw, const double* in, double* out, hipStream_t s) {
+  const bool em = sw.xcdMap >= 0;
+  const bool ep = sw.slabPace >= 0;  // 1 = barrier per group (random operands), 0 = free-running waves
+  if (em) M.xcdMap = sw.xcdMap != 0;
+  if (ep) M.noPace = sw.slabPace == 0;
   if (M.nnz < 200000) {  // small operands live in every L2 anyway
     if (!em) M.xcdMap = 1;
     return;
@@ -311,6 +238,47 @@ void tuneXcdMap(DeviceMatrix& M, const double* in, double* out, hipStream_t s) {
   M.noPace = bestFree;
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
+}
+
+// The environment, read ONCE per solver (never per launch).  What a user may need is listed in INTEGRATION.md section 4;
+// the rest are development and test switches.
+DevSwitches DevSwitches::fromEnv() {
+  DevSwitches w;
+  auto num = [](const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+  };
+  auto str = [](const char* name) {
+    const char* e = getenv(name);
+    return std::string(e ? e : "");
+  };
+  w.graph = num("PDLP_MI355X_GRAPH", -1);
+  w.forceComm = num("PDLP_MI355X_FORCE_COMM", 0);
+  w.gpuSetup = num("PDLP_MI355X_GPU_SETUP", -1);
+  w.slab = num("PDLP_MI355X_SLAB", -1);
+  w.slabW = num("PDLP_MI355X_SLAB_W", 0);
+  w.xcdMap = num("PDLP_MI355X_XCD_MAP", -1);
+  w.slabPace = num("PDLP_MI355X_SLAB_PACE", -1);
+  w.fused = num("PDLP_MI355X_FUSED", -1);
+  w.fusedStream = num("PDLP_MI355X_FUSED_STREAM", 0);
+  w.persistent = num("PDLP_MI355X_PERSISTENT", -1);
+  w.xcdLocal = num("PDLP_MI355X_XCD_LOCAL", -1);
+  w.hierBarrier = num("PDLP_MI355X_HIER_BARRIER", -1);
+  w.deviceCheck = num("PDLP_MI355X_DEVICE_CHECK", -1);
+  w.barrierTimeoutMs = num("PDLP_MI355X_BARRIER_TIMEOUT_MS", 1000);
+  w.fault = num("PDLP_MI355X_FAULT", 0);
+  w.exchange = str("PDLP_MI355X_EXCHANGE");
+  w.meshLayout = str("PDLP_MI355X_MESH_LAYOUT");
+  return w;
+}
+
+// One launch sequence with in-kernel grid barriers at a time per device and process: two solvers (two Highs instances on
+// two threads: SURVEY section 8(b), lp_data/HighsSolve.cpp:97-104) whose barrier launches interleave could each hold
+// CUs the other one's last workgroups need.  A solver holds the gate from the first launch of a round to the
+// synchronisation that ends it; solvers without barrier launches (sharded, HiPDLP, after a fall-back) never take it.
+std::mutex& Solver::deviceGate(int device) {
+  static std::mutex gates[64];
+  return gates[device >= 0 && device < 64 ? device : 0];
 }
 
 double Solver::elapsed() const {
@@ -360,19 +328,19 @@ void Solver::construct(const pdlp_problem_t& P, const void* id128) {
     throw std::runtime_error("pdlp_mi355x: no HIP device available (this library has no CPU fallback)");
   PDLP_HIP(hipSetDevice(opt_.device));
   PDLP_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-  if (const char* g = getenv("PDLP_MI355X_GRAPH")) useGraph_ = atoi(g) != 0;
+  sw_ = DevSwitches::fromEnv();
+  if (sw_.graph >= 0) useGraph_ = sw_.graph != 0;
 
   adaptive_ = !(opt_.features_off & PDLP_FEATURE_ADAPTIVE_STEP_OFF);
   restartOn_ = !(opt_.features_off & PDLP_FEATURE_RESTART_OFF) && opt_.restart_method != 0;
 
   log(1, "Solving with PDLP on MI355X (gfx950, HIP)\n");
-  const char* fc = getenv("PDLP_MI355X_FORCE_COMM");
-  sharded_ = world_ > 1 || (fc && atoi(fc) != 0);
+  sharded_ = world_ > 1 || sw_.forceComm != 0;
   // GPU-side setup pays off once the matrix is big enough to amortise its ~40 launches / syncs;
   // small LPs are prepared on the host (same bits either way)
   const int64_t nnzIn = P.num_col > 0 && P.a_start ? (int64_t)P.a_start[P.num_col] : 0;
   gpuSetup_ = nnzIn >= 200000;
-  if (const char* g = getenv("PDLP_MI355X_GPU_SETUP")) gpuSetup_ = atoi(g) != 0;
+  if (sw_.gpuSetup >= 0) gpuSetup_ = sw_.gpuSetup != 0;
   hasQoff_ = hessianHasOffDiagonal(P);
   if (hasQoff_) {
     gpuSetup_ = false;  // the off-diagonal part of Q is scaled with the columns on the host (pdlp_host.cpp applyScaling)
@@ -447,8 +415,7 @@ void Solver::construct(const pdlp_problem_t& P, const void* id128) {
     r1_ = off[rank_ + 1];
     // Exchange: the direct xGMI mesh unless PDLP_MI355X_EXCHANGE=rccl, or the mesh cannot be
     // set up / fails its known-answer test on some rank (then EVERY rank uses RCCL).
-    const char* ex = getenv("PDLP_MI355X_EXCHANGE");
-    bool wantMesh = !(ex && !strcmp(ex, "rccl"));
+    bool wantMesh = sw_.exchange != "rccl";
     if (wantMesh) {
       try {
         mesh_ = new Mesh(rank_, world_, id128, F_.n, F_.m, off, stream_);
@@ -464,8 +431,7 @@ void Solver::construct(const pdlp_problem_t& P, const void* id128) {
     }
     meshMode_ = mesh_ != nullptr;
     if (meshMode_) {
-      const char* ml = getenv("PDLP_MI355X_MESH_LAYOUT");
-      colblock_ = !(ml && !strcmp(ml, "partial"));
+      colblock_ = sw_.meshLayout != "partial";
       c0_ = mesh_->c0();
       c1_ = mesh_->c1();
       nLoc_ = c1_ - c0_;
@@ -488,47 +454,39 @@ void Solver::construct(const pdlp_problem_t& P, const void* id128) {
   if (gpuSetup_) uploadProblemFromDevice(devProb);
   else uploadProblem();
   // block -> XCD assignment of the two operands (x_ / y_ are zero here: any input will do)
-  tuneXcdMap(dA_, x_[0].get(), ax_[0].get(), stream_);
-  tuneXcdMap(dAt_, y_[0].get(), sharded_ ? commBuf_.get() : aty_[0].get(), stream_);
-  if (hasQoff_) tuneXcdMap(dQ_, x_[0].get(), nx_[0].get(), stream_);
+  tuneXcdMap(dA_, sw_, x_[0].get(), ax_[0].get(), stream_);
+  tuneXcdMap(dAt_, sw_, y_[0].get(), sharded_ ? commBuf_.get() : aty_[0].get(), stream_);
+  if (hasQoff_) tuneXcdMap(dQ_, sw_, x_[0].get(), nx_[0].get(), stream_);
   // 2-launch trial where the A' y grid is resident all at once (grid barrier inside the kernel); PDLP_MI355X_FUSED=0 forces
   // 3 launches.  Slab layout (one block per CU): on by default, 140.0 -> 135.0 us per iteration at 1M x 1M.  Stream
   // layout: off by default — measured in round 3 the barrier + decision tail costs what the separate launch did
   // (100k x 100k: 33.1 us fused vs 32.1; 25fv47: 19.5 vs 20.2); PDLP_MI355X_FUSED_STREAM=1 turns it on.
   if (!sharded_) {
-    const char* fe = getenv("PDLP_MI355X_FUSED");
-    const char* fs = getenv("PDLP_MI355X_FUSED_STREAM");
     const MatView at = dAt_.view();
-    const bool allowed = at.useSlab ? !(fe && atoi(fe) == 0) : (fs && atoi(fs) != 0);
+    const bool allowed = at.useSlab ? sw_.fused != 0 : sw_.fusedStream != 0;
     fused_ = allowed && !hasQoff_ && fusedAtyBlocks(at) > 0 && fusedAtyBlocksResident(at, opt_.device) >= fusedAtyBlocks(at);
     // Netlib-class LPs (both operands below 2^18 nonzeros, stream layout, no long majors): the whole trial batch is one
     // persistent launch with grid barriers between the phases (pdlp_small.hip); PDLP_MI355X_PERSISTENT=0 turns it off
-    const char* pe = getenv("PDLP_MI355X_PERSISTENT");
     int resident = 0;
-    const int g = (pe && atoi(pe) == 0) || hasQoff_ ? 0 : smallTrialsGrid(dA_.view(), at, F_.n, opt_.device, &resident);
+    const int g = sw_.persistent == 0 || hasQoff_ ? 0 : smallTrialsGrid(dA_.view(), at, F_.n, opt_.device, &resident);
     if (g > 0 && g <= resident) {
       persistent_ = true;
       smallGrid_ = g;
       fused_ = false;
-      const char* xl = getenv("PDLP_MI355X_XCD_LOCAL");
       // one XCD has 32 CUs: up to one workgroup per CU the XCD-local mode wins (25fv47, 21 workgroups: 17.6 us per
       // iteration against 19.4 with agent-scope accesses on all XCDs and 20.3 with launches), beyond it the single L2 and
       // the shared CUs cost more than the memory round trips they save (80bau3b, 48 workgroups: 19.7 / 16.8 / 17.4)
-      xcdLocal_ = g <= 32 && !(xl && atoi(xl) == 0);
+      xcdLocal_ = g <= 32 && sw_.xcdLocal != 0;
       // beyond a few dozen workgroups the all-poll-all barrier is what a trial waits for (490 workgroups: 4.8 us per
       // barrier): meet per XCD in its L2 first (PDLP_MI355X_HIER_BARRIER=0/1 forces either)
-      const char* hbEnv = getenv("PDLP_MI355X_HIER_BARRIER");
       const bool smallChunks = dA_.view().csr.chunk == kChunkSmall && at.csr.chunk == kChunkSmall;
-      hierBar_ = !smallChunks || (hbEnv ? atoi(hbEnv) != 0 : g > 64);
+      hierBar_ = !smallChunks || (sw_.hierBarrier >= 0 ? sw_.hierBarrier != 0 : g > 64);
     }
     if (fused_) gridBar_.alloc(gridBarWords(fusedAtyBlocks(at)));
     if (persistent_) gridBar_.alloc(smallBarWords(smallGrid_));
   }
   // check iterations on the device (single GPU; the sharded paths issue their check collectives from the host)
-  {
-    const char* dc = getenv("PDLP_MI355X_DEVICE_CHECK");
-    devCheck_ = !sharded_ && !(dc && atoi(dc) == 0);
-  }
+  devCheck_ = !sharded_ && sw_.deviceCheck != 0;
   reset();
   // the trial-batch graph is part of the setup, not of the first iterations
   if (useGraph_ && !persistent_ && (!sharded_ || meshMode_)) captureGraph();
@@ -555,15 +513,13 @@ Solver::~Solver() { release(); }
 
 void Solver::uploadProblem() {
   const int32_t n = F_.n;
-  int slabMode = -1;  // auto
-  if (const char* g = getenv("PDLP_MI355X_SLAB")) slabMode = atoi(g);
   if (!sharded_) {
-    dA_.upload(F_.csr, F_.m, n, slabMode, stream_);
-    dAt_.upload(F_.cscSorted, n, F_.m, slabMode, stream_);
+    dA_.upload(F_.csr, F_.m, n, sw_, stream_);
+    dAt_.upload(F_.cscSorted, n, F_.m, sw_, stream_);
   } else {
     Compressed csrSlab, cscSlab;
     extractSlab(F_, r0_, r1_, csrSlab, cscSlab);
-    dA_.upload(csrSlab, mLoc_, n, slabMode, stream_);
+    dA_.upload(csrSlab, mLoc_, n, sw_, stream_);
     if (colblock_) {  // A'y operand: the columns this rank owns, over ALL rows (rows ascending, as on one GPU)
       Compressed cb;
       const int32_t b = F_.cscSorted.beg[c0_], e = F_.cscSorted.beg[c1_];
@@ -571,9 +527,9 @@ void Solver::uploadProblem() {
       for (int32_t j = 0; j <= nLoc_; ++j) cb.beg[j] = F_.cscSorted.beg[c0_ + j] - b;
       cb.idx.assign(F_.cscSorted.idx.begin() + b, F_.cscSorted.idx.begin() + e);
       cb.val.assign(F_.cscSorted.val.begin() + b, F_.cscSorted.val.begin() + e);
-      dAt_.upload(cb, nLoc_, F_.m, slabMode, stream_);
+      dAt_.upload(cb, nLoc_, F_.m, sw_, stream_);
     } else {
-      dAt_.upload(cscSlab, n, mLoc_, slabMode, stream_);
+      dAt_.upload(cscSlab, n, mLoc_, sw_, stream_);
     }
   }
   cost_.alloc(n); rhs_.alloc(mLoc_); lower_.alloc(n); upper_.alloc(n); colScale_.alloc(n); rowScale_.alloc(mLoc_);
@@ -589,7 +545,7 @@ void Solver::uploadProblem() {
     if (F_.qoff.beg.empty()) log(1, "Quadratic objective (diagonal Hessian): proximal primal step\n");
   }
   if (!F_.qoff.beg.empty()) {
-    dQ_.upload(F_.qoff, n, n, slabMode, stream_);
+    dQ_.upload(F_.qoff, n, n, sw_, stream_);
     log(1, "Quadratic objective (%lld off-diagonal Hessian entries): proximal step on the diagonal, explicit Q x term for the rest\n",
         (long long)F_.qoff.beg[n]);
     F_.qoff = Compressed();
@@ -633,10 +589,8 @@ void Solver::downloadForm(DeviceProblem& D, StandardForm& F, hipStream_t s) {
 }
 
 void Solver::uploadProblemFromDevice(DeviceProblem& D) {
-  int slabMode = -1;  // auto
-  if (const char* g = getenv("PDLP_MI355X_SLAB")) slabMode = atoi(g);
-  dA_.buildFromDevice(D.A, slabMode, stream_);
-  dAt_.buildFromDevice(D.At, slabMode, stream_);
+  dA_.buildFromDevice(D.A, sw_, stream_);
+  dAt_.buildFromDevice(D.At, sw_, stream_);
   cost_ = std::move(D.cost); rhs_ = std::move(D.rhs); lower_ = std::move(D.lower); upper_ = std::move(D.upper);
   colScale_ = std::move(D.colScale); rowScale_ = std::move(D.rowScale);
   if (D.qdiag.size()) {
@@ -731,6 +685,24 @@ void Solver::syncState() {
     PDLP_HIP(hipMemcpyAsync(dst(), hostState_, sizeof(DevState), hipMemcpyHostToDevice, stream_));
     PDLP_HIP(hipStreamSynchronize(stream_));
     log(1, "Note: the XCD-local trial loop is not placed on one XCD on this device; continuing with agent-scope accesses\n");
+  }
+  if (hostState_->commError == 3 && (persistent_ || fused_)) {
+    // A launch with in-kernel grid barriers did not get all its workgroups resident in time (the device is shared): the
+    // persistent launch has changed nothing (roll call), the fused trial is undecided (pdlp_kernels.hip fusedBarrierFailed:
+    // only the pending average weight of y has been consumed).  From here on plain launches, which need no co-residency.
+    const bool wasFused = fused_;
+    log(1, "Note: the workgroups of a launch with grid barriers were not resident together within %d ms (shared device?); "
+           "continuing with %s\n", sw_.barrierTimeoutMs, "3 launches per trial step");
+    persistent_ = false;
+    fused_ = false;
+    xcdLocal_ = false;
+    if (graphExec_) { (void)hipGraphExecDestroy(graphExec_); graphExec_ = nullptr; }
+    hostState_->commError = 0;
+    hostState_->halted = hostState_->nIter >= hostState_->haltIter ? 1 : 0;
+    if (wasFused) hostState_->avgW = 0.0;
+    gridBar_.zero(stream_);
+    ++barrierFallbacks_;
+    pushState();
   }
   if (hostState_->commError)
     throw std::runtime_error("pdlp_mi355x: a grid barrier or a peer did not answer in time (exchange timed out)");
@@ -955,7 +927,7 @@ void Solver::enqueueTrial() {
   }
   if (persistent_) {
     launchSmallTrials(dA_.view(), dAt_.view(), vecs_, dst(), partDY_.get(), partDX_.get(), partInter_.get(), gridBar_.get(), smallGrid_, 1,
-                      smallMode(), stream_);
+                      smallMode(), stream_, sw_.barrierTimeoutMs, sw_.fault == 1 && smallLaunches_++ == 0);
     return;
   }
   if (!sharded_ && fused_) {
@@ -982,7 +954,7 @@ void Solver::enqueueTrial() {
     if (ev) PDLP_HIP(hipEventRecord(ev[1], stream_));
     stPar_ ^= 1;
     launchSpmvAtyFusedPrimal(dAt_.view(), vecs_, st, dst(), partDY_.get(), dA_.nPartials(), partDX_.get(), partInter_.get(),
-                             gridBar_.get(), stream_);
+                             gridBar_.get(), stream_, sw_.barrierTimeoutMs, sw_.fault == 2 ? 12 : 0);
     if (ev) {
       PDLP_HIP(hipEventRecord(ev[2], stream_));
       PDLP_HIP(hipEventRecord(ev[3], stream_));
@@ -1055,7 +1027,7 @@ void Solver::captureGraph() {
 void Solver::enqueueBatch(int32_t todo) {
   if (persistent_ && !profile_) {  // the whole stretch to the next check (plus spare trials for rejections) in one launch
     launchSmallTrials(dA_.view(), dAt_.view(), vecs_, dst(), partDY_.get(), partDX_.get(), partInter_.get(), gridBar_.get(),
-                      smallGrid_, todo + 8, smallMode(), stream_);
+                      smallGrid_, todo + 8, smallMode(), stream_, sw_.barrierTimeoutMs, sw_.fault == 1 && smallLaunches_++ == 0);
     return;
   }
   if (useGraph_ && !persistent_ && !profile_ && (!sharded_ || meshMode_) && todo >= kGraphMinTodo) {
@@ -1080,9 +1052,12 @@ void Solver::runUntilHalt() {
     if (remaining > 4 * kCheckInterval) remaining = 4 * kCheckInterval;
     int32_t todo = (int32_t)remaining;
     const int32_t trialsBefore = hostState_->nTrials;
+    std::unique_lock<std::mutex> gate;
+    if (persistent_ || fused_) gate = std::unique_lock<std::mutex>(deviceGate(opt_.device));
     enqueueBatch(todo);
     const int32_t iterBefore = hostState_->nIter;
     syncState();
+    if (gate.owns_lock()) gate.unlock();
     if (profile_) profCollect(hostState_->nTrials - trialsBefore);
     if (hostState_->halted) return;
     // The reference's step-size search is a `while (!accepted)` loop: with NaN / Inf in the data it never ends.
@@ -1409,6 +1384,8 @@ void Solver::doSolveDevice(bool terminate, int32_t target) {
     const auto roundBeg = std::chrono::steady_clock::now();
     const int32_t iterBefore = s.nIter, trialsBefore = s.nTrials;
     const int64_t seq0 = checkSeq_;
+    std::unique_lock<std::mutex> gate;
+    if (persistent_ || fused_) gate = std::unique_lock<std::mutex>(deviceGate(opt_.device));
     int64_t itExp = s.nIter, haltExp = s.haltIter;
     if (s.halted) {  // (entry only: every batch below is followed by its check)
       enqueueCheckDevice();
@@ -1429,6 +1406,7 @@ void Solver::doSolveDevice(bool terminate, int32_t target) {
       if (itExp == haltExp) haltExp = haltAfter(itExp);
     }
     syncState();
+    if (gate.owns_lock()) gate.unlock();
     processRecords(terminate, iterLim, logSinceHeader);
     bool over = false;  // a check of this round has ended the solve (everything queued behind it was a no-op)
     for (int64_t q = seq0; q < checkSeq_; ++q) over = over || (hostRing_[q % kRingSlots].ran && hostRing_[q % kRingSlots].terminated);
@@ -1724,6 +1702,8 @@ void Solver::stage(const std::string& name, double* out, int32_t cap) {
     for (int k = 0; k < 3; ++k) { put(k, us[k]); put(3 + k, cnt[k]); }
   } else if (name == "trial_launches") {  // kernels per trial step of the hot loop (2 = fused decision + primal step)
     put(0, meshMode_ ? (colblock_ ? 10.0 : 9.0) : sharded_ ? 7.0 : persistent_ ? 0.0 : fused_ ? 2.0 : 3.0);  // 0: one persistent launch per batch
+  } else if (name == "barrier_fallbacks") {  // times a launch with grid barriers gave up and the loop went on with plain launches
+    put(0, (double)barrierFallbacks_);
   } else if (name == "exchange") {  // 0 = not sharded, 1 = RCCL all-reduce, 2 = direct xGMI mesh (partials), 3 = mesh, two all-gathers
     put(0, !sharded_ ? 0.0 : !meshMode_ ? 1.0 : colblock_ ? 3.0 : 2.0);
   } else if (name == "residuals") {

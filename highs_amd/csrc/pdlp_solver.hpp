@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cstdint>
 #include <map>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -18,6 +19,20 @@
 
 namespace pdlp {
 
+// Environment switches of a solver, read once at creation (pdlp_solver.cpp DevSwitches::fromEnv); -1 = not set.
+struct DevSwitches {
+  int graph = -1, forceComm = 0, gpuSetup = -1;
+  int slab = -1;          // PDLP_MI355X_SLAB: 0 CSR stream only, 1 slab layout, -1 automatic by the gathered vector's size
+  int slabW = 0;          // PDLP_MI355X_SLAB_W: log2 of the slab width (development)
+  int xcdMap = -1, slabPace = -1;
+  int fused = -1, fusedStream = 0, persistent = -1, xcdLocal = -1, hierBarrier = -1, deviceCheck = -1;
+  int barrierTimeoutMs = 1000;  // PDLP_MI355X_BARRIER_TIMEOUT_MS: how long a grid barrier / roll call waits for missing workgroups
+  int fault = 0;          // PDLP_MI355X_FAULT (tests): 1 = the first persistent launch expects one workgroup too many,
+                          // 2 = the 12th fused trial's barrier expects one block too many (both then time out and fall back)
+  std::string exchange, meshLayout;
+  static DevSwitches fromEnv();
+};
+
 // One operand matrix in HBM: CSR stream plan or slab layout for the majors that are summed left to right,
 // segment tasks for the long ones (pdlp_host.hpp LongPlan).
 struct DeviceMatrix {
@@ -26,9 +41,6 @@ struct DeviceMatrix {
   DeviceArray<double> val, slabVal;
   // long majors
   DeviceArray<LongTask> lTasks;
-  // LDS staging of the gathered vector (SlabMat::tileLog2 and its tables)
-  DeviceArray<int32_t> tBlkPtr, tSlab, tGroups, tWaveBeg;
-  int32_t tileLog2 = 0;
   DeviceArray<double> lSegSum, lContrib;
   DeviceArray<uint32_t> lTicket;
   int32_t nLong = 0, nTasks = 0, longSlots = 0, longGroup = 1;
@@ -39,24 +51,22 @@ struct DeviceMatrix {
   int32_t noPace = 0;  // slab kernel without the per-group block barrier (SlabMat::noPace), see tuneXcdMap
   int32_t xcdMap = 1;  // block -> XCD assignment of the SpMV kernels (pdlp_kernels.hip xcdContiguousBlock), see tuneXcdMap
   SlabMat slab{};
-  // mode: 0 = CSR stream only, 1 = slab layout, -1 = auto by nMinor
-  void upload(const Compressed& c, int32_t nMajor_, int32_t nMinor_, int mode, hipStream_t s);
+  // sw.slab: 0 = CSR stream only, 1 = slab layout, -1 = auto by nMinor
+  void upload(const Compressed& c, int32_t nMajor_, int32_t nMinor_, const DevSwitches& sw, hipStream_t s);
   // same, from a matrix that is already in HBM (GPU-side setup); takes M's arrays
-  void buildFromDevice(DeviceCsrData& M, int mode, hipStream_t s);
+  void buildFromDevice(DeviceCsrData& M, const DevSwitches& sw, hipStream_t s);
   MatView view() const;
   int32_t nPartials() const { return (useSlab ? slab.nBlocks : 0) + nBlocks + longSlots; }
 
  private:
   void uploadPlans(const std::vector<int32_t>& hostBeg, int32_t nCsrMajor, const int32_t* longVecIndex, hipStream_t s);
-  // should the operand be staged through LDS (per-block span / entry count of its short majors)? -> slab width to build with
-  static bool wantStaging(const std::vector<int32_t>& lo, const std::vector<int32_t>& hi, const std::vector<int32_t>& cnt, int32_t R,
-                          bool* local);  // *local: blocks touch few tiles of the gathered vector densely
-  void buildTileTables(int32_t nMinor, hipStream_t s);
+  // per-block column span / entry count of the short majors -> do the blocks touch few stretches of the gathered vector densely?
+  static bool touchesFewTiles(const std::vector<int32_t>& lo, const std::vector<int32_t>& hi, const std::vector<int32_t>& cnt);
 };
 
 // Picks M.xcdMap by timing the plain SpMV out = M * in with both block -> XCD assignments (a few launches; the
 // result vector is scratch).  PDLP_MI355X_XCD_MAP=0|1 forces one.
-void tuneXcdMap(DeviceMatrix& M, const double* in, double* out, hipStream_t s);
+void tuneXcdMap(DeviceMatrix& M, const DevSwitches& sw, const double* in, double* out, hipStream_t s);
 
 class Comm;  // RCCL wrapper (pdlp_comm.cpp)
 
@@ -141,6 +151,7 @@ class Solver : public SolverBase {
   bool timeIsUp();  // elapsed() > time_limit, agreed across ranks when sharded (identical control flow)
 
   pdlp_params_t opt_;
+  DevSwitches sw_;
   StandardForm F_;
   bool hasStart_ = false;
   std::vector<double> startX_, startY_;
@@ -192,6 +203,8 @@ class Solver : public SolverBase {
   int smallMode() const { return xcdLocal_ ? 1 : hierBar_ ? 2 : 0; }
   int32_t smallGrid_ = 0;
   DeviceArray<unsigned long long> gridBar_;
+  int32_t barrierFallbacks_ = 0, smallLaunches_ = 0;
+  static std::mutex& deviceGate(int device);
   int32_t stalledRounds_ = 0, stalledSince_ = 0;  // consecutive device stops without an accepted trial
   // Device-driven check iterations (pdlp_kernels.hpp CheckCtl; PDLP_MI355X_DEVICE_CHECK=0 gives the host-driven loop back)
   bool devCheck_ = true;

@@ -7,7 +7,7 @@ Runs the REAL cuPDLP-C core compiled from the reference sources (oracle/_ref/lib
 north_star parity criterion compares: objective, cuPDLP primal / dual objective, residual norms,
 HiGHS-style KKT measures and the iteration count.
 
-    python tests/golden/make_golden_synth.py [a] [b] [c_small] [c]   (default: a b; "b" takes ~1-2 h of one core)
+    python tests/golden/make_golden_synth.py [a] [b] [c_small] [c] [d_small] [d]   (default: a b; "b" takes ~1-2 h of one core)
 
 Output: tests/golden/reference_synth.json (one record per config; existing records of configs that are
 not re-run are kept).  The LP itself is regenerated on the GPU box by the library's seeded generator
@@ -31,14 +31,20 @@ CONFIGS = {"a": (100_000, 100_000, 1_000_000), "b": (1_000_000, 1_000_000, 8_000
            # BASELINE config 3 stand-in (pds-100 is not in the reference tree): tests/lpgen.py::structured_lp,
            # block-angular network LP with dense linking rows; "c" = the bench size (5.3M nnz), "c_small" = 1/16
            "c_small": dict(commodities=16, nodes=1024, arcs=8192, link_rows=64, link_nnz=2048, extra_rows=128),
-           "c": dict()}
+           "c": dict(),
+           # second structured family (round 4): tests/lpgen.py::dense_column_lp — staircase LP with DENSE COLUMNS and
+           # power-law row lengths; "d" = the bench size (~4.4M nnz), "d_small" ~ 1/8
+           "d_small": dict(family="dense_column", periods=64, rows_per=1024, cols_per=896, dense_cols=48, dense_nnz=4000,
+                           tail_rows=512, tail_max=2500),
+           "d": dict(family="dense_column")}
 OUT = os.path.join(HERE, "reference_synth.json")
 
 
 def record(key, tol):
     if isinstance(CONFIGS[key], dict):
-        from lpgen import structured_lp
-        lp = structured_lp(1, **CONFIGS[key])
+        from lpgen import dense_column_lp, structured_lp
+        kw = dict(CONFIGS[key])
+        lp = dense_column_lp(1, **kw) if kw.pop("family", None) == "dense_column" else structured_lp(1, **kw)
         m, n, nnz = lp.num_row, lp.num_col, lp.num_nz
     else:
         m, n, nnz = CONFIGS[key]

@@ -164,3 +164,87 @@ def structured_lp(seed=1, commodities=64, nodes=4096, arcs=32768, link_rows=256,
     np.add.at(c, cols, vals * y0[rows])
     return L.HighsLp(n, m, c, cl, cu, rl, ru, a_start.astype(np.int32), rows.astype(np.int32), vals, 1, 3.0,
                      f"structured{seed}").normalise()
+
+
+def dense_column_lp(seed=1, periods=512, rows_per=1024, cols_per=896, dense_cols=192, dense_nnz=6000, tail_rows=2048,
+                    tail_max=3000):
+    """A second structured family next to structured_lp (BASELINE config 3 stands for real-world LPs; pds-100 itself is
+    not in the tree): a STAIRCASE of `periods` time periods — period t owns `cols_per` columns and `rows_per` rows whose
+    entries sit in the columns of periods t-1 and t (multi-period production / inventory models: a banded matrix, every
+    row block gathers from two neighbouring column blocks) — plus what such models carry in practice and what the
+    block-angular LP does not have:
+      * DENSE COLUMNS: `dense_cols` linking columns (capacity-expansion variables) with ~`dense_nnz` nonzeros each
+        spread over ALL periods — longer than the slab layout's 256-entry limit and the stream plan's 2048-entry blocks,
+        so A'y runs them as segment tasks (the transpose of structured_lp's dense rows);
+      * POWER-LAW ROW LENGTHS: `tail_rows` extra rows whose lengths follow a Pareto law (most below 20 entries, the
+        longest ~`tail_max`), entries anywhere in the staircase;
+      * <=, >=, ranged and equality rows, boxed / fixed / free / one-sided columns, a maximisation sense and an offset.
+    Feasible and bounded by construction (a point strictly inside the bounds; costs = A'y0 + reduced costs of the sign
+    each bound admits).  Defaults: 459k columns, 526k rows, ~4.4M nonzeros.  Deterministic for a given seed."""
+    rng = np.random.default_rng(seed)
+    inf = float("inf")
+    T, R, Cp = periods, rows_per, cols_per
+    n_st = T * Cp
+    n = n_st + dense_cols
+    m_st = T * R
+    # --- staircase rows: 2..6 entries in the own period's columns, 1..3 in the previous period's
+    k_own = rng.integers(2, 7, size=m_st)
+    k_prev = rng.integers(1, 4, size=m_st)
+    k_prev[:R] = 0
+    per = np.repeat(np.arange(T, dtype=np.int64), R)
+    r_own = np.repeat(np.arange(m_st, dtype=np.int64), k_own)
+    c_own = np.repeat(per, k_own) * Cp + rng.integers(0, Cp, size=r_own.size)
+    r_prev = np.repeat(np.arange(m_st, dtype=np.int64), k_prev)
+    c_prev = (np.repeat(per, k_prev) - 1) * Cp + rng.integers(0, Cp, size=r_prev.size)
+    # --- power-law rows
+    lens = np.minimum(tail_max, (4.0 * (1.0 + rng.pareto(1.1, size=tail_rows))).astype(np.int64))
+    r_tail = m_st + np.repeat(np.arange(tail_rows, dtype=np.int64), lens)
+    c_tail = rng.integers(0, n_st, size=r_tail.size)
+    m = m_st + tail_rows
+    # --- dense columns: ~dense_nnz rows each, anywhere
+    r_dense = rng.integers(0, m, size=(dense_cols, dense_nnz)).ravel()
+    c_dense = n_st + np.repeat(np.arange(dense_cols, dtype=np.int64), dense_nnz)
+    rows = np.concatenate([r_own, r_prev, r_tail, r_dense])
+    cols = np.concatenate([c_own, c_prev, c_tail, c_dense])
+    vals = rng.uniform(0.2, 2.0, size=rows.size) * np.where(rng.random(rows.size) < 0.4, -1.0, 1.0)
+    # one entry per (column, row): sort column-major and drop repeats
+    order = np.lexsort((rows, cols))
+    rows, cols, vals = rows[order], cols[order], vals[order]
+    first = np.ones(rows.size, dtype=bool)
+    first[1:] = (rows[1:] != rows[:-1]) | (cols[1:] != cols[:-1])
+    rows, cols, vals = rows[first], cols[first], vals[first]
+    a_start = np.zeros(n + 1, np.int64)
+    a_start[1:] = np.cumsum(np.bincount(cols, minlength=n))
+    # --- a primal point and the column bounds around it
+    xs = rng.uniform(-1.0, 1.0, n)
+    cl = xs - rng.uniform(0.1, 1.0, n)
+    cu = xs + rng.uniform(0.1, 1.0, n)
+    kind = rng.random(n)
+    cl[kind < 0.15] = -inf                      # only an upper bound
+    cu[(kind >= 0.15) & (kind < 0.35)] = inf    # only a lower bound
+    free = (kind >= 0.35) & (kind < 0.38)
+    cl[free], cu[free] = -inf, inf
+    fixed = (kind >= 0.38) & (kind < 0.39)
+    cl[fixed] = cu[fixed] = xs[fixed]
+    ax = np.zeros(m)
+    np.add.at(ax, rows, vals * xs[cols])
+    rk = rng.random(m)
+    rl, ru = ax.copy(), ax.copy()                                   # rk < 0.3: equality
+    le = (rk >= 0.3) & (rk < 0.55)
+    rl[le], ru[le] = -inf, ax[le] + rng.uniform(0.0, 1.0, int(le.sum()))
+    ge = (rk >= 0.55) & (rk < 0.8)
+    rl[ge], ru[ge] = ax[ge] - rng.uniform(0.0, 1.0, int(ge.sum())), inf
+    rg = rk >= 0.8
+    rl[rg], ru[rg] = ax[rg] - rng.uniform(0.1, 1.0, int(rg.sum())), ax[rg] + rng.uniform(0.1, 1.0, int(rg.sum()))
+    # --- a bounded objective for the MINIMISATION form, then handed over as a maximisation: c = A'y0 + z
+    y0 = rng.standard_normal(m)
+    y0[le] = -np.abs(y0[le])
+    y0[ge] = np.abs(y0[ge])
+    z = rng.standard_normal(n)
+    z = np.where(np.isinf(cl) & ~np.isinf(cu), -np.abs(z), z)   # only an upper bound: z <= 0
+    z = np.where(np.isinf(cu) & ~np.isinf(cl), np.abs(z), z)    # only a lower bound: z >= 0
+    z[free] = 0.0
+    c = z.copy()
+    np.add.at(c, cols, vals * y0[rows])
+    return L.HighsLp(n, m, -c, cl, cu, rl, ru, a_start.astype(np.int32), rows.astype(np.int32), vals, -1, -7.5,
+                     f"staircase{seed}").normalise()

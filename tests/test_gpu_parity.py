@@ -391,6 +391,35 @@ def test_structured_lp_converged_matches_reference(key):
     assert 0.25 * g["num_iter"] <= R.num_iter <= 4 * g["num_iter"]
 
 
+D_SMALL = dict(periods=64, rows_per=1024, cols_per=896, dense_cols=48, dense_nnz=4000, tail_rows=512, tail_max=2500)
+
+
+@pytest.mark.parametrize("key", ["d_small_tol1e-07", "d_tol1e-07"])
+def test_dense_column_lp_converged_matches_reference(key):
+    """Second structured family (round 4, tests/lpgen.py::dense_column_lp): a staircase LP with DENSE COLUMNS (thousands
+    of entries: segment tasks in the A'y launch — the transpose of config c's dense rows), power-law row lengths,
+    <= / >= / ranged rows and a maximisation sense; converged objectives against the real cuPDLP-C core
+    (tests/golden/make_golden_synth.py d_small / d), 1e-6 relative, and the trial loop must not fall off its fast path
+    because of the long columns."""
+    if key not in SYNTH:
+        pytest.skip("golden not generated")
+    from lpgen import dense_column_lp
+    lp = dense_column_lp(1, **(D_SMALL if "small" in key else {}))
+    g = SYNTH[key]
+    assert (lp.num_row, lp.num_col, lp.num_nz) == (g["m"], g["n"], g["nnz"])
+    out = solver.solveLpCupdlp(lp)
+    assert out.model_status == solver.kOptimal
+    R = out.result
+    ref = g["objective_function_value"]
+    scale = 1.0 + abs(ref)
+    assert abs(out.info["objective_function_value"] - ref) <= 1e-6 * scale
+    assert abs(R.primal_obj - g["primal_obj"]) <= 1e-6 * scale and abs(R.dual_obj - g["dual_obj"]) <= 1e-6 * scale
+    assert R.norm_rhs == g["norm_rhs"] and R.norm_cost == g["norm_cost"]
+    assert out.info["max_primal_residual_error"] <= max(10 * g["kkt"]["max_primal_residual_error"], 1e-9)
+    assert out.info["max_dual_residual_error"] <= max(10 * g["kkt"]["max_dual_residual_error"], 1e-9)
+    assert 0.25 * g["num_iter"] <= R.num_iter <= 4 * g["num_iter"]
+
+
 @pytest.mark.skipif("b_tol1e-07" not in SYNTH, reason="golden for config 4 not generated")
 def test_synthetic_1m_converged_matches_reference():
     _converged_against_reference("b_tol1e-07", 1000000, 1000000, 8000000)
@@ -502,17 +531,20 @@ def test_gpu_setup_long_rows_slab_layout(monkeypatch):
     S.close()
 
 
-def test_lds_staged_slab_layout_bit_identical(monkeypatch):
-    """Structured operand (block-angular network LP in small): the slab kernel that stages the gathered vector through
-    LDS tile by tile (SlabMat::tileLog2) must give the bits of the plain slab kernel — entry order and every sum are
-    unchanged —, for the plain SpMVs (also against the oracle's device order) and for the iterates after 120
-    iterations with every fused epilogue in the loop."""
+def test_slab_width_does_not_change_the_bits(monkeypatch):
+    """Structured operand (block-angular network LP in small): its row blocks touch few stretches of the gathered vector
+    densely, so the slab layout is built with 2^14-column slabs instead of 2^17 (pdlp_kernels.hpp kSlabTileLog2).  Entry
+    order inside a major, hence every sum, does not depend on the slab width: the plain SpMVs (also against the oracle's
+    device order) and the iterates after 120 iterations with every fused epilogue in the loop agree bit for bit."""
     from lpgen import structured_lp
     lp = structured_lp(seed=2, commodities=12, nodes=1024, arcs=8192, link_rows=24, link_nnz=700, extra_rows=40)
     monkeypatch.setenv("PDLP_MI355X_SLAB", "1")
     out = {}
-    for stage in ("0", "1"):
-        monkeypatch.setenv("PDLP_MI355X_SLAB_STAGE", stage)
+    for width in ("", "17", "12"):
+        if width:
+            monkeypatch.setenv("PDLP_MI355X_SLAB_W", width)
+        else:
+            monkeypatch.delenv("PDLP_MI355X_SLAB_W", raising=False)
         P = solver.Prepared(lp)
         S = solver.DeviceSolver(lp)
         rng = np.random.default_rng(4)
@@ -524,10 +556,11 @@ def test_lds_staged_slab_layout_bit_identical(monkeypatch):
         S.close()
         S = solver.DeviceSolver(lp)
         S.iterate(120)
-        out[stage] = (ax, aty, S.get("x", P.n), S.get("y", P.m), S.get("steps", 8))
+        out[width] = (ax, aty, S.get("x", P.n), S.get("y", P.m), S.get("steps", 8))
         S.close()
-    for a, b in zip(out["0"], out["1"]):
-        assert np.array_equal(a, b)
+    for w in ("17", "12"):
+        for a, b in zip(out[""], out[w]):
+            assert np.array_equal(a, b)
 
 
 @pytest.mark.parametrize("name,iters", [("afiro", 160), ("25fv47", 400), ("80bau3b", 400), ("synthetic", 240)])
@@ -629,6 +662,96 @@ def test_concurrent_solver_contexts_on_two_threads():
         assert out[k].pdlp_iteration_count == alone[k].pdlp_iteration_count
         assert np.array_equal(out[k].solution.col_value, alone[k].solution.col_value), k
         assert np.array_equal(out[k].solution.row_dual, alone[k].solution.row_dual), k
+
+
+def _iterate_state(kw, iters):
+    S = solver.DeviceSolver(**kw)
+    st = S.iterate(iters)
+    out = (S.get("x", S.n), S.get("y", S.m), S.get("steps", 8), int(st.trials), int(st.iters), int(S.stage("trial_launches")[0]),
+           int(S.stage("barrier_fallbacks")[0]))
+    S.close()
+    return out
+
+
+@pytest.mark.parametrize("which", ["persistent", "fused"])
+def test_barrier_launch_that_cannot_be_resident_falls_back_to_plain_launches(which, monkeypatch):
+    """Launches with in-kernel grid barriers (the persistent trial loop, the 2-launch fused trial) are plain launches: HIP
+    promises no co-residency, and on a shared device a workgroup may wait for CUs another tenant holds.  The persistent
+    launch therefore starts with a roll call and changes nothing if it fails; the fused trial's barrier fails for all
+    blocks or for none and leaves the trial undecided (pdlp_devfn.hpp rollCall / gridBarrier).  PDLP_MI355X_FAULT makes
+    exactly that happen once (one workgroup too many expected, 30 ms timeout): the solver must go on with plain launches
+    — and, because a failed launch changes nothing, with the very same bits."""
+    if which == "persistent":
+        kw, iters, fault = dict(lp=_lp("25fv47")), 400, "1"
+    else:
+        sp_ = solver.SyntheticProblem(300000, 280000, 2000000, 5)
+        kw, iters, fault = dict(problem_struct=sp_.struct), 160, "2"
+    ref = _iterate_state(kw, iters)
+    assert ref[5] == (0 if which == "persistent" else 2) and ref[6] == 0
+    monkeypatch.setenv("PDLP_MI355X_FAULT", fault)
+    monkeypatch.setenv("PDLP_MI355X_BARRIER_TIMEOUT_MS", "30")
+    out = _iterate_state(kw, iters)
+    assert out[5] == 3 and out[6] == 1, out[5:]
+    for a, b in zip(ref[:3], out[:3]):
+        assert np.array_equal(a, b)
+    assert ref[3:5] == out[3:5]
+    # the same through a whole solve (device-driven checks queued behind the failing launch must all stay shut)
+    if which == "persistent":
+        monkeypatch.delenv("PDLP_MI355X_FAULT")
+        a = solver.solveLpCupdlp(kw["lp"])
+        monkeypatch.setenv("PDLP_MI355X_FAULT", fault)
+        b = solver.solveLpCupdlp(kw["lp"])
+        assert a.pdlp_iteration_count == b.pdlp_iteration_count and np.array_equal(a.solution.col_value, b.solution.col_value)
+
+
+def test_two_large_contexts_concurrently():
+    """Two solver contexts with grid-barrier launches on ONE device at the same time (several Highs
+    instances on several threads): two mid-size LPs on the persistent loop (hundreds of workgroups each, more than the
+    device holds together) and two slab-layout LPs on the fused 2-launch trial, next to a third tenant that needs no
+    barriers (a HiPDLP solve whose 1024-thread kernels keep taking and releasing every CU).  The per-device gate lets
+    one barrier round run at a time: no deadlock, no barrier timeouts (the default timeout is 1 s: a stall would show
+    in the wall clock), and every result bit-identical to the same work done alone."""
+    import threading
+    import time
+    mids = [solver.SyntheticProblem(40000, 35000, 400000, 9), solver.SyntheticProblem(38000, 36000, 380000, 10)]
+    bigs = [solver.SyntheticProblem(300000, 280000, 2000000, 5), solver.SyntheticProblem(290000, 300000, 2100000, 6)]
+    jobs = {"mid0": (dict(problem_struct=mids[0].struct), 2000), "mid1": (dict(problem_struct=mids[1].struct), 2000),
+            "big0": (dict(problem_struct=bigs[0].struct), 400), "big1": (dict(problem_struct=bigs[1].struct), 400)}
+    t0 = time.time()
+    alone = {k: _iterate_state(kw, it) for k, (kw, it) in jobs.items()}
+    t_alone = time.time() - t0
+    assert alone["mid0"][5] == 0 and alone["big0"][5] == 2
+    hip_lp = bigs[1].to_lp()
+    out, errs = {}, []
+
+    def work(name):
+        try:
+            out[name] = _iterate_state(*jobs[name])
+        except Exception as e:  # noqa: BLE001
+            errs.append((name, repr(e)))
+
+    def tenant():
+        try:
+            out["tenant"] = solver.solveLpHiPdlp(hip_lp, kkt_tolerance=1e-12, pdlp_iteration_limit=1200)
+        except Exception as e:  # noqa: BLE001
+            errs.append(("tenant", repr(e)))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in jobs] + [threading.Thread(target=tenant)]
+    t0 = time.time()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    t_together = time.time() - t0
+    assert not errs, errs
+    for k in jobs:
+        assert out[k][6] == 0, (k, "a barrier launch gave up")
+        for a, b in zip(alone[k][:3], out[k][:3]):
+            assert np.array_equal(a, b), k
+        assert alone[k][3:6] == out[k][3:6], k
+    assert t_together < 3.0 * t_alone + 3.0, (t_together, t_alone)
+    for p in mids + bigs:
+        p.close()
 
 
 def test_time_limit_status_on_both_paths():

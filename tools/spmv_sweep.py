@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from highs_amd import abi, solver  # noqa: E402
 
 ENV = {"slab": "PDLP_MI355X_SLAB", "w": "PDLP_MI355X_SLAB_W", "xcd": "PDLP_MI355X_XCD_MAP", "graph": "PDLP_MI355X_GRAPH",
-       "gpusetup": "PDLP_MI355X_GPU_SETUP", "pipe": "PDLP_MI355X_SLAB_PIPE", "occ2": "PDLP_MI355X_SLAB_OCC2"}
+       "gpusetup": "PDLP_MI355X_GPU_SETUP", "pipe": "PDLP_MI355X_SLAB_PIPE"}
 DEFAULT = "slab=1;slab=1,w=15;slab=1,w=16;slab=1,w=18;slab=1,xcd=0;slab=1,xcd=1;slab=0"
 
 ap = argparse.ArgumentParser()
