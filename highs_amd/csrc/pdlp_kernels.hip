@@ -52,6 +52,7 @@ struct SpmvArgs {
   unsigned long long* bar;
   unsigned long long barLimit;  // 100 MHz ticks the grid barrier may wait for a missing block
   int32_t faultTrial;           // tests: the barrier of the trial that raises the trial counter to this value expects one block too many
+  int32_t inlineTasks;          // kAtyFused: the streaming blocks run the segment tasks of the long majors themselves (no extra blocks)
   CheckGate gate;  // kPlain inside a device-driven check: the launch is a no-op unless the check is due
 };
 
@@ -234,12 +235,15 @@ __device__ __forceinline__ void longBlock(const SpmvArgs& a, Epi<EPI>& epi, int 
     const double keep0 = epi.acc0, keep1 = epi.acc1;
     epi.acc0 = 0.0; epi.acc1 = 0.0;
     epi.apply(T.major, total, pre);
+    // kAtyFused: the block that owns this column takes (A'y+)_c from memory for the next primal step, and every block
+    // reads the major's contributions behind the grid barrier: write-through (agent-scope) stores
+    if (EPI == kAtyFused) stAgent(a.v.aty[epi.nxt] + T.major, total);
     if (EPI == kDualStep || EPI == kQxInteract || isInteract(EPI)) {  // the major's own slot (or, beyond kLongSlotCap, its entry for k_long_groups)
       double* o0 = L.contrib ? L.contrib + T.c : a.part0 + L.slotBase + T.c;
-      *o0 = epi.acc0;
+      if (EPI == kAtyFused) stAgent(o0, epi.acc0); else *o0 = epi.acc0;
       if (isInteract(EPI)) {
         double* o1 = L.contrib ? L.contrib + L.nLong + T.c : a.part1 + L.slotBase + T.c;
-        *o1 = epi.acc1;
+        if (EPI == kAtyFused) stAgent(o1, epi.acc1); else *o1 = epi.acc1;
       }
     }
     epi.acc0 = keep0; epi.acc1 = keep1;
@@ -620,6 +624,18 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
     }
   }
   epi.template finish<kSlabThreads>(blk, scratch);
+  if (EPI == kAtyFused && a.inlineTasks) {
+    // Long columns in the fused trial: their segment tasks cannot be extra workgroups (those would have to be resident
+    // next to the waiting blocks), so the streaming blocks take them — task group tb goes to block tb % nBlocks, one
+    // task per wave, same lanes and sums as in the extra blocks of the other launches (longBlock).
+    const int nTB = (a.L.nTasks + kWaves - 1) / kWaves;
+    for (int tb = (int)blockIdx.x; tb < nTB; tb += a.S.nBlocks) {
+      longBlock<EPI, kWaves>(a, epi, tb, &scratch[0][0]);
+      __syncthreads();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave's published words have landed before the block arrives
+    __syncthreads();
+  }
   if (EPI == kAtyFused) {
     // ---- every block's partials in HBM -> decision (identical in every block) -> the next trial's primal step ----
     double(*tscr)[kVecThreads / kWave] = reinterpret_cast<double(*)[kVecThreads / kWave]>(&scratch[2][0]);
@@ -670,19 +686,21 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
       t = t > l ? t : l;
       xOut[r] = t;  // gathered by the A x+ kernel: ordinary store
     };
+    // (a long column's A'y+ was computed by a segment task, maybe in another block: taken from memory, agent scope)
+    auto isLong = [&](int lr) { return a.inlineTasks && ((mask[lr >> 5] >> (lr & 31)) & 1u) != 0u; };
 #pragma unroll
     for (int k = 0; k < kSlabPre; ++k) {
       const int lr = tid + k * kSlabThreads;
       if (rBase + lr < rEnd) {  // (a rejected trial, 3 %, fetches x and A'y again)
         const int r = rBase + lr;
-        step(r, accepted ? pre[k].b : ldStream(xBase + r), accepted ? acc[lr] : ldStream(atyBase + r), fix[k].a, fix[k].b, fix[k].c,
-             fix[k].d);
+        const double ab = isLong(lr) ? ldAgent(atyBase + r) : accepted ? acc[lr] : ldStream(atyBase + r);
+        step(r, accepted ? pre[k].b : ldStream(xBase + r), ab, fix[k].a, fix[k].b, fix[k].c, fix[k].d);
       }
     }
     for (int lr = tid + kSlabPre * kSlabThreads; rBase + lr < rEnd; lr += kSlabThreads) {  // (more than 4096 majors per block)
       const int r = rBase + lr;
-      step(r, ldStream(xBase + r), accepted ? acc[lr] : ldStream(atyBase + r), ldStream(a.v.cost + r), ldStream(a.v.lower + r),
-           ldStream(a.v.upper + r), ldStream(a.v.xSum + r));
+      const double ab = isLong(lr) ? ldAgent(atyBase + r) : accepted ? acc[lr] : ldStream(atyBase + r);
+      step(r, ldStream(xBase + r), ab, ldStream(a.v.cost + r), ldStream(a.v.lower + r), ldStream(a.v.upper + r), ldStream(a.v.xSum + r));
     }
   }
 }
@@ -1139,7 +1157,9 @@ size_t fusedLds(const MatView& At) {
 }
 }  // namespace
 int fusedAtyBlocksResident(const MatView& At, int device) {
-  if (At.lng.nTasks > 0) return 0;  // (long majors run in extra blocks that take no part in the barrier)
+  // long columns: the slab kernel's streaming blocks run their segment tasks themselves (SpmvArgs::inlineTasks); not
+  // the stream-layout kernel, and not beyond kLongSlotCap long columns (their contributions need the k_long_groups launch)
+  if (At.lng.nTasks > 0 && (!At.useSlab || At.lng.contrib != nullptr)) return 0;
   int perCu = 0, cus = 0;
   hipError_t e;
   if (At.useSlab) {
@@ -1161,6 +1181,7 @@ void launchSpmvAtyFusedPrimal(const MatView& At, const IterVecs& v, const DevSta
   SpmvArgs a{};
   a.barLimit = (unsigned long long)(timeoutMs > 0 ? timeoutMs : 1000) * 100000ull;
   a.faultTrial = faultTrial;
+  a.inlineTasks = At.useSlab && At.lng.nTasks > 0 ? 1 : 0;
   a.st = stIn; a.v = v; a.part0 = partDX; a.part1 = partInter;
   a.stOut = stOut; a.partDY = partDY; a.nDY = nDY; a.nDX = At.nPartials; a.bar = bar;
   a.xcdMap = At.xcdMap; a.L = At.lng; a.A = At.csr; a.S = At.slab;

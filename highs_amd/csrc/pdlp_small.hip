@@ -43,6 +43,8 @@ namespace {
 
 struct SmallArgs {
   SpmvMat A, At;
+  LongMat LA, LAt;           // segment tasks of the long majors (nTasks = 0: none)
+  int32_t nPartA, nPartAt;   // partial slots of each operand: stream blocks + long majors
   IterVecs v;
   DevState* st;
   double* partDY;
@@ -168,6 +170,108 @@ __device__ __forceinline__ void smallSpmvBlock(const SmallArgs& a, const SpmvMat
   }
 }
 
+
+// The segment tasks of the long majors inside the persistent loop (majors longer than a stream block: standata, standgub,
+// standmps, cplex1 of the reference's instances; dense rows / columns of structured LPs).  Task group tb = one task per
+// wave, exactly the lanes, sums, LDS / ticket hand-overs and per-major partial slots of pdlp_kernels.hip longBlock — so
+// the bits are those of the launch loop — with the loop's accesses to the changing vectors (ldM / stM).  Task groups are
+// dealt to the workgroups round robin after their stream block; a major whose segments span task groups is finished by
+// the wave with the last ticket, in whichever workgroup that is (agent-scope segment sums and tickets in every mode).
+template <bool DUAL, bool LOCAL>
+__device__ __forceinline__ void smallLongBlock(const SmallArgs& a, const LongMat& L, int tb, int cur, double sigma, double avgW,
+                                               double* lds /* [4] */, double* part0, double* part1) {
+  constexpr int W = kSpmvThreads / kWave;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x / kWave);
+  const int nxt = cur ^ 1;
+  const int t = tb * W + wave;
+  LongTask T;
+  T.c = -1; T.pBeg = T.pEnd = 0; T.first = t; T.nSeg = 1; T.major = 0; T.contained = 1; T.pad_ = 0;
+  if (t < L.nTasks) {
+    const int32_t* q = reinterpret_cast<const int32_t*>(L.tasks + t);
+    T.pBeg = ldUniform(q); T.pEnd = ldUniform(q + 1); T.c = ldUniform(q + 2); T.first = ldUniform(q + 3);
+    T.nSeg = ldUniform(q + 4); T.major = ldUniform(q + 5); T.contained = ldUniform(q + 6);
+  }
+  const bool active = T.c >= 0;
+  const int seg = t - T.first;
+  const int r = T.major;
+  double pa = 0.0, pb = 0.0, pc = 0.0;
+  if (active && (seg == 0 || !T.contained)) {
+    if (DUAL) { pa = ldM<LOCAL>(a.v.y[cur] + r); pb = a.v.rhs[r]; pc = ldM<LOCAL>(a.v.ax[cur] + r); }
+    else { pa = ldM<LOCAL>(a.v.x[cur] + r); pb = ldM<LOCAL>(a.v.x[nxt] + r); pc = ldM<LOCAL>(a.v.aty[cur] + r); }
+  }
+  const int32_t* __restrict__ idx = L.idx;
+  const double* __restrict__ val = L.val;
+  const double* in = DUAL ? a.v.x[nxt] : a.v.y[nxt];
+  constexpr int kPer = kLongSegment / kWave;
+  double s = 0.0;
+  for (int base = T.pBeg; base < T.pEnd; base += kLongSegment) {
+    int32_t ci[kPer];
+    double va[kPer], xg[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {  // unconditional, clamped
+      const int q = base + k * kWave + lane;
+      const int qq = q < T.pEnd ? q : T.pEnd - 1;
+      ci[k] = idx[qq];
+      va[k] = val[qq];
+    }
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) xg[k] = ldM<LOCAL>(in + ci[k]);
+#pragma unroll
+    for (int k = 0; k < kPer; ++k)
+      if (base + k * kWave + lane < T.pEnd) s += va[k] * xg[k];
+  }
+  s = waveSum(s);
+  int last = 0;
+  if (lane == 0) {
+    lds[wave] = s;
+    if (active && !T.contained) {
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(L.segSum + t), (unsigned long long)__double_as_longlong(s),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the segment sum has landed before the ticket is taken
+      const unsigned old = __hip_atomic_fetch_add(L.ticket + T.c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = old == (unsigned)(T.nSeg - 1) ? 1 : 0;
+    }
+  }
+  last = __builtin_amdgcn_readfirstlane(last);
+  __syncthreads();
+  double total = 0.0;
+  bool finish = false;
+  if (active && T.contained && seg == 0) {
+    for (int k = 0; k < T.nSeg; ++k) total += lds[wave + k];  // left to right
+    finish = true;
+  } else if (last) {
+    if (lane == 0) __hip_atomic_store(L.ticket + T.c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed
+    double v = 0.0;
+    if (lane < T.nSeg)
+      v = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(L.segSum + T.first + lane),
+                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    for (int k = 0; k < T.nSeg; ++k) total += __shfl(v, k, kWave);  // left to right
+    finish = true;
+  }
+  if (finish && lane == 0) {
+    if (DUAL) {
+      const double yv = pa;
+      if (avgW != 0.0) stM<LOCAL>(a.v.ySum + r, ldM<LOCAL>(a.v.ySum + r) + avgW * yv);  // deferred PDHG_Update_Average (step.c:438)
+      double tt = yv;
+      tt += sigma * pb;
+      tt += (-2.0 * sigma) * total;
+      tt += sigma * pc;
+      if (r + a.v.rowOffset >= a.v.nEqs) tt = tt > 0.0 ? tt : 0.0;
+      stM<LOCAL>(a.v.ax[nxt] + r, total);
+      stM<LOCAL>(a.v.y[nxt] + r, tt);
+      const double d = yv - tt;
+      stM<LOCAL>(part0 + L.slotBase + T.c, 0.0 + d * d);
+    } else {
+      const double dx = pa - pb;
+      const double da = pc - total;
+      stM<LOCAL>(a.v.aty[nxt] + r, total);
+      stM<LOCAL>(part0 + L.slotBase + T.c, 0.0 + dx * dx);
+      stM<LOCAL>(part1 + L.slotBase + T.c, 0.0 + dx * da);
+    }
+  }
+}
+
 // MODE 0: agent-scope accesses, sweep barrier; 1: XCD-local; 2: agent-scope accesses, XCD-hierarchical barrier
 template <int CHUNK_A, int CHUNK_AT, int MODE>
 __global__ __launch_bounds__(kSpmvThreads) void k_trials_small(const SmallArgs a) {
@@ -203,6 +307,8 @@ __global__ __launch_bounds__(kSpmvThreads) void k_trials_small(const SmallArgs a
   __syncthreads();
   // the blocks this workgroup owns (the grid has at least as many workgroups as either operand has blocks)
   const int nA = a.A.nBlocks, nAt = a.At.nBlocks;
+  const int nTBA = (a.LA.nTasks + kSpmvThreads / kWave - 1) / (kSpmvThreads / kWave);    // task groups of 4 (one task per wave)
+  const int nTBAt = (a.LAt.nTasks + kSpmvThreads / kWave - 1) / (kSpmvThreads / kWave);
   OwnBlock<CHUNK_A> bA;
   OwnBlock<CHUNK_AT> bAt;
   if (lb < nA) bA.load(a.A, a.xcdA ? xcdContiguousBlock(lb, nA) : lb, true, a.v.rhs);
@@ -306,6 +412,10 @@ __global__ __launch_bounds__(kSpmvThreads) void k_trials_small(const SmallArgs a
       const double t = blockSum<kSpmvThreads>(acc0, scratch[0]);
       if (tid == 0) stM<LOCAL>(a.partDY + bA.slot_, t);
     }
+    for (int tb = lb; tb < nTBA; tb += G) {  // long rows: segment tasks
+      smallLongBlock<true, LOCAL>(a, a.LA, tb, cur, sigma, avgW, scratch[0], a.partDY, nullptr);
+      __syncthreads();
+    }
     stamp(2);
     meet(e0 + 2);
     stamp(3);
@@ -317,13 +427,17 @@ __global__ __launch_bounds__(kSpmvThreads) void k_trials_small(const SmallArgs a
       const double t1 = blockSum<kSpmvThreads>(acc1, scratch[1]);
       if (tid == 0) { stM<LOCAL>(a.partDX + bAt.slot_, t0); stM<LOCAL>(a.partInter + bAt.slot_, t1); }
     }
+    for (int tb = lb; tb < nTBAt; tb += G) {  // long columns: segment tasks
+      smallLongBlock<false, LOCAL>(a, a.LAt, tb, cur, sigma, avgW, scratch[0], a.partDX, a.partInter);
+      __syncthreads();
+    }
     stamp(4);
     meet(e0 + 3);
     stamp(5);
     prefetchPrimal();  // for the next trial's primal step: in flight while the decision is computed
     // ---- D: the decision, identical in every workgroup ----
     double dY2, dX2, inter;
-    trialSumsT<true>(a.partDY, nA, a.partDX, a.partInter, nAt, tscr, dY2, dX2, inter);
+    trialSumsT<true>(a.partDY, a.nPartA, a.partDX, a.partInter, a.nPartAt, tscr, dY2, dX2, inter);
     if (tid == 0) {
       decideUpdate<true>(&sh, dX2, dY2, inter);
       if (__hip_atomic_load(a.bar + G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { sh.commError = 1; sh.halted = 1; }
@@ -354,7 +468,8 @@ SmallKernel pick(int chunkA, int chunkAt, int mode) {
 // keeps resident at once.
 int smallTrialsGrid(const MatView& A, const MatView& At, int32_t n, int device, int* residentOut) {
   *residentOut = 0;
-  if (A.useSlab || At.useSlab || A.lng.nTasks > 0 || At.lng.nTasks > 0) return 0;
+  // (long majors ride along as segment tasks; beyond kLongSlotCap of them their contributions need the k_long_groups launch)
+  if (A.useSlab || At.useSlab || A.lng.contrib != nullptr || At.lng.contrib != nullptr) return 0;
   SmallKernel k = pick(A.csr.chunk, At.csr.chunk, 2);
   if (!k || A.csr.nBlocks <= 0 || At.csr.nBlocks <= 0) return 0;
   int perCu = 0, cus = 0;
@@ -378,6 +493,7 @@ void launchSmallTrials(const MatView& A, const MatView& At, const IterVecs& v, D
   SmallArgs a{};
   a.expect = grid + (failRollCall ? 1 : 0);
   a.limit = (unsigned long long)(timeoutMs > 0 ? timeoutMs : 1000) * 100000ull;
+  a.LA = A.lng; a.LAt = At.lng; a.nPartA = A.nPartials; a.nPartAt = At.nPartials;
   a.A = A.csr; a.At = At.csr; a.v = v; a.st = st; a.partDY = partDY; a.partDX = partDX; a.partInter = partInter; a.bar = bar;
   a.xcdA = A.xcdMap; a.xcdAt = At.xcdMap; a.maxTrials = maxTrials;
   static unsigned long long* prof = [] {  // PDLP_MI355X_SMALL_PROF=1: per-phase ticks, printed at exit (development)

@@ -40,7 +40,9 @@ def _csr_layout(monkeypatch):
 
 @pytest.mark.parametrize("name", ["afiro", "adlittle", "sctest", "e226", "shell", "25fv47",
                                   # LPs outside the ctest list: optimal ones and primal infeasible / unbounded ones
-                                  "qap04", "standmps", "israel", "woodinfe", "box1", "bgetam", "galenet"])
+                                  "qap04", "standmps", "israel", "woodinfe", "box1", "bgetam", "galenet",
+                                  # majors longer than a 512-entry work block: segment tasks inside the persistent loop
+                                  "standata", "standgub", "cplex1"])
 def test_instances_bit_exact(name):
     lp = L.HighsLp.from_npz(os.path.join(GOLD, "instances", name + ".npz"))
     assert _check(lp) > 0
@@ -83,6 +85,16 @@ def test_slab_layout_bit_exact(name, monkeypatch):
     monkeypatch.setenv("PDLP_MI355X_SLAB", "1")
     lp = L.HighsLp.from_npz(os.path.join(GOLD, "instances", name + ".npz"))
     _check(lp, layout="slab")
+
+
+@pytest.mark.parametrize("layout", ["csr", "slab"])
+def test_dense_column_lp_bit_exact(layout, monkeypatch):
+    """tests/lpgen.py::dense_column_lp in small: dense columns (segment tasks in A'y — inside the persistent loop in the
+    stream layout, inside the streaming blocks of the fused trial in the slab layout), long rows, every row kind."""
+    from lpgen import dense_column_lp
+    monkeypatch.setenv("PDLP_MI355X_SLAB", "1" if layout == "slab" else "0")
+    lp = dense_column_lp(2, periods=12, rows_per=256, cols_per=224, dense_cols=6, dense_nnz=1500, tail_rows=64, tail_max=900)
+    assert _check(lp, layout=layout, kkt_tolerance=1e-5, pdlp_iteration_limit=30000) > 0
 
 
 def test_bench_workload_bit_exact_first_iterations(monkeypatch):

@@ -113,7 +113,7 @@ def test_qp_through_highs_run_with_the_gate_lifted(tmp_path, name):
     status, obj, it, qit, hnz = int(m[1]), float(m[2]), int(m[3]), int(m[4]), int(m[5])
     ref = REF_QP[name]["objective_value"]
     assert "MI355X" in txt and "Quadratic objective" in txt  # the library's banner: the QP went down the PDLP path ...
-    assert it > 0 and qit <= 0 and hnz > 0                    # ... not to the active-set solver
+    assert it > 0 and qit <= 0 and hnz > 0, txt[-3000:]       # ... not to the active-set solver
     assert status == 7, txt[-1500:]                           # kHighsModelStatusOptimal
     assert abs(obj - ref) <= 1e-6 * (1 + abs(ref)), (obj, ref)
 

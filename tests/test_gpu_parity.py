@@ -563,7 +563,9 @@ def test_slab_width_does_not_change_the_bits(monkeypatch):
             assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("name,iters", [("afiro", 160), ("25fv47", 400), ("80bau3b", 400), ("synthetic", 240)])
+@pytest.mark.parametrize("name,iters", [("afiro", 160), ("25fv47", 400), ("80bau3b", 400), ("synthetic", 240),
+                                        # majors longer than a work block (segment tasks inside the persistent loop):
+                                        ("standata", 400), ("standgub", 400), ("standmps", 400), ("cplex1", 400), ("staircase", 240)])
 def test_trial_loop_variants_give_the_same_bits(name, iters, monkeypatch):
     """The trial loop exists as separate launches and as ONE persistent launch (pdlp_small.hip) — on one XCD, on all
     XCDs with every workgroup sweeping the arrival words, on all XCDs with the XCD-hierarchical barrier; mid-size LPs
@@ -574,12 +576,17 @@ def test_trial_loop_variants_give_the_same_bits(name, iters, monkeypatch):
     if name == "synthetic":
         sp_ = solver.SyntheticProblem(40000, 35000, 400000, 9)  # above 2^18 nonzeros: ~200 work blocks of 2048 entries per operand
         kw = dict(problem_struct=sp_.struct)
+    elif name == "staircase":  # dense columns (~2800 entries) and a power-law tail of rows, mid-size work blocks
+        from lpgen import dense_column_lp
+        kw = dict(lp=dense_column_lp(3, periods=48, rows_per=512, cols_per=448, dense_cols=24, dense_nnz=3000, tail_rows=256, tail_max=2600))
     else:
         kw = dict(lp=_lp(name))
     variants = {"launches": {"PDLP_MI355X_PERSISTENT": "0"},
                 "persistent": {},
                 "all-xcds-sweep": {"PDLP_MI355X_XCD_LOCAL": "0", "PDLP_MI355X_HIER_BARRIER": "0"},
                 "all-xcds-hierarchical": {"PDLP_MI355X_XCD_LOCAL": "0", "PDLP_MI355X_HIER_BARRIER": "1"}}
+    if name == "staircase":  # 2048-entry blocks: only the hierarchical barrier
+        del variants["all-xcds-sweep"]
     out = {}
     for vname, env in variants.items():
         for k in ("PDLP_MI355X_PERSISTENT", "PDLP_MI355X_XCD_LOCAL", "PDLP_MI355X_HIER_BARRIER"):
@@ -662,6 +669,24 @@ def test_concurrent_solver_contexts_on_two_threads():
         assert out[k].pdlp_iteration_count == alone[k].pdlp_iteration_count
         assert np.array_equal(out[k].solution.col_value, alone[k].solution.col_value), k
         assert np.array_equal(out[k].solution.row_dual, alone[k].solution.row_dual), k
+
+
+def test_fused_trial_keeps_long_columns(monkeypatch):
+    """Dense columns in a slab-layout operand: the 2-launch fused trial used to be switched off by a single long column
+    (its segment tasks ran in extra workgroups that took no part in the grid barrier); now the streaming blocks run the
+    tasks themselves (SpmvArgs::inlineTasks).  Same lanes and sums: the bits of the 3-launch trial, and of the oracle."""
+    from lpgen import dense_column_lp
+    lp = dense_column_lp(5, periods=40, rows_per=512, cols_per=448, dense_cols=16, dense_nnz=5000, tail_rows=128, tail_max=700)
+    monkeypatch.setenv("PDLP_MI355X_SLAB", "1")
+    monkeypatch.setenv("PDLP_MI355X_PERSISTENT", "0")
+    out = {}
+    for fused in ("0", "1"):
+        monkeypatch.setenv("PDLP_MI355X_FUSED", fused)
+        out[fused] = _iterate_state(dict(lp=lp), 240)
+    assert out["0"][5] == 3 and out["1"][5] == 2, (out["0"][5], out["1"][5])
+    for a, b in zip(out["0"][:3], out["1"][:3]):
+        assert np.array_equal(a, b)
+    assert out["0"][3:5] == out["1"][3:5]
 
 
 def _iterate_state(kw, iters):
