@@ -37,6 +37,9 @@ CONFIGS = {
     # multi-commodity network LP of tests/lpgen.py::structured_lp — 64 network blocks, 256 dense linking rows of
     # 4096 nonzeros (segment tasks), ranged and free rows: 2.1M columns, 263k rows, 5.3M nonzeros
     "c": dict(structured=True, name="structured block-angular network LP, 263k x 2.1M, 5.3M nnz, 256 dense linking rows (seed 1)"),
+    # second structured family (round 4): tests/lpgen.py::dense_column_lp — staircase LP with 192 DENSE COLUMNS of ~6000
+    # nonzeros (segment tasks in the A'y launch), power-law row lengths: 459k columns, 526k rows, 4.4M nonzeros
+    "d": dict(staircase=True, name="structured staircase LP with dense columns, 526k x 459k, 4.4M nnz, 192 dense columns (seed 1)"),
     "qp": dict(m=500_000, n=500_000, nnz=4_000_000, qp=True,
                name="synthetic random sparse QP 500kx500k, 4M nnz, diagonal Q ~ U(0,1) (seed 1)"),
     # the same with a NON-diagonal Hessian (the Q x SpMV of the general-Q path, a fourth launch per trial): tridiagonal,
@@ -65,6 +68,54 @@ def algorithmic_bytes_hipdlp(n, m, nnz):
     b_aty = 12 * nnz + 4 * (n + 1) + 8 * m + 8 * 7 * n
     b_ax = 12 * nnz + 4 * (m + 1) + 8 * n + 8 * 5 * m
     return b_ax + b_aty, b_ax, b_aty
+
+
+def build_workload(config):
+    """The LP / QP of one bench configuration as a problem handle (`.struct` = pdlp_problem_t) plus the arrays that must
+    stay alive next to it.  Shared with tools/kbench.py (the command the rocprofv3 passes run)."""
+    from highs_amd import abi, solver
+    cfg = CONFIGS[config]
+    if cfg.get("structured") or cfg.get("staircase"):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from lpgen import dense_column_lp, structured_lp
+        sp_ = abi.ProblemHandle(dense_column_lp(1) if cfg.get("staircase") else structured_lp(1))  # same attribute (.struct) as the library-generated problem
+    else:
+        sp_ = solver.SyntheticProblem(cfg["m"], cfg["n"], cfg["nnz"], 1)
+    qkeep = None
+    if cfg.get("qp"):
+        import numpy as np
+        ncol = sp_.struct.num_col
+        if cfg.get("banded"):
+            rng = np.random.default_rng(1)
+            off = rng.uniform(-0.5, 0.5, ncol - 1)
+            diag = np.abs(np.concatenate([off, [0.0]])) + np.abs(np.concatenate([[0.0], off])) + rng.uniform(0.0, 1.0, ncol)
+            st = np.zeros(ncol + 1, np.int32)
+            st[1:] = np.cumsum(np.concatenate([np.full(ncol - 1, 2), [1]]))
+            qi = np.empty(2 * ncol - 1, np.int32)
+            qv = np.empty(2 * ncol - 1)
+            qi[0::2], qv[0::2] = np.arange(ncol), diag
+            qi[1::2], qv[1::2] = np.arange(1, ncol), off
+            qkeep = (st, qi, qv)
+        else:
+            qkeep = (np.arange(ncol + 1, dtype=np.int32), np.arange(ncol, dtype=np.int32),
+                     np.random.default_rng(1).uniform(0.0, 1.0, ncol))
+        sp_.struct.q_dim = ncol
+        sp_.struct.q_start = qkeep[0].ctypes.data_as(abi.c_i32p)
+        sp_.struct.q_index = qkeep[1].ctypes.data_as(abi.c_i32p)
+        sp_.struct.q_value = qkeep[2].ctypes.data_as(abi.c_f64p)
+    return sp_, qkeep
+
+
+def needed_bytes(n, m, nnz, fused, qp=False):
+    """Bytes the two launches of a trial MUST move, counted from what the kernels read and write —
+    next to SURVEY section 8(d)'s per-operation formula (algorithmic_bytes), which credits the fused launches with the
+    re-reads of x, x+ and A'y that fusing the primal step into the A'y launch removed (it is the formula for the
+    reference's separate level-1 calls).  A x+ launch: matrix 12 B/nnz, row pointers, gathered x+ (n), y / b / A x in,
+    A x+ / y+ out, ySum in and out (7m).  A'y+ launch: matrix, column pointers, gathered y+ (m), x / x+ / A'y in, A'y+ out
+    (4n); fused: + c / l / u / xSum in, x++ / xSum out (6n; QP: + the diagonal of Q)."""
+    ax = 12 * nnz + 4 * (m + 1) + 8 * n + 8 * 7 * m
+    aty = 12 * nnz + 4 * (n + 1) + 8 * m + 8 * 4 * n + (8 * 6 * n + (8 * n if qp else 0) if fused else 0)
+    return ax, aty
 
 
 def scaling_model(n, m, nnz, G, ax_us_1gpu, aty_us_1gpu, vec_us_1gpu):
@@ -174,36 +225,9 @@ def main():
         dist.broadcast(t, src=0)
         return (C.c_uint8 * 128)(*t.cpu().tolist())
 
-    if cfg.get("structured"):
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from lpgen import structured_lp
-        sp_ = abi.ProblemHandle(structured_lp(1))  # same attribute (.struct) as the library-generated problem
-    else:
-        sp_ = solver.SyntheticProblem(cfg["m"], cfg["n"], cfg["nnz"], 1)
-    qkeep = None
-    if cfg.get("qp"):
-        if args.solver != "pdlp":
-            raise SystemExit("--config qp runs on the pdlp path only")
-        import numpy as np
-        ncol = sp_.struct.num_col
-        if cfg.get("banded"):
-            rng = np.random.default_rng(1)
-            off = rng.uniform(-0.5, 0.5, ncol - 1)
-            diag = np.abs(np.concatenate([off, [0.0]])) + np.abs(np.concatenate([[0.0], off])) + rng.uniform(0.0, 1.0, ncol)
-            st = np.zeros(ncol + 1, np.int32)
-            st[1:] = np.cumsum(np.concatenate([np.full(ncol - 1, 2), [1]]))
-            qi = np.empty(2 * ncol - 1, np.int32)
-            qv = np.empty(2 * ncol - 1)
-            qi[0::2], qv[0::2] = np.arange(ncol), diag
-            qi[1::2], qv[1::2] = np.arange(1, ncol), off
-            qkeep = (st, qi, qv)
-        else:
-            qkeep = (np.arange(ncol + 1, dtype=np.int32), np.arange(ncol, dtype=np.int32),
-                     np.random.default_rng(1).uniform(0.0, 1.0, ncol))
-        sp_.struct.q_dim = ncol
-        sp_.struct.q_start = qkeep[0].ctypes.data_as(abi.c_i32p)
-        sp_.struct.q_index = qkeep[1].ctypes.data_as(abi.c_i32p)
-        sp_.struct.q_value = qkeep[2].ctypes.data_as(abi.c_f64p)
+    if cfg.get("qp") and args.solver != "pdlp":
+        raise SystemExit("--config qp runs on the pdlp path only")
+    sp_, qkeep = build_workload(args.config)
     params = abi.default_params(kkt_tolerance=1e-4, device=local_rank, solver=args.solver)
 
     def sync():
@@ -342,8 +366,14 @@ def main():
         # included, so this understates the kernel a little).  k_ax / k_aty below are the stand-alone SpMV kernels
         # re-launched in isolation — what the 3-launch loop would run.
         dom_name, dom_ms, dom_bytes = "trials_persistent(per trial)", ms_step * st.iters / max(int(st.trials), 1), b_iter
+    # what the two launches really have to move (needed_bytes) next to SURVEY's per-operation formula
+    nb_ax, nb_aty = needed_bytes(n, m, nnz, fused, bool(cfg.get("qp")))
+    if args.solver != "pdlp":  # (the Halpern launches: their formula already counts what the fused kernels move)
+        nb_ax, nb_aty = b_ax, b_aty
+    dom_needed = b_iter if persistent else nb_ax if dom_name == "spmv_ax_dual" else nb_aty
     if world > 1:  # each rank streams 1/world of the matrix
         dom_bytes = dom_bytes / world
+        dom_needed = dom_needed / world
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
     copy_gbs = None
     if args.solver == "pdlp" and world == 1:
@@ -353,9 +383,10 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if args.solver == "hipdlp":  # same SpMV kernels with the Halpern epilogues
         dom_name = {"spmv_ax_dual": "spmv_ax_halpern_dual", "spmv_aty_interact": "spmv_aty_halpern_primal"}.get(dom_name, dom_name)
+    traffic_key = "trials_persistent_per_trial" if persistent else dom_name
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(args.config, {}).get(dom_name)
+            traffic = json.load(open(tpath)).get(args.config if args.solver == "pdlp" else "b", {}).get(traffic_key)
         except Exception:
             traffic = None
     out = {
@@ -373,6 +404,8 @@ def main():
         "startup_ms_first_40": startup_ms,
         # `value` / `ms_per_step` / `checks`: this window — whole check periods of the reference's schedule
         "timed_window": "iterations %d..%d" % (val_start, val_start + int(st.iters)), "timed_steps": int(st.iters),
+        "steps_note": "`steps` / `warmup` echo the flags; `value` and `ms_per_step` are over `timed_steps` iterations (whole check "
+                      "periods of the reference's schedule); the flags' own K-step window is `window_of_the_K_steps`",
         "window_of_the_K_steps": k_window,
         "iter_algorithmic_bytes": b_iter,
         "iter_hbm_gbs": b_iter / (ms_step * 1e-3) / 1e9,
@@ -382,6 +415,11 @@ def main():
                      "traffic_source": "profiles/pmc_traffic.json (static: rocprofv3 --pmc passes of tools/make_profiles.sh, not "
                                        "measured in this run)" if traffic is not None else None,
                      "algorithmic_bytes_per_launch": dom_bytes,
+                     # the bytes this launch must move, counted from what the kernel reads and writes (needed_bytes): the
+                     # SURVEY formula above credits a fused launch with the re-reads that the fusion removed
+                     "needed_bytes_per_launch": dom_needed,
+                     "frac_needed": dom_needed / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "traffic_over_needed": (traffic / dom_needed) if traffic else None,
                      "measured_copy_ceiling_gbs": copy_gbs,
                      "frac_of_copy_ceiling": (achieved / copy_gbs) if copy_gbs else None,
                      "avg_launch_ms": dom_ms, "timed_launches_in_loop": prof_launches,
@@ -392,9 +430,20 @@ def main():
                      "isolated_relaunch_ms": {"spmv_ax_dual": iso_ax, "spmv_aty_interact": iso_aty}},
     }
     if args.solver == "pdlp" and not cfg.get("qp"):
-        # the model of DESIGN.md §6 for this LP: single-GPU kernel times of the round-3 profiles (us), scaled by 1/G
-        base = {"b": (56.0, 53.0, 15.5), "a": (8.9, 8.2, 4.0), "c": (41.0, 33.0, 25.6)}[args.config]
+        # the model of DESIGN.md §6 for this LP, fed with THIS run's kernel times (us): the two SpMV launches re-launched in
+        # isolation on one GPU (what a rank runs on its 1/G share; the fused A'y launch would carry the primal step, which the
+        # sharded sequence runs as its own kernel) and the stand-alone primal-step kernel
+        if world == 1:
+            base = (iso_ax * 1e3, iso_aty * 1e3, S.time_kernel("decide_primal", 30) * 1e3)
+        else:  # (a rank of a sharded run measures its own share: scale back to one GPU)
+            base = (iso_ax * 1e3 * world, iso_aty * 1e3 * world, 15.5 * n / 1e6)
         out["scaling_model"] = {("G=%d" % G): scaling_model(n, m, nnz, G, *base) for G in ((world,) if world > 1 else (2, 4, 8))}
+        out["scaling_model"]["inputs_us_one_gpu"] = {"spmv_ax_dual": base[0], "spmv_aty_interact": base[1], "primal_step": base[2],
+                                                     "source": "measured in this run (isolated re-launches)"}
+        if world == 1:
+            one = ms_step * 1e3 * st.iters / max(int(st.trials), 1)
+            for G in (2, 4, 8):
+                out["scaling_model"]["G=%d" % G]["speedup_vs_this_run"] = one / out["scaling_model"]["G=%d" % G]["us_per_trial"]
         if world > 1:
             out["scaling_model"]["measured_us_per_trial"] = ms_step * 1e3 * st.iters / max(int(st.trials), 1)
     if cfg.get("qp"):
@@ -403,12 +452,12 @@ def main():
                          "pinned on the reference's QP solver for small instances (tests/golden/reference_qp.json)")
     if args.solver == "hipdlp":
         out["config"]["options"] = "presolve=off, kkt_tolerance=1e-4, Halpern restarts + PID primal weight (reference defaults)"
-    if cfg.get("structured") and world == 1 and args.solver == "pdlp":
+    if (cfg.get("structured") or cfg.get("staircase")) and world == 1 and args.solver == "pdlp":
         # the dense linking rows (> 256 nonzeros) are cut into segment tasks that run as extra workgroups of the SAME
         # launch: what they add to the plain A x (they hold 20 % of the nonzeros of this LP)
         full, nolong = S.time_kernel("spmv_ax_plain", 50), S.time_kernel("spmv_ax_plain_nolong", 50)
         out["long_majors"] = {"spmv_ax_plain_ms": full, "without_the_long_majors_ms": nolong, "share": (full - nolong) / full,
-                              "share_of_nonzeros": 256 * 4096 / nnz}
+                              "share_of_nonzeros": (256 * 4096 / nnz) if cfg.get("structured") else None}
     if args.kernels and rank == 0 and world == 1 and args.solver == "pdlp":
         ks = {k: S.time_kernel(k, 50) for k in ("decide_primal", "primal_step", "spmv_ax", "spmv_aty", "decide", "trial",
                                                 "spmv_ax_plain", "spmv_aty_plain", "copy")}
@@ -417,7 +466,7 @@ def main():
         out["kernels_ms"] = ks
     if rank == 0 and world == 1:
         # two iteration limits (whole check periods + 1: the reference stops at limit - 1), about 10-30 s of one core
-        budget = args.cpu_iters if args.cpu_iters is not None else {"b": 201, "qp": 361, "c": 361}.get(args.config, 3001)
+        budget = args.cpu_iters if args.cpu_iters is not None else {"b": 201, "qp": 361, "c": 361, "d": 361, "qpn": 361}.get(args.config, 3001)
         if budget > 0:
             lo = max(41, (budget - 1) * 2 // 5 // 40 * 40 + 1)
             hi = max(budget, lo + 40)

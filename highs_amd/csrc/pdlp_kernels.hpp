@@ -283,10 +283,11 @@ int smallTrialsGrid(const MatView& A, const MatView& At, int32_t n, int device, 
 // within timeoutMs, the launch changes nothing but commError = 3 in *st (failRollCall: a test asks for exactly that).
 void launchSmallTrials(const MatView& A, const MatView& At, const IterVecs& v, DevState* st, double* partDY, double* partDX,
                        double* partInter, unsigned long long* bar, int32_t grid, int32_t maxTrials, int mode, hipStream_t s,
-                       int32_t timeoutMs = 1000, bool failRollCall = false);
+                       int32_t timeoutMs = 1000, bool failRollCall = false, bool selfTest = false);
 constexpr int kSmallHierWords = 4 * 16 * 32;  // the XCD-hierarchical barrier's words (pdlp_devfn.hpp HierBar)
 // arrival words, timeout flag, XCC ids of the placement check; behind them (256-byte aligned) the hierarchical barrier's words
-inline size_t smallBarWords(int grid) { return ((2 * (size_t)grid + 16 + 31) / 32) * 32 + kSmallHierWords; }
+// ... and, last, the words of the XCD-local mode's coherence self-test (grid test words, grid arrival words, flag, failure word)
+inline __host__ __device__ size_t smallBarWords(int grid) { return ((2 * (size_t)grid + 16 + 31) / 32) * 32 + kSmallHierWords + 2 * (size_t)grid + 8; }
 
 // ---- check-iteration kernels --------------------------------------------------------------------------------------
 // Every launcher takes a CheckGate.  {nullptr, nullptr}: host-driven check (sharded paths, stage("residuals"),

@@ -119,13 +119,15 @@ void parallelFor(int T, Fn&& fn) {
   };
   std::vector<std::thread> th;
   th.reserve((size_t)T - 1);
+  int spawned = 1;  // pieces 1 .. spawned-1 have a thread of their own
   try {
-    for (int t = 1; t < T; ++t) th.emplace_back(guarded, t);
-  } catch (...) {  // (thread creation failed: run what is left on this thread)
-    std::lock_guard<std::mutex> lock(mu);
-    if (!first) first = std::current_exception();
+    for (; spawned < T; ++spawned) th.emplace_back(guarded, spawned);
+  } catch (...) {
+    // thread creation failed (EAGAIN under a process limit): not an error of the read — the pieces that got no thread
+    // run on the calling thread below
   }
   guarded(0);
+  for (int t = spawned; t < T; ++t) guarded(t);
   for (auto& x : th) x.join();
   if (first) std::rethrow_exception(first);
 }

@@ -53,6 +53,8 @@ struct SmallArgs {
   unsigned long long* bar;
   int32_t xcdA, xcdAt;
   int32_t maxTrials;
+  int32_t selfTest;          // XCD-local mode, first launch of a solver: check that nt loads see another CU's store behind an L1-warm line
+  int32_t pad_;
   int32_t expect;            // workgroups the roll call waits for (= the working workgroups of the launch, unless a test asks for a failure)
   unsigned long long limit;  // 100 MHz ticks a roll call or barrier wait may last
   unsigned long long* prof;  // development: 100 MHz ticks per phase {P, barrier, A, barrier, T, barrier, D}, accumulated by workgroup 0
@@ -329,6 +331,43 @@ __global__ __launch_bounds__(kSpmvThreads) void k_trials_small(const SmallArgs a
       if (lb == 0 && tid == 0) a.st->commError = 2;
       return;
     }
+    if (a.selfTest) {
+      // What this mode relies on, checked once per solver on the placement it actually got: a `global_load ... nt` is served
+      // by the XCD's L2, never by a line this CU's L1 still holds from an earlier read (measured so on this part:
+      // MI355X_MICROARCH.md, "sc1 / sc0 sc1 / nt loads bypass L1 only"; the ISA does not promise it for nt).  Every
+      // workgroup warms its L1 with a plain read of its neighbour's word, the neighbour then stores a new value (plain
+      // store, as the loop's stores), and an nt load must return the new value.  If any workgroup reads the old one the
+      // launch changes nothing and reports the placement as unusable: the solver goes on with agent-scope accesses.
+      unsigned long long* tw = a.bar + smallBarWords(G) - (size_t)(2 * G + 8);  // G test words, G arrival words, flag, failure word
+      unsigned long long* tbar = tw + G;
+      unsigned long long* fail = tbar + G + 1;
+      const int nb = (lb + 1) % G;
+      auto plainLoad = [&](const unsigned long long* p) {
+        unsigned long long v;
+        asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+        return v;
+      };
+      auto ntLoad = [&](const unsigned long long* p) {
+        unsigned long long v;
+        asm volatile("global_load_dwordx2 %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+        return v;
+      };
+      if (tid == 0) *reinterpret_cast<volatile unsigned long long*>(tw + lb) = 1ull;
+      arrive<true>(tbar, lb, G, 1ull, a.limit);
+      unsigned long long warm = 0;
+      if (tid == 0) warm = plainLoad(tw + nb);  // now in this CU's L1
+      arrive<true>(tbar, lb, G, 2ull, a.limit);
+      if (tid == 0) *reinterpret_cast<volatile unsigned long long*>(tw + lb) = 2ull;
+      arrive<true>(tbar, lb, G, 3ull, a.limit);
+      if (tid == 0 && (warm != 1ull || ntLoad(tw + nb) != 2ull)) __hip_atomic_store(fail, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      arrive<true>(tbar, lb, G, 4ull, a.limit);
+      if (tid == 0) placementOk = __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull ? 1 : 0;
+      __syncthreads();
+      if (!placementOk) {
+        if (lb == 0 && tid == 0) a.st->commError = 2;
+        return;
+      }
+    }
   }
   HierBar hb{};
   unsigned long long kbar = 0;
@@ -485,13 +524,16 @@ int smallTrialsGrid(const MatView& A, const MatView& At, int32_t n, int device, 
 
 void launchSmallTrials(const MatView& A, const MatView& At, const IterVecs& v, DevState* st, double* partDY, double* partDX,
                        double* partInter, unsigned long long* bar, int32_t grid, int32_t maxTrials, int mode, hipStream_t s,
-                       int32_t timeoutMs, bool failRollCall) {
+                       int32_t timeoutMs, bool failRollCall, bool selfTest) {
   const bool xcdLocal = mode == 1;
   static_assert(kHierBarWords == kSmallHierWords, "barrier buffer layout");
   if (mode == 2) (void)hipMemsetAsync(bar, 0, smallBarWords(grid) * sizeof(unsigned long long), s);  // launch-local barrier counters
   else (void)hipMemsetAsync(bar + grid + 1, 0, sizeof(unsigned long long), s);                    // the roll-call word
   SmallArgs a{};
   a.expect = grid + (failRollCall ? 1 : 0);
+  a.selfTest = xcdLocal && selfTest ? 1 : 0;
+  if (a.selfTest)  // its words: the tail of the buffer
+    (void)hipMemsetAsync(bar + smallBarWords(grid) - (size_t)(2 * grid + 8), 0, (size_t)(2 * grid + 8) * sizeof(unsigned long long), s);
   a.limit = (unsigned long long)(timeoutMs > 0 ? timeoutMs : 1000) * 100000ull;
   a.LA = A.lng; a.LAt = At.lng; a.nPartA = A.nPartials; a.nPartAt = At.nPartials;
   a.A = A.csr; a.At = At.csr; a.v = v; a.st = st; a.partDY = partDY; a.partDX = partDX; a.partInter = partInter; a.bar = bar;

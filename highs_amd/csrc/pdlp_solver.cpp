@@ -927,7 +927,8 @@ void Solver::enqueueTrial() {
   }
   if (persistent_) {
     launchSmallTrials(dA_.view(), dAt_.view(), vecs_, dst(), partDY_.get(), partDX_.get(), partInter_.get(), gridBar_.get(), smallGrid_, 1,
-                      smallMode(), stream_, sw_.barrierTimeoutMs, sw_.fault == 1 && smallLaunches_++ == 0);
+                      smallMode(), stream_, sw_.barrierTimeoutMs, sw_.fault == 1 && smallLaunches_ == 0, smallLaunches_ == 0);
+    ++smallLaunches_;
     return;
   }
   if (!sharded_ && fused_) {
@@ -1027,7 +1028,9 @@ void Solver::captureGraph() {
 void Solver::enqueueBatch(int32_t todo) {
   if (persistent_ && !profile_) {  // the whole stretch to the next check (plus spare trials for rejections) in one launch
     launchSmallTrials(dA_.view(), dAt_.view(), vecs_, dst(), partDY_.get(), partDX_.get(), partInter_.get(), gridBar_.get(),
-                      smallGrid_, todo + 8, smallMode(), stream_, sw_.barrierTimeoutMs, sw_.fault == 1 && smallLaunches_++ == 0);
+                      smallGrid_, todo + 8, smallMode(), stream_, sw_.barrierTimeoutMs, sw_.fault == 1 && smallLaunches_ == 0,
+                      smallLaunches_ == 0);
+    ++smallLaunches_;
     return;
   }
   if (useGraph_ && !persistent_ && !profile_ && (!sharded_ || meshMode_) && todo >= kGraphMinTodo) {

@@ -89,8 +89,10 @@ typedef struct pdlp_problem {
   /* Optional quadratic objective  + 1/2 x' Q x  (no reference counterpart on the PDLP
    * path: HiGHS gates solver="pdlp" to LPs, lp_data/HighsOptions.cpp:1178-1181).  Q as HiGHS holds it in
    * HighsHessian (model/HighsHessian.h:22-34): lower-triangular, column-wise, dimension q_dim <= num_col.
-   * This library solves the case of a DIAGONAL Q (closed-form proximal primal step); off-diagonal
-   * nonzeros are rejected with an error.  q_dim = 0 / NULL arrays = LP. */
+   * The diagonal of Q enters the primal step in closed form (proximal step), its off-diagonal part as an explicit
+   * N x term (a third SpMV per trial; single GPU only).  Entries above the diagonal, and a diagonal of the wrong sign
+   * for the objective sense, are errors.  q_dim = 0 / NULL arrays = LP.  Through Highs::run() the QP case needs the
+   * reference's QP gate lifted (integration/qp_gate_patch.py). */
   int32_t q_dim;
   int32_t reserved_q;
   const int32_t* q_start; /* [q_dim+1] */
