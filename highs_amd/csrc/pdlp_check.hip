@@ -15,6 +15,7 @@
 
 #include <cmath>
 
+#include "pdlp_checkfn.hpp"
 #include "pdlp_devfn.hpp"
 #include "pdlp_kernels.hpp"
 
@@ -22,135 +23,30 @@ namespace pdlp {
 
 namespace {
 
-// cuPDLP's resobj numbers of one iterate from its 4 row and 11 column statistics (Solver::computeResiduals `fill`)
-__device__ void fillResiduals(ResidualsDev& r, const double* rs, const double* cs, const CheckCtl& c) {
-  // QP (cs[10] = 1/2 x'Qx): primal c'x + 1/2 x'Qx, dual b'y + l's+ - u's- - 1/2 x'Qx
-  r.pObj = (c.qp ? cs[0] + cs[10] : cs[0]) * c.sense + c.offset;
-  r.pFeas = sqrt(rs[0]);
-  r.dObj = (c.qp ? ((rs[1] + cs[1]) - cs[2]) - cs[10] : (rs[1] + cs[1] - cs[2])) * c.sense + c.offset;
-  r.dFeas = sqrt(cs[3]);
-  r.gap = r.pObj - r.dObj;
-  r.relGap = fabs(r.pObj - r.dObj) / (1.0 + fabs(r.pObj) + fabs(r.dObj));
-  double dScale = sqrt(rs[2] + cs[4] + cs[5]);  // ||(y, s+, s-)||, cupdlp_solver.c:230-237
-  if (dScale < 1e-8) dScale = 1.0;
-  r.pInfObj = (r.dObj - c.offset) / c.sense / dScale;
-  r.pInfRes = sqrt(cs[6]) / dScale;
-  double pScale = sqrt(cs[7]);  // ||x||, :328-332
-  if (pScale < 1e-8) pScale = 1.0;
-  r.dInfObj = (r.pObj - c.offset) / c.sense / pScale;
-  r.dInfRes = sqrt(rs[3] + cs[8] + cs[9]) / pScale;
-}
-__device__ bool converged(const ResidualsDev& r, const CheckCtl& c) {  // cupdlp_solver.c:797-841
-  return (r.pFeas < c.primalTolAbs) && (r.dFeas < c.dualTolAbs) && (r.relGap < c.gapTol);
-}
-__device__ bool certificate(const ResidualsDev& r, double feasTol) {  // cupdlp_solver.c:710-795
-  const bool primalInf = r.pInfObj > 0.0 && r.pInfRes < feasTol * r.pInfObj;
-  const bool dualInf = r.dInfObj < 0.0 && r.dInfRes < -feasTol * r.dInfObj;
-  return primalInf || dualInf;
-}
-__device__ double restartScore(double beta, double p, double d, double g) {  // cupdlp_restart.c:113-124
-  return sqrt(beta * p * p + d * d / beta + g * g);
-}
-// next halt of the reference's schedule (Solver::nextCheckIter), clipped to the fixed-work target
-__device__ int nextHalt(int it, const CheckCtl& c) {
-  long long next;
-  if (it + 1 < 10) next = it + 1;
-  else next = ((long long)it / c.interval + 1) * c.interval;
-  const long long last = (long long)c.optIterLimit - 1;
-  if (last > it && last < next) next = last;
-  if (!c.terminate && next > c.iterLimit) next = c.iterLimit;
-  if (next > 2147483647LL) next = 2147483647LL;
-  return (int)next;
-}
-__device__ void writeRecord(CheckRecord* rec, const DevState& s, const CheckCtl& c) {
-  if (!rec) return;
-  rec->it = c.lastCheckIter; rec->terminated = c.terminated; rec->termCode = c.termCode; rec->termIterate = c.termIterate;
-  rec->restartKind = c.restartKind; rec->nRestarts = c.nRestarts; rec->nChecks = c.nChecks; rec->nTrials = s.nTrials;
-  rec->beta = s.beta;
-  rec->cur = c.cur; rec->avg = c.avg;
-  __threadfence_system();
-  rec->ran = 1;
-}
-
-constexpr int kStatRowCur = 0, kStatRowAvg = kRowStats, kStatColCur = 2 * kRowStats, kStatColAvg = 2 * kRowStats + kColStats;
-
 __global__ __launch_bounds__(kWave) void k_check_decide(DevState* st, CheckCtl* cc, const double* __restrict__ stat, CheckRecord* rec) {
   if (threadIdx.x != 0) return;
   if (!checkDue(st, cc)) return;
-  CheckCtl& c = *cc;
-  DevState& s = *st;
-  const int it = s.nIter;
-  fillResiduals(c.cur, stat + kStatRowCur, stat + kStatColCur, c);
-  fillResiduals(c.avg, stat + kStatRowAvg, stat + kStatColAvg, c);
-  c.nChecks += 1;
-  c.lastCheckIter = it;
-  c.restartKind = 0;
-  s.avgW = 0.0;  // the flush kernel of this check has added the pending averages
-  s.avgWx = 0.0;
-  if (c.terminate) {
-    bool term = true;
-    if (converged(c.cur, c)) { c.termIterate = 0; c.termCode = 0 /* PDLP_TERM_OPTIMAL */; }
-    else if (converged(c.avg, c)) { c.termIterate = 1; c.termCode = 0; }
-    else if (certificate(c.cur, c.feasTol) || certificate(c.avg, c.feasTol)) c.termCode = 3 /* PDLP_TERM_INFEASIBLE_OR_UNBOUNDED */;
-    else if (it >= c.iterLimit - 1) c.termCode = 4 /* PDLP_TERM_TIMELIMIT_OR_ITERLIMIT */;
-    else term = false;
-    if (term) {
-      c.terminated = 1;  // the device stays halted: everything queued behind is a no-op
-      writeRecord(rec, s, c);
-      return;
-    }
-  }
-  // ---- PDHG_Check_Restart_GPU (cupdlp_restart.c:3-124) ----
-  if (!c.restartOn) return;
-  if (it == c.iLastRestartIter) {
-    c.pFeasLR = c.cur.pFeas; c.dFeasLR = c.cur.dFeas; c.gapLR = c.cur.gap;
-    c.pFeasLC = c.cur.pFeas; c.dFeasLC = c.cur.dFeas; c.gapLC = c.cur.gap;
-    return;
-  }
-  const double muCur = restartScore(s.beta, c.cur.pFeas, c.cur.dFeas, c.cur.gap);
-  const double muAvg = restartScore(s.beta, c.avg.pFeas, c.avg.dFeas, c.avg.gap);
-  const bool toCurrent = muCur < muAvg;
-  const double muCand = toCurrent ? muCur : muAvg;
-  bool restart = true;
-  if ((it - c.iLastRestartIter) >= 0.36 * it) {
-    // artificial restart
-  } else {
-    const double muLR = restartScore(s.beta, c.pFeasLR, c.dFeasLR, c.gapLR);
-    if (muCand < 0.2 * muLR) {
-      // sufficient decay
-    } else {
-      const double muLC = restartScore(s.beta, c.pFeasLC, c.dFeasLC, c.gapLC);
-      if (!(muCand < 0.8 * muLR && muCand > muLC)) restart = false;  // necessary decay
-    }
-  }
-  const ResidualsDev& cand = toCurrent ? c.cur : c.avg;
-  c.pFeasLC = cand.pFeas; c.dFeasLC = cand.dFeas; c.gapLC = cand.gap;
-  if (!restart) return;
-  c.pFeasLR = cand.pFeas; c.dFeasLR = cand.dFeas; c.gapLR = cand.gap;
-  c.restartKind = toCurrent ? 1 : 2;
+  if (checkDecideCore(*st, *cc, stat)) writeRecord(rec, *st, *cc);  // (the solve has ended; otherwise k_restart_finish writes the record)
 }
 
-// Grid: nbX blocks over the columns, then nbY blocks over the rows — each part with the lanes, strides and block sums
-// of k_diff_norm2 on its own grid (launchDiffNorm2 with vecBlocks(len) blocks), so that the two norms have the bits
-// of the host-driven restart.
-__global__ __launch_bounds__(kVecThreads) void k_restart_vec(const IterVecs v, const DevState* st, const CheckCtl* cc, const RestartVecs r,
-                                                             double* partX, int nbX, double* partY, int nbY) {
-  if (!checkDue(st, cc)) return;
-  const int kind = cc->restartKind;
-  if (kind == 0) return;
-  __shared__ double scratch[kVecThreads / kWave];
-  const int c = st->cur;
+// The vector side of a restart for one (virtual) block of the grid nbX + nbY of k_restart_vec: blocks < nbX work on the
+// columns, the others on the rows, each part with the lanes, strides and block sums of k_diff_norm2 on its own grid
+// (launchDiffNorm2 with vecBlocks(len) blocks), so that the two norms have the bits of the host-driven restart.
+// AGENT: the average vectors were written, and the partials are read, by other workgroups of the same launch.
+template <bool AGENT>
+__device__ __forceinline__ void restartVecBlock(const IterVecs& v, int c, int kind, const RestartVecs& r, int vb, double* partX, int nbX,
+                                                double* partY, int nbY, double* scratch) {
   double acc = 0.0;
-  if ((int)blockIdx.x < nbX) {
+  if (vb < nbX) {
     double* __restrict__ x = v.x[c];
     const int stride = nbX * kVecThreads;
-    for (int j = blockIdx.x * kVecThreads + threadIdx.x; j < v.n; j += stride) {
-      v.xSum[j] = 0.0;
+    for (int j = vb * kVecThreads + threadIdx.x; j < v.n; j += stride) {
+      if (AGENT) stAgent(v.xSum + j, 0.0); else v.xSum[j] = 0.0;  // (one launch: phase F of another workgroup wrote it, see k_check_small)
       double xv;
       if (kind == 2) {
-        xv = r.xAvg[j];
+        xv = ldChk<AGENT>(r.xAvg + j);
         x[j] = xv;
-        v.aty[c][j] = r.atyAvg[j];
+        v.aty[c][j] = ldChk<AGENT>(r.atyAvg + j);
         if (v.nx[0]) v.nx[c][j] = r.nxAvg[j];
       } else {
         xv = x[j];
@@ -160,18 +56,18 @@ __global__ __launch_bounds__(kVecThreads) void k_restart_vec(const IterVecs v, c
       r.xLast[j] = xv;
     }
     const double t = blockSum<kVecThreads>(acc, scratch);
-    if (threadIdx.x == 0) partX[blockIdx.x] = t;
+    if (threadIdx.x == 0) { if (AGENT) stAgent(partX + vb, t); else partX[vb] = t; }
   } else {
-    const int b = (int)blockIdx.x - nbX;
+    const int b = vb - nbX;
     double* __restrict__ y = v.y[c];
     const int stride = nbY * kVecThreads;
     for (int i = b * kVecThreads + threadIdx.x; i < v.m; i += stride) {
-      v.ySum[i] = 0.0;
+      if (AGENT) stAgent(v.ySum + i, 0.0); else v.ySum[i] = 0.0;
       double yv;
       if (kind == 2) {
-        yv = r.yAvg[i];
+        yv = ldChk<AGENT>(r.yAvg + i);
         y[i] = yv;
-        v.ax[c][i] = r.axAvg[i];
+        v.ax[c][i] = ldChk<AGENT>(r.axAvg + i);
       } else {
         yv = y[i];
       }
@@ -180,51 +76,290 @@ __global__ __launch_bounds__(kVecThreads) void k_restart_vec(const IterVecs v, c
       r.yLast[i] = yv;
     }
     const double t = blockSum<kVecThreads>(acc, scratch);
-    if (threadIdx.x == 0) partY[b] = t;
+    if (threadIdx.x == 0) { if (AGENT) stAgent(partY + b, t); else partY[b] = t; }
   }
+}
+
+__global__ __launch_bounds__(kVecThreads) void k_restart_vec(const IterVecs v, const DevState* st, const CheckCtl* cc, const RestartVecs r,
+                                                             double* partX, int nbX, double* partY, int nbY) {
+  if (!checkDue(st, cc)) return;
+  const int kind = cc->restartKind;
+  if (kind == 0) return;
+  __shared__ double scratch[kVecThreads / kWave];
+  restartVecBlock<false>(v, st->cur, kind, r, (int)blockIdx.x, partX, nbX, partY, nbY, scratch);
 }
 
 __global__ __launch_bounds__(kVecThreads) void k_restart_finish(DevState* st, CheckCtl* cc, const double* __restrict__ partX, int nbX,
                                                                 const double* __restrict__ partY, int nbY, CheckRecord* rec) {
   if (!checkDue(st, cc)) return;
   __shared__ double scratch[kVecThreads / kWave];
-  const int kind = cc->restartKind;
   double dP2 = 0.0, dD2 = 0.0;
-  if (kind) {  // the sums of k_final_reduce over each partial array
+  if (cc->restartKind) {  // the sums of k_final_reduce over each partial array
     dP2 = reducePartials(partX, nbX, scratch);
     dD2 = reducePartials(partY, nbY, scratch);
   }
   if (threadIdx.x != 0) return;
-  CheckCtl& c = *cc;
-  DevState& s = *st;
-  const int it = s.nIter;
-  if (kind) {
-    s.sumPrimalStep = 0.0;
-    s.sumDualStep = 0.0;
-    // PDHG_Compute_Step_Size_Ratio, cupdlp_step.c:147-176
-    const double mean = sqrt(s.primalStep * s.dualStep);
-    const double dP = sqrt(dP2), dD = sqrt(dD2);
-    if (fmin(dP, dD) > 1e-10) {
-      const double lg = 0.5 * pdlp_det_log(dD / dP) + 0.5 * pdlp_det_log(sqrt(s.beta));
-      s.beta = pdlp_det_exp(lg) * pdlp_det_exp(lg);
-    }
-    s.primalStep = mean / sqrt(s.beta);
-    s.dualStep = s.primalStep * s.beta;
-    s.eta = sqrt(s.primalStep * s.dualStep);
-    if (c.adaptive) {
-      s.tau = s.eta / sqrt(s.beta);
-      s.sigma = s.eta * sqrt(s.beta);
-    } else {
-      s.tau = s.primalStep;
-      s.sigma = s.dualStep;
-    }
-    c.iLastRestartIter = it;
-    c.nRestarts += 1;
+  restartFinishCore(*st, *cc, dP2, dD2);
+  writeRecord(rec, *st, *cc);
+}
+
+// ---- the whole check of a small LP as ONE launch --------------------------------------------------------------------
+// Netlib-class LPs run their trials in one persistent launch per check period (pdlp_small.hip); the check behind it was
+// ten launches of a few microseconds each — 48 us per period on 25fv47, a tenth of the loop.  Here the same phases run
+// inside one launch of the same few dozen resident workgroups, separated by grid barriers (sweep barrier, agent-scope
+// hand-overs, roll call first — this is a barrier launch like the trial loop):
+//     F  pending averages + xAvg, yAvg                      | barrier
+//     S  A xAvg, A' yAvg (stream blocks + segment tasks)    | barrier
+//     R  row / column statistics of both iterates           | barrier     virtual blocks: block vb of the grid of
+//     Q  the 30 fixed-order sums of the block partials      | barrier     k_row_stats2 / k_col_stats2 / k_restart_vec is
+//     D  residuals, termination, restart decision — in every workgroup      run by workgroup vb % G with the same lanes,
+//     V  (restart) sums cleared, average -> current, norms  | barrier     strides and trees: the same bits
+//     W  primal weight, next halt; workgroup 0 writes the state, the control record and the host's record
+// Every per-element expression and the scalar logic are the functions of pdlp_checkfn.hpp that the launch sequence uses.
+struct CheckSmallArgs {
+  SpmvMat A, At;
+  LongMat LA, LAt;
+  IterVecs v;
+  DevState* st;
+  CheckCtl* cc;
+  CheckRecord* rec;
+  RestartVecs r;  // xAvg, yAvg, axAvg, atyAvg, xLast, yLast
+  double* xAvg; double* yAvg; double* axAvg; double* atyAvg;
+  const double* rowScale; const double* colScale;
+  double* spC; double* snC; double* spA; double* snA;
+  double* statPart; double* statOut; double* partX; double* partY;
+  unsigned long long* bar;   // G arrival words, the timeout flag, the roll-call word
+  unsigned long long seq;    // number of this launch since the words were zeroed (1, 2, ...)
+  unsigned long long limit;
+  int32_t statStride, scaled;
+};
+
+__device__ __forceinline__ int vecBlocksDev(int len) {
+  long long b = ((long long)len + kVecThreads - 1) / kVecThreads;
+  if (b < 1) b = 1;
+  if (b > 2048) b = 2048;
+  return (int)b;
+}
+
+// out[r] = sum of the major's products, left to right (k_spmv's stream path with the plain epilogue), for one work block
+template <int CHUNK>
+__device__ __forceinline__ void plainSpmvBlock(const SpmvMat& M, int blk, const double* in, double* out, double* prod) {
+  constexpr int kPer = CHUNK / kSpmvThreads;
+  const int tid = threadIdx.x;
+  const int4 bb = *reinterpret_cast<const int4*>(M.blockBeg + 4 * blk);
+  const int r0 = bb.x, r1 = bb.y, p0 = bb.z, cnt = bb.w - bb.z;
+  const int last = cnt > 0 ? cnt - 1 : 0;
+  int32_t ci[kPer];
+  double va[kPer], xg[kPer];
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    const int q = tid + k * kSpmvThreads;
+    const int qq = q < last ? q : last;
+    ci[k] = M.idx[p0 + qq];
+    va[k] = M.val[p0 + qq];
   }
-  s.haltIter = nextHalt(it, c);
-  s.halted = 0;
-  s.pending = 0;
-  writeRecord(rec, s, c);
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) xg[k] = ldAgent(in + ci[k]);
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    const int q = tid + k * kSpmvThreads;
+    if (q < cnt) prod[slot(q)] = va[k] * xg[k];
+  }
+  __syncthreads();
+  for (int r = r0 + tid; r < r1; r += kSpmvThreads) {
+    const int qb = M.beg[r] - p0, qe = M.beg[r + 1] - p0;
+    stAgent(out + r, majorSum(prod, qb, qe));
+  }
+  __syncthreads();
+}
+// a group of four segment tasks of the long majors, plain epilogue (pdlp_kernels.hip longBlock: same lanes and sums)
+__device__ __forceinline__ void plainLongBlock(const LongMat& L, int tb, const double* in, double* out, double* lds /* [4] */) {
+  constexpr int W = kSpmvThreads / kWave;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x / kWave);
+  const int t = tb * W + wave;
+  LongTask T;
+  T.c = -1; T.pBeg = T.pEnd = 0; T.first = t; T.nSeg = 1; T.major = 0; T.contained = 1; T.pad_ = 0;
+  if (t < L.nTasks) {
+    const int32_t* q = reinterpret_cast<const int32_t*>(L.tasks + t);
+    T.pBeg = ldUniform(q); T.pEnd = ldUniform(q + 1); T.c = ldUniform(q + 2); T.first = ldUniform(q + 3);
+    T.nSeg = ldUniform(q + 4); T.major = ldUniform(q + 5); T.contained = ldUniform(q + 6);
+  }
+  const bool active = T.c >= 0;
+  const int seg = t - T.first;
+  constexpr int kPer = kLongSegment / kWave;
+  double s = 0.0;
+  for (int base = T.pBeg; base < T.pEnd; base += kLongSegment) {
+    int32_t ci[kPer];
+    double va[kPer], xg[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int q = base + k * kWave + lane;
+      const int qq = q < T.pEnd ? q : T.pEnd - 1;
+      ci[k] = L.idx[qq];
+      va[k] = L.val[qq];
+    }
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) xg[k] = ldAgent(in + ci[k]);
+#pragma unroll
+    for (int k = 0; k < kPer; ++k)
+      if (base + k * kWave + lane < T.pEnd) s += va[k] * xg[k];
+  }
+  s = waveSum(s);
+  int last = 0;
+  if (lane == 0) {
+    lds[wave] = s;
+    if (active && !T.contained) {
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(L.segSum + t), (unsigned long long)__double_as_longlong(s),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned old = __hip_atomic_fetch_add(L.ticket + T.c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = old == (unsigned)(T.nSeg - 1) ? 1 : 0;
+    }
+  }
+  last = __builtin_amdgcn_readfirstlane(last);
+  __syncthreads();
+  double total = 0.0;
+  bool finish = false;
+  if (active && T.contained && seg == 0) {
+    for (int k = 0; k < T.nSeg; ++k) total += lds[wave + k];
+    finish = true;
+  } else if (last) {
+    if (lane == 0) __hip_atomic_store(L.ticket + T.c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double v = 0.0;
+    if (lane < T.nSeg)
+      v = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(L.segSum + T.first + lane),
+                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    for (int k = 0; k < T.nSeg; ++k) total += __shfl(v, k, kWave);
+    finish = true;
+  }
+  if (finish && lane == 0) stAgent(out + T.major, total);
+  __syncthreads();
+}
+
+template <int CHUNK_A, int CHUNK_AT>
+__global__ __launch_bounds__(kVecThreads) void k_check_small(const CheckSmallArgs a) {
+  constexpr int kMaxChunk = CHUNK_A > CHUNK_AT ? CHUNK_A : CHUNK_AT;
+  __shared__ double prod[kMaxChunk + kMaxChunk / 8 + 8];
+  __shared__ double scratch[2 * kColStats][kVecThreads / kWave];
+  __shared__ double stat[kStatTotal];
+  __shared__ DevState sh;
+  __shared__ CheckCtl ctl;
+  __shared__ int flag;
+  const int tid = threadIdx.x, lb = blockIdx.x, G = gridDim.x;
+  // roll call: every launch of the sequence takes part, due or not (the count is cumulative)
+  if (tid < kWave) {
+    const bool here = rollCall(a.bar + G + 1, (int)(a.seq * (unsigned long long)G), a.limit, tid);
+    if (tid == 0) flag = here ? 1 : 0;
+  }
+  __syncthreads();
+  if (!flag) {
+    if (tid == 0) __hip_atomic_store(&a.st->commError, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  if (!checkDue(a.st, a.cc)) return;  // (nobody writes the two records before the last barrier of the launch)
+  for (int w = tid; w < (int)(sizeof(DevState) / 4); w += kVecThreads) reinterpret_cast<uint32_t*>(&sh)[w] = reinterpret_cast<const uint32_t*>(a.st)[w];
+  for (int w = tid; w < (int)(sizeof(CheckCtl) / 4); w += kVecThreads) reinterpret_cast<uint32_t*>(&ctl)[w] = reinterpret_cast<const uint32_t*>(a.cc)[w];
+  padSlots(prod, kMaxChunk + kMaxChunk / 8 + 8, tid, kVecThreads);
+  __syncthreads();
+  unsigned long long epoch = 8ull * a.seq;
+  auto meet = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid < kWave) (void)gridBarrier<false>(a.bar, lb, G, ++epoch, tid, a.limit);
+    else ++epoch;
+    __syncthreads();
+  };
+  const IterVecs& v = a.v;
+  const int cur = sh.cur, n = v.n, m = v.m;
+  // ---- F: pending average update and the averages (k_flush_scale) ----
+  {
+    const double w = sh.avgW, wx = sh.avgWx;
+    const double ps = sh.sumPrimalStep > 0.0 ? 1.0 / sh.sumPrimalStep : 1.0;
+    const double ds = sh.sumDualStep > 0.0 ? 1.0 / sh.sumDualStep : 1.0;
+    for (int i = lb * kVecThreads + tid; i < n + m; i += G * kVecThreads) {
+      if (i < n) {
+        double sx = ldStream(v.xSum + i);
+        // (xSum / ySum are written again in phase V, by another workgroup on maybe another XCD: two dirty copies of a line
+        // in two L2s would be written back in no particular order — both writers store through to memory)
+        if (wx != 0.0) { sx = sx + wx * ldStream(v.x[cur] + i); stAgent(v.xSum + i, sx); }
+        stAgent(a.xAvg + i, sx * ps);
+      } else {
+        const int k = i - n;
+        double sy = ldStream(v.ySum + k);
+        if (w != 0.0) { sy = sy + w * ldStream(v.y[cur] + k); stAgent(v.ySum + k, sy); }
+        stAgent(a.yAvg + k, sy * ds);
+      }
+    }
+  }
+  meet();
+  // ---- S: A xAvg and A' yAvg ----
+  for (int b = lb; b < a.A.nBlocks; b += G) plainSpmvBlock<CHUNK_A>(a.A, b, a.xAvg, a.axAvg, prod);
+  for (int tb = lb; tb * (kSpmvThreads / kWave) < a.LA.nTasks; tb += G) plainLongBlock(a.LA, tb, a.xAvg, a.axAvg, scratch[0]);
+  for (int b = lb; b < a.At.nBlocks; b += G) plainSpmvBlock<CHUNK_AT>(a.At, b, a.yAvg, a.atyAvg, prod);
+  for (int tb = lb; tb * (kSpmvThreads / kWave) < a.LAt.nTasks; tb += G) plainLongBlock(a.LAt, tb, a.yAvg, a.atyAvg, scratch[0]);
+  meet();
+  // ---- R: statistics of both iterates on the grids of k_row_stats2 / k_col_stats2 ----
+  const int nbM = vecBlocksDev(m > 0 ? m : 1), nbN = vecBlocksDev(n > 0 ? n : 1);
+  for (int vb = lb; vb < nbM; vb += G) {
+    double acc[2 * kRowStats];
+#pragma unroll
+    for (int q = 0; q < 2 * kRowStats; ++q) acc[q] = 0.0;
+    for (int i = vb * kVecThreads + tid; i < m; i += nbM * kVecThreads)
+      rowStatsElem<true>(acc, i, v.ax[cur], v.y[cur], a.axAvg, a.yAvg, v.rhs, a.rowScale, a.scaled, (i + v.rowOffset) >= v.nEqs);
+    blockSumManyAt<2 * kRowStats, true>(acc, scratch, a.statPart + (size_t)kStatRowCur * a.statStride, a.statStride, vb);
+    __syncthreads();
+  }
+  {
+    const ColStatPtrs p{v.aty[cur], v.x[cur], a.atyAvg, a.xAvg, v.cost, v.lower, v.upper, a.colScale, v.qdiag, nullptr, nullptr,
+                        a.spC, a.snC, a.spA, a.snA};
+    for (int vb = lb; vb < nbN; vb += G) {
+      double acc[2 * kColStats];
+#pragma unroll
+      for (int q = 0; q < 2 * kColStats; ++q) acc[q] = 0.0;
+      for (int j = vb * kVecThreads + tid; j < n; j += nbN * kVecThreads) colStatsElem<true>(acc, j, p, a.scaled);
+      blockSumManyAt<2 * kColStats, true>(acc, scratch, a.statPart + (size_t)kStatColCur * a.statStride, a.statStride, vb);
+      __syncthreads();
+    }
+  }
+  meet();
+  // ---- Q: the 30 fixed-order sums (k_final_reduce2) ----
+  for (int q = lb; q < kStatTotal; q += G) {
+    const double r = reducePartialsAgent(a.statPart + (size_t)q * a.statStride, q < 2 * kRowStats ? nbM : nbN, scratch[0]);
+    if (tid == 0) stAgent(a.statOut + q, r);
+  }
+  meet();
+  // ---- D: residuals, termination, restart decision: the same in every workgroup ----
+  if (tid < kStatTotal) stat[tid] = ldAgent(a.statOut + tid);
+  __syncthreads();
+  if (tid == 0) flag = checkDecideCore(sh, ctl, stat) ? 1 : 0;
+  __syncthreads();
+  const bool over = flag != 0;
+  const int kind = ctl.restartKind;
+  double dP2 = 0.0, dD2 = 0.0;
+  if (!over && kind) {
+    // ---- V: the vector side of the restart on the grid of k_restart_vec ----
+    for (int vb = lb; vb < nbN + nbM; vb += G) restartVecBlock<true>(v, cur, kind, a.r, vb, a.partX, nbN, a.partY, nbM, scratch[0]);
+    meet();
+    dP2 = reducePartialsAgent(a.partX, nbN, scratch[0]);
+    dD2 = reducePartialsAgent(a.partY, nbM, scratch[0]);
+  }
+  // ---- W: primal weight, step sizes, next halt; workgroup 0 hands the records on ----
+  if (lb != 0) return;
+  if (tid == 0 && !over) restartFinishCore(sh, ctl, dP2, dD2);
+  __syncthreads();
+  for (int w = tid; w < (int)(sizeof(DevState) / 4); w += kVecThreads) reinterpret_cast<uint32_t*>(a.st)[w] = reinterpret_cast<const uint32_t*>(&sh)[w];
+  for (int w = tid; w < (int)(sizeof(CheckCtl) / 4); w += kVecThreads) reinterpret_cast<uint32_t*>(a.cc)[w] = reinterpret_cast<const uint32_t*>(&ctl)[w];
+  if (tid == 0) writeRecord(a.rec, sh, ctl);
+}
+
+using CheckSmallKernel = void (*)(const CheckSmallArgs);
+CheckSmallKernel pickCheckSmall(int chunkA, int chunkAt) {
+  if (chunkA == kChunkSmall && chunkAt == kChunkSmall) return k_check_small<kChunkSmall, kChunkSmall>;
+  if (chunkA == kChunk && chunkAt == kChunk) return k_check_small<kChunk, kChunk>;
+  if (chunkA == kChunk && chunkAt == kChunkSmall) return k_check_small<kChunk, kChunkSmall>;
+  if (chunkA == kChunkSmall && chunkAt == kChunk) return k_check_small<kChunkSmall, kChunk>;
+  return nullptr;
 }
 
 }  // namespace
@@ -239,6 +374,32 @@ void launchRestartVec(const IterVecs& v, const DevState* st, const CheckCtl* cc,
 void launchRestartFinish(DevState* st, CheckCtl* cc, const double* partX, int32_t nbX, const double* partY, int32_t nbY,
                          CheckRecord* rec, hipStream_t s) {
   hipLaunchKernelGGL(k_restart_finish, dim3(1), dim3(kVecThreads), 0, s, st, cc, partX, nbX, partY, nbY, rec);
+}
+
+// Workgroups the device keeps resident of the one-launch check (0: this pair of operands does not qualify)
+int checkSmallResident(const MatView& A, const MatView& At, int device) {
+  if (A.useSlab || At.useSlab || A.lng.contrib != nullptr || At.lng.contrib != nullptr) return 0;
+  CheckSmallKernel k = pickCheckSmall(A.csr.chunk, At.csr.chunk);
+  if (!k) return 0;
+  int perCu = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k, kVecThreads, 0) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
+  return (perCu < 4 ? perCu : 4) * cus;
+}
+void launchCheckSmall(const MatView& A, const MatView& At, const IterVecs& v, DevState* st, CheckCtl* cc, CheckRecord* rec,
+                      const RestartVecs& r, const double* rowScale, const double* colScale, int scaled, double* spC, double* snC,
+                      double* spA, double* snA, double* statPart, int32_t statStride, double* statOut, double* partX, double* partY,
+                      unsigned long long* bar, int32_t grid, unsigned long long seq, int32_t timeoutMs, hipStream_t s) {
+  CheckSmallArgs a{};
+  a.A = A.csr; a.At = At.csr; a.LA = A.lng; a.LAt = At.lng; a.v = v; a.st = st; a.cc = cc; a.rec = rec; a.r = r;
+  a.xAvg = const_cast<double*>(r.xAvg); a.yAvg = const_cast<double*>(r.yAvg);
+  a.axAvg = const_cast<double*>(r.axAvg); a.atyAvg = const_cast<double*>(r.atyAvg);
+  a.rowScale = rowScale; a.colScale = colScale; a.scaled = scaled;
+  a.spC = spC; a.snC = snC; a.spA = spA; a.snA = snA;
+  a.statPart = statPart; a.statStride = statStride; a.statOut = statOut; a.partX = partX; a.partY = partY;
+  a.bar = bar; a.seq = seq;
+  a.limit = (unsigned long long)(timeoutMs > 0 ? timeoutMs : 1000) * 100000ull;
+  hipLaunchKernelGGL(pickCheckSmall(A.csr.chunk, At.csr.chunk), dim3(grid), dim3(kVecThreads), 0, s, a);
 }
 
 }  // namespace pdlp

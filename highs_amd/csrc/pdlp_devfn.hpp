@@ -131,7 +131,7 @@ __device__ __attribute__((unused)) double reducePartials(const double* __restric
 // (cupdlp_step.c:237-306), the bookkeeping of PDHG_Update_Average (:433-441)
 // and the parity flip that the reference gets from ++nIter.  One thread.
 // TABLE_ONLY (the fused trial kernel, which has no registers to spare for an inlined pow): the host-tabulated powers
-// must cover the trial counter — Solver::refreshPowTable keeps >= 1024 entries ahead at every stop; if they ever
+// must cover the trial counter — Solver::refreshPowTable keeps >= 4096 entries ahead at every stop; if they ever
 // do not, the state is flagged (commError) instead of silently taking the device's own pow.
 // QP with off-diagonal Hessian entries (no reference counterpart): the explicit N x term of the primal step is a
 // forward step on a smooth function, so the trial must also satisfy tau <= |dx|^2 / |dx . N dx|; with tau = eta/w the

@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstddef>
 
+#include "pdlp_checkfn.hpp"
 #include "pdlp_devfn.hpp"
 
 namespace pdlp {
@@ -905,25 +906,6 @@ __global__ __launch_bounds__(kVecThreads) void k_flush_scale(const IterVecs v, c
   }
 }
 
-// NQ block sums with ONE barrier: every wave shuffles its NQ values down, lane 0 parks them, thread q adds the wave
-// results of quantity q in order — the same tree as blockSum per quantity (bit-identical), without 2 NQ barriers.
-template <int NQ>
-__device__ __forceinline__ void blockSumMany(double (&a)[NQ], double (*scratch)[kVecThreads / kWave], double* partials, int pstride) {
-  const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const double t = waveSum(a[q]);
-    if (lane == 0) scratch[q][w] = t;
-  }
-  __syncthreads();
-  if (threadIdx.x < NQ) {
-    double r = 0.0;
-#pragma unroll
-    for (int i = 0; i < kVecThreads / kWave; ++i) r += scratch[threadIdx.x][i];
-    partials[threadIdx.x * pstride + blockIdx.x] = r;
-  }
-}
-
 __global__ __launch_bounds__(kVecThreads) void k_scale_copy(double* __restrict__ dst, const double* __restrict__ src,
                                                             double a, int len) {
   const int stride = gridDim.x * blockDim.x;
@@ -970,26 +952,9 @@ __global__ __launch_bounds__(kVecThreads) void k_row_stats2(const IterVecs v, co
 #pragma unroll
   for (int q = 0; q < 2 * kRowStats; ++q) a[q] = 0.0;
   const int stride = gridDim.x * blockDim.x;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
-    const bool ineq = (i + rowOffset) >= nEqs;
-    const double b = ldStream(rhs + i);
-    const double rs = scaled ? ldStream(rowScale + i) : 1.0;
-    const double axv[2] = {ldStream(axC + i), ldStream(axA + i)}, yv[2] = {ldStream(yC + i), ldStream(yA + i)};
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      double r = axv[k] + (-1.0) * b;
-      if (ineq) r = r < 0.0 ? r : 0.0;
-      r *= rs;
-      a[4 * k + 0] += r * r;
-      a[4 * k + 1] += yv[k] * b;
-      a[4 * k + 2] += yv[k] * yv[k];
-      double c = axv[k];
-      if (ineq) c = c < 0.0 ? c : 0.0;
-      c *= rs;
-      a[4 * k + 3] += c * c;
-    }
-  }
-  blockSumMany<2 * kRowStats>(a, scratch, partials, pstride);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride)
+    rowStatsElem<false>(a, i, axC, yC, axA, yA, rhs, rowScale, scaled, (i + rowOffset) >= nEqs);
+  blockSumManyAt<2 * kRowStats, false>(a, scratch, partials, pstride, (int)blockIdx.x);
 }
 
 // Column pass of PDHG_Compute_Dual_Feasibility and the x-side certificates (cupdlp_solver.c:69-204, 229-256,
@@ -1003,60 +968,16 @@ __global__ __launch_bounds__(kVecThreads) void k_col_stats2(const IterVecs v, co
     if (!checkDue(g.st, g.cc)) return;
     cur = g.st->cur;
   }
-  const double* __restrict__ atyC = v.aty[cur];
-  const double* __restrict__ xC = v.x[cur];
-  const double* __restrict__ cost = v.cost;
-  const double* __restrict__ lower = v.lower;
-  const double* __restrict__ upper = v.upper;
-  const double* __restrict__ qdiag = v.qdiag;
-  const double* __restrict__ nxC = v.nx[0] ? v.nx[cur] : nullptr;
+  const ColStatPtrs p{v.aty[cur], v.x[cur], atyA, xA, v.cost, v.lower, v.upper, colScale, v.qdiag, v.nx[0] ? v.nx[cur] : nullptr, nxA,
+                      spC, snC, spA, snA};
   const int n = v.n;
   __shared__ double scratch[2 * kColStats][kVecThreads / kWave];
   double a[2 * kColStats];
 #pragma unroll
   for (int q = 0; q < 2 * kColStats; ++q) a[q] = 0.0;
   const int stride = gridDim.x * blockDim.x;
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
-    const double c = ldStream(cost + j), l = ldStream(lower + j), u = ldStream(upper + j);
-    const double cs = scaled ? ldStream(colScale + j) : 1.0;
-    const double hasL = l > -INFINITY ? 1.0 : 0.0, hasU = u < INFINITY ? 1.0 : 0.0;
-    const double lF = l > -INFINITY ? l : 0.0, uF = u < INFINITY ? u : 0.0;
-    const double qj = qdiag ? qdiag[j] : 0.0;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const double xv = ldStream((k ? xA : xC) + j), atyv = ldStream((k ? atyA : atyC) + j);
-      const double* __restrict__ nx = k ? nxA : nxC;
-      double* a_ = a + kColStats * k;
-      double r = -atyv + c;
-      double half = 0.0;
-      if (qdiag) { r += qj * xv; half = (0.5 * qj * xv) * xv; }
-      if (nx) { const double nj = ldStream(nx + j); r += nj; half += (0.5 * nj) * xv; }
-      a_[10] += half;
-      const double sp = (r > 0.0 ? r : 0.0) * hasL;
-      const double sn = (-(r < 0.0 ? r : 0.0)) * hasU;
-      stStream((k ? spA : spC) + j, sp);
-      stStream((k ? snA : snC) + j, sn);
-      a_[0] += xv * c;
-      a_[1] += sp * lF;
-      a_[2] += sn * uF;
-      double rd = r + (-1.0) * sp;
-      rd += sn;
-      rd *= cs;
-      a_[3] += rd * rd;
-      a_[4] += sp * sp;
-      a_[5] += sn * sn;
-      double pc = (atyv + sp) - sn;
-      pc *= cs;
-      a_[6] += pc * pc;
-      a_[7] += xv * xv;
-      double lb = (xv < 0.0 ? xv : 0.0) * hasL;
-      double ub = (xv > 0.0 ? xv : 0.0) * hasU;
-      if (scaled) { lb /= cs; ub /= cs; }
-      a_[8] += lb * lb;
-      a_[9] += ub * ub;
-    }
-  }
-  blockSumMany<2 * kColStats>(a, scratch, partials, pstride);
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) colStatsElem<false>(a, j, p, scaled);
+  blockSumManyAt<2 * kColStats, false>(a, scratch, partials, pstride, (int)blockIdx.x);
 }
 
 // out[q] = fixed-order sum of quantity q's per-block partials; the first nQ0 quantities have nBlocks0 partials each,

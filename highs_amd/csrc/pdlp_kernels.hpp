@@ -281,9 +281,10 @@ void launchSpmvAtyFusedPrimal(const MatView& At, const IterVecs& v, const DevSta
 int smallTrialsGrid(const MatView& A, const MatView& At, int32_t n, int device, int* resident);
 // Every launch begins with a roll call of its working workgroups (pdlp_devfn.hpp rollCall): if they are not all resident
 // within timeoutMs, the launch changes nothing but commError = 3 in *st (failRollCall: a test asks for exactly that).
+// seq: number of this launch since the caller zeroed `bar` (1, 2, ...): the roll call counts cumulatively.
 void launchSmallTrials(const MatView& A, const MatView& At, const IterVecs& v, DevState* st, double* partDY, double* partDX,
                        double* partInter, unsigned long long* bar, int32_t grid, int32_t maxTrials, int mode, hipStream_t s,
-                       int32_t timeoutMs = 1000, bool failRollCall = false, bool selfTest = false);
+                       int32_t timeoutMs = 1000, bool failRollCall = false, bool selfTest = false, unsigned long long seq = 1);
 constexpr int kSmallHierWords = 4 * 16 * 32;  // the XCD-hierarchical barrier's words (pdlp_devfn.hpp HierBar)
 // arrival words, timeout flag, XCC ids of the placement check; behind them (256-byte aligned) the hierarchical barrier's words
 // ... and, last, the words of the XCD-local mode's coherence self-test (grid test words, grid arrival words, flag, failure word)
@@ -336,6 +337,18 @@ void launchDiffNorm2(const double* a, const double* b, int32_t len, double* part
                      hipStream_t s);
 // partials of a.b
 void launchDot(const double* a, const double* b, int32_t len, double* partials, int32_t nBlocks, hipStream_t s);
+
+// ---- the whole device-driven check of a small LP as ONE launch (pdlp_check.hip k_check_small) ----
+// For the LPs of the persistent trial loop with at most 64 workgroups: the phases of the launch sequence below separated by
+// grid barriers inside one launch of `grid` resident workgroups; same statistics grids, same scalar logic, same bits.
+// bar: grid + 8 words zeroed when the solve starts; seq = 1, 2, ... counts the launches since.  A roll call that fails
+// (shared device) leaves everything untouched and sets commError = 3.
+int checkSmallResident(const MatView& A, const MatView& At, int device);
+struct RestartVecs;
+void launchCheckSmall(const MatView& A, const MatView& At, const IterVecs& v, DevState* st, CheckCtl* cc, CheckRecord* rec,
+                      const RestartVecs& r, const double* rowScale, const double* colScale, int scaled, double* spC, double* snC,
+                      double* spA, double* snA, double* statPart, int32_t statStride, double* statOut, double* partX, double* partY,
+                      unsigned long long* bar, int32_t grid, unsigned long long seq, int32_t timeoutMs, hipStream_t s);
 
 // ---- the scalar side of a device-driven check (pdlp_check.hip) ------------------------------------------------------
 // stat: the 2*kRowStats + 2*kColStats statistics (launchFinalReduce2).  Residuals of both iterates, termination

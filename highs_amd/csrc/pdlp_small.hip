@@ -524,13 +524,15 @@ int smallTrialsGrid(const MatView& A, const MatView& At, int32_t n, int device, 
 
 void launchSmallTrials(const MatView& A, const MatView& At, const IterVecs& v, DevState* st, double* partDY, double* partDX,
                        double* partInter, unsigned long long* bar, int32_t grid, int32_t maxTrials, int mode, hipStream_t s,
-                       int32_t timeoutMs, bool failRollCall, bool selfTest) {
+                       int32_t timeoutMs, bool failRollCall, bool selfTest, unsigned long long seq) {
   const bool xcdLocal = mode == 1;
   static_assert(kHierBarWords == kSmallHierWords, "barrier buffer layout");
-  if (mode == 2) (void)hipMemsetAsync(bar, 0, smallBarWords(grid) * sizeof(unsigned long long), s);  // launch-local barrier counters
-  else (void)hipMemsetAsync(bar + grid + 1, 0, sizeof(unsigned long long), s);                    // the roll-call word
+  // mode 2: the hierarchical barrier's counters (and the roll-call word) start from zero in every launch; the other modes
+  // keep their words — arrival epochs grow with the trial counter, the roll-call count with the launches (seq = 1, 2, ...
+  // since the caller zeroed the buffer), so no memset launch sits between two launches of the loop
+  if (mode == 2) (void)hipMemsetAsync(bar, 0, smallBarWords(grid) * sizeof(unsigned long long), s);
   SmallArgs a{};
-  a.expect = grid + (failRollCall ? 1 : 0);
+  a.expect = (mode == 2 ? grid : (int32_t)(seq * (unsigned long long)grid)) + (failRollCall ? 1 : 0);
   a.selfTest = xcdLocal && selfTest ? 1 : 0;
   if (a.selfTest)  // its words: the tail of the buffer
     (void)hipMemsetAsync(bar + smallBarWords(grid) - (size_t)(2 * grid + 8), 0, (size_t)(2 * grid + 8) * sizeof(unsigned long long), s);

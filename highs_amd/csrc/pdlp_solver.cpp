@@ -265,6 +265,7 @@ DevSwitches DevSwitches::fromEnv() {
   w.xcdLocal = num("PDLP_MI355X_XCD_LOCAL", -1);
   w.hierBarrier = num("PDLP_MI355X_HIER_BARRIER", -1);
   w.deviceCheck = num("PDLP_MI355X_DEVICE_CHECK", -1);
+  w.checkSmall = num("PDLP_MI355X_CHECK_SMALL", -1);
   w.barrierTimeoutMs = num("PDLP_MI355X_BARRIER_TIMEOUT_MS", 1000);
   w.fault = num("PDLP_MI355X_FAULT", 0);
   w.exchange = str("PDLP_MI355X_EXCHANGE");
@@ -484,6 +485,9 @@ void Solver::construct(const pdlp_problem_t& P, const void* id128) {
     }
     if (fused_) gridBar_.alloc(gridBarWords(fusedAtyBlocks(at)));
     if (persistent_) gridBar_.alloc(smallBarWords(smallGrid_));
+    // Netlib-class LPs (at most 64 workgroups): the check iteration as one launch too (PDLP_MI355X_CHECK_SMALL=0: ten launches)
+    checkSmall_ = persistent_ && smallGrid_ <= 64 && sw_.checkSmall != 0 && checkSmallResident(dA_.view(), at, opt_.device) >= smallGrid_;
+    if (checkSmall_) checkBar_.alloc((size_t)smallGrid_ + 8);
   }
   // check iterations on the device (single GPU; the sharded paths issue their check collectives from the host)
   devCheck_ = !sharded_ && sw_.deviceCheck != 0;
@@ -696,6 +700,7 @@ void Solver::syncState() {
     persistent_ = false;
     fused_ = false;
     xcdLocal_ = false;
+    checkSmall_ = false;
     if (graphExec_) { (void)hipGraphExecDestroy(graphExec_); graphExec_ = nullptr; }
     hostState_->commError = 0;
     hostState_->halted = hostState_->nIter >= hostState_->haltIter ? 1 : 0;
@@ -711,7 +716,7 @@ void Solver::syncState() {
 // kPowWindow trial counters, computed with the host's pow so that the device takes exactly the
 // CPU's values (the oracle can then follow a GPU solve bit for bit).
 void Solver::refreshPowTable() {
-  constexpr int32_t kPowWindow = 4096, kPowMargin = 1024;
+  constexpr int32_t kPowWindow = 16384, kPowMargin = 4096;
   DevState& s = *hostState_;
   if (s.powRed && s.nTrials >= s.powBase && s.nTrials + kPowMargin < s.powBase + s.powCount) return;
   if (powRed_.size() == 0) { powRed_.alloc(kPowWindow); powGrow_.alloc(kPowWindow); }
@@ -861,7 +866,8 @@ void Solver::initVariables() {
 void Solver::reset() {
   DevState& s = *hostState_;
   memset(&s, 0, sizeof(s));
-  if (fused_ || persistent_) gridBar_.zero(stream_);  // arrival epochs follow the trial counter, which starts again
+  if (fused_ || persistent_) { gridBar_.zero(stream_); smallSeq_ = 0; }  // arrival epochs follow the trial counter, which starts again
+  if (checkSmall_) { checkBar_.zero(stream_); checkSmallSeq_ = 0; }
   s.adaptive = adaptive_ ? 1 : 0;
   initStepSizes();
   initVariables();
@@ -927,7 +933,7 @@ void Solver::enqueueTrial() {
   }
   if (persistent_) {
     launchSmallTrials(dA_.view(), dAt_.view(), vecs_, dst(), partDY_.get(), partDX_.get(), partInter_.get(), gridBar_.get(), smallGrid_, 1,
-                      smallMode(), stream_, sw_.barrierTimeoutMs, sw_.fault == 1 && smallLaunches_ == 0, smallLaunches_ == 0);
+                      smallMode(), stream_, sw_.barrierTimeoutMs, sw_.fault == 1 && smallLaunches_ == 0, smallLaunches_ == 0, ++smallSeq_);
     ++smallLaunches_;
     return;
   }
@@ -1029,7 +1035,7 @@ void Solver::enqueueBatch(int32_t todo) {
   if (persistent_ && !profile_) {  // the whole stretch to the next check (plus spare trials for rejections) in one launch
     launchSmallTrials(dA_.view(), dAt_.view(), vecs_, dst(), partDY_.get(), partDX_.get(), partInter_.get(), gridBar_.get(),
                       smallGrid_, todo + 8, smallMode(), stream_, sw_.barrierTimeoutMs, sw_.fault == 1 && smallLaunches_ == 0,
-                      smallLaunches_ == 0);
+                      smallLaunches_ == 0, ++smallSeq_);
     ++smallLaunches_;
     return;
   }
@@ -1076,7 +1082,7 @@ void Solver::runUntilHalt() {
     if (timeIsUp()) return;
     // a stretch without check iterations (check_interval beyond the host's 160-iteration rounds): keep the tabulated
     // powers of the step rule ahead of the trial counter (the fused / persistent kernels take no other)
-    if (hostState_->powRed && hostState_->nTrials + 1024 >= hostState_->powBase + hostState_->powCount) pushState();
+    if (hostState_->powRed && hostState_->nTrials + 4096 >= hostState_->powBase + hostState_->powCount) pushState();
   }
 }
 
@@ -1312,6 +1318,18 @@ void Solver::downloadCtl() {
 void Solver::enqueueCheckDevice() {
   DevState* st = dst();
   const CheckGate g{st, dCtl_.get()};
+  if (persistent_ && checkSmall_) {
+    // the small-LP form: the whole check is ONE launch of the trial loop's workgroups (pdlp_check.hip k_check_small)
+    CheckRecord* rec = hostRing_ + (checkSeq_ % kRingSlots);
+    rec->ran = 0;
+    ++checkSeq_;
+    const RestartVecs rv{xAvg_.get(), yAvg_.get(), axAvg_.get(), atyAvg_.get(), nullptr, xLast_.get(), yLast_.get()};
+    launchCheckSmall(dA_.view(), dAt_.view(), vecs_, st, dCtl_.get(), rec, rv, rowScale_.get(), colScale_.get(), F_.scaled ? 1 : 0,
+                     slackPos_.get(), slackNeg_.get(), slackPosAvg_.get(), slackNegAvg_.get(), statPart_.get(), statStride_, statOut_.get(),
+                     partDX_.get(), partRestartY_.get(), checkBar_.get(), smallGrid_, ++checkSmallSeq_, sw_.barrierTimeoutMs, stream_);
+    needPrimal_ = true;
+    return;
+  }
   if (!persistent_ && !fused_)  // 3-launch loop: the decision of the last trial may still be pending
     launchDecide(st, partDY_.get(), dA_.nPartials(), partDX_.get(), partInter_.get(), dAt_.nPartials(), nullptr, stream_, true,
                  hasQoff_ ? partQ_.get() : nullptr, hasQoff_ ? dQ_.nPartials() : 0);
@@ -1395,7 +1413,8 @@ void Solver::doSolveDevice(bool terminate, int32_t target) {
       haltExp = haltAfter(itExp);
     }
     int32_t units = 0;
-    for (int32_t u = 0; u < ahead; ++u) {
+    int64_t queuedTrials = 0;  // (the tabulated powers of the step rule reach 4096 trials beyond the last refresh)
+    for (int32_t u = 0; u < ahead && queuedTrials < 3000; ++u) {
       int64_t todo = haltExp - itExp;
       if (todo < 1) todo = 1;
       if (todo > 4 * kCheckInterval) todo = 4 * kCheckInterval;
@@ -1404,6 +1423,7 @@ void Solver::doSolveDevice(bool terminate, int32_t target) {
       enqueueBatch((int32_t)todo + (batched ? 0 : todo >= 8 ? 2 : 1));
       enqueueCheckDevice();
       ++units;
+      queuedTrials += todo + 8;
       itExp = std::min(itExp + todo, haltExp);
       if (itExp >= iterLim || (terminate && itExp >= iterLim - 1)) break;  // the target / the check that ends the solve
       if (itExp == haltExp) haltExp = haltAfter(itExp);
@@ -1426,7 +1446,7 @@ void Solver::doSolveDevice(bool terminate, int32_t target) {
     }
     if (timeIsUp()) { timeUp = true; break; }
     // tabulated powers of the step rule: kept ahead of the trial counter while the stream is idle
-    if (s.powRed && s.nTrials + 1024 >= s.powBase + s.powCount) pushState(false);
+    if (s.powRed && s.nTrials + 4096 >= s.powBase + s.powCount) pushState(false);
     // queue depth: ~25 ms of work, at most 16 units
     const double roundMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - roundBeg).count();
     if (units > 0 && roundMs > 0.0) aheadMax = std::max(1, std::min(16, (int32_t)(25.0 * units / roundMs)));
@@ -1705,6 +1725,8 @@ void Solver::stage(const std::string& name, double* out, int32_t cap) {
     for (int k = 0; k < 3; ++k) { put(k, us[k]); put(3 + k, cnt[k]); }
   } else if (name == "trial_launches") {  // kernels per trial step of the hot loop (2 = fused decision + primal step)
     put(0, meshMode_ ? (colblock_ ? 10.0 : 9.0) : sharded_ ? 7.0 : persistent_ ? 0.0 : fused_ ? 2.0 : 3.0);  // 0: one persistent launch per batch
+  } else if (name == "check_launches") {  // kernels of one device-driven check iteration (1: the one-launch form of small LPs)
+    put(0, !devCheck_ ? 0.0 : persistent_ && checkSmall_ ? 1.0 : 10.0);
   } else if (name == "barrier_fallbacks") {  // times a launch with grid barriers gave up and the loop went on with plain launches
     put(0, (double)barrierFallbacks_);
   } else if (name == "exchange") {  // 0 = not sharded, 1 = RCCL all-reduce, 2 = direct xGMI mesh (partials), 3 = mesh, two all-gathers

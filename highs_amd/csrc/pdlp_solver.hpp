@@ -25,7 +25,7 @@ struct DevSwitches {
   int slab = -1;          // PDLP_MI355X_SLAB: 0 CSR stream only, 1 slab layout, -1 automatic by the gathered vector's size
   int slabW = 0;          // PDLP_MI355X_SLAB_W: log2 of the slab width (development)
   int xcdMap = -1, slabPace = -1;
-  int fused = -1, fusedStream = 0, persistent = -1, xcdLocal = -1, hierBarrier = -1, deviceCheck = -1;
+  int fused = -1, fusedStream = 0, persistent = -1, xcdLocal = -1, hierBarrier = -1, deviceCheck = -1, checkSmall = -1;
   int barrierTimeoutMs = 1000;  // PDLP_MI355X_BARRIER_TIMEOUT_MS: how long a grid barrier / roll call waits for missing workgroups
   int fault = 0;          // PDLP_MI355X_FAULT (tests): 1 = the first persistent launch expects one workgroup too many,
                           // 2 = the 12th fused trial's barrier expects one block too many (both then time out and fall back)
@@ -204,6 +204,7 @@ class Solver : public SolverBase {
   int32_t smallGrid_ = 0;
   DeviceArray<unsigned long long> gridBar_;
   int32_t barrierFallbacks_ = 0, smallLaunches_ = 0;
+  unsigned long long smallSeq_ = 0;  // persistent launches since gridBar_ was zeroed (their roll call counts cumulatively)
   static std::mutex& deviceGate(int device);
   int32_t stalledRounds_ = 0, stalledSince_ = 0;  // consecutive device stops without an accepted trial
   // Device-driven check iterations (pdlp_kernels.hpp CheckCtl; PDLP_MI355X_DEVICE_CHECK=0 gives the host-driven loop back)
@@ -214,6 +215,10 @@ class Solver : public SolverBase {
   static constexpr int32_t kRingSlots = 64;
   int64_t checkSeq_ = 0, checkSeen_ = 0;  // checks enqueued / records looked at
   DeviceArray<double> partRestartY_;
+  // Small LPs: the check as ONE launch (pdlp_check.hip k_check_small); its barrier words and launch counter
+  bool checkSmall_ = false;
+  DeviceArray<unsigned long long> checkBar_;
+  unsigned long long checkSmallSeq_ = 0;
   DevState* dst() const { return dState_.get() + stPar_; }
   DeviceArray<double> powRed_, powGrow_;  // host-tabulated powers of the trial counter (see DevState)
   void refreshPowTable();

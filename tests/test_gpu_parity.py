@@ -608,7 +608,7 @@ def test_trial_loop_variants_give_the_same_bits(name, iters, monkeypatch):
         assert ref[3:5] == o[3:5], vname
 
 
-@pytest.mark.parametrize("name", ["afiro", "25fv47", "standata", "synthetic-stream", "synthetic-slab", "qp"])
+@pytest.mark.parametrize("name", ["afiro", "25fv47", "standata", "standmps", "80bau3b", "synthetic-stream", "synthetic-slab", "qp"])
 def test_device_driven_checks_give_the_bits_of_host_driven_checks(name, monkeypatch):
     """Since round 4 the check iteration (residuals, termination, restart, primal-weight update) runs on the device
     behind the trial batch, several periods queued ahead of the host (pdlp_check.hip, Solver::doSolveDevice);
@@ -626,18 +626,26 @@ def test_device_driven_checks_give_the_bits_of_host_driven_checks(name, monkeypa
         lp, kw = L.HighsLp.from_npz(os.path.join(GOLD, "qp", "qp0.npz")), dict(kkt_tolerance=1e-8)
     else:
         lp, kw = _lp(name), {}
+    # host-driven | device-driven as a sequence of ten launches | device-driven, the check as ONE launch where the LP runs
+    # on the persistent loop with at most 64 workgroups (pdlp_check.hip k_check_small; elsewhere the same as the second)
+    modes = {"host": {"PDLP_MI355X_DEVICE_CHECK": "0"}, "launches": {"PDLP_MI355X_CHECK_SMALL": "0"}, "default": {}}
     out = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("PDLP_MI355X_DEVICE_CHECK", mode)
+    for mode, env in modes.items():
+        for k in ("PDLP_MI355X_DEVICE_CHECK", "PDLP_MI355X_CHECK_SMALL"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         out[mode] = solver.solveLpCupdlp(lp, **kw)
     if sp_ is not None:
         sp_.close()
-    a, b = out["0"].result, out["1"].result
-    assert (a.term_code, a.term_iterate, a.num_iter, a.num_trials, a.num_restarts) == (b.term_code, b.term_iterate, b.num_iter, b.num_trials, b.num_restarts)
-    assert (a.primal_obj, a.dual_obj, a.primal_feas, a.dual_feas, a.rel_gap) == (b.primal_obj, b.dual_obj, b.primal_feas, b.dual_feas, b.rel_gap)
-    for v in ("col_value", "col_dual", "row_value", "row_dual"):
-        assert np.array_equal(getattr(out["0"].solution, v), getattr(out["1"].solution, v)), v
-    assert b.num_iter > 0
+    a = out["host"].result
+    for mode in ("launches", "default"):
+        b = out[mode].result
+        assert (a.term_code, a.term_iterate, a.num_iter, a.num_trials, a.num_restarts) == (b.term_code, b.term_iterate, b.num_iter, b.num_trials, b.num_restarts), mode
+        assert (a.primal_obj, a.dual_obj, a.primal_feas, a.dual_feas, a.rel_gap) == (b.primal_obj, b.dual_obj, b.primal_feas, b.dual_feas, b.rel_gap), mode
+        for v in ("col_value", "col_dual", "row_value", "row_dual"):
+            assert np.array_equal(getattr(out["host"].solution, v), getattr(out[mode].solution, v)), (mode, v)
+    assert a.num_iter > 0
 
 
 def test_concurrent_solver_contexts_on_two_threads():
