@@ -112,7 +112,7 @@ __device__ bool waitPeers(const MeshArgs& ma, int kind, long long e) {
   __syncthreads();
   const bool good = ok != 0;
   if (ma.fences) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // (payload reads are system-scope loads anyway)
-  if (threadIdx.x == 0 && kind < 3) {  // hot-loop exchanges: how long this block waited (integer atomics)
+  if (threadIdx.x == 0 && blockIdx.x == 0 && kind < 3) {  // hot-loop exchanges: how long (the first block of) this kernel waited
     atomicAdd(&ma.ms->waitTicks[kind], (unsigned long long)(wall_clock64() - tEnter));
     atomicAdd(&ma.ms->waitCount[kind], 1ull);
   }
@@ -219,6 +219,7 @@ __global__ __launch_bounds__(kVecThreads) void k_mesh_wait_copy_x(const IterVecs
                                                                   const MeshArgs ma) {
   const MeshView* __restrict__ mv = ma.v; (void)mv;
   if (st->halted || dead(ma)) return;  // (k_mesh_wait ran before: flag X has arrived, or the exchange is dead)
+  if (ma.fusedWait && !waitPeers(ma, kFlagX, ma.ms->seq + 1)) { fail(ma, st); return; }  // ... or every block waits itself
   const int nxt = st->cur ^ 1;
   const int c0 = mv->colOff[ma.g], c1 = mv->colOff[ma.g + 1];
   const double* __restrict__ src = recvX(ma, ma.g);
@@ -276,6 +277,7 @@ __global__ __launch_bounds__(kVecThreads) void k_mesh_wait_copy_y(double* __rest
                                                                   const DevState* st, const MeshArgs ma) {
   const MeshView* __restrict__ mv = ma.v; (void)mv;
   if (st->halted || dead(ma)) return;  // (k_mesh_wait ran before: flag P has arrived, or the exchange is dead)
+  if (ma.fusedWait && !waitPeers(ma, kFlagP, ma.ms->seq + 1)) { fail(ma, const_cast<DevState*>(st)); return; }
   double* __restrict__ dst = (st->cur ^ 1) ? y1 : y0;
   const int r0 = mv->rowOff[ma.g], r1 = mv->rowOff[ma.g + 1];
   const double* __restrict__ src = recvY(ma, ma.g);
@@ -628,9 +630,10 @@ void launchMeshPrimalStep(const IterVecs& vc, const DevState* st, const MeshArgs
   hipLaunchKernelGGL(k_mesh_primal_step, dim3(meshBlocks(vc.n)), dim3(kVecThreads), 0, s, vc, st, dmv);
 }
 void launchMeshWaitCopyX(const IterVecs& vf, const DevState* st, const MeshArgs& dmv, hipStream_t s) {
-  hipLaunchKernelGGL(k_mesh_wait, dim3(1), dim3(kWave), 0, s, const_cast<DevState*>(st), dmv, (int)kFlagX, 0LL);
-  hipLaunchKernelGGL(k_mesh_wait_copy_x, dim3(meshConsumerBlocks(vf.n)), dim3(kVecThreads), 0, s, vf,
-                     const_cast<DevState*>(st), dmv);
+  if (!dmv.fusedWait) hipLaunchKernelGGL(k_mesh_wait, dim3(1), dim3(kWave), 0, s, const_cast<DevState*>(st), dmv, (int)kFlagX, 0LL);
+  // (every block polls when the wait is fused: one block per CU at most)
+  hipLaunchKernelGGL(k_mesh_wait_copy_x, dim3(dmv.fusedWait ? capped((vf.n + 3) / 4, 256) : meshConsumerBlocks(vf.n)), dim3(kVecThreads), 0,
+                     s, vf, const_cast<DevState*>(st), dmv);
 }
 void launchMeshPushPartial(const double* partial, int32_t n, const DevState* st, const MeshArgs& dmv, hipStream_t s) {
   hipLaunchKernelGGL(k_mesh_push_partial, dim3(meshBlocks(n)), dim3(kVecThreads), 0, s, partial, st, dmv, 0LL);
@@ -650,9 +653,9 @@ void launchMeshPushY(const IterVecs& vf, const double* const yFull[2], const Dev
   hipLaunchKernelGGL(k_mesh_push_y, dim3(meshBlocks(std::max(vf.m, 1))), dim3(kVecThreads), 0, s, yFull[0], yFull[1], st, dmv);
 }
 void launchMeshWaitCopyY(double* const yFull[2], int32_t m, const DevState* st, const MeshArgs& dmv, hipStream_t s) {
-  hipLaunchKernelGGL(k_mesh_wait, dim3(1), dim3(kWave), 0, s, const_cast<DevState*>(st), dmv, (int)kFlagP, 0LL);
-  hipLaunchKernelGGL(k_mesh_wait_copy_y, dim3(meshConsumerBlocks(std::max(m, 1))), dim3(kVecThreads), 0, s, yFull[0], yFull[1], m,
-                     st, dmv);
+  if (!dmv.fusedWait) hipLaunchKernelGGL(k_mesh_wait, dim3(1), dim3(kWave), 0, s, const_cast<DevState*>(st), dmv, (int)kFlagP, 0LL);
+  hipLaunchKernelGGL(k_mesh_wait_copy_y, dim3(dmv.fusedWait ? capped((std::max(m, 1) + 3) / 4, 256) : meshConsumerBlocks(std::max(m, 1))),
+                     dim3(kVecThreads), 0, s, yFull[0], yFull[1], m, st, dmv);
 }
 
 void launchMeshHalpernStep(const MatView& A, const MatView& At, const HalpernVecs& hFull, const HalpernVecs& hCol,
@@ -682,6 +685,7 @@ struct ShmSlot {
   uint64_t rawPtr;   // the arena's device pointer: what a rank of the SAME process maps (peer access, no IPC)
   int32_t device;    // HIP device ordinal of the owner
   int32_t pad_;
+  uint64_t busHash;  // hash of the owner's PCI bus id: two ranks on the same physical GPU have the same
   hipIpcMemHandle_t handle;
   std::atomic<uint32_t> agree[64];  // round -> 1 ok / 2 not ok
 };
@@ -820,6 +824,11 @@ void Mesh::construct(int32_t rank, int32_t world, const void* id128, int32_t n, 
   mine.arenaBytes = arenaBytes_;
   mine.rawPtr = (uint64_t)(uintptr_t)arena_;
   mine.device = myDevice;
+  {
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus) - 1, myDevice) != hipSuccess) { (void)hipGetLastError(); bus[0] = 0; }
+    mine.busHash = bus[0] ? fnv64(bus, strlen(bus)) : 0ull;  // (0: unknown — treated as shared)
+  }
   mine.pid = (uint32_t)getpid();
   mine.ready.store(exported ? 1u : 3u, std::memory_order_release);
   hostBarrier(0, 60.0);
@@ -854,7 +863,14 @@ void Mesh::construct(int32_t rank, int32_t world, const void* id128, int32_t n, 
   }
   if (ok) ok = hipMemcpy(dView_, &v_, sizeof(MeshView), hipMemcpyHostToDevice) == hipSuccess;
   setupOk_ = ok;
-  args_ = MeshArgs{dView_, state_, v_.G, v_.g, v_.waitTicks, meshFences(), 0};
+  // does every rank have a physical GPU of its own?  (every rank reads the same table: the same answer everywhere)
+  bool own = true;
+  for (int a = 0; a < world; ++a)
+    for (int b = a + 1; b < world; ++b)
+      if (seg->slot[a].busHash == 0ull || seg->slot[a].busHash == seg->slot[b].busHash) own = false;
+  int fusedWait = own ? 1 : 0;
+  if (const char* e = getenv("PDLP_MI355X_MESH_FUSED_WAIT")) fusedWait = atoi(e) != 0 ? 1 : 0;
+  args_ = MeshArgs{dView_, state_, v_.G, v_.g, v_.waitTicks, meshFences(), fusedWait};
   hostBarrier(1, 60.0);
 }
 

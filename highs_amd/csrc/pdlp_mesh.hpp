@@ -73,7 +73,11 @@ struct MeshArgs {
   int32_t G, g;
   int64_t waitTicks;
   int32_t fences;  // PDLP_MI355X_MESH_FENCES=1: system-scope release before every flag store, acquire after every wait
-  int32_t pad_;
+  // 1: the kernels that consume an all-gather wait for the peers' flags themselves (every block polls; two launches
+  // less per trial).  Taken when every rank has a GPU of its own — with ranks folded onto one device (the tests of
+  // this repository's one-GPU box) a spinning grid per rank could keep the producers it waits for off the CUs, so
+  // there the wait stays a single-block kernel of its own.  PDLP_MI355X_MESH_FUSED_WAIT=0|1 forces either.
+  int32_t fusedWait;
 };
 
 // Host side: arena allocation, IPC rendezvous through a POSIX shared-memory

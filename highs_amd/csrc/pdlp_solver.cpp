@@ -1724,7 +1724,8 @@ void Solver::stage(const std::string& name, double* out, int32_t cap) {
     if (meshMode_) mesh_->phaseStats(us, cnt, stream_);
     for (int k = 0; k < 3; ++k) { put(k, us[k]); put(3 + k, cnt[k]); }
   } else if (name == "trial_launches") {  // kernels per trial step of the hot loop (2 = fused decision + primal step)
-    put(0, meshMode_ ? (colblock_ ? 10.0 : 9.0) : sharded_ ? 7.0 : persistent_ ? 0.0 : fused_ ? 2.0 : 3.0);  // 0: one persistent launch per batch
+    const double fw = meshMode_ && mesh_->args().fusedWait ? 1.0 : 0.0;  // (all-gather consumers wait themselves: two / one launches less)
+    put(0, meshMode_ ? (colblock_ ? 10.0 - 2.0 * fw : 9.0 - fw) : sharded_ ? 7.0 : persistent_ ? 0.0 : fused_ ? 2.0 : 3.0);  // 0: one persistent launch per batch
   } else if (name == "check_launches") {  // kernels of one device-driven check iteration (1: the one-launch form of small LPs)
     put(0, !devCheck_ ? 0.0 : persistent_ && checkSmall_ ? 1.0 : 10.0);
   } else if (name == "barrier_fallbacks") {  // times a launch with grid barriers gave up and the loop went on with plain launches

@@ -175,6 +175,22 @@ def test_mesh_with_release_acquire_fences_gives_the_same_bits(tmp_path):
     assert b[0]["exchange"] in (2.0, 3.0)
 
 
+@pytest.mark.parametrize("case,world", [("solve:e226", 2), ("iterate:synth:120", 2), ("iterate:synthbig:40", 2)])
+def test_mesh_consumers_that_wait_themselves_give_the_same_bits(case, world, tmp_path):
+    """With every rank on a GPU of its own the kernels that consume the two all-gathers poll the peers' flags themselves
+    (MeshArgs::fusedWait: two launches less per trial); with ranks folded onto one device — this box — the wait is a
+    single-block kernel of its own, so that a spinning grid cannot keep the producers off the CUs.
+    PDLP_MI355X_MESH_FUSED_WAIT=1 runs the multi-GPU form here with two ranks (room for both): ordering of launches
+    only, same iterates bit for bit."""
+    a = _run_ranks(world, case, tmp_path, extra_env={"PDLP_MI355X_MESH_FUSED_WAIT": "0"})
+    b = _run_ranks(world, case, tmp_path, extra_env={"PDLP_MI355X_MESH_FUSED_WAIT": "1"})
+    keys = [k for k in a[0] if k not in ("seconds",)]
+    assert keys
+    for r in range(world):
+        for k in keys:
+            assert np.array_equal(a[r][k], b[r][k]), (r, k)
+
+
 @pytest.mark.parametrize("case,world", [("solve:e226", 2), ("iterate:synth:120", 4)])
 def test_sharded_ranks_prepared_on_the_device_give_the_same_bits(case, world, tmp_path):
     """Sharded ranks prepare the whole problem on their device (formulate + scaling + both orientations, automatic

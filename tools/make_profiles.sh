@@ -11,7 +11,7 @@
 #   test logs       : pytest -m gpu (includes the drop-in tests: reference CLI, Catch2 cases, C API client)
 set -u
 R=$(cd "$(dirname "$0")/.." && pwd)
-RND=${1:-r03}
+RND=${1:-r04}
 if [ "${2:-}" = "collect" ]; then
   S=$R/gpurun_out/profiles_$RND
   cp $S/r*.json $S/r*.csv $S/r*.log $R/profiles/ 2>/dev/null
@@ -22,47 +22,29 @@ fi
 OUT=$R/gpurun_out/profiles_$RND
 mkdir -p $OUT
 cd $R
+# PMC traffic of the dominant kernels of every configuration first (separate --pmc passes): the bench lines below then
+# carry THIS tree's counters in roofline.traffic (bench.py reads profiles/pmc_traffic.json)
+bash tools/pmc_traffic.sh $RND > $OUT/pmc_traffic.log 2>&1
+cp $OUT/pmc_traffic.json $R/profiles/pmc_traffic.json
 python bench.py > $OUT/${RND}_bench_1M.json 2> $OUT/bench_1M.err
 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${RND}_bench_1M_driver_flags.json 2>> $OUT/bench_1M.err
 python bench.py --config a > $OUT/${RND}_bench_100k.json 2>> $OUT/bench_1M.err
 python bench.py --config c > $OUT/${RND}_bench_structured.json 2>> $OUT/bench_1M.err
+python bench.py --config d > $OUT/${RND}_bench_staircase_dense_columns.json 2>> $OUT/bench_1M.err
 python bench.py --config qp > $OUT/${RND}_bench_qp.json 2>> $OUT/bench_1M.err
 python bench.py --config qpn > $OUT/${RND}_bench_qp_sparse_hessian.json 2>> $OUT/bench_1M.err
 python bench.py --solver hipdlp > $OUT/${RND}_bench_hipdlp_1M.json 2>> $OUT/bench_1M.err
 python tools/solve_times.py > $OUT/${RND}_small_lp_times.log 2>&1
+python tools/small_loop.py 25fv47 80bau3b >> $OUT/${RND}_small_lp_times.log 2>&1
 ( cd /tmp; export TMPDIR=/tmp
   rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- python $R/bench.py --steps 2000 --warmup 200 --cpu-iters 0 > /dev/null 2>&1
   cp $OUT/trace/t_kernel_stats.csv $OUT/${RND}_bench_1M_kernel_stats.csv
   cp $OUT/trace/t_kernel_trace.csv $OUT/kernel_trace_1M.csv 2>/dev/null
   rocprofv3 --kernel-trace --stats -d $OUT/trace_h -o t --output-format csv -- python $R/bench.py --solver hipdlp --cpu-iters 0 > /dev/null 2>&1
   cp $OUT/trace_h/t_kernel_stats.csv $OUT/${RND}_bench_hipdlp_1M_kernel_stats.csv
-  for SOLVER in pdlp hipdlp; do for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
-    D=$OUT/pmc_${SOLVER}_$(echo $C | tr ' ' '_')
-    timeout 150 rocprofv3 --pmc $C --kernel-trace -d $D -o p --output-format csv -- python $R/tools/kbench.py --solver $SOLVER --iters 120 --reps 3 --kernels spmv_ax,spmv_aty > $D.log 2>&1
-  done; done )
+)
 python - <<PY
 import csv, collections, glob, json, re
-agg = collections.defaultdict(list)
-for f in glob.glob("$OUT/pmc_*/p_counter_collection.csv"):
-    for r in csv.DictReader(open(f)):
-        m = re.search(r"k_spmv_slab<(\d)", r["Kernel_Name"])
-        if m:
-            agg[(int(m.group(1)), r["Counter_Name"])].append(float(r["Counter_Value"]))
-names = {1: "spmv_ax_dual", 2: "spmv_aty_interact", 4: "spmv_aty_halpern_primal", 5: "spmv_ax_halpern_dual",
-         6: "spmv_aty_interact_decide_primal"}
-raw, traffic = {}, {}
-for (k, c), v in sorted(agg.items()):
-    if k in names:
-        raw.setdefault(names[k], {})[c] = sum(v) / len(v)
-for k, d in raw.items():
-    if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
-        traffic[k] = (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024
-json.dump({"b": traffic, "raw_per_launch_means": raw,
-           "note": "HBM-side bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from rocprofv3 --pmc (one counter per pass, "
-                   "tools/make_profiles.sh; kernels inside 120 PDHG iterations plus isolated launches on the 1Mx1M/8M LP): on gfx950 "
-                   "FETCH_SIZE counts coalesced streams at half their size (MI355X_MICROARCH.md), so it is doubled."},
-          open("$OUT/pmc_traffic.json", "w"), indent=1)
-print(json.dumps(traffic, indent=1))
 # per-kernel averages over WORKING launches only: launches queued after the device halted return at once (a few hundred ns)
 # and must not dilute the averages rocprofv3 --stats prints
 try:
