@@ -10,17 +10,22 @@
 //     D  accept / reject and the step-size update, in EVERY workgroup          cupdlp_step.c:215-310
 // are separated by grid barriers instead of kernel boundaries — one arrival word per workgroup and a sweep by one wave
 // (pdlp_devfn.hpp gridBarrier) for a few dozen workgroups; per XCD first, then between the XCDs (hierBarrier) for the
-// hundreds of workgroups of a mid-size LP (100k x 100k / 1M nonzeros: 490), where the sweep costs 4.8 us per barrier.  Work blocks, lane assignments and reduction trees are EXACTLY those of k_spmv /
-// k_decide_primal (pdlp_kernels.hip), so iterates and decisions are bit-identical to the 3-launch loop and the
-// oracle's device-order mode follows them unchanged.
+// hundreds of workgroups of a mid-size LP (100k x 100k / 1M nonzeros: 490), where the sweep costs 4.8 us per barrier.
+// Work blocks, lane assignments and reduction trees are EXACTLY those of k_spmv / k_decide_primal (pdlp_kernels.hip),
+// majors longer than a work block ride along as the segment tasks of longBlock (smallLongBlock, round 4), so iterates
+// and decisions are bit-identical to the 3-launch loop and the oracle's device-order mode follows them unchanged.
+//   Every launch starts with a ROLL CALL (pdlp_devfn.hpp rollCall): a plain launch promises no co-residency, and on a
+// shared device a workgroup may not get its CU — the launch then changes nothing, reports commError = 3, and the solver
+// goes on with plain launches (Solver::syncState).
 //   Visibility inside a launch: per-CU L1s are never refreshed by other CUs' stores and the eight XCD L2s are not
 // coherent with each other, so EVERY access to a vector that changes during the launch (iterates, sums, partials)
 // is an agent-scope relaxed atomic (global_load/store sc1: write-through, L1-bypassing); a workgroup's stores have
 // landed (s_waitcnt vmcnt(0) in every wave, then the block barrier) before its arrival word is written.  Matrix,
 // plans, costs, bounds and right-hand sides never change: ordinary loads.
-//   (Measured alternative for the gathers: ordinary cached loads behind an agent-scope acquire — buffer_inv sc1 — after
-// every barrier.  The invalidate empties the XCD's L2 for EVERYTHING, three times per trial: phase A 5.8 -> 8.9 us,
-// the decision 3.3 -> 6.2 us at 100k x 100k.  The per-access agent-scope loads stay.)
+//   (Measured alternative for the gathers, round 3: ordinary cached loads behind an agent-scope acquire — buffer_inv sc1
+// in every wave — after every barrier: phase A 5.8 -> 8.9 us, the decision 3.3 -> 6.2 us at 100k x 100k.  Round 4's
+// tools/barrier_bench.hip prices the instruction itself: +1.5 us per barrier when ONE wave of a workgroup issues it,
+// +28 us when all sixteen do.  The per-access agent-scope loads stay.)
 //   XCD-LOCAL mode (the default): only every eighth workgroup of the launch works — under the dispatch order observed
 // on this part those share ONE XCD, i.e. one coherent L2 — and then ordinary stores (the L1 is write-through) with
 // non-temporal loads (served by the L2, never by a stale L1 line) are coherent without a trip to memory: a dependent
