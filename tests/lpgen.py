@@ -248,3 +248,28 @@ def dense_column_lp(seed=1, periods=512, rows_per=1024, cols_per=896, dense_cols
     np.add.at(c, cols, vals * y0[rows])
     return L.HighsLp(n, m, -c, cl, cu, rl, ru, a_start.astype(np.int32), rows.astype(np.int32), vals, -1, -7.5,
                      f"staircase{seed}").normalise()
+
+
+def bench_qp_at_scale(n, banded, seed=1):
+    """bench.py's QP configurations (`--config qp`: diagonal Q ~ U(0,1); `--config qpn`: tridiagonal, diagonally dominant
+    PSD Q) built by the SAME generators at a size the reference's active-set QP solver can still take (at n = 400 it needs
+    181 000 iterations and misses the optimum in the fourth digit; n = 1000 does not finish in 50 minutes): the library's seeded synthetic LP with 8 nonzeros per row plus the
+    Hessian of bench.build_workload."""
+    from highs_amd import solver
+    sp_ = solver.SyntheticProblem(n, n, 8 * n, seed)
+    lp = sp_.to_lp()
+    sp_.close()
+    rng = np.random.default_rng(1)
+    if banded:
+        off = rng.uniform(-0.5, 0.5, n - 1)
+        diag = np.abs(np.concatenate([off, [0.0]])) + np.abs(np.concatenate([[0.0], off])) + rng.uniform(0.0, 1.0, n)
+        st = np.zeros(n + 1, np.int32)
+        st[1:] = np.cumsum(np.concatenate([np.full(n - 1, 2), [1]]))
+        qi = np.empty(2 * n - 1, np.int32)
+        qv = np.empty(2 * n - 1)
+        qi[0::2], qv[0::2] = np.arange(n), diag
+        qi[1::2], qv[1::2] = np.arange(1, n), off
+        lp.hessian = (st, qi, qv)
+    else:
+        lp.hessian = (np.arange(n + 1, dtype=np.int32), np.arange(n, dtype=np.int32), rng.uniform(0.0, 1.0, n))
+    return lp

@@ -114,6 +114,25 @@ def test_bench_qp_config_converges_to_a_self_consistent_kkt_point():
     assert np.all(x >= lp.col_lower - 1e-9) and np.all(x <= lp.col_upper + 1e-9)
 
 
+BENCH_SCALE = json.load(open(os.path.join(GOLD, "reference_qp_bench_scale.json")))
+
+
+@pytest.mark.parametrize("key", sorted(BENCH_SCALE))
+def test_bench_qp_generators_at_a_scale_the_reference_solves(key):
+    """bench.py --config qp / qpn at 500k x 500k have no reference to compare with (the reference has no PDLP for QPs and
+    its active-set solver does not finish n = 1000 of this generator in 50 minutes).  The SAME generators at n = 100 ... 200
+    (tests/lpgen.py::bench_qp_at_scale) are solved by the reference's QP solver through its own C API
+    (tests/golden/make_golden_qp_bench_scale.py): the GPU path must reach those objectives to 1e-6 relative — diagonal Q and
+    the tridiagonal PSD Hessian (third SpMV per trial) alike."""
+    from lpgen import bench_qp_at_scale
+    g = BENCH_SCALE[key]
+    lp = bench_qp_at_scale(g["n"], g["banded"])
+    out = solver.solveLpCupdlp(lp, kkt_tolerance=1e-8, pdlp_iteration_limit=2000000)
+    assert out.model_status == solver.kOptimal
+    obj = lp.objective_value(out.solution.col_value)
+    assert abs(obj - g["objective_value"]) <= 1e-6 * (1 + abs(g["objective_value"])), (obj, g["objective_value"])
+
+
 def test_synthetic_qp_iterates_and_improves():
     """BASELINE config 5 in small: random sparse A + random PSD diagonal Q.  The fused QP kernels keep the
     per-iteration invariants (bounds, ax == A x, aty == A' y) and converge."""
