@@ -16,6 +16,9 @@ namespace pdlp {
 namespace {
 constexpr int kCheckInterval = 40;  // PDHG_CHECK_INTERVAL, pdhg.cc:32
 constexpr int kStatSlots = 8;       // rows of the partial-sum table
+// statOut_/hostStats_ slots of one block's ONE download (doSolve): [fpe 3 | check 6 | fpe after the block's first step 3]
+constexpr int kSlotFpe = 0, kSlotCheck = 3, kSlotFpe0 = kSlotCheck + kHRowStats + kHColStats, kStatOut = 16;
+static_assert(kSlotFpe0 + 3 <= kStatOut, "stat slots");
 }  // namespace
 
 double HalpernSolver::elapsed() const {
@@ -139,10 +142,11 @@ void HalpernSolver::construct(const pdlp_problem_t& P, const void* id128) {
   stride_ = std::max(vecBlocks(std::max(n, 1)), vecBlocks(std::max(m, 1)));
   (void)m;
   part_.alloc((size_t)kStatSlots * stride_);
-  statOut_.alloc(kStatSlots);
+  statOut_.alloc(kStatOut);
+  statOut_.zero(stream_);
   dState_.alloc(1);
   PDLP_HIP(hipHostMalloc((void**)&hostState_, sizeof(HalpernState), hipHostMallocDefault));
-  PDLP_HIP(hipHostMalloc((void**)&hostStats_, sizeof(double) * kStatSlots, hipHostMallocDefault));
+  PDLP_HIP(hipHostMalloc((void**)&hostStats_, sizeof(double) * kStatOut, hipHostMallocDefault));
   memset(hostState_, 0, sizeof(HalpernState));
   PDLP_HIP(hipStreamSynchronize(stream_));
   F_.csc = Compressed(); F_.csr = Compressed(); F_.cscSorted = Compressed();
@@ -344,10 +348,7 @@ void HalpernSolver::runBlock(bool fpeAfterFirst) {
   pushState();
   enqueueStep(true, 1);
   slackValid_ = true;
-  if (fpeAfterFirst) {
-    fpe_ = fixedPointError();
-    initialFpe_ = fpe_;
-  }
+  if (fpeAfterFirst) enqueueFpe(kSlotFpe0);  // read with the block's other statistics (fetchStats)
   if (profile_ && !sharded_) {
     for (int i = 2; i <= kCheckInterval - 1; ++i) enqueueStep(false, i);
     enqueueStep(true, kCheckInterval);
@@ -369,8 +370,8 @@ void HalpernSolver::runBlock(bool fpeAfterFirst) {
   }
 }
 
-// computeFixedPointError, pdhg.cc:709-739
-double HalpernSolver::fixedPointError() {
+// computeFixedPointError, pdhg.cc:709-739: the three sums into statOut_[slot..slot+2]
+void HalpernSolver::enqueueFpe(int slot) {
   const int32_t m = mLoc_;
   const int32_t nbM = vecBlocks(std::max(m, 1)), nbN = vecBlocks(std::max(nLoc_, 1));
   double* part = part_.get();
@@ -378,26 +379,35 @@ double HalpernSolver::fixedPointError() {
   spmvAt(tmpM_.get(), tmpN_.get());
   launchHalpernFpeCols(xn_.get() + c0_, rx_.get() + c0_, tmpN_.get() + c0_, nLoc_, part + stride_,
                        part + 2 * (size_t)stride_, nbN, stream_);
-  launchFinalReduce(part, stride_, nbM, 1, statOut_.get(), stream_);
-  launchFinalReduce(part + stride_, stride_, nbN, 2, statOut_.get() + 1, stream_);
-  if (sharded_) sumOverRanks(statOut_.get(), 3);
-  PDLP_HIP(hipMemcpyAsync(hostStats_, statOut_.get(), sizeof(double) * 3, hipMemcpyDeviceToHost, stream_));
-  PDLP_HIP(hipStreamSynchronize(stream_));
-  if (mesh_) mesh_->checkError(stream_);
-  const double dn = hostStats_[0], pn = hostStats_[1], cross = hostStats_[2];
+  launchFinalReduce(part, stride_, nbM, 1, statOut_.get() + slot, stream_);
+  launchFinalReduce(part + stride_, stride_, nbN, 2, statOut_.get() + slot + 1, stream_);
+}
+
+double HalpernSolver::fpeFrom(const double* h) const {
+  const double dn = h[0], pn = h[1], cross = h[2];
   const double movement = pn * omega_ + dn / omega_;
   const double interaction = 2.0 * eta_ * cross;
   return std::sqrt(std::max(0.0, movement + interaction));
 }
 
-// runConvergenceCheck's "current" leg (pdhg.cc:820-833) + checkConvergence (:1474-1527).
+// The first `count` statistics slots: summed over the ranks, brought to the host, ONE stream synchronisation.
+void HalpernSolver::fetchStats(int count) {
+  if (sharded_) sumOverRanks(statOut_.get(), count);
+  PDLP_HIP(hipMemcpyAsync(hostStats_, statOut_.get(), sizeof(double) * count, hipMemcpyDeviceToHost, stream_));
+  PDLP_HIP(hipStreamSynchronize(stream_));
+  PDLP_HIP(hipGetLastError());  // a failed kernel launch since the last check surfaces here
+  if (mesh_) mesh_->checkError(stream_);
+}
+
+// runConvergenceCheck's "current" leg (pdhg.cc:820-833): A x, A'y and the six sums into statOut_[kSlotCheck..].
 // x: full-length buffer whose own column slice is valid (all of it on one GPU); y: local rows.
-bool HalpernSolver::check(double* x, const double* y, bool cachedSlack, Res& r) {
+void HalpernSolver::enqueueCheck(double* x, const double* y, bool cachedSlack) {
   const int32_t m = mLoc_;
   const int32_t nbM = vecBlocks(std::max(m, 1)), nbN = vecBlocks(std::max(nLoc_, 1));
   const int sc = F_.scaled ? 1 : 0;
   const size_t co = (size_t)c0_;
   double* part = part_.get();
+  double* out = statOut_.get() + kSlotCheck;
   if (sharded_) mesh_->allGather(x, false, stream_);  // A x needs every column slice
   launchSpmvPlain(dA_.view(), x, tmpM_.get(), stream_);
   spmvAt(y, tmpN_.get());
@@ -405,20 +415,16 @@ bool HalpernSolver::check(double* x, const double* y, bool cachedSlack, Res& r) 
   launchHalpernColStats(tmpN_.get() + co, x + co, cost_.get() + co, lower_.get() + co, upper_.get() + co,
                         colScale_.get() + co, cachedSlack ? slack_.get() + co : nullptr, nLoc_, sc, sp_.get() + co,
                         sn_.get() + co, part + (size_t)kHRowStats * stride_, stride_, nbN, stream_);
-  launchFinalReduce(part, stride_, nbM, kHRowStats, statOut_.get(), stream_);
-  launchFinalReduce(part + (size_t)kHRowStats * stride_, stride_, nbN, kHColStats, statOut_.get() + kHRowStats, stream_);
-  if (sharded_) sumOverRanks(statOut_.get(), kHRowStats + kHColStats);
-  PDLP_HIP(hipMemcpyAsync(hostStats_, statOut_.get(), sizeof(double) * (kHRowStats + kHColStats), hipMemcpyDeviceToHost,
-                          stream_));
-  PDLP_HIP(hipStreamSynchronize(stream_));
-  PDLP_HIP(hipGetLastError());  // a failed kernel launch since the last check surfaces here
-  if (mesh_) {
-    mesh_->checkError(stream_);
-    mesh_->verifyReplicated(rx_.get(), F_.n, stream_);  // the reflected x is the vector every rank holds in full
-  }
+  launchFinalReduce(part, stride_, nbM, kHRowStats, out, stream_);
+  launchFinalReduce(part + (size_t)kHRowStats * stride_, stride_, nbN, kHColStats, out + kHRowStats, stream_);
+}
+
+// checkConvergence (pdhg.cc:1474-1527) on the fetched sums
+bool HalpernSolver::evalCheck(Res& r) {
+  if (mesh_) mesh_->verifyReplicated(rx_.get(), F_.n, stream_);  // the reflected x is the vector every rank holds in full
   ++nChecks_;
-  const double* rs = hostStats_;
-  const double* cs = hostStats_ + kHRowStats;
+  const double* rs = hostStats_ + kSlotCheck;
+  const double* cs = rs + kHRowStats;
   r.pFeas = std::sqrt(rs[0]);
   r.dFeas = std::sqrt(cs[0]);
   r.pObj = F_.offset + cs[1];
@@ -499,7 +505,9 @@ void HalpernSolver::doSolve(bool terminate, int64_t iterTarget) {
   };
   if (iters_ == 0 && terminate) {  // initial convergence check, pdhg.cc:563-570
     Res r;
-    if (check(xc_.get(), yc_.get(), false, r)) {
+    enqueueCheck(xc_.get(), yc_.get(), false);
+    fetchStats(kSlotFpe0);
+    if (evalCheck(r)) {
       keepOutput(xc_.get(), yc_.get());
       res_ = r;
       termStatus_ = 0;
@@ -521,13 +529,20 @@ void HalpernSolver::doSolve(bool terminate, int64_t iterTarget) {
       }
       if (up) { termStatus_ = 2; return; }
     }
-    runBlock(doRestart_);
+    // One block, its fixed-point error(s) and its convergence statistics are queued back to back and read with ONE
+    // download: the host only decides (converged / restart) between blocks.
+    const bool fpeAfterFirst = doRestart_;
+    runBlock(fpeAfterFirst);
     doRestart_ = false;
-    fpe_ = fixedPointError();
+    enqueueFpe(kSlotFpe);
+    enqueueCheck(xn_.get(), yn_.get(), slackValid_);
+    fetchStats(fpeAfterFirst ? kSlotFpe0 + 3 : kSlotFpe0);
+    if (fpeAfterFirst) initialFpe_ = fpeFrom(hostStats_ + kSlotFpe0);
+    fpe_ = fpeFrom(hostStats_ + kSlotFpe);
     halpernIter_ += kCheckInterval;
     iters_ += kCheckInterval;
     Res r;
-    const bool converged = check(xn_.get(), yn_.get(), slackValid_, r);
+    const bool converged = evalCheck(r);
     res_ = r;
     if (opt_.log_level > 1 && rank_ == 0)
       logLine(opt_, 2, "%9lld  %+15.8e  %+15.8e  %8.2e  %10.2e  %8.2e  fpe %8.2e  w %8.2e\n", (long long)iters_, r.pObj, r.dObj,
@@ -698,7 +713,9 @@ void HalpernSolver::stage(const std::string& name, double* out, int32_t cap) {
   auto put = [&](int i, double v) { if (out && i < cap) out[i] = v; };
   if (name == "block") {  // one block of 40 steps from the current state, then the fixed-point error
     runBlock(false);
-    fpe_ = fixedPointError();
+    enqueueFpe(kSlotFpe);
+    fetchStats(3);
+    fpe_ = fpeFrom(hostStats_ + kSlotFpe);
     put(0, fpe_);
   } else if (name == "steps") {  // out[0] = number of steps (1..40), the last one major: returns nothing
     const int k = out && cap > 0 ? (int)out[0] : kCheckInterval;

@@ -60,8 +60,11 @@ class HalpernSolver : public SolverBase {
   void pushState();
   void enqueueStep(bool major, int32_t kOff);
   void runBlock(bool fpeAfterFirst);           // steps 1..40 of one block
-  double fixedPointError();
-  bool check(double* x, const double* y, bool cachedSlack, Res& r);  // A x, A'y + checkConvergence
+  void enqueueFpe(int slot);                   // computeFixedPointError's three sums -> statOut_[slot..]
+  double fpeFrom(const double* h) const;
+  void enqueueCheck(double* x, const double* y, bool cachedSlack);  // A x, A'y + the sums of checkConvergence
+  bool evalCheck(Res& r);
+  void fetchStats(int count);                  // all queued statistics: one all-reduce, one download, one sync
   void updatePrimalWeight(const Res& r);
   void restart();
   bool restartCriteria() const;

@@ -278,13 +278,15 @@ void launchSpmvAtyFusedPrimal(const MatView& At, const IterVecs& v, const DevSta
 // 8 * grid workgroups works (one XCD, one coherent L2: no agent-scope traffic); the launch checks that placement and,
 // if it does not hold, changes nothing and sets commError = 2 in *st — the caller then goes on with another mode.
 // mode 2: all XCDs, XCD-hierarchical barrier (pdlp_devfn.hpp hierBarrier) — what hundreds of workgroups need.
-int smallTrialsGrid(const MatView& A, const MatView& At, int32_t n, int device, int* resident);
+int smallTrialsGrid(const MatView& A, const MatView& At, int32_t n, int device, int* resident, bool primalInA = false);
 // Every launch begins with a roll call of its working workgroups (pdlp_devfn.hpp rollCall): if they are not all resident
 // within timeoutMs, the launch changes nothing but commError = 3 in *st (failRollCall: a test asks for exactly that).
 // seq: number of this launch since the caller zeroed `bar` (1, 2, ...): the roll call counts cumulatively.
+// primalInA: two barriers per trial — phase A's gathers recompute x+ themselves (partDY then needs 2 * A.nPartials slots).
 void launchSmallTrials(const MatView& A, const MatView& At, const IterVecs& v, DevState* st, double* partDY, double* partDX,
                        double* partInter, unsigned long long* bar, int32_t grid, int32_t maxTrials, int mode, hipStream_t s,
-                       int32_t timeoutMs = 1000, bool failRollCall = false, bool selfTest = false, unsigned long long seq = 1);
+                       int32_t timeoutMs = 1000, bool failRollCall = false, bool selfTest = false, unsigned long long seq = 1,
+                       bool primalInA = false);
 constexpr int kSmallHierWords = 4 * 16 * 32;  // the XCD-hierarchical barrier's words (pdlp_devfn.hpp HierBar)
 // arrival words, timeout flag, XCC ids of the placement check; behind them (256-byte aligned) the hierarchical barrier's words
 // ... and, last, the words of the XCD-local mode's coherence self-test (grid test words, grid arrival words, flag, failure word)

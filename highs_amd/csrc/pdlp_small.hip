@@ -11,6 +11,14 @@
 // are separated by grid barriers instead of kernel boundaries — one arrival word per workgroup and a sweep by one wave
 // (pdlp_devfn.hpp gridBarrier) for a few dozen workgroups; per XCD first, then between the XCDs (hierBarrier) for the
 // hundreds of workgroups of a mid-size LP (100k x 100k / 1M nonzeros: 490), where the sweep costs 4.8 us per barrier.
+//   TWO barriers per trial where both operands have the small (512-entry) work blocks and no row is a segment task
+// (template parameter PINA, round 4): x+_j = clamp(x_j - tau (c_j - (A'y)_j)) costs seven operations, so phase A does not
+// wait for the owners of the columns it gathers — every lane recomputes x+ of its two entries' columns from (x, A'y) of
+// the iterate the trial starts from (fetched for both parities while the previous decision is computed; cost and bounds
+// sit in registers), with the operations of phase P in their order: the bits are the owner's.  The owner still stores
+// x+ (phase T and the next trial read it) but nobody waits for that store: P | barrier | A becomes one phase.  Measured:
+// 25fv47 12.4 -> 11.5, 80bau3b 14.2 -> 12.2 us per trial.  Mid-size blocks (eight entries per lane, five loads each,
+// scratch) measured 26.8 -> 46.9 us per trial and LPs with long rows 11.2 -> 11.8: those keep the P phase.
 // Work blocks, lane assignments and reduction trees are EXACTLY those of k_spmv / k_decide_primal (pdlp_kernels.hip),
 // majors longer than a work block ride along as the segment tasks of longBlock (smallLongBlock, round 4), so iterates
 // and decisions are bit-identical to the 3-launch loop and the oracle's device-order mode follows them unchanged.
@@ -59,7 +67,7 @@ struct SmallArgs {
   int32_t xcdA, xcdAt;
   int32_t maxTrials;
   int32_t selfTest;          // XCD-local mode, first launch of a solver: check that nt loads see another CU's store behind an L1-warm line
-  int32_t pad_;
+  int32_t primalInA;         // the primal step is recomputed by the gathers of phase A (no P phase, no barrier behind it)
   int32_t expect;            // workgroups the roll call waits for (= the working workgroups of the launch, unless a test asks for a failure)
   unsigned long long limit;  // 100 MHz ticks a roll call or barrier wait may last
   unsigned long long* prof;  // development: 100 MHz ticks per phase {P, barrier, A, barrier, T, barrier, D}, accumulated by workgroup 0
@@ -96,8 +104,19 @@ struct OwnBlock {
   int r0 = 0, r1 = 0, p0 = 0, cnt = 0, qb = 0, qe = 0, slot_ = 0;
   int32_t ci[kPer];
   double va[kPer];
+  // primal step inside phase A (small blocks, two entries per lane): cost, bounds (and the diagonal of Q) of every entry's column
+  static constexpr bool kKeepPrimal = kPer <= 2;
+  double pc[kKeepPrimal ? kPer : 1], pl[kKeepPrimal ? kPer : 1], pu[kKeepPrimal ? kPer : 1], pq[kKeepPrimal ? kPer : 1];
   double fixed = 0.0;  // rhs of the lane's first row (phase A)
   bool have = false;
+  __device__ __forceinline__ void loadPrimal(const IterVecs& v) {
+    if (kKeepPrimal) {
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) {
+        pc[k] = v.cost[ci[k]]; pl[k] = v.lower[ci[k]]; pu[k] = v.upper[ci[k]]; pq[k] = v.qdiag ? v.qdiag[ci[k]] : 0.0;
+      }
+    }
+  }
   __device__ __forceinline__ void load(const SpmvMat& M, int blk, bool dual, const double* rhs) {
     have = true;
     slot_ = M.partOffset + blk;
@@ -122,9 +141,22 @@ struct OwnBlock {
 
 // One trial's pass over the owned block (same plan, lanes and sums as k_spmv's stream path) with the epilogue of
 // phase A (DUAL) or T.  Per-thread reduction partials are added to acc0 / acc1.
-template <int CHUNK, bool DUAL, bool LOCAL>
+// The primal step of a column from (x, A'y) of the iterate the trial starts from: the operations of phase P in their order,
+// so every workgroup that needs x+_j gets the bits its owner stores (cupdlp_step.c:16-40; Q diagonal: the prox step of the QP path).
+__device__ __forceinline__ double primalFrom(double x, double ay, double tau, double c, double l, double u, bool prox, double q) {
+  double t = x;
+  t += (-tau) * c;
+  t += tau * ay;
+  if (prox) t = t / (1.0 + tau * q);
+  t = t < u ? t : u;
+  t = t > l ? t : l;
+  return t;
+}
+
+// xIn (PINA, phase A): the gathered vector's entries are handed in — x+ recomputed by the caller — instead of gathered here.
+template <int CHUNK, bool DUAL, bool LOCAL, bool PINA = false>
 __device__ __forceinline__ void smallSpmvBlock(const SmallArgs& a, const SpmvMat& M, const OwnBlock<CHUNK>& B, int cur, double sigma,
-                                               double avgW, double* prod, double& acc0, double& acc1) {
+                                               double avgW, double* prod, double& acc0, double& acc1, const double* xIn = nullptr) {
   const int tid = threadIdx.x, nxt = cur ^ 1;
   const double* in = DUAL ? a.v.x[nxt] : a.v.y[nxt];
   constexpr int kPer = CHUNK / kSpmvThreads;
@@ -140,7 +172,7 @@ __device__ __forceinline__ void smallSpmvBlock(const SmallArgs& a, const SpmvMat
   };
   double xg[kPer];
 #pragma unroll
-  for (int k = 0; k < kPer; ++k) xg[k] = ldM<LOCAL>(in + B.ci[k]);
+  for (int k = 0; k < kPer; ++k) xg[k] = DUAL && PINA ? xIn[k] : ldM<LOCAL>(in + B.ci[k]);
   Pre pre = prefetch(rr, true);
 #pragma unroll
   for (int k = 0; k < kPer; ++k) {
@@ -280,7 +312,10 @@ __device__ __forceinline__ void smallLongBlock(const SmallArgs& a, const LongMat
 }
 
 // MODE 0: agent-scope accesses, sweep barrier; 1: XCD-local; 2: agent-scope accesses, XCD-hierarchical barrier
-template <int CHUNK_A, int CHUNK_AT, int MODE>
+// PINA: no P phase — the gathers of phase A recompute x+ of their columns (primalOf), the owner of a column stores it
+// alongside; two barriers per trial instead of three.  A workgroup may then enter phase A of the next trial while another
+// still sums the (dy)^2 partials of this one: those alternate between two halves of partDY with the trial's parity.
+template <int CHUNK_A, int CHUNK_AT, int MODE, bool PINA>
 __global__ __launch_bounds__(kSpmvThreads) void k_trials_small(const SmallArgs a) {
   constexpr bool LOCAL = MODE == 1;
   constexpr int kMaxChunk = CHUNK_A > CHUNK_AT ? CHUNK_A : CHUNK_AT;
@@ -318,7 +353,10 @@ __global__ __launch_bounds__(kSpmvThreads) void k_trials_small(const SmallArgs a
   const int nTBAt = (a.LAt.nTasks + kSpmvThreads / kWave - 1) / (kSpmvThreads / kWave);
   OwnBlock<CHUNK_A> bA;
   OwnBlock<CHUNK_AT> bAt;
-  if (lb < nA) bA.load(a.A, a.xcdA ? xcdContiguousBlock(lb, nA) : lb, true, a.v.rhs);
+  if (lb < nA) {
+    bA.load(a.A, a.xcdA ? xcdContiguousBlock(lb, nA) : lb, true, a.v.rhs);
+    if (PINA) bA.loadPrimal(a.v);
+  }
   if (lb < nAt) bAt.load(a.At, a.xcdAt ? xcdContiguousBlock(lb, nAt) : lb, false, nullptr);
   if (LOCAL) {
     // the placement check: XCC ids of all workers (words behind the arrival words and the timeout flag)
@@ -416,7 +454,21 @@ __global__ __launch_bounds__(kSpmvThreads) void k_trials_small(const SmallArgs a
     pa[0] = ldM<LOCAL>(a.v.aty[0] + jc); pa[1] = ldM<LOCAL>(a.v.aty[1] + jc);
     pxs = ldM<LOCAL>(a.v.xSum + jc);
   };
+  // PINA: (x, A'y) of the columns phase A gathers, both parities — in flight across the decision like the own column's
+  constexpr int kPerA = CHUNK_A / kSpmvThreads;
+  double gx[2][PINA ? kPerA : 1], ga[2][PINA ? kPerA : 1];
+  auto prefetchGather = [&]() {
+    if (PINA && bA.have) {
+#pragma unroll
+      for (int k = 0; k < kPerA; ++k) {
+        const int j = bA.ci[k];
+        gx[0][k] = ldM<LOCAL>(a.v.x[0] + j); gx[1][k] = ldM<LOCAL>(a.v.x[1] + j);
+        ga[0][k] = ldM<LOCAL>(a.v.aty[0] + j); ga[1][k] = ldM<LOCAL>(a.v.aty[1] + j);
+      }
+    }
+  };
   prefetchPrimal();
+  prefetchGather();
   for (int trial = 0; trial < a.maxTrials; ++trial) {
     if (sh.halted) break;
     const int cur = sh.cur, nxt = cur ^ 1;
@@ -447,17 +499,24 @@ __global__ __launch_bounds__(kSpmvThreads) void k_trials_small(const SmallArgs a
       stM<LOCAL>(a.v.x[nxt] + j, t);
     }
     stamp(0);
-    meet(e0 + 1);
+    if (!PINA) meet(e0 + 1);
     stamp(1);
     // ---- A: A x+ and the dual step ----
+    double* partDY = PINA && (sh.nTrials & 1) ? a.partDY + a.nPartA : a.partDY;
     if (bA.have) {
       double acc0 = 0.0, acc1 = 0.0;
-      smallSpmvBlock<CHUNK_A, true, LOCAL>(a, a.A, bA, cur, sigma, avgW, prod, acc0, acc1);
+      double xIn[kPerA];
+      if (PINA) {
+#pragma unroll
+        for (int k = 0; k < kPerA; ++k)
+          xIn[k] = primalFrom(cur ? gx[1][k] : gx[0][k], cur ? ga[1][k] : ga[0][k], tau, bA.pc[k], bA.pl[k], bA.pu[k], a.v.qdiag != nullptr, bA.pq[k]);
+      }
+      smallSpmvBlock<CHUNK_A, true, LOCAL, PINA>(a, a.A, bA, cur, sigma, avgW, prod, acc0, acc1, xIn);
       const double t = blockSum<kSpmvThreads>(acc0, scratch[0]);
-      if (tid == 0) stM<LOCAL>(a.partDY + bA.slot_, t);
+      if (tid == 0) stM<LOCAL>(partDY + bA.slot_, t);
     }
     for (int tb = lb; tb < nTBA; tb += G) {  // long rows: segment tasks
-      smallLongBlock<true, LOCAL>(a, a.LA, tb, cur, sigma, avgW, scratch[0], a.partDY, nullptr);
+      smallLongBlock<true, LOCAL>(a, a.LA, tb, cur, sigma, avgW, scratch[0], partDY, nullptr);
       __syncthreads();
     }
     stamp(2);
@@ -479,9 +538,10 @@ __global__ __launch_bounds__(kSpmvThreads) void k_trials_small(const SmallArgs a
     meet(e0 + 3);
     stamp(5);
     prefetchPrimal();  // for the next trial's primal step: in flight while the decision is computed
+    prefetchGather();
     // ---- D: the decision, identical in every workgroup ----
     double dY2, dX2, inter;
-    trialSumsT<true>(a.partDY, a.nPartA, a.partDX, a.partInter, a.nPartAt, tscr, dY2, dX2, inter);
+    trialSumsT<true>(partDY, a.nPartA, a.partDX, a.partInter, a.nPartAt, tscr, dY2, dX2, inter);
     if (tid == 0) {
       decideUpdate<true>(&sh, dX2, dY2, inter);
       if (__hip_atomic_load(a.bar + G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { sh.commError = 1; sh.halted = 1; }
@@ -494,27 +554,33 @@ __global__ __launch_bounds__(kSpmvThreads) void k_trials_small(const SmallArgs a
 }
 
 using SmallKernel = void (*)(const SmallArgs);
-SmallKernel pick(int chunkA, int chunkAt, int mode) {
+template <bool PINA>
+SmallKernel pickT(int chunkA, int chunkAt, int mode) {
   if (chunkA == kChunkSmall && chunkAt == kChunkSmall)
-    return mode == 1 ? k_trials_small<kChunkSmall, kChunkSmall, 1> : mode == 2 ? k_trials_small<kChunkSmall, kChunkSmall, 2>
-                                                                               : k_trials_small<kChunkSmall, kChunkSmall, 0>;
-  // mid-size operands (2048-entry blocks): hundreds of workgroups, always the hierarchical barrier
-  if (mode != 2) return nullptr;
-  if (chunkA == kChunk && chunkAt == kChunk) return k_trials_small<kChunk, kChunk, 2>;
-  if (chunkA == kChunk && chunkAt == kChunkSmall) return k_trials_small<kChunk, kChunkSmall, 2>;
-  if (chunkA == kChunkSmall && chunkAt == kChunk) return k_trials_small<kChunkSmall, kChunk, 2>;
+    return mode == 1 ? k_trials_small<kChunkSmall, kChunkSmall, 1, PINA> : mode == 2 ? k_trials_small<kChunkSmall, kChunkSmall, 2, PINA>
+                                                                                     : k_trials_small<kChunkSmall, kChunkSmall, 0, PINA>;
+  // mid-size operands (2048-entry blocks): hundreds of workgroups, always the hierarchical barrier, and the P phase stays
+  // (measured with the primal step inside phase A, 100k x 100k: 26.8 -> 46.9 us per trial — eight entries per lane, five
+  // agent-scope or cached loads each, 204 bytes of scratch per lane)
+  if (mode != 2 || PINA) return nullptr;
+  if (chunkA == kChunk && chunkAt == kChunk) return k_trials_small<kChunk, kChunk, 2, false>;
+  if (chunkA == kChunk && chunkAt == kChunkSmall) return k_trials_small<kChunk, kChunkSmall, 2, false>;
+  if (chunkA == kChunkSmall && chunkAt == kChunk) return k_trials_small<kChunkSmall, kChunk, 2, false>;
   return nullptr;
 }
+SmallKernel pick(int chunkA, int chunkAt, int mode, bool pina = false) { return pina ? pickT<true>(chunkA, chunkAt, mode) : pickT<false>(chunkA, chunkAt, mode); }
 
 }  // namespace
 
 // Workgroups the persistent launch would use (0: this pair of operands does not qualify) and how many the device
 // keeps resident at once.
-int smallTrialsGrid(const MatView& A, const MatView& At, int32_t n, int device, int* residentOut) {
+int smallTrialsGrid(const MatView& A, const MatView& At, int32_t n, int device, int* residentOut, bool primalInA) {
   *residentOut = 0;
   // (long majors ride along as segment tasks; beyond kLongSlotCap of them their contributions need the k_long_groups launch)
   if (A.useSlab || At.useSlab || A.lng.contrib != nullptr || At.lng.contrib != nullptr) return 0;
-  SmallKernel k = pick(A.csr.chunk, At.csr.chunk, 2);
+  // (the long rows' segment tasks gather x+ from memory: with them the P phase stays — standmps 11.2 -> 11.8 us per trial without it)
+  if (primalInA && A.lng.nTasks > 0) return 0;
+  SmallKernel k = pick(A.csr.chunk, At.csr.chunk, 2, primalInA);  // (the variants of one chunk pair differ little; mode 2 exists for all)
   if (!k || A.csr.nBlocks <= 0 || At.csr.nBlocks <= 0) return 0;
   int perCu = 0, cus = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k, kSpmvThreads, 0) != hipSuccess) return 0;
@@ -529,7 +595,7 @@ int smallTrialsGrid(const MatView& A, const MatView& At, int32_t n, int device, 
 
 void launchSmallTrials(const MatView& A, const MatView& At, const IterVecs& v, DevState* st, double* partDY, double* partDX,
                        double* partInter, unsigned long long* bar, int32_t grid, int32_t maxTrials, int mode, hipStream_t s,
-                       int32_t timeoutMs, bool failRollCall, bool selfTest, unsigned long long seq) {
+                       int32_t timeoutMs, bool failRollCall, bool selfTest, unsigned long long seq, bool primalInA) {
   const bool xcdLocal = mode == 1;
   static_assert(kHierBarWords == kSmallHierWords, "barrier buffer layout");
   // mode 2: the hierarchical barrier's counters (and the roll-call word) start from zero in every launch; the other modes
@@ -539,6 +605,7 @@ void launchSmallTrials(const MatView& A, const MatView& At, const IterVecs& v, D
   SmallArgs a{};
   a.expect = (mode == 2 ? grid : (int32_t)(seq * (unsigned long long)grid)) + (failRollCall ? 1 : 0);
   a.selfTest = xcdLocal && selfTest ? 1 : 0;
+  a.primalInA = primalInA ? 1 : 0;
   if (a.selfTest)  // its words: the tail of the buffer
     (void)hipMemsetAsync(bar + smallBarWords(grid) - (size_t)(2 * grid + 8), 0, (size_t)(2 * grid + 8) * sizeof(unsigned long long), s);
   a.limit = (unsigned long long)(timeoutMs > 0 ? timeoutMs : 1000) * 100000ull;
@@ -560,7 +627,7 @@ void launchSmallTrials(const MatView& A, const MatView& At, const IterVecs& v, D
     return p;
   }();
   a.prof = prof;
-  hipLaunchKernelGGL(pick(A.csr.chunk, At.csr.chunk, mode), dim3(xcdLocal ? 8 * grid : grid), dim3(kSpmvThreads), 0, s, a);
+  hipLaunchKernelGGL(pick(A.csr.chunk, At.csr.chunk, mode, primalInA), dim3(xcdLocal ? 8 * grid : grid), dim3(kSpmvThreads), 0, s, a);
 }
 
 }  // namespace pdlp

@@ -266,6 +266,7 @@ DevSwitches DevSwitches::fromEnv() {
   w.hierBarrier = num("PDLP_MI355X_HIER_BARRIER", -1);
   w.deviceCheck = num("PDLP_MI355X_DEVICE_CHECK", -1);
   w.checkSmall = num("PDLP_MI355X_CHECK_SMALL", -1);
+  w.primalInA = num("PDLP_MI355X_PRIMAL_IN_A", -1);
   w.barrierTimeoutMs = num("PDLP_MI355X_BARRIER_TIMEOUT_MS", 1000);
   w.fault = num("PDLP_MI355X_FAULT", 0);
   w.exchange = str("PDLP_MI355X_EXCHANGE");
@@ -469,7 +470,17 @@ void Solver::construct(const pdlp_problem_t& P, const void* id128) {
     // Netlib-class LPs (both operands below 2^18 nonzeros, stream layout, no long majors): the whole trial batch is one
     // persistent launch with grid barriers between the phases (pdlp_small.hip); PDLP_MI355X_PERSISTENT=0 turns it off
     int resident = 0;
-    const int g = sw_.persistent == 0 || hasQoff_ ? 0 : smallTrialsGrid(dA_.view(), at, F_.n, opt_.device, &resident);
+    int g = 0;
+    if (sw_.persistent != 0 && !hasQoff_) {
+      // two barriers per trial instead of three: phase A recomputes x+ of the columns it gathers (PDLP_MI355X_PRIMAL_IN_A=0/1)
+      // — where that variant's registers still leave the whole grid resident
+      primalInA_ = sw_.primalInA != 0;
+      g = smallTrialsGrid(dA_.view(), at, F_.n, opt_.device, &resident, primalInA_);
+      if (primalInA_ && (g == 0 || g > resident)) {
+        primalInA_ = false;
+        g = smallTrialsGrid(dA_.view(), at, F_.n, opt_.device, &resident, false);
+      }
+    }
     if (g > 0 && g <= resident) {
       persistent_ = true;
       smallGrid_ = g;
@@ -626,7 +637,7 @@ void Solver::allocIterates() {
   tmpM_.zero(stream_);
 
   const int32_t nbV = std::max(vecBlocks(n), vecBlocks(std::max(mLoc_, 1)));
-  partDY_.alloc(std::max(dA_.nPartials(), 1));
+  partDY_.alloc(2 * (size_t)std::max(dA_.nPartials(), 1));  // (two halves: the persistent loop without a P phase alternates)
   partDX_.alloc(std::max(std::max(dAt_.nPartials(), nbV), 1));
   partInter_.alloc(std::max(std::max(dAt_.nPartials(), nbV), 1));
   statStride_ = nbV;
@@ -933,7 +944,7 @@ void Solver::enqueueTrial() {
   }
   if (persistent_) {
     launchSmallTrials(dA_.view(), dAt_.view(), vecs_, dst(), partDY_.get(), partDX_.get(), partInter_.get(), gridBar_.get(), smallGrid_, 1,
-                      smallMode(), stream_, sw_.barrierTimeoutMs, sw_.fault == 1 && smallLaunches_ == 0, smallLaunches_ == 0, ++smallSeq_);
+                      smallMode(), stream_, sw_.barrierTimeoutMs, sw_.fault == 1 && smallLaunches_ == 0, smallLaunches_ == 0, ++smallSeq_, primalInA_);
     ++smallLaunches_;
     return;
   }
@@ -1035,7 +1046,7 @@ void Solver::enqueueBatch(int32_t todo) {
   if (persistent_ && !profile_) {  // the whole stretch to the next check (plus spare trials for rejections) in one launch
     launchSmallTrials(dA_.view(), dAt_.view(), vecs_, dst(), partDY_.get(), partDX_.get(), partInter_.get(), gridBar_.get(),
                       smallGrid_, todo + 8, smallMode(), stream_, sw_.barrierTimeoutMs, sw_.fault == 1 && smallLaunches_ == 0,
-                      smallLaunches_ == 0, ++smallSeq_);
+                      smallLaunches_ == 0, ++smallSeq_, primalInA_);
     ++smallLaunches_;
     return;
   }
@@ -1726,6 +1737,8 @@ void Solver::stage(const std::string& name, double* out, int32_t cap) {
   } else if (name == "trial_launches") {  // kernels per trial step of the hot loop (2 = fused decision + primal step)
     const double fw = meshMode_ && mesh_->args().fusedWait ? 1.0 : 0.0;  // (all-gather consumers wait themselves: two / one launches less)
     put(0, meshMode_ ? (colblock_ ? 10.0 - 2.0 * fw : 9.0 - fw) : sharded_ ? 7.0 : persistent_ ? 0.0 : fused_ ? 2.0 : 3.0);  // 0: one persistent launch per batch
+  } else if (name == "trial_barriers") {  // grid barriers per trial of the persistent loop (0: no persistent loop)
+    put(0, !persistent_ ? 0.0 : primalInA_ ? 2.0 : 3.0);
   } else if (name == "check_launches") {  // kernels of one device-driven check iteration (1: the one-launch form of small LPs)
     put(0, !devCheck_ ? 0.0 : persistent_ && checkSmall_ ? 1.0 : 10.0);
   } else if (name == "barrier_fallbacks") {  // times a launch with grid barriers gave up and the loop went on with plain launches

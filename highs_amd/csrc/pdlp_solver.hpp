@@ -26,6 +26,7 @@ struct DevSwitches {
   int slabW = 0;          // PDLP_MI355X_SLAB_W: log2 of the slab width (development)
   int xcdMap = -1, slabPace = -1;
   int fused = -1, fusedStream = 0, persistent = -1, xcdLocal = -1, hierBarrier = -1, deviceCheck = -1, checkSmall = -1;
+  int primalInA = -1;     // PDLP_MI355X_PRIMAL_IN_A: the persistent loop without its P phase (pdlp_small.hip PINA); -1 = where measured faster
   int barrierTimeoutMs = 1000;  // PDLP_MI355X_BARRIER_TIMEOUT_MS: how long a grid barrier / roll call waits for missing workgroups
   int fault = 0;          // PDLP_MI355X_FAULT (tests): 1 = the first persistent launch expects one workgroup too many,
                           // 2 = the 12th fused trial's barrier expects one block too many (both then time out and fall back)
@@ -199,7 +200,7 @@ class Solver : public SolverBase {
   // starts with a stand-alone primal step.
   bool fused_ = false, needPrimal_ = true;
   // Small LPs: a batch of trials is ONE persistent launch (pdlp_small.hip); smallGrid_ = its workgroups
-  bool persistent_ = false, xcdLocal_ = false, hierBar_ = false;
+  bool persistent_ = false, xcdLocal_ = false, hierBar_ = false, primalInA_ = false;
   int smallMode() const { return xcdLocal_ ? 1 : hierBar_ ? 2 : 0; }
   int32_t smallGrid_ = 0;
   DeviceArray<unsigned long long> gridBar_;

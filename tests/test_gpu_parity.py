@@ -569,9 +569,11 @@ def test_slab_width_does_not_change_the_bits(monkeypatch):
 def test_trial_loop_variants_give_the_same_bits(name, iters, monkeypatch):
     """The trial loop exists as separate launches and as ONE persistent launch (pdlp_small.hip) — on one XCD, on all
     XCDs with every workgroup sweeping the arrival words, on all XCDs with the XCD-hierarchical barrier; mid-size LPs
-    (2048-entry work blocks, hundreds of workgroups) only take the last.  Work blocks, lanes and sums are the same in
-    all of them: iterates, step sizes and trial counts after a few hundred iterations (several check iterations and
-    restarts among them) must agree bit for bit."""
+    (2048-entry work blocks, hundreds of workgroups) only take the last.  Small work blocks without long rows run it
+    with TWO barriers per trial (phase A recomputes x+ of the columns it gathers: no P phase), everything else — and
+    PDLP_MI355X_PRIMAL_IN_A=0 — with three.  Work blocks, lanes and sums are the same in all of them: iterates, step
+    sizes and trial counts after a few hundred iterations (several check iterations and restarts among them) must
+    agree bit for bit."""
     sp_ = None
     if name == "synthetic":
         sp_ = solver.SyntheticProblem(40000, 35000, 400000, 9)  # above 2^18 nonzeros: ~200 work blocks of 2048 entries per operand
@@ -584,23 +586,29 @@ def test_trial_loop_variants_give_the_same_bits(name, iters, monkeypatch):
     variants = {"launches": {"PDLP_MI355X_PERSISTENT": "0"},
                 "persistent": {},
                 "all-xcds-sweep": {"PDLP_MI355X_XCD_LOCAL": "0", "PDLP_MI355X_HIER_BARRIER": "0"},
-                "all-xcds-hierarchical": {"PDLP_MI355X_XCD_LOCAL": "0", "PDLP_MI355X_HIER_BARRIER": "1"}}
+                "all-xcds-hierarchical": {"PDLP_MI355X_XCD_LOCAL": "0", "PDLP_MI355X_HIER_BARRIER": "1"},
+                "persistent-three-barriers": {"PDLP_MI355X_PRIMAL_IN_A": "0"},
+                "all-xcds-sweep-three-barriers": {"PDLP_MI355X_XCD_LOCAL": "0", "PDLP_MI355X_HIER_BARRIER": "0", "PDLP_MI355X_PRIMAL_IN_A": "0"},
+                "all-xcds-hierarchical-three-barriers": {"PDLP_MI355X_XCD_LOCAL": "0", "PDLP_MI355X_HIER_BARRIER": "1", "PDLP_MI355X_PRIMAL_IN_A": "0"}}
     if name == "staircase":  # 2048-entry blocks: only the hierarchical barrier
-        del variants["all-xcds-sweep"]
+        del variants["all-xcds-sweep"], variants["all-xcds-sweep-three-barriers"]
     out = {}
     for vname, env in variants.items():
-        for k in ("PDLP_MI355X_PERSISTENT", "PDLP_MI355X_XCD_LOCAL", "PDLP_MI355X_HIER_BARRIER"):
+        for k in ("PDLP_MI355X_PERSISTENT", "PDLP_MI355X_XCD_LOCAL", "PDLP_MI355X_HIER_BARRIER", "PDLP_MI355X_PRIMAL_IN_A"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         S = solver.DeviceSolver(**kw)
         st = S.iterate(iters)
         launches = int(S.stage("trial_launches")[0])
-        out[vname] = (S.get("x", S.n), S.get("y", S.m), S.get("steps", 8), int(st.trials), int(st.iters), launches)
+        out[vname] = (S.get("x", S.n), S.get("y", S.m), S.get("steps", 8), int(st.trials), int(st.iters), launches, int(S.stage("trial_barriers")[0]))
         S.close()
     if sp_ is not None:
         sp_.close()
     assert out["launches"][5] in (2, 3) and out["persistent"][5] == 0 and out["all-xcds-hierarchical"][5] == 0
+    # two barriers where the work blocks are small and no row is a segment task; three on request and everywhere else
+    two = name in ("afiro", "25fv47", "80bau3b", "staircase")  # (cplex1 and the stand* LPs have rows longer than a work block)
+    assert out["launches"][6] == 0 and out["persistent"][6] == (2 if two else 3) and out["persistent-three-barriers"][6] == 3, [o[6] for o in out.values()]
     ref = out["launches"]
     for vname, o in out.items():
         for a, b in zip(ref[:3], o[:3]):
