@@ -401,16 +401,17 @@ struct Pre { double a, b, c, d, e; };
 
 // Fixed-order sums of the three per-block partial arrays by 256 threads: lane t sums elements t, t+256, ...
 // (4 independent chains), then wave shuffle tree, then the 4 wave results in order.  Results valid in thread 0.
-// Shared by k_decide, k_decide_primal and the fused trial kernel, so all take identical decisions.  AGENT: the
-// partials were written by other workgroups of the SAME launch (agent-scope loads); threads >= 256 of a larger
+// Shared by k_decide, k_decide_primal and the fused trial kernel, so all take identical decisions.  AGENT = 1: the
+// partials were written by other workgroups of the SAME launch (agent-scope loads); 2: the same inside ONE XCD (the
+// persistent loop's XCD-local mode: non-temporal loads, served by the shared L2); threads >= 256 of a larger
 // block only take part in the barrier.
-template <bool AGENT>
+template <int AGENT>
 __device__ __forceinline__ void trialSumsT(const double* __restrict__ partDY, int nDY, const double* __restrict__ partDX,
                                            const double* __restrict__ partInter, int nDX, double (*scratch)[kVecThreads / kWave],
                                            double& dY2, double& dX2, double& inter, const double* __restrict__ partQ = nullptr,
                                            int nQ = 0, double* qint = nullptr) {
   const int tid = threadIdx.x;
-  auto ld = [&](const double* q) { return AGENT ? ldAgent(q) : *q; };
+  auto ld = [&](const double* q) { return AGENT == 2 ? ldStream(q) : AGENT == 1 ? ldAgent(q) : *q; };
   auto laneSum = [&](const double* __restrict__ p, int count) {
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int i = tid;
@@ -422,10 +423,23 @@ __device__ __forceinline__ void trialSumsT(const double* __restrict__ partDY, in
     return (s0 + s1) + (s2 + s3);
   };
   if (tid < kVecThreads) {
-    double vY = partDY ? laneSum(partDY, nDY) : 0.0;
-    double vX = laneSum(partDX, nDX);
-    double vI = laneSum(partInter, nDX);
-    double vQ = partQ ? laneSum(partQ, nQ) : 0.0;  // (QP with off-diagonal Hessian entries: dx . N dx)
+    double vY, vX, vI, vQ;
+    if (nDY <= kVecThreads && nDX <= kVecThreads && nQ <= kVecThreads) {
+      // at most one partial per lane (up to 256 work blocks per operand — the 1M x 1M slab launches and every Netlib-class
+      // LP): the loads of all arrays leave together, ONE memory round trip instead of one per array; the additions are
+      // those of laneSum for a single element
+      const double aY = partDY && tid < nDY ? ld(partDY + tid) : 0.0;
+      const double aX = tid < nDX ? ld(partDX + tid) : 0.0;
+      const double aI = tid < nDX ? ld(partInter + tid) : 0.0;
+      const double aQ = partQ && tid < nQ ? ld(partQ + tid) : 0.0;
+      auto one = [](double a, bool have) { double s0 = 0.0; if (have) s0 += a; return (s0 + 0.0) + (0.0 + 0.0); };
+      vY = one(aY, partDY && tid < nDY); vX = one(aX, tid < nDX); vI = one(aI, tid < nDX); vQ = one(aQ, partQ && tid < nQ);
+    } else {
+      vY = partDY ? laneSum(partDY, nDY) : 0.0;
+      vX = laneSum(partDX, nDX);
+      vI = laneSum(partInter, nDX);
+      vQ = partQ ? laneSum(partQ, nQ) : 0.0;  // (QP with off-diagonal Hessian entries: dx . N dx)
+    }
     vY = waveSum(vY); vX = waveSum(vX); vI = waveSum(vI);
     if (partQ) vQ = waveSum(vQ);
     const int lane = tid & (kWave - 1), w = tid / kWave;
@@ -444,7 +458,7 @@ __device__ __forceinline__ void trialSums(const double* __restrict__ partDY, int
                                           const double* __restrict__ partInter, int nDX, double (*scratch)[kVecThreads / kWave],
                                           double& dY2, double& dX2, double& inter, const double* __restrict__ partQ = nullptr,
                                           int nQ = 0, double* qint = nullptr) {
-  trialSumsT<false>(partDY, nDY, partDX, partInter, nDX, scratch, dY2, dX2, inter, partQ, nQ, qint);
+  trialSumsT<0>(partDY, nDY, partDX, partInter, nDX, scratch, dY2, dX2, inter, partQ, nQ, qint);
 }
 
 // HiPDLP step, column side (pdhg.cc:975-990 and :1008-1011): s = (A'y)_j.

@@ -380,7 +380,7 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
         return;
       }
       double dY2, dX2, inter;
-      trialSumsT<true>(a.partDY, a.nDY, a.part0, a.part1, a.nDX, tscr, dY2, dX2, inter);
+      trialSumsT<1>(a.partDY, a.nDY, a.part0, a.part1, a.nDX, tscr, dY2, dX2, inter);
       if (tid == 0) {
         decideUpdate<true>(sh, dX2, dY2, inter);
         if (__hip_atomic_load(a.bar + a.A.nBlocks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) sh->commError = 1;
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
       return;
     }
     double dY2, dX2, inter;
-    trialSumsT<true>(a.partDY, a.nDY, a.part0, a.part1, a.nDX, tscr, dY2, dX2, inter);
+    trialSumsT<1>(a.partDY, a.nDY, a.part0, a.part1, a.nDX, tscr, dY2, dX2, inter);
     if (tid == 0) {
       decideUpdate<true>(sh, dX2, dY2, inter);
       if (__hip_atomic_load(a.bar + a.S.nBlocks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) sh->commError = 1;

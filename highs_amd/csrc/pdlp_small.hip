@@ -540,11 +540,13 @@ __global__ __launch_bounds__(kSpmvThreads) void k_trials_small(const SmallArgs a
     prefetchPrimal();  // for the next trial's primal step: in flight while the decision is computed
     prefetchGather();
     // ---- D: the decision, identical in every workgroup ----
+    // (the timeout flag of the barriers: fetched next to the partials, looked at behind the decision)
+    const unsigned long long timedOut = tid == 0 ? __hip_atomic_load(a.bar + G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
     double dY2, dX2, inter;
-    trialSumsT<true>(partDY, a.nPartA, a.partDX, a.partInter, a.nPartAt, tscr, dY2, dX2, inter);
+    trialSumsT<LOCAL ? 2 : 1>(partDY, a.nPartA, a.partDX, a.partInter, a.nPartAt, tscr, dY2, dX2, inter);
     if (tid == 0) {
       decideUpdate<true>(&sh, dX2, dY2, inter);
-      if (__hip_atomic_load(a.bar + G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { sh.commError = 1; sh.halted = 1; }
+      if (timedOut) { sh.commError = 1; sh.halted = 1; }
     }
     __syncthreads();
     stamp(6);
