@@ -405,7 +405,9 @@ struct Pre { double a, b, c, d, e; };
 // partials were written by other workgroups of the SAME launch (agent-scope loads); 2: the same inside ONE XCD (the
 // persistent loop's XCD-local mode: non-temporal loads, served by the shared L2); threads >= 256 of a larger
 // block only take part in the barrier.
-template <int AGENT>
+// WIDE (the persistent loop of mid-size LPs, up to 1024 partials per array): up to four partials per lane and array,
+// again fetched together; the additions are laneSum's for that count.
+template <int AGENT, bool WIDE = false>
 __device__ __forceinline__ void trialSumsT(const double* __restrict__ partDY, int nDY, const double* __restrict__ partDX,
                                            const double* __restrict__ partInter, int nDX, double (*scratch)[kVecThreads / kWave],
                                            double& dY2, double& dX2, double& inter, const double* __restrict__ partQ = nullptr,
@@ -434,6 +436,30 @@ __device__ __forceinline__ void trialSumsT(const double* __restrict__ partDY, in
       const double aQ = partQ && tid < nQ ? ld(partQ + tid) : 0.0;
       auto one = [](double a, bool have) { double s0 = 0.0; if (have) s0 += a; return (s0 + 0.0) + (0.0 + 0.0); };
       vY = one(aY, partDY && tid < nDY); vX = one(aX, tid < nDX); vI = one(aI, tid < nDX); vQ = one(aQ, partQ && tid < nQ);
+    } else if (WIDE && !partQ && nDY <= 4 * kVecThreads && nDX <= 4 * kVecThreads) {
+      double eY[4], eX[4], eI[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = tid + k * kVecThreads;
+        eY[k] = partDY && i < nDY ? ld(partDY + i) : 0.0;
+        eX[k] = i < nDX ? ld(partDX + i) : 0.0;
+        eI[k] = i < nDX ? ld(partInter + i) : 0.0;
+      }
+      auto four = [&](const double* e, int count) {  // laneSum for count <= 1024: one full round of four chains, or a tail on chain 0
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        if (tid + 3 * kVecThreads < count) {
+          s0 += e[0]; s1 += e[1]; s2 += e[2]; s3 += e[3];
+        } else {
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            if (tid + k * kVecThreads < count) s0 += e[k];
+        }
+        return (s0 + s1) + (s2 + s3);
+      };
+      vY = partDY ? four(eY, nDY) : 0.0;
+      vX = four(eX, nDX);
+      vI = four(eI, nDX);
+      vQ = 0.0;
     } else {
       vY = partDY ? laneSum(partDY, nDY) : 0.0;
       vX = laneSum(partDX, nDX);

@@ -543,7 +543,7 @@ __global__ __launch_bounds__(kSpmvThreads) void k_trials_small(const SmallArgs a
     // (the timeout flag of the barriers: fetched next to the partials, looked at behind the decision)
     const unsigned long long timedOut = tid == 0 ? __hip_atomic_load(a.bar + G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
     double dY2, dX2, inter;
-    trialSumsT<LOCAL ? 2 : 1>(partDY, a.nPartA, a.partDX, a.partInter, a.nPartAt, tscr, dY2, dX2, inter);
+    trialSumsT<LOCAL ? 2 : 1, (CHUNK_A > kChunkSmall || CHUNK_AT > kChunkSmall)>(partDY, a.nPartA, a.partDX, a.partInter, a.nPartAt, tscr, dY2, dX2, inter);
     if (tid == 0) {
       decideUpdate<true>(&sh, dX2, dY2, inter);
       if (timedOut) { sh.commError = 1; sh.halted = 1; }
