@@ -507,59 +507,4 @@ void buildSlabLayout(const Compressed& csr, int32_t nMajor, int32_t nMinor, int3
   }
 }
 
-// Sliced-ELL plan from the major lengths (pdlp_host.hpp SellPlan).
-void planSell(const int32_t* beg, int32_t nMajor, int32_t Rw, int32_t longLimit, SellPlan& out) {
-  out = SellPlan();
-  out.rowsPerWave = Rw;
-  const int32_t R = Rw * kSlabWavesPerBlock;
-  const int32_t nBlocks = (nMajor + R - 1) / R;
-  out.nWaves = nBlocks * kSlabWavesPerBlock;
-  out.waveSlice.assign((size_t)out.nWaves + 1, 0);
-  out.sliceStep.push_back(0);
-  std::vector<std::pair<int32_t, int32_t>> rows;  // (length, local major)
-  for (int32_t w = 0; w < out.nWaves; ++w) {
-    out.waveSlice[w] = (int32_t)out.sliceStep.size() - 1;
-    rows.clear();
-    const int64_t r0 = (int64_t)w * Rw;
-    for (int32_t lr = 0; lr < Rw && r0 + lr < nMajor; ++lr) {
-      const int32_t len = beg[r0 + lr + 1] - beg[r0 + lr];
-      if (len > 0 && len <= longLimit) rows.emplace_back(len, lr);
-    }
-    std::stable_sort(rows.begin(), rows.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
-    for (size_t q = 0; q < rows.size(); q += 64) {
-      const size_t e = std::min(rows.size(), q + 64);
-      for (size_t k = q; k < q + 64; ++k) {
-        if (k < e) {
-          out.rowCnt.push_back((uint32_t)rows[k].second | ((uint32_t)rows[k].first << 16));
-          out.slotMajor.push_back((int32_t)(r0 + rows[k].second));
-        } else {
-          out.rowCnt.push_back(0u);
-          out.slotMajor.push_back(-1);
-        }
-      }
-      out.nSteps += rows[q].first;
-      if (out.nSteps * 64 >= (int64_t)0x7fffffff) throw std::runtime_error("sliced-ELL layout: too many entries");
-      out.sliceStep.push_back((int32_t)out.nSteps);
-    }
-  }
-  out.waveSlice[out.nWaves] = (int32_t)out.sliceStep.size() - 1;
-}
-
-void fillSell(const Compressed& csr, const SellPlan& plan, std::vector<uint32_t>& ent, std::vector<double>& val) {
-  ent.assign((size_t)plan.nSteps * 64 + 64, 0u);  // (one pad step: a wave without slices still reads its first step)
-  val.assign((size_t)plan.nSteps * 64 + 64, 0.0);
-  const size_t nSlices = plan.sliceStep.size() - 1;
-  for (size_t j = 0; j < nSlices; ++j)
-    for (int l = 0; l < 64; ++l) {
-      const int32_t r = plan.slotMajor[j * 64 + l];
-      if (r < 0) continue;
-      const int32_t p0 = csr.beg[r], cnt = csr.beg[r + 1] - p0;
-      for (int32_t k = 0; k < cnt; ++k) {
-        const size_t q = ((size_t)plan.sliceStep[j] + k) * 64 + l;
-        ent[q] = (uint32_t)csr.idx[p0 + k];
-        val[q] = csr.val[p0 + k];
-      }
-    }
-}
-
 }  // namespace pdlp

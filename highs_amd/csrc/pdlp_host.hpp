@@ -140,24 +140,4 @@ int32_t slabRowsPerWave(int32_t nMajor, int32_t nMinor);
 void buildSlabLayout(const Compressed& csr, int32_t nMajor, int32_t nMinor, int32_t longLimit, int32_t slabWidthLog2,
                      SlabLayout& out);
 
-// "One lane per major" layout (sliced ELL, round 4) for operands whose short majors are long enough to be worth a lane
-// each — rows of structured LPs (network blocks, staircases: ~16 entries).  Same blocks and waves as the slab layout
-// (rowsPerWave consecutive majors per wave, 16 waves per block); inside a wave the majors with short entries are sorted
-// by length (descending, stable) and cut into SLICES of 64: step k of a slice holds the k-th entry of each of its 64
-// majors, lane after lane, so a wave reads 64 entries per step fully coalesced and every lane adds ITS major left to
-// right in a register — ascending minors, the reference's order, bit-identical to every other layout — with no run
-// detection and no LDS traffic per entry.  Built from the major lengths alone (planSell); the entries are then placed by
-// fillSell (host) or k_sell_fill (device).  Padding (lanes whose major is shorter than the slice's first) is never
-// added: the lane is predicated off.
-struct SellPlan {
-  int32_t rowsPerWave = 0, nWaves = 0;
-  int64_t nSteps = 0;                 // 64-entry steps of all slices (= entries incl. padding / 64)
-  std::vector<int32_t> waveSlice;     // [nWaves+1] slice range of each wave
-  std::vector<int32_t> sliceStep;     // [nSlices+1] first step of each slice (its length = the difference)
-  std::vector<uint32_t> rowCnt;       // [nSlices*64] local major within the wave | entries << 16 (0 entries: idle lane)
-  std::vector<int32_t> slotMajor;     // [nSlices*64] global major of the lane, -1: idle
-};
-void planSell(const int32_t* beg, int32_t nMajor, int32_t rowsPerWave, int32_t longLimit, SellPlan& out);
-void fillSell(const Compressed& csr, const SellPlan& plan, std::vector<uint32_t>& ent, std::vector<double>& val);
-
 }  // namespace pdlp

@@ -547,131 +547,63 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
       }
     }
   };
-  if (a.S.sell) {
-    // ---- one lane per major (sliced ELL, pdlp_host.hpp SellPlan) ----
-    // The wave walks its slices step by step: 64 entries per step, lane l holding the k-th entry of ITS major of the
-    // slice; every lane adds its major left to right in a register (ascending minors: the reference's order) and stores
-    // the sum into the major's LDS accumulator when the slice ends.  Same register pipeline as the slab stream below —
-    // entry / value loads NB steps ahead, the gather GD ahead — running across the slice boundaries; the NEXT slice's
-    // lane table and length are fetched one slice ahead.  No block barrier: the waves run free.
-    const int j0 = ldUniform(a.S.sellWaveSlice + gw), j1 = ldUniform(a.S.sellWaveSlice + gw + 1);
-    const int T0 = ldUniform(a.S.sellSliceStep + j0), nT = ldUniform(a.S.sellSliceStep + j1) - T0;
-    const uint32_t* __restrict__ ent = a.S.sellEnt + (size_t)T0 * kWave;
-    const double* __restrict__ val = a.S.sellVal + (size_t)T0 * kWave;
-    const int lastT = nT > 0 ? nT - 1 : 0;  // (a wave without slices reads the pad step)
-    auto stepIndex = [&](int g) { return (g < lastT ? g : lastT) * kWave + lane; };
-    auto gather = [&](uint32_t e) -> double {
-      return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(in) + ((uint64_t)e << 3));
-    };
-    auto sliceEnd = [&](int j) { return ldUniform(a.S.sellSliceStep + j + 1) - T0; };
-    int sl = j0;
-    int jn = j0 + 1 < j1 ? j0 + 1 : j0;
-    uint32_t rc = nT > 0 ? a.S.sellRowCnt[(size_t)j0 * kWave + lane] : 0u;
-    uint32_t rcN = nT > 0 ? a.S.sellRowCnt[(size_t)jn * kWave + lane] : 0u;
-    int sEnd = nT > 0 ? sliceEnd(j0) : 0, sEndN = nT > 0 ? sliceEnd(jn) : 0;
-    double sum = 0.0;
-    int k = 0;
-    uint32_t E[NB];
-    double V[NB], X[NB];
+  // ---- the stream ----
+  // Register pipeline over NB slots, unrolled NB times so that a slot is a fixed register (no moves of
+  // values still in flight, which would drain vmcnt): step g gathers for group g+1, then consumes
+  // group g (slot g % NB) and refills that slot with group g+NB.  All loads are unconditional; past the
+  // wave's last entry they re-read that entry (same cache line), and groups past nG contribute nothing.
+  const uint32_t* __restrict__ ent = a.S.ent + e0;
+  const double* __restrict__ val = a.S.val + e0;
+  const int cnt = e1 - e0;
+  const int nG = (cnt + kWave - 1) / kWave;
+  const int last = cnt > 0 ? cnt - 1 : 0;  // (an empty wave reads entry e0, which exists: ent/val carry one pad element)
+  auto entryIndex = [&](int g) { const int q = g * kWave + lane; return q < last ? q : last; };
+  auto gather = [&](uint32_t e) -> double {
+    const uint32_t off = (e & mmask) << 3;  // byte offset: minor < 2^26
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(in) + off);
+  };
+  uint32_t E[NB];
+  double V[NB], X[NB];
+  // prologue = the steps -NB..-1 of the same schedule (same issue order as the steady state, so the
+  // compiler's vmcnt bookkeeping at the loop header does not have to assume the worst)
 #pragma unroll
-    for (int q = 0; q < NB; ++q) {
-      if (q + GD >= NB) X[(q + GD) % NB] = gather(E[(q + GD) % NB]);
-      const int ix = stepIndex(q);
-      E[q] = ent[ix];
-      V[q] = val[ix];
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    const int nR = (nT + NB - 1) / NB;
-    for (int o = 0; o < nR; ++o) {
-#pragma unroll
-      for (int u = 0; u < NB; ++u) {
-        const int g = o * NB + u;
-        X[(u + GD) % NB] = gather(E[(u + GD) % NB]);  // step g+GD
-        const double prod = V[u] * X[u];
-        {  // slot u is free: refill it with step g+NB
-          const int ix = stepIndex(g + NB);
-          E[u] = ent[ix];
-          V[u] = val[ix];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (g < nT) {  // (wave-uniform)
-          if (g == sEnd) {  // the slice is done: its sums to the accumulators, the next slice's lane table takes over
-            if (rc >> 16) wacc[rc & 0xffffu] = sum;
-            sum = 0.0;
-            k = 0;
-            ++sl;
-            rc = rcN;
-            sEnd = sEndN;
-            jn = sl + 1 < j1 ? sl + 1 : sl;
-            rcN = a.S.sellRowCnt[(size_t)jn * kWave + lane];
-            sEndN = sliceEnd(jn);
-          }
-          if (k < (int)(rc >> 16)) sum += prod;
-          ++k;
-        }
-      }
-    }
-    if (nT > 0 && (rc >> 16)) wacc[rc & 0xffffu] = sum;
-    __syncthreads();  // every wave's accumulators are final before the epilogue reads them
-  } else {
-    // ---- the stream ----
-    // Register pipeline over NB slots, unrolled NB times so that a slot is a fixed register (no moves of
-    // values still in flight, which would drain vmcnt): step g gathers for group g+1, then consumes
-    // group g (slot g % NB) and refills that slot with group g+NB.  All loads are unconditional; past the
-    // wave's last entry they re-read that entry (same cache line), and groups past nG contribute nothing.
-    const uint32_t* __restrict__ ent = a.S.ent + e0;
-    const double* __restrict__ val = a.S.val + e0;
-    const int cnt = e1 - e0;
-    const int nG = (cnt + kWave - 1) / kWave;
-    const int last = cnt > 0 ? cnt - 1 : 0;  // (an empty wave reads entry e0, which exists: ent/val carry one pad element)
-    auto entryIndex = [&](int g) { const int q = g * kWave + lane; return q < last ? q : last; };
-    auto gather = [&](uint32_t e) -> double {
-      const uint32_t off = (e & mmask) << 3;  // byte offset: minor < 2^26
-      return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(in) + off);
-    };
-    uint32_t E[NB];
-    double V[NB], X[NB];
-    // prologue = the steps -NB..-1 of the same schedule (same issue order as the steady state, so the
-    // compiler's vmcnt bookkeeping at the loop header does not have to assume the worst)
-  #pragma unroll
-    for (int k = 0; k < NB; ++k) {
-      if (k + GD >= NB) X[(k + GD) % NB] = gather(E[(k + GD) % NB]);
-      const int q = entryIndex(k);
-      E[k] = ent[q];
-      V[k] = val[q];
-      __builtin_amdgcn_sched_barrier(0);  // keep this issue order
-    }
-    // block-uniform trip count: the per-step barrier must be reached by every wave
-    int nRounds = (nG + NB - 1) / NB;
-    {
-      int* share = reinterpret_cast<int*>(scratch);
-      if (lane == 0) share[wave] = nRounds;
-      __syncthreads();
-  #pragma unroll
-      for (int w = 0; w < kWaves; ++w) nRounds = share[w] > nRounds ? share[w] : nRounds;
-      __syncthreads();
-    }
-    for (int o = 0; o < nRounds; ++o) {
-  #pragma unroll
-      for (int u = 0; u < NB; ++u) {
-        const int g = o * NB + u;
-        X[(u + GD) % NB] = gather(E[(u + GD) % NB]);  // group g+GD
-        // consume group g
-        const int nValid = cnt - g * kWave;  // lanes >= nValid hold nothing of this wave (<= 0: phantom group)
-        const uint32_t eCur = E[u];
-        const double prod = V[u] * X[u];
-        {  // slot u is free: refill it with group g+NB
-          const int q = entryIndex(g + NB);
-          E[u] = ent[q];
-          V[u] = val[q];
-        }
-        __builtin_amdgcn_sched_barrier(0);  // gather, then refill, then the LDS work: in this order
-        consumeGroup(eCur, prod, nValid);
-        if (!a.S.noPace) __syncthreads();  // pacing: the CU's waves stay on the same slab
-      }
-    }
-    if (a.S.noPace) __syncthreads();  // (free-running waves: every wave's accumulators are final before the epilogue reads them)
+  for (int k = 0; k < NB; ++k) {
+    if (k + GD >= NB) X[(k + GD) % NB] = gather(E[(k + GD) % NB]);
+    const int q = entryIndex(k);
+    E[k] = ent[q];
+    V[k] = val[q];
+    __builtin_amdgcn_sched_barrier(0);  // keep this issue order
   }
+  // block-uniform trip count: the per-step barrier must be reached by every wave
+  int nRounds = (nG + NB - 1) / NB;
+  {
+    int* share = reinterpret_cast<int*>(scratch);
+    if (lane == 0) share[wave] = nRounds;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) nRounds = share[w] > nRounds ? share[w] : nRounds;
+    __syncthreads();
+  }
+  for (int o = 0; o < nRounds; ++o) {
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int g = o * NB + u;
+      X[(u + GD) % NB] = gather(E[(u + GD) % NB]);  // group g+GD
+      // consume group g
+      const int nValid = cnt - g * kWave;  // lanes >= nValid hold nothing of this wave (<= 0: phantom group)
+      const uint32_t eCur = E[u];
+      const double prod = V[u] * X[u];
+      {  // slot u is free: refill it with group g+NB
+        const int q = entryIndex(g + NB);
+        E[u] = ent[q];
+        V[u] = val[q];
+      }
+      __builtin_amdgcn_sched_barrier(0);  // gather, then refill, then the LDS work: in this order
+      consumeGroup(eCur, prod, nValid);
+      if (!a.S.noPace) __syncthreads();  // pacing: the CU's waves stay on the same slab
+    }
+  }
+  if (a.S.noPace) __syncthreads();  // (free-running waves: every wave's accumulators are final before the epilogue reads them)
 
   const uint32_t* __restrict__ mask = a.S.longMask + (size_t)blk * (R / 32);
 #pragma unroll
@@ -1299,32 +1231,6 @@ void launchBlockSpan(const int32_t* beg, const int32_t* idx, int32_t nMajor, int
   if (nMajor <= 0) return;
   hipLaunchKernelGGL(k_block_span, dim3((nMajor + kVecThreads - 1) / kVecThreads), dim3(kVecThreads), 0, s, beg, idx, nMajor, R, longLimit,
                      lo, hi, cnt);
-}
-namespace {
-// Sliced-ELL fill (pdlp_host.hpp SellPlan): lane l of slice j copies the entries of its major to steps sliceStep[j]..., one
-// thread per lane slot.  ent / val were zeroed: the padding stays (minor 0, value 0; those lanes are predicated off anyway).
-__global__ __launch_bounds__(kVecThreads) void k_sell_fill(const int32_t* __restrict__ beg, const int32_t* __restrict__ idx,
-                                                           const double* __restrict__ val, const int32_t* __restrict__ slotMajor,
-                                                           const int32_t* __restrict__ sliceStep, long long nSlots, uint32_t* __restrict__ outEnt,
-                                                           double* __restrict__ outVal) {
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nSlots) return;
-  const int r = slotMajor[t];
-  if (r < 0) return;
-  const int l = (int)(t & (kWave - 1));
-  const long long base = (long long)sliceStep[t >> 6] * kWave + l;
-  const int p0 = beg[r], cnt = beg[r + 1] - p0;
-  for (int k = 0; k < cnt; ++k) {
-    outEnt[base + (long long)k * kWave] = (uint32_t)idx[p0 + k];
-    outVal[base + (long long)k * kWave] = val[p0 + k];
-  }
-}
-}  // namespace
-void launchSellFill(const int32_t* beg, const int32_t* idx, const double* val, const int32_t* slotMajor, const int32_t* sliceStep,
-                    int64_t nSlots, uint32_t* outEnt, double* outVal, hipStream_t s) {
-  if (nSlots <= 0) return;
-  hipLaunchKernelGGL(k_sell_fill, dim3((unsigned)((nSlots + kVecThreads - 1) / kVecThreads)), dim3(kVecThreads), 0, s, beg, idx, val, slotMajor,
-                     sliceStep, (long long)nSlots, outEnt, outVal);
 }
 void launchDot(const double* a, const double* b, int32_t len, double* partials, int32_t nBlocks, hipStream_t s) {
   hipLaunchKernelGGL(k_dot, dim3(nBlocks), dim3(kVecThreads), 0, s, a, b, len, partials);

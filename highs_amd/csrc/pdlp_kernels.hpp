@@ -157,14 +157,6 @@ struct SlabMat {
   // vector anyway runs faster free (block-angular LP of bench.py --config c: 31.8 -> 29.0 us).  Chosen per operand by
   // timing both at set-up (tuneXcdMap).
   int32_t noPace;
-  // sell != 0: the short majors are laid out one LANE per major instead (sliced ELL, pdlp_host.hpp SellPlan) — same
-  // blocks, waves and sums; the operand keeps whichever of the two layouts measured faster at set-up (tuneXcdMap)
-  int32_t sell;
-  const int32_t* sellWaveSlice;  // [16*nBlocks+1] slice range per wave
-  const int32_t* sellSliceStep;  // [nSlices+1] first 64-entry step of each slice
-  const uint32_t* sellRowCnt;    // [nSlices*64] local major | entries << 16
-  const uint32_t* sellEnt;       // [nSteps*64 + 64] minor
-  const double* sellVal;         // [nSteps*64 + 64]
 };
 // Slab width for operands whose row blocks touch few 2^14-entry stretches of the gathered vector densely (network
 // blocks, staircases): shorter runs of equal majors per 64-entry group, more lanes adding (bench.py --config c, A x:
@@ -382,8 +374,6 @@ int32_t vecBlocks(int32_t len);  // grid size used by the vector/statistics kern
 
 // ---- set-up: which slab width suits an operand ----
 // lo/hi/cnt [ceil(nMajor/R)], pre-set to INT_MAX / -1 / 0: column span and entry count of each block's short majors
-void launchSellFill(const int32_t* beg, const int32_t* idx, const double* val, const int32_t* slotMajor, const int32_t* sliceStep,
-                    int64_t nSlots, uint32_t* outEnt, double* outVal, hipStream_t s);
 void launchBlockSpan(const int32_t* beg, const int32_t* idx, int32_t nMajor, int32_t R, int32_t longLimit, int32_t* lo, int32_t* hi,
                      int32_t* cnt, hipStream_t s);
 

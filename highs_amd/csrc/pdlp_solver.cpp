@@ -99,45 +99,6 @@ bool DeviceMatrix::touchesFewTiles(const std::vector<int32_t>& lo, const std::ve
   return all > 0 && good * 5 >= all * 4;
 }
 
-// The lane-per-major layout is worth building where the short majors hold a few entries each on average (a lane per
-// major of one or two entries would idle); PDLP_MI355X_SELL=0/1 forces.
-bool DeviceMatrix::wantSell(const DevSwitches& sw, const int32_t* hostBeg, int32_t nMajor_) const {
-  if (sw.sell == 0) return false;
-  int64_t rows = 0, entries = 0;
-  for (int32_t r = 0; r < nMajor_; ++r) {
-    const int32_t len = hostBeg[r + 1] - hostBeg[r];
-    if (len > 0 && len <= kSlabLongLimit) { ++rows; entries += len; }
-  }
-  if (rows == 0) return false;
-  return sw.sell == 1 || entries >= 4 * rows;
-}
-
-void DeviceMatrix::uploadSellPlan(const SellPlan& P, hipStream_t s) {
-  sellWaveSlice.alloc(P.waveSlice.size());
-  sellSliceStep.alloc(P.sliceStep.size());
-  sellRowCnt.alloc(std::max<size_t>(P.rowCnt.size(), 1));
-  sellEnt.alloc((size_t)P.nSteps * 64 + 64);
-  sellVal.alloc((size_t)P.nSteps * 64 + 64);
-  sellEnt.zero(s);
-  sellVal.zero(s);
-  sellRowCnt.zero(s);
-  sellWaveSlice.upload(P.waveSlice.data(), P.waveSlice.size(), s);
-  sellSliceStep.upload(P.sliceStep.data(), P.sliceStep.size(), s);
-  sellRowCnt.upload(P.rowCnt.data(), P.rowCnt.size(), s);
-  haveSell = true;
-  useSell = false;
-}
-
-void DeviceMatrix::dropSell() {
-  sellWaveSlice = DeviceArray<int32_t>(); sellSliceStep = DeviceArray<int32_t>();
-  sellRowCnt = DeviceArray<uint32_t>(); sellEnt = DeviceArray<uint32_t>(); sellVal = DeviceArray<double>();
-  haveSell = useSell = false;
-}
-void DeviceMatrix::dropSlabStream() {
-  ent = DeviceArray<uint32_t>(); slabVal = DeviceArray<double>();
-  slab.ent = nullptr; slab.val = nullptr;
-}
-
 void DeviceMatrix::upload(const Compressed& cIn, int32_t nMajor_, int32_t nMinor_, const DevSwitches& sw, hipStream_t s) {
   nMajor = nMajor_;
   nnz = cIn.beg.empty() ? 0 : cIn.beg[nMajor_];
@@ -165,17 +126,6 @@ void DeviceMatrix::upload(const Compressed& cIn, int32_t nMajor_, int32_t nMinor
     slabVal.upload(L.val.data(), L.val.size(), s);
     longMask.upload(L.longMask.data(), L.longMask.size(), s);
     slab = SlabMat{wavePtr.get(), ent.get(), slabVal.get(), longMask.get(), nMajor_, L.nBlocks, L.rowsPerBlock, L.minorBits};
-    if (wantSell(sw, cIn.beg.data(), nMajor_)) {
-      SellPlan P;
-      planSell(cIn.beg.data(), nMajor_, L.rowsPerWave, kSlabLongLimit, P);
-      std::vector<uint32_t> he;
-      std::vector<double> hv;
-      fillSell(cIn, P, he, hv);
-      uploadSellPlan(P, s);
-      sellEnt.upload(he.data(), he.size(), s);
-      sellVal.upload(hv.data(), hv.size(), s);
-      PDLP_HIP(hipStreamSynchronize(s));
-    }
     c = &L.longCsr;
   }
   const int32_t nCsrMajor = useSlab ? (int32_t)L.longMap.size() : nMajor_;
@@ -210,22 +160,6 @@ void DeviceMatrix::buildFromDevice(DeviceCsrData& M, const DevSwitches& sw, hipS
       dLo.download(lo.data(), nB, s); dHi.download(hi.data(), nB, s); dCn.download(cnt.data(), nB, s);
       PDLP_HIP(hipStreamSynchronize(s));
       localM = touchesFewTiles(lo, hi, cnt);
-    }
-    {  // the lane-per-major layout next to it, from the same CSR (tuneXcdMap keeps the faster one)
-      std::vector<int32_t> hb((size_t)M.nMajor + 1);
-      M.beg.download(hb.data(), hb.size(), s);
-      PDLP_HIP(hipStreamSynchronize(s));
-      if (wantSell(sw, hb.data(), M.nMajor)) {
-        SellPlan P;
-        planSell(hb.data(), M.nMajor, R / 16, kSlabLongLimit, P);
-        uploadSellPlan(P, s);
-        DeviceArray<int32_t> dSlot;
-        dSlot.alloc(std::max<size_t>(P.slotMajor.size(), 1));
-        dSlot.upload(P.slotMajor.data(), P.slotMajor.size(), s);
-        launchSellFill(M.beg.get(), M.idx.get(), M.val.get(), dSlot.get(), sellSliceStep.get(), (int64_t)P.slotMajor.size(), sellEnt.get(),
-                       sellVal.get(), s);
-        PDLP_HIP(hipStreamSynchronize(s));
-      }
     }
     DeviceSlabLayout L;
     // (an operand whose blocks touch few 16384-entry tiles of the gathered vector densely gets slabs of that width: its
@@ -262,9 +196,6 @@ MatView DeviceMatrix::view() const {
   v.csr = SpmvMat{beg.get(), idx.get(), val.get(), blockBeg.get(), nMajor, nBlocks, slabBlocks, chunk};
   v.slab = slab;
   v.slab.noPace = noPace;
-  v.slab.sell = haveSell && useSell ? 1 : 0;
-  v.slab.sellWaveSlice = sellWaveSlice.get(); v.slab.sellSliceStep = sellSliceStep.get(); v.slab.sellRowCnt = sellRowCnt.get();
-  v.slab.sellEnt = sellEnt.get(); v.slab.sellVal = sellVal.get();
   v.lng = LongMat{idx.get(), val.get(), lTasks.get(), lSegSum.get(), lTicket.get(), longGroup > 1 ? lContrib.get() : nullptr,
                   nLong, nTasks, slabBlocks + nBlocks, longSlots, longGroup};
   v.useSlab = useSlab ? 1 : 0;
@@ -276,55 +207,35 @@ MatView DeviceMatrix::view() const {
 void tuneXcdMap(DeviceMatrix& M, const DevSwitches& sw, const double* in, double* out, hipStream_t s) {
   const bool em = sw.xcdMap >= 0;
   const bool ep = sw.slabPace >= 0;  // 1 = barrier per group (random operands), 0 = free-running waves
-  const bool el = sw.sell >= 0 || !M.haveSell;  // layout of the short majors fixed (forced, or only one was built)
   if (em) M.xcdMap = sw.xcdMap != 0;
   if (ep) M.noPace = sw.slabPace == 0;
-  if (M.haveSell && sw.sell == 1) M.useSell = true;
-  // whichever layout of the short majors is not used is freed when the choice is made
-  auto keepOneLayout = [&]() {
-    if (!M.haveSell) return;
-    if (M.useSell) M.dropSlabStream();
-    else M.dropSell();
-  };
   if (M.nnz < 200000) {  // small operands live in every L2 anyway
     if (!em) M.xcdMap = 1;
-    keepOneLayout();
     return;
   }
-  if (em && el && (ep || !M.useSlab || M.useSell)) {
-    keepOneLayout();
-    return;
-  }
+  if (em && (ep || !M.useSlab)) return;
   hipEvent_t e0, e1;
   PDLP_HIP(hipEventCreate(&e0));
   PDLP_HIP(hipEventCreate(&e1));
   float best = 0.f;
   int bestMap = M.xcdMap, bestFree = M.noPace;
-  bool bestSell = M.useSell;
   bool first = true;
-  for (int kind = (el && M.useSell ? 1 : 0); kind < (el ? (M.useSell ? 2 : 1) : 2); ++kind) {  // 0: slab stream, 1: one lane per major
-    for (int fr = 0; fr < (M.useSlab && !ep && kind == 0 ? 2 : 1); ++fr) {
-      for (int map = 0; map < (em ? 1 : 2); ++map) {
-        if (!em) M.xcdMap = map;
-        if (!ep) M.noPace = fr;
-        M.useSell = kind == 1;
-        launchSpmvPlain(M.view(), in, out, s);  // warm-up
-        PDLP_HIP(hipEventRecord(e0, s));
-        for (int r = 0; r < 3; ++r) launchSpmvPlain(M.view(), in, out, s);
-        PDLP_HIP(hipEventRecord(e1, s));
-        PDLP_HIP(hipEventSynchronize(e1));
-        float ms = 0.f;
-        PDLP_HIP(hipEventElapsedTime(&ms, e0, e1));
-        if (first || ms < 0.97f * best) {  // a change only when clearly faster
-          best = ms; bestMap = M.xcdMap; bestFree = M.noPace; bestSell = M.useSell; first = false;
-        }
-      }
+  for (int fr = 0; fr < (M.useSlab && !ep ? 2 : 1); ++fr) {
+    for (int map = 0; map < (em ? 1 : 2); ++map) {
+      if (!em) M.xcdMap = map;
+      if (!ep) M.noPace = fr;
+      launchSpmvPlain(M.view(), in, out, s);  // warm-up
+      PDLP_HIP(hipEventRecord(e0, s));
+      for (int r = 0; r < 3; ++r) launchSpmvPlain(M.view(), in, out, s);
+      PDLP_HIP(hipEventRecord(e1, s));
+      PDLP_HIP(hipEventSynchronize(e1));
+      float ms = 0.f;
+      PDLP_HIP(hipEventElapsedTime(&ms, e0, e1));
+      if (first || ms < 0.97f * best) { best = ms; bestMap = M.xcdMap; bestFree = M.noPace; first = false; }  // a change only when clearly faster
     }
   }
   M.xcdMap = bestMap;
   M.noPace = bestFree;
-  M.useSell = bestSell;
-  keepOneLayout();
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
 }
@@ -356,7 +267,6 @@ DevSwitches DevSwitches::fromEnv() {
   w.deviceCheck = num("PDLP_MI355X_DEVICE_CHECK", -1);
   w.checkSmall = num("PDLP_MI355X_CHECK_SMALL", -1);
   w.primalInA = num("PDLP_MI355X_PRIMAL_IN_A", -1);
-  w.sell = num("PDLP_MI355X_SELL", -1);
   w.barrierTimeoutMs = num("PDLP_MI355X_BARRIER_TIMEOUT_MS", 1000);
   w.fault = num("PDLP_MI355X_FAULT", 0);
   w.exchange = str("PDLP_MI355X_EXCHANGE");
@@ -1827,9 +1737,6 @@ void Solver::stage(const std::string& name, double* out, int32_t cap) {
   } else if (name == "trial_launches") {  // kernels per trial step of the hot loop (2 = fused decision + primal step)
     const double fw = meshMode_ && mesh_->args().fusedWait ? 1.0 : 0.0;  // (all-gather consumers wait themselves: two / one launches less)
     put(0, meshMode_ ? (colblock_ ? 10.0 - 2.0 * fw : 9.0 - fw) : sharded_ ? 7.0 : persistent_ ? 0.0 : fused_ ? 2.0 : 3.0);  // 0: one persistent launch per batch
-  } else if (name == "layouts") {  // of A and A': 0 = CSR stream, 1 = slab stream, 2 = one lane per major (sliced ELL); then xcdMap, noPace of each
-    auto kind = [](const DeviceMatrix& M) { return !M.useSlab ? 0.0 : M.haveSell && M.useSell ? 2.0 : 1.0; };
-    put(0, kind(dA_)); put(1, kind(dAt_)); put(2, dA_.xcdMap); put(3, dAt_.xcdMap); put(4, dA_.noPace); put(5, dAt_.noPace);
   } else if (name == "trial_barriers") {  // grid barriers per trial of the persistent loop (0: no persistent loop)
     put(0, !persistent_ ? 0.0 : primalInA_ ? 2.0 : 3.0);
   } else if (name == "check_launches") {  // kernels of one device-driven check iteration (1: the one-launch form of small LPs)

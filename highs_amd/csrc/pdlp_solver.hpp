@@ -28,7 +28,6 @@ struct DevSwitches {
   int fused = -1, fusedStream = 0, persistent = -1, xcdLocal = -1, hierBarrier = -1, deviceCheck = -1, checkSmall = -1;
   int primalInA = -1;     // PDLP_MI355X_PRIMAL_IN_A: the persistent loop without its P phase (pdlp_small.hip PINA); -1 = where measured faster
   int barrierTimeoutMs = 1000;  // PDLP_MI355X_BARRIER_TIMEOUT_MS: how long a grid barrier / roll call waits for missing workgroups
-  int sell = -1;          // PDLP_MI355X_SELL: 0 never the lane-per-major layout, 1 always where it can be built, -1 = timed at set-up
   int fault = 0;          // PDLP_MI355X_FAULT (tests): 1 = the first persistent launch expects one workgroup too many,
                           // 2 = the 12th fused trial's barrier expects one block too many (both then time out and fall back)
   std::string exchange, meshLayout;
@@ -51,14 +50,6 @@ struct DeviceMatrix {
   int64_t nnz = 0;
   bool useSlab = false;
   int32_t noPace = 0;  // slab kernel without the per-group block barrier (SlabMat::noPace), see tuneXcdMap
-  // the short majors one lane each (sliced ELL, pdlp_host.hpp SellPlan): built next to the slab arrays where the majors
-  // are long enough, tuneXcdMap keeps the faster of the two and frees the other
-  DeviceArray<int32_t> sellWaveSlice, sellSliceStep;
-  DeviceArray<uint32_t> sellRowCnt, sellEnt;
-  DeviceArray<double> sellVal;
-  bool haveSell = false, useSell = false;
-  void dropSell();      // free the sliced-ELL arrays (the slab stream stays)
-  void dropSlabStream();  // free the slab stream's entries (the sliced-ELL layout stays)
   int32_t xcdMap = 1;  // block -> XCD assignment of the SpMV kernels (pdlp_kernels.hip xcdContiguousBlock), see tuneXcdMap
   SlabMat slab{};
   // sw.slab: 0 = CSR stream only, 1 = slab layout, -1 = auto by nMinor
@@ -70,8 +61,6 @@ struct DeviceMatrix {
 
  private:
   void uploadPlans(const std::vector<int32_t>& hostBeg, int32_t nCsrMajor, const int32_t* longVecIndex, hipStream_t s);
-  bool wantSell(const DevSwitches& sw, const int32_t* hostBeg, int32_t nMajor_) const;
-  void uploadSellPlan(const struct SellPlan& P, hipStream_t s);
   // per-block column span / entry count of the short majors -> do the blocks touch few stretches of the gathered vector densely?
   static bool touchesFewTiles(const std::vector<int32_t>& lo, const std::vector<int32_t>& hi, const std::vector<int32_t>& cnt);
 };

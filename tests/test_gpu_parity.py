@@ -563,52 +563,6 @@ def test_slab_width_does_not_change_the_bits(monkeypatch):
             assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("case", ["block-angular", "staircase", "random", "block-angular-host-setup"])
-def test_lane_per_major_layout_bit_identical(case, monkeypatch):
-    """Round 4: the short majors of a slab-layout operand can also be laid out one LANE per major (sliced ELL: slices of 64
-    majors sorted by length, step k = the k-th entry of each; pdlp_host.hpp SellPlan) — every lane adds its major left to
-    right in a register, the reference's order, so A x, A'y and whole iterations have the bits of the slab stream and of
-    the CSR restatement.  PDLP_MI355X_SELL=0/1 forces either; by default the faster one at set-up stays."""
-    from lpgen import structured_lp, dense_column_lp
-    sp_ = None
-    if case.startswith("block-angular"):
-        kw = dict(lp=structured_lp(seed=2, commodities=12, nodes=1024, arcs=8192, link_rows=24, link_nnz=700, extra_rows=40))
-    elif case == "staircase":
-        kw = dict(lp=dense_column_lp(3, periods=48, rows_per=512, cols_per=448, dense_cols=24, dense_nnz=3000, tail_rows=256, tail_max=2600))
-    else:
-        sp_ = solver.SyntheticProblem(40000, 35000, 400000, 9)
-        kw = dict(problem_struct=sp_.struct)
-    monkeypatch.setenv("PDLP_MI355X_SLAB", "1")
-    if case.endswith("host-setup"):
-        monkeypatch.setenv("PDLP_MI355X_GPU_SETUP", "0")
-    out = {}
-    for sell in ("0", "1"):
-        monkeypatch.setenv("PDLP_MI355X_SELL", sell)
-        S = solver.DeviceSolver(**kw)
-        lay = S.stage("layouts")
-        assert list(lay[:2]) == ([2.0, 2.0] if sell == "1" else [1.0, 1.0]), lay
-        rng = np.random.default_rng(4)
-        x, y = rng.standard_normal(S.n), rng.standard_normal(S.m)
-        S.set("x", x); S.set("y", y); S.stage("ax"); S.stage("aty")
-        ax, aty = S.get("ax", S.m), S.get("aty", S.n)
-        S.close()
-        S = solver.DeviceSolver(**kw)
-        st = S.iterate(160)
-        out[sell] = (ax, aty, S.get("x", S.n), S.get("y", S.m), S.get("steps", 8), int(st.trials))
-        S.close()
-    if "lp" in kw:  # against the CSR restatement of the scaled operands
-        P = solver.Prepared(kw["lp"])
-        rng = np.random.default_rng(4)
-        x, y = rng.standard_normal(P.n), rng.standard_normal(P.m)
-        assert np.array_equal(out["1"][0], _spmv(P.csr_beg, P.csr_idx, P.csr_val, x, P.m, 256))
-        assert np.array_equal(out["1"][1], _spmv(P.csc_beg, P.csc_idx, P.csc_val, y, P.n, 256))
-    if sp_ is not None:
-        sp_.close()
-    for a, b in zip(out["0"][:5], out["1"][:5]):
-        assert np.array_equal(a, b)
-    assert out["0"][5] == out["1"][5]
-
-
 @pytest.mark.parametrize("name,iters", [("afiro", 160), ("25fv47", 400), ("80bau3b", 400), ("synthetic", 240),
                                         # majors longer than a work block (segment tasks inside the persistent loop):
                                         ("standata", 400), ("standgub", 400), ("standmps", 400), ("cplex1", 400), ("staircase", 240)])
