@@ -55,6 +55,9 @@ struct SpmvArgs {
   int32_t faultTrial;           // tests: the barrier of the trial that raises the trial counter to this value expects one block too many
   int32_t inlineTasks;          // kAtyFused: the streaming blocks run the segment tasks of the long majors themselves (no extra blocks)
   CheckGate gate;  // kPlain inside a device-driven check: the launch is a no-op unless the check is due
+  // development (PDLP_MI355X_SLAB_PROF=1): per block {launches, ticks to the end of the stream, to the end of the epilogue, to
+  // the barrier's end, to the kernel's end} of the slab launches kDualStep / kAtyFused, 100 MHz wall clock
+  unsigned long long* prof;
 };
 
 // The major-local epilogue fused into both SpMV kernels: what happens to (A v)_r once it is known.
@@ -95,6 +98,7 @@ struct Epi {
     Pre p{0.0, 0.0, 0.0, 0.0, 0.0};
     if (EPI == kDualStep) {
       p.a = ldStream(a.v.y[cur] + r); p.b = ldStream(a.v.rhs + r); p.c = ldStream(a.v.ax[cur] + r);
+      if (avgW != 0.0) p.d = ldStream(a.v.ySum + r);  // (the running sum the deferred average update adds to: not a round trip behind the stream)
     } else if (isInteract(EPI)) {
       p.a = ldStream(a.v.x[cur] + r); p.b = ldStream(a.v.x[nxt] + r); p.c = ldStream(a.v.aty[cur] + r);
     } else if (EPI == kQxInteract) {
@@ -122,7 +126,7 @@ struct Epi {
       acc0 += dx * dq;
     } else if (EPI == kDualStep) {
       const double yv = p.a;
-      if (avgW != 0.0) stStream(a.v.ySum + r, ldStream(a.v.ySum + r) + avgW * yv);  // deferred PDHG_Update_Average (step.c:438)
+      if (avgW != 0.0) stStream(a.v.ySum + r, p.d + avgW * yv);  // deferred PDHG_Update_Average (step.c:438)
       double t = yv;
       t += sigma * p.b;
       t += (-2.0 * sigma) * s;
@@ -379,11 +383,12 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
         fusedBarrierFailed(a.stOut, shWords, barVerdict, blockIdx.x == 0, tid);
         return;
       }
+      const unsigned long long timedOut = tid == 0 ? __hip_atomic_load(a.bar + a.A.nBlocks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
       double dY2, dX2, inter;
       trialSumsT<1>(a.partDY, a.nDY, a.part0, a.part1, a.nDX, tscr, dY2, dX2, inter);
       if (tid == 0) {
         decideUpdate<true>(sh, dX2, dY2, inter);
-        if (__hip_atomic_load(a.bar + a.A.nBlocks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) sh->commError = 1;
+        if (timedOut) sh->commError = 1;
       }
       __syncthreads();
       const int halted = sh->halted, curN = sh->cur, accepted = sh->lastAccepted;
@@ -457,6 +462,14 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
   if (usesDevState(EPI) && a.st->halted) return;
   if (EPI == kPlain && !gateOpen(a.gate)) return;
   static_assert(GD >= 1 && NB >= GD + 2, "entry loads need two steps, gathers GD steps");
+  const unsigned long long tProf0 = a.prof ? wall_clock64() : 0ull;
+  auto profStamp = [&](int k) {
+    if (a.prof && threadIdx.x == 0 && (int)blockIdx.x < a.S.nBlocks) {
+      unsigned long long* q = a.prof + ((EPI == kAtyFused ? 1024 : 0) + (int)blockIdx.x) * 8;
+      if (k == 0) q[0] += 1;
+      q[1 + k] += wall_clock64() - tProf0;
+    }
+  };
   constexpr int kWaves = kSlabThreads / kWave;
   constexpr int kSlabPre = TWO ? 2 : 4;  // majors per thread whose epilogue operands are fetched before the stream
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -605,6 +618,7 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
   }
   if (a.S.noPace) __syncthreads();  // (free-running waves: every wave's accumulators are final before the epilogue reads them)
 
+  profStamp(0);
   const uint32_t* __restrict__ mask = a.S.longMask + (size_t)blk * (R / 32);
 #pragma unroll
   for (int k = 0; k < kSlabPre; ++k) {
@@ -612,10 +626,20 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
     if (rBase + lr < rEnd && !((mask[lr >> 5] >> (lr & 31)) & 1u))  // (long major: the CSR side kernel owns it)
       epi.apply(rBase + lr, acc[lr], pre[k]);
   }
-  for (int lr = tid + kSlabPre * kSlabThreads; rBase + lr < rEnd; lr += kSlabThreads) {
-    if ((mask[lr >> 5] >> (lr & 31)) & 1u) continue;
-    const int r = rBase + lr;
-    epi.apply(r, acc[lr], epi.prefetch(r));
+  // (more than kSlabPre majors per thread — 2.1 M columns in 256 blocks: the operands of the next kSlabPre majors are
+  // fetched together, one memory round trip per batch instead of one per major; same majors in the same order)
+  for (int lr0 = tid + kSlabPre * kSlabThreads; rBase + lr0 < rEnd; lr0 += kSlabPre * kSlabThreads) {
+    Pre more[kSlabPre];
+#pragma unroll
+    for (int k = 0; k < kSlabPre; ++k) {
+      const int r = rBase + lr0 + k * kSlabThreads;
+      more[k] = epi.prefetch(r < rEnd ? r : rEnd - 1);
+    }
+#pragma unroll
+    for (int k = 0; k < kSlabPre; ++k) {
+      const int lr = lr0 + k * kSlabThreads;
+      if (rBase + lr < rEnd && !((mask[lr >> 5] >> (lr & 31)) & 1u)) epi.apply(rBase + lr, acc[lr], more[k]);
+    }
   }
   if (EPI == kAtyFused) {  // xSum of the own columns: in flight across the barrier and the decision
 #pragma unroll
@@ -625,6 +649,7 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
     }
   }
   epi.template finish<kSlabThreads>(blk, scratch);
+  profStamp(1);
   if (EPI == kAtyFused && a.inlineTasks) {
     // Long columns in the fused trial: their segment tasks cannot be extra workgroups (those would have to be resident
     // next to the waiting blocks), so the streaming blocks take them — task group tb goes to block tb % nBlocks, one
@@ -653,15 +678,18 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
       if (tid >= kVecThreads && tid - kVecThreads < (int)(sizeof(DevState) / 4)) dstw[tid - kVecThreads] = src[tid - kVecThreads];
     }
     __syncthreads();
+    profStamp(2);
     if (*barVerdict != kBarOk) {  // not every block of this launch was resident in time: the trial stays undecided (fusedBarrierFailed)
       fusedBarrierFailed(a.stOut, reinterpret_cast<const uint32_t*>(sh), *barVerdict, blockIdx.x == 0, tid);
       return;
     }
+    // (the barrier's timeout flag: fetched together with the partials, looked at behind the decision — not a round trip of its own)
+    const unsigned long long timedOut = tid == 0 ? __hip_atomic_load(a.bar + a.S.nBlocks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
     double dY2, dX2, inter;
     trialSumsT<1>(a.partDY, a.nDY, a.part0, a.part1, a.nDX, tscr, dY2, dX2, inter);
     if (tid == 0) {
       decideUpdate<true>(sh, dX2, dY2, inter);
-      if (__hip_atomic_load(a.bar + a.S.nBlocks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) sh->commError = 1;
+      if (timedOut) sh->commError = 1;
     }
     __syncthreads();
     const int halted = sh->halted, curN = sh->cur, accepted = sh->lastAccepted;
@@ -698,10 +726,27 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
         step(r, accepted ? pre[k].b : ldStream(xBase + r), ab, fix[k].a, fix[k].b, fix[k].c, fix[k].d);
       }
     }
-    for (int lr = tid + kSlabPre * kSlabThreads; rBase + lr < rEnd; lr += kSlabThreads) {  // (more than 4096 majors per block)
-      const int r = rBase + lr;
-      const double ab = isLong(lr) ? ldAgent(atyBase + r) : accepted ? acc[lr] : ldStream(atyBase + r);
-      step(r, ldStream(xBase + r), ab, ldStream(a.v.cost + r), ldStream(a.v.lower + r), ldStream(a.v.upper + r), ldStream(a.v.xSum + r));
+    for (int lr0 = tid + kSlabPre * kSlabThreads; rBase + lr0 < rEnd; lr0 += kSlabPre * kSlabThreads) {  // (more than 4096 majors per block:
+      double xb[kSlabPre], ab[kSlabPre], cc[kSlabPre], ll[kSlabPre], uu[kSlabPre], xs[kSlabPre];      //  kSlabPre columns' operands per round trip)
+#pragma unroll
+      for (int k = 0; k < kSlabPre; ++k) {
+        const int lr1 = lr0 + k * kSlabThreads;
+        const int lr = rBase + lr1 < rEnd ? lr1 : rEnd - 1 - rBase;
+        const int r = rBase + lr;
+        xb[k] = ldStream(xBase + r);
+        ab[k] = isLong(lr) ? ldAgent(atyBase + r) : accepted ? acc[lr] : ldStream(atyBase + r);
+        cc[k] = ldStream(a.v.cost + r); ll[k] = ldStream(a.v.lower + r); uu[k] = ldStream(a.v.upper + r); xs[k] = ldStream(a.v.xSum + r);
+      }
+#pragma unroll
+      for (int k = 0; k < kSlabPre; ++k) {
+        const int lr = lr0 + k * kSlabThreads;
+        if (rBase + lr < rEnd) step(rBase + lr, xb[k], ab[k], cc[k], ll[k], uu[k], xs[k]);
+      }
+    }
+    if (a.prof) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      profStamp(3);
     }
   }
 }
@@ -1035,9 +1080,46 @@ void launchPrimalStep(const IterVecs& v, const DevState* st, hipStream_t s) {
 }
 
 namespace {
+// PDLP_MI355X_SLAB_PROF=1 (development): per-block phase times of the two slab launches of a trial, printed at exit —
+// mean / fastest / slowest block of {stream, + epilogue, + grid barrier, + decision and primal step}, us per launch.
+unsigned long long* slabProf() {
+  static unsigned long long* prof = [] {
+    unsigned long long* p = nullptr;
+    constexpr size_t kWords = 2 * 1024 * 8;
+    if (getenv("PDLP_MI355X_SLAB_PROF") && hipMalloc((void**)&p, kWords * 8) == hipSuccess) {
+      (void)hipMemset(p, 0, kWords * 8);
+      static unsigned long long* keep = p;
+      atexit([] {
+        std::vector<unsigned long long> h(kWords);
+        if (hipMemcpy(h.data(), keep, kWords * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+        for (int half = 0; half < 2; ++half) {
+          const int base = half * 1024, nBlocks = 1024;
+          for (int k = 0; k < 4; ++k) {
+            double mean = 0, lo = 1e300, hi = 0;
+            int cnt = 0;
+            for (int b = 0; b < nBlocks; ++b) {
+              const unsigned long long n = h[(size_t)(base + b) * 8];
+              if (!n) continue;
+              const double us = (double)h[(size_t)(base + b) * 8 + 1 + k] * 0.01 / (double)n;
+              mean += us; lo = us < lo ? us : lo; hi = us > hi ? us : hi; ++cnt;
+            }
+            if (cnt && hi > 0)
+              fprintf(stderr, "slab launch %s, %d blocks, to the end of %s: mean %.2f us, fastest block %.2f, slowest %.2f\n",
+                      half ? "A'y+ (fused)" : "A x+", cnt, k == 0 ? "the stream" : k == 1 ? "the epilogue" : k == 2 ? "the grid barrier" : "the kernel",
+                      mean / cnt, lo, hi);
+          }
+        }
+      });
+    }
+    return p;
+  }();
+  return prof;
+}
+
 template <int EPI>
 void launchSpmv(const MatView& M, SpmvArgs a, hipStream_t s) {
   a.xcdMap = M.xcdMap;
+  if (EPI == kDualStep && M.useSlab && M.slab.nBlocks <= 1024) a.prof = slabProf();
   a.L = M.lng;
   a.A = M.csr;
   const int nTasks = M.lng.nTasks;
@@ -1078,6 +1160,7 @@ size_t fusedLds(const MatView& At) {
 }
 }  // namespace
 int fusedAtyBlocksResident(const MatView& At, int device) {
+  (void)slabProf();  // (development buffer: allocated at set-up, never inside a stream capture)
   // long columns: the slab kernel's streaming blocks run their segment tasks themselves (SpmvArgs::inlineTasks); not
   // the stream-layout kernel, and not beyond kLongSlotCap long columns (their contributions need the k_long_groups launch)
   if (At.lng.nTasks > 0 && (!At.useSlab || At.lng.contrib != nullptr)) return 0;
@@ -1105,6 +1188,7 @@ void launchSpmvAtyFusedPrimal(const MatView& At, const IterVecs& v, const DevSta
   a.inlineTasks = At.useSlab && At.lng.nTasks > 0 ? 1 : 0;
   a.st = stIn; a.v = v; a.part0 = partDX; a.part1 = partInter;
   a.stOut = stOut; a.partDY = partDY; a.nDY = nDY; a.nDX = At.nPartials; a.bar = bar;
+  if (At.useSlab && At.slab.nBlocks <= 1024) a.prof = slabProf();
   a.xcdMap = At.xcdMap; a.L = At.lng; a.A = At.csr; a.S = At.slab;
   if (At.useSlab)
     hipLaunchKernelGGL((k_spmv_slab<kAtyFused, false, kSlabSlots, 1>), dim3(At.slab.nBlocks), dim3(kSlabThreads), fusedLds(At), s, a);

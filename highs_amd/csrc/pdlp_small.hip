@@ -166,7 +166,10 @@ __device__ __forceinline__ void smallSpmvBlock(const SmallArgs& a, const SpmvMat
   int qb = B.qb, qe = B.qe;
   auto prefetch = [&](int r, bool first) {
     Pre p{0.0, 0.0, 0.0, 0.0, 0.0};
-    if (DUAL) { p.a = ldM<LOCAL>(a.v.y[cur] + r); p.b = first ? B.fixed : a.v.rhs[r]; p.c = ldM<LOCAL>(a.v.ax[cur] + r); }
+    if (DUAL) {
+      p.a = ldM<LOCAL>(a.v.y[cur] + r); p.b = first ? B.fixed : a.v.rhs[r]; p.c = ldM<LOCAL>(a.v.ax[cur] + r);
+      if (avgW != 0.0) p.d = ldM<LOCAL>(a.v.ySum + r);  // (the deferred average update's running sum: fetched with the rest, not behind the row sum)
+    }
     else { p.a = ldM<LOCAL>(a.v.x[cur] + r); p.b = ldM<LOCAL>(a.v.x[nxt] + r); p.c = ldM<LOCAL>(a.v.aty[cur] + r); }
     return p;
   };
@@ -189,7 +192,7 @@ __device__ __forceinline__ void smallSpmvBlock(const SmallArgs& a, const SpmvMat
     const double s = majorSum(prod, qb, qe);
     if (DUAL) {
       const double yv = pre.a;
-      if (avgW != 0.0) stM<LOCAL>(a.v.ySum + r, ldM<LOCAL>(a.v.ySum + r) + avgW * yv);  // deferred PDHG_Update_Average (step.c:438)
+      if (avgW != 0.0) stM<LOCAL>(a.v.ySum + r, pre.d + avgW * yv);  // deferred PDHG_Update_Average (step.c:438)
       double t = yv;
       t += sigma * pre.b;
       t += (-2.0 * sigma) * s;
@@ -234,9 +237,12 @@ __device__ __forceinline__ void smallLongBlock(const SmallArgs& a, const LongMat
   const bool active = T.c >= 0;
   const int seg = t - T.first;
   const int r = T.major;
-  double pa = 0.0, pb = 0.0, pc = 0.0;
+  double pa = 0.0, pb = 0.0, pc = 0.0, pd = 0.0;
   if (active && (seg == 0 || !T.contained)) {
-    if (DUAL) { pa = ldM<LOCAL>(a.v.y[cur] + r); pb = a.v.rhs[r]; pc = ldM<LOCAL>(a.v.ax[cur] + r); }
+    if (DUAL) {
+      pa = ldM<LOCAL>(a.v.y[cur] + r); pb = a.v.rhs[r]; pc = ldM<LOCAL>(a.v.ax[cur] + r);
+      if (avgW != 0.0) pd = ldM<LOCAL>(a.v.ySum + r);
+    }
     else { pa = ldM<LOCAL>(a.v.x[cur] + r); pb = ldM<LOCAL>(a.v.x[nxt] + r); pc = ldM<LOCAL>(a.v.aty[cur] + r); }
   }
   const int32_t* __restrict__ idx = L.idx;
@@ -291,7 +297,7 @@ __device__ __forceinline__ void smallLongBlock(const SmallArgs& a, const LongMat
   if (finish && lane == 0) {
     if (DUAL) {
       const double yv = pa;
-      if (avgW != 0.0) stM<LOCAL>(a.v.ySum + r, ldM<LOCAL>(a.v.ySum + r) + avgW * yv);  // deferred PDHG_Update_Average (step.c:438)
+      if (avgW != 0.0) stM<LOCAL>(a.v.ySum + r, pd + avgW * yv);  // deferred PDHG_Update_Average (step.c:438)
       double tt = yv;
       tt += sigma * pb;
       tt += (-2.0 * sigma) * total;
