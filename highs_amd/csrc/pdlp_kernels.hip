@@ -171,11 +171,18 @@ struct Epi {
 // (sc1: write-through stores, L1-bypassing loads), and the segment sum has landed (s_waitcnt vmcnt(0)) before the
 // ticket is taken.  The epilogue operands of the major are fetched with the first loads, not after the reduction.
 template <int EPI, int W>
-__device__ __forceinline__ void longBlock(const SpmvArgs& a, Epi<EPI>& epi, int lb, double* lds /* [W] */) {
+__device__ __forceinline__ void longBlock(const SpmvArgs& a, Epi<EPI>& epi, int lb, double* lds /* [W] */, bool many = false) {
   const LongMat& L = a.L;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x / kWave);
-  const int t = lb * W + wave;
+  // task group lb * (W / g) + wave / g, g = L.taskGroup tasks each: a workgroup of W waves takes W / g consecutive groups
+  // when it runs tasks behind its stream (`many`), ONE group — waves beyond g idle — as an extra workgroup of a launch
+  // (more, lighter task workgroups: every CU gets one next to its streaming block)
+  const int g = L.taskGroup;
+  const int sub = wave / g;
+  const int grp = many ? lb * (W / g) + sub : lb;
+  const bool mine = many || sub == 0;
+  const int t = mine ? grp * g + (wave - sub * g) : L.nTasks;
   LongTask T;
   T.c = -1; T.pBeg = T.pEnd = 0; T.first = t; T.nSeg = 1; T.major = 0; T.contained = 1; T.pad_ = 0;
   if (t < L.nTasks) {  // (one 32-byte scalar load)
@@ -654,9 +661,9 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
     // Long columns in the fused trial: their segment tasks cannot be extra workgroups (those would have to be resident
     // next to the waiting blocks), so the streaming blocks take them — task group tb goes to block tb % nBlocks, one
     // task per wave, same lanes and sums as in the extra blocks of the other launches (longBlock).
-    const int nTB = (a.L.nTasks + kWaves - 1) / kWaves;
+    const int nTB = (a.L.nTasks + kWaves - 1) / kWaves;  // passes of kWaves tasks (kWaves / taskGroup groups each)
     for (int tb = (int)blockIdx.x; tb < nTB; tb += a.S.nBlocks) {
-      longBlock<EPI, kWaves>(a, epi, tb, &scratch[0][0]);
+      longBlock<EPI, kWaves>(a, epi, tb, &scratch[0][0], true);
       __syncthreads();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave's published words have landed before the block arrives
@@ -1092,6 +1099,9 @@ unsigned long long* slabProf() {
       atexit([] {
         std::vector<unsigned long long> h(kWords);
         if (hipMemcpy(h.data(), keep, kWords * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+        if (const char* path = getenv("PDLP_MI355X_SLAB_PROF"); path && path[0] != '1') {  // a path: the raw table too
+          if (FILE* f = fopen(path, "wb")) { fwrite(h.data(), 8, kWords, f); fclose(f); }
+        }
         for (int half = 0; half < 2; ++half) {
           const int base = half * 1024, nBlocks = 1024;
           for (int k = 0; k < 4; ++k) {
@@ -1126,7 +1136,7 @@ void launchSpmv(const MatView& M, SpmvArgs a, hipStream_t s) {
   if (M.useSlab && M.slab.nBlocks > 0) {
     a.S = M.slab;
     const size_t lds = (size_t)M.slab.rowsPerBlock * 8 + kSlabThreads * 8 + 2 * (kSlabThreads / kWave) * 8;
-    const dim3 grid(M.slab.nBlocks + (nTasks + kSlabThreads / kWave - 1) / (kSlabThreads / kWave));
+    const dim3 grid(M.slab.nBlocks + (nTasks + M.lng.taskGroup - 1) / M.lng.taskGroup);  // one task group per extra workgroup
     // (gather distance 2 / 3 with 4 / 6 slots measured the same as (3, 1) on the random and on the structured LP, round 3)
     // segment tasks ride along: register budget for two resident blocks per CU, so that a task block runs NEXT to a streaming one
     if (nTasks > 0) hipLaunchKernelGGL((k_spmv_slab<EPI, true, kSlabSlots, 1>), grid, dim3(kSlabThreads), lds, s, a);

@@ -140,6 +140,10 @@ struct LongMat {
   int32_t slotBase;          // first slot of the long majors in the partial arrays
   int32_t nSlots;            // nLong, or the number of groups
   int32_t groupSize;         // long majors per slot (1 unless nLong > kLongSlotCap)
+  // tasks per workgroup (the plan's group, pdlp_host.hpp planLong): 4 in the stream layout; 16, 8, ... 1 in the slab
+  // layout — as many task workgroups as the device has CUs where there are enough tasks, so that every CU carries the
+  // same extra load next to its streaming block (DeviceMatrix::uploadPlans)
+  int32_t taskGroup;
 };
 
 // Slab layout (pdlp_host.hpp SlabLayout), device pointers.  One 1024-thread block = 16 waves, each

@@ -65,8 +65,22 @@ void DeviceMatrix::uploadPlans(const std::vector<int32_t>& hostBeg, int32_t nCsr
   if (longVecIndex)
     for (int32_t c : plan.longMajors) vecIdx.push_back(longVecIndex[c]);
   static_assert(sizeof(LongTask) == sizeof(LongTaskHost) && sizeof(LongTask) == 32, "task record layout");
-  LongPlan L = planLong(hostBeg, plan.longMajors, longVecIndex ? vecIdx.data() : nullptr,
-                        (useSlab ? kSlabThreads : kSpmvThreads) / 64);
+  // tasks per workgroup.  Stream layout: the 4 waves of a workgroup.  Slab layout: task workgroups run NEXT to the
+  // streaming blocks (two per CU), and 128 of them on 256 CUs slow down half of the streaming blocks (bench.py --config c,
+  // A x+: blocks sharing their CU 37 us, the others 26.5 — the launch takes the 37); the group is halved until there are
+  // at least as many task workgroups as CUs, so every CU carries the same extra load
+  taskGroup = (useSlab ? kSlabThreads : kSpmvThreads) / 64;
+  if (useSlab && balanceTaskBlocks) {
+    int64_t segs = 0;
+    for (int32_t c : plan.longMajors) {
+      const int64_t len = hostBeg[c + 1] - hostBeg[c];
+      int64_t seg = kLongSegment;
+      while ((len + seg - 1) / seg > kLongMaxSegments) seg *= 2;
+      segs += (len + seg - 1) / seg;
+    }
+    while (taskGroup > 1 && segs / taskGroup < kSlabTargetBlocks) taskGroup /= 2;
+  }
+  LongPlan L = planLong(hostBeg, plan.longMajors, longVecIndex ? vecIdx.data() : nullptr, taskGroup);
   nLong = L.nLong;
   nTasks = L.nTasks;
   longGroup = nLong > kLongSlotCap ? (nLong + kLongSlotCap - 1) / kLongSlotCap : 1;
@@ -197,7 +211,7 @@ MatView DeviceMatrix::view() const {
   v.slab = slab;
   v.slab.noPace = noPace;
   v.lng = LongMat{idx.get(), val.get(), lTasks.get(), lSegSum.get(), lTicket.get(), longGroup > 1 ? lContrib.get() : nullptr,
-                  nLong, nTasks, slabBlocks + nBlocks, longSlots, longGroup};
+                  nLong, nTasks, slabBlocks + nBlocks, longSlots, longGroup, taskGroup};
   v.useSlab = useSlab ? 1 : 0;
   v.xcdMap = xcdMap;
   v.nPartials = nPartials();
@@ -529,6 +543,7 @@ Solver::~Solver() { release(); }
 void Solver::uploadProblem() {
   const int32_t n = F_.n;
   if (!sharded_) {
+    dAt_.balanceTaskBlocks = sw_.fused == 0;  // (the fused trial runs the long columns' tasks inside its streaming blocks)
     dA_.upload(F_.csr, F_.m, n, sw_, stream_);
     dAt_.upload(F_.cscSorted, n, F_.m, sw_, stream_);
   } else {
@@ -604,6 +619,7 @@ void Solver::downloadForm(DeviceProblem& D, StandardForm& F, hipStream_t s) {
 }
 
 void Solver::uploadProblemFromDevice(DeviceProblem& D) {
+  dAt_.balanceTaskBlocks = sharded_ || sw_.fused == 0;  // (the fused trial runs the long columns' tasks inside its streaming blocks)
   dA_.buildFromDevice(D.A, sw_, stream_);
   dAt_.buildFromDevice(D.At, sw_, stream_);
   cost_ = std::move(D.cost); rhs_ = std::move(D.rhs); lower_ = std::move(D.lower); upper_ = std::move(D.upper);

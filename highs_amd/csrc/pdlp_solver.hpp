@@ -44,7 +44,10 @@ struct DeviceMatrix {
   DeviceArray<LongTask> lTasks;
   DeviceArray<double> lSegSum, lContrib;
   DeviceArray<uint32_t> lTicket;
-  int32_t nLong = 0, nTasks = 0, longSlots = 0, longGroup = 1;
+  int32_t nLong = 0, nTasks = 0, longSlots = 0, longGroup = 1, taskGroup = 4;
+  // slab layout: size the task workgroups so that every CU gets one (uploadPlans).  Off for the operand whose tasks the
+  // fused trial runs inside its streaming blocks (already spread evenly; full groups of 16 keep long columns in LDS)
+  bool balanceTaskBlocks = true;
   int32_t nMajor = 0, nBlocks = 0;  // nBlocks = CSR stream blocks
   int32_t chunk = kChunk;           // work-plan block size of the CSR stream (spmvChunkFor)
   int64_t nnz = 0;
