@@ -523,7 +523,7 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
       const int r0_ = rBase + tid + k * kSlabThreads;
       const int r = r0_ < rEnd ? r0_ : rEnd - 1;
       fix[k].a = ldStream(a.v.cost + r); fix[k].b = ldStream(a.v.lower + r); fix[k].c = ldStream(a.v.upper + r);
-      fix[k].d = 0.0; fix[k].e = 0.0;
+      fix[k].d = 0.0; fix[k].e = a.v.qdiag ? ldStream(a.v.qdiag + r) : 0.0;  // (QP: the diagonal of Q of the prox step)
     }
   }
 
@@ -712,12 +712,12 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
     const double* __restrict__ xBase = a.v.x[curN];
     const double* __restrict__ atyBase = a.v.aty[curN];
     double* __restrict__ xOut = a.v.x[curN ^ 1];
-    auto step = [&](int r, double xb, double ab, double c, double l, double u, double xs) {
+    auto step = [&](int r, double xb, double ab, double c, double l, double u, double xs, double q) {
       if (avgWx != 0.0) stStream(a.v.xSum + r, xs + avgWx * xb);  // deferred PDHG_Update_Average (step.c:437)
       double t = xb;
       t += (-tau) * c;
       t += tau * ab;
-      if (a.v.qdiag) t = t / (1.0 + tau * ldStream(a.v.qdiag + r));
+      if (a.v.qdiag) t = t / (1.0 + tau * q);
       t = t < u ? t : u;
       t = t > l ? t : l;
       xOut[r] = t;  // gathered by the A x+ kernel: ordinary store
@@ -730,11 +730,11 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
       if (rBase + lr < rEnd) {  // (a rejected trial, 3 %, fetches x and A'y again)
         const int r = rBase + lr;
         const double ab = isLong(lr) ? ldAgent(atyBase + r) : accepted ? acc[lr] : ldStream(atyBase + r);
-        step(r, accepted ? pre[k].b : ldStream(xBase + r), ab, fix[k].a, fix[k].b, fix[k].c, fix[k].d);
+        step(r, accepted ? pre[k].b : ldStream(xBase + r), ab, fix[k].a, fix[k].b, fix[k].c, fix[k].d, fix[k].e);
       }
     }
     for (int lr0 = tid + kSlabPre * kSlabThreads; rBase + lr0 < rEnd; lr0 += kSlabPre * kSlabThreads) {  // (more than 4096 majors per block:
-      double xb[kSlabPre], ab[kSlabPre], cc[kSlabPre], ll[kSlabPre], uu[kSlabPre], xs[kSlabPre];      //  kSlabPre columns' operands per round trip)
+      double xb[kSlabPre], ab[kSlabPre], cc[kSlabPre], ll[kSlabPre], uu[kSlabPre], xs[kSlabPre], qq[kSlabPre];  //  kSlabPre columns' operands per round trip)
 #pragma unroll
       for (int k = 0; k < kSlabPre; ++k) {
         const int lr1 = lr0 + k * kSlabThreads;
@@ -743,11 +743,12 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
         xb[k] = ldStream(xBase + r);
         ab[k] = isLong(lr) ? ldAgent(atyBase + r) : accepted ? acc[lr] : ldStream(atyBase + r);
         cc[k] = ldStream(a.v.cost + r); ll[k] = ldStream(a.v.lower + r); uu[k] = ldStream(a.v.upper + r); xs[k] = ldStream(a.v.xSum + r);
+        qq[k] = a.v.qdiag ? ldStream(a.v.qdiag + r) : 0.0;
       }
 #pragma unroll
       for (int k = 0; k < kSlabPre; ++k) {
         const int lr = lr0 + k * kSlabThreads;
-        if (rBase + lr < rEnd) step(rBase + lr, xb[k], ab[k], cc[k], ll[k], uu[k], xs[k]);
+        if (rBase + lr < rEnd) step(rBase + lr, xb[k], ab[k], cc[k], ll[k], uu[k], xs[k], qq[k]);
       }
     }
     if (a.prof) {
