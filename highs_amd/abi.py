@@ -138,7 +138,7 @@ class PdlpSlabLayout(C.Structure):
         ("slab_width_log2", C.c_int32), ("n_long", C.c_int32),
         ("nnz_short", C.c_int64),
         ("wave_ptr", c_i32p), ("ent", C.POINTER(C.c_uint32)), ("val", c_f64p),
-        ("long_mask", C.POINTER(C.c_uint32)), ("long_map", c_i32p),
+        ("long_mask", C.POINTER(C.c_uint32)), ("long_map", c_i32p), ("wave_beg", c_i32p),
     ]
 
 

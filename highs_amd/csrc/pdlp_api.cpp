@@ -304,17 +304,17 @@ int pdlp_mi355x_host_slab_layout(const pdlp_prepared_t* prep, int32_t which, int
     c.val.assign(which ? prep->csc_val : prep->csr_val, (which ? prep->csc_val : prep->csr_val) + prep->nnz);
     pdlp::SlabLayout L;
     pdlp::buildSlabLayout(c, nMajor, nMinor, long_limit, pdlp::kSlabWidthLog2, L);
-    out->rows_per_block = L.rowsPerBlock; out->rows_per_wave = L.rowsPerWave; out->n_blocks = L.nBlocks;
+    out->rows_per_block = L.rowsPerBlock; out->rows_per_wave = 0; out->n_blocks = L.nBlocks;
     out->minor_bits = L.minorBits; out->slab_width_log2 = L.slabWidthLog2;
     out->n_long = (int32_t)L.longMap.size(); out->nnz_short = (int64_t)L.ent.size();
     out->wave_ptr = dupVec(L.wavePtr); out->ent = dupVec(L.ent); out->val = dupVec(L.val);
-    out->long_mask = dupVec(L.longMask); out->long_map = dupVec(L.longMap);
+    out->long_mask = dupVec(L.longMask); out->long_map = dupVec(L.longMap); out->wave_beg = dupVec(L.waveBeg);
   });
 }
 
 void pdlp_mi355x_free_slab_layout(pdlp_slab_layout_t* o) {
   if (!o) return;
-  free(o->wave_ptr); free(o->ent); free(o->val); free(o->long_mask); free(o->long_map);
+  free(o->wave_ptr); free(o->ent); free(o->val); free(o->long_mask); free(o->long_map); free(o->wave_beg);
   memset(o, 0, sizeof(*o));
 }
 

@@ -427,56 +427,92 @@ LongPlan planLong(const std::vector<int32_t>& beg, const std::vector<int32_t>& l
 }
 
 namespace {
-int32_t bitsForRows(int32_t rows) {
-  int rb = 0;
-  while ((1 << rb) < rows) ++rb;
-  return rb;
+int32_t bitsFor(int64_t count) {  // smallest b with 2^b >= count
+  int b = 0;
+  while (((int64_t)1 << b) < count) ++b;
+  return b;
+}
+// Fills `units` consecutive ranges of [r0, r1) by work (see SlabPartition): out[0..units] boundaries.
+void fillByWork(const int32_t* beg, int32_t longLimit, int32_t r0, int32_t r1, int32_t units, int64_t cap, bool nonEmpty,
+                int32_t* out) {
+  auto cost = [&](int32_t r) -> int64_t {
+    const int32_t len = beg[r + 1] - beg[r];
+    return (len > longLimit ? 0 : len) + kSlabMajorCost;
+  };
+  int64_t rem = 0;
+  for (int32_t r = r0; r < r1; ++r) rem += cost(r);
+  int32_t r = r0;
+  out[0] = r0;
+  for (int32_t u = 0; u < units; ++u) {
+    const int64_t left = units - u;
+    const int64_t target = (rem + left - 1) / left;
+    const int64_t rows = (int64_t)r1 - r;
+    const int64_t minRows = std::max<int64_t>(nonEmpty && rows > 0 ? 1 : 0, rows - (left - 1) * cap);
+    const int64_t maxRows = std::min<int64_t>(cap, nonEmpty ? std::max<int64_t>(rows - (left - 1), 1) : rows);
+    int64_t acc = 0, cnt = 0;
+    while (cnt < rows && cnt < maxRows && (cnt < minRows || acc < target)) { acc += cost(r); ++r; ++cnt; }
+    rem -= acc;
+    out[u + 1] = r;
+  }
 }
 }  // namespace
 
-int32_t slabRowsPerWave(int32_t nMajor, int32_t nMinor) {
-  const int64_t waves = (int64_t)kSlabTargetBlocks * kSlabWavesPerBlock;
-  int64_t Rw = ((int64_t)nMajor + waves - 1) / waves;
-  Rw = (Rw + 1) / 2 * 2;  // even: rowsPerBlock is then a multiple of 32 (longMask words)
-  if (Rw < 16) Rw = 16;
-  if (Rw > 1024) Rw = 1024;  // 16384 majors per block: 128 KB of LDS accumulators (gfx950 has 160 KB per CU)
-  // (localMajor << minorBits | minor) must fit 32 bits: shrink the waves until it does
-  while (Rw > 16 && ((int64_t)1 << (32 - bitsForRows((int32_t)Rw))) < (int64_t)nMinor) Rw = (Rw / 2 + 1) / 2 * 2;
-  if (((int64_t)1 << (32 - bitsForRows((int32_t)Rw))) < (int64_t)nMinor) return 0;
-  return (int32_t)Rw;
+bool slabFits(int32_t nMajor, int32_t nMinor) {
+  (void)nMajor;
+  return bitsFor(nMinor) <= 28;  // at least 16 majors per wave
+}
+
+SlabPartition slabPartition(const int32_t* beg, int32_t nMajor, int32_t nMinor, int32_t longLimit) {
+  SlabPartition P;
+  if (!slabFits(nMajor, nMinor)) throw std::runtime_error("slab layout: minor index does not fit the entry packing");
+  P.minorBits = std::max(bitsFor(nMinor), 4);
+  const int64_t waveCap = std::min<int64_t>((int64_t)1 << (32 - P.minorBits), kSlabBlockRowCap);
+  const int64_t blockCap = std::min<int64_t>(kSlabBlockRowCap, waveCap * kSlabWavesPerBlock);
+  int64_t nB = ((int64_t)nMajor + kSlabMinRowsPerBlock - 1) / kSlabMinRowsPerBlock;
+  nB = std::min<int64_t>(nB, kSlabTargetBlocks);
+  nB = std::max<int64_t>(nB, ((int64_t)nMajor + blockCap - 1) / blockCap);
+  P.nBlocks = (int32_t)nB;
+  P.waveBeg.assign((size_t)nB * kSlabWavesPerBlock + 1, 0);
+  if (nB == 0) return P;
+  std::vector<int32_t> blockBeg((size_t)nB + 1);
+  fillByWork(beg, longLimit, 0, nMajor, (int32_t)nB, blockCap, true, blockBeg.data());
+  for (int32_t b = 0; b < (int32_t)nB; ++b) {
+    fillByWork(beg, longLimit, blockBeg[b], blockBeg[b + 1], kSlabWavesPerBlock, waveCap, false,
+               P.waveBeg.data() + (size_t)b * kSlabWavesPerBlock);
+    P.maxRowsPerBlock = std::max(P.maxRowsPerBlock, blockBeg[b + 1] - blockBeg[b]);
+  }
+  return P;
 }
 
 void buildSlabLayout(const Compressed& csr, int32_t nMajor, int32_t nMinor, int32_t longLimit, int32_t slabWidthLog2,
                      SlabLayout& out) {
   out = SlabLayout();
-  const int32_t Rw = slabRowsPerWave(nMajor, nMinor);
-  if (Rw == 0) throw std::runtime_error("slab layout: minor index does not fit the entry packing");
-  const int32_t R = Rw * kSlabWavesPerBlock;
-  out.rowsPerWave = Rw;
-  out.rowsPerBlock = R;
-  out.nBlocks = (nMajor + R - 1) / R;
-  out.minorBits = 32 - bitsForRows(Rw);
+  SlabPartition P = slabPartition(csr.beg.data(), nMajor, nMinor, longLimit);
+  out.rowsPerBlock = P.maxRowsPerBlock;
+  out.nBlocks = P.nBlocks;
+  out.minorBits = P.minorBits;
   out.slabWidthLog2 = slabWidthLog2;
+  out.waveBeg = std::move(P.waveBeg);
   const int32_t nWaves = out.nBlocks * kSlabWavesPerBlock;
   const int32_t S = std::max(1, (int32_t)(((int64_t)nMinor + ((int64_t)1 << slabWidthLog2) - 1) >> slabWidthLog2));
   if ((int64_t)nWaves * S >= (int64_t)0x7fffffff) throw std::runtime_error("slab layout: too many segments");
-  out.longMask.assign((size_t)out.nBlocks * (R / 32), 0u);
+  out.longMask.assign(((size_t)nMajor + 31) / 32 + 1, 0u);
   out.longCsr.beg.push_back(0);
   // pass 1: per (wave, slab) counts; long majors go to the side CSR
   std::vector<int32_t> count((size_t)nWaves * S, 0);
-  for (int32_t r = 0; r < nMajor; ++r) {
-    const int32_t b = r / R, len = csr.beg[r + 1] - csr.beg[r];
-    if (len > longLimit) {
-      out.longMask[(size_t)b * (R / 32) + (r % R) / 32] |= 1u << ((r % R) % 32);
-      out.longMap.push_back(r);
-      out.longCsr.idx.insert(out.longCsr.idx.end(), csr.idx.begin() + csr.beg[r], csr.idx.begin() + csr.beg[r + 1]);
-      out.longCsr.val.insert(out.longCsr.val.end(), csr.val.begin() + csr.beg[r], csr.val.begin() + csr.beg[r + 1]);
-      out.longCsr.beg.push_back((int32_t)out.longCsr.idx.size());
-      continue;
+  for (int32_t w = 0; w < nWaves; ++w)
+    for (int32_t r = out.waveBeg[w]; r < out.waveBeg[w + 1]; ++r) {
+      const int32_t len = csr.beg[r + 1] - csr.beg[r];
+      if (len > longLimit) {
+        out.longMask[(size_t)r >> 5] |= 1u << (r & 31);
+        out.longMap.push_back(r);
+        out.longCsr.idx.insert(out.longCsr.idx.end(), csr.idx.begin() + csr.beg[r], csr.idx.begin() + csr.beg[r + 1]);
+        out.longCsr.val.insert(out.longCsr.val.end(), csr.val.begin() + csr.beg[r], csr.val.begin() + csr.beg[r + 1]);
+        out.longCsr.beg.push_back((int32_t)out.longCsr.idx.size());
+        continue;
+      }
+      for (int32_t p = csr.beg[r]; p < csr.beg[r + 1]; ++p) ++count[(size_t)w * S + (csr.idx[p] >> slabWidthLog2)];
     }
-    const size_t w = (size_t)(r / Rw);
-    for (int32_t p = csr.beg[r]; p < csr.beg[r + 1]; ++p) ++count[w * S + (csr.idx[p] >> slabWidthLog2)];
-  }
   // exclusive scan in (wave, slab) order; wavePtr = the wave boundaries of it
   out.wavePtr.assign((size_t)nWaves + 1, 0);
   std::vector<int32_t> pos((size_t)nWaves * S);
@@ -493,18 +529,18 @@ void buildSlabLayout(const Compressed& csr, int32_t nMajor, int32_t nMinor, int3
   out.val.resize((size_t)acc);
   // pass 2: majors in order, minors ascending within a major => each (wave, slab) segment comes out
   // sorted by (local major, minor)
-  for (int32_t r = 0; r < nMajor; ++r) {
-    const int32_t len = csr.beg[r + 1] - csr.beg[r];
-    if (len > longLimit) continue;
-    const size_t w = (size_t)(r / Rw);
-    const uint32_t lr = (uint32_t)(r % Rw);
-    for (int32_t p = csr.beg[r]; p < csr.beg[r + 1]; ++p) {
-      const int32_t c = csr.idx[p];
-      const int32_t q = pos[w * S + (c >> slabWidthLog2)]++;
-      out.ent[q] = (lr << out.minorBits) | (uint32_t)c;
-      out.val[q] = csr.val[p];
+  for (int32_t w = 0; w < nWaves; ++w)
+    for (int32_t r = out.waveBeg[w]; r < out.waveBeg[w + 1]; ++r) {
+      const int32_t len = csr.beg[r + 1] - csr.beg[r];
+      if (len > longLimit) continue;
+      const uint32_t lr = (uint32_t)(r - out.waveBeg[w]);
+      for (int32_t p = csr.beg[r]; p < csr.beg[r + 1]; ++p) {
+        const int32_t c = csr.idx[p];
+        const int32_t q = pos[(size_t)w * S + (c >> slabWidthLog2)]++;
+        out.ent[q] = (lr << out.minorBits) | (uint32_t)c;
+        out.val[q] = csr.val[p];
+      }
     }
-  }
 }
 
 }  // namespace pdlp

@@ -113,30 +113,50 @@ LongPlan planLong(const std::vector<int32_t>& beg, const std::vector<int32_t>& l
 // gather.  Here every wave sweeps the gathered vector slab by slab (slab = 2^slabWidthLog2 consecutive
 // minor indices, 1 MB by default), in step with all the others, so the slab being gathered from stays
 // in every XCD's L2.  The unit of ownership is the WAVE: a block of 16 waves (one block per CU) owns
-// rowsPerBlock = 16*rowsPerWave consecutive majors, wave w of it the majors [w*rowsPerWave,
-// (w+1)*rowsPerWave).  A wave's nonzeros are ONE dense stream sorted by (minor >> slabWidthLog2, local
-// major, minor): no windows, no per-slab padding.  An entry packs (localMajor << minorBits | minor) with
-// minorBits = 32 - ceil(log2(rowsPerWave)): the GLOBAL minor, so the kernel needs no slab table at all —
-// a slab boundary inside a 64-entry group shows up as a descent of the local major.  rowsPerWave is
-// chosen so that the blocks just cover the 256 CUs of an MI355X (every CU then does the same work per
-// slab).  Majors longer than `longLimit` are left out (marked in longMask) and handled by the CSR
-// kernel.
-struct SlabLayout {
-  int32_t rowsPerBlock = 0, rowsPerWave = 0, nBlocks = 0, minorBits = 0, slabWidthLog2 = 0;
-  std::vector<int32_t> wavePtr;   // [16*nBlocks+1] entry offsets
-  std::vector<uint32_t> ent;      // [nnzShort]
-  std::vector<double> val;        // [nnzShort]
-  std::vector<uint32_t> longMask; // [nBlocks * rowsPerBlock/32]
-  Compressed longCsr;             // compacted long majors
-  std::vector<int32_t> longMap;   // compact index -> major
-};
+// the consecutive majors [waveBeg[16 b], waveBeg[16 b + 16]), wave w of it [waveBeg[16 b + w],
+// waveBeg[16 b + w + 1]).  Blocks and waves are cut by WORK, not by major count (slabPartition below):
+// with skewed major lengths a block of equal major COUNT streams up to twice the mean number of entries
+// and the launch is its slowest block (round 4, per-block phase profile).  A wave's nonzeros are ONE
+// dense stream sorted by (minor >> slabWidthLog2, local major, minor): no windows, no per-slab padding.
+// An entry packs (localMajor << minorBits | minor), local = major - the wave's first major, with the
+// GLOBAL minor, so the kernel needs no slab table at all — a slab boundary inside a 64-entry group
+// shows up as a descent of the local major.  Majors longer than `longLimit` are left out (marked in
+// longMask, one bit per major) and handled as segment tasks.
 constexpr int32_t kSlabWidthLog2 = 17;  // 1 MB slabs: 56.2 vs 57.0 us per A x at the bench size (15..18 within 1.5 %)
 constexpr int32_t kSlabWavesPerBlock = 16;
 constexpr int32_t kSlabTargetBlocks = 256;  // CUs of an MI355X
-// Majors per wave for an operand of this shape: even, in [16, 1024], ceil(nMajor / (256*16)) when that
-// fits; halved until the minor index fits the entry packing; 0 when it cannot (nMinor > 2^28: the
-// caller then uses the CSR stream kernel).
-int32_t slabRowsPerWave(int32_t nMajor, int32_t nMinor);
+constexpr int32_t kSlabBlockRowCap = 16384; // majors per block: 128 KB of LDS accumulators (gfx950 has 160 KB per CU)
+constexpr int32_t kSlabMinRowsPerBlock = 256;
+constexpr int32_t kSlabMajorCost = 2;       // work of a major besides its entries (epilogue), in entries
+
+// The partition of the majors over blocks and waves.  Work of major r = (its entries if it is not a long major)
+// + kSlabMajorCost.  nBlocks = ceil(nMajor / 256) capped at 256 (more only when 256 blocks of 16384 majors do
+// not hold the operand).  Blocks are filled one after the other: block b takes majors until its work reaches
+// ceil(work left / blocks left) — the major that crosses the mark included — but at least one, at most
+// kSlabBlockRowCap, and never so few / many that the blocks behind it could not hold / would not get the
+// rest; the 16 waves of a block are filled the same way from the block's majors (cap: 2^(32 - minorBits)
+// majors, the local-major field of an entry).  Sequential and exact in integers: the device-side set-up
+// (pdlp_setup.hip) calls this same function on the downloaded major starts, oracle/gpu_order.h restates it.
+struct SlabPartition {
+  int32_t nBlocks = 0, minorBits = 0, maxRowsPerBlock = 0;
+  std::vector<int32_t> waveBeg;  // [16*nBlocks+1] first major of every wave
+  int32_t blockBeg(int32_t b) const { return waveBeg[(size_t)b * kSlabWavesPerBlock]; }
+};
+// false: the minor index does not fit the entry packing (nMinor > 2^28: the caller uses the CSR stream kernel)
+bool slabFits(int32_t nMajor, int32_t nMinor);
+SlabPartition slabPartition(const int32_t* beg, int32_t nMajor, int32_t nMinor, int32_t longLimit);
+
+struct SlabLayout {
+  int32_t rowsPerBlock = 0;  // most majors in one block (LDS accumulators)
+  int32_t nBlocks = 0, minorBits = 0, slabWidthLog2 = 0;
+  std::vector<int32_t> waveBeg;   // [16*nBlocks+1] first major of every wave
+  std::vector<int32_t> wavePtr;   // [16*nBlocks+1] entry offsets
+  std::vector<uint32_t> ent;      // [nnzShort]
+  std::vector<double> val;        // [nnzShort]
+  std::vector<uint32_t> longMask; // [ceil(nMajor/32)] bit r: major r is a long one
+  Compressed longCsr;             // compacted long majors
+  std::vector<int32_t> longMap;   // compact index -> major
+};
 void buildSlabLayout(const Compressed& csr, int32_t nMajor, int32_t nMinor, int32_t longLimit, int32_t slabWidthLog2,
                      SlabLayout& out);
 

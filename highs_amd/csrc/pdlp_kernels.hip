@@ -435,8 +435,8 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
 }
 
 // Slab SpMV (layout: pdlp_host.hpp SlabLayout) — for operands whose gathered vector does not fit an
-// XCD's 4 MB L2.  One 1024-thread block per CU; each of its 16 WAVES owns rowsPerBlock/16 consecutive
-// majors and streams its own nonzeros — one dense list sorted by (slab of the gathered vector, local
+// XCD's 4 MB L2.  One 1024-thread block per CU; each of its 16 WAVES owns a run of consecutive majors
+// (blocks and waves are cut by work, pdlp_host.hpp slabPartition) and streams its own nonzeros — one dense list sorted by (slab of the gathered vector, local
 // major, minor) — 64 at a time through a register pipeline: entry/value loads kSlabSlots groups ahead of
 // the accumulation, the gather one group ahead, all counted on vmcnt by the compiler.  A workgroup
 // barrier per group keeps the CU's waves on the same slab (pacing only: a wave touches nothing but its
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
     return;
   }
   // dynamic LDS: acc[R] f64 | stg[16][64] f64 | scratch[2][16] f64 | (kAtyFused) trial scratch[4][4] f64, DevState
-  const int R = a.S.rowsPerBlock;
+  const int R = (a.S.rowsPerBlock + 1) & ~1;  // (the most majors any block owns; even: the strips behind stay 16-byte aligned)
   double* acc = reinterpret_cast<double*>(smem);
   double* stgAll = acc + R;
   double(*scratch)[kWaves] = reinterpret_cast<double(*)[kWaves]>(stgAll + kSlabThreads);
@@ -494,14 +494,14 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
   const int blk = a.xcdMap ? xcdContiguousBlock(blockIdx.x, a.S.nBlocks) : (int)blockIdx.x;
-  const int Rw = R / kWaves;
   const int mb = a.S.minorBits;
   const uint32_t mmask = (1u << mb) - 1u;
-  const int rBase = blk * R;
-  const int rEnd = (rBase + R < a.S.nMajor) ? rBase + R : a.S.nMajor;
   const int gw = blk * kWaves + wave;
+  const int rBase = ldUniform(a.S.waveBeg + blk * kWaves), rEnd = ldUniform(a.S.waveBeg + blk * kWaves + kWaves);  // never empty
+  const int wBeg = ldUniform(a.S.waveBeg + gw);
+  const int Rw = ldUniform(a.S.waveBeg + gw + 1) - wBeg;
   const int e0 = ldUniform(a.S.wavePtr + gw), e1 = ldUniform(a.S.wavePtr + gw + 1);
-  double* wacc = acc + wave * Rw;
+  double* wacc = acc + (wBeg - rBase);
   double* stg = stgAll + wave * kWave;
   Epi<EPI> epi(a);
   const double* __restrict__ in = epi.input();
@@ -626,12 +626,12 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
   if (a.S.noPace) __syncthreads();  // (free-running waves: every wave's accumulators are final before the epilogue reads them)
 
   profStamp(0);
-  const uint32_t* __restrict__ mask = a.S.longMask + (size_t)blk * (R / 32);
+  const uint32_t* __restrict__ mask = a.S.longMask;  // bit r: major r is a long one (its segment tasks own it)
+  auto longMajor = [&](int r) { return ((mask[r >> 5] >> (r & 31)) & 1u) != 0u; };
 #pragma unroll
   for (int k = 0; k < kSlabPre; ++k) {
     const int lr = tid + k * kSlabThreads;
-    if (rBase + lr < rEnd && !((mask[lr >> 5] >> (lr & 31)) & 1u))  // (long major: the CSR side kernel owns it)
-      epi.apply(rBase + lr, acc[lr], pre[k]);
+    if (rBase + lr < rEnd && !longMajor(rBase + lr)) epi.apply(rBase + lr, acc[lr], pre[k]);
   }
   // (more than kSlabPre majors per thread — 2.1 M columns in 256 blocks: the operands of the next kSlabPre majors are
   // fetched together, one memory round trip per batch instead of one per major; same majors in the same order)
@@ -645,7 +645,7 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
 #pragma unroll
     for (int k = 0; k < kSlabPre; ++k) {
       const int lr = lr0 + k * kSlabThreads;
-      if (rBase + lr < rEnd && !((mask[lr >> 5] >> (lr & 31)) & 1u)) epi.apply(rBase + lr, acc[lr], more[k]);
+      if (rBase + lr < rEnd && !longMajor(rBase + lr)) epi.apply(rBase + lr, acc[lr], more[k]);
     }
   }
   if (EPI == kAtyFused) {  // xSum of the own columns: in flight across the barrier and the decision
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
       xOut[r] = t;  // gathered by the A x+ kernel: ordinary store
     };
     // (a long column's A'y+ was computed by a segment task, maybe in another block: taken from memory, agent scope)
-    auto isLong = [&](int lr) { return a.inlineTasks && ((mask[lr >> 5] >> (lr & 31)) & 1u) != 0u; };
+    auto isLong = [&](int lr) { return a.inlineTasks && longMajor(rBase + lr); };
 #pragma unroll
     for (int k = 0; k < kSlabPre; ++k) {
       const int lr = tid + k * kSlabThreads;
@@ -1136,7 +1136,7 @@ void launchSpmv(const MatView& M, SpmvArgs a, hipStream_t s) {
   const int nTasks = M.lng.nTasks;
   if (M.useSlab && M.slab.nBlocks > 0) {
     a.S = M.slab;
-    const size_t lds = (size_t)M.slab.rowsPerBlock * 8 + kSlabThreads * 8 + 2 * (kSlabThreads / kWave) * 8;
+    const size_t lds = (size_t)((M.slab.rowsPerBlock + 1) & ~1) * 8 + kSlabThreads * 8 + 2 * (kSlabThreads / kWave) * 8;
     const dim3 grid(M.slab.nBlocks + (nTasks + M.lng.taskGroup - 1) / M.lng.taskGroup);  // one task group per extra workgroup
     // (gather distance 2 / 3 with 4 / 6 slots measured the same as (3, 1) on the random and on the structured LP, round 3)
     // segment tasks ride along: register budget for two resident blocks per CU, so that a task block runs NEXT to a streaming one
@@ -1166,7 +1166,7 @@ void launchSpmvAtyInteract(const MatView& At, const IterVecs& v, const DevState*
 }
 namespace {
 size_t fusedLds(const MatView& At) {
-  return (size_t)At.slab.rowsPerBlock * 8 + kSlabThreads * 8 + 2 * (kSlabThreads / kWave) * 8 + 4 * (kVecThreads / kWave) * 8 +
+  return (size_t)((At.slab.rowsPerBlock + 1) & ~1) * 8 + kSlabThreads * 8 + 2 * (kSlabThreads / kWave) * 8 + 4 * (kVecThreads / kWave) * 8 +
          sizeof(DevState) + 16;
 }
 }  // namespace
@@ -1307,25 +1307,30 @@ void launchDiffNorm2(const double* a, const double* b, int32_t len, double* part
   hipLaunchKernelGGL(k_diff_norm2, dim3(nBlocks), dim3(kVecThreads), 0, s, a, b, len, partials);
 }
 namespace {
-// Per block of R consecutive majors: smallest and largest minor index over its majors of at most `longLimit` entries
-// (CSR with ascending minors: the first and the last entry of a major) and their entry count.
+// Per slab block (majors [waveBeg[16 b], waveBeg[16 b + 16])): smallest and largest minor index over its majors of at most
+// `longLimit` entries (CSR with ascending minors: the first and the last entry of a major) and their entry count.
 __global__ __launch_bounds__(kVecThreads) void k_block_span(const int32_t* __restrict__ beg, const int32_t* __restrict__ idx, int nMajor,
-                                                            int R, int longLimit, int32_t* lo, int32_t* hi, int32_t* cnt) {
+                                                            const int32_t* __restrict__ waveBeg, int nBlocks, int longLimit, int32_t* lo,
+                                                            int32_t* hi, int32_t* cnt) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nMajor) return;
   const int p0 = beg[r], p1 = beg[r + 1];
   if (p1 <= p0 || p1 - p0 > longLimit) return;
-  const int b = r / R;
+  int b = 0, e = nBlocks;  // last block whose first major is <= r
+  while (e - b > 1) {
+    const int mid = (b + e) >> 1;
+    if (waveBeg[mid * 16] <= r) b = mid; else e = mid;
+  }
   atomicMin(lo + b, idx[p0]);
   atomicMax(hi + b, idx[p1 - 1]);
   atomicAdd(cnt + b, p1 - p0);
 }
 }  // namespace
-void launchBlockSpan(const int32_t* beg, const int32_t* idx, int32_t nMajor, int32_t R, int32_t longLimit, int32_t* lo, int32_t* hi,
-                     int32_t* cnt, hipStream_t s) {
+void launchBlockSpan(const int32_t* beg, const int32_t* idx, int32_t nMajor, const int32_t* waveBeg, int32_t nBlocks, int32_t longLimit,
+                     int32_t* lo, int32_t* hi, int32_t* cnt, hipStream_t s) {
   if (nMajor <= 0) return;
-  hipLaunchKernelGGL(k_block_span, dim3((nMajor + kVecThreads - 1) / kVecThreads), dim3(kVecThreads), 0, s, beg, idx, nMajor, R, longLimit,
-                     lo, hi, cnt);
+  hipLaunchKernelGGL(k_block_span, dim3((nMajor + kVecThreads - 1) / kVecThreads), dim3(kVecThreads), 0, s, beg, idx, nMajor, waveBeg,
+                     nBlocks, longLimit, lo, hi, cnt);
 }
 void launchDot(const double* a, const double* b, int32_t len, double* partials, int32_t nBlocks, hipStream_t s) {
   hipLaunchKernelGGL(k_dot, dim3(nBlocks), dim3(kVecThreads), 0, s, a, b, len, partials);

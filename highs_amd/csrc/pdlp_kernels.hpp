@@ -147,15 +147,17 @@ struct LongMat {
 };
 
 // Slab layout (pdlp_host.hpp SlabLayout), device pointers.  One 1024-thread block = 16 waves, each
-// owning rowsPerBlock/16 consecutive majors and its own sorted entry list.
+// owning the consecutive majors [waveBeg[gw], waveBeg[gw+1]) (cut by work, pdlp_host.hpp slabPartition) and its own
+// sorted entry list.
 constexpr int kSlabThreads = 1024;
 constexpr int kSlabMaxRows = 16384;  // majors per block (LDS accumulators: 128 KB of the 160 KB)
 struct SlabMat {
   const int32_t* wavePtr;    // [16*nBlocks+1] entry offsets per wave
   const uint32_t* ent;       // [nnz] (localMajor << minorBits | minor)
   const double* val;         // [nnz]
-  const uint32_t* longMask;  // [nBlocks*rowsPerBlock/32]
-  int32_t nMajor, nBlocks, rowsPerBlock, minorBits;
+  const uint32_t* longMask;  // [ceil(nMajor/32)+1] bit r: major r is a long one
+  const int32_t* waveBeg;    // [16*nBlocks+1] first major of every wave
+  int32_t nMajor, nBlocks, rowsPerBlock, minorBits;  // rowsPerBlock: the most majors any block owns (LDS accumulators)
   // 1: no block barrier per 64-entry group.  The barrier keeps the CU's waves on the same slab of the gathered vector
   // (a random matrix needs that: 50 -> 58 us at 1M x 1M without); an operand whose blocks touch little of the gathered
   // vector anyway runs faster free (block-angular LP of bench.py --config c: 31.8 -> 29.0 us).  Chosen per operand by
@@ -378,7 +380,7 @@ int32_t vecBlocks(int32_t len);  // grid size used by the vector/statistics kern
 
 // ---- set-up: which slab width suits an operand ----
 // lo/hi/cnt [ceil(nMajor/R)], pre-set to INT_MAX / -1 / 0: column span and entry count of each block's short majors
-void launchBlockSpan(const int32_t* beg, const int32_t* idx, int32_t nMajor, int32_t R, int32_t longLimit, int32_t* lo, int32_t* hi,
-                     int32_t* cnt, hipStream_t s);
+void launchBlockSpan(const int32_t* beg, const int32_t* idx, int32_t nMajor, const int32_t* waveBeg, int32_t nBlocks, int32_t longLimit,
+                     int32_t* lo, int32_t* hi, int32_t* cnt, hipStream_t s);
 
 }  // namespace pdlp

@@ -230,21 +230,34 @@ __global__ void k_absmax_partial(const double* __restrict__ val, int64_t nnz, do
 }
 
 // ---- slab layout ------------------------------------------------------------------
+// waveOf[r] = the wave that owns major r (waveBeg: first major of every wave, ascending; empty waves repeat a value)
+__global__ void k_wave_of(const int32_t* __restrict__ waveBeg, int nWaves, int nMajor, int32_t* waveOf) {
+  GSTRIDE(r, nMajor) {
+    int lo = 0, hi = nWaves;  // last w with waveBeg[w] <= r
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (waveBeg[mid] <= (int)r) lo = mid; else hi = mid;
+    }
+    waveOf[r] = lo;
+  }
+}
 __global__ void k_slab_keys(const int32_t* __restrict__ beg, const int32_t* __restrict__ major,
-                            const int32_t* __restrict__ idx, int64_t nnz, int Rw, int S, int W, int longLimit,
-                            uint32_t keyMax, uint32_t* keys) {
+                            const int32_t* __restrict__ idx, int64_t nnz, const int32_t* __restrict__ waveOf, int S, int W,
+                            int longLimit, uint32_t keyMax, uint32_t* keys) {
   GSTRIDE(p, nnz) {
     const int r = major[p];
     const int len = beg[r + 1] - beg[r];
-    keys[p] = len > longLimit ? keyMax : (uint32_t)(r / Rw) * (uint32_t)S + ((uint32_t)idx[p] >> W);
+    keys[p] = len > longLimit ? keyMax : (uint32_t)waveOf[r] * (uint32_t)S + ((uint32_t)idx[p] >> W);
   }
 }
 __global__ void k_slab_entries(const int32_t* __restrict__ perm, const int32_t* __restrict__ major,
-                               const int32_t* __restrict__ idx, const double* __restrict__ valIn, int64_t nShort, int Rw,
-                               int minorBits, uint32_t* ent, double* val) {
+                               const int32_t* __restrict__ idx, const double* __restrict__ valIn, int64_t nShort,
+                               const int32_t* __restrict__ waveOf, const int32_t* __restrict__ waveBeg, int minorBits,
+                               uint32_t* ent, double* val) {
   GSTRIDE(q, nShort) {
     const int p = perm[q];
-    ent[q] = ((uint32_t)(major[p] % Rw) << minorBits) | (uint32_t)idx[p];
+    const int r = major[p];
+    ent[q] = ((uint32_t)(r - waveBeg[waveOf[r]]) << minorBits) | (uint32_t)idx[p];
     val[q] = valIn[p];
   }
 }
@@ -260,14 +273,12 @@ __global__ void k_wave_ptr(const uint32_t* __restrict__ sortedKeys, int64_t nnz,
     out[w] = (int32_t)lo;
   }
 }
-__global__ void k_long_mask(const int32_t* __restrict__ beg, int nMajor, int R, int longLimit, int nWords,
+__global__ void k_long_mask(const int32_t* __restrict__ beg, int nMajor, int longLimit, int nWords,
                             uint32_t* mask, int32_t* longFlag) {
-  GSTRIDE(w, nWords) {
-    const int wordsPerBlock = R / 32;
-    const int b = (int)(w / wordsPerBlock), wi = (int)(w % wordsPerBlock);
+  GSTRIDE(w, nWords) {  // bit r of the mask: major r is a long one
     uint32_t bits = 0;
     for (int k = 0; k < 32; ++k) {
-      const int r = b * R + wi * 32 + k;
+      const int64_t r = w * 32 + k;
       if (r < nMajor && beg[r + 1] - beg[r] > longLimit) bits |= 1u << k;
     }
     mask[w] = bits;
@@ -566,31 +577,42 @@ void gpuPrepare(const pdlp_problem_t& P, bool doScale, hipStream_t s, DeviceProb
   for (double v : hb) D.sumRhs2 += v * v;
 }
 
+void gpuSlabPartition(const DeviceCsrData& M, int32_t longLimit, hipStream_t s, DeviceSlabLayout& L) {
+  // the partition by work is sequential and cheap: on the host, from the major starts (4 bytes per major over PCIe),
+  // by the same function the host-side build uses
+  std::vector<int32_t> hb((size_t)M.nMajor + 1);
+  M.beg.download(hb.data(), hb.size(), s);
+  PDLP_HIP(hipStreamSynchronize(s));
+  SlabPartition P = slabPartition(hb.data(), M.nMajor, M.nMinor, longLimit);
+  L.rowsPerBlock = P.maxRowsPerBlock;
+  L.nBlocks = P.nBlocks;
+  L.minorBits = P.minorBits;
+  L.hostWaveBeg = std::move(P.waveBeg);
+  L.waveBeg.alloc(L.hostWaveBeg.size());
+  L.waveBeg.upload(L.hostWaveBeg.data(), L.hostWaveBeg.size(), s);
+  PDLP_HIP(hipStreamSynchronize(s));
+}
+
 void gpuBuildSlabLayout(const DeviceCsrData& M, int32_t longLimit, int32_t W, hipStream_t s, DeviceSlabLayout& L) {
   const int32_t nMajor = M.nMajor, nMinor = M.nMinor;
   const int64_t nnz = M.nnz;
-  const int32_t Rw = slabRowsPerWave(nMajor, nMinor);
-  if (Rw == 0) throw std::runtime_error("slab layout: minor index does not fit the entry packing");
-  const int32_t R = Rw * kSlabWavesPerBlock;
-  int rb = 0;
-  while ((1 << rb) < Rw) ++rb;
-  L.rowsPerWave = Rw;
-  L.rowsPerBlock = R;
-  L.nBlocks = (nMajor + R - 1) / R;
-  L.minorBits = 32 - rb;
+  if (L.hostWaveBeg.empty()) gpuSlabPartition(M, longLimit, s, L);
   const int32_t nWaves = L.nBlocks * kSlabWavesPerBlock;
+  DeviceArray<int32_t> waveOf;
+  waveOf.alloc((size_t)std::max(nMajor, 1));
+  if (nMajor > 0) hipLaunchKernelGGL(k_wave_of, dim3(gridFor(nMajor)), dim3(kT), 0, s, L.waveBeg.get(), nWaves, nMajor, waveOf.get());
   const int32_t S = std::max(1, (int32_t)(((int64_t)nMinor + ((int64_t)1 << W) - 1) >> W));
   const int64_t nSeg = (int64_t)nWaves * S;
   if (nSeg >= (int64_t)0x7fffffff) throw std::runtime_error("slab layout: too many segments");
   const uint32_t keyMax = (uint32_t)nSeg;  // sorts after every real segment
 
   // long majors: mask, map, compact CSR
-  const int nWords = L.nBlocks * (R / 32);
-  L.longMask.alloc((size_t)std::max(nWords, 1));
+  const int nWords = (nMajor + 31) / 32 + 1;
+  L.longMask.alloc((size_t)nWords);
   DeviceArray<int32_t> longFlag, longRank;
   longFlag.alloc((size_t)std::max(nMajor, 1));
   longRank.alloc((size_t)std::max(nMajor, 1));
-  hipLaunchKernelGGL(k_long_mask, dim3(gridFor(std::max(nWords, nMajor))), dim3(kT), 0, s, M.beg.get(), nMajor, R,
+  hipLaunchKernelGGL(k_long_mask, dim3(gridFor(std::max(nWords, nMajor))), dim3(kT), 0, s, M.beg.get(), nMajor,
                      longLimit, nWords, L.longMask.get(), longFlag.get());
   exclusiveSum(longFlag.get(), longRank.get(), nMajor, s);
   L.nLong = nMajor > 0 ? fetchOne(longRank.get() + (nMajor - 1), s) + fetchOne(longFlag.get() + (nMajor - 1), s) : 0;
@@ -632,8 +654,8 @@ void gpuBuildSlabLayout(const DeviceCsrData& M, int32_t longLimit, int32_t W, hi
   DeviceArray<int32_t> perm;
   keys.alloc((size_t)std::max<int64_t>(nnz, 1));
   if (nnz > 0)
-    hipLaunchKernelGGL(k_slab_keys, dim3(gridFor(nnz)), dim3(kT), 0, s, M.beg.get(), M.major.get(), M.idx.get(), nnz, Rw,
-                       S, W, longLimit, keyMax, keys.get());
+    hipLaunchKernelGGL(k_slab_keys, dim3(gridFor(nnz)), dim3(kT), 0, s, M.beg.get(), M.major.get(), M.idx.get(), nnz,
+                       waveOf.get(), S, W, longLimit, keyMax, keys.get());
   sortByKey(keys.get(), nnz, (uint64_t)keyMax, sortedKeys, perm, s);
   L.wavePtr.alloc((size_t)nWaves + 1);
   hipLaunchKernelGGL(k_wave_ptr, dim3(gridFor(nWaves + 1)), dim3(kT), 0, s, sortedKeys.get(), nnz, nWaves, S,
@@ -645,7 +667,7 @@ void gpuBuildSlabLayout(const DeviceCsrData& M, int32_t longLimit, int32_t W, hi
   L.val.zero(s);
   if (L.nnzShort > 0)
     hipLaunchKernelGGL(k_slab_entries, dim3(gridFor(L.nnzShort)), dim3(kT), 0, s, perm.get(), M.major.get(),
-                       M.idx.get(), M.val.get(), L.nnzShort, Rw, L.minorBits, L.ent.get(), L.val.get());
+                       M.idx.get(), M.val.get(), L.nnzShort, waveOf.get(), L.waveBeg.get(), L.minorBits, L.ent.get(), L.val.get());
   PDLP_HIP(hipStreamSynchronize(s));
 }
 

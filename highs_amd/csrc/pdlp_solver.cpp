@@ -45,7 +45,7 @@ int32_t slabWidthFor(const DevSwitches& sw, bool fewTiles) {
 // mode (PDLP_MI355X_SLAB or auto) -> is the slab layout used for an operand of this shape
 bool chooseSlab(int mode, int32_t nMajor, int32_t nMinor) {
   const bool want = mode == 1 || (mode < 0 && nMinor >= kSlabAutoMinor);
-  return want && slabRowsPerWave(nMajor, nMinor) != 0;  // minors that do not fit the packing: CSR stream
+  return want && nMajor > 0 && slabFits(nMajor, nMinor);  // minors that do not fit the packing: CSR stream
 }
 }  // namespace
 
@@ -120,17 +120,21 @@ void DeviceMatrix::upload(const Compressed& cIn, int32_t nMajor_, int32_t nMinor
   const Compressed* c = &cIn;
   SlabLayout L;
   if (useSlab) {
-    const int32_t R = slabRowsPerWave(nMajor_, nMinor_) * 16, nB = (nMajor_ + R - 1) / R;
+    const SlabPartition part = slabPartition(cIn.beg.data(), nMajor_, nMinor_, kSlabLongLimit);
+    const int32_t nB = part.nBlocks;
     std::vector<int32_t> lo((size_t)nB, INT_MAX), hi((size_t)nB, -1), cnt((size_t)nB, 0);
-    for (int32_t r = 0; r < nMajor_; ++r) {
-      const int32_t p0 = cIn.beg[r], p1 = cIn.beg[r + 1];
-      if (p1 <= p0 || p1 - p0 > kSlabLongLimit) continue;
-      lo[r / R] = std::min(lo[r / R], cIn.idx[p0]); hi[r / R] = std::max(hi[r / R], cIn.idx[p1 - 1]); cnt[r / R] += p1 - p0;
-    }
+    for (int32_t b = 0; b < nB; ++b)
+      for (int32_t r = part.blockBeg(b); r < part.blockBeg(b + 1); ++r) {
+        const int32_t p0 = cIn.beg[r], p1 = cIn.beg[r + 1];
+        if (p1 <= p0 || p1 - p0 > kSlabLongLimit) continue;
+        lo[b] = std::min(lo[b], cIn.idx[p0]); hi[b] = std::max(hi[b], cIn.idx[p1 - 1]); cnt[b] += p1 - p0;
+      }
     buildSlabLayout(cIn, nMajor_, nMinor_, kSlabLongLimit, slabWidthFor(sw, touchesFewTiles(lo, hi, cnt)), L);
     if (L.rowsPerBlock > kSlabMaxRows) throw std::runtime_error("slab layout: too many majors per block");
     wavePtr.alloc(L.wavePtr.size());
     wavePtr.upload(L.wavePtr.data(), L.wavePtr.size(), s);
+    waveBeg.alloc(L.waveBeg.size());
+    waveBeg.upload(L.waveBeg.data(), L.waveBeg.size(), s);
     ent.alloc(L.ent.size() + 1);  // one pad element: an empty wave still reads its first entry
     slabVal.alloc(L.val.size() + 1);
     longMask.alloc(L.longMask.size());
@@ -139,7 +143,7 @@ void DeviceMatrix::upload(const Compressed& cIn, int32_t nMajor_, int32_t nMinor
     ent.upload(L.ent.data(), L.ent.size(), s);
     slabVal.upload(L.val.data(), L.val.size(), s);
     longMask.upload(L.longMask.data(), L.longMask.size(), s);
-    slab = SlabMat{wavePtr.get(), ent.get(), slabVal.get(), longMask.get(), nMajor_, L.nBlocks, L.rowsPerBlock, L.minorBits};
+    slab = SlabMat{wavePtr.get(), ent.get(), slabVal.get(), longMask.get(), waveBeg.get(), nMajor_, L.nBlocks, L.rowsPerBlock, L.minorBits};
     c = &L.longCsr;
   }
   const int32_t nCsrMajor = useSlab ? (int32_t)L.longMap.size() : nMajor_;
@@ -164,27 +168,29 @@ void DeviceMatrix::buildFromDevice(DeviceCsrData& M, const DevSwitches& sw, hipS
   int32_t nCsrMajor = nMajor;
   bool localM = false;
   if (useSlab) {
-    const int32_t R = slabRowsPerWave(M.nMajor, M.nMinor) * 16, nB = (M.nMajor + R - 1) / R;
+    DeviceSlabLayout L;
+    gpuSlabPartition(M, kSlabLongLimit, s, L);
+    const int32_t nB = L.nBlocks;
     {  // per-block span of the short majors, from the CSR that is already in HBM
       std::vector<int32_t> lo((size_t)nB, INT_MAX), hi((size_t)nB, -1), cnt((size_t)nB, 0);
       DeviceArray<int32_t> dLo, dHi, dCn;
       dLo.alloc(nB); dHi.alloc(nB); dCn.alloc(nB);
       dLo.upload(lo.data(), nB, s); dHi.upload(hi.data(), nB, s); dCn.upload(cnt.data(), nB, s);
-      launchBlockSpan(M.beg.get(), M.idx.get(), M.nMajor, R, kSlabLongLimit, dLo.get(), dHi.get(), dCn.get(), s);
+      launchBlockSpan(M.beg.get(), M.idx.get(), M.nMajor, L.waveBeg.get(), nB, kSlabLongLimit, dLo.get(), dHi.get(), dCn.get(), s);
       dLo.download(lo.data(), nB, s); dHi.download(hi.data(), nB, s); dCn.download(cnt.data(), nB, s);
       PDLP_HIP(hipStreamSynchronize(s));
       localM = touchesFewTiles(lo, hi, cnt);
     }
-    DeviceSlabLayout L;
     // (an operand whose blocks touch few 16384-entry tiles of the gathered vector densely gets slabs of that width: its
     // runs of equal majors are shorter, more lanes add in parallel — bench.py --config c, A x: 44.0 -> 41.1 us)
     gpuBuildSlabLayout(M, kSlabLongLimit, slabWidthFor(sw, localM), s, L);
     if (L.rowsPerBlock > kSlabMaxRows) throw std::runtime_error("slab layout: too many majors per block");
     wavePtr = std::move(L.wavePtr);
+    waveBeg = std::move(L.waveBeg);
     ent = std::move(L.ent);
     slabVal = std::move(L.val);
     longMask = std::move(L.longMask);
-    slab = SlabMat{wavePtr.get(), ent.get(), slabVal.get(), longMask.get(), nMajor, L.nBlocks, L.rowsPerBlock, L.minorBits};
+    slab = SlabMat{wavePtr.get(), ent.get(), slabVal.get(), longMask.get(), waveBeg.get(), nMajor, L.nBlocks, L.rowsPerBlock, L.minorBits};
     beg = std::move(L.longCsr.beg);
     idx = std::move(L.longCsr.idx);
     val = std::move(L.longCsr.val);

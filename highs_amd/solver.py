@@ -376,10 +376,10 @@ class Prepared:
             _check(lib().pdlp_mi355x_host_slab_layout(C.byref(F), which, slab_long_limit, C.byref(SL)), "slab_layout")
             nb, R = SL.n_blocks, SL.rows_per_block
             self._slabs[which] = dict(
-                rows_per_block=R, rows_per_wave=SL.rows_per_wave, n_blocks=nb, minor_bits=SL.minor_bits,
+                rows_per_block=R, n_blocks=nb, minor_bits=SL.minor_bits, wave_beg=g(SL.wave_beg, 16 * nb + 1, np.int64),
                 slab_width_log2=SL.slab_width_log2, wave_ptr=g(SL.wave_ptr, 16 * nb + 1, np.int64),
                 ent=g(SL.ent, SL.nnz_short, np.uint32), val=g(SL.val, SL.nnz_short, np.float64),
-                long_mask=g(SL.long_mask, nb * (R // 32), np.uint32), long_map=g(SL.long_map, SL.n_long, np.int32))
+                long_mask=g(SL.long_mask, (n if which else m) // 32 + 1, np.uint32), long_map=g(SL.long_map, SL.n_long, np.int32))
             lib().pdlp_mi355x_free_slab_layout(C.byref(SL))
         self._parts = {}
         for w in (1, 2, 3, 4, 8):

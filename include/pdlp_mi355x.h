@@ -294,13 +294,17 @@ int pdlp_mi355x_row_partition(const pdlp_prepared_t* prep, int32_t world,
  * host for inspection by the CPU tests: which = 0 for A (rows), 1 for A' (columns).  Free with
  * pdlp_mi355x_free_slab_layout. */
 typedef struct pdlp_slab_layout {
-  int32_t rows_per_block, rows_per_wave, n_blocks, minor_bits, slab_width_log2, n_long;
+  int32_t rows_per_block; /* the most majors any block owns (size of the LDS accumulators) */
+  int32_t rows_per_wave;  /* reserved (0): waves own variable runs of majors, see wave_beg */
+  int32_t n_blocks, minor_bits, slab_width_log2, n_long;
   int64_t nnz_short;
-  int32_t* wave_ptr;  /* [16*n_blocks+1] */
-  uint32_t* ent;      /* [nnz_short] (local_major << minor_bits | minor), local to the owning wave */
+  int32_t* wave_ptr;  /* [16*n_blocks+1] entry offsets */
+  uint32_t* ent;      /* [nnz_short] (local_major << minor_bits | minor), local = major - first major of the owning wave */
   double* val;        /* [nnz_short] */
-  uint32_t* long_mask;/* [n_blocks*rows_per_block/32] */
+  uint32_t* long_mask;/* [n_major/32 + 1] bit r: major r is a long one */
   int32_t* long_map;  /* [n_long] */
+  int32_t* wave_beg;  /* [16*n_blocks+1] first major of every wave: blocks and waves are cut by work
+                         (entries of the short majors + 2 per major), not by major count */
 } pdlp_slab_layout_t;
 int pdlp_mi355x_host_slab_layout(const pdlp_prepared_t* prep, int32_t which,
                                  int32_t long_limit, pdlp_slab_layout_t* out);

@@ -15,21 +15,48 @@
 enum { G_T = 256, G_WAVE = 64, G_CHUNK = 2048, G_CHUNK_SMALL = 512, G_MAXMAJ = 2048, G_MAXGRID = 2048 };
 /* spmvChunkFor (pdlp_kernels.hpp): work-plan block size of a CSR stream with this many nonzeros */
 static inline int g_chunk_for(long nnz) { return nnz < (1L << 18) ? G_CHUNK_SMALL : G_CHUNK; }
-/* slab SpMV (k_spmv_slab): 1024-thread blocks of 16 waves, rows per wave by slabRowsPerWave (pdlp_host.cpp) */
-enum { G_SLAB_T = 1024, G_SLAB_WAVES = 16, G_SLAB_BLOCKS = 256 };
-static inline int g_slab_rows_per_wave(int nMajor, int nMinor) {
-  const long waves = (long)G_SLAB_BLOCKS * G_SLAB_WAVES;
-  long rw = ((long)nMajor + waves - 1) / waves;
-  rw = (rw + 1) / 2 * 2;
-  if (rw < 16) rw = 16;
-  if (rw > 1024) rw = 1024;
-  for (;;) {
-    int rb = 0;
-    while ((1L << rb) < rw) ++rb;
-    if ((1L << (32 - rb)) >= (long)nMinor) return (int)rw;
-    if (rw <= 16) return 0;
-    rw = (rw / 2 + 1) / 2 * 2;
+/* slab SpMV (k_spmv_slab): 1024-thread blocks of 16 waves.  The majors are dealt to blocks (and, inside a block, to its
+ * waves — which does not matter for any sum) by WORK: pdlp_host.cpp slabPartition, restated here.  Work of a major = its
+ * entries (0 for a long major, whose segment tasks run elsewhere) + 2.  nBlocks = ceil(nMajor / 256) capped at 256 (more
+ * only when 256 blocks of 16384 majors do not hold the operand); block b takes majors until its work reaches
+ * ceil(work left / blocks left), the crossing major included, at least one and at most 16384, and never so few / many
+ * that the blocks behind it could not hold / would not get the rest. */
+enum { G_SLAB_T = 1024, G_SLAB_WAVES = 16, G_SLAB_BLOCKS = 256, G_SLAB_BLOCK_CAP = 16384, G_SLAB_MIN_ROWS = 256, G_SLAB_MAJOR_COST = 2 };
+static inline int g_slab_fits(int nMajor, int nMinor) { /* the minor index must fit 28 bits of an entry */
+  (void)nMajor;
+  return (long)nMinor <= (1L << 28);
+}
+/* blockBeg[0..nBlocks] (caller provides room for G_SLAB_BLOCKS + nMajor / G_SLAB_BLOCK_CAP + 2 ints); returns nBlocks */
+static inline int g_slab_blocks(const int* beg, int nMajor, int nMinor, int longLimit, int* blockBeg) {
+  int mb = 0;
+  while ((1L << mb) < (long)nMinor) ++mb;
+  if (mb < 4) mb = 4;
+  long waveCap = 1L << (32 - mb);
+  if (waveCap > G_SLAB_BLOCK_CAP) waveCap = G_SLAB_BLOCK_CAP;
+  long cap = waveCap * G_SLAB_WAVES;
+  if (cap > G_SLAB_BLOCK_CAP) cap = G_SLAB_BLOCK_CAP;
+  long nB = ((long)nMajor + G_SLAB_MIN_ROWS - 1) / G_SLAB_MIN_ROWS;
+  if (nB > G_SLAB_BLOCKS) nB = G_SLAB_BLOCKS;
+  if (nB < ((long)nMajor + cap - 1) / cap) nB = ((long)nMajor + cap - 1) / cap;
+  long rem = 0;
+  for (int r = 0; r < nMajor; ++r) { const int len = beg[r + 1] - beg[r]; rem += (len > longLimit ? 0 : len) + G_SLAB_MAJOR_COST; }
+  int r = 0;
+  blockBeg[0] = 0;
+  for (long u = 0; u < nB; ++u) {
+    const long left = nB - u, target = (rem + left - 1) / left, rows = (long)nMajor - r;
+    long minRows = rows - (left - 1) * cap, maxRows = rows - (left - 1);
+    if (minRows < 1) minRows = rows > 0 ? 1 : 0;
+    if (maxRows < 1) maxRows = 1;
+    if (maxRows > cap) maxRows = cap;
+    long acc = 0, cnt = 0;
+    while (cnt < rows && cnt < maxRows && (cnt < minRows || acc < target)) {
+      const int len = beg[r + 1] - beg[r];
+      acc += (len > longLimit ? 0 : len) + G_SLAB_MAJOR_COST; ++r; ++cnt;
+    }
+    rem -= acc;
+    blockBeg[u + 1] = r;
   }
+  return (int)nB;
 }
 
 static inline double g_wave_tree(const double* lane /* [64] */) {
@@ -82,7 +109,7 @@ static inline double g_major_sum(const int* beg, const int* idx, const double* v
  * >= 2^18 entries), 1 = CSR, 2 = slab. */
 static inline int g_long_major_chunk(const int* beg, int nMajor, int nMinor, int layoutMode) {
   int slab = layoutMode == 2 || (layoutMode == 0 && nMinor >= (1 << 18));
-  if (slab && g_slab_rows_per_wave(nMajor, nMinor) == 0) slab = 0;
+  if (slab && (nMajor <= 0 || !g_slab_fits(nMajor, nMinor))) slab = 0;
   if (!slab) return g_chunk_for(nMajor > 0 ? beg[nMajor] : 0);
   return G_SLAB_LONG;
 }

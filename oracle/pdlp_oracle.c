@@ -93,7 +93,7 @@ typedef struct {
   int *qnBeg, *qnIdx;
   double* qnVal;
   double *nx[2], *nxAvg; /* N x by parity (like A'y), N xAvg at checks */
-  int slabQ, RQ, chunkQ, *planQ, nPlanQ; /* device-order layout of N (g_setup) */
+  int slabQ, chunkQ, *planQ, nPlanQ; /* device-order layout of N (g_setup) */
   int *rowType, *rowNewIdx;
   double offset, sense;
   /* scaling */
@@ -129,7 +129,7 @@ typedef struct {
   int *planA, nPlanA, *planAt, nPlanAt; /* CSR-adaptive work plans, identical to the product's */
   /* slab layout (operands whose gathered vector has >= 2^18 entries): blocks of R consecutive majors,
    * majors longer than 256 entries go to a CSR side plan over the compacted long majors */
-  int slabA, slabAt, RA, RAt, nLongA, nLongAt, chunkA, chunkAt;
+  int slabA, slabAt, nLongA, nLongAt, chunkA, chunkAt;
   int *longMapA, *longMapAt, *longBegA, *longBegAt;
   double *gPartA, *gPartB, *gStat;
 } Work;
@@ -480,20 +480,21 @@ static void g_setup(Work* w, int layoutMode) {
   /* layoutMode: 0 = the product's automatic rule, 1 = CSR stream, 2 = slab */
   w->slabA = layoutMode == 2 || (layoutMode == 0 && n >= G_SLAB_AUTO_MINOR);   /* A gathers x (n) */
   w->slabAt = layoutMode == 2 || (layoutMode == 0 && m >= G_SLAB_AUTO_MINOR);  /* A' gathers y (m) */
-  if (w->slabA && g_slab_rows_per_wave(m, n) == 0) w->slabA = 0;   /* minors do not fit the entry packing */
-  if (w->slabAt && g_slab_rows_per_wave(n, m) == 0) w->slabAt = 0;
+  if (w->slabA && (m <= 0 || !g_slab_fits(m, n))) w->slabA = 0;   /* minors do not fit the entry packing */
+  if (w->slabAt && (n <= 0 || !g_slab_fits(n, m))) w->slabAt = 0;
   /* the longest major that is summed left to right (longer ones: segment tasks, gpu_order.h g_long_major_sum) */
   w->chunkA = w->slabA ? G_SLAB_LONG : g_chunk_for(w->nnz);
   w->chunkAt = w->slabAt ? G_SLAB_LONG : g_chunk_for(w->nnz);
-  if (w->slabA) { w->RA = g_slab_rows_per_wave(m, n) * G_SLAB_WAVES; w->planA = ialloc(2); w->nPlanA = 0; }
+  /* slab layout: planA / planAt / planQ hold the block boundaries of the work partition, nPlan* = -(number of blocks) */
+  if (w->slabA) { w->planA = ialloc(G_SLAB_BLOCKS + m / G_SLAB_BLOCK_CAP + 3); w->nPlanA = -g_slab_blocks(w->csrBeg, m, n, w->chunkA, w->planA); }
   else w->planA = g_plan(w->csrBeg, m, w->chunkA, &w->nPlanA);
-  if (w->slabAt) { w->RAt = g_slab_rows_per_wave(n, m) * G_SLAB_WAVES; w->planAt = ialloc(2); w->nPlanAt = 0; }
+  if (w->slabAt) { w->planAt = ialloc(G_SLAB_BLOCKS + n / G_SLAB_BLOCK_CAP + 3); w->nPlanAt = -g_slab_blocks(w->cssBeg, n, m, w->chunkAt, w->planAt); }
   else w->planAt = g_plan(w->cssBeg, n, w->chunkAt, &w->nPlanAt);
   if (w->qnBeg) { /* N gathers x (n), majors = n */
     w->slabQ = layoutMode == 2 || (layoutMode == 0 && n >= G_SLAB_AUTO_MINOR);
-    if (w->slabQ && g_slab_rows_per_wave(n, n) == 0) w->slabQ = 0;
+    if (w->slabQ && (n <= 0 || !g_slab_fits(n, n))) w->slabQ = 0;
     w->chunkQ = w->slabQ ? G_SLAB_LONG : g_chunk_for(w->qnBeg[n]);
-    if (w->slabQ) { w->RQ = g_slab_rows_per_wave(n, n) * G_SLAB_WAVES; w->planQ = ialloc(2); w->nPlanQ = 0; }
+    if (w->slabQ) { w->planQ = ialloc(G_SLAB_BLOCKS + n / G_SLAB_BLOCK_CAP + 3); w->nPlanQ = -g_slab_blocks(w->qnBeg, n, n, w->chunkQ, w->planQ); }
     else w->planQ = g_plan(w->qnBeg, n, w->chunkQ, &w->nPlanQ);
   }
   const long mx = 2L * (n > m ? n : m) + G_MAXGRID + 8;
@@ -516,14 +517,13 @@ static double g_epilogue_total(Work* w, int isAt /* 0: A, 1: A', 2: N (off-diago
   if (!slab) {
     for (int b = 0; b < nPlan; ++b) part[np++] = g_block_partial(plan, b, perMajor);
   } else {
-    const int R = isAt == 2 ? w->RQ : isAt ? w->RAt : w->RA;
-    const int nBlocks = (nMajor + R - 1) / R;
-    for (int b = 0; b < nBlocks; ++b) { /* k_spmv_slab: 1024 threads, thread t owns majors b*R + t, + 1024, ... */
+    const int nBlocks = -nPlan;
+    for (int b = 0; b < nBlocks; ++b) { /* k_spmv_slab: 1024 threads, thread t owns majors plan[b] + t, + 1024, ... */
       double lane[G_SLAB_T];
-      const int rEnd = (b + 1) * R < nMajor ? (b + 1) * R : nMajor;
+      const int rEnd = plan[b + 1];
       for (int t = 0; t < G_SLAB_T; ++t) {
         double a = 0.0;
-        for (int r = b * R + t; r < rEnd; r += G_SLAB_T)
+        for (int r = plan[b] + t; r < rEnd; r += G_SLAB_T)
           if (beg[r + 1] - beg[r] <= limit) a += perMajor[r];
         lane[t] = a;
       }

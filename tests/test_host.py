@@ -140,13 +140,44 @@ def test_solver_mirror_runs_against_oracle():
 
 def _slab_to_coo(sl, n_major):
     """Rebuild (major, minor, value) triplets from the slab layout, in storage order."""
-    Rw, mb = sl["rows_per_wave"], sl["minor_bits"]
-    wp = sl["wave_ptr"]
+    mb = sl["minor_bits"]
+    wp, wb = sl["wave_ptr"], sl["wave_beg"]
     ent, val = sl["ent"].astype(np.int64), sl["val"]
     wave = np.repeat(np.arange(len(wp) - 1), np.diff(wp))
-    majors = wave * Rw + (ent >> mb)
+    majors = wb[wave] + (ent >> mb)
     minors = ent & ((1 << mb) - 1)
-    return majors, minors, val
+    return majors, minors, val, wave
+
+
+def _slab_partition_restated(beg, n_major, n_minor, long_limit):
+    """pdlp_host.cpp slabPartition, restated: blocks, then the 16 waves of every block, filled one after the other by
+    work = entries of the short majors + 2 per major."""
+    lens = np.diff(beg)
+    cost = np.where(lens > long_limit, 0, lens) + 2
+    mb = max(int(np.ceil(np.log2(max(n_minor, 1)))), 4)
+    wave_cap = min(1 << (32 - mb), 16384)
+    block_cap = min(16384, wave_cap * 16)
+    nb = max(min(-(-n_major // 256), 256), -(-n_major // block_cap))
+
+    def fill(r0, r1, units, cap, non_empty):
+        out, r, rem = [r0], r0, int(cost[r0:r1].sum())
+        for u in range(units):
+            left = units - u
+            target = -(-rem // left)
+            rows = r1 - r
+            min_rows = max(1 if non_empty and rows > 0 else 0, rows - (left - 1) * cap)
+            max_rows = min(cap, max(rows - (left - 1), 1) if non_empty else rows)
+            acc = cnt = 0
+            while cnt < rows and cnt < max_rows and (cnt < min_rows or acc < target):
+                acc += int(cost[r]); r += 1; cnt += 1
+            rem -= acc
+            out.append(r)
+        return out
+    bb = fill(0, n_major, nb, block_cap, True)
+    wb = [0]
+    for b in range(nb):
+        wb += fill(bb[b], bb[b + 1], 16, wave_cap, False)[1:]
+    return nb, mb, np.array(wb, dtype=np.int64)
 
 
 @pytest.mark.parametrize("which", [0, 1])
@@ -162,11 +193,9 @@ def test_slab_layout_is_a_permutation_of_the_csr(which, long_limit):
     lens = np.diff(beg)
     long_rows = np.nonzero(lens > long_limit)[0]
     assert np.array_equal(sl["long_map"], long_rows)
-    R = sl["rows_per_block"]
-    mask_rows = [b * R + w * 32 + bit for b in range(sl["n_blocks"]) for w in range(R // 32) for bit in range(32)
-                 if (sl["long_mask"][b * (R // 32) + w] >> bit) & 1]
+    mask_rows = [r for r in range(n_major) if (sl["long_mask"][r >> 5] >> (r & 31)) & 1]
     assert mask_rows == list(long_rows)
-    maj, mnr, v = _slab_to_coo(sl, n_major)
+    maj, mnr, v, wave = _slab_to_coo(sl, n_major)
     short = np.ones(n_major, bool)
     short[long_rows] = False
     rows_csr = np.repeat(np.arange(n_major), lens)
@@ -179,13 +208,44 @@ def test_slab_layout_is_a_permutation_of_the_csr(which, long_limit):
     for r in (np.random.default_rng(0).choice(cand, size=min(50, len(cand)), replace=False) if len(cand) else []):
         pos = np.nonzero(maj == r)[0]
         assert np.all(np.diff(pos) > 0) and np.all(np.diff(mnr[pos]) > 0)
-    Rw, W = sl["rows_per_wave"], sl["slab_width_log2"]
-    assert R == 16 * Rw and Rw % 2 == 0 and (1 << sl["minor_bits"]) >= (P.n if which == 0 else P.m)
-    wave = maj // Rw
+    W, wb = sl["slab_width_log2"], sl["wave_beg"]
+    assert (1 << sl["minor_bits"]) >= (P.n if which == 0 else P.m)
+    assert wb[0] == 0 and wb[-1] == n_major and np.all(np.diff(wb) >= 0) and np.all(np.diff(wb) <= 1 << (32 - sl["minor_bits"]))
+    blk = wb[::16]
+    assert np.all(np.diff(blk) >= 1) and np.max(np.diff(blk)) == sl["rows_per_block"] <= 16384
+    # the partition is the restated rule, and it balances work: no block above the mean by more than one major's worth
+    nb, mb, wb2 = _slab_partition_restated(beg, n_major, P.n if which == 0 else P.m, long_limit)
+    assert nb == sl["n_blocks"] and mb == sl["minor_bits"] and np.array_equal(wb2, wb)
+    cost = np.where(lens > long_limit, 0, lens) + 2
+    work = np.add.reduceat(cost, blk[:-1])
+    assert work.max() <= work.mean() + long_limit + 2
+    # a wave's entries are those of its majors
+    assert np.all((maj >= wb[wave]) & (maj < wb[wave + 1]))
     assert np.all(np.diff(wave) >= 0)
     # inside a wave the key (slab, local major, minor) ascends
-    key = (wave << 52) | ((mnr >> W) << 40) | ((maj % Rw) << 28) | (mnr & ((1 << W) - 1))
+    key = (wave << 52) | ((mnr >> W) << 40) | ((maj - wb[wave]) << 28) | (mnr & ((1 << W) - 1))
     assert np.all(np.diff(key) > 0)
+
+
+def test_slab_partition_balances_skewed_majors():
+    """Power-law major lengths (the staircase LP of bench.py --config d): blocks of equal major COUNT would differ by 2x
+    in entries; blocks cut by work do not."""
+    rng = np.random.default_rng(3)
+    n_major = 120000
+    lens = np.minimum((rng.pareto(1.2, n_major) * 3 + 1).astype(np.int64), 600)
+    lens[:20000] = 1  # a stretch of very short majors: these blocks hit no cap, they just own more majors
+    beg = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    nb, mb, wb = _slab_partition_restated(beg, n_major, 300000, 256)
+    cost = np.where(lens > 256, 0, lens) + 2
+    blk = wb[::16]
+    work = np.add.reduceat(cost, blk[:-1])
+    assert nb == 256 and work.max() <= 1.02 * work.mean() + 258
+    equal_count = np.add.reduceat(cost, np.arange(0, n_major, -(-n_major // 256)))
+    assert equal_count.max() > 1.3 * equal_count.mean()  # what the old partition did on this operand
+    for b in range(0, nb, 37):  # waves of a block carry equal work too
+        w = wb[16 * b:16 * b + 17]
+        ww = np.array([cost[w[k]:w[k + 1]].sum() for k in range(16)])
+        assert ww.max() <= ww.mean() + 258
 
 
 @pytest.mark.parametrize("corrupt", ["start0", "decreasing", "row_index", "overrun"])
