@@ -15,6 +15,7 @@
 #include "pdlp_halpern.hpp"
 #include "pdlp_mps.hpp"
 #include "pdlp_solver.hpp"
+#include "pdlp_detmath.h"
 
 struct pdlp_mi355x_solver {
   pdlp::SolverBase* impl;
@@ -316,6 +317,10 @@ void pdlp_mi355x_free_slab_layout(pdlp_slab_layout_t* o) {
   if (!o) return;
   free(o->wave_ptr); free(o->ent); free(o->val); free(o->long_mask); free(o->long_map); free(o->wave_beg);
   memset(o, 0, sizeof(*o));
+}
+
+void pdlp_mi355x_det_exp_log(int32_t n, const double* x, double* exp_out, double* log_out) {
+  for (int32_t i = 0; i < n; ++i) { exp_out[i] = pdlp_det_exp(x[i]); log_out[i] = pdlp_det_log(x[i]); }
 }
 
 int64_t pdlp_mi355x_sizeof(int32_t which) {

@@ -246,10 +246,12 @@ __global__ __launch_bounds__(kVecThreads) void k_check_small(const CheckSmallArg
   __shared__ DevState sh;
   __shared__ CheckCtl ctl;
   __shared__ int flag;
+  __shared__ int barBad;  // a grid barrier of this launch did not hold in this workgroup (gridBarrier's verdict)
   const int tid = threadIdx.x, lb = blockIdx.x, G = gridDim.x;
+  if (tid == 0) barBad = 0;
   // roll call: every launch of the sequence takes part, due or not (the count is cumulative)
   if (tid < kWave) {
-    const bool here = rollCall(a.bar + G + 1, (int)(a.seq * (unsigned long long)G), a.limit, tid);
+    const bool here = rollCall(a.bar + G + 1, a.seq * (unsigned long long)G, a.limit, tid);
     if (tid == 0) flag = here ? 1 : 0;
   }
   __syncthreads();
@@ -263,11 +265,19 @@ __global__ __launch_bounds__(kVecThreads) void k_check_small(const CheckSmallArg
   padSlots(prod, kMaxChunk + kMaxChunk / 8 + 8, tid, kVecThreads);
   __syncthreads();
   unsigned long long epoch = 8ull * a.seq;
+  // A barrier that does not hold (a resident workgroup stalled for longer than the timeout, a poisoned word) must not let
+  // the phases behind it pass for a check: the verdict is kept, and before anything is handed on (phase W) workgroup 0
+  // also reads the timeout flag behind the arrival words — set by ANY workgroup that gave up — as the trial loop does.
+  // Then the records are not written; commError = 1 and halted = 1 instead (syncState throws).
   auto meet = [&]() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid < kWave) (void)gridBarrier<false>(a.bar, lb, G, ++epoch, tid, a.limit);
-    else ++epoch;
+    if (tid < kWave) {
+      const int verdict = gridBarrier<false>(a.bar, lb, G, ++epoch, tid, a.limit);
+      if (tid == 0 && verdict != kBarOk) barBad = 1;
+    } else {
+      ++epoch;
+    }
     __syncthreads();
   };
   const IterVecs& v = a.v;
@@ -345,7 +355,24 @@ __global__ __launch_bounds__(kVecThreads) void k_check_small(const CheckSmallArg
     dD2 = reducePartialsAgent(a.partY, nbM, scratch[0]);
   }
   // ---- W: primal weight, step sizes, next halt; workgroup 0 hands the records on ----
-  if (lb != 0) return;
+  if (lb != 0) {
+    // (a workgroup whose own barrier failed may be the only one that knows: it raises the flag workgroup 0 reads — it
+    // is already set when the failure was a timeout, this covers a poisoned word met on the way)
+    if (tid == 0 && barBad) __hip_atomic_store(a.bar + G, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  if (tid == 0) {
+    const unsigned long long timedOut = __hip_atomic_load(a.bar + G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (timedOut) barBad = 1;
+  }
+  __syncthreads();
+  if (barBad) {  // the phases above may have run unsynchronised: nothing of this check is handed on
+    if (tid == 0) {
+      __hip_atomic_store(&a.st->commError, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&a.st->halted, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
   if (tid == 0 && !over) restartFinishCore(sh, ctl, dP2, dD2);
   __syncthreads();
   for (int w = tid; w < (int)(sizeof(DevState) / 4); w += kVecThreads) reinterpret_cast<uint32_t*>(a.st)[w] = reinterpret_cast<const uint32_t*>(&sh)[w];

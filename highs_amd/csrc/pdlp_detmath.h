@@ -5,12 +5,22 @@
  * beta = exp(2 * (0.5 log(dD/dP) + 0.5 log(sqrt(beta))))) runs on the device, behind the check iteration, without a
  * host round trip.  The device's libm (ocml) and the host's (glibc) round exp/log differently in the last place —
  * and glibc's own variants differ between CPUs — so a solve that uses either is not reproducible across the two.
- * These two functions are: the classic table-free reduction + minimax-polynomial scheme (argument reduced to
- * [sqrt(2)/2, sqrt(2)) for log, to |r| <= ln2/2 for exp), error below 1 ulp (checked against libm in
+ * These two functions are fdlibm's e_log.c / e_exp.c (FreeBSD msun / SunPro): table-free argument reduction (to
+ * [sqrt(2)/2, sqrt(2)) for log, to |r| <= ln2/2 for exp) + minimax polynomial, with fdlibm's coefficients (Lg1..Lg7,
+ * P1..P5, ln2_hi / ln2_lo, 1/ln2) digit for digit; error below 1 ulp (checked against long-double libm in
  * tests/test_host.py), every operation a single correctly rounded IEEE operation in a fixed order.  Compile with
- * -ffp-contract=off (the product and the oracle both do).
+ * -ffp-contract=off.
+ *   ====================================================
+ *   Copyright (C) 1993, 2004 by Sun Microsystems, Inc. All rights reserved.
+ *   Developed at SunPro / SunSoft, a Sun Microsystems, Inc. business.
+ *   Permission to use, copy, modify, and distribute this software is freely granted, provided that this notice
+ *   is preserved.
+ *   ====================================================
+ * (The notice covers the algorithm and constants taken from fdlibm; this restatement — bit-level reduction without the
+ * high / low word macros, no errno / exception paths — is this repository's.)
  *
- * Plain C so that oracle/pdlp_oracle.c can include it. */
+ * The test oracle does NOT include this file: its device-order mode has a separately written restatement
+ * (oracle/det_math.h), and tests/test_host.py compares the two bit for bit (pdlp_mi355x_det_exp_log). */
 #ifndef PDLP_DETMATH_H_
 #define PDLP_DETMATH_H_
 

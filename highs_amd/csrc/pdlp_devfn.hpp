@@ -305,20 +305,21 @@ __device__ __forceinline__ int gridBarrier(unsigned long long* bar, int blk, int
 // poison bit with a compare-and-swap that fails once the count is complete; an arrival that finds the poison bit (its
 // own fetch-add returns it) leaves at once; a waiter that reads the complete count without the bit has won for good —
 // the count never drops and the bit can no longer be set.  Called by wave 0; the verdict is returned in every lane.
-__device__ __forceinline__ bool rollCall(unsigned long long* word, int G, unsigned long long limitTicks, int lane) {
+__device__ __forceinline__ bool rollCall(unsigned long long* word, unsigned long long G, unsigned long long limitTicks, int lane) {
+  // (the count is cumulative over the launches of a solve: 62 bits of it, next to the poison bit)
   int verdict = 0;  // 1: everybody is here, 2: not this time
   if (lane == 0) {
     unsigned long long v = __hip_atomic_fetch_add(word, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
     const unsigned long long t0 = wall_clock64();
     for (uint32_t spins = 0;; ++spins) {
       if (v & kBarPoison) { verdict = 2; break; }
-      if ((long long)(v & 0xffffffffull) >= (long long)G) { verdict = 1; break; }
+      if ((v & (kBarPoison - 1ull)) >= G) { verdict = 1; break; }
       __builtin_amdgcn_s_sleep(2);
       if ((spins & 15u) == 15u && wall_clock64() - t0 > limitTicks) {
         unsigned long long cur = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (;;) {
           if (cur & kBarPoison) { verdict = 2; break; }
-          if ((long long)(cur & 0xffffffffull) >= (long long)G) { verdict = 1; break; }
+          if ((cur & (kBarPoison - 1ull)) >= G) { verdict = 1; break; }
           if (__hip_atomic_compare_exchange_strong(word, &cur, cur | kBarPoison, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
             verdict = 2;
             break;

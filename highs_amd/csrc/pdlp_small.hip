@@ -68,7 +68,7 @@ struct SmallArgs {
   int32_t maxTrials;
   int32_t selfTest;          // XCD-local mode, first launch of a solver: check that nt loads see another CU's store behind an L1-warm line
   int32_t primalInA;         // the primal step is recomputed by the gathers of phase A (no P phase, no barrier behind it)
-  int32_t expect;            // workgroups the roll call waits for (= the working workgroups of the launch, unless a test asks for a failure)
+  unsigned long long expect; // workgroups the roll call waits for (= the working workgroups of the launch, unless a test asks for a failure)
   unsigned long long limit;  // 100 MHz ticks a roll call or barrier wait may last
   unsigned long long* prof;  // development: 100 MHz ticks per phase {P, barrier, A, barrier, T, barrier, D}, accumulated by workgroup 0
 };
@@ -611,7 +611,7 @@ void launchSmallTrials(const MatView& A, const MatView& At, const IterVecs& v, D
   // since the caller zeroed the buffer), so no memset launch sits between two launches of the loop
   if (mode == 2) (void)hipMemsetAsync(bar, 0, smallBarWords(grid) * sizeof(unsigned long long), s);
   SmallArgs a{};
-  a.expect = (mode == 2 ? grid : (int32_t)(seq * (unsigned long long)grid)) + (failRollCall ? 1 : 0);
+  a.expect = (mode == 2 ? (unsigned long long)grid : seq * (unsigned long long)grid) + (failRollCall ? 1ull : 0ull);
   a.selfTest = xcdLocal && selfTest ? 1 : 0;
   a.primalInA = primalInA ? 1 : 0;
   if (a.selfTest)  // its words: the tail of the buffer

@@ -289,6 +289,8 @@ DevSwitches DevSwitches::fromEnv() {
   w.primalInA = num("PDLP_MI355X_PRIMAL_IN_A", -1);
   w.barrierTimeoutMs = num("PDLP_MI355X_BARRIER_TIMEOUT_MS", 1000);
   w.fault = num("PDLP_MI355X_FAULT", 0);
+  if (w.fault) fprintf(stderr, "pdlp_mi355x: PDLP_MI355X_FAULT=%d is set — a TEST hook that makes a barrier launch time out on purpose; "
+                               "this solve will stall for the barrier timeout and continue on the slower plain-launch path\n", w.fault);
   w.exchange = str("PDLP_MI355X_EXCHANGE");
   w.meshLayout = str("PDLP_MI355X_MESH_LAYOUT");
   return w;
@@ -549,7 +551,8 @@ Solver::~Solver() { release(); }
 void Solver::uploadProblem() {
   const int32_t n = F_.n;
   if (!sharded_) {
-    dAt_.balanceTaskBlocks = sw_.fused == 0;  // (the fused trial runs the long columns' tasks inside its streaming blocks)
+    // (the fused trial runs the long columns' tasks inside its streaming blocks — but it is not used with an off-diagonal Hessian)
+    dAt_.balanceTaskBlocks = sw_.fused == 0 || hasQoff_;
     dA_.upload(F_.csr, F_.m, n, sw_, stream_);
     dAt_.upload(F_.cscSorted, n, F_.m, sw_, stream_);
   } else {
@@ -625,7 +628,7 @@ void Solver::downloadForm(DeviceProblem& D, StandardForm& F, hipStream_t s) {
 }
 
 void Solver::uploadProblemFromDevice(DeviceProblem& D) {
-  dAt_.balanceTaskBlocks = sharded_ || sw_.fused == 0;  // (the fused trial runs the long columns' tasks inside its streaming blocks)
+  dAt_.balanceTaskBlocks = sharded_ || sw_.fused == 0 || hasQoff_;  // (the fused trial runs the long columns' tasks inside its streaming blocks)
   dA_.buildFromDevice(D.A, sw_, stream_);
   dAt_.buildFromDevice(D.At, sw_, stream_);
   cost_ = std::move(D.cost); rhs_ = std::move(D.rhs); lower_ = std::move(D.lower); upper_ = std::move(D.upper);
@@ -1488,8 +1491,10 @@ void Solver::doSolveDevice(bool terminate, int32_t target) {
   downloadCtl();
   if (timeUp) {
     // The time limit: the reference checks at once and stops (cupdlp_solver.c:953-962).  The device stands right behind
-    // a check (fresh residuals) unless a period was cut short by rejected trials — then one host-driven check.
-    if (s.nIter != hostCtl_->lastCheckIter) {
+    // a check (fresh residuals) unless a period was cut short by rejected trials — then one host-driven check.  The
+    // same when that last check went on to RESTART: its records describe the iterate before the restart, the vectors
+    // that post-solve returns are the restarted ones (the host-driven loop stops in front of the restart).
+    if (s.nIter != hostCtl_->lastCheckIter || hostCtl_->restartKind != 0) {
       computeAverage();
       computeResiduals();
       ++nChecks_;

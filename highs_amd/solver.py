@@ -39,7 +39,7 @@ EXPORTS = [
     "pdlp_mi355x_comm_unique_id", "pdlp_mi355x_create_sharded", "pdlp_mi355x_gen_synthetic",
     "pdlp_mi355x_free_problem", "pdlp_mi355x_last_error", "pdlp_mi355x_abi_version",
     "pdlp_mi355x_host_prepare", "pdlp_mi355x_free_prepared", "pdlp_mi355x_row_partition", "pdlp_mi355x_sizeof",
-    "pdlp_mi355x_host_slab_layout", "pdlp_mi355x_free_slab_layout",
+    "pdlp_mi355x_host_slab_layout", "pdlp_mi355x_free_slab_layout", "pdlp_mi355x_det_exp_log",
     "pdlp_mi355x_read_mps", "pdlp_mi355x_read_mps_timed", "pdlp_mi355x_free_mps_model",
 ]
 
@@ -94,6 +94,8 @@ def lib():
         L.pdlp_mi355x_read_mps_timed.argtypes = [C.c_char_p, C.c_int32, C.c_double, pMps]
         L.pdlp_mi355x_free_mps_model.argtypes = [pMps]
         L.pdlp_mi355x_free_mps_model.restype = None
+        L.pdlp_mi355x_det_exp_log.argtypes = [C.c_int32, abi.c_f64p, abi.c_f64p, abi.c_f64p]
+        L.pdlp_mi355x_det_exp_log.restype = None
         L.pdlp_mi355x_sizeof.argtypes = [C.c_int32]
         L.pdlp_mi355x_sizeof.restype = C.c_int64
         L.pdlp_mi355x_last_error.restype = C.c_char_p

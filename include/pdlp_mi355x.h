@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define PDLP_MI355X_ABI_VERSION 5
+#define PDLP_MI355X_ABI_VERSION 6
 
 /* Termination codes: same numbering as cuPDLP-C's termination_code
  * (cupdlp_defs.h:61-68) so the status map of CupdlpWrapper.cpp:225-251
@@ -309,6 +309,10 @@ typedef struct pdlp_slab_layout {
 int pdlp_mi355x_host_slab_layout(const pdlp_prepared_t* prep, int32_t which,
                                  int32_t long_limit, pdlp_slab_layout_t* out);
 void pdlp_mi355x_free_slab_layout(pdlp_slab_layout_t* out);
+/* exp(x[i]) and log(x[i]) as the solver computes them in the restart's primal-weight update (plain IEEE arithmetic,
+ * csrc/pdlp_detmath.h: the same bits on host and device) — for the CPU tests, which compare them with long-double libm
+ * and with the oracle's separately written restatement.  Reference arithmetic: cupdlp_step.c:165-170 (libm). */
+void pdlp_mi355x_det_exp_log(int32_t n, const double* x, double* exp_out, double* log_out);
 /* ---- MPS ingest (host-only, no GPU needed) --------------------------------------
  * Multi-threaded reader of free-format MPS files (fixed-format files without spaces in names are free
  * format too).  Replaces, for such files, the reference's single-threaded parser

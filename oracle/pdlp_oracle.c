@@ -421,7 +421,7 @@ static void o_Nx(const Work* w, double* nx, const double* x) {
 /* shuffle tree, fixed-order sum of 4 wave results, 4-chain sum of     */
 /* per-block partials) — and, since round 4, the exp / log of the      */
 /* restart's primal-weight update, which the device computes with the  */
-/* product's own plain-arithmetic functions (pdlp_detmath.h, < 1 ulp   */
+/* plain-arithmetic functions (restated in det_math.h, < 1 ulp         */
 /* from libm) instead of the host's libm.                              */
 /* This section restates those orders exactly                          */
 /* (highs_amd/csrc/pdlp_kernels.hip: waveSum, blockSum, reducePartials,*/
@@ -432,7 +432,7 @@ static void o_Nx(const Work* w, double* nx, const double* x) {
 /* nonzeros / 2048 majors per work block, vector grids capped at 2048. */
 /* ------------------------------------------------------------------ */
 #include "gpu_order.h"
-#include "../highs_amd/csrc/pdlp_detmath.h" /* (test infrastructure may read a product header, never the other way round) */
+#include "det_math.h" /* the oracle's own exp / log in plain IEEE arithmetic: nothing of the product is included here */
 /* planStream (pdlp_host.cpp): blocks of whole majors with at most `chunk` entries in total; a major longer than
  * chunk belongs to no block.  Returns [2*nBlocks] (first, end) pairs. */
 static int* g_plan(const int* beg, int nMajor, int chunk, int* nBlocksOut) {
@@ -1003,9 +1003,9 @@ static void step_size_ratio(Work* w) {
     dD = o_nrm2(m, d);
   }
   if (fmin(dP, dD) > 1e-10) {
-    if (w->gpuOrder) { /* the product's exp / log (pdlp_detmath.h: plain IEEE arithmetic, the same bits on host and device) */
-      const double lg = 0.5 * pdlp_det_log(dD / dP) + 0.5 * pdlp_det_log(sqrt(w->beta));
-      w->beta = pdlp_det_exp(lg) * pdlp_det_exp(lg);
+    if (w->gpuOrder) { /* exp / log in plain IEEE arithmetic as the device computes them (det_math.h: the oracle's own restatement) */
+      const double lg = 0.5 * o_det_log(dD / dP) + 0.5 * o_det_log(sqrt(w->beta));
+      w->beta = o_det_exp(lg) * o_det_exp(lg);
     } else { /* the reference: libm (cupdlp_step.c:165-170) */
       const double lg = 0.5 * log(dD / dP) + 0.5 * log(sqrt(w->beta));
       w->beta = exp(lg) * exp(lg);
@@ -1294,9 +1294,10 @@ void pdlp_oracle_spmv_csr(int m, const int* beg, const int* idx, const double* v
   }
 }
 
-/* exp and log as the product computes them (highs_amd/csrc/pdlp_detmath.h), for the accuracy test against libm */
+/* exp and log of the oracle's device-order mode (det_math.h), for the accuracy test against libm and the comparison
+ * with the product's functions (pdlp_mi355x_det_exp_log) */
 void pdlp_oracle_det_exp_log(int n, const double* x, double* expOut, double* logOut) {
-  for (int i = 0; i < n; ++i) { expOut[i] = pdlp_det_exp(x[i]); logOut[i] = pdlp_det_log(x[i]); }
+  for (int i = 0; i < n; ++i) { expOut[i] = o_det_exp(x[i]); logOut[i] = o_det_log(x[i]); }
 }
 
 /* the same in the product's summation order: majors with more than long_limit entries are cut into segment tasks

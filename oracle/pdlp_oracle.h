@@ -28,7 +28,7 @@ int pdlp_oracle_solve(const pdlp_problem_t* P, const pdlp_params_t* opt, pdlp_re
 int pdlp_oracle_solve_traced(const pdlp_problem_t* P, const pdlp_params_t* opt, pdlp_result_t* R,
                              pdlp_oracle_trace_fn trace, void* trace_ctx);
 
-/* exp(x[i]) and log(x[i]) of the product's plain-arithmetic functions (highs_amd/csrc/pdlp_detmath.h) */
+/* exp(x[i]) and log(x[i]) of the oracle's own plain-arithmetic functions (det_math.h) */
 void pdlp_oracle_det_exp_log(int n, const double* x, double* expOut, double* logOut);
 
 /* Formulated + scaled problem (CupdlpWrapper.cpp:104-176), arrays owned by the struct. */

@@ -44,8 +44,7 @@ def oracle():
     global _oracle
     if _oracle is None:
         path = os.path.join(ORACLE_DIR, "liboracle.so")
-        srcs = [os.path.join(ORACLE_DIR, f) for f in ("pdlp_oracle.c", "hipdlp_oracle.c", "gpu_order.h",
-                                                       "../highs_amd/csrc/pdlp_detmath.h")]
+        srcs = [os.path.join(ORACLE_DIR, f) for f in ("pdlp_oracle.c", "hipdlp_oracle.c", "gpu_order.h", "det_math.h")]
         if not os.path.exists(path) or os.path.getmtime(path) < max(os.path.getmtime(f) for f in srcs):
             build_oracle()
         lib = C.CDLL(path)

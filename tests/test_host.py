@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/pdlp_mi355x.h but not exported"
     assert set(solver.EXPORTS) == declared
-    assert lib.pdlp_mi355x_abi_version() == int(re.search(r"#define PDLP_MI355X_ABI_VERSION (\d+)", hdr).group(1)) == 5
+    assert lib.pdlp_mi355x_abi_version() == int(re.search(r"#define PDLP_MI355X_ABI_VERSION (\d+)", hdr).group(1)) == 6
 
 
 def test_struct_sizes_match_ctypes_mirror():
@@ -282,8 +282,10 @@ def test_lp_without_constraints_is_refused_by_the_oracle_not_looped_on():
 
 
 def test_plain_arithmetic_exp_log_within_one_ulp_of_libm():
-    """pdlp_detmath.h (the primal-weight update of a device-driven restart): exp and log in plain IEEE arithmetic, the
-    same bits on host and device; here the gcc build against numpy's libm results, error in units of the last place."""
+    """The primal-weight update of a device-driven restart: exp and log in plain IEEE arithmetic, the same bits on host and
+    device.  The product's functions (csrc/pdlp_detmath.h, through pdlp_mi355x_det_exp_log) and the oracle's separately
+    written restatement (oracle/det_math.h) against numpy's long-double libm, error in units of the last place — and against
+    each other, bit for bit."""
     rng = np.random.default_rng(7)
     x = np.concatenate([rng.uniform(-700, 700, 200000), rng.uniform(-10, 10, 200000), rng.uniform(-1, 1, 200000),
                         rng.uniform(-1e-3, 1e-3, 100000), [0.0, 1.0, -1.0, 709.0, -745.0]])
@@ -297,3 +299,12 @@ def test_plain_arithmetic_exp_log_within_one_ulp_of_libm():
     refl = np.log(y.astype(np.longdouble))
     err = np.abs(l2 - refl) / np.maximum(np.spacing(np.abs(refl.astype(np.float64))), 5e-324)
     assert np.max(err[refl != 0]) < 1.0 and l2[len(y) - 5] == 0.0
+    # the product's own functions: within one ulp of libm as well, and the same bits as the oracle's restatement
+    for arg, oe, ol in ((x, e, l), (y, e2, l2)):
+        pe, pl = np.zeros(len(arg)), np.zeros(len(arg))
+        solver.lib().pdlp_mi355x_det_exp_log(len(arg), arg.ctypes.data_as(abi.c_f64p), pe.ctypes.data_as(abi.c_f64p), pl.ctypes.data_as(abi.c_f64p))
+        assert np.array_equal(pe.view(np.uint64), oe.view(np.uint64))
+        assert np.array_equal(pl.view(np.uint64), ol.view(np.uint64))
+    pe = np.zeros(len(x)); pl = np.zeros(len(x))
+    solver.lib().pdlp_mi355x_det_exp_log(len(x), x.ctypes.data_as(abi.c_f64p), pe.ctypes.data_as(abi.c_f64p), pl.ctypes.data_as(abi.c_f64p))
+    assert np.max(np.abs(pe - ref) / np.spacing(np.abs(ref.astype(np.float64)))) < 1.0
