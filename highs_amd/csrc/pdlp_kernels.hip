@@ -485,10 +485,12 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
     longBlock<EPI, kWaves>(a, epiL, (int)blockIdx.x - a.S.nBlocks, reinterpret_cast<double*>(smem));
     return;
   }
-  // dynamic LDS: acc[R] f64 | stg[16][64] f64 | scratch[2][16] f64 | (kAtyFused) trial scratch[4][4] f64, DevState
+  // dynamic LDS: acc[R] f64 | segment slots[SL] f64 | stg[16][64] f64 | scratch[2][16] f64 | (kAtyFused) trial scratch[4][4] f64, DevState
   const int R = (a.S.rowsPerBlock + 1) & ~1;  // (the most majors any block owns; even: the strips behind stay 16-byte aligned)
+  const int SL = (a.S.slotsPerBlock + 1) & ~1;
   double* acc = reinterpret_cast<double*>(smem);
-  double* stgAll = acc + R;
+  double* slots = acc + R;  // sums of the in-block segments of the block's medium majors
+  double* stgAll = slots + SL;
   double(*scratch)[kWaves] = reinterpret_cast<double(*)[kWaves]>(stgAll + kSlabThreads);
 
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
@@ -501,6 +503,10 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
   const int wBeg = ldUniform(a.S.waveBeg + gw);
   const int Rw = ldUniform(a.S.waveBeg + gw + 1) - wBeg;
   const int e0 = ldUniform(a.S.wavePtr + gw), e1 = ldUniform(a.S.wavePtr + gw + 1);
+  const int regCnt = ldUniform(a.S.waveReg + gw);  // the head of the list: regular entries; behind them (from the next whole group) the segments
+  int si = ldUniform(a.S.waveSegBeg + gw);
+  const int siEnd = ldUniform(a.S.waveSegBeg + gw + 1);
+  const int medBeg = ldUniform(a.S.blockMedBeg + blk), nMed = ldUniform(a.S.blockMedBeg + blk + 1) - medBeg;
   double* wacc = acc + (wBeg - rBase);
   double* stg = stgAll + wave * kWave;
   Epi<EPI> epi(a);
@@ -526,6 +532,10 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
       fix[k].d = 0.0; fix[k].e = a.v.qdiag ? ldStream(a.v.qdiag + r) : 0.0;  // (QP: the diagonal of Q of the prox step)
     }
   }
+
+  // this thread's medium major (if the block has that many): descriptor fetched ahead of the stream
+  uint32_t med0 = 0u, med1 = 0u;
+  if (!TWO && tid < nMed) { med0 = a.S.medDesc[2 * (medBeg + tid)]; med1 = a.S.medDesc[2 * (medBeg + tid) + 1]; }  // (TWO: 64 registers — fetched behind the stream)
 
   // Consume one 64-entry group of this wave: products to the wave's LDS strip, the first lane of each run of equal
   // local majors adds the run, left to right, onto the major's accumulator (ascending stretches one after the other
@@ -574,9 +584,15 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
   // wave's last entry they re-read that entry (same cache line), and groups past nG contribute nothing.
   const uint32_t* __restrict__ ent = a.S.ent + e0;
   const double* __restrict__ val = a.S.val + e0;
-  const int cnt = e1 - e0;
+  const int cnt = e1 - e0;  // the whole list: regular entries, padding, segment groups
   const int nG = (cnt + kWave - 1) / kWave;
+  const int nGreg = (regCnt + kWave - 1) / kWave;
   const int last = cnt > 0 ? cnt - 1 : 0;  // (an empty wave reads entry e0, which exists: ent/val carry one pad element)
+  // the current in-block segment of this wave: its first group, entries and LDS slot; lane l adds the products of the
+  // segment's entries l, l+64, ... (ascending), 64-lane shuffle tree at its end — the order of the segment tasks (longBlock)
+  int segG0 = nGreg;
+  uint32_t segWord = si < siEnd ? (uint32_t)ldUniform(reinterpret_cast<const int32_t*>(a.S.segDesc) + si) : 0u;
+  double segAcc = 0.0;
   auto entryIndex = [&](int g) { const int q = g * kWave + lane; return q < last ? q : last; };
   auto gather = [&](uint32_t e) -> double {
     const uint32_t off = (e & mmask) << 3;  // byte offset: minor < 2^26
@@ -610,7 +626,7 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
       const int g = o * NB + u;
       X[(u + GD) % NB] = gather(E[(u + GD) % NB]);  // group g+GD
       // consume group g
-      const int nValid = cnt - g * kWave;  // lanes >= nValid hold nothing of this wave (<= 0: phantom group)
+      const int nValid = regCnt - g * kWave;  // lanes >= nValid hold nothing regular of this wave (<= 0: phantom group)
       const uint32_t eCur = E[u];
       const double prod = V[u] * X[u];
       {  // slot u is free: refill it with group g+NB
@@ -619,11 +635,35 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
         V[u] = val[q];
       }
       __builtin_amdgcn_sched_barrier(0);  // gather, then refill, then the LDS work: in this order
-      consumeGroup(eCur, prod, nValid);
+      if (g < nGreg) {
+        consumeGroup(eCur, prod, nValid);
+      } else if (si < siEnd) {  // (wave-uniform) a group of an in-block segment
+        const int segLen = (int)(segWord & 0xffffu);
+        const int k0 = (g - segG0) * kWave;
+        if (k0 + lane < segLen) segAcc += prod;
+        if (k0 + kWave >= segLen) {  // the segment's last group
+          const double ssum = waveSum(segAcc);
+          if (lane == 0) slots[segWord >> 16] = ssum;
+          segAcc = 0.0;
+          segG0 = g + 1;
+          ++si;
+          segWord = si < siEnd ? (uint32_t)ldUniform(reinterpret_cast<const int32_t*>(a.S.segDesc) + si) : 0u;
+        }
+      }
       if (!a.S.noPace) __syncthreads();  // pacing: the CU's waves stay on the same slab
     }
   }
   if (a.S.noPace) __syncthreads();  // (free-running waves: every wave's accumulators are final before the epilogue reads them)
+  if (nMed > 0) {  // (block-uniform) medium majors: segment sums left to right -> the major's accumulator
+    for (int t = tid; t < nMed; t += kSlabThreads) {
+      if (TWO || t != tid) { med0 = a.S.medDesc[2 * (medBeg + t)]; med1 = a.S.medDesc[2 * (medBeg + t) + 1]; }
+      const int first = (int)(med1 >> 8), ns = (int)(med1 & 0xffu);
+      double total = 0.0;
+      for (int k = 0; k < ns; ++k) total += slots[first + k];
+      acc[med0] = total;
+    }
+    __syncthreads();
+  }
 
   profStamp(0);
   const uint32_t* __restrict__ mask = a.S.longMask;  // bit r: major r is a long one (its segment tasks own it)
@@ -1136,7 +1176,7 @@ void launchSpmv(const MatView& M, SpmvArgs a, hipStream_t s) {
   const int nTasks = M.lng.nTasks;
   if (M.useSlab && M.slab.nBlocks > 0) {
     a.S = M.slab;
-    const size_t lds = (size_t)((M.slab.rowsPerBlock + 1) & ~1) * 8 + kSlabThreads * 8 + 2 * (kSlabThreads / kWave) * 8;
+    const size_t lds = (size_t)(((M.slab.rowsPerBlock + 1) & ~1) + ((M.slab.slotsPerBlock + 1) & ~1)) * 8 + kSlabThreads * 8 + 2 * (kSlabThreads / kWave) * 8;
     const dim3 grid(M.slab.nBlocks + (nTasks + M.lng.taskGroup - 1) / M.lng.taskGroup);  // one task group per extra workgroup
     // (gather distance 2 / 3 with 4 / 6 slots measured the same as (3, 1) on the random and on the structured LP, round 3)
     // segment tasks ride along: register budget for two resident blocks per CU, so that a task block runs NEXT to a streaming one
@@ -1166,7 +1206,7 @@ void launchSpmvAtyInteract(const MatView& At, const IterVecs& v, const DevState*
 }
 namespace {
 size_t fusedLds(const MatView& At) {
-  return (size_t)((At.slab.rowsPerBlock + 1) & ~1) * 8 + kSlabThreads * 8 + 2 * (kSlabThreads / kWave) * 8 + 4 * (kVecThreads / kWave) * 8 +
+  return (size_t)(((At.slab.rowsPerBlock + 1) & ~1) + ((At.slab.slotsPerBlock + 1) & ~1)) * 8 + kSlabThreads * 8 + 2 * (kSlabThreads / kWave) * 8 + 4 * (kVecThreads / kWave) * 8 +
          sizeof(DevState) + 16;
 }
 }  // namespace
