@@ -387,7 +387,9 @@ def main():
     traffic_key = "trials_persistent_per_trial" if persistent else dom_name
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(args.config if args.solver == "pdlp" else "b", {}).get(traffic_key)
+            # (counters exist per configuration; the HiPDLP path was profiled on the headline LP only — another config: none)
+            cfg_key = args.config if (args.solver == "pdlp" or args.config == "b") else None
+            traffic = json.load(open(tpath)).get(cfg_key, {}).get(traffic_key) if cfg_key else None
         except Exception:
             traffic = None
     out = {
@@ -436,8 +438,9 @@ def main():
         # sharded sequence runs as its own kernel) and the stand-alone primal-step kernel
         if world == 1:
             base = (iso_ax * 1e3, iso_aty * 1e3, S.time_kernel("decide_primal", 30) * 1e3)
-        else:  # (a rank of a sharded run measures its own share: scale back to one GPU)
-            base = (iso_ax * 1e3 * world, iso_aty * 1e3 * world, 15.5 * n / 1e6)
+        else:  # (a rank of a sharded run measures its own share of the two SpMVs: scaled back to one GPU; the primal step is
+            # timed full length on this rank's device — the stand-alone kernel a single GPU would run)
+            base = (iso_ax * 1e3 * world, iso_aty * 1e3 * world, S.time_kernel("primal_step", 30) * 1e3)
         out["scaling_model"] = {("G=%d" % G): scaling_model(n, m, nnz, G, *base) for G in ((world,) if world > 1 else (2, 4, 8))}
         out["scaling_model"]["inputs_us_one_gpu"] = {"spmv_ax_dual": base[0], "spmv_aty_interact": base[1], "primal_step": base[2],
                                                      "source": "measured in this run (isolated re-launches)"}

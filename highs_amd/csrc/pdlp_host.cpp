@@ -544,8 +544,7 @@ SlabPlan slabPlan(const int32_t* beg, int32_t nMajor, int32_t nMinor, int32_t lo
       P.waveReg[gw] = (int32_t)reg;
       P.wavePtr[gw] = (int32_t)pos;
       P.waveSegBeg[gw] = (int32_t)P.segs.size();
-      pos += reg;
-      if (!wsegs[w].empty()) pos = (pos + 63) / 64 * 64;
+      pos += wsegs[w].empty() ? reg : (reg + 63) / 64 * 64;  // (segments start at a whole group of THIS wave's list)
       for (SlabSeg sgm : wsegs[w]) {
         sgm.dst = (int32_t)pos;
         pos += (sgm.len + 63) / 64 * 64;

@@ -307,13 +307,37 @@ DevSwitches DevSwitches::fromEnv() {
   return w;
 }
 
-// One launch sequence with in-kernel grid barriers at a time per device and process: two solvers (two Highs instances on
+// One launch sequence with in-kernel grid barriers at a time per DEVICE and process: two solvers (two Highs instances on
 // two threads: SURVEY section 8(b), lp_data/HighsSolve.cpp:97-104) whose barrier launches interleave could each hold
-// CUs the other one's last workgroups need.  A solver holds the gate from the first launch of a round to the
-// synchronisation that ends it; solvers without barrier launches (sharded, HiPDLP, after a fall-back) never take it.
-std::mutex& Solver::deviceGate(int device) {
-  static std::mutex gates[64];
+// CUs the other one's last workgroups need.  The order is imposed on the device, not on the hosts: a solver takes the
+// gate only while it ENQUEUES a round — its stream first waits for the event that ends the previous barrier round of
+// any context on this device, and records the next event behind its own launches — and synchronises with the gate
+// released, so the next context's round is queued (and starts on the device) while this one is still waiting for, and
+// then looking at, its results.  (Round 4 held the gate across the synchronisation: two contexts never overlapped at
+// all, not even host work with device work.)  Solvers without barrier launches (sharded, HiPDLP, after a fall-back)
+// never take it.  The two events per device are created by the first solver that needs them and live as long as the
+// process: no solver owns what another one's stream may still be waiting on.
+Solver::DeviceGate& Solver::deviceGate(int device) {
+  static DeviceGate gates[64];
   return gates[device >= 0 && device < 64 ? device : 0];
+}
+std::unique_lock<std::mutex> Solver::beginBarrierRound() {
+  std::unique_lock<std::mutex> gate;
+  if (!(persistent_ || fused_)) return gate;
+  DeviceGate& G = deviceGate(opt_.device);
+  gate = std::unique_lock<std::mutex>(G.mu);
+  if (G.recorded) PDLP_HIP(hipStreamWaitEvent(stream_, G.ev[G.cur], 0));
+  return gate;
+}
+void Solver::endBarrierRound(std::unique_lock<std::mutex>& gate) {
+  if (!gate.owns_lock()) return;
+  DeviceGate& G = deviceGate(opt_.device);
+  const int nxt = G.cur ^ 1;
+  if (!G.ev[nxt]) PDLP_HIP(hipEventCreateWithFlags(&G.ev[nxt], hipEventDisableTiming));
+  PDLP_HIP(hipEventRecord(G.ev[nxt], stream_));
+  G.cur = nxt;
+  G.recorded = true;
+  gate.unlock();
 }
 
 double Solver::elapsed() const {
@@ -1108,12 +1132,11 @@ void Solver::runUntilHalt() {
     if (remaining > 4 * kCheckInterval) remaining = 4 * kCheckInterval;
     int32_t todo = (int32_t)remaining;
     const int32_t trialsBefore = hostState_->nTrials;
-    std::unique_lock<std::mutex> gate;
-    if (persistent_ || fused_) gate = std::unique_lock<std::mutex>(deviceGate(opt_.device));
+    std::unique_lock<std::mutex> gate = beginBarrierRound();
     enqueueBatch(todo);
     const int32_t iterBefore = hostState_->nIter;
+    endBarrierRound(gate);
     syncState();
-    if (gate.owns_lock()) gate.unlock();
     if (profile_) profCollect(hostState_->nTrials - trialsBefore);
     if (hostState_->halted) return;
     // The reference's step-size search is a `while (!accepted)` loop: with NaN / Inf in the data it never ends.
@@ -1452,8 +1475,7 @@ void Solver::doSolveDevice(bool terminate, int32_t target) {
     const auto roundBeg = std::chrono::steady_clock::now();
     const int32_t iterBefore = s.nIter, trialsBefore = s.nTrials;
     const int64_t seq0 = checkSeq_;
-    std::unique_lock<std::mutex> gate;
-    if (persistent_ || fused_) gate = std::unique_lock<std::mutex>(deviceGate(opt_.device));
+    std::unique_lock<std::mutex> gate = beginBarrierRound();
     int64_t itExp = s.nIter, haltExp = s.haltIter;
     if (s.halted) {  // (entry only: every batch below is followed by its check)
       enqueueCheckDevice();
@@ -1475,8 +1497,8 @@ void Solver::doSolveDevice(bool terminate, int32_t target) {
       if (itExp >= iterLim || (terminate && itExp >= iterLim - 1)) break;  // the target / the check that ends the solve
       if (itExp == haltExp) haltExp = haltAfter(itExp);
     }
+    endBarrierRound(gate);
     syncState();
-    if (gate.owns_lock()) gate.unlock();
     processRecords(terminate, iterLim, logSinceHeader);
     bool over = false;  // a check of this round has ended the solve (everything queued behind it was a no-op)
     for (int64_t q = seq0; q < checkSeq_; ++q) over = over || (hostRing_[q % kRingSlots].ran && hostRing_[q % kRingSlots].terminated);

@@ -209,7 +209,11 @@ class Solver : public SolverBase {
   DeviceArray<unsigned long long> gridBar_;
   int32_t barrierFallbacks_ = 0, smallLaunches_ = 0;
   unsigned long long smallSeq_ = 0;  // persistent launches since gridBar_ was zeroed (their roll call counts cumulatively)
-  static std::mutex& deviceGate(int device);
+  // (barrier rounds of the contexts of one device: ordered on the DEVICE by an event chain, see pdlp_solver.cpp)
+  struct DeviceGate { std::mutex mu; hipEvent_t ev[2] = {nullptr, nullptr}; int cur = 0; bool recorded = false; };
+  static DeviceGate& deviceGate(int device);
+  std::unique_lock<std::mutex> beginBarrierRound();          // locked (and the stream ordered behind the last round) iff this solver launches grid barriers
+  void endBarrierRound(std::unique_lock<std::mutex>& gate);  // marks the end of this round on the stream, releases the gate
   int32_t stalledRounds_ = 0, stalledSince_ = 0;  // consecutive device stops without an accepted trial
   // Device-driven check iterations (pdlp_kernels.hpp CheckCtl; PDLP_MI355X_DEVICE_CHECK=0 gives the host-driven loop back)
   bool devCheck_ = true;

@@ -325,6 +325,49 @@ def test_more_instances_match_reference_cpu_pdlp(name):
     assert out.pdlp_iteration_count == GPU_PINS[name]["pdlp_iteration_count"]
 
 
+HARD = json.load(open(os.path.join(GOLD, "reference_hard.json"))) if os.path.exists(os.path.join(GOLD, "reference_hard.json")) else {}
+
+
+@pytest.mark.parametrize("name", ["perold", "greenbea", "gas11", "primal1"])
+def test_hard_instances_first_iterations_bit_exact(name, monkeypatch):
+    """The LPs of check/instances on which a first-order method struggles (millions of iterations, many restarts;
+    make_golden_hard.py): the first 4 000 iterations of the GPU solve, bit for bit against the oracle's device-order mode
+    — iterates of the last iteration, step sizes, trial and restart counts.  (primal1 is a QP with a diagonal Hessian: the
+    oracle's QP extension.)"""
+    monkeypatch.setenv("PDLP_MI355X_SLAB", "0")
+    lp = _lp(name)
+    kw = dict(kkt_tolerance=1e-12, pdlp_iteration_limit=4000)
+    cpu = O.oracle_solve(lp, device_reduction_order=True, device_layout="csr", **kw)
+    gpu = solver.solveLpCupdlp(lp, **kw)
+    R = gpu.result
+    assert (R.term_code, R.num_iter, R.num_trials, R.num_restarts) == (cpu.term_code, cpu.num_iter, cpu.num_trials, cpu.num_restarts)
+    assert R.num_iter == 3999 or R.term_code == 0  # (the reference stops at limit - 1; primal1 is solved to 1e-12 after 680)
+    assert R.primal_obj == cpu.primal_obj and R.dual_obj == cpu.dual_obj and R.primal_feas == cpu.primal_feas and R.dual_feas == cpu.dual_feas
+    assert np.array_equal(gpu.solution.col_value, cpu.col_value) and np.array_equal(gpu.solution.row_dual, cpu.row_dual)
+
+
+@pytest.mark.parametrize("name", ["perold", "greenbea", "gas11", "primal1"])
+def test_hard_instances_reach_the_reference_simplex_result(name):
+    """... and the converged result at the DEFAULT tolerance against the reference's own simplex (primal1: its QP solver):
+    optimal objectives to 1e-6, gas11 (unbounded) gets the reference's verdict.  No CPU-pdlp convergence is needed for
+    the golden; where the real cuPDLP-C core does converge within its time budget the record holds
+    its iteration count for comparison.  Iteration counts on the device are reproducible exactly and pinned."""
+    g = HARD[name]
+    pin = GPU_PINS.get(name)
+    if pin is None or pin.get("skip"):
+        pytest.skip("no GPU pin recorded for %s: %s" % (name, (pin or {}).get("skip", "run tools/r5_hard.py on an MI355X")))
+    lp = _lp(name)
+    out = solver.solveLpCupdlp(lp, time_limit=600.0)
+    ref = g["simplex"]
+    if ref["model_status"] == "Optimal":
+        assert out.model_status == solver.kOptimal, out.model_status
+        obj = lp.objective_value(out.solution.col_value)
+        assert abs(obj - ref["objective_value"]) <= 1e-6 * max(1.0, abs(ref["objective_value"])), (obj, ref["objective_value"])
+    else:
+        assert ref["model_status"] == "Unbounded" and out.model_status == solver.kUnboundedOrInfeasible
+    assert out.pdlp_iteration_count == pin["pdlp_iteration_count"]
+
+
 SYNTH = json.load(open(os.path.join(GOLD, "reference_synth.json"))) if os.path.exists(os.path.join(GOLD, "reference_synth.json")) else {}
 
 
@@ -749,9 +792,12 @@ def test_two_large_contexts_concurrently():
     """Two solver contexts with grid-barrier launches on ONE device at the same time (several Highs
     instances on several threads): two mid-size LPs on the persistent loop (hundreds of workgroups each, more than the
     device holds together) and two slab-layout LPs on the fused 2-launch trial, next to a third tenant that needs no
-    barriers (a HiPDLP solve whose 1024-thread kernels keep taking and releasing every CU).  The per-device gate lets
-    one barrier round run at a time: no deadlock, no barrier timeouts (the default timeout is 1 s: a stall would show
-    in the wall clock), and every result bit-identical to the same work done alone."""
+    barriers (a HiPDLP solve whose 1024-thread kernels keep taking and releasing every CU).  Barrier rounds of different
+    contexts are ordered ON THE DEVICE (an event chain per device; the host-side gate is held only while a round is being
+    enqueued): no deadlock, no barrier timeouts (the default timeout is 1 s: a stall would show in the wall clock), every
+    result bit-identical to the same work done alone — and since a context's round is queued while another one's is
+    still running, doing the work together costs no more than doing it one after the other (round 4 held the gate across
+    the synchronisation and only promised 3x)."""
     import threading
     import time
     mids = [solver.SyntheticProblem(40000, 35000, 400000, 9), solver.SyntheticProblem(38000, 36000, 380000, 10)]
@@ -763,6 +809,9 @@ def test_two_large_contexts_concurrently():
     t_alone = time.time() - t0
     assert alone["mid0"][5] == 0 and alone["big0"][5] == 2
     hip_lp = bigs[1].to_lp()
+    t0 = time.time()
+    solver.solveLpHiPdlp(hip_lp, kkt_tolerance=1e-12, pdlp_iteration_limit=1200)
+    t_alone += time.time() - t0
     out, errs = {}, []
 
     def work(name):
@@ -790,7 +839,7 @@ def test_two_large_contexts_concurrently():
         for a, b in zip(alone[k][:3], out[k][:3]):
             assert np.array_equal(a, b), k
         assert alone[k][3:6] == out[k][3:6], k
-    assert t_together < 3.0 * t_alone + 3.0, (t_together, t_alone)
+    assert t_together < 1.25 * t_alone + 1.0, (t_together, t_alone)
     for p in mids + bigs:
         p.close()
 

@@ -286,6 +286,66 @@ def test_slab_partition_balances_skewed_majors():
     assert equal_count.max() > 1.3 * equal_count.mean()  # what the old partition did on this operand
 
 
+def _wave_tree(lane):
+    lane = lane.copy()
+    off = 32
+    while off:
+        lane = lane + np.concatenate([lane[off:], lane[64 - off:]])  # __shfl_down: lanes beyond the end read themselves
+        off //= 2
+    return lane[0]
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_slab_layout_read_the_way_the_kernel_reads_it_gives_the_modelled_sums(which):
+    """k_spmv_slab restated on the exported layout — regular entries added per major in storage order; a segment's entries
+    lane-strided (entry k of the segment to lane k % 64, ascending), 64-lane shuffle tree, a medium major's segment sums left
+    to right; a segment's first group = the first whole group behind the wave's regular entries — gives, bit for bit, the
+    sums of the oracle's device-order model (g_major_sum: what the GPU tests pin the kernel to).  Dense-column staircase LP:
+    medium rows and columns, long columns, empty waves, lists that do not start on a group boundary."""
+    from lpgen import dense_column_lp
+    lp = dense_column_lp(2, periods=12, rows_per=256, cols_per=224, dense_cols=6, dense_nnz=1500, tail_rows=64, tail_max=900)
+    P = solver.Prepared(lp)
+    sl = P.slab_layout(which)
+    beg, idx, val = (P.csr_beg, P.csr_idx, P.csr_val) if which == 0 else (P.csc_beg, P.csc_idx, P.csc_val)
+    n_major, n_minor = (P.m, P.n) if which == 0 else (P.n, P.m)
+    x = np.random.default_rng(4).standard_normal(n_minor)
+    mb, wp, wb, wr = sl["minor_bits"], sl["wave_ptr"], sl["wave_beg"], sl["wave_reg"]
+    ent, v = sl["ent"].astype(np.int64), sl["val"]
+    msk = (1 << mb) - 1
+    out = np.zeros(n_major)
+    for w in range(len(wr)):
+        for q in range(wp[w], wp[w] + wr[w]):
+            out[wb[w] + (ent[q] >> mb)] += v[q] * x[ent[q] & msk]
+    blk = wb[::16]
+    n_med = 0
+    for b in range(sl["n_blocks"]):
+        slots = {}
+        for w in range(16 * b, 16 * b + 16):
+            q = wp[w] + (-(-wr[w] // 64)) * 64
+            for si in range(sl["wave_seg_beg"][w], sl["wave_seg_beg"][w + 1]):
+                d = int(sl["seg_desc"][si])
+                ln, slot = d & 0xffff, d >> 16
+                lane = np.zeros(64)
+                for k in range(ln):
+                    lane[k % 64] += v[q + k] * x[ent[q + k] & msk]
+                slots[slot] = _wave_tree(lane)
+                q += (-(-ln // 64)) * 64
+        for k in range(sl["block_med_beg"][b], sl["block_med_beg"][b + 1]):
+            lr, w1 = int(sl["med_desc"][2 * k]), int(sl["med_desc"][2 * k + 1])
+            tot = 0.0
+            for j in range(w1 & 0xff):
+                tot += slots[(w1 >> 8) + j]
+            out[blk[b] + lr] = tot
+            n_med += 1
+    ref = np.zeros(n_major)
+    p = lambda a, t: np.ascontiguousarray(a).ctypes.data_as(t)
+    O.oracle().pdlp_oracle_spmv_csr_device_order(n_major, p(beg, abi.c_i32p), p(idx, abi.c_i32p), p(val, abi.c_f64p),
+                                                 np.ascontiguousarray(x).ctypes.data_as(abi.c_f64p), ref.ctypes.data_as(abi.c_f64p), 256)
+    keep = np.diff(beg) <= sl["med_max"]
+    assert n_med > 0 and np.any(wp[:-1][np.diff(sl["wave_seg_beg"]) > 0] % 64 != 0)
+    assert np.array_equal(out[keep], ref[keep])
+
+
 @pytest.mark.parametrize("corrupt", ["start0", "decreasing", "row_index", "overrun"])
 def test_malformed_csc_is_rejected_not_read_out_of_bounds(corrupt):
     """formulate()/formulateHipdlp()/the device-side setup validate the caller's CSC arrays first."""

@@ -14,3 +14,8 @@ for cfg in ${PROF_CONFIGS:-b c d}; do
   echo "== bench.py --config $cfg (PDLP_MI355X_SLAB_PROF=1)"
   PDLP_MI355X_SLAB_PROF=1 python bench.py --config $cfg --cpu-iters 0 2>&1 >/dev/null | grep "slab launch"
 done | tee $OUT/slab_phase_profile.log
+if [ -n "${EXTRA_A:-}" ]; then
+  echo "== config a forced onto the slab layout (fused 2-launch trial) vs the persistent loop"
+  PDLP_MI355X_SLAB=1 python bench.py --config a --cpu-iters 0 2>/dev/null | line a_slab_fused
+  PDLP_MI355X_SLAB=1 PDLP_MI355X_FUSED=0 python bench.py --config a --cpu-iters 0 2>/dev/null | line a_slab_3launch
+fi
