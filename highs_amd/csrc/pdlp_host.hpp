@@ -155,7 +155,7 @@ constexpr int32_t kSlabMajorCost = 2;       // work of a major besides its entri
 constexpr int32_t kSlabSegment = 512;       // entries per in-block segment (= pdlp_kernels.hpp kLongSegment: the same sums)
 constexpr int32_t kSlabMedMaxCap = 16384;   // a medium major has at most 32 segments
 
-// The plan.  Work of major r = (its entries unless it is a long major) + kSlabMajorCost; LDS units of major r = 1 + its
+// The plan.  Work of major r = (its entries — half of them for a medium major, none for a long one) + kSlabMajorCost; LDS units of major r = 1 + its
 // segments (medium majors).  nBlocks = ceil(nMajor / 256) capped at 256 (more only when the units do not fit);
 // medMax = half of the mean work per block, within [512, 16384].  Blocks are filled one after the other: block b
 // takes majors while it is closer to ceil(work left / blocks left) with the next major than without, at least one,

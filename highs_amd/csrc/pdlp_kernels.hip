@@ -502,7 +502,7 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
   const int rBase = ldUniform(a.S.waveBeg + blk * kWaves), rEnd = ldUniform(a.S.waveBeg + blk * kWaves + kWaves);  // never empty
   const int wBeg = ldUniform(a.S.waveBeg + gw);
   const int Rw = ldUniform(a.S.waveBeg + gw + 1) - wBeg;
-  const int e0 = ldUniform(a.S.wavePtr + gw), e1 = ldUniform(a.S.wavePtr + gw + 1);
+  const int e0 = ldUniform(a.S.wavePtr + gw);
   const int regCnt = ldUniform(a.S.waveReg + gw);  // the head of the list: regular entries; behind them (from the next whole group) the segments
   int si = ldUniform(a.S.waveSegBeg + gw);
   const int siEnd = ldUniform(a.S.waveSegBeg + gw + 1);
@@ -584,15 +584,9 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
   // wave's last entry they re-read that entry (same cache line), and groups past nG contribute nothing.
   const uint32_t* __restrict__ ent = a.S.ent + e0;
   const double* __restrict__ val = a.S.val + e0;
-  const int cnt = e1 - e0;  // the whole list: regular entries, padding, segment groups
+  const int cnt = regCnt;  // the paced stream: the regular entries at the head of the list (the segments behind them: below)
   const int nG = (cnt + kWave - 1) / kWave;
-  const int nGreg = (regCnt + kWave - 1) / kWave;
-  const int last = cnt > 0 ? cnt - 1 : 0;  // (an empty wave reads entry e0, which exists: ent/val carry one pad element)
-  // the current in-block segment of this wave: its first group, entries and LDS slot; lane l adds the products of the
-  // segment's entries l, l+64, ... (ascending), 64-lane shuffle tree at its end — the order of the segment tasks (longBlock)
-  int segG0 = nGreg;
-  uint32_t segWord = si < siEnd ? (uint32_t)ldUniform(reinterpret_cast<const int32_t*>(a.S.segDesc) + si) : 0u;
-  double segAcc = 0.0;
+  const int last = cnt > 0 ? cnt - 1 : 0;  // (an empty wave reads entry e0, which exists: ent/val carry pad elements)
   auto entryIndex = [&](int g) { const int q = g * kWave + lane; return q < last ? q : last; };
   auto gather = [&](uint32_t e) -> double {
     const uint32_t off = (e & mmask) << 3;  // byte offset: minor < 2^26
@@ -626,7 +620,7 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
       const int g = o * NB + u;
       X[(u + GD) % NB] = gather(E[(u + GD) % NB]);  // group g+GD
       // consume group g
-      const int nValid = regCnt - g * kWave;  // lanes >= nValid hold nothing regular of this wave (<= 0: phantom group)
+      const int nValid = cnt - g * kWave;  // lanes >= nValid hold nothing of this wave (<= 0: phantom group)
       const uint32_t eCur = E[u];
       const double prod = V[u] * X[u];
       {  // slot u is free: refill it with group g+NB
@@ -635,25 +629,47 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
         V[u] = val[q];
       }
       __builtin_amdgcn_sched_barrier(0);  // gather, then refill, then the LDS work: in this order
-      if (g < nGreg) {
-        consumeGroup(eCur, prod, nValid);
-      } else if (si < siEnd) {  // (wave-uniform) a group of an in-block segment
-        const int segLen = (int)(segWord & 0xffffu);
-        const int k0 = (g - segG0) * kWave;
-        if (k0 + lane < segLen) segAcc += prod;
-        if (k0 + kWave >= segLen) {  // the segment's last group
-          const double ssum = waveSum(segAcc);
-          if (lane == 0) slots[segWord >> 16] = ssum;
-          segAcc = 0.0;
-          segG0 = g + 1;
-          ++si;
-          segWord = si < siEnd ? (uint32_t)ldUniform(reinterpret_cast<const int32_t*>(a.S.segDesc) + si) : 0u;
-        }
-      }
+      consumeGroup(eCur, prod, nValid);
       if (!a.S.noPace) __syncthreads();  // pacing: the CU's waves stay on the same slab
     }
   }
-  if (a.S.noPace) __syncthreads();  // (free-running waves: every wave's accumulators are final before the epilogue reads them)
+  // ---- the in-block segments of this wave (medium majors of the block) ----
+  // Their gathers go wherever the major's minors are — not with the slab the block is sweeping — so every one is a miss
+  // of its own: not through the paced one-gather-ahead pipeline above (measured: a serial miss per 64 entries, 2 us each),
+  // but four groups at a time, 8 entry / value loads and then 4 gathers per lane in flight, free-running.  Lane l adds the
+  // products of the segment's entries l, l+64, ... in ascending order, 64-lane shuffle tree: the order of the segment
+  // tasks (longBlock), i.e. of the oracle's g_long_major_sum.
+  if (si < siEnd) {
+    constexpr int kSegBatch = 4;
+    int segOff = (regCnt + kWave - 1) / kWave * kWave;  // the first whole group behind the regular entries
+    for (; si < siEnd; ++si) {
+      const uint32_t word = (uint32_t)ldUniform(reinterpret_cast<const int32_t*>(a.S.segDesc) + si);
+      const int segLen = (int)(word & 0xffffu);
+      const uint32_t* __restrict__ se = a.S.ent + e0 + segOff;
+      const double* __restrict__ sv = a.S.val + e0 + segOff;
+      double sacc = 0.0;
+      for (int b = 0; b < segLen; b += kSegBatch * kWave) {
+        uint32_t e4[kSegBatch];
+        double v4[kSegBatch], x4[kSegBatch];
+#pragma unroll
+        for (int k = 0; k < kSegBatch; ++k) {  // unconditional, clamped (a load in an exec-masked branch drains vmcnt)
+          const int q = b + k * kWave + lane;
+          const int qq = q < segLen ? q : segLen - 1;
+          e4[k] = se[qq];
+          v4[k] = sv[qq];
+        }
+#pragma unroll
+        for (int k = 0; k < kSegBatch; ++k) x4[k] = gather(e4[k]);
+#pragma unroll
+        for (int k = 0; k < kSegBatch; ++k)
+          if (b + k * kWave + lane < segLen) sacc += v4[k] * x4[k];
+      }
+      const double ssum = waveSum(sacc);
+      if (lane == 0) slots[word >> 16] = ssum;
+      segOff += (segLen + kWave - 1) / kWave * kWave;
+    }
+  }
+  if (a.S.noPace || nMed > 0) __syncthreads();  // (every wave's accumulators and segment sums are final before they are read)
   if (nMed > 0) {  // (block-uniform) medium majors: segment sums left to right -> the major's accumulator
     for (int t = tid; t < nMed; t += kSlabThreads) {
       if (TWO || t != tid) { med0 = a.S.medDesc[2 * (medBeg + t)]; med1 = a.S.medDesc[2 * (medBeg + t) + 1]; }

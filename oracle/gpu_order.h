@@ -21,7 +21,7 @@ static inline int g_chunk_for(long nnz) { return nnz < (1L << 18) ? G_CHUNK_SMAL
  * medMax entries: in-block segments — the segment sums of g_long_major_sum, and otherwise an ordinary major of its block)
  * and long (more: segment tasks, the major's contributions to the reductions in a slot of its own).
  *   nBlocks0 = ceil(nMajor / 256) capped at 256; medMax = half of the mean work per block, (nnz + 2 nMajor) / nBlocks0 / 2,
- * within [512, 16384].  Work of a major = its entries (0 for a long major) + 2; LDS units = 1 + its in-block segments of
+ * within [512, 16384].  Work of a major = its entries (half of them for a medium major, 0 for a long one) + 2; LDS units = 1 + its in-block segments of
  * 512 entries.  nBlocks = nBlocks0, or more when the units do not fit (cap 16384 units per block, 64 of them kept as room).
  * Block b takes majors while it is closer to ceil(work left / blocks left) with the next major than without, at least
  * one, never beyond the unit cap, and never so few / many that the blocks behind it could not hold / would not get the
@@ -56,7 +56,7 @@ static inline int g_slab_blocks(const int* beg, int nMajor, int nMinor, int long
   if (medMax < longLimit) medMax = longLimit;
   *medMaxOut = (int)medMax;
 #define G_LEN(r) (beg[(r) + 1] - beg[(r)])
-#define G_COST(r) ((long)(G_LEN(r) > medMax ? 0 : G_LEN(r)) + G_SLAB_MAJOR_COST)
+#define G_COST(r) ((long)(G_LEN(r) > medMax ? 0 : G_LEN(r) > longLimit ? G_LEN(r) / 2 : G_LEN(r)) + G_SLAB_MAJOR_COST)
 #define G_UNITS(r) (1L + ((G_LEN(r) > longLimit && G_LEN(r) <= medMax) ? (G_LEN(r) + G_SLAB_SEGMENT - 1) / G_SLAB_SEGMENT : 0))
   long rem = 0, unitsLeft = 0;
   for (int r = 0; r < nMajor; ++r) { rem += G_COST(r); unitsLeft += G_UNITS(r); }

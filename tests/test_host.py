@@ -185,7 +185,7 @@ def _slab_partition_restated(beg, n_major, n_minor, long_limit):
     unit_room = unit_cap - 64 if unit_cap - 64 > 64 else unit_cap
     nb = min(-(-n_major // 256), 256)
     med_max = max(min(max((nnz + 2 * n_major) // nb // 2, 512), 16384), long_limit)
-    cost = np.where(lens > med_max, 0, lens) + 2
+    cost = np.where(lens > med_max, 0, np.where(lens > long_limit, lens // 2, lens)) + 2
     units = 1 + np.where((lens > long_limit) & (lens <= med_max), -(-lens // 512), 0)
     nb = max(nb, -(-int(units.sum()) // unit_room))
     out, r, rem, units_left = [0], 0, int(cost.sum()), int(units.sum())
@@ -259,7 +259,7 @@ def test_slab_layout_is_a_permutation_of_the_csr(which, long_limit):
     # the block boundaries are the restated rule, and they balance work
     nb, mb, mm, bb = _slab_partition_restated(beg, n_major, P.n if which == 0 else P.m, long_limit)
     assert nb == sl["n_blocks"] and mb == sl["minor_bits"] and mm == med_max and np.array_equal(bb, blk)
-    cost = np.where(lens > med_max, 0, lens) + 2
+    cost = np.where(lens > med_max, 0, np.where(lens > long_limit, lens // 2, lens)) + 2
     work = np.add.reduceat(cost, blk[:-1])
     assert work.max() <= work.mean() + med_max / 2 + 2
     # a wave's regular entries are those of its majors
@@ -279,7 +279,7 @@ def test_slab_partition_balances_skewed_majors():
     lens[:20000] = 1  # a stretch of very short majors: these blocks hit no cap, they just own more majors
     beg = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     nb, mb, med_max, blk = _slab_partition_restated(beg, n_major, 300000, 256)
-    cost = np.where(lens > med_max, 0, lens) + 2
+    cost = np.where(lens > med_max, 0, np.where(lens > 256, lens // 2, lens)) + 2
     work = np.add.reduceat(cost, blk[:-1])
     assert nb == 256 and work.max() <= 1.02 * work.mean() + med_max / 2
     equal_count = np.add.reduceat(cost, np.arange(0, n_major, -(-n_major // 256)))
