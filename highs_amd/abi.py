@@ -134,13 +134,11 @@ class PdlpPrepared(C.Structure):
 
 class PdlpSlabLayout(C.Structure):
     _fields_ = [
-        ("rows_per_block", C.c_int32), ("slots_per_block", C.c_int32), ("n_blocks", C.c_int32), ("minor_bits", C.c_int32),
-        ("slab_width_log2", C.c_int32), ("n_long", C.c_int32), ("med_max", C.c_int32), ("n_segs", C.c_int32), ("n_med", C.c_int32),
-        ("list_len", C.c_int64),
+        ("rows_per_block", C.c_int32), ("rows_per_wave", C.c_int32), ("n_blocks", C.c_int32), ("minor_bits", C.c_int32),
+        ("slab_width_log2", C.c_int32), ("n_long", C.c_int32),
+        ("nnz_short", C.c_int64),
         ("wave_ptr", c_i32p), ("ent", C.POINTER(C.c_uint32)), ("val", c_f64p),
         ("long_mask", C.POINTER(C.c_uint32)), ("long_map", c_i32p), ("wave_beg", c_i32p),
-        ("wave_reg", c_i32p), ("wave_seg_beg", c_i32p), ("seg_desc", C.POINTER(C.c_uint32)),
-        ("block_med_beg", c_i32p), ("med_desc", C.POINTER(C.c_uint32)),
     ]
 
 

@@ -305,22 +305,17 @@ int pdlp_mi355x_host_slab_layout(const pdlp_prepared_t* prep, int32_t which, int
     c.val.assign(which ? prep->csc_val : prep->csr_val, (which ? prep->csc_val : prep->csr_val) + prep->nnz);
     pdlp::SlabLayout L;
     pdlp::buildSlabLayout(c, nMajor, nMinor, long_limit, pdlp::kSlabWidthLog2, L);
-    const pdlp::SlabPlan& P = L.plan;
-    out->rows_per_block = P.maxRowsPerBlock; out->slots_per_block = P.maxSlotsPerBlock; out->n_blocks = P.nBlocks;
-    out->minor_bits = P.minorBits; out->slab_width_log2 = L.slabWidthLog2; out->med_max = P.medMax;
-    out->n_long = (int32_t)L.longMap.size(); out->list_len = P.listLen;
-    out->n_segs = (int32_t)P.segDesc.size(); out->n_med = (int32_t)(P.medDesc.size() / 2);
-    out->wave_ptr = dupVec(P.wavePtr); out->ent = dupVec(L.ent); out->val = dupVec(L.val);
-    out->long_mask = dupVec(L.longMask); out->long_map = dupVec(L.longMap); out->wave_beg = dupVec(P.waveBeg);
-    out->wave_reg = dupVec(P.waveReg); out->wave_seg_beg = dupVec(P.waveSegBeg); out->seg_desc = dupVec(P.segDesc);
-    out->block_med_beg = dupVec(P.blockMedBeg); out->med_desc = dupVec(P.medDesc);
+    out->rows_per_block = L.rowsPerBlock; out->rows_per_wave = 0; out->n_blocks = L.nBlocks;
+    out->minor_bits = L.minorBits; out->slab_width_log2 = L.slabWidthLog2;
+    out->n_long = (int32_t)L.longMap.size(); out->nnz_short = (int64_t)L.ent.size();
+    out->wave_ptr = dupVec(L.wavePtr); out->ent = dupVec(L.ent); out->val = dupVec(L.val);
+    out->long_mask = dupVec(L.longMask); out->long_map = dupVec(L.longMap); out->wave_beg = dupVec(L.waveBeg);
   });
 }
 
 void pdlp_mi355x_free_slab_layout(pdlp_slab_layout_t* o) {
   if (!o) return;
   free(o->wave_ptr); free(o->ent); free(o->val); free(o->long_mask); free(o->long_map); free(o->wave_beg);
-  free(o->wave_reg); free(o->wave_seg_beg); free(o->seg_desc); free(o->block_med_beg); free(o->med_desc);
   memset(o, 0, sizeof(*o));
 }
 

@@ -432,189 +432,120 @@ int32_t bitsFor(int64_t count) {  // smallest b with 2^b >= count
   while (((int64_t)1 << b) < count) ++b;
   return b;
 }
-struct MajorClass {
-  const int32_t* beg;
-  int32_t longLimit, medMax;
-  int32_t len(int32_t r) const { return beg[r + 1] - beg[r]; }
-  bool medium(int32_t r) const { return len(r) > longLimit && len(r) <= medMax; }
-  bool isLong(int32_t r) const { return len(r) > medMax; }
-  int32_t segments(int32_t r) const { return medium(r) ? (len(r) + kSlabSegment - 1) / kSlabSegment : 0; }
-  // (a segment's entries are streamed four groups at a time with all their gathers in flight: about half the time per
-  // entry of the regular entries, whose gathers go one group ahead and whose runs are added through LDS)
-  int64_t cost(int32_t r) const { return (isLong(r) ? 0 : medium(r) ? len(r) / 2 : len(r)) + kSlabMajorCost; }
-  int64_t rowCost(int32_t r) const { return (len(r) > longLimit ? 0 : len(r)) + kSlabMajorCost; }  // in its wave's run: regular entries only
-  int64_t units(int32_t r) const { return 1 + segments(r); }
-};
+// Fills `units` consecutive ranges of [r0, r1) by work (see SlabPartition): out[0..units] boundaries.
+void fillByWork(const int32_t* beg, int32_t longLimit, int32_t r0, int32_t r1, int32_t units, int64_t cap, bool nonEmpty,
+                int32_t* out) {
+  auto cost = [&](int32_t r) -> int64_t { return slabMajorWork(beg[r + 1] - beg[r], longLimit); };
+  int64_t rem = 0;
+  for (int32_t r = r0; r < r1; ++r) rem += cost(r);
+  int32_t r = r0;
+  out[0] = r0;
+  for (int32_t u = 0; u < units; ++u) {
+    const int64_t left = units - u;
+    const int64_t target = (rem + left - 1) / left;
+    const int64_t rows = (int64_t)r1 - r;
+    const int64_t minRows = std::max<int64_t>(nonEmpty && rows > 0 ? 1 : 0, rows - (left - 1) * cap);
+    const int64_t maxRows = std::min<int64_t>(cap, nonEmpty ? std::max<int64_t>(rows - (left - 1), 1) : rows);
+    int64_t acc = 0, cnt = 0;
+    while (cnt < rows && cnt < maxRows) {  // a major is taken while the range is closer to its target with it than without
+      const int64_t c = cost(r);
+      if (cnt >= minRows && 2 * acc + c > 2 * target) break;
+      acc += c; ++r; ++cnt;
+    }
+    rem -= acc;
+    out[u + 1] = r;
+  }
+}
 }  // namespace
+
+int64_t slabMajorWork(int32_t len, int32_t longLimit) {
+  if (len > longLimit) return kSlabMajorCost;  // (its segment tasks run elsewhere)
+  return (int64_t)len + ((int64_t)len * std::min(len, 64)) / 32 + kSlabMajorCost;
+}
 
 bool slabFits(int32_t nMajor, int32_t nMinor) {
   (void)nMajor;
   return bitsFor(nMinor) <= 28;  // at least 16 majors per wave
 }
 
-SlabPlan slabPlan(const int32_t* beg, int32_t nMajor, int32_t nMinor, int32_t longLimit) {
-  SlabPlan P;
+SlabPartition slabPartition(const int32_t* beg, int32_t nMajor, int32_t nMinor, int32_t longLimit) {
+  SlabPartition P;
   if (!slabFits(nMajor, nMinor)) throw std::runtime_error("slab layout: minor index does not fit the entry packing");
-  P.longLimit = longLimit;
   P.minorBits = std::max(bitsFor(nMinor), 4);
-  const int64_t waveCap = std::min<int64_t>((int64_t)1 << (32 - P.minorBits), kSlabBlockUnitCap);
-  const int64_t nnz = nMajor > 0 ? (int64_t)beg[nMajor] - beg[0] : 0;
+  const int64_t waveCap = std::min<int64_t>((int64_t)1 << (32 - P.minorBits), kSlabBlockRowCap);
+  const int64_t blockCap = std::min<int64_t>(kSlabBlockRowCap, waveCap * kSlabWavesPerBlock);
   int64_t nB = ((int64_t)nMajor + kSlabMinRowsPerBlock - 1) / kSlabMinRowsPerBlock;
   nB = std::min<int64_t>(nB, kSlabTargetBlocks);
-  if (nB > 0) P.medMax = (int32_t)std::min<int64_t>(std::max<int64_t>((nnz + (int64_t)kSlabMajorCost * nMajor) / nB / 2, kSlabSegment), kSlabMedMaxCap);
-  else P.medMax = kSlabSegment;
-  if (P.medMax < longLimit) P.medMax = longLimit;
-  const MajorClass C{beg, longLimit, P.medMax};
-  // units: the block cap keeps room for one more major (at most 1 + 32 units), so that a block can always take the next one
-  const int64_t unitCap = std::min<int64_t>(kSlabBlockUnitCap, waveCap * kSlabWavesPerBlock) ;
-  const int64_t unitRoom = unitCap - 64 > 64 ? unitCap - 64 : unitCap;
-  int64_t totalUnits = 0, rem = 0;
-  for (int32_t r = 0; r < nMajor; ++r) { totalUnits += C.units(r); rem += C.cost(r); }
-  nB = std::max<int64_t>(nB, (totalUnits + unitRoom - 1) / unitRoom);
+  nB = std::max<int64_t>(nB, ((int64_t)nMajor + blockCap - 1) / blockCap);
   P.nBlocks = (int32_t)nB;
-  const int32_t nW = P.nBlocks * kSlabWavesPerBlock;
-  P.waveBeg.assign((size_t)nW + 1, 0);
-  P.waveReg.assign((size_t)nW, 0);
-  P.wavePtr.assign((size_t)nW + 1, 0);
-  P.waveSegBeg.assign((size_t)nW + 1, 0);
-  P.blockMedBeg.assign((size_t)nB + 1, 0);
+  P.waveBeg.assign((size_t)nB * kSlabWavesPerBlock + 1, 0);
   if (nB == 0) return P;
-  // ---- blocks ----
-  std::vector<int32_t> blockBeg((size_t)nB + 1, 0);
-  {
-    int32_t r = 0;
-    int64_t unitsLeft = totalUnits;
-    for (int64_t b = 0; b < nB; ++b) {
-      const int64_t left = nB - b, target = (rem + left - 1) / left, rows = (int64_t)nMajor - r;
-      const int64_t minUnits = unitsLeft - (left - 1) * unitRoom;  // the blocks behind can hold this much at most
-      const int64_t maxRows = std::max<int64_t>(rows - (left - 1), 1);  // ... and get one major each at least
-      int64_t acc = 0, cnt = 0, units = 0;
-      while (cnt < rows && cnt < maxRows) {
-        const int64_t c = C.cost(r), u = C.units(r);
-        if (cnt > 0 && units + u > unitCap) break;
-        const bool must = cnt == 0 || units < minUnits;
-        if (!must && 2 * acc + c > 2 * target) break;  // closer to the target without this major
-        acc += c; units += u; ++r; ++cnt;
-      }
-      rem -= acc;
-      unitsLeft -= units;
-      blockBeg[b + 1] = r;
-    }
-    if (blockBeg[nB] != nMajor) throw std::runtime_error("slab layout: the majors do not fit the blocks");
-  }
-  // ---- inside the blocks: segments of the medium majors round robin, then the majors by work ----
-  int64_t pos = 0;
+  std::vector<int32_t> blockBeg((size_t)nB + 1);
+  fillByWork(beg, longLimit, 0, nMajor, (int32_t)nB, blockCap, true, blockBeg.data());
   for (int32_t b = 0; b < (int32_t)nB; ++b) {
-    const int32_t r0 = blockBeg[b], r1 = blockBeg[b + 1];
-    std::vector<SlabSeg> wsegs[kSlabWavesPerBlock];
-    int64_t segCost[kSlabWavesPerBlock] = {0};
-    int32_t slot = 0;
-    P.blockMedBeg[b] = (int32_t)(P.medDesc.size() / 2);
-    int64_t regLeft = 0;
-    for (int32_t r = r0; r < r1; ++r) {
-      regLeft += C.rowCost(r);
-      const int32_t ns = C.segments(r);
-      if (ns == 0) continue;
-      P.medDesc.push_back((uint32_t)(r - r0));
-      P.medDesc.push_back(((uint32_t)slot << 8) | (uint32_t)ns);
-      for (int32_t k = 0; k < ns; ++k, ++slot) {
-        const int32_t a = beg[r] + k * kSlabSegment, e = std::min(beg[r + 1], a + kSlabSegment);
-        wsegs[slot % kSlabWavesPerBlock].push_back(SlabSeg{a, e - a, 0, slot});
-        segCost[slot % kSlabWavesPerBlock] += (e - a) / 2;
-      }
-    }
-    P.maxSlotsPerBlock = std::max(P.maxSlotsPerBlock, slot);
-    P.maxRowsPerBlock = std::max(P.maxRowsPerBlock, r1 - r0);
-    int64_t segLeft = 0;
-    for (int w = 0; w < kSlabWavesPerBlock; ++w) segLeft += segCost[w];
-    int32_t r = r0;
-    for (int w = 0; w < kSlabWavesPerBlock; ++w) {
-      const int32_t gw = b * kSlabWavesPerBlock + w;
-      const int64_t left = kSlabWavesPerBlock - w, rows = (int64_t)r1 - r;
-      const int64_t target = (regLeft + segLeft + left - 1) / left - segCost[w];
-      const int64_t minRows = std::max<int64_t>(0, rows - (left - 1) * waveCap);
-      int64_t acc = 0, cnt = 0, reg = 0;
-      P.waveBeg[gw] = r;
-      while (cnt < rows && cnt < waveCap) {
-        const int64_t c = C.rowCost(r);
-        const bool must = cnt < minRows || w == kSlabWavesPerBlock - 1;
-        if (!must && 2 * acc + c > 2 * target) break;
-        acc += c; reg += c - kSlabMajorCost; ++r; ++cnt;
-      }
-      regLeft -= acc;
-      segLeft -= segCost[w];
-      P.waveReg[gw] = (int32_t)reg;
-      P.wavePtr[gw] = (int32_t)pos;
-      P.waveSegBeg[gw] = (int32_t)P.segs.size();
-      pos += wsegs[w].empty() ? reg : (reg + 63) / 64 * 64;  // (segments start at a whole group of THIS wave's list)
-      for (SlabSeg sgm : wsegs[w]) {
-        sgm.dst = (int32_t)pos;
-        pos += (sgm.len + 63) / 64 * 64;
-        P.segs.push_back(sgm);
-        P.segDesc.push_back(((uint32_t)sgm.slot << 16) | (uint32_t)sgm.len);
-      }
-      if (pos >= (int64_t)0x7fffffff - 64) throw std::runtime_error("slab layout: too many entries");
-    }
-    if (r != r1) throw std::runtime_error("slab layout: the majors of a block do not fit its waves");
+    fillByWork(beg, longLimit, blockBeg[b], blockBeg[b + 1], kSlabWavesPerBlock, waveCap, false,
+               P.waveBeg.data() + (size_t)b * kSlabWavesPerBlock);
+    P.maxRowsPerBlock = std::max(P.maxRowsPerBlock, blockBeg[b + 1] - blockBeg[b]);
   }
-  P.waveBeg[nW] = nMajor;
-  P.wavePtr[nW] = (int32_t)pos;
-  P.waveSegBeg[nW] = (int32_t)P.segs.size();
-  P.blockMedBeg[nB] = (int32_t)(P.medDesc.size() / 2);
-  P.listLen = pos;
   return P;
 }
 
 void buildSlabLayout(const Compressed& csr, int32_t nMajor, int32_t nMinor, int32_t longLimit, int32_t slabWidthLog2,
-                     SlabLayout& out, const SlabPlan* planIn) {
+                     SlabLayout& out) {
   out = SlabLayout();
-  out.plan = planIn ? *planIn : slabPlan(csr.beg.data(), nMajor, nMinor, longLimit);
-  const SlabPlan& P = out.plan;
+  SlabPartition P = slabPartition(csr.beg.data(), nMajor, nMinor, longLimit);
+  out.rowsPerBlock = P.maxRowsPerBlock;
+  out.nBlocks = P.nBlocks;
+  out.minorBits = P.minorBits;
   out.slabWidthLog2 = slabWidthLog2;
-  const int32_t nWaves = P.nBlocks * kSlabWavesPerBlock;
+  out.waveBeg = std::move(P.waveBeg);
+  const int32_t nWaves = out.nBlocks * kSlabWavesPerBlock;
   const int32_t S = std::max(1, (int32_t)(((int64_t)nMinor + ((int64_t)1 << slabWidthLog2) - 1) >> slabWidthLog2));
   if ((int64_t)nWaves * S >= (int64_t)0x7fffffff) throw std::runtime_error("slab layout: too many segments");
   out.longMask.assign(((size_t)nMajor + 31) / 32 + 1, 0u);
   out.longCsr.beg.push_back(0);
-  out.ent.assign((size_t)P.listLen, 0u);   // (padding: minor 0 with value 0 — a product that is +-0)
-  out.val.assign((size_t)P.listLen, 0.0);
-  std::vector<int32_t> pos((size_t)S);
-  for (int32_t w = 0; w < nWaves; ++w) {
-    // per-slab counts of the wave's regular entries -> start of every (wave, slab) stretch
-    std::fill(pos.begin(), pos.end(), 0);
-    for (int32_t r = P.waveBeg[w]; r < P.waveBeg[w + 1]; ++r) {
+  // pass 1: per (wave, slab) counts; long majors go to the side CSR
+  std::vector<int32_t> count((size_t)nWaves * S, 0);
+  for (int32_t w = 0; w < nWaves; ++w)
+    for (int32_t r = out.waveBeg[w]; r < out.waveBeg[w + 1]; ++r) {
       const int32_t len = csr.beg[r + 1] - csr.beg[r];
-      if (len > P.medMax) {
+      if (len > longLimit) {
         out.longMask[(size_t)r >> 5] |= 1u << (r & 31);
         out.longMap.push_back(r);
         out.longCsr.idx.insert(out.longCsr.idx.end(), csr.idx.begin() + csr.beg[r], csr.idx.begin() + csr.beg[r + 1]);
         out.longCsr.val.insert(out.longCsr.val.end(), csr.val.begin() + csr.beg[r], csr.val.begin() + csr.beg[r + 1]);
         out.longCsr.beg.push_back((int32_t)out.longCsr.idx.size());
+        continue;
       }
-      if (len > longLimit) continue;
-      for (int32_t p = csr.beg[r]; p < csr.beg[r + 1]; ++p) ++pos[csr.idx[p] >> slabWidthLog2];
+      for (int32_t p = csr.beg[r]; p < csr.beg[r + 1]; ++p) ++count[(size_t)w * S + (csr.idx[p] >> slabWidthLog2)];
     }
-    int32_t acc = P.wavePtr[w];
-    for (int32_t k = 0; k < S; ++k) { const int32_t c = pos[k]; pos[k] = acc; acc += c; }
-    if (acc - P.wavePtr[w] != P.waveReg[w]) throw std::runtime_error("slab layout: plan and matrix disagree");
-    // majors in order, minors ascending within a major => every (wave, slab) stretch comes out sorted by (local major, minor)
-    for (int32_t r = P.waveBeg[w]; r < P.waveBeg[w + 1]; ++r) {
-      const int32_t len = csr.beg[r + 1] - csr.beg[r];
-      if (len > longLimit) continue;
-      const uint32_t lr = (uint32_t)(r - P.waveBeg[w]);
-      for (int32_t p = csr.beg[r]; p < csr.beg[r + 1]; ++p) {
-        const int32_t c = csr.idx[p];
-        const int32_t q = pos[c >> slabWidthLog2]++;
-        out.ent[q] = (lr << P.minorBits) | (uint32_t)c;
-        out.val[q] = csr.val[p];
-      }
+  // exclusive scan in (wave, slab) order; wavePtr = the wave boundaries of it
+  out.wavePtr.assign((size_t)nWaves + 1, 0);
+  std::vector<int32_t> pos((size_t)nWaves * S);
+  int64_t acc = 0;
+  for (int32_t w = 0; w < nWaves; ++w) {
+    out.wavePtr[w] = (int32_t)acc;
+    for (int32_t k = 0; k < S; ++k) {
+      pos[(size_t)w * S + k] = (int32_t)acc;
+      acc += count[(size_t)w * S + k];
     }
   }
-  // the segments of the medium majors: entries in the major's own (ascending minor) order, local-major field unused
-  for (const SlabSeg& g : P.segs)
-    for (int32_t k = 0; k < g.len; ++k) {
-      out.ent[(size_t)g.dst + k] = (uint32_t)csr.idx[(size_t)g.src + k];
-      out.val[(size_t)g.dst + k] = csr.val[(size_t)g.src + k];
+  out.wavePtr[nWaves] = (int32_t)acc;
+  out.ent.resize((size_t)acc);
+  out.val.resize((size_t)acc);
+  // pass 2: majors in order, minors ascending within a major => each (wave, slab) segment comes out
+  // sorted by (local major, minor)
+  for (int32_t w = 0; w < nWaves; ++w)
+    for (int32_t r = out.waveBeg[w]; r < out.waveBeg[w + 1]; ++r) {
+      const int32_t len = csr.beg[r + 1] - csr.beg[r];
+      if (len > longLimit) continue;
+      const uint32_t lr = (uint32_t)(r - out.waveBeg[w]);
+      for (int32_t p = csr.beg[r]; p < csr.beg[r + 1]; ++p) {
+        const int32_t c = csr.idx[p];
+        const int32_t q = pos[(size_t)w * S + (c >> slabWidthLog2)]++;
+        out.ent[q] = (lr << out.minorBits) | (uint32_t)c;
+        out.val[q] = csr.val[p];
+      }
     }
 }
 

@@ -114,72 +114,54 @@ LongPlan planLong(const std::vector<int32_t>& beg, const std::vector<int32_t>& l
 // minor indices, 1 MB by default), in step with all the others, so the slab being gathered from stays
 // in every XCD's L2.  The unit of ownership is the WAVE: a block of 16 waves (one block per CU) owns
 // the consecutive majors [waveBeg[16 b], waveBeg[16 b + 16]), wave w of it [waveBeg[16 b + w],
-// waveBeg[16 b + w + 1]).  Blocks and waves are cut by WORK, not by major count (SlabPlan below):
+// waveBeg[16 b + w + 1]).  Blocks and waves are cut by WORK, not by major count (slabPartition below):
 // with skewed major lengths a block of equal major COUNT streams up to twice the mean number of entries
-// and the launch is its slowest block (round 4, per-block phase profile).
-//   Three classes of majors by length:
-//   * regular (at most longLimit = 256 entries): in the owning wave's list, sorted by (minor >> slabWidthLog2,
-//     local major, minor); the first lane of a run of equal majors adds the run left to right.  An entry packs
-//     (localMajor << minorBits | minor), local = major - the wave's first major, with the GLOBAL minor — no slab table:
-//     a slab boundary inside a 64-entry group shows up as a descent of the local major;
-//   * medium (longLimit < entries <= medMax): cut into segments of 512 entries that are dealt to the 16 waves of the
-//     block that OWNS the major and appended to those waves' lists behind their regular entries (each segment padded
-//     to whole 64-entry groups with zero-valued entries).  A wave streams them through the same register pipeline:
-//     lane l adds the products of the segment's entries l, l+64, ... in a register, 64-lane shuffle tree, the segment
-//     sum goes to a slot in LDS; after the stream one lane adds a major's segment sums left to right.  That is the
-//     summation order of the segment tasks below (oracle: g_long_major_sum) — no extra workgroups, no tickets, nothing
-//     crosses the block — and the major then is an ordinary major of the block for the epilogue;
-//   * long (more than medMax entries): left out (marked in longMask, one bit per major), segment tasks as before
-//     (LongPlan): a major that would unbalance its block.
-struct SlabSeg { int32_t src, len, dst, slot; };  // CSR position of the first entry, entries (<= 512), position in ent/val, slot in the block
-struct SlabPlan {
-  int32_t nBlocks = 0, minorBits = 0, longLimit = 0, medMax = 0;
-  int32_t maxRowsPerBlock = 0, maxSlotsPerBlock = 0;
-  int64_t listLen = 0;                // entries of all lists incl. padding
-  std::vector<int32_t> waveBeg;       // [16*nBlocks+1] first major of every wave
-  std::vector<int32_t> waveReg;       // [16*nBlocks] regular entries of the wave
-  std::vector<int32_t> wavePtr;       // [16*nBlocks+1] list offsets: regular entries, (pad to 64 if segments follow), segments
-  std::vector<int32_t> waveSegBeg;    // [16*nBlocks+1] the wave's segments in segs / segDesc
-  std::vector<SlabSeg> segs;          // wave by wave, in list order
-  std::vector<uint32_t> segDesc;      // [nSegs] slot << 16 | len (what the kernel reads)
-  std::vector<int32_t> blockMedBeg;   // [nBlocks+1] the block's medium majors in medDesc
-  std::vector<uint32_t> medDesc;      // [2*nMed] {major - first major of the block, firstSlot << 8 | nSeg}
-  int32_t blockBeg(int32_t b) const { return waveBeg[(size_t)b * 16]; }
-};
+// and the launch is its slowest block (round 4, per-block phase profile).  A wave's nonzeros are ONE
+// dense stream sorted by (minor >> slabWidthLog2, local major, minor): no windows, no per-slab padding.
+// An entry packs (localMajor << minorBits | minor), local = major - the wave's first major, with the
+// GLOBAL minor, so the kernel needs no slab table at all — a slab boundary inside a 64-entry group
+// shows up as a descent of the local major.  Majors longer than `longLimit` are left out (marked in
+// longMask, one bit per major) and handled as segment tasks.
 constexpr int32_t kSlabWidthLog2 = 17;  // 1 MB slabs: 56.2 vs 57.0 us per A x at the bench size (15..18 within 1.5 %)
 constexpr int32_t kSlabWavesPerBlock = 16;
 constexpr int32_t kSlabTargetBlocks = 256;  // CUs of an MI355X
-constexpr int32_t kSlabBlockUnitCap = 16384;// LDS doubles per block for the majors' accumulators AND the segment slots: 128 KB of 160
+constexpr int32_t kSlabBlockRowCap = 16384; // majors per block: 128 KB of LDS accumulators (gfx950 has 160 KB per CU)
 constexpr int32_t kSlabMinRowsPerBlock = 256;
 constexpr int32_t kSlabMajorCost = 2;       // work of a major besides its entries (epilogue), in entries
-constexpr int32_t kSlabSegment = 512;       // entries per in-block segment (= pdlp_kernels.hpp kLongSegment: the same sums)
-constexpr int32_t kSlabMedMaxCap = 16384;   // a medium major has at most 32 segments
 
-// The plan.  Work of major r = (its entries — half of them for a medium major, none for a long one) + kSlabMajorCost; LDS units of major r = 1 + its
-// segments (medium majors).  nBlocks = ceil(nMajor / 256) capped at 256 (more only when the units do not fit);
-// medMax = half of the mean work per block, within [512, 16384].  Blocks are filled one after the other: block b
-// takes majors while it is closer to ceil(work left / blocks left) with the next major than without, at least one,
-// at most kSlabBlockUnitCap units, and never so few / many that the blocks behind it could not hold / would not get
-// the rest.  Inside a block: segment i of the block (medium majors in order, their segments in order) goes to wave
-// i mod 16; the majors are then dealt to the 16 waves the same way by work, each wave's target lowered by the segment
-// entries it already has (cap: 2^(32 - minorBits) majors, the local-major field of an entry).  Sequential and exact
-// in integers: the device-side set-up (pdlp_setup.hip) calls this same function on the downloaded major starts;
-// oracle/gpu_order.h restates the BLOCK boundaries and medMax (all that sums depend on).
+// The partition of the majors over blocks and waves.  Work of a major of len entries = len + len * min(len, 64) / 32 + 2
+// (kSlabMajorCost: the epilogue), 2 alone for a long major: the entries of a run of equal majors inside a 64-entry
+// group are added by ONE lane, so a group made of one run of 64 costs about three times a group of eight runs of
+// eight (config d, blocks of equal ENTRY counts: the block with the longest rows still streamed 1.66x the mean time).
+// nBlocks = ceil(nMajor / 256) capped at 256 (more only when 256 blocks of 16384 majors do not hold the operand).
+// Blocks are filled one after the other: block b takes majors while it is closer to ceil(work left / blocks left)
+// with the next major than without, but at least one, at most kSlabBlockRowCap, and never so few / many that the
+// blocks behind it could not hold / would not get the rest; the 16 waves of a block are filled the same way from the
+// block's majors (cap: 2^(32 - minorBits) majors, the local-major field of an entry).  Sequential and exact in
+// integers: the device-side set-up (pdlp_setup.hip) calls this same function on the downloaded major starts,
+// oracle/gpu_order.h restates it.
+int64_t slabMajorWork(int32_t len, int32_t longLimit);
+struct SlabPartition {
+  int32_t nBlocks = 0, minorBits = 0, maxRowsPerBlock = 0;
+  std::vector<int32_t> waveBeg;  // [16*nBlocks+1] first major of every wave
+  int32_t blockBeg(int32_t b) const { return waveBeg[(size_t)b * kSlabWavesPerBlock]; }
+};
 // false: the minor index does not fit the entry packing (nMinor > 2^28: the caller uses the CSR stream kernel)
 bool slabFits(int32_t nMajor, int32_t nMinor);
-SlabPlan slabPlan(const int32_t* beg, int32_t nMajor, int32_t nMinor, int32_t longLimit);
+SlabPartition slabPartition(const int32_t* beg, int32_t nMajor, int32_t nMinor, int32_t longLimit);
 
 struct SlabLayout {
-  SlabPlan plan;
-  int32_t slabWidthLog2 = 0;
-  std::vector<uint32_t> ent;      // [plan.listLen]
-  std::vector<double> val;        // [plan.listLen]
-  std::vector<uint32_t> longMask; // [ceil(nMajor/32)+1] bit r: major r is a long one
+  int32_t rowsPerBlock = 0;  // most majors in one block (LDS accumulators)
+  int32_t nBlocks = 0, minorBits = 0, slabWidthLog2 = 0;
+  std::vector<int32_t> waveBeg;   // [16*nBlocks+1] first major of every wave
+  std::vector<int32_t> wavePtr;   // [16*nBlocks+1] entry offsets
+  std::vector<uint32_t> ent;      // [nnzShort]
+  std::vector<double> val;        // [nnzShort]
+  std::vector<uint32_t> longMask; // [ceil(nMajor/32)] bit r: major r is a long one
   Compressed longCsr;             // compacted long majors
   std::vector<int32_t> longMap;   // compact index -> major
 };
-// plan: a plan computed before (slabPlan of the same arguments), or nullptr
 void buildSlabLayout(const Compressed& csr, int32_t nMajor, int32_t nMinor, int32_t longLimit, int32_t slabWidthLog2,
-                     SlabLayout& out, const SlabPlan* plan = nullptr);
+                     SlabLayout& out);
 
 }  // namespace pdlp

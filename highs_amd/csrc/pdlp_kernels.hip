@@ -485,12 +485,10 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
     longBlock<EPI, kWaves>(a, epiL, (int)blockIdx.x - a.S.nBlocks, reinterpret_cast<double*>(smem));
     return;
   }
-  // dynamic LDS: acc[R] f64 | segment slots[SL] f64 | stg[16][64] f64 | scratch[2][16] f64 | (kAtyFused) trial scratch[4][4] f64, DevState
+  // dynamic LDS: acc[R] f64 | stg[16][64] f64 | scratch[2][16] f64 | (kAtyFused) trial scratch[4][4] f64, DevState
   const int R = (a.S.rowsPerBlock + 1) & ~1;  // (the most majors any block owns; even: the strips behind stay 16-byte aligned)
-  const int SL = (a.S.slotsPerBlock + 1) & ~1;
   double* acc = reinterpret_cast<double*>(smem);
-  double* slots = acc + R;  // sums of the in-block segments of the block's medium majors
-  double* stgAll = slots + SL;
+  double* stgAll = acc + R;
   double(*scratch)[kWaves] = reinterpret_cast<double(*)[kWaves]>(stgAll + kSlabThreads);
 
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
@@ -502,11 +500,7 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
   const int rBase = ldUniform(a.S.waveBeg + blk * kWaves), rEnd = ldUniform(a.S.waveBeg + blk * kWaves + kWaves);  // never empty
   const int wBeg = ldUniform(a.S.waveBeg + gw);
   const int Rw = ldUniform(a.S.waveBeg + gw + 1) - wBeg;
-  const int e0 = ldUniform(a.S.wavePtr + gw);
-  const int regCnt = ldUniform(a.S.waveReg + gw);  // the head of the list: regular entries; behind them (from the next whole group) the segments
-  int si = ldUniform(a.S.waveSegBeg + gw);
-  const int siEnd = ldUniform(a.S.waveSegBeg + gw + 1);
-  const int medBeg = ldUniform(a.S.blockMedBeg + blk), nMed = ldUniform(a.S.blockMedBeg + blk + 1) - medBeg;
+  const int e0 = ldUniform(a.S.wavePtr + gw), e1 = ldUniform(a.S.wavePtr + gw + 1);
   double* wacc = acc + (wBeg - rBase);
   double* stg = stgAll + wave * kWave;
   Epi<EPI> epi(a);
@@ -532,10 +526,6 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
       fix[k].d = 0.0; fix[k].e = a.v.qdiag ? ldStream(a.v.qdiag + r) : 0.0;  // (QP: the diagonal of Q of the prox step)
     }
   }
-
-  // this thread's medium major (if the block has that many): descriptor fetched ahead of the stream
-  uint32_t med0 = 0u, med1 = 0u;
-  if (!TWO && tid < nMed) { med0 = a.S.medDesc[2 * (medBeg + tid)]; med1 = a.S.medDesc[2 * (medBeg + tid) + 1]; }  // (TWO: 64 registers — fetched behind the stream)
 
   // Consume one 64-entry group of this wave: products to the wave's LDS strip, the first lane of each run of equal
   // local majors adds the run, left to right, onto the major's accumulator (ascending stretches one after the other
@@ -584,9 +574,9 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
   // wave's last entry they re-read that entry (same cache line), and groups past nG contribute nothing.
   const uint32_t* __restrict__ ent = a.S.ent + e0;
   const double* __restrict__ val = a.S.val + e0;
-  const int cnt = regCnt;  // the paced stream: the regular entries at the head of the list (the segments behind them: below)
+  const int cnt = e1 - e0;
   const int nG = (cnt + kWave - 1) / kWave;
-  const int last = cnt > 0 ? cnt - 1 : 0;  // (an empty wave reads entry e0, which exists: ent/val carry pad elements)
+  const int last = cnt > 0 ? cnt - 1 : 0;  // (an empty wave reads entry e0, which exists: ent/val carry one pad element)
   auto entryIndex = [&](int g) { const int q = g * kWave + lane; return q < last ? q : last; };
   auto gather = [&](uint32_t e) -> double {
     const uint32_t off = (e & mmask) << 3;  // byte offset: minor < 2^26
@@ -633,53 +623,7 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
       if (!a.S.noPace) __syncthreads();  // pacing: the CU's waves stay on the same slab
     }
   }
-  // ---- the in-block segments of this wave (medium majors of the block) ----
-  // Their gathers go wherever the major's minors are — not with the slab the block is sweeping — so every one is a miss
-  // of its own: not through the paced one-gather-ahead pipeline above (measured: a serial miss per 64 entries, 2 us each),
-  // but four groups at a time, 8 entry / value loads and then 4 gathers per lane in flight, free-running.  Lane l adds the
-  // products of the segment's entries l, l+64, ... in ascending order, 64-lane shuffle tree: the order of the segment
-  // tasks (longBlock), i.e. of the oracle's g_long_major_sum.
-  if (si < siEnd) {
-    constexpr int kSegBatch = 4;
-    int segOff = (regCnt + kWave - 1) / kWave * kWave;  // the first whole group behind the regular entries
-    for (; si < siEnd; ++si) {
-      const uint32_t word = (uint32_t)ldUniform(reinterpret_cast<const int32_t*>(a.S.segDesc) + si);
-      const int segLen = (int)(word & 0xffffu);
-      const uint32_t* __restrict__ se = a.S.ent + e0 + segOff;
-      const double* __restrict__ sv = a.S.val + e0 + segOff;
-      double sacc = 0.0;
-      for (int b = 0; b < segLen; b += kSegBatch * kWave) {
-        uint32_t e4[kSegBatch];
-        double v4[kSegBatch], x4[kSegBatch];
-#pragma unroll
-        for (int k = 0; k < kSegBatch; ++k) {  // unconditional, clamped (a load in an exec-masked branch drains vmcnt)
-          const int q = b + k * kWave + lane;
-          const int qq = q < segLen ? q : segLen - 1;
-          e4[k] = se[qq];
-          v4[k] = sv[qq];
-        }
-#pragma unroll
-        for (int k = 0; k < kSegBatch; ++k) x4[k] = gather(e4[k]);
-#pragma unroll
-        for (int k = 0; k < kSegBatch; ++k)
-          if (b + k * kWave + lane < segLen) sacc += v4[k] * x4[k];
-      }
-      const double ssum = waveSum(sacc);
-      if (lane == 0) slots[word >> 16] = ssum;
-      segOff += (segLen + kWave - 1) / kWave * kWave;
-    }
-  }
-  if (a.S.noPace || nMed > 0) __syncthreads();  // (every wave's accumulators and segment sums are final before they are read)
-  if (nMed > 0) {  // (block-uniform) medium majors: segment sums left to right -> the major's accumulator
-    for (int t = tid; t < nMed; t += kSlabThreads) {
-      if (TWO || t != tid) { med0 = a.S.medDesc[2 * (medBeg + t)]; med1 = a.S.medDesc[2 * (medBeg + t) + 1]; }
-      const int first = (int)(med1 >> 8), ns = (int)(med1 & 0xffu);
-      double total = 0.0;
-      for (int k = 0; k < ns; ++k) total += slots[first + k];
-      acc[med0] = total;
-    }
-    __syncthreads();
-  }
+  if (a.S.noPace) __syncthreads();  // (free-running waves: every wave's accumulators are final before the epilogue reads them)
 
   profStamp(0);
   const uint32_t* __restrict__ mask = a.S.longMask;  // bit r: major r is a long one (its segment tasks own it)
@@ -1192,7 +1136,7 @@ void launchSpmv(const MatView& M, SpmvArgs a, hipStream_t s) {
   const int nTasks = M.lng.nTasks;
   if (M.useSlab && M.slab.nBlocks > 0) {
     a.S = M.slab;
-    const size_t lds = (size_t)(((M.slab.rowsPerBlock + 1) & ~1) + ((M.slab.slotsPerBlock + 1) & ~1)) * 8 + kSlabThreads * 8 + 2 * (kSlabThreads / kWave) * 8;
+    const size_t lds = (size_t)((M.slab.rowsPerBlock + 1) & ~1) * 8 + kSlabThreads * 8 + 2 * (kSlabThreads / kWave) * 8;
     const dim3 grid(M.slab.nBlocks + (nTasks + M.lng.taskGroup - 1) / M.lng.taskGroup);  // one task group per extra workgroup
     // (gather distance 2 / 3 with 4 / 6 slots measured the same as (3, 1) on the random and on the structured LP, round 3)
     // segment tasks ride along: register budget for two resident blocks per CU, so that a task block runs NEXT to a streaming one
@@ -1222,7 +1166,7 @@ void launchSpmvAtyInteract(const MatView& At, const IterVecs& v, const DevState*
 }
 namespace {
 size_t fusedLds(const MatView& At) {
-  return (size_t)(((At.slab.rowsPerBlock + 1) & ~1) + ((At.slab.slotsPerBlock + 1) & ~1)) * 8 + kSlabThreads * 8 + 2 * (kSlabThreads / kWave) * 8 + 4 * (kVecThreads / kWave) * 8 +
+  return (size_t)((At.slab.rowsPerBlock + 1) & ~1) * 8 + kSlabThreads * 8 + 2 * (kSlabThreads / kWave) * 8 + 4 * (kVecThreads / kWave) * 8 +
          sizeof(DevState) + 16;
 }
 }  // namespace

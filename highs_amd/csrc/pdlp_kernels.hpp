@@ -150,20 +150,14 @@ struct LongMat {
 // owning the consecutive majors [waveBeg[gw], waveBeg[gw+1]) (cut by work, pdlp_host.hpp slabPartition) and its own
 // sorted entry list.
 constexpr int kSlabThreads = 1024;
-constexpr int kSlabMaxRows = 16384;  // majors + segment slots per block (LDS: 128 KB of the 160 KB)
+constexpr int kSlabMaxRows = 16384;  // majors per block (LDS accumulators: 128 KB of the 160 KB)
 struct SlabMat {
-  const int32_t* wavePtr;    // [16*nBlocks+1] list offsets per wave: regular entries, (pad to 64), segment groups
-  const uint32_t* ent;       // [listLen] (localMajor << minorBits | minor)
-  const double* val;         // [listLen]
+  const int32_t* wavePtr;    // [16*nBlocks+1] entry offsets per wave
+  const uint32_t* ent;       // [nnz] (localMajor << minorBits | minor)
+  const double* val;         // [nnz]
   const uint32_t* longMask;  // [ceil(nMajor/32)+1] bit r: major r is a long one
   const int32_t* waveBeg;    // [16*nBlocks+1] first major of every wave
-  const int32_t* waveReg;    // [16*nBlocks] regular entries of the wave (the head of its list)
-  const int32_t* waveSegBeg; // [16*nBlocks+1] the wave's in-block segments in segDesc
-  const uint32_t* segDesc;   // slot << 16 | entries
-  const int32_t* blockMedBeg;// [nBlocks+1] the block's medium majors in medDesc
-  const uint32_t* medDesc;   // {major - first major of the block, firstSlot << 8 | nSeg}
   int32_t nMajor, nBlocks, rowsPerBlock, minorBits;  // rowsPerBlock: the most majors any block owns (LDS accumulators)
-  int32_t slotsPerBlock;     // the most segment slots any block needs (LDS, behind the accumulators)
   // 1: no block barrier per 64-entry group.  The barrier keeps the CU's waves on the same slab of the gathered vector
   // (a random matrix needs that: 50 -> 58 us at 1M x 1M without); an operand whose blocks touch little of the gathered
   // vector anyway runs faster free (block-angular LP of bench.py --config c: 31.8 -> 29.0 us).  Chosen per operand by

@@ -250,32 +250,27 @@ __global__ void k_slab_keys(const int32_t* __restrict__ beg, const int32_t* __re
     keys[p] = len > longLimit ? keyMax : (uint32_t)waveOf[r] * (uint32_t)S + ((uint32_t)idx[p] >> W);
   }
 }
-// sorted position q (regular entries only, wave by wave) -> its place in the wave's list: the lists also hold padding
-// and the segment groups of the medium majors, so wave w starts at wavePtr[w], not at the prefix of the regular counts
 __global__ void k_slab_entries(const int32_t* __restrict__ perm, const int32_t* __restrict__ major,
                                const int32_t* __restrict__ idx, const double* __restrict__ valIn, int64_t nShort,
-                               const int32_t* __restrict__ waveOf, const int32_t* __restrict__ waveBeg,
-                               const int32_t* __restrict__ wavePtr, const int32_t* __restrict__ regPrefix, int minorBits,
+                               const int32_t* __restrict__ waveOf, const int32_t* __restrict__ waveBeg, int minorBits,
                                uint32_t* ent, double* val) {
   GSTRIDE(q, nShort) {
     const int p = perm[q];
     const int r = major[p];
-    const int w = waveOf[r];
-    const int64_t dst = (int64_t)wavePtr[w] + (q - regPrefix[w]);
-    ent[dst] = ((uint32_t)(r - waveBeg[w]) << minorBits) | (uint32_t)idx[p];
-    val[dst] = valIn[p];
+    ent[q] = ((uint32_t)(r - waveBeg[waveOf[r]]) << minorBits) | (uint32_t)idx[p];
+    val[q] = valIn[p];
   }
 }
-// the in-block segments of the medium majors: seg[4 t .. 4 t + 3] = {first CSR position, entries, place in the list, slot};
-// entries in the major's own (ascending minor) order, the local-major field stays 0
-__global__ void k_copy_segments(const int32_t* __restrict__ seg, int nSegs, const int32_t* __restrict__ idx,
-                                const double* __restrict__ valIn, uint32_t* ent, double* val) {
-  const int t = blockIdx.x;
-  if (t >= nSegs) return;
-  const int src = seg[4 * t], len = seg[4 * t + 1], dst = seg[4 * t + 2];
-  for (int k = threadIdx.x; k < len; k += blockDim.x) {
-    ent[dst + k] = (uint32_t)idx[src + k];
-    val[dst + k] = valIn[src + k];
+// wavePtr[w] = first q with sortedKey[q] >= w*S  (w = 0..nWaves; keyMax sorts after every wave)
+__global__ void k_wave_ptr(const uint32_t* __restrict__ sortedKeys, int64_t nnz, int nWaves, int S, int32_t* out) {
+  GSTRIDE(w, nWaves + 1) {
+    const uint64_t key = (uint64_t)w * (uint64_t)S;
+    int64_t lo = 0, hi = nnz;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if ((uint64_t)sortedKeys[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    out[w] = (int32_t)lo;
   }
 }
 __global__ void k_long_mask(const int32_t* __restrict__ beg, int nMajor, int longLimit, int nWords,
@@ -583,33 +578,25 @@ void gpuPrepare(const pdlp_problem_t& P, bool doScale, hipStream_t s, DeviceProb
 }
 
 void gpuSlabPartition(const DeviceCsrData& M, int32_t longLimit, hipStream_t s, DeviceSlabLayout& L) {
-  // the plan is sequential and cheap: on the host, from the major starts (4 bytes per major over PCIe), by the same
-  // function the host-side build uses
+  // the partition by work is sequential and cheap: on the host, from the major starts (4 bytes per major over PCIe),
+  // by the same function the host-side build uses
   std::vector<int32_t> hb((size_t)M.nMajor + 1);
   M.beg.download(hb.data(), hb.size(), s);
   PDLP_HIP(hipStreamSynchronize(s));
-  L.plan = slabPlan(hb.data(), M.nMajor, M.nMinor, longLimit);
-  const SlabPlan& P = L.plan;
+  SlabPartition P = slabPartition(hb.data(), M.nMajor, M.nMinor, longLimit);
   L.rowsPerBlock = P.maxRowsPerBlock;
-  L.slotsPerBlock = P.maxSlotsPerBlock;
   L.nBlocks = P.nBlocks;
   L.minorBits = P.minorBits;
-  L.listLen = P.listLen;
-  auto up = [&](auto& dev, const auto& host) {
-    dev.alloc(std::max<size_t>(host.size(), 1));
-    dev.zero(s);
-    if (!host.empty()) dev.upload(host.data(), host.size(), s);
-  };
-  up(L.wavePtr, P.wavePtr); up(L.waveBeg, P.waveBeg); up(L.waveReg, P.waveReg); up(L.waveSegBeg, P.waveSegBeg);
-  up(L.segDesc, P.segDesc); up(L.blockMedBeg, P.blockMedBeg); up(L.medDesc, P.medDesc);
+  L.hostWaveBeg = std::move(P.waveBeg);
+  L.waveBeg.alloc(L.hostWaveBeg.size());
+  L.waveBeg.upload(L.hostWaveBeg.data(), L.hostWaveBeg.size(), s);
   PDLP_HIP(hipStreamSynchronize(s));
 }
 
 void gpuBuildSlabLayout(const DeviceCsrData& M, int32_t longLimit, int32_t W, hipStream_t s, DeviceSlabLayout& L) {
   const int32_t nMajor = M.nMajor, nMinor = M.nMinor;
   const int64_t nnz = M.nnz;
-  if (L.plan.waveBeg.empty()) gpuSlabPartition(M, longLimit, s, L);
-  const SlabPlan& P = L.plan;
+  if (L.hostWaveBeg.empty()) gpuSlabPartition(M, longLimit, s, L);
   const int32_t nWaves = L.nBlocks * kSlabWavesPerBlock;
   DeviceArray<int32_t> waveOf;
   waveOf.alloc((size_t)std::max(nMajor, 1));
@@ -619,14 +606,14 @@ void gpuBuildSlabLayout(const DeviceCsrData& M, int32_t longLimit, int32_t W, hi
   if (nSeg >= (int64_t)0x7fffffff) throw std::runtime_error("slab layout: too many segments");
   const uint32_t keyMax = (uint32_t)nSeg;  // sorts after every real segment
 
-  // long majors (more than medMax entries): mask, map, compact CSR
+  // long majors: mask, map, compact CSR
   const int nWords = (nMajor + 31) / 32 + 1;
   L.longMask.alloc((size_t)nWords);
   DeviceArray<int32_t> longFlag, longRank;
   longFlag.alloc((size_t)std::max(nMajor, 1));
   longRank.alloc((size_t)std::max(nMajor, 1));
   hipLaunchKernelGGL(k_long_mask, dim3(gridFor(std::max(nWords, nMajor))), dim3(kT), 0, s, M.beg.get(), nMajor,
-                     P.medMax, nWords, L.longMask.get(), longFlag.get());
+                     longLimit, nWords, L.longMask.get(), longFlag.get());
   exclusiveSum(longFlag.get(), longRank.get(), nMajor, s);
   L.nLong = nMajor > 0 ? fetchOne(longRank.get() + (nMajor - 1), s) + fetchOne(longFlag.get() + (nMajor - 1), s) : 0;
   L.longMap.alloc((size_t)std::max(L.nLong, 1));
@@ -662,8 +649,7 @@ void gpuBuildSlabLayout(const DeviceCsrData& M, int32_t longLimit, int32_t W, hi
     L.longCsr.val.alloc(1);
   }
 
-  // regular entries (majors of at most longLimit entries) sorted by (wave, slab); the stable sort keeps (major, minor)
-  // order inside; medium and long majors sort behind everything (keyMax)
+  // short entries sorted by (wave, slab); the stable sort keeps (major, minor) order inside
   DeviceArray<uint32_t> keys, sortedKeys;
   DeviceArray<int32_t> perm;
   keys.alloc((size_t)std::max<int64_t>(nnz, 1));
@@ -671,30 +657,17 @@ void gpuBuildSlabLayout(const DeviceCsrData& M, int32_t longLimit, int32_t W, hi
     hipLaunchKernelGGL(k_slab_keys, dim3(gridFor(nnz)), dim3(kT), 0, s, M.beg.get(), M.major.get(), M.idx.get(), nnz,
                        waveOf.get(), S, W, longLimit, keyMax, keys.get());
   sortByKey(keys.get(), nnz, (uint64_t)keyMax, sortedKeys, perm, s);
-  // regular entries in front of wave w in sorted order = prefix of the plan's regular counts (the plan was made from
-  // the same major starts, so the two agree: checked on the total)
-  std::vector<int32_t> regPrefix((size_t)nWaves + 1, 0);
-  for (int32_t w = 0; w < nWaves; ++w) regPrefix[(size_t)w + 1] = regPrefix[w] + P.waveReg[w];
-  const int64_t nShort = regPrefix[nWaves];
-  DeviceArray<int32_t> dRegPrefix, dSegs;
-  dRegPrefix.alloc(regPrefix.size());
-  dRegPrefix.upload(regPrefix.data(), regPrefix.size(), s);
-  L.ent.alloc((size_t)L.listLen + 64);  // pad elements: an empty wave still reads its first entry
-  L.val.alloc((size_t)L.listLen + 64);
-  L.ent.zero(s);  // (padding: minor 0 with value 0 — a product that is +-0)
+  L.wavePtr.alloc((size_t)nWaves + 1);
+  hipLaunchKernelGGL(k_wave_ptr, dim3(gridFor(nWaves + 1)), dim3(kT), 0, s, sortedKeys.get(), nnz, nWaves, S,
+                     L.wavePtr.get());
+  L.nnzShort = fetchOne(L.wavePtr.get() + nWaves, s);
+  L.ent.alloc((size_t)L.nnzShort + 1);
+  L.val.alloc((size_t)L.nnzShort + 1);
+  L.ent.zero(s);
   L.val.zero(s);
-  if (nShort > 0)
-    hipLaunchKernelGGL(k_slab_entries, dim3(gridFor(nShort)), dim3(kT), 0, s, perm.get(), M.major.get(), M.idx.get(),
-                       M.val.get(), nShort, waveOf.get(), L.waveBeg.get(), L.wavePtr.get(), dRegPrefix.get(), L.minorBits,
-                       L.ent.get(), L.val.get());
-  const int32_t nSegs = (int32_t)P.segs.size();
-  if (nSegs > 0) {
-    static_assert(sizeof(SlabSeg) == 16, "segment record layout");
-    dSegs.alloc((size_t)4 * nSegs);
-    dSegs.upload(reinterpret_cast<const int32_t*>(P.segs.data()), (size_t)4 * nSegs, s);
-    hipLaunchKernelGGL(k_copy_segments, dim3(nSegs), dim3(kT), 0, s, dSegs.get(), nSegs, M.idx.get(), M.val.get(), L.ent.get(),
-                       L.val.get());
-  }
+  if (L.nnzShort > 0)
+    hipLaunchKernelGGL(k_slab_entries, dim3(gridFor(L.nnzShort)), dim3(kT), 0, s, perm.get(), M.major.get(),
+                       M.idx.get(), M.val.get(), L.nnzShort, waveOf.get(), L.waveBeg.get(), L.minorBits, L.ent.get(), L.val.get());
   PDLP_HIP(hipStreamSynchronize(s));
 }
 

@@ -61,18 +61,18 @@ void gpuPrepare(const pdlp_problem_t& P, bool doScale, hipStream_t s, DeviceProb
 
 // Slab layout (pdlp_host.hpp SlabLayout) built on the device from a device CSR.
 struct DeviceSlabLayout {
-  int32_t rowsPerBlock = 0, slotsPerBlock = 0, nBlocks = 0, minorBits = 0, nLong = 0;  // rowsPerBlock / slotsPerBlock: the most of any block
-  int64_t listLen = 0;
-  SlabPlan plan;  // pdlp_host.hpp slabPlan, computed on the host from the major starts
-  DeviceArray<int32_t> wavePtr, waveBeg, waveReg, waveSegBeg, blockMedBeg;
-  DeviceArray<uint32_t> ent, longMask, segDesc, medDesc;
+  int32_t rowsPerBlock = 0, nBlocks = 0, minorBits = 0, nLong = 0;  // rowsPerBlock: most majors in one block
+  int64_t nnzShort = 0;
+  std::vector<int32_t> hostWaveBeg;  // the partition (pdlp_host.hpp slabPartition), computed on the host from the major starts
+  DeviceArray<int32_t> wavePtr, waveBeg;
+  DeviceArray<uint32_t> ent, longMask;
   DeviceArray<double> val;
   DeviceCsrData longCsr;            // compacted long majors (major[] unused)
   DeviceArray<int32_t> longMap;     // compact index -> major
   std::vector<int32_t> hostLongBeg; // for the stream plan of the side kernel
 };
-// gpuSlabPartition: the plan alone (and its device copies); gpuBuildSlabLayout computes it itself when `out` does not hold
-// one yet.
+// gpuSlabPartition: the partition alone (nBlocks, minorBits, rowsPerBlock, hostWaveBeg, waveBeg); gpuBuildSlabLayout
+// computes it itself when `out` does not hold one yet.
 void gpuSlabPartition(const DeviceCsrData& M, int32_t longLimit, hipStream_t s, DeviceSlabLayout& out);
 void gpuBuildSlabLayout(const DeviceCsrData& M, int32_t longLimit, int32_t slabWidthLog2, hipStream_t s,
                         DeviceSlabLayout& out);

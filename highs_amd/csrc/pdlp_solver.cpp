@@ -120,7 +120,7 @@ void DeviceMatrix::upload(const Compressed& cIn, int32_t nMajor_, int32_t nMinor
   const Compressed* c = &cIn;
   SlabLayout L;
   if (useSlab) {
-    const SlabPlan part = slabPlan(cIn.beg.data(), nMajor_, nMinor_, kSlabLongLimit);
+    const SlabPartition part = slabPartition(cIn.beg.data(), nMajor_, nMinor_, kSlabLongLimit);
     const int32_t nB = part.nBlocks;
     std::vector<int32_t> lo((size_t)nB, INT_MAX), hi((size_t)nB, -1), cnt((size_t)nB, 0);
     for (int32_t b = 0; b < nB; ++b)
@@ -129,26 +129,21 @@ void DeviceMatrix::upload(const Compressed& cIn, int32_t nMajor_, int32_t nMinor
         if (p1 <= p0 || p1 - p0 > kSlabLongLimit) continue;
         lo[b] = std::min(lo[b], cIn.idx[p0]); hi[b] = std::max(hi[b], cIn.idx[p1 - 1]); cnt[b] += p1 - p0;
       }
-    buildSlabLayout(cIn, nMajor_, nMinor_, kSlabLongLimit, slabWidthFor(sw, touchesFewTiles(lo, hi, cnt)), L, &part);
-    const SlabPlan& P = L.plan;
-    if (P.maxRowsPerBlock + P.maxSlotsPerBlock > kSlabMaxRows + 64) throw std::runtime_error("slab layout: too many majors per block");
-    auto up = [&](auto& dev, const auto& host) {
-      dev.alloc(std::max<size_t>(host.size(), 1));
-      dev.zero(s);
-      if (!host.empty()) dev.upload(host.data(), host.size(), s);
-    };
-    up(wavePtr, P.wavePtr); up(waveBeg, P.waveBeg); up(waveReg, P.waveReg); up(waveSegBeg, P.waveSegBeg);
-    up(segDesc, P.segDesc); up(blockMedBeg, P.blockMedBeg); up(medDesc, P.medDesc);
-    ent.alloc(L.ent.size() + 64);  // pad elements: an empty wave still reads its first entry
-    slabVal.alloc(L.val.size() + 64);
+    buildSlabLayout(cIn, nMajor_, nMinor_, kSlabLongLimit, slabWidthFor(sw, touchesFewTiles(lo, hi, cnt)), L);
+    if (L.rowsPerBlock > kSlabMaxRows) throw std::runtime_error("slab layout: too many majors per block");
+    wavePtr.alloc(L.wavePtr.size());
+    wavePtr.upload(L.wavePtr.data(), L.wavePtr.size(), s);
+    waveBeg.alloc(L.waveBeg.size());
+    waveBeg.upload(L.waveBeg.data(), L.waveBeg.size(), s);
+    ent.alloc(L.ent.size() + 1);  // one pad element: an empty wave still reads its first entry
+    slabVal.alloc(L.val.size() + 1);
     longMask.alloc(L.longMask.size());
     ent.zero(s);
     slabVal.zero(s);
-    if (!L.ent.empty()) ent.upload(L.ent.data(), L.ent.size(), s);
-    if (!L.val.empty()) slabVal.upload(L.val.data(), L.val.size(), s);
+    ent.upload(L.ent.data(), L.ent.size(), s);
+    slabVal.upload(L.val.data(), L.val.size(), s);
     longMask.upload(L.longMask.data(), L.longMask.size(), s);
-    slab = SlabMat{wavePtr.get(), ent.get(), slabVal.get(), longMask.get(), waveBeg.get(), waveReg.get(), waveSegBeg.get(), segDesc.get(),
-                   blockMedBeg.get(), medDesc.get(), nMajor_, P.nBlocks, P.maxRowsPerBlock, P.minorBits, P.maxSlotsPerBlock};
+    slab = SlabMat{wavePtr.get(), ent.get(), slabVal.get(), longMask.get(), waveBeg.get(), nMajor_, L.nBlocks, L.rowsPerBlock, L.minorBits};
     c = &L.longCsr;
   }
   const int32_t nCsrMajor = useSlab ? (int32_t)L.longMap.size() : nMajor_;
@@ -189,19 +184,13 @@ void DeviceMatrix::buildFromDevice(DeviceCsrData& M, const DevSwitches& sw, hipS
     // (an operand whose blocks touch few 16384-entry tiles of the gathered vector densely gets slabs of that width: its
     // runs of equal majors are shorter, more lanes add in parallel — bench.py --config c, A x: 44.0 -> 41.1 us)
     gpuBuildSlabLayout(M, kSlabLongLimit, slabWidthFor(sw, localM), s, L);
-    if (L.rowsPerBlock + L.slotsPerBlock > kSlabMaxRows + 64) throw std::runtime_error("slab layout: too many majors per block");
+    if (L.rowsPerBlock > kSlabMaxRows) throw std::runtime_error("slab layout: too many majors per block");
     wavePtr = std::move(L.wavePtr);
     waveBeg = std::move(L.waveBeg);
-    waveReg = std::move(L.waveReg);
-    waveSegBeg = std::move(L.waveSegBeg);
-    segDesc = std::move(L.segDesc);
-    blockMedBeg = std::move(L.blockMedBeg);
-    medDesc = std::move(L.medDesc);
     ent = std::move(L.ent);
     slabVal = std::move(L.val);
     longMask = std::move(L.longMask);
-    slab = SlabMat{wavePtr.get(), ent.get(), slabVal.get(), longMask.get(), waveBeg.get(), waveReg.get(), waveSegBeg.get(), segDesc.get(),
-                   blockMedBeg.get(), medDesc.get(), nMajor, L.nBlocks, L.rowsPerBlock, L.minorBits, L.slotsPerBlock};
+    slab = SlabMat{wavePtr.get(), ent.get(), slabVal.get(), longMask.get(), waveBeg.get(), nMajor, L.nBlocks, L.rowsPerBlock, L.minorBits};
     beg = std::move(L.longCsr.beg);
     idx = std::move(L.longCsr.idx);
     val = std::move(L.longCsr.val);

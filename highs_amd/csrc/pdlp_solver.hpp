@@ -37,8 +37,8 @@ struct DevSwitches {
 // One operand matrix in HBM: CSR stream plan or slab layout for the majors that are summed left to right,
 // segment tasks for the long ones (pdlp_host.hpp LongPlan).
 struct DeviceMatrix {
-  DeviceArray<int32_t> beg, idx, blockBeg, wavePtr, waveBeg, waveReg, waveSegBeg, blockMedBeg;
-  DeviceArray<uint32_t> ent, longMask, segDesc, medDesc;
+  DeviceArray<int32_t> beg, idx, blockBeg, wavePtr, waveBeg;
+  DeviceArray<uint32_t> ent, longMask;
   DeviceArray<double> val, slabVal;
   // long majors
   DeviceArray<LongTask> lTasks;

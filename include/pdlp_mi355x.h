@@ -295,23 +295,16 @@ int pdlp_mi355x_row_partition(const pdlp_prepared_t* prep, int32_t world,
  * pdlp_mi355x_free_slab_layout. */
 typedef struct pdlp_slab_layout {
   int32_t rows_per_block; /* the most majors any block owns (size of the LDS accumulators) */
-  int32_t slots_per_block;/* the most in-block segment slots any block needs (LDS, behind the accumulators) */
+  int32_t rows_per_wave;  /* reserved (0): waves own variable runs of majors, see wave_beg */
   int32_t n_blocks, minor_bits, slab_width_log2, n_long;
-  int32_t med_max;        /* majors with long_limit < entries <= med_max: in-block segments; more: segment tasks (long_map) */
-  int32_t n_segs, n_med;
-  int64_t list_len;   /* entries of all wave lists incl. padding */
-  int32_t* wave_ptr;  /* [16*n_blocks+1] list offsets: regular entries, (pad to a whole 64-entry group), segment groups */
-  uint32_t* ent;      /* [list_len] (local_major << minor_bits | minor), local = major - first major of the owning wave */
-  double* val;        /* [list_len] */
+  int64_t nnz_short;
+  int32_t* wave_ptr;  /* [16*n_blocks+1] entry offsets */
+  uint32_t* ent;      /* [nnz_short] (local_major << minor_bits | minor), local = major - first major of the owning wave */
+  double* val;        /* [nnz_short] */
   uint32_t* long_mask;/* [n_major/32 + 1] bit r: major r is a long one */
   int32_t* long_map;  /* [n_long] */
   int32_t* wave_beg;  /* [16*n_blocks+1] first major of every wave: blocks and waves are cut by work
-                         (entries of the regular and medium majors + 2 per major), not by major count */
-  int32_t* wave_reg;  /* [16*n_blocks] regular entries at the head of every wave's list */
-  int32_t* wave_seg_beg; /* [16*n_blocks+1] the wave's segments in seg_desc */
-  uint32_t* seg_desc; /* [n_segs] slot << 16 | entries; a segment occupies ceil(entries / 64) whole groups of the list */
-  int32_t* block_med_beg; /* [n_blocks+1] the block's medium majors in med_desc */
-  uint32_t* med_desc; /* [2*n_med] {major - first major of the block, first_slot << 8 | segments} */
+                         (entries of the short majors + 2 per major), not by major count */
 } pdlp_slab_layout_t;
 int pdlp_mi355x_host_slab_layout(const pdlp_prepared_t* prep, int32_t which,
                                  int32_t long_limit, pdlp_slab_layout_t* out);

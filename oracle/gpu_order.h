@@ -16,73 +16,51 @@ enum { G_T = 256, G_WAVE = 64, G_CHUNK = 2048, G_CHUNK_SMALL = 512, G_MAXMAJ = 2
 /* spmvChunkFor (pdlp_kernels.hpp): work-plan block size of a CSR stream with this many nonzeros */
 static inline int g_chunk_for(long nnz) { return nnz < (1L << 18) ? G_CHUNK_SMALL : G_CHUNK; }
 /* slab SpMV (k_spmv_slab): 1024-thread blocks of 16 waves.  The majors are dealt to blocks (and, inside a block, to its
- * waves — which does not matter for any sum) by WORK: pdlp_host.cpp slabPlan, restated here as far as sums depend on it.
- * Three classes of majors: regular (at most longLimit = 256 entries: one lane adds them left to right), medium (up to
- * medMax entries: in-block segments — the segment sums of g_long_major_sum, and otherwise an ordinary major of its block)
- * and long (more: segment tasks, the major's contributions to the reductions in a slot of its own).
- *   nBlocks0 = ceil(nMajor / 256) capped at 256; medMax = half of the mean work per block, (nnz + 2 nMajor) / nBlocks0 / 2,
- * within [512, 16384].  Work of a major = its entries (half of them for a medium major, 0 for a long one) + 2; LDS units = 1 + its in-block segments of
- * 512 entries.  nBlocks = nBlocks0, or more when the units do not fit (cap 16384 units per block, 64 of them kept as room).
- * Block b takes majors while it is closer to ceil(work left / blocks left) with the next major than without, at least
- * one, never beyond the unit cap, and never so few / many that the blocks behind it could not hold / would not get the
+ * waves — which does not matter for any sum) by WORK: pdlp_host.cpp slabPartition, restated here.  Work of a major of len
+ * entries = len + len * min(len, 64) / 32 + 2 (integer division; 2 alone for a long major, whose segment tasks run
+ * elsewhere).  nBlocks = ceil(nMajor / 256) capped at 256 (more only when 256 blocks of 16384 majors do not hold the
+ * operand); block b takes majors while it is closer to ceil(work left / blocks left) with the next major than without,
+ * at least one and at most 16384, and never so few / many that the blocks behind it could not hold / would not get the
  * rest. */
-enum { G_SLAB_T = 1024, G_SLAB_WAVES = 16, G_SLAB_BLOCKS = 256, G_SLAB_UNIT_CAP = 16384, G_SLAB_MIN_ROWS = 256, G_SLAB_MAJOR_COST = 2,
-       G_SLAB_SEGMENT = 512, G_SLAB_MED_CAP = 16384 };
+enum { G_SLAB_T = 1024, G_SLAB_WAVES = 16, G_SLAB_BLOCKS = 256, G_SLAB_BLOCK_CAP = 16384, G_SLAB_MIN_ROWS = 256, G_SLAB_MAJOR_COST = 2 };
 static inline int g_slab_fits(int nMajor, int nMinor) { /* the minor index must fit 28 bits of an entry */
   (void)nMajor;
   return (long)nMinor <= (1L << 28);
 }
-/* room the caller needs in blockBeg */
-static inline long g_slab_blocks_room(int nMajor, long nnz) { return G_SLAB_BLOCKS + ((long)nMajor + nnz / G_SLAB_SEGMENT) / 1024 + 8; }
-/* blockBeg[0..nBlocks], *medMaxOut; returns nBlocks */
-static inline int g_slab_blocks(const int* beg, int nMajor, int nMinor, int longLimit, int* blockBeg, int* medMaxOut) {
+/* blockBeg[0..nBlocks] (caller provides room for G_SLAB_BLOCKS + nMajor / G_SLAB_BLOCK_CAP + 2 ints); returns nBlocks */
+static inline int g_slab_blocks(const int* beg, int nMajor, int nMinor, int longLimit, int* blockBeg) {
   int mb = 0;
   while ((1L << mb) < (long)nMinor) ++mb;
   if (mb < 4) mb = 4;
   long waveCap = 1L << (32 - mb);
-  if (waveCap > G_SLAB_UNIT_CAP) waveCap = G_SLAB_UNIT_CAP;
-  long unitCap = waveCap * G_SLAB_WAVES;
-  if (unitCap > G_SLAB_UNIT_CAP) unitCap = G_SLAB_UNIT_CAP;
-  const long unitRoom = unitCap - 64 > 64 ? unitCap - 64 : unitCap;
-  const long nnz = nMajor > 0 ? (long)beg[nMajor] - beg[0] : 0;
+  if (waveCap > G_SLAB_BLOCK_CAP) waveCap = G_SLAB_BLOCK_CAP;
+  long cap = waveCap * G_SLAB_WAVES;
+  if (cap > G_SLAB_BLOCK_CAP) cap = G_SLAB_BLOCK_CAP;
   long nB = ((long)nMajor + G_SLAB_MIN_ROWS - 1) / G_SLAB_MIN_ROWS;
   if (nB > G_SLAB_BLOCKS) nB = G_SLAB_BLOCKS;
-  long medMax = G_SLAB_SEGMENT;
-  if (nB > 0) {
-    medMax = (nnz + (long)G_SLAB_MAJOR_COST * nMajor) / nB / 2;
-    if (medMax < G_SLAB_SEGMENT) medMax = G_SLAB_SEGMENT;
-    if (medMax > G_SLAB_MED_CAP) medMax = G_SLAB_MED_CAP;
-  }
-  if (medMax < longLimit) medMax = longLimit;
-  *medMaxOut = (int)medMax;
-#define G_LEN(r) (beg[(r) + 1] - beg[(r)])
-#define G_COST(r) ((long)(G_LEN(r) > medMax ? 0 : G_LEN(r) > longLimit ? G_LEN(r) / 2 : G_LEN(r)) + G_SLAB_MAJOR_COST)
-#define G_UNITS(r) (1L + ((G_LEN(r) > longLimit && G_LEN(r) <= medMax) ? (G_LEN(r) + G_SLAB_SEGMENT - 1) / G_SLAB_SEGMENT : 0))
-  long rem = 0, unitsLeft = 0;
-  for (int r = 0; r < nMajor; ++r) { rem += G_COST(r); unitsLeft += G_UNITS(r); }
-  if (nB < (unitsLeft + unitRoom - 1) / unitRoom) nB = (unitsLeft + unitRoom - 1) / unitRoom;
+  if (nB < ((long)nMajor + cap - 1) / cap) nB = ((long)nMajor + cap - 1) / cap;
+#define G_WORK(len) ((len) > longLimit ? (long)G_SLAB_MAJOR_COST : (long)(len) + ((long)(len) * ((len) < 64 ? (len) : 64)) / 32 + G_SLAB_MAJOR_COST)
+  long rem = 0;
+  for (int r = 0; r < nMajor; ++r) { const int len = beg[r + 1] - beg[r]; rem += G_WORK(len); }
   int r = 0;
   blockBeg[0] = 0;
-  for (long b = 0; b < nB; ++b) {
-    const long left = nB - b, target = (rem + left - 1) / left, rows = (long)nMajor - r;
-    const long minUnits = unitsLeft - (left - 1) * unitRoom;
-    long maxRows = rows - (left - 1);
+  for (long u = 0; u < nB; ++u) {
+    const long left = nB - u, target = (rem + left - 1) / left, rows = (long)nMajor - r;
+    long minRows = rows - (left - 1) * cap, maxRows = rows - (left - 1);
+    if (minRows < 1) minRows = rows > 0 ? 1 : 0;
     if (maxRows < 1) maxRows = 1;
-    long acc = 0, cnt = 0, units = 0;
+    if (maxRows > cap) maxRows = cap;
+    long acc = 0, cnt = 0;
     while (cnt < rows && cnt < maxRows) {
-      const long c = G_COST(r), u = G_UNITS(r);
-      if (cnt > 0 && units + u > unitCap) break;
-      const int must = cnt == 0 || units < minUnits;
-      if (!must && 2 * acc + c > 2 * target) break;
-      acc += c; units += u; ++r; ++cnt;
+      const int len = beg[r + 1] - beg[r];
+      const long c = G_WORK(len);
+      if (cnt >= minRows && 2 * acc + c > 2 * target) break;
+      acc += c; ++r; ++cnt;
     }
     rem -= acc;
-    unitsLeft -= units;
-    blockBeg[b + 1] = r;
+    blockBeg[u + 1] = r;
   }
-#undef G_LEN
-#undef G_COST
-#undef G_UNITS
+#undef G_WORK
   return (int)nB;
 }
 

@@ -93,7 +93,7 @@ typedef struct {
   int *qnBeg, *qnIdx;
   double* qnVal;
   double *nx[2], *nxAvg; /* N x by parity (like A'y), N xAvg at checks */
-  int slabQ, chunkQ, ownSlotQ, *planQ, nPlanQ; /* device-order layout of N (g_setup) */
+  int slabQ, chunkQ, *planQ, nPlanQ; /* device-order layout of N (g_setup) */
   int *rowType, *rowNewIdx;
   double offset, sense;
   /* scaling */
@@ -129,7 +129,7 @@ typedef struct {
   int *planA, nPlanA, *planAt, nPlanAt; /* CSR-adaptive work plans, identical to the product's */
   /* slab layout (operands whose gathered vector has >= 2^18 entries): blocks of R consecutive majors,
    * majors longer than 256 entries go to a CSR side plan over the compacted long majors */
-  int slabA, slabAt, ownSlotA, ownSlotAt, nLongA, nLongAt, chunkA, chunkAt;
+  int slabA, slabAt, nLongA, nLongAt, chunkA, chunkAt;
   int *longMapA, *longMapAt, *longBegA, *longBegAt;
   double *gPartA, *gPartB, *gStat;
 } Work;
@@ -485,20 +485,16 @@ static void g_setup(Work* w, int layoutMode) {
   /* the longest major that is summed left to right (longer ones: segment tasks, gpu_order.h g_long_major_sum) */
   w->chunkA = w->slabA ? G_SLAB_LONG : g_chunk_for(w->nnz);
   w->chunkAt = w->slabAt ? G_SLAB_LONG : g_chunk_for(w->nnz);
-  /* majors longer than this contribute to the reductions through a slot of their own (CSR stream: the long majors; slab
-   * layout: only those beyond medMax — medium majors are ordinary majors of their block, g_slab_blocks sets it) */
-  w->ownSlotA = w->chunkA; w->ownSlotAt = w->chunkAt;
   /* slab layout: planA / planAt / planQ hold the block boundaries of the work partition, nPlan* = -(number of blocks) */
-  if (w->slabA) { w->planA = ialloc(g_slab_blocks_room(m, w->nnz)); w->nPlanA = -g_slab_blocks(w->csrBeg, m, n, w->chunkA, w->planA, &w->ownSlotA); }
+  if (w->slabA) { w->planA = ialloc(G_SLAB_BLOCKS + m / G_SLAB_BLOCK_CAP + 3); w->nPlanA = -g_slab_blocks(w->csrBeg, m, n, w->chunkA, w->planA); }
   else w->planA = g_plan(w->csrBeg, m, w->chunkA, &w->nPlanA);
-  if (w->slabAt) { w->planAt = ialloc(g_slab_blocks_room(n, w->nnz)); w->nPlanAt = -g_slab_blocks(w->cssBeg, n, m, w->chunkAt, w->planAt, &w->ownSlotAt); }
+  if (w->slabAt) { w->planAt = ialloc(G_SLAB_BLOCKS + n / G_SLAB_BLOCK_CAP + 3); w->nPlanAt = -g_slab_blocks(w->cssBeg, n, m, w->chunkAt, w->planAt); }
   else w->planAt = g_plan(w->cssBeg, n, w->chunkAt, &w->nPlanAt);
   if (w->qnBeg) { /* N gathers x (n), majors = n */
     w->slabQ = layoutMode == 2 || (layoutMode == 0 && n >= G_SLAB_AUTO_MINOR);
     if (w->slabQ && (n <= 0 || !g_slab_fits(n, n))) w->slabQ = 0;
     w->chunkQ = w->slabQ ? G_SLAB_LONG : g_chunk_for(w->qnBeg[n]);
-    w->ownSlotQ = w->chunkQ;
-    if (w->slabQ) { w->planQ = ialloc(g_slab_blocks_room(n, w->qnBeg[n])); w->nPlanQ = -g_slab_blocks(w->qnBeg, n, n, w->chunkQ, w->planQ, &w->ownSlotQ); }
+    if (w->slabQ) { w->planQ = ialloc(G_SLAB_BLOCKS + n / G_SLAB_BLOCK_CAP + 3); w->nPlanQ = -g_slab_blocks(w->qnBeg, n, n, w->chunkQ, w->planQ); }
     else w->planQ = g_plan(w->qnBeg, n, w->chunkQ, &w->nPlanQ);
   }
   const long mx = 2L * (n > m ? n : m) + G_MAXGRID + 8;
@@ -514,7 +510,7 @@ static double g_epilogue_total(Work* w, int isAt /* 0: A, 1: A', 2: N (off-diago
   const int slab = isAt == 2 ? w->slabQ : isAt ? w->slabAt : w->slabA;
   const int* plan = isAt == 2 ? w->planQ : isAt ? w->planAt : w->planA;
   const int nPlan = isAt == 2 ? w->nPlanQ : isAt ? w->nPlanAt : w->nPlanA;
-  const int limit = isAt == 2 ? w->ownSlotQ : isAt ? w->ownSlotAt : w->ownSlotA;
+  const int limit = isAt == 2 ? w->chunkQ : isAt ? w->chunkAt : w->chunkA;
   const int* beg = isAt == 2 ? w->qnBeg : isAt ? w->cssBeg : w->csrBeg;
   double* part = w->gPartA;
   int np = 0;

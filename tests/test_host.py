@@ -139,130 +139,95 @@ def test_solver_mirror_runs_against_oracle():
 
 
 def _slab_to_coo(sl, n_major):
-    """Rebuild (major, minor, value) triplets from the slab layout: the regular entries at the head of every wave's list,
-    in storage order (with their wave), and the entries of the in-block segments (major by major, segment by segment)."""
+    """Rebuild (major, minor, value) triplets from the slab layout, in storage order."""
     mb = sl["minor_bits"]
-    wp, wb, wr = sl["wave_ptr"], sl["wave_beg"], sl["wave_reg"]
+    wp, wb = sl["wave_ptr"], sl["wave_beg"]
     ent, val = sl["ent"].astype(np.int64), sl["val"]
-    nw = len(wr)
-    pos = np.concatenate([np.arange(wp[w], wp[w] + wr[w]) for w in range(nw)]) if nw else np.zeros(0, np.int64)
-    wave = np.repeat(np.arange(nw), wr)
-    majors = wb[wave] + (ent[pos] >> mb)
-    minors = ent[pos] & ((1 << mb) - 1)
-    # segments: slot -> (major, ordinal) through the block's medium-major records
-    seg = []
-    blk_beg = wb[::16]
-    for b in range(sl["n_blocks"]):
-        slot_major = {}
-        for k in range(sl["block_med_beg"][b], sl["block_med_beg"][b + 1]):
-            lr, w1 = int(sl["med_desc"][2 * k]), int(sl["med_desc"][2 * k + 1])
-            for j in range(w1 & 0xff):
-                slot_major[(w1 >> 8) + j] = (blk_beg[b] + lr, j)
-        for w in range(16 * b, 16 * b + 16):
-            q = wp[w] + (-(-wr[w] // 64)) * 64 if sl["wave_seg_beg"][w + 1] > sl["wave_seg_beg"][w] else None
-            for si in range(sl["wave_seg_beg"][w], sl["wave_seg_beg"][w + 1]):
-                d = int(sl["seg_desc"][si])
-                ln, slot = d & 0xffff, d >> 16
-                mj, ordinal = slot_major[slot]
-                seg.append((mj, ordinal, ent[q:q + ln] & ((1 << mb) - 1), val[q:q + ln], ent[q:q + ln] >> mb,
-                            val[q + ln:q + (-(-ln // 64)) * 64]))
-                q += (-(-ln // 64)) * 64
-            if q is not None:
-                assert q == wp[w + 1]
-            else:
-                assert wp[w] + wr[w] == wp[w + 1]
-    return majors, minors, val[pos], wave, seg
+    wave = np.repeat(np.arange(len(wp) - 1), np.diff(wp))
+    majors = wb[wave] + (ent >> mb)
+    minors = ent & ((1 << mb) - 1)
+    return majors, minors, val, wave
+
+
+def _slab_work(lens, long_limit):
+    """pdlp_host.cpp slabMajorWork: entries + the run-accumulation term + 2 per major; a long major: 2."""
+    lens = np.asarray(lens, dtype=np.int64)
+    return np.where(lens > long_limit, 2, lens + (lens * np.minimum(lens, 64)) // 32 + 2)
 
 
 def _slab_partition_restated(beg, n_major, n_minor, long_limit):
-    """pdlp_host.cpp slabPlan, the block boundaries restated: blocks filled one after the other by work = entries of the
-    regular and medium majors + 2 per major, a major taken while the block is closer to its target with it."""
+    """pdlp_host.cpp slabPartition, restated: blocks, then the 16 waves of every block, filled one after the other by
+    work = entries of the short majors + 2 per major."""
     lens = np.diff(beg)
-    nnz = int(lens.sum())
+    cost = _slab_work(lens, long_limit)
     mb = max(int(np.ceil(np.log2(max(n_minor, 1)))), 4)
     wave_cap = min(1 << (32 - mb), 16384)
-    unit_cap = min(16384, wave_cap * 16)
-    unit_room = unit_cap - 64 if unit_cap - 64 > 64 else unit_cap
-    nb = min(-(-n_major // 256), 256)
-    med_max = max(min(max((nnz + 2 * n_major) // nb // 2, 512), 16384), long_limit)
-    cost = np.where(lens > med_max, 0, np.where(lens > long_limit, lens // 2, lens)) + 2
-    units = 1 + np.where((lens > long_limit) & (lens <= med_max), -(-lens // 512), 0)
-    nb = max(nb, -(-int(units.sum()) // unit_room))
-    out, r, rem, units_left = [0], 0, int(cost.sum()), int(units.sum())
+    block_cap = min(16384, wave_cap * 16)
+    nb = max(min(-(-n_major // 256), 256), -(-n_major // block_cap))
+
+    def fill(r0, r1, units, cap, non_empty):
+        out, r, rem = [r0], r0, int(cost[r0:r1].sum())
+        for u in range(units):
+            left = units - u
+            target = -(-rem // left)
+            rows = r1 - r
+            min_rows = max(1 if non_empty and rows > 0 else 0, rows - (left - 1) * cap)
+            max_rows = min(cap, max(rows - (left - 1), 1) if non_empty else rows)
+            acc = cnt = 0
+            while cnt < rows and cnt < max_rows:
+                if cnt >= min_rows and 2 * acc + int(cost[r]) > 2 * target:
+                    break
+                acc += int(cost[r]); r += 1; cnt += 1
+            rem -= acc
+            out.append(r)
+        return out
+    bb = fill(0, n_major, nb, block_cap, True)
+    wb = [0]
     for b in range(nb):
-        left = nb - b
-        target = -(-rem // left)
-        rows = n_major - r
-        min_units = units_left - (left - 1) * unit_room
-        max_rows = max(rows - (left - 1), 1)
-        acc = cnt = u = 0
-        while cnt < rows and cnt < max_rows:
-            c, uu = int(cost[r]), int(units[r])
-            if cnt > 0 and u + uu > unit_cap:
-                break
-            must = cnt == 0 or u < min_units
-            if not must and 2 * acc + c > 2 * target:
-                break
-            acc += c; u += uu; r += 1; cnt += 1
-        rem -= acc; units_left -= u
-        out.append(r)
-    return nb, mb, med_max, np.array(out, dtype=np.int64)
+        wb += fill(bb[b], bb[b + 1], 16, wave_cap, False)[1:]
+    return nb, mb, np.array(wb, dtype=np.int64)
 
 
 @pytest.mark.parametrize("which", [0, 1])
 @pytest.mark.parametrize("long_limit", [256, 6])
 def test_slab_layout_is_a_permutation_of_the_csr(which, long_limit):
-    """Slab layout (regular entries + in-block segments of the medium majors) + long-major side list hold exactly the CSR's
-    nonzeros; every regular major's entries stay in ascending minor order when read in storage order (=> same summation
-    order as the reference), every medium major's segments hold its entries in CSR order, 512 at a time."""
+    """Slab layout + long-major side list hold exactly the CSR's nonzeros; every major's entries stay
+    in ascending minor order when read in storage order (=> same summation order as the reference)."""
     sp_ = solver.SyntheticProblem(3000, 200000, 24000, 5)  # wide: 4 slabs of 65536 columns for A
     P = solver.Prepared(problem_struct=sp_.struct, slab_long_limit=long_limit)
     sl = P.slab_layout(which)
     beg, idx, val = (P.csr_beg, P.csr_idx, P.csr_val) if which == 0 else (P.csc_beg, P.csc_idx, P.csc_val)
     n_major = P.m if which == 0 else P.n
     lens = np.diff(beg)
-    med_max = sl["med_max"]
-    long_rows = np.nonzero(lens > med_max)[0]
-    med_rows = np.nonzero((lens > long_limit) & (lens <= med_max))[0]
+    long_rows = np.nonzero(lens > long_limit)[0]
     assert np.array_equal(sl["long_map"], long_rows)
     mask_rows = [r for r in range(n_major) if (sl["long_mask"][r >> 5] >> (r & 31)) & 1]
     assert mask_rows == list(long_rows)
-    maj, mnr, v, wave, seg = _slab_to_coo(sl, n_major)
-    regular = lens <= long_limit
+    maj, mnr, v, wave = _slab_to_coo(sl, n_major)
+    short = np.ones(n_major, bool)
+    short[long_rows] = False
     rows_csr = np.repeat(np.arange(n_major), lens)
-    keep = regular[rows_csr]
-    # regular entries: the same multiset of triplets
+    keep = short[rows_csr]
+    # same multiset of triplets
     a = np.lexsort((mnr, maj))
     assert np.array_equal(maj[a], rows_csr[keep]) and np.array_equal(mnr[a], idx[keep]) and np.array_equal(v[a], val[keep])
     # storage order: within a wave sorted by (slab, major, minor); so per major minors ascend
-    cand = np.nonzero(regular & (lens > 1))[0]
+    cand = np.nonzero(short & (lens > 1))[0]
     for r in (np.random.default_rng(0).choice(cand, size=min(50, len(cand)), replace=False) if len(cand) else []):
         pos = np.nonzero(maj == r)[0]
         assert np.all(np.diff(pos) > 0) and np.all(np.diff(mnr[pos]) > 0)
-    # medium majors: every segment k holds the major's entries [512 k, 512 k + 512) in CSR order, local-major field 0, zero padding
-    got = {}
-    for mj, ordinal, sm, sv, slr, pad in seg:
-        lo = beg[mj] + 512 * ordinal
-        hi = min(beg[mj + 1], lo + 512)
-        assert np.array_equal(sm, idx[lo:hi]) and np.array_equal(sv, val[lo:hi]) and not slr.any() and not pad.any()
-        got.setdefault(mj, set()).add(ordinal)
-    assert sorted(got) == list(med_rows)
-    for mj, ords in got.items():
-        assert ords == set(range(-(-int(lens[mj]) // 512)))
-    if long_limit == 6 and which == 0:
-        assert len(med_rows) > 100  # (rows of ~8 entries: all of them in-block segments)
     W, wb = sl["slab_width_log2"], sl["wave_beg"]
     assert (1 << sl["minor_bits"]) >= (P.n if which == 0 else P.m)
     assert wb[0] == 0 and wb[-1] == n_major and np.all(np.diff(wb) >= 0) and np.all(np.diff(wb) <= 1 << (32 - sl["minor_bits"]))
     blk = wb[::16]
-    assert np.all(np.diff(blk) >= 1) and np.max(np.diff(blk)) == sl["rows_per_block"] and sl["rows_per_block"] + sl["slots_per_block"] <= 16384
-    # the block boundaries are the restated rule, and they balance work
-    nb, mb, mm, bb = _slab_partition_restated(beg, n_major, P.n if which == 0 else P.m, long_limit)
-    assert nb == sl["n_blocks"] and mb == sl["minor_bits"] and mm == med_max and np.array_equal(bb, blk)
-    cost = np.where(lens > med_max, 0, np.where(lens > long_limit, lens // 2, lens)) + 2
+    assert np.all(np.diff(blk) >= 1) and np.max(np.diff(blk)) == sl["rows_per_block"] <= 16384
+    # the partition is the restated rule, and it balances work: no block above the mean by more than one major's worth
+    nb, mb, wb2 = _slab_partition_restated(beg, n_major, P.n if which == 0 else P.m, long_limit)
+    assert nb == sl["n_blocks"] and mb == sl["minor_bits"] and np.array_equal(wb2, wb)
+    cost = _slab_work(lens, long_limit)
     work = np.add.reduceat(cost, blk[:-1])
-    assert work.max() <= work.mean() + med_max / 2 + 2
-    # a wave's regular entries are those of its majors
+    assert work.max() <= work.mean() + cost.max()
+    # a wave's entries are those of its majors
     assert np.all((maj >= wb[wave]) & (maj < wb[wave + 1]))
     assert np.all(np.diff(wave) >= 0)
     # inside a wave the key (slab, local major, minor) ascends
@@ -278,72 +243,17 @@ def test_slab_partition_balances_skewed_majors():
     lens = np.minimum((rng.pareto(1.2, n_major) * 3 + 1).astype(np.int64), 600)
     lens[:20000] = 1  # a stretch of very short majors: these blocks hit no cap, they just own more majors
     beg = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-    nb, mb, med_max, blk = _slab_partition_restated(beg, n_major, 300000, 256)
-    cost = np.where(lens > med_max, 0, np.where(lens > 256, lens // 2, lens)) + 2
+    nb, mb, wb = _slab_partition_restated(beg, n_major, 300000, 256)
+    cost = _slab_work(lens, 256)
+    blk = wb[::16]
     work = np.add.reduceat(cost, blk[:-1])
-    assert nb == 256 and work.max() <= 1.02 * work.mean() + med_max / 2
+    assert nb == 256 and work.max() <= 1.02 * work.mean() + cost.max()
     equal_count = np.add.reduceat(cost, np.arange(0, n_major, -(-n_major // 256)))
     assert equal_count.max() > 1.3 * equal_count.mean()  # what the old partition did on this operand
-
-
-def _wave_tree(lane):
-    lane = lane.copy()
-    off = 32
-    while off:
-        lane = lane + np.concatenate([lane[off:], lane[64 - off:]])  # __shfl_down: lanes beyond the end read themselves
-        off //= 2
-    return lane[0]
-
-
-@pytest.mark.parametrize("which", [0, 1])
-def test_slab_layout_read_the_way_the_kernel_reads_it_gives_the_modelled_sums(which):
-    """k_spmv_slab restated on the exported layout — regular entries added per major in storage order; a segment's entries
-    lane-strided (entry k of the segment to lane k % 64, ascending), 64-lane shuffle tree, a medium major's segment sums left
-    to right; a segment's first group = the first whole group behind the wave's regular entries — gives, bit for bit, the
-    sums of the oracle's device-order model (g_major_sum: what the GPU tests pin the kernel to).  Dense-column staircase LP:
-    medium rows and columns, long columns, empty waves, lists that do not start on a group boundary."""
-    from lpgen import dense_column_lp
-    lp = dense_column_lp(2, periods=12, rows_per=256, cols_per=224, dense_cols=6, dense_nnz=1500, tail_rows=64, tail_max=900)
-    P = solver.Prepared(lp)
-    sl = P.slab_layout(which)
-    beg, idx, val = (P.csr_beg, P.csr_idx, P.csr_val) if which == 0 else (P.csc_beg, P.csc_idx, P.csc_val)
-    n_major, n_minor = (P.m, P.n) if which == 0 else (P.n, P.m)
-    x = np.random.default_rng(4).standard_normal(n_minor)
-    mb, wp, wb, wr = sl["minor_bits"], sl["wave_ptr"], sl["wave_beg"], sl["wave_reg"]
-    ent, v = sl["ent"].astype(np.int64), sl["val"]
-    msk = (1 << mb) - 1
-    out = np.zeros(n_major)
-    for w in range(len(wr)):
-        for q in range(wp[w], wp[w] + wr[w]):
-            out[wb[w] + (ent[q] >> mb)] += v[q] * x[ent[q] & msk]
-    blk = wb[::16]
-    n_med = 0
-    for b in range(sl["n_blocks"]):
-        slots = {}
-        for w in range(16 * b, 16 * b + 16):
-            q = wp[w] + (-(-wr[w] // 64)) * 64
-            for si in range(sl["wave_seg_beg"][w], sl["wave_seg_beg"][w + 1]):
-                d = int(sl["seg_desc"][si])
-                ln, slot = d & 0xffff, d >> 16
-                lane = np.zeros(64)
-                for k in range(ln):
-                    lane[k % 64] += v[q + k] * x[ent[q + k] & msk]
-                slots[slot] = _wave_tree(lane)
-                q += (-(-ln // 64)) * 64
-        for k in range(sl["block_med_beg"][b], sl["block_med_beg"][b + 1]):
-            lr, w1 = int(sl["med_desc"][2 * k]), int(sl["med_desc"][2 * k + 1])
-            tot = 0.0
-            for j in range(w1 & 0xff):
-                tot += slots[(w1 >> 8) + j]
-            out[blk[b] + lr] = tot
-            n_med += 1
-    ref = np.zeros(n_major)
-    p = lambda a, t: np.ascontiguousarray(a).ctypes.data_as(t)
-    O.oracle().pdlp_oracle_spmv_csr_device_order(n_major, p(beg, abi.c_i32p), p(idx, abi.c_i32p), p(val, abi.c_f64p),
-                                                 np.ascontiguousarray(x).ctypes.data_as(abi.c_f64p), ref.ctypes.data_as(abi.c_f64p), 256)
-    keep = np.diff(beg) <= sl["med_max"]
-    assert n_med > 0 and np.any(wp[:-1][np.diff(sl["wave_seg_beg"]) > 0] % 64 != 0)
-    assert np.array_equal(out[keep], ref[keep])
+    for b in range(0, nb, 37):  # waves of a block carry equal work too
+        w = wb[16 * b:16 * b + 17]
+        ww = np.array([cost[w[k]:w[k + 1]].sum() for k in range(16)])
+        assert ww.max() <= ww.mean() + cost.max()
 
 
 @pytest.mark.parametrize("corrupt", ["start0", "decreasing", "row_index", "overrun"])

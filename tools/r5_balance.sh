@@ -5,7 +5,12 @@ cd "$(dirname "$0")/.."
 TAG=${1:-r05}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-PYTEST_TIMEOUT=1500 bash tools/gpu_pytest.sh $TAG/pytest_gpu tests -m gpu -q ${PYTEST_ARGS:-}
+if [ -n "${SUBSET:-}" ]; then  # the tests that see the slab layout, the loop variants and the device gate
+  PYTEST_TIMEOUT=${PYTEST_TIMEOUT:-600} bash tools/gpu_pytest.sh $TAG/pytest_gpu tests -m gpu -q -x --timeout 200 \
+    -k "bit_exact or long or dense or structured or spmv or fused or two_large or setup or trial_loop or hard_instances_first"
+else
+  PYTEST_TIMEOUT=${PYTEST_TIMEOUT:-1500} bash tools/gpu_pytest.sh $TAG/pytest_gpu tests -m gpu -q ${PYTEST_ARGS:-}
+fi
 line() { python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('$1', round(d['value']), round(d['ms_per_step']*1e3,2), {k:round(v['ms']*1e3,1) for k,v in d['roofline']['per_kernel'].items()})"; }
 for cfg in ${CONFIGS:-b c d a qp}; do
   python bench.py --config $cfg --cpu-iters 0 2>$OUT/bench_$cfg.err | tee $OUT/bench_$cfg.json | line $cfg
