@@ -54,6 +54,7 @@ struct SpmvArgs {
   unsigned long long barLimit;  // 100 MHz ticks the grid barrier may wait for a missing block
   int32_t faultTrial;           // tests: the barrier of the trial that raises the trial counter to this value expects one block too many
   int32_t inlineTasks;          // kAtyFused: the streaming blocks run the segment tasks of the long majors themselves (no extra blocks)
+  int32_t coTaskBlocks;         // kAtyFused: ... or that many extra workgroups run them, resident next to the streaming blocks, and arrive at the barrier
   CheckGate gate;  // kPlain inside a device-driven check: the launch is a no-op unless the check is due
   // development (PDLP_MI355X_SLAB_PROF=1): per block {launches, ticks to the end of the stream, to the end of the epilogue, to
   // the barrier's end, to the kernel's end} of the slab launches kDualStep / kAtyFused, 100 MHz wall clock
@@ -483,6 +484,14 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
   if ((int)blockIdx.x >= a.S.nBlocks) {  // the extra blocks: one segment task of a long major per wave
     Epi<EPI> epiL(a);
     longBlock<EPI, kWaves>(a, epiL, (int)blockIdx.x - a.S.nBlocks, reinterpret_cast<double*>(smem));
+    if (EPI == kAtyFused) {
+      // a task workgroup of the fused launch: what it published (A'y+ of its long columns, their contributions) has landed;
+      // it arrives at the grid barrier the streaming blocks wait at — and leaves (it needs nothing from behind the barrier)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0)
+        __hip_atomic_store(a.bar + blockIdx.x, (unsigned long long)a.st->nTrials + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     return;
   }
   // dynamic LDS: acc[R] f64 | stg[16][64] f64 | scratch[2][16] f64 | (kAtyFused) trial scratch[4][4] f64, DevState
@@ -516,8 +525,10 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
     pre[k] = epi.prefetch(r < rEnd ? r : rEnd - 1);
   }
   // kAtyFused: the operands of the NEXT primal step that no decision can change (c, l, u, xSum) travel with the stream
+  // (not in the 64-register variant that leaves room for the task workgroups: there they are fetched behind the barrier)
+  constexpr bool kFixEarly = !TWO;
   Pre fix[EPI == kAtyFused ? kSlabPre : 1];
-  if (EPI == kAtyFused) {
+  if (EPI == kAtyFused && kFixEarly) {
 #pragma unroll
     for (int k = 0; k < kSlabPre; ++k) {
       const int r0_ = rBase + tid + k * kSlabThreads;
@@ -648,7 +659,7 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
       if (rBase + lr < rEnd && !longMajor(rBase + lr)) epi.apply(rBase + lr, acc[lr], more[k]);
     }
   }
-  if (EPI == kAtyFused) {  // xSum of the own columns: in flight across the barrier and the decision
+  if (EPI == kAtyFused && kFixEarly) {  // xSum of the own columns: in flight across the barrier and the decision
 #pragma unroll
     for (int k = 0; k < kSlabPre; ++k) {
       const int r0_ = rBase + tid + k * kSlabThreads;
@@ -657,7 +668,7 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
   }
   epi.template finish<kSlabThreads>(blk, scratch);
   profStamp(1);
-  if (EPI == kAtyFused && a.inlineTasks) {
+  if (EPI == kAtyFused && !TWO && a.inlineTasks) {  // (the 64-register variant carries task workgroups instead)
     // Long columns in the fused trial: their segment tasks cannot be extra workgroups (those would have to be resident
     // next to the waiting blocks), so the streaming blocks take them — task group tb goes to block tb % nBlocks, one
     // task per wave, same lanes and sums as in the extra blocks of the other launches (longBlock).
@@ -675,7 +686,7 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
     DevState* sh = reinterpret_cast<DevState*>(&tscr[4][0]);
     int* barVerdict = reinterpret_cast<int*>(reinterpret_cast<char*>(sh) + ((sizeof(DevState) + 7) / 8) * 8);
     if (wave == 0) {
-      const int nExp = a.S.nBlocks + (a.st->nTrials + 1 == a.faultTrial ? 1 : 0);
+      const int nExp = a.S.nBlocks + a.coTaskBlocks + (a.st->nTrials + 1 == a.faultTrial ? 1 : 0);
       const int verdict = gridBarrier(a.bar, (int)blockIdx.x, nExp, (unsigned long long)a.st->nTrials + 1ull, lane, a.barLimit);
       if (lane == 0) *barVerdict = verdict;
     }
@@ -691,7 +702,7 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
       return;
     }
     // (the barrier's timeout flag: fetched together with the partials, looked at behind the decision — not a round trip of its own)
-    const unsigned long long timedOut = tid == 0 ? __hip_atomic_load(a.bar + a.S.nBlocks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    const unsigned long long timedOut = tid == 0 ? __hip_atomic_load(a.bar + a.S.nBlocks + a.coTaskBlocks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
     double dY2, dX2, inter;
     trialSumsT<1>(a.partDY, a.nDY, a.part0, a.part1, a.nDX, tscr, dY2, dX2, inter);
     if (tid == 0) {
@@ -722,8 +733,17 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
       t = t > l ? t : l;
       xOut[r] = t;  // gathered by the A x+ kernel: ordinary store
     };
+    if (!kFixEarly) {
+#pragma unroll
+      for (int k = 0; k < kSlabPre; ++k) {
+        const int r0_ = rBase + tid + k * kSlabThreads;
+        const int r = r0_ < rEnd ? r0_ : rEnd - 1;
+        fix[k].a = ldStream(a.v.cost + r); fix[k].b = ldStream(a.v.lower + r); fix[k].c = ldStream(a.v.upper + r);
+        fix[k].d = ldStream(a.v.xSum + r); fix[k].e = a.v.qdiag ? ldStream(a.v.qdiag + r) : 0.0;
+      }
+    }
     // (a long column's A'y+ was computed by a segment task, maybe in another block: taken from memory, agent scope)
-    auto isLong = [&](int lr) { return a.inlineTasks && longMajor(rBase + lr); };
+    auto isLong = [&](int lr) { return (a.inlineTasks || a.coTaskBlocks) && longMajor(rBase + lr); };
 #pragma unroll
     for (int k = 0; k < kSlabPre; ++k) {
       const int lr = tid + k * kSlabThreads;
@@ -1170,16 +1190,34 @@ size_t fusedLds(const MatView& At) {
          sizeof(DevState) + 16;
 }
 }  // namespace
+namespace {
+int fusedTaskGroups(const MatView& At) { return (At.lng.nTasks + At.lng.taskGroup - 1) / At.lng.taskGroup; }
+}  // namespace
+int fusedCoTaskBlocks(const MatView& At, int device) {
+  // long columns of a slab operand (not beyond kLongSlotCap: their contributions would need the k_long_groups launch):
+  // the 64-register variant of the fused kernel holds two 1024-thread blocks per CU — every streaming block and every
+  // task workgroup resident at once — where its LDS request fits twice
+  if (!At.useSlab || At.lng.nTasks <= 0 || At.lng.contrib != nullptr || At.slab.nBlocks <= 0) return 0;
+  int perCu = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_spmv_slab<kAtyFused, true, kSlabSlots, 1>, kSlabThreads, fusedLds(At)) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
+  const int groups = fusedTaskGroups(At);
+  if (perCu < 2 || At.slab.nBlocks > cus || groups > cus) return 0;  // (one streaming block and at most one task workgroup per CU)
+  return groups;
+}
 int fusedAtyBlocksResident(const MatView& At, int device) {
   (void)slabProf();  // (development buffer: allocated at set-up, never inside a stream capture)
-  // long columns: the slab kernel's streaming blocks run their segment tasks themselves (SpmvArgs::inlineTasks); not
-  // the stream-layout kernel, and not beyond kLongSlotCap long columns (their contributions need the k_long_groups launch)
+  // long columns: the slab kernel runs their segment tasks inside the fused launch (co-resident task workgroups,
+  // MatView::coTaskBlocks, or the streaming blocks themselves, SpmvArgs::inlineTasks); not the stream-layout kernel, and
+  // not beyond kLongSlotCap long columns (their contributions need the k_long_groups launch)
   if (At.lng.nTasks > 0 && (!At.useSlab || At.lng.contrib != nullptr)) return 0;
   int perCu = 0, cus = 0;
   hipError_t e;
   if (At.useSlab) {
     if (At.slab.nBlocks <= 0) return 0;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_spmv_slab<kAtyFused, false, kSlabSlots, 1>, kSlabThreads, fusedLds(At));
+    e = At.coTaskBlocks > 0
+            ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_spmv_slab<kAtyFused, true, kSlabSlots, 1>, kSlabThreads, fusedLds(At))
+            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_spmv_slab<kAtyFused, false, kSlabSlots, 1>, kSlabThreads, fusedLds(At));
   } else {
     if (At.csr.nBlocks <= 0) return 0;
     e = At.csr.chunk == kChunkSmall ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_spmv<kAtyFused, kChunkSmall>, kSpmvThreads, 0)
@@ -1189,19 +1227,22 @@ int fusedAtyBlocksResident(const MatView& At, int device) {
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
   return perCu * cus;
 }
-int fusedAtyBlocks(const MatView& At) { return At.useSlab ? At.slab.nBlocks : At.csr.nBlocks; }
+int fusedAtyBlocks(const MatView& At) { return At.useSlab ? At.slab.nBlocks + At.coTaskBlocks : At.csr.nBlocks; }
 void launchSpmvAtyFusedPrimal(const MatView& At, const IterVecs& v, const DevState* stIn, DevState* stOut,
                               const double* partDY, int32_t nDY, double* partDX, double* partInter, unsigned long long* bar,
                               hipStream_t s, int32_t timeoutMs, int32_t faultTrial) {
   SpmvArgs a{};
   a.barLimit = (unsigned long long)(timeoutMs > 0 ? timeoutMs : 1000) * 100000ull;
   a.faultTrial = faultTrial;
-  a.inlineTasks = At.useSlab && At.lng.nTasks > 0 ? 1 : 0;
+  a.coTaskBlocks = At.useSlab && At.lng.nTasks > 0 ? At.coTaskBlocks : 0;
+  a.inlineTasks = At.useSlab && At.lng.nTasks > 0 && a.coTaskBlocks == 0 ? 1 : 0;
   a.st = stIn; a.v = v; a.part0 = partDX; a.part1 = partInter;
   a.stOut = stOut; a.partDY = partDY; a.nDY = nDY; a.nDX = At.nPartials; a.bar = bar;
   if (At.useSlab && At.slab.nBlocks <= 1024) a.prof = slabProf();
   a.xcdMap = At.xcdMap; a.L = At.lng; a.A = At.csr; a.S = At.slab;
-  if (At.useSlab)
+  if (At.useSlab && a.coTaskBlocks > 0)
+    hipLaunchKernelGGL((k_spmv_slab<kAtyFused, true, kSlabSlots, 1>), dim3(At.slab.nBlocks + a.coTaskBlocks), dim3(kSlabThreads), fusedLds(At), s, a);
+  else if (At.useSlab)
     hipLaunchKernelGGL((k_spmv_slab<kAtyFused, false, kSlabSlots, 1>), dim3(At.slab.nBlocks), dim3(kSlabThreads), fusedLds(At), s, a);
   else if (At.csr.chunk == kChunkSmall)
     hipLaunchKernelGGL((k_spmv<kAtyFused, kChunkSmall>), dim3(At.csr.nBlocks), dim3(kSpmvThreads), 0, s, a);

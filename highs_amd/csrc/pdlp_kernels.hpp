@@ -180,6 +180,11 @@ struct MatView {
   int32_t useSlab;
   int32_t nPartials;  // slab.nBlocks (if used) + csr.nBlocks + lng.nSlots
   int32_t xcdMap;     // 1: XCD x owns a contiguous range of work blocks, 0: round robin (chosen per operand at setup)
+  // Fused trial on an operand with long majors: > 0 = their segment tasks run as that many EXTRA workgroups of the fused
+  // launch, resident next to the streaming blocks (two 1024-thread blocks per CU at 64 registers) and counted by its grid
+  // barrier; 0 = the streaming blocks run the task passes themselves behind their stream (where two blocks per CU do
+  // not fit).  Set by the solver from fusedCoTaskBlocks().
+  int32_t coTaskBlocks;
 };
 
 // Vectors of the iteration (device pointers). Pairs are double-buffered by parity.
@@ -268,6 +273,8 @@ void launchDecide(DevState* st, const double* partDY, int32_t nDY, const double*
 inline size_t gridBarWords(int nBlocks) { return (size_t)nBlocks + 8; }
 int fusedAtyBlocksResident(const MatView& At, int device);
 int fusedAtyBlocks(const MatView& At);  // blocks of the fused launch (= arrival words of the barrier)
+// Task workgroups the fused launch can carry next to its streaming blocks (0: none / not resident together)
+int fusedCoTaskBlocks(const MatView& At, int device);
 // timeoutMs: how long the barrier waits for a block that is not resident (a shared device); then the trial stays
 // undecided, *stOut carries commError = 3 and the caller falls back to the 3-launch trial.  faultTrial (tests): the
 // trial that raises the trial counter to this value expects one block too many (0: none).

@@ -220,6 +220,7 @@ MatView DeviceMatrix::view() const {
                   nLong, nTasks, slabBlocks + nBlocks, longSlots, longGroup, taskGroup};
   v.useSlab = useSlab ? 1 : 0;
   v.xcdMap = xcdMap;
+  v.coTaskBlocks = fusedCoTasks;
   v.nPartials = nPartials();
   return v;
 }
@@ -281,6 +282,7 @@ DevSwitches DevSwitches::fromEnv() {
   w.slabPace = num("PDLP_MI355X_SLAB_PACE", -1);
   w.fused = num("PDLP_MI355X_FUSED", -1);
   w.fusedStream = num("PDLP_MI355X_FUSED_STREAM", 0);
+  w.fusedCoTasks = num("PDLP_MI355X_FUSED_COTASKS", -1);
   w.persistent = num("PDLP_MI355X_PERSISTENT", -1);
   w.xcdLocal = num("PDLP_MI355X_XCD_LOCAL", -1);
   w.hierBarrier = num("PDLP_MI355X_HIER_BARRIER", -1);
@@ -510,6 +512,9 @@ void Solver::construct(const pdlp_problem_t& P, const void* id128) {
   // layout: off by default — measured in round 3 the barrier + decision tail costs what the separate launch did
   // (100k x 100k: 33.1 us fused vs 32.1; 25fv47: 19.5 vs 20.2); PDLP_MI355X_FUSED_STREAM=1 turns it on.
   if (!sharded_) {
+    // (long columns: their segment tasks as workgroups of the fused launch, resident next to its streaming blocks, where
+    // two 1024-thread blocks per CU fit — PDLP_MI355X_FUSED_COTASKS=0 keeps the task passes inside the streaming blocks)
+    dAt_.fusedCoTasks = sw_.fusedCoTasks != 0 ? fusedCoTaskBlocks(dAt_.view(), opt_.device) : 0;
     const MatView at = dAt_.view();
     const bool allowed = at.useSlab ? sw_.fused != 0 : sw_.fusedStream != 0;
     fused_ = allowed && !hasQoff_ && fusedAtyBlocks(at) > 0 && fusedAtyBlocksResident(at, opt_.device) >= fusedAtyBlocks(at);

@@ -25,6 +25,7 @@ struct DevSwitches {
   int slab = -1;          // PDLP_MI355X_SLAB: 0 CSR stream only, 1 slab layout, -1 automatic by the gathered vector's size
   int slabW = 0;          // PDLP_MI355X_SLAB_W: log2 of the slab width (development)
   int xcdMap = -1, slabPace = -1;
+  int fusedCoTasks = -1;  // PDLP_MI355X_FUSED_COTASKS: 0 = the fused trial's streaming blocks run the long columns' task passes themselves
   int fused = -1, fusedStream = 0, persistent = -1, xcdLocal = -1, hierBarrier = -1, deviceCheck = -1, checkSmall = -1;
   int primalInA = -1;     // PDLP_MI355X_PRIMAL_IN_A: the persistent loop without its P phase (pdlp_small.hip PINA); -1 = where measured faster
   int barrierTimeoutMs = 1000;  // PDLP_MI355X_BARRIER_TIMEOUT_MS: how long a grid barrier / roll call waits for missing workgroups
@@ -48,6 +49,7 @@ struct DeviceMatrix {
   // slab layout: size the task workgroups so that every CU gets one (uploadPlans).  Off for the operand whose tasks the
   // fused trial runs inside its streaming blocks (already spread evenly; full groups of 16 keep long columns in LDS)
   bool balanceTaskBlocks = true;
+  int32_t fusedCoTasks = 0;  // MatView::coTaskBlocks (the fused trial's task workgroups), decided by the solver at set-up
   int32_t nMajor = 0, nBlocks = 0;  // nBlocks = CSR stream blocks
   int32_t chunk = kChunk;           // work-plan block size of the CSR stream (spmvChunkFor)
   int64_t nnz = 0;

@@ -11,7 +11,7 @@
 #   test logs       : pytest -m gpu (includes the drop-in tests: reference CLI, Catch2 cases, C API client)
 set -u
 R=$(cd "$(dirname "$0")/.." && pwd)
-RND=${1:-r04}
+RND=${1:-r05}
 if [ "${2:-}" = "collect" ]; then
   S=$R/gpurun_out/profiles_$RND
   cp $S/r*.json $S/r*.csv $S/r*.log $R/profiles/ 2>/dev/null
@@ -34,6 +34,10 @@ python bench.py --config d > $OUT/${RND}_bench_staircase_dense_columns.json 2>> 
 python bench.py --config qp > $OUT/${RND}_bench_qp.json 2>> $OUT/bench_1M.err
 python bench.py --config qpn > $OUT/${RND}_bench_qp_sparse_hessian.json 2>> $OUT/bench_1M.err
 python bench.py --solver hipdlp > $OUT/${RND}_bench_hipdlp_1M.json 2>> $OUT/bench_1M.err
+for cfg in b c d qp; do  # per-block phase profile of the two slab launches of a trial (development buffer, 100 MHz wall clock)
+  echo "== bench.py --config $cfg (PDLP_MI355X_SLAB_PROF=1)"
+  PDLP_MI355X_SLAB_PROF=1 python bench.py --config $cfg --cpu-iters 0 2>&1 >/dev/null | grep "slab launch"
+done > $OUT/${RND}_slab_phase_profile.log
 python tools/solve_times.py > $OUT/${RND}_small_lp_times.log 2>&1
 python tools/small_loop.py 25fv47 80bau3b >> $OUT/${RND}_small_lp_times.log 2>&1
 ( cd /tmp; export TMPDIR=/tmp

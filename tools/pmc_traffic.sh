@@ -8,7 +8,7 @@
 #   only launches with at least a fifth of the median counter value enter the means.  The persistent trial loop (config a)
 #   is ONE launch per check period: its bytes are divided by the trials it ran (the per-trial traffic of the loop).
 set -u
-R=$(cd "$(dirname "$0")/.." && pwd); RND=${1:-r04}; shift
+R=$(cd "$(dirname "$0")/.." && pwd); RND=${1:-r05}; shift
 CONFIGS=${*:-b a c d qp qpn}
 OUT=$R/gpurun_out/profiles_$RND; mkdir -p $OUT
 ( cd /tmp; export TMPDIR=/tmp
