@@ -127,10 +127,10 @@ constexpr int32_t kSlabWavesPerBlock = 16;
 constexpr int32_t kSlabTargetBlocks = 256;  // CUs of an MI355X
 constexpr int32_t kSlabBlockRowCap = 16384; // majors per block: 128 KB of LDS accumulators (gfx950 has 160 KB per CU)
 constexpr int32_t kSlabMinRowsPerBlock = 256;
-constexpr int32_t kSlabMajorCost = 2;       // work of a major besides its entries (epilogue), in entries
+constexpr int32_t kSlabMajorCost = 6;       // work of a major besides its entries (its epilogue: ~10 vector loads and stores against 1.5 per entry), in entries
 
-// The partition of the majors over blocks and waves.  Work of a major of len entries = len + len * min(len, 64) / 32 + 2
-// (kSlabMajorCost: the epilogue), 2 alone for a long major: the entries of a run of equal majors inside a 64-entry
+// The partition of the majors over blocks and waves.  Work of a major of len entries = len + len * min(len, 64) / 32 + 6
+// (kSlabMajorCost: the epilogue), 6 alone for a long major: the entries of a run of equal majors inside a 64-entry
 // group are added by ONE lane, so a group made of one run of 64 costs about three times a group of eight runs of
 // eight (config d, blocks of equal ENTRY counts: the block with the longest rows still streamed 1.66x the mean time).
 // nBlocks = ceil(nMajor / 256) capped at 256 (more only when 256 blocks of 16384 majors do not hold the operand).

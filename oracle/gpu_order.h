@@ -17,12 +17,12 @@ enum { G_T = 256, G_WAVE = 64, G_CHUNK = 2048, G_CHUNK_SMALL = 512, G_MAXMAJ = 2
 static inline int g_chunk_for(long nnz) { return nnz < (1L << 18) ? G_CHUNK_SMALL : G_CHUNK; }
 /* slab SpMV (k_spmv_slab): 1024-thread blocks of 16 waves.  The majors are dealt to blocks (and, inside a block, to its
  * waves — which does not matter for any sum) by WORK: pdlp_host.cpp slabPartition, restated here.  Work of a major of len
- * entries = len + len * min(len, 64) / 32 + 2 (integer division; 2 alone for a long major, whose segment tasks run
+ * entries = len + len * min(len, 64) / 32 + 6 (integer division; 6 alone for a long major, whose segment tasks run
  * elsewhere).  nBlocks = ceil(nMajor / 256) capped at 256 (more only when 256 blocks of 16384 majors do not hold the
  * operand); block b takes majors while it is closer to ceil(work left / blocks left) with the next major than without,
  * at least one and at most 16384, and never so few / many that the blocks behind it could not hold / would not get the
  * rest. */
-enum { G_SLAB_T = 1024, G_SLAB_WAVES = 16, G_SLAB_BLOCKS = 256, G_SLAB_BLOCK_CAP = 16384, G_SLAB_MIN_ROWS = 256, G_SLAB_MAJOR_COST = 2 };
+enum { G_SLAB_T = 1024, G_SLAB_WAVES = 16, G_SLAB_BLOCKS = 256, G_SLAB_BLOCK_CAP = 16384, G_SLAB_MIN_ROWS = 256, G_SLAB_MAJOR_COST = 6 };
 static inline int g_slab_fits(int nMajor, int nMinor) { /* the minor index must fit 28 bits of an entry */
   (void)nMajor;
   return (long)nMinor <= (1L << 28);

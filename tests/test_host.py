@@ -150,14 +150,14 @@ def _slab_to_coo(sl, n_major):
 
 
 def _slab_work(lens, long_limit):
-    """pdlp_host.cpp slabMajorWork: entries + the run-accumulation term + 2 per major; a long major: 2."""
+    """pdlp_host.cpp slabMajorWork: entries + the run-accumulation term + 6 per major; a long major: 6."""
     lens = np.asarray(lens, dtype=np.int64)
-    return np.where(lens > long_limit, 2, lens + (lens * np.minimum(lens, 64)) // 32 + 2)
+    return np.where(lens > long_limit, 6, lens + (lens * np.minimum(lens, 64)) // 32 + 6)
 
 
 def _slab_partition_restated(beg, n_major, n_minor, long_limit):
     """pdlp_host.cpp slabPartition, restated: blocks, then the 16 waves of every block, filled one after the other by
-    work = entries of the short majors + 2 per major."""
+    work = _slab_work."""
     lens = np.diff(beg)
     cost = _slab_work(lens, long_limit)
     mb = max(int(np.ceil(np.log2(max(n_minor, 1)))), 4)
