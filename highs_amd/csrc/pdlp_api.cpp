@@ -304,7 +304,7 @@ int pdlp_mi355x_host_slab_layout(const pdlp_prepared_t* prep, int32_t which, int
     c.idx.assign(which ? prep->csc_idx : prep->csr_idx, (which ? prep->csc_idx : prep->csr_idx) + prep->nnz);
     c.val.assign(which ? prep->csc_val : prep->csr_val, (which ? prep->csc_val : prep->csr_val) + prep->nnz);
     pdlp::SlabLayout L;
-    pdlp::buildSlabLayout(c, nMajor, nMinor, long_limit, pdlp::kSlabWidthLog2, L);
+    pdlp::buildSlabLayout(c, nMajor, nMinor, long_limit, pdlp::kSlabWidthLog2, which ? pdlp::kSlabMajorCostCols : pdlp::kSlabMajorCostRows, L);
     out->rows_per_block = L.rowsPerBlock; out->rows_per_wave = 0; out->n_blocks = L.nBlocks;
     out->minor_bits = L.minorBits; out->slab_width_log2 = L.slabWidthLog2;
     out->n_long = (int32_t)L.longMap.size(); out->nnz_short = (int64_t)L.ent.size();

@@ -93,6 +93,7 @@ void HalpernSolver::construct(const pdlp_problem_t& P, const void* id128) {
     F_.normCost = D.normCost; F_.normRhs = D.normRhs;
     F_.rowKind = std::move(D.rowKind); F_.rowNewIdx = std::move(D.rowNewIdx);
     F_.colScale = std::move(D.hColScale); F_.rowScale = std::move(D.hRowScale);
+    dAt_.majorCost = kSlabMajorCostCols;
     dA_.buildFromDevice(D.A, sw, stream_);
     dAt_.buildFromDevice(D.At, sw, stream_);
     cost_ = std::move(D.cost); lower_ = std::move(D.lower); upper_ = std::move(D.upper); rl_ = std::move(D.rhs);
@@ -113,11 +114,13 @@ void HalpernSolver::construct(const pdlp_problem_t& P, const void* id128) {
       c0_ = mesh_->c0(); c1_ = mesh_->c1();
       Compressed csrSlab, cscSlab;
       extractSlab(F_, r0_, r1_, csrSlab, cscSlab);
+      dAt_.majorCost = kSlabMajorCostCols;
       dA_.upload(csrSlab, r1_ - r0_, F_.n, sw, stream_);
       dAt_.upload(cscSlab, F_.n, r1_ - r0_, sw, stream_);
       commBuf_.alloc((size_t)F_.n + 8);
       commBuf_.zero(stream_);
     } else {
+      dAt_.majorCost = kSlabMajorCostCols;
       dA_.upload(F_.csr, F_.m, F_.n, sw, stream_);
       dAt_.upload(F_.cscSorted, F_.n, F_.m, sw, stream_);
     }

@@ -127,10 +127,13 @@ constexpr int32_t kSlabWavesPerBlock = 16;
 constexpr int32_t kSlabTargetBlocks = 256;  // CUs of an MI355X
 constexpr int32_t kSlabBlockRowCap = 16384; // majors per block: 128 KB of LDS accumulators (gfx950 has 160 KB per CU)
 constexpr int32_t kSlabMinRowsPerBlock = 256;
-constexpr int32_t kSlabMajorCost = 6;       // work of a major besides its entries (its epilogue: ~10 vector loads and stores against 1.5 per entry), in entries
+// work of a major besides its entries, in entries: its epilogue.  The operand by rows (A x+: dual step, ~7 vector
+// loads and stores per row) and the transposed one (A'y+ with the interaction sums AND the next primal step of the column:
+// ~10, most of them behind the grid barrier) differ: with one value for both, config d lost 3 us on one launch or the other
+constexpr int32_t kSlabMajorCostRows = 2, kSlabMajorCostCols = 6;
 
-// The partition of the majors over blocks and waves.  Work of a major of len entries = len + len * min(len, 64) / 32 + 6
-// (kSlabMajorCost: the epilogue), 6 alone for a long major: the entries of a run of equal majors inside a 64-entry
+// The partition of the majors over blocks and waves.  Work of a major of len entries = len + len * min(len, 64) / 32 +
+// majorCost (the epilogue: kSlabMajorCostRows / Cols), majorCost alone for a long major: the entries of a run of equal majors inside a 64-entry
 // group are added by ONE lane, so a group made of one run of 64 costs about three times a group of eight runs of
 // eight (config d, blocks of equal ENTRY counts: the block with the longest rows still streamed 1.66x the mean time).
 // nBlocks = ceil(nMajor / 256) capped at 256 (more only when 256 blocks of 16384 majors do not hold the operand).
@@ -140,7 +143,7 @@ constexpr int32_t kSlabMajorCost = 6;       // work of a major besides its entri
 // block's majors (cap: 2^(32 - minorBits) majors, the local-major field of an entry).  Sequential and exact in
 // integers: the device-side set-up (pdlp_setup.hip) calls this same function on the downloaded major starts,
 // oracle/gpu_order.h restates it.
-int64_t slabMajorWork(int32_t len, int32_t longLimit);
+int64_t slabMajorWork(int32_t len, int32_t longLimit, int32_t majorCost);
 struct SlabPartition {
   int32_t nBlocks = 0, minorBits = 0, maxRowsPerBlock = 0;
   std::vector<int32_t> waveBeg;  // [16*nBlocks+1] first major of every wave
@@ -148,7 +151,7 @@ struct SlabPartition {
 };
 // false: the minor index does not fit the entry packing (nMinor > 2^28: the caller uses the CSR stream kernel)
 bool slabFits(int32_t nMajor, int32_t nMinor);
-SlabPartition slabPartition(const int32_t* beg, int32_t nMajor, int32_t nMinor, int32_t longLimit);
+SlabPartition slabPartition(const int32_t* beg, int32_t nMajor, int32_t nMinor, int32_t longLimit, int32_t majorCost);
 
 struct SlabLayout {
   int32_t rowsPerBlock = 0;  // most majors in one block (LDS accumulators)
@@ -162,6 +165,6 @@ struct SlabLayout {
   std::vector<int32_t> longMap;   // compact index -> major
 };
 void buildSlabLayout(const Compressed& csr, int32_t nMajor, int32_t nMinor, int32_t longLimit, int32_t slabWidthLog2,
-                     SlabLayout& out);
+                     int32_t majorCost, SlabLayout& out);
 
 }  // namespace pdlp

@@ -577,13 +577,13 @@ void gpuPrepare(const pdlp_problem_t& P, bool doScale, hipStream_t s, DeviceProb
   for (double v : hb) D.sumRhs2 += v * v;
 }
 
-void gpuSlabPartition(const DeviceCsrData& M, int32_t longLimit, hipStream_t s, DeviceSlabLayout& L) {
+void gpuSlabPartition(const DeviceCsrData& M, int32_t longLimit, int32_t majorCost, hipStream_t s, DeviceSlabLayout& L) {
   // the partition by work is sequential and cheap: on the host, from the major starts (4 bytes per major over PCIe),
   // by the same function the host-side build uses
   std::vector<int32_t> hb((size_t)M.nMajor + 1);
   M.beg.download(hb.data(), hb.size(), s);
   PDLP_HIP(hipStreamSynchronize(s));
-  SlabPartition P = slabPartition(hb.data(), M.nMajor, M.nMinor, longLimit);
+  SlabPartition P = slabPartition(hb.data(), M.nMajor, M.nMinor, longLimit, majorCost);
   L.rowsPerBlock = P.maxRowsPerBlock;
   L.nBlocks = P.nBlocks;
   L.minorBits = P.minorBits;
@@ -593,10 +593,10 @@ void gpuSlabPartition(const DeviceCsrData& M, int32_t longLimit, hipStream_t s, 
   PDLP_HIP(hipStreamSynchronize(s));
 }
 
-void gpuBuildSlabLayout(const DeviceCsrData& M, int32_t longLimit, int32_t W, hipStream_t s, DeviceSlabLayout& L) {
+void gpuBuildSlabLayout(const DeviceCsrData& M, int32_t longLimit, int32_t W, int32_t majorCost, hipStream_t s, DeviceSlabLayout& L) {
   const int32_t nMajor = M.nMajor, nMinor = M.nMinor;
   const int64_t nnz = M.nnz;
-  if (L.hostWaveBeg.empty()) gpuSlabPartition(M, longLimit, s, L);
+  if (L.hostWaveBeg.empty()) gpuSlabPartition(M, longLimit, majorCost, s, L);
   const int32_t nWaves = L.nBlocks * kSlabWavesPerBlock;
   DeviceArray<int32_t> waveOf;
   waveOf.alloc((size_t)std::max(nMajor, 1));

@@ -73,8 +73,8 @@ struct DeviceSlabLayout {
 };
 // gpuSlabPartition: the partition alone (nBlocks, minorBits, rowsPerBlock, hostWaveBeg, waveBeg); gpuBuildSlabLayout
 // computes it itself when `out` does not hold one yet.
-void gpuSlabPartition(const DeviceCsrData& M, int32_t longLimit, hipStream_t s, DeviceSlabLayout& out);
-void gpuBuildSlabLayout(const DeviceCsrData& M, int32_t longLimit, int32_t slabWidthLog2, hipStream_t s,
+void gpuSlabPartition(const DeviceCsrData& M, int32_t longLimit, int32_t majorCost, hipStream_t s, DeviceSlabLayout& out);
+void gpuBuildSlabLayout(const DeviceCsrData& M, int32_t longLimit, int32_t slabWidthLog2, int32_t majorCost, hipStream_t s,
                         DeviceSlabLayout& out);
 
 }  // namespace pdlp

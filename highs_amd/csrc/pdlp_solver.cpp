@@ -120,7 +120,7 @@ void DeviceMatrix::upload(const Compressed& cIn, int32_t nMajor_, int32_t nMinor
   const Compressed* c = &cIn;
   SlabLayout L;
   if (useSlab) {
-    const SlabPartition part = slabPartition(cIn.beg.data(), nMajor_, nMinor_, kSlabLongLimit);
+    const SlabPartition part = slabPartition(cIn.beg.data(), nMajor_, nMinor_, kSlabLongLimit, majorCost);
     const int32_t nB = part.nBlocks;
     std::vector<int32_t> lo((size_t)nB, INT_MAX), hi((size_t)nB, -1), cnt((size_t)nB, 0);
     for (int32_t b = 0; b < nB; ++b)
@@ -129,7 +129,7 @@ void DeviceMatrix::upload(const Compressed& cIn, int32_t nMajor_, int32_t nMinor
         if (p1 <= p0 || p1 - p0 > kSlabLongLimit) continue;
         lo[b] = std::min(lo[b], cIn.idx[p0]); hi[b] = std::max(hi[b], cIn.idx[p1 - 1]); cnt[b] += p1 - p0;
       }
-    buildSlabLayout(cIn, nMajor_, nMinor_, kSlabLongLimit, slabWidthFor(sw, touchesFewTiles(lo, hi, cnt)), L);
+    buildSlabLayout(cIn, nMajor_, nMinor_, kSlabLongLimit, slabWidthFor(sw, touchesFewTiles(lo, hi, cnt)), majorCost, L);
     if (L.rowsPerBlock > kSlabMaxRows) throw std::runtime_error("slab layout: too many majors per block");
     wavePtr.alloc(L.wavePtr.size());
     wavePtr.upload(L.wavePtr.data(), L.wavePtr.size(), s);
@@ -169,7 +169,7 @@ void DeviceMatrix::buildFromDevice(DeviceCsrData& M, const DevSwitches& sw, hipS
   bool localM = false;
   if (useSlab) {
     DeviceSlabLayout L;
-    gpuSlabPartition(M, kSlabLongLimit, s, L);
+    gpuSlabPartition(M, kSlabLongLimit, majorCost, s, L);
     const int32_t nB = L.nBlocks;
     {  // per-block span of the short majors, from the CSR that is already in HBM
       std::vector<int32_t> lo((size_t)nB, INT_MAX), hi((size_t)nB, -1), cnt((size_t)nB, 0);
@@ -183,7 +183,7 @@ void DeviceMatrix::buildFromDevice(DeviceCsrData& M, const DevSwitches& sw, hipS
     }
     // (an operand whose blocks touch few 16384-entry tiles of the gathered vector densely gets slabs of that width: its
     // runs of equal majors are shorter, more lanes add in parallel — bench.py --config c, A x: 44.0 -> 41.1 us)
-    gpuBuildSlabLayout(M, kSlabLongLimit, slabWidthFor(sw, localM), s, L);
+    gpuBuildSlabLayout(M, kSlabLongLimit, slabWidthFor(sw, localM), majorCost, s, L);
     if (L.rowsPerBlock > kSlabMaxRows) throw std::runtime_error("slab layout: too many majors per block");
     wavePtr = std::move(L.wavePtr);
     waveBeg = std::move(L.waveBeg);
@@ -579,6 +579,7 @@ Solver::~Solver() { release(); }
 
 void Solver::uploadProblem() {
   const int32_t n = F_.n;
+  dAt_.majorCost = kSlabMajorCostCols;
   if (!sharded_) {
     // (the fused trial runs the long columns' tasks inside its streaming blocks — but it is not used with an off-diagonal Hessian)
     dAt_.balanceTaskBlocks = sw_.fused == 0 || hasQoff_;
@@ -657,6 +658,7 @@ void Solver::downloadForm(DeviceProblem& D, StandardForm& F, hipStream_t s) {
 }
 
 void Solver::uploadProblemFromDevice(DeviceProblem& D) {
+  dAt_.majorCost = kSlabMajorCostCols;
   dAt_.balanceTaskBlocks = sharded_ || sw_.fused == 0 || hasQoff_;  // (the fused trial runs the long columns' tasks inside its streaming blocks)
   dA_.buildFromDevice(D.A, sw_, stream_);
   dAt_.buildFromDevice(D.At, sw_, stream_);

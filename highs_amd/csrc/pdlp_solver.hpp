@@ -49,6 +49,7 @@ struct DeviceMatrix {
   // slab layout: size the task workgroups so that every CU gets one (uploadPlans).  Off for the operand whose tasks the
   // fused trial runs inside its streaming blocks (already spread evenly; full groups of 16 keep long columns in LDS)
   bool balanceTaskBlocks = true;
+  int32_t majorCost = kSlabMajorCostRows;  // slab partition: work of a major besides its entries (the owner sets kSlabMajorCostCols on its transposed operand)
   int32_t fusedCoTasks = 0;  // MatView::coTaskBlocks (the fused trial's task workgroups), decided by the solver at set-up
   int32_t nMajor = 0, nBlocks = 0;  // nBlocks = CSR stream blocks
   int32_t chunk = kChunk;           // work-plan block size of the CSR stream (spmvChunkFor)

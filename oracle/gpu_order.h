@@ -17,18 +17,19 @@ enum { G_T = 256, G_WAVE = 64, G_CHUNK = 2048, G_CHUNK_SMALL = 512, G_MAXMAJ = 2
 static inline int g_chunk_for(long nnz) { return nnz < (1L << 18) ? G_CHUNK_SMALL : G_CHUNK; }
 /* slab SpMV (k_spmv_slab): 1024-thread blocks of 16 waves.  The majors are dealt to blocks (and, inside a block, to its
  * waves — which does not matter for any sum) by WORK: pdlp_host.cpp slabPartition, restated here.  Work of a major of len
- * entries = len + len * min(len, 64) / 32 + 6 (integer division; 6 alone for a long major, whose segment tasks run
- * elsewhere).  nBlocks = ceil(nMajor / 256) capped at 256 (more only when 256 blocks of 16384 majors do not hold the
+ * entries = len + len * min(len, 64) / 32 + majorCost (integer division; majorCost alone for a long major, whose segment
+ * tasks run elsewhere; majorCost = 2 for the operand by rows, 6 for the transposed one, whose launch also carries the
+ * next primal step of every column).  nBlocks = ceil(nMajor / 256) capped at 256 (more only when 256 blocks of 16384 majors do not hold the
  * operand); block b takes majors while it is closer to ceil(work left / blocks left) with the next major than without,
  * at least one and at most 16384, and never so few / many that the blocks behind it could not hold / would not get the
  * rest. */
-enum { G_SLAB_T = 1024, G_SLAB_WAVES = 16, G_SLAB_BLOCKS = 256, G_SLAB_BLOCK_CAP = 16384, G_SLAB_MIN_ROWS = 256, G_SLAB_MAJOR_COST = 6 };
+enum { G_SLAB_T = 1024, G_SLAB_WAVES = 16, G_SLAB_BLOCKS = 256, G_SLAB_BLOCK_CAP = 16384, G_SLAB_MIN_ROWS = 256, G_SLAB_MAJOR_COST_ROWS = 2, G_SLAB_MAJOR_COST_COLS = 6 };
 static inline int g_slab_fits(int nMajor, int nMinor) { /* the minor index must fit 28 bits of an entry */
   (void)nMajor;
   return (long)nMinor <= (1L << 28);
 }
 /* blockBeg[0..nBlocks] (caller provides room for G_SLAB_BLOCKS + nMajor / G_SLAB_BLOCK_CAP + 2 ints); returns nBlocks */
-static inline int g_slab_blocks(const int* beg, int nMajor, int nMinor, int longLimit, int* blockBeg) {
+static inline int g_slab_blocks(const int* beg, int nMajor, int nMinor, int longLimit, int majorCost, int* blockBeg) {
   int mb = 0;
   while ((1L << mb) < (long)nMinor) ++mb;
   if (mb < 4) mb = 4;
@@ -39,7 +40,7 @@ static inline int g_slab_blocks(const int* beg, int nMajor, int nMinor, int long
   long nB = ((long)nMajor + G_SLAB_MIN_ROWS - 1) / G_SLAB_MIN_ROWS;
   if (nB > G_SLAB_BLOCKS) nB = G_SLAB_BLOCKS;
   if (nB < ((long)nMajor + cap - 1) / cap) nB = ((long)nMajor + cap - 1) / cap;
-#define G_WORK(len) ((len) > longLimit ? (long)G_SLAB_MAJOR_COST : (long)(len) + ((long)(len) * ((len) < 64 ? (len) : 64)) / 32 + G_SLAB_MAJOR_COST)
+#define G_WORK(len) ((len) > longLimit ? (long)majorCost : (long)(len) + ((long)(len) * ((len) < 64 ? (len) : 64)) / 32 + majorCost)
   long rem = 0;
   for (int r = 0; r < nMajor; ++r) { const int len = beg[r + 1] - beg[r]; rem += G_WORK(len); }
   int r = 0;

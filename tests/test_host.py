@@ -149,17 +149,18 @@ def _slab_to_coo(sl, n_major):
     return majors, minors, val, wave
 
 
-def _slab_work(lens, long_limit):
-    """pdlp_host.cpp slabMajorWork: entries + the run-accumulation term + 6 per major; a long major: 6."""
+def _slab_work(lens, long_limit, major_cost=2):
+    """pdlp_host.cpp slabMajorWork: entries + the run-accumulation term + major_cost (2 for the operand by rows, 6 for the
+    transposed one); a long major: major_cost alone."""
     lens = np.asarray(lens, dtype=np.int64)
-    return np.where(lens > long_limit, 6, lens + (lens * np.minimum(lens, 64)) // 32 + 6)
+    return np.where(lens > long_limit, major_cost, lens + (lens * np.minimum(lens, 64)) // 32 + major_cost)
 
 
-def _slab_partition_restated(beg, n_major, n_minor, long_limit):
+def _slab_partition_restated(beg, n_major, n_minor, long_limit, major_cost=2):
     """pdlp_host.cpp slabPartition, restated: blocks, then the 16 waves of every block, filled one after the other by
     work = _slab_work."""
     lens = np.diff(beg)
-    cost = _slab_work(lens, long_limit)
+    cost = _slab_work(lens, long_limit, major_cost)
     mb = max(int(np.ceil(np.log2(max(n_minor, 1)))), 4)
     wave_cap = min(1 << (32 - mb), 16384)
     block_cap = min(16384, wave_cap * 16)
@@ -222,9 +223,9 @@ def test_slab_layout_is_a_permutation_of_the_csr(which, long_limit):
     blk = wb[::16]
     assert np.all(np.diff(blk) >= 1) and np.max(np.diff(blk)) == sl["rows_per_block"] <= 16384
     # the partition is the restated rule, and it balances work: no block above the mean by more than one major's worth
-    nb, mb, wb2 = _slab_partition_restated(beg, n_major, P.n if which == 0 else P.m, long_limit)
+    nb, mb, wb2 = _slab_partition_restated(beg, n_major, P.n if which == 0 else P.m, long_limit, 6 if which else 2)
     assert nb == sl["n_blocks"] and mb == sl["minor_bits"] and np.array_equal(wb2, wb)
-    cost = _slab_work(lens, long_limit)
+    cost = _slab_work(lens, long_limit, 6 if which else 2)
     work = np.add.reduceat(cost, blk[:-1])
     assert work.max() <= work.mean() + cost.max()
     # a wave's entries are those of its majors

@@ -5,7 +5,9 @@ cd "$(dirname "$0")/.."
 TAG=${1:-r05}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-if [ -n "${SUBSET:-}" ]; then  # the tests that see the slab layout, the loop variants and the device gate
+if [ -n "${SKIP_TESTS:-}" ]; then
+  echo "(GPU tests skipped)"
+elif [ -n "${SUBSET:-}" ]; then  # the tests that see the slab layout, the loop variants and the device gate
   PYTEST_TIMEOUT=${PYTEST_TIMEOUT:-600} bash tools/gpu_pytest.sh $TAG/pytest_gpu tests -m gpu -q -x --timeout 200 \
     -k "bit_exact or long or dense or structured or spmv or fused or two_large or setup or trial_loop or hard_instances_first"
 else
