@@ -149,18 +149,28 @@ def _slab_to_coo(sl, n_major):
     return majors, minors, val, wave
 
 
-def _slab_work(lens, long_limit, major_cost=2):
-    """pdlp_host.cpp slabMajorWork: entries + the run-accumulation term + major_cost (2 for the operand by rows, 6 for the
-    transposed one); a long major: major_cost alone."""
+def _slab_work(lens, long_limit, major_cost=2, scattered=None):
+    """pdlp_host.cpp slabMajorWork: entries (twice for a scattered major) + the run-accumulation term + major_cost (2 for the
+    operand by rows, 6 for the transposed one); a long major: major_cost alone."""
     lens = np.asarray(lens, dtype=np.int64)
-    return np.where(lens > long_limit, major_cost, lens + (lens * np.minimum(lens, 64)) // 32 + major_cost)
+    mult = 1 if scattered is None else np.where(scattered, 2, 1)
+    return np.where(lens > long_limit, major_cost, lens * mult + (lens * np.minimum(lens, 64)) // 32 + major_cost)
 
 
-def _slab_partition_restated(beg, n_major, n_minor, long_limit, major_cost=2):
+def _scattered(beg, idx):
+    """pdlp_host.hpp slabMajorScattered: first and last minor of the major in different stretches of 2^17 minors"""
+    beg = np.asarray(beg, dtype=np.int64)
+    lens = np.diff(beg)
+    first = np.asarray(idx)[np.minimum(beg[:-1], len(idx) - 1)] >> 17
+    last = np.asarray(idx)[np.maximum(beg[1:] - 1, 0)] >> 17
+    return (lens >= 2) & (first != last)
+
+
+def _slab_partition_restated(beg, n_major, n_minor, long_limit, major_cost=2, scattered=None):
     """pdlp_host.cpp slabPartition, restated: blocks, then the 16 waves of every block, filled one after the other by
     work = _slab_work."""
     lens = np.diff(beg)
-    cost = _slab_work(lens, long_limit, major_cost)
+    cost = _slab_work(lens, long_limit, major_cost, scattered)
     mb = max(int(np.ceil(np.log2(max(n_minor, 1)))), 4)
     wave_cap = min(1 << (32 - mb), 16384)
     block_cap = min(16384, wave_cap * 16)
@@ -223,9 +233,11 @@ def test_slab_layout_is_a_permutation_of_the_csr(which, long_limit):
     blk = wb[::16]
     assert np.all(np.diff(blk) >= 1) and np.max(np.diff(blk)) == sl["rows_per_block"] <= 16384
     # the partition is the restated rule, and it balances work: no block above the mean by more than one major's worth
-    nb, mb, wb2 = _slab_partition_restated(beg, n_major, P.n if which == 0 else P.m, long_limit, 6 if which else 2)
+    sc = _scattered(beg, idx)
+    assert which == 1 or sc.sum() > 100  # (200 000 columns: rows of 8 random columns leave their 2^17-stretch)
+    nb, mb, wb2 = _slab_partition_restated(beg, n_major, P.n if which == 0 else P.m, long_limit, 6 if which else 2, sc)
     assert nb == sl["n_blocks"] and mb == sl["minor_bits"] and np.array_equal(wb2, wb)
-    cost = _slab_work(lens, long_limit, 6 if which else 2)
+    cost = _slab_work(lens, long_limit, 6 if which else 2, sc)
     work = np.add.reduceat(cost, blk[:-1])
     assert work.max() <= work.mean() + cost.max()
     # a wave's entries are those of its majors
