@@ -143,12 +143,12 @@ constexpr int32_t kSlabMajorCostRows = 2, kSlabMajorCostCols = 6;
 // block's majors (cap: 2^(32 - minorBits) majors, the local-major field of an entry).  Sequential and exact in
 // integers: the device-side set-up (pdlp_setup.hip) calls this same function on the downloaded major starts,
 // oracle/gpu_order.h restates it.
-// scattered: the major's first and last minor lie in different stretches of 2^kSlabWidthLog2 minors — its gathers do not
+// scattered: the major's first and last minor are 2^kSlabWidthLog2 or more apart — its gathers do not
 // stay with the part of the gathered vector its block works in (config c: 512 rows of 12 random columns at the end of a
 // block-angular matrix made the block that owns them the straggler of the launch, 42.8 against 35.3 us): entries x 2
 int64_t slabMajorWork(int32_t len, int32_t longLimit, int32_t majorCost, bool scattered);
 inline bool slabMajorScattered(const int32_t* beg, const int32_t* idx, int32_t r) {
-  return beg[r + 1] - beg[r] >= 2 && (idx[beg[r + 1] - 1] >> kSlabWidthLog2) != (idx[beg[r]] >> kSlabWidthLog2);
+  return beg[r + 1] - beg[r] >= 2 && idx[beg[r + 1] - 1] - idx[beg[r]] >= (1 << kSlabWidthLog2);
 }
 struct SlabPartition {
   int32_t nBlocks = 0, minorBits = 0, maxRowsPerBlock = 0;

@@ -577,11 +577,11 @@ void gpuPrepare(const pdlp_problem_t& P, bool doScale, hipStream_t s, DeviceProb
   for (double v : hb) D.sumRhs2 += v * v;
 }
 
-// scattered[r] = 1: the first and the last minor of major r lie in different stretches of 2^W minors (pdlp_host.hpp slabMajorScattered)
+// scattered[r] = 1: the first and the last minor of major r are 2^W or more apart (pdlp_host.hpp slabMajorScattered)
 __global__ void k_major_scattered(const int32_t* __restrict__ beg, const int32_t* __restrict__ idx, int nMajor, int W, uint8_t* out) {
   GSTRIDE(r, nMajor) {
     const int p0 = beg[r], p1 = beg[r + 1];
-    out[r] = (p1 - p0 >= 2 && (idx[p1 - 1] >> W) != (idx[p0] >> W)) ? 1 : 0;
+    out[r] = (p1 - p0 >= 2 && idx[p1 - 1] - idx[p0] >= (1 << W)) ? 1 : 0;
   }
 }
 

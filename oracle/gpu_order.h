@@ -17,7 +17,7 @@ enum { G_T = 256, G_WAVE = 64, G_CHUNK = 2048, G_CHUNK_SMALL = 512, G_MAXMAJ = 2
 static inline int g_chunk_for(long nnz) { return nnz < (1L << 18) ? G_CHUNK_SMALL : G_CHUNK; }
 /* slab SpMV (k_spmv_slab): 1024-thread blocks of 16 waves.  The majors are dealt to blocks (and, inside a block, to its
  * waves — which does not matter for any sum) by WORK: pdlp_host.cpp slabPartition, restated here.  Work of a major of len
- * entries = len (twice that for a major whose first and last minor lie in different stretches of 2^17 minors: its
+ * entries = len (twice that for a major whose first and last minor are 2^17 or more apart: its
  * gathers leave the part of the gathered vector its block works in) + len * min(len, 64) / 32 + majorCost (integer division; majorCost alone for a long major, whose segment
  * tasks run elsewhere; majorCost = 2 for the operand by rows, 6 for the transposed one, whose launch also carries the
  * next primal step of every column).  nBlocks = ceil(nMajor / 256) capped at 256 (more only when 256 blocks of 16384 majors do not hold the
@@ -41,8 +41,8 @@ static inline int g_slab_blocks(const int* beg, const int* idx, int nMajor, int 
   long nB = ((long)nMajor + G_SLAB_MIN_ROWS - 1) / G_SLAB_MIN_ROWS;
   if (nB > G_SLAB_BLOCKS) nB = G_SLAB_BLOCKS;
   if (nB < ((long)nMajor + cap - 1) / cap) nB = ((long)nMajor + cap - 1) / cap;
-/* scattered major: first and last minor in different stretches of 2^17 minors — its entries count twice */
-#define G_SCAT(r) (beg[(r) + 1] - beg[(r)] >= 2 && (idx[beg[(r) + 1] - 1] >> 17) != (idx[beg[(r)]] >> 17))
+/* scattered major: first and last minor 2^17 or more apart — its entries count twice */
+#define G_SCAT(r) (beg[(r) + 1] - beg[(r)] >= 2 && idx[beg[(r) + 1] - 1] - idx[beg[(r)]] >= (1 << 17))
 #define G_WORK(r, len) ((len) > longLimit ? (long)majorCost : (long)(len) * (G_SCAT(r) ? 2 : 1) + ((long)(len) * ((len) < 64 ? (len) : 64)) / 32 + majorCost)
   long rem = 0;
   for (int r = 0; r < nMajor; ++r) { const int len = beg[r + 1] - beg[r]; rem += G_WORK(r, len); }

@@ -158,12 +158,12 @@ def _slab_work(lens, long_limit, major_cost=2, scattered=None):
 
 
 def _scattered(beg, idx):
-    """pdlp_host.hpp slabMajorScattered: first and last minor of the major in different stretches of 2^17 minors"""
+    """pdlp_host.hpp slabMajorScattered: first and last minor of the major 2^17 or more apart"""
     beg = np.asarray(beg, dtype=np.int64)
     lens = np.diff(beg)
-    first = np.asarray(idx)[np.minimum(beg[:-1], len(idx) - 1)] >> 17
-    last = np.asarray(idx)[np.maximum(beg[1:] - 1, 0)] >> 17
-    return (lens >= 2) & (first != last)
+    first = np.asarray(idx, dtype=np.int64)[np.minimum(beg[:-1], len(idx) - 1)]
+    last = np.asarray(idx, dtype=np.int64)[np.maximum(beg[1:] - 1, 0)]
+    return (lens >= 2) & (last - first >= (1 << 17))
 
 
 def _slab_partition_restated(beg, n_major, n_minor, long_limit, major_cost=2, scattered=None):
@@ -234,7 +234,7 @@ def test_slab_layout_is_a_permutation_of_the_csr(which, long_limit):
     assert np.all(np.diff(blk) >= 1) and np.max(np.diff(blk)) == sl["rows_per_block"] <= 16384
     # the partition is the restated rule, and it balances work: no block above the mean by more than one major's worth
     sc = _scattered(beg, idx)
-    assert which == 1 or sc.sum() > 100  # (200 000 columns: rows of 8 random columns leave their 2^17-stretch)
+    assert which == 1 or sc.sum() > 100  # (200 000 columns: most rows of 8 random columns span 2^17 of them)
     nb, mb, wb2 = _slab_partition_restated(beg, n_major, P.n if which == 0 else P.m, long_limit, 6 if which else 2, sc)
     assert nb == sl["n_blocks"] and mb == sl["minor_bits"] and np.array_equal(wb2, wb)
     cost = _slab_work(lens, long_limit, 6 if which else 2, sc)
