@@ -494,9 +494,12 @@ SlabPartition slabPartition(const int32_t* beg, const uint8_t* scattered, int32_
 void buildSlabLayout(const Compressed& csr, int32_t nMajor, int32_t nMinor, int32_t longLimit, int32_t slabWidthLog2,
                      int32_t majorCost, SlabLayout& out) {
   out = SlabLayout();
-  std::vector<uint8_t> scattered((size_t)nMajor);
-  for (int32_t r = 0; r < nMajor; ++r) scattered[r] = slabMajorScattered(csr.beg.data(), csr.idx.data(), r) ? 1 : 0;
-  SlabPartition P = slabPartition(csr.beg.data(), scattered.data(), nMajor, nMinor, longLimit, majorCost);
+  std::vector<uint8_t> scattered;
+  if (slabScatterAware(majorCost, nMinor)) {
+    scattered.resize((size_t)nMajor);
+    for (int32_t r = 0; r < nMajor; ++r) scattered[r] = slabMajorScattered(csr.beg.data(), csr.idx.data(), r) ? 1 : 0;
+  }
+  SlabPartition P = slabPartition(csr.beg.data(), scattered.empty() ? nullptr : scattered.data(), nMajor, nMinor, longLimit, majorCost);
   out.rowsPerBlock = P.maxRowsPerBlock;
   out.nBlocks = P.nBlocks;
   out.minorBits = P.minorBits;

@@ -147,6 +147,10 @@ constexpr int32_t kSlabMajorCostRows = 2, kSlabMajorCostCols = 6;
 // stay with the part of the gathered vector its block works in (config c: 512 rows of 12 random columns at the end of a
 // block-angular matrix made the block that owns them the straggler of the launch, 42.8 against 35.3 us): entries x 2
 int64_t slabMajorWork(int32_t len, int32_t longLimit, int32_t majorCost, bool scattered);
+// Applied to the operand by rows, and only where the gathered vector does not fit an XCD's L2 (more than 2^19 doubles):
+// measured on the transposed operands of configs c and d the same rule made things worse — their far entries (the
+// rows of the dense linking constraints, which every column touches) are the hottest part of the gathered vector.
+inline bool slabScatterAware(int32_t majorCost, int32_t nMinor) { return majorCost == kSlabMajorCostRows && nMinor > (1 << 19); }
 inline bool slabMajorScattered(const int32_t* beg, const int32_t* idx, int32_t r) {
   return beg[r + 1] - beg[r] >= 2 && idx[beg[r + 1] - 1] - idx[beg[r]] >= (1 << kSlabWidthLog2);
 }

@@ -592,11 +592,12 @@ void gpuSlabPartition(const DeviceCsrData& M, int32_t longLimit, int32_t majorCo
   std::vector<uint8_t> hs((size_t)std::max(M.nMajor, 1));
   DeviceArray<uint8_t> ds;
   ds.alloc(hs.size());
-  if (M.nMajor > 0) hipLaunchKernelGGL(k_major_scattered, dim3(gridFor(M.nMajor)), dim3(kT), 0, s, M.beg.get(), M.idx.get(), M.nMajor, kSlabWidthLog2, ds.get());
+  const bool aware = slabScatterAware(majorCost, M.nMinor) && M.nMajor > 0;
+  if (aware) hipLaunchKernelGGL(k_major_scattered, dim3(gridFor(M.nMajor)), dim3(kT), 0, s, M.beg.get(), M.idx.get(), M.nMajor, kSlabWidthLog2, ds.get());
   M.beg.download(hb.data(), hb.size(), s);
-  if (M.nMajor > 0) ds.download(hs.data(), (size_t)M.nMajor, s);
+  if (aware) ds.download(hs.data(), (size_t)M.nMajor, s);
   PDLP_HIP(hipStreamSynchronize(s));
-  SlabPartition P = slabPartition(hb.data(), hs.data(), M.nMajor, M.nMinor, longLimit, majorCost);
+  SlabPartition P = slabPartition(hb.data(), aware ? hs.data() : nullptr, M.nMajor, M.nMinor, longLimit, majorCost);
   L.rowsPerBlock = P.maxRowsPerBlock;
   L.nBlocks = P.nBlocks;
   L.minorBits = P.minorBits;

@@ -42,8 +42,10 @@ static inline int g_slab_blocks(const int* beg, const int* idx, int nMajor, int 
   if (nB > G_SLAB_BLOCKS) nB = G_SLAB_BLOCKS;
   if (nB < ((long)nMajor + cap - 1) / cap) nB = ((long)nMajor + cap - 1) / cap;
 /* scattered major: first and last minor 2^17 or more apart — its entries count twice */
-#define G_SCAT(r) (beg[(r) + 1] - beg[(r)] >= 2 && idx[beg[(r) + 1] - 1] - idx[beg[(r)]] >= (1 << 17))
+#define G_SCAT(r) (aware && beg[(r) + 1] - beg[(r)] >= 2 && idx[beg[(r) + 1] - 1] - idx[beg[(r)]] >= (1 << 17))
 #define G_WORK(r, len) ((len) > longLimit ? (long)majorCost : (long)(len) * (G_SCAT(r) ? 2 : 1) + ((long)(len) * ((len) < 64 ? (len) : 64)) / 32 + majorCost)
+  /* (only for the operand by rows, and only when the gathered vector exceeds an XCD's L2: 2^19 doubles) */
+  const int aware = majorCost == G_SLAB_MAJOR_COST_ROWS && nMinor > (1 << 19);
   long rem = 0;
   for (int r = 0; r < nMajor; ++r) { const int len = beg[r + 1] - beg[r]; rem += G_WORK(r, len); }
   int r = 0;
