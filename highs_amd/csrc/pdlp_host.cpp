@@ -433,9 +433,9 @@ int32_t bitsFor(int64_t count) {  // smallest b with 2^b >= count
   return b;
 }
 // Fills `units` consecutive ranges of [r0, r1) by work (see SlabPartition): out[0..units] boundaries.
-void fillByWork(const int32_t* beg, const uint8_t* scattered, int32_t longLimit, int32_t majorCost, int32_t r0, int32_t r1, int32_t units, int64_t cap, bool nonEmpty,
+void fillByWork(const int32_t* beg, int32_t longLimit, int32_t majorCost, int32_t r0, int32_t r1, int32_t units, int64_t cap, bool nonEmpty,
                 int32_t* out) {
-  auto cost = [&](int32_t r) -> int64_t { return slabMajorWork(beg[r + 1] - beg[r], longLimit, majorCost, scattered && scattered[r]); };
+  auto cost = [&](int32_t r) -> int64_t { return slabMajorWork(beg[r + 1] - beg[r], longLimit, majorCost); };
   int64_t rem = 0;
   for (int32_t r = r0; r < r1; ++r) rem += cost(r);
   int32_t r = r0;
@@ -458,9 +458,9 @@ void fillByWork(const int32_t* beg, const uint8_t* scattered, int32_t longLimit,
 }
 }  // namespace
 
-int64_t slabMajorWork(int32_t len, int32_t longLimit, int32_t majorCost, bool scattered) {
+int64_t slabMajorWork(int32_t len, int32_t longLimit, int32_t majorCost) {
   if (len > longLimit) return majorCost;  // (its segment tasks run elsewhere)
-  return (int64_t)len * (scattered ? 2 : 1) + ((int64_t)len * std::min(len, 64)) / 32 + majorCost;
+  return (int64_t)len + ((int64_t)len * std::min(len, 64)) / 32 + majorCost;
 }
 
 bool slabFits(int32_t nMajor, int32_t nMinor) {
@@ -468,8 +468,7 @@ bool slabFits(int32_t nMajor, int32_t nMinor) {
   return bitsFor(nMinor) <= 28;  // at least 16 majors per wave
 }
 
-SlabPartition slabPartition(const int32_t* beg, const uint8_t* scattered, int32_t nMajor, int32_t nMinor, int32_t longLimit,
-                            int32_t majorCost) {
+SlabPartition slabPartition(const int32_t* beg, int32_t nMajor, int32_t nMinor, int32_t longLimit, int32_t majorCost) {
   SlabPartition P;
   if (!slabFits(nMajor, nMinor)) throw std::runtime_error("slab layout: minor index does not fit the entry packing");
   P.minorBits = std::max(bitsFor(nMinor), 4);
@@ -482,9 +481,9 @@ SlabPartition slabPartition(const int32_t* beg, const uint8_t* scattered, int32_
   P.waveBeg.assign((size_t)nB * kSlabWavesPerBlock + 1, 0);
   if (nB == 0) return P;
   std::vector<int32_t> blockBeg((size_t)nB + 1);
-  fillByWork(beg, scattered, longLimit, majorCost, 0, nMajor, (int32_t)nB, blockCap, true, blockBeg.data());
+  fillByWork(beg, longLimit, majorCost, 0, nMajor, (int32_t)nB, blockCap, true, blockBeg.data());
   for (int32_t b = 0; b < (int32_t)nB; ++b) {
-    fillByWork(beg, scattered, longLimit, majorCost, blockBeg[b], blockBeg[b + 1], kSlabWavesPerBlock, waveCap, false,
+    fillByWork(beg, longLimit, majorCost, blockBeg[b], blockBeg[b + 1], kSlabWavesPerBlock, waveCap, false,
                P.waveBeg.data() + (size_t)b * kSlabWavesPerBlock);
     P.maxRowsPerBlock = std::max(P.maxRowsPerBlock, blockBeg[b + 1] - blockBeg[b]);
   }
@@ -494,12 +493,7 @@ SlabPartition slabPartition(const int32_t* beg, const uint8_t* scattered, int32_
 void buildSlabLayout(const Compressed& csr, int32_t nMajor, int32_t nMinor, int32_t longLimit, int32_t slabWidthLog2,
                      int32_t majorCost, SlabLayout& out) {
   out = SlabLayout();
-  std::vector<uint8_t> scattered;
-  if (slabScatterAware(majorCost, nMinor)) {
-    scattered.resize((size_t)nMajor);
-    for (int32_t r = 0; r < nMajor; ++r) scattered[r] = slabMajorScattered(csr.beg.data(), csr.idx.data(), r) ? 1 : 0;
-  }
-  SlabPartition P = slabPartition(csr.beg.data(), scattered.empty() ? nullptr : scattered.data(), nMajor, nMinor, longLimit, majorCost);
+  SlabPartition P = slabPartition(csr.beg.data(), nMajor, nMinor, longLimit, majorCost);
   out.rowsPerBlock = P.maxRowsPerBlock;
   out.nBlocks = P.nBlocks;
   out.minorBits = P.minorBits;

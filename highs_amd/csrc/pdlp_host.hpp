@@ -143,17 +143,7 @@ constexpr int32_t kSlabMajorCostRows = 2, kSlabMajorCostCols = 6;
 // block's majors (cap: 2^(32 - minorBits) majors, the local-major field of an entry).  Sequential and exact in
 // integers: the device-side set-up (pdlp_setup.hip) calls this same function on the downloaded major starts,
 // oracle/gpu_order.h restates it.
-// scattered: the major's first and last minor are 2^kSlabWidthLog2 or more apart — its gathers do not
-// stay with the part of the gathered vector its block works in (config c: 512 rows of 12 random columns at the end of a
-// block-angular matrix made the block that owns them the straggler of the launch, 42.8 against 35.3 us): entries x 2
-int64_t slabMajorWork(int32_t len, int32_t longLimit, int32_t majorCost, bool scattered);
-// Applied to the operand by rows, and only where the gathered vector does not fit an XCD's L2 (more than 2^19 doubles):
-// measured on the transposed operands of configs c and d the same rule made things worse — their far entries (the
-// rows of the dense linking constraints, which every column touches) are the hottest part of the gathered vector.
-inline bool slabScatterAware(int32_t majorCost, int32_t nMinor) { return majorCost == kSlabMajorCostRows && nMinor > (1 << 19); }
-inline bool slabMajorScattered(const int32_t* beg, const int32_t* idx, int32_t r) {
-  return beg[r + 1] - beg[r] >= 2 && idx[beg[r + 1] - 1] - idx[beg[r]] >= (1 << kSlabWidthLog2);
-}
+int64_t slabMajorWork(int32_t len, int32_t longLimit, int32_t majorCost);
 struct SlabPartition {
   int32_t nBlocks = 0, minorBits = 0, maxRowsPerBlock = 0;
   std::vector<int32_t> waveBeg;  // [16*nBlocks+1] first major of every wave
@@ -161,9 +151,7 @@ struct SlabPartition {
 };
 // false: the minor index does not fit the entry packing (nMinor > 2^28: the caller uses the CSR stream kernel)
 bool slabFits(int32_t nMajor, int32_t nMinor);
-// scattered: one byte per major (slabMajorScattered), or nullptr: none
-SlabPartition slabPartition(const int32_t* beg, const uint8_t* scattered, int32_t nMajor, int32_t nMinor, int32_t longLimit,
-                            int32_t majorCost);
+SlabPartition slabPartition(const int32_t* beg, int32_t nMajor, int32_t nMinor, int32_t longLimit, int32_t majorCost);
 
 struct SlabLayout {
   int32_t rowsPerBlock = 0;  // most majors in one block (LDS accumulators)

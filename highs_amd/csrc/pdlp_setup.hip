@@ -577,27 +577,13 @@ void gpuPrepare(const pdlp_problem_t& P, bool doScale, hipStream_t s, DeviceProb
   for (double v : hb) D.sumRhs2 += v * v;
 }
 
-// scattered[r] = 1: the first and the last minor of major r are 2^W or more apart (pdlp_host.hpp slabMajorScattered)
-__global__ void k_major_scattered(const int32_t* __restrict__ beg, const int32_t* __restrict__ idx, int nMajor, int W, uint8_t* out) {
-  GSTRIDE(r, nMajor) {
-    const int p0 = beg[r], p1 = beg[r + 1];
-    out[r] = (p1 - p0 >= 2 && idx[p1 - 1] - idx[p0] >= (1 << W)) ? 1 : 0;
-  }
-}
-
 void gpuSlabPartition(const DeviceCsrData& M, int32_t longLimit, int32_t majorCost, hipStream_t s, DeviceSlabLayout& L) {
   // the partition by work is sequential and cheap: on the host, from the major starts (4 bytes per major over PCIe),
   // by the same function the host-side build uses
   std::vector<int32_t> hb((size_t)M.nMajor + 1);
-  std::vector<uint8_t> hs((size_t)std::max(M.nMajor, 1));
-  DeviceArray<uint8_t> ds;
-  ds.alloc(hs.size());
-  const bool aware = slabScatterAware(majorCost, M.nMinor) && M.nMajor > 0;
-  if (aware) hipLaunchKernelGGL(k_major_scattered, dim3(gridFor(M.nMajor)), dim3(kT), 0, s, M.beg.get(), M.idx.get(), M.nMajor, kSlabWidthLog2, ds.get());
   M.beg.download(hb.data(), hb.size(), s);
-  if (aware) ds.download(hs.data(), (size_t)M.nMajor, s);
   PDLP_HIP(hipStreamSynchronize(s));
-  SlabPartition P = slabPartition(hb.data(), aware ? hs.data() : nullptr, M.nMajor, M.nMinor, longLimit, majorCost);
+  SlabPartition P = slabPartition(hb.data(), M.nMajor, M.nMinor, longLimit, majorCost);
   L.rowsPerBlock = P.maxRowsPerBlock;
   L.nBlocks = P.nBlocks;
   L.minorBits = P.minorBits;

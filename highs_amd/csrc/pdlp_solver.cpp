@@ -120,12 +120,7 @@ void DeviceMatrix::upload(const Compressed& cIn, int32_t nMajor_, int32_t nMinor
   const Compressed* c = &cIn;
   SlabLayout L;
   if (useSlab) {
-    std::vector<uint8_t> scattered;
-    if (slabScatterAware(majorCost, nMinor_)) {
-      scattered.resize((size_t)nMajor_);
-      for (int32_t r = 0; r < nMajor_; ++r) scattered[r] = slabMajorScattered(cIn.beg.data(), cIn.idx.data(), r) ? 1 : 0;
-    }
-    const SlabPartition part = slabPartition(cIn.beg.data(), scattered.empty() ? nullptr : scattered.data(), nMajor_, nMinor_, kSlabLongLimit, majorCost);
+    const SlabPartition part = slabPartition(cIn.beg.data(), nMajor_, nMinor_, kSlabLongLimit, majorCost);
     const int32_t nB = part.nBlocks;
     std::vector<int32_t> lo((size_t)nB, INT_MAX), hi((size_t)nB, -1), cnt((size_t)nB, 0);
     for (int32_t b = 0; b < nB; ++b)

@@ -17,8 +17,7 @@ enum { G_T = 256, G_WAVE = 64, G_CHUNK = 2048, G_CHUNK_SMALL = 512, G_MAXMAJ = 2
 static inline int g_chunk_for(long nnz) { return nnz < (1L << 18) ? G_CHUNK_SMALL : G_CHUNK; }
 /* slab SpMV (k_spmv_slab): 1024-thread blocks of 16 waves.  The majors are dealt to blocks (and, inside a block, to its
  * waves — which does not matter for any sum) by WORK: pdlp_host.cpp slabPartition, restated here.  Work of a major of len
- * entries = len (twice that for a major whose first and last minor are 2^17 or more apart: its
- * gathers leave the part of the gathered vector its block works in) + len * min(len, 64) / 32 + majorCost (integer division; majorCost alone for a long major, whose segment
+ * entries = len + len * min(len, 64) / 32 + majorCost (integer division; majorCost alone for a long major, whose segment
  * tasks run elsewhere; majorCost = 2 for the operand by rows, 6 for the transposed one, whose launch also carries the
  * next primal step of every column).  nBlocks = ceil(nMajor / 256) capped at 256 (more only when 256 blocks of 16384 majors do not hold the
  * operand); block b takes majors while it is closer to ceil(work left / blocks left) with the next major than without,
@@ -30,7 +29,7 @@ static inline int g_slab_fits(int nMajor, int nMinor) { /* the minor index must 
   return (long)nMinor <= (1L << 28);
 }
 /* blockBeg[0..nBlocks] (caller provides room for G_SLAB_BLOCKS + nMajor / G_SLAB_BLOCK_CAP + 2 ints); returns nBlocks */
-static inline int g_slab_blocks(const int* beg, const int* idx, int nMajor, int nMinor, int longLimit, int majorCost, int* blockBeg) {
+static inline int g_slab_blocks(const int* beg, int nMajor, int nMinor, int longLimit, int majorCost, int* blockBeg) {
   int mb = 0;
   while ((1L << mb) < (long)nMinor) ++mb;
   if (mb < 4) mb = 4;
@@ -41,13 +40,9 @@ static inline int g_slab_blocks(const int* beg, const int* idx, int nMajor, int 
   long nB = ((long)nMajor + G_SLAB_MIN_ROWS - 1) / G_SLAB_MIN_ROWS;
   if (nB > G_SLAB_BLOCKS) nB = G_SLAB_BLOCKS;
   if (nB < ((long)nMajor + cap - 1) / cap) nB = ((long)nMajor + cap - 1) / cap;
-/* scattered major: first and last minor 2^17 or more apart — its entries count twice */
-#define G_SCAT(r) (aware && beg[(r) + 1] - beg[(r)] >= 2 && idx[beg[(r) + 1] - 1] - idx[beg[(r)]] >= (1 << 17))
-#define G_WORK(r, len) ((len) > longLimit ? (long)majorCost : (long)(len) * (G_SCAT(r) ? 2 : 1) + ((long)(len) * ((len) < 64 ? (len) : 64)) / 32 + majorCost)
-  /* (only for the operand by rows, and only when the gathered vector exceeds an XCD's L2: 2^19 doubles) */
-  const int aware = majorCost == G_SLAB_MAJOR_COST_ROWS && nMinor > (1 << 19);
+#define G_WORK(len) ((len) > longLimit ? (long)majorCost : (long)(len) + ((long)(len) * ((len) < 64 ? (len) : 64)) / 32 + majorCost)
   long rem = 0;
-  for (int r = 0; r < nMajor; ++r) { const int len = beg[r + 1] - beg[r]; rem += G_WORK(r, len); }
+  for (int r = 0; r < nMajor; ++r) { const int len = beg[r + 1] - beg[r]; rem += G_WORK(len); }
   int r = 0;
   blockBeg[0] = 0;
   for (long u = 0; u < nB; ++u) {
@@ -59,7 +54,7 @@ static inline int g_slab_blocks(const int* beg, const int* idx, int nMajor, int 
     long acc = 0, cnt = 0;
     while (cnt < rows && cnt < maxRows) {
       const int len = beg[r + 1] - beg[r];
-      const long c = G_WORK(r, len);
+      const long c = G_WORK(len);
       if (cnt >= minRows && 2 * acc + c > 2 * target) break;
       acc += c; ++r; ++cnt;
     }
@@ -67,7 +62,6 @@ static inline int g_slab_blocks(const int* beg, const int* idx, int nMajor, int 
     blockBeg[u + 1] = r;
   }
 #undef G_WORK
-#undef G_SCAT
   return (int)nB;
 }
 

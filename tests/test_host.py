@@ -149,28 +149,18 @@ def _slab_to_coo(sl, n_major):
     return majors, minors, val, wave
 
 
-def _slab_work(lens, long_limit, major_cost=2, scattered=None):
-    """pdlp_host.cpp slabMajorWork: entries (twice for a scattered major) + the run-accumulation term + major_cost (2 for the
-    operand by rows, 6 for the transposed one); a long major: major_cost alone."""
+def _slab_work(lens, long_limit, major_cost=2):
+    """pdlp_host.cpp slabMajorWork: entries + the run-accumulation term + major_cost (2 for the operand by rows, 6 for the
+    transposed one); a long major: major_cost alone."""
     lens = np.asarray(lens, dtype=np.int64)
-    mult = 1 if scattered is None else np.where(scattered, 2, 1)
-    return np.where(lens > long_limit, major_cost, lens * mult + (lens * np.minimum(lens, 64)) // 32 + major_cost)
+    return np.where(lens > long_limit, major_cost, lens + (lens * np.minimum(lens, 64)) // 32 + major_cost)
 
 
-def _scattered(beg, idx):
-    """pdlp_host.hpp slabMajorScattered: first and last minor of the major 2^17 or more apart"""
-    beg = np.asarray(beg, dtype=np.int64)
-    lens = np.diff(beg)
-    first = np.asarray(idx, dtype=np.int64)[np.minimum(beg[:-1], len(idx) - 1)]
-    last = np.asarray(idx, dtype=np.int64)[np.maximum(beg[1:] - 1, 0)]
-    return (lens >= 2) & (last - first >= (1 << 17))
-
-
-def _slab_partition_restated(beg, n_major, n_minor, long_limit, major_cost=2, scattered=None):
+def _slab_partition_restated(beg, n_major, n_minor, long_limit, major_cost=2):
     """pdlp_host.cpp slabPartition, restated: blocks, then the 16 waves of every block, filled one after the other by
     work = _slab_work."""
     lens = np.diff(beg)
-    cost = _slab_work(lens, long_limit, major_cost, scattered)
+    cost = _slab_work(lens, long_limit, major_cost)
     mb = max(int(np.ceil(np.log2(max(n_minor, 1)))), 4)
     wave_cap = min(1 << (32 - mb), 16384)
     block_cap = min(16384, wave_cap * 16)
@@ -233,12 +223,9 @@ def test_slab_layout_is_a_permutation_of_the_csr(which, long_limit):
     blk = wb[::16]
     assert np.all(np.diff(blk) >= 1) and np.max(np.diff(blk)) == sl["rows_per_block"] <= 16384
     # the partition is the restated rule, and it balances work: no block above the mean by more than one major's worth
-    # (scattered majors: only the operand by rows of a gathered vector beyond 2^19 entries — not this LP; the rule itself is
-    # exercised by test_slab_partition_counts_scattered_rows_twice)
-    sc = None
-    nb, mb, wb2 = _slab_partition_restated(beg, n_major, P.n if which == 0 else P.m, long_limit, 6 if which else 2, sc)
+    nb, mb, wb2 = _slab_partition_restated(beg, n_major, P.n if which == 0 else P.m, long_limit, 6 if which else 2)
     assert nb == sl["n_blocks"] and mb == sl["minor_bits"] and np.array_equal(wb2, wb)
-    cost = _slab_work(lens, long_limit, 6 if which else 2, sc)
+    cost = _slab_work(lens, long_limit, 6 if which else 2)
     work = np.add.reduceat(cost, blk[:-1])
     assert work.max() <= work.mean() + cost.max()
     # a wave's entries are those of its majors
@@ -247,37 +234,6 @@ def test_slab_layout_is_a_permutation_of_the_csr(which, long_limit):
     # inside a wave the key (slab, local major, minor) ascends
     key = (wave << 52) | ((mnr >> W) << 40) | ((maj - wb[wave]) << 28) | (mnr & ((1 << W) - 1))
     assert np.all(np.diff(key) > 0)
-
-
-def test_slab_partition_counts_scattered_rows_twice():
-    """The operand by rows of an LP with more than 2^19 columns: rows whose first and last column are 2^17 or more apart
-    count their entries twice (their gathers leave the part of x the block works in); the product's block boundaries are
-    the restated rule's.  600 000 columns, banded rows + a tail of rows with random columns."""
-    rng = np.random.default_rng(5)
-    n, m_band, m_tail = 600000, 6000, 300
-    rows, cols = [], []
-    for i in range(m_band):
-        c0 = int(i * (n - 64) / m_band)
-        cols += sorted(rng.choice(np.arange(c0, c0 + 64), size=6, replace=False)); rows += [i] * 6
-    for i in range(m_band, m_band + m_tail):
-        cols += sorted(rng.choice(n, size=10, replace=False)); rows += [i] * 10
-    m = m_band + m_tail
-    r_start = np.searchsorted(np.array(rows), np.arange(m + 1))
-    inf = float("inf")
-    lp = L.HighsLp.from_rowwise(n, m, r_start, cols, rng.standard_normal(len(cols)), col_cost=np.ones(n), col_lower=np.zeros(n),
-                                col_upper=np.ones(n), row_lower=np.full(m, -inf), row_upper=np.ones(m))
-    P = solver.Prepared(lp, pdlp_features_off=1)
-    sl = P.slab_layout(0)
-    sc = _scattered(P.csr_beg, P.csr_idx)
-    assert 250 < sc.sum() < 400
-    nb, mb, wb = _slab_partition_restated(P.csr_beg, P.m, P.n, 256, 2, sc)
-    assert nb == sl["n_blocks"] and np.array_equal(wb, sl["wave_beg"])
-    nb0, _, wb0 = _slab_partition_restated(P.csr_beg, P.m, P.n, 256, 2, None)
-    assert not np.array_equal(wb0, wb)  # the rule moved boundaries
-    # the transposed operand does not use it
-    slt = P.slab_layout(1)
-    nbt, _, wbt = _slab_partition_restated(P.csc_beg, P.n, P.m, 256, 6, None)
-    assert nbt == slt["n_blocks"] and np.array_equal(wbt, slt["wave_beg"])
 
 
 def test_slab_partition_balances_skewed_majors():
