@@ -433,9 +433,9 @@ int32_t bitsFor(int64_t count) {  // smallest b with 2^b >= count
   return b;
 }
 // Fills `units` consecutive ranges of [r0, r1) by work (see SlabPartition): out[0..units] boundaries.
-void fillByWork(const int32_t* beg, int32_t longLimit, int32_t majorCost, int32_t r0, int32_t r1, int32_t units, int64_t cap, bool nonEmpty,
+void fillByWork(const int32_t* beg, const int32_t* cold, int32_t longLimit, int32_t majorCost, int32_t r0, int32_t r1, int32_t units, int64_t cap, bool nonEmpty,
                 int32_t* out) {
-  auto cost = [&](int32_t r) -> int64_t { return slabMajorWork(beg[r + 1] - beg[r], longLimit, majorCost); };
+  auto cost = [&](int32_t r) -> int64_t { return slabMajorWork(beg[r + 1] - beg[r], cold ? cold[r] : 0, longLimit, majorCost); };
   int64_t rem = 0;
   for (int32_t r = r0; r < r1; ++r) rem += cost(r);
   int32_t r = r0;
@@ -458,9 +458,27 @@ void fillByWork(const int32_t* beg, int32_t longLimit, int32_t majorCost, int32_
 }
 }  // namespace
 
-int64_t slabMajorWork(int32_t len, int32_t longLimit, int32_t majorCost) {
+int64_t slabMajorWork(int32_t len, int32_t nCold, int32_t longLimit, int32_t majorCost) {
   if (len > longLimit) return majorCost;  // (its segment tasks run elsewhere)
-  return (int64_t)len + ((int64_t)len * std::min(len, 64)) / 32 + majorCost;
+  return (int64_t)len + nCold + ((int64_t)len * std::min(len, 64)) / 32 + majorCost;
+}
+
+void slabColdCounts(const int32_t* beg, const int32_t* idx, int32_t nMajor, int32_t nMinor, int32_t longLimit, int32_t* cold) {
+  std::vector<int32_t> count((size_t)std::max(nMinor, 1), 0);
+  const int64_t nnz = nMajor > 0 ? beg[nMajor] : 0;
+  for (int64_t p = 0; p < nnz; ++p) ++count[idx[p]];
+  for (int32_t r = 0; r < nMajor; ++r) {
+    const int32_t p0 = beg[r], len = beg[r + 1] - beg[r];
+    int32_t c = 0;
+    if (len >= 2 && len <= longLimit) {
+      const int32_t mid = idx[p0 + len / 2];
+      for (int32_t p = p0; p < p0 + len; ++p) {
+        const int32_t d = idx[p] > mid ? idx[p] - mid : mid - idx[p];
+        if (d >= kSlabFar && count[idx[p]] <= kSlabHotCount) ++c;
+      }
+    }
+    cold[r] = c;
+  }
 }
 
 bool slabFits(int32_t nMajor, int32_t nMinor) {
@@ -468,7 +486,8 @@ bool slabFits(int32_t nMajor, int32_t nMinor) {
   return bitsFor(nMinor) <= 28;  // at least 16 majors per wave
 }
 
-SlabPartition slabPartition(const int32_t* beg, int32_t nMajor, int32_t nMinor, int32_t longLimit, int32_t majorCost) {
+SlabPartition slabPartition(const int32_t* beg, const int32_t* cold, int32_t nMajor, int32_t nMinor, int32_t longLimit,
+                            int32_t majorCost) {
   SlabPartition P;
   if (!slabFits(nMajor, nMinor)) throw std::runtime_error("slab layout: minor index does not fit the entry packing");
   P.minorBits = std::max(bitsFor(nMinor), 4);
@@ -481,9 +500,9 @@ SlabPartition slabPartition(const int32_t* beg, int32_t nMajor, int32_t nMinor, 
   P.waveBeg.assign((size_t)nB * kSlabWavesPerBlock + 1, 0);
   if (nB == 0) return P;
   std::vector<int32_t> blockBeg((size_t)nB + 1);
-  fillByWork(beg, longLimit, majorCost, 0, nMajor, (int32_t)nB, blockCap, true, blockBeg.data());
+  fillByWork(beg, cold, longLimit, majorCost, 0, nMajor, (int32_t)nB, blockCap, true, blockBeg.data());
   for (int32_t b = 0; b < (int32_t)nB; ++b) {
-    fillByWork(beg, longLimit, majorCost, blockBeg[b], blockBeg[b + 1], kSlabWavesPerBlock, waveCap, false,
+    fillByWork(beg, cold, longLimit, majorCost, blockBeg[b], blockBeg[b + 1], kSlabWavesPerBlock, waveCap, false,
                P.waveBeg.data() + (size_t)b * kSlabWavesPerBlock);
     P.maxRowsPerBlock = std::max(P.maxRowsPerBlock, blockBeg[b + 1] - blockBeg[b]);
   }
@@ -493,7 +512,9 @@ SlabPartition slabPartition(const int32_t* beg, int32_t nMajor, int32_t nMinor, 
 void buildSlabLayout(const Compressed& csr, int32_t nMajor, int32_t nMinor, int32_t longLimit, int32_t slabWidthLog2,
                      int32_t majorCost, SlabLayout& out) {
   out = SlabLayout();
-  SlabPartition P = slabPartition(csr.beg.data(), nMajor, nMinor, longLimit, majorCost);
+  std::vector<int32_t> cold((size_t)std::max(nMajor, 1));
+  slabColdCounts(csr.beg.data(), csr.idx.data(), nMajor, nMinor, longLimit, cold.data());
+  SlabPartition P = slabPartition(csr.beg.data(), cold.data(), nMajor, nMinor, longLimit, majorCost);
   out.rowsPerBlock = P.maxRowsPerBlock;
   out.nBlocks = P.nBlocks;
   out.minorBits = P.minorBits;

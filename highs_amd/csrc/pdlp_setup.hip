@@ -577,13 +577,43 @@ void gpuPrepare(const pdlp_problem_t& P, bool doScale, hipStream_t s, DeviceProb
   for (double v : hb) D.sumRhs2 += v * v;
 }
 
+// pdlp_host.cpp slabColdCounts on the device: how many majors touch every minor, then the cold entries of every major
+__global__ void k_minor_count(const int32_t* __restrict__ idx, int64_t nnz, int32_t* count) {
+  GSTRIDE(p, nnz) atomicAdd(count + idx[p], 1);
+}
+__global__ void k_major_cold(const int32_t* __restrict__ beg, const int32_t* __restrict__ idx, const int32_t* __restrict__ count,
+                             int nMajor, int longLimit, int far, int hot, int32_t* cold) {
+  GSTRIDE(r, nMajor) {
+    const int p0 = beg[r], len = beg[r + 1] - beg[r];
+    int c = 0;
+    if (len >= 2 && len <= longLimit) {
+      const int mid = idx[p0 + len / 2];
+      for (int p = p0; p < p0 + len; ++p) {
+        const int j = idx[p];
+        const int d = j > mid ? j - mid : mid - j;
+        if (d >= far && count[j] <= hot) ++c;
+      }
+    }
+    cold[r] = c;
+  }
+}
+
 void gpuSlabPartition(const DeviceCsrData& M, int32_t longLimit, int32_t majorCost, hipStream_t s, DeviceSlabLayout& L) {
   // the partition by work is sequential and cheap: on the host, from the major starts (4 bytes per major over PCIe),
   // by the same function the host-side build uses
-  std::vector<int32_t> hb((size_t)M.nMajor + 1);
+  std::vector<int32_t> hb((size_t)M.nMajor + 1), hc((size_t)std::max(M.nMajor, 1), 0);
+  DeviceArray<int32_t> count, cold;
+  count.alloc((size_t)std::max(M.nMinor, 1));
+  cold.alloc(hc.size());
+  count.zero(s);
+  if (M.nnz > 0) hipLaunchKernelGGL(k_minor_count, dim3(gridFor(M.nnz)), dim3(kT), 0, s, M.idx.get(), M.nnz, count.get());
+  if (M.nMajor > 0)
+    hipLaunchKernelGGL(k_major_cold, dim3(gridFor(M.nMajor)), dim3(kT), 0, s, M.beg.get(), M.idx.get(), count.get(), M.nMajor, longLimit,
+                       kSlabFar, kSlabHotCount, cold.get());
   M.beg.download(hb.data(), hb.size(), s);
+  if (M.nMajor > 0) cold.download(hc.data(), (size_t)M.nMajor, s);
   PDLP_HIP(hipStreamSynchronize(s));
-  SlabPartition P = slabPartition(hb.data(), M.nMajor, M.nMinor, longLimit, majorCost);
+  SlabPartition P = slabPartition(hb.data(), hc.data(), M.nMajor, M.nMinor, longLimit, majorCost);
   L.rowsPerBlock = P.maxRowsPerBlock;
   L.nBlocks = P.nBlocks;
   L.minorBits = P.minorBits;

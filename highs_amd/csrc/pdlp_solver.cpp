@@ -120,7 +120,9 @@ void DeviceMatrix::upload(const Compressed& cIn, int32_t nMajor_, int32_t nMinor
   const Compressed* c = &cIn;
   SlabLayout L;
   if (useSlab) {
-    const SlabPartition part = slabPartition(cIn.beg.data(), nMajor_, nMinor_, kSlabLongLimit, majorCost);
+    std::vector<int32_t> cold((size_t)std::max(nMajor_, 1));
+    slabColdCounts(cIn.beg.data(), cIn.idx.data(), nMajor_, nMinor_, kSlabLongLimit, cold.data());
+    const SlabPartition part = slabPartition(cIn.beg.data(), cold.data(), nMajor_, nMinor_, kSlabLongLimit, majorCost);
     const int32_t nB = part.nBlocks;
     std::vector<int32_t> lo((size_t)nB, INT_MAX), hi((size_t)nB, -1), cnt((size_t)nB, 0);
     for (int32_t b = 0; b < nB; ++b)

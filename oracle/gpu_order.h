@@ -17,7 +17,7 @@ enum { G_T = 256, G_WAVE = 64, G_CHUNK = 2048, G_CHUNK_SMALL = 512, G_MAXMAJ = 2
 static inline int g_chunk_for(long nnz) { return nnz < (1L << 18) ? G_CHUNK_SMALL : G_CHUNK; }
 /* slab SpMV (k_spmv_slab): 1024-thread blocks of 16 waves.  The majors are dealt to blocks (and, inside a block, to its
  * waves — which does not matter for any sum) by WORK: pdlp_host.cpp slabPartition, restated here.  Work of a major of len
- * entries = len + len * min(len, 64) / 32 + majorCost (integer division; majorCost alone for a long major, whose segment
+ * entries = len + its cold entries (g_slab_cold) + len * min(len, 64) / 32 + majorCost (integer division; majorCost alone for a long major, whose segment
  * tasks run elsewhere; majorCost = 2 for the operand by rows, 6 for the transposed one, whose launch also carries the
  * next primal step of every column).  nBlocks = ceil(nMajor / 256) capped at 256 (more only when 256 blocks of 16384 majors do not hold the
  * operand); block b takes majors while it is closer to ceil(work left / blocks left) with the next major than without,
@@ -29,7 +29,25 @@ static inline int g_slab_fits(int nMajor, int nMinor) { /* the minor index must 
   return (long)nMinor <= (1L << 28);
 }
 /* blockBeg[0..nBlocks] (caller provides room for G_SLAB_BLOCKS + nMajor / G_SLAB_BLOCK_CAP + 2 ints); returns nBlocks */
-static inline int g_slab_blocks(const int* beg, int nMajor, int nMinor, int longLimit, int majorCost, int* blockBeg) {
+/* cold entries of every major (pdlp_host.cpp slabColdCounts): 2^17 or more minors away from the major's middle entry, in a
+ * minor that at most 64 majors touch; they count twice.  cold: caller's scratch of nMajor ints, count: of nMinor ints */
+static inline void g_slab_cold(const int* beg, const int* idx, int nMajor, int nMinor, int longLimit, int* cold, int* count) {
+  for (int j = 0; j < nMinor; ++j) count[j] = 0;
+  for (long p = 0; p < (nMajor > 0 ? beg[nMajor] : 0); ++p) count[idx[p]]++;
+  for (int r = 0; r < nMajor; ++r) {
+    const int p0 = beg[r], len = beg[r + 1] - beg[r];
+    int c = 0;
+    if (len >= 2 && len <= longLimit) {
+      const int mid = idx[p0 + len / 2];
+      for (int p = p0; p < p0 + len; ++p) {
+        const int d = idx[p] > mid ? idx[p] - mid : mid - idx[p];
+        if (d >= (1 << 17) && count[idx[p]] <= 64) ++c;
+      }
+    }
+    cold[r] = c;
+  }
+}
+static inline int g_slab_blocks(const int* beg, const int* cold, int nMajor, int nMinor, int longLimit, int majorCost, int* blockBeg) {
   int mb = 0;
   while ((1L << mb) < (long)nMinor) ++mb;
   if (mb < 4) mb = 4;
@@ -40,9 +58,9 @@ static inline int g_slab_blocks(const int* beg, int nMajor, int nMinor, int long
   long nB = ((long)nMajor + G_SLAB_MIN_ROWS - 1) / G_SLAB_MIN_ROWS;
   if (nB > G_SLAB_BLOCKS) nB = G_SLAB_BLOCKS;
   if (nB < ((long)nMajor + cap - 1) / cap) nB = ((long)nMajor + cap - 1) / cap;
-#define G_WORK(len) ((len) > longLimit ? (long)majorCost : (long)(len) + ((long)(len) * ((len) < 64 ? (len) : 64)) / 32 + majorCost)
+#define G_WORK(r, len) ((len) > longLimit ? (long)majorCost : (long)(len) + cold[r] + ((long)(len) * ((len) < 64 ? (len) : 64)) / 32 + majorCost)
   long rem = 0;
-  for (int r = 0; r < nMajor; ++r) { const int len = beg[r + 1] - beg[r]; rem += G_WORK(len); }
+  for (int r = 0; r < nMajor; ++r) { const int len = beg[r + 1] - beg[r]; rem += G_WORK(r, len); }
   int r = 0;
   blockBeg[0] = 0;
   for (long u = 0; u < nB; ++u) {
@@ -54,7 +72,7 @@ static inline int g_slab_blocks(const int* beg, int nMajor, int nMinor, int long
     long acc = 0, cnt = 0;
     while (cnt < rows && cnt < maxRows) {
       const int len = beg[r + 1] - beg[r];
-      const long c = G_WORK(len);
+      const long c = G_WORK(r, len);
       if (cnt >= minRows && 2 * acc + c > 2 * target) break;
       acc += c; ++r; ++cnt;
     }

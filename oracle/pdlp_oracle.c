@@ -486,17 +486,29 @@ static void g_setup(Work* w, int layoutMode) {
   w->chunkA = w->slabA ? G_SLAB_LONG : g_chunk_for(w->nnz);
   w->chunkAt = w->slabAt ? G_SLAB_LONG : g_chunk_for(w->nnz);
   /* slab layout: planA / planAt / planQ hold the block boundaries of the work partition, nPlan* = -(number of blocks) */
-  if (w->slabA) { w->planA = ialloc(G_SLAB_BLOCKS + m / G_SLAB_BLOCK_CAP + 3); w->nPlanA = -g_slab_blocks(w->csrBeg, m, n, w->chunkA, G_SLAB_MAJOR_COST_ROWS, w->planA); }
+  int* gCold = ialloc((long)(n > m ? n : m) + 1);
+  int* gCount = ialloc((long)(n > m ? n : m) + 1);
+  if (w->slabA) {
+    g_slab_cold(w->csrBeg, w->csrIdx, m, n, w->chunkA, gCold, gCount);
+    w->planA = ialloc(G_SLAB_BLOCKS + m / G_SLAB_BLOCK_CAP + 3); w->nPlanA = -g_slab_blocks(w->csrBeg, gCold, m, n, w->chunkA, G_SLAB_MAJOR_COST_ROWS, w->planA);
+  }
   else w->planA = g_plan(w->csrBeg, m, w->chunkA, &w->nPlanA);
-  if (w->slabAt) { w->planAt = ialloc(G_SLAB_BLOCKS + n / G_SLAB_BLOCK_CAP + 3); w->nPlanAt = -g_slab_blocks(w->cssBeg, n, m, w->chunkAt, G_SLAB_MAJOR_COST_COLS, w->planAt); }
+  if (w->slabAt) {
+    g_slab_cold(w->cssBeg, w->cssIdx, n, m, w->chunkAt, gCold, gCount);
+    w->planAt = ialloc(G_SLAB_BLOCKS + n / G_SLAB_BLOCK_CAP + 3); w->nPlanAt = -g_slab_blocks(w->cssBeg, gCold, n, m, w->chunkAt, G_SLAB_MAJOR_COST_COLS, w->planAt);
+  }
   else w->planAt = g_plan(w->cssBeg, n, w->chunkAt, &w->nPlanAt);
   if (w->qnBeg) { /* N gathers x (n), majors = n */
     w->slabQ = layoutMode == 2 || (layoutMode == 0 && n >= G_SLAB_AUTO_MINOR);
     if (w->slabQ && (n <= 0 || !g_slab_fits(n, n))) w->slabQ = 0;
     w->chunkQ = w->slabQ ? G_SLAB_LONG : g_chunk_for(w->qnBeg[n]);
-    if (w->slabQ) { w->planQ = ialloc(G_SLAB_BLOCKS + n / G_SLAB_BLOCK_CAP + 3); w->nPlanQ = -g_slab_blocks(w->qnBeg, n, n, w->chunkQ, G_SLAB_MAJOR_COST_ROWS, w->planQ); }
+    if (w->slabQ) {
+      g_slab_cold(w->qnBeg, w->qnIdx, n, n, w->chunkQ, gCold, gCount);
+      w->planQ = ialloc(G_SLAB_BLOCKS + n / G_SLAB_BLOCK_CAP + 3); w->nPlanQ = -g_slab_blocks(w->qnBeg, gCold, n, n, w->chunkQ, G_SLAB_MAJOR_COST_ROWS, w->planQ);
+    }
     else w->planQ = g_plan(w->qnBeg, n, w->chunkQ, &w->nPlanQ);
   }
+  free(gCold); free(gCount);
   const long mx = 2L * (n > m ? n : m) + G_MAXGRID + 8;
   w->gPartA = dalloc(mx); w->gPartB = dalloc(mx); w->gStat = dalloc(mx);
 }

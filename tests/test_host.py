@@ -149,18 +149,31 @@ def _slab_to_coo(sl, n_major):
     return majors, minors, val, wave
 
 
-def _slab_work(lens, long_limit, major_cost=2):
-    """pdlp_host.cpp slabMajorWork: entries + the run-accumulation term + major_cost (2 for the operand by rows, 6 for the
-    transposed one); a long major: major_cost alone."""
+def _slab_work(lens, long_limit, major_cost=2, cold=0):
+    """pdlp_host.cpp slabMajorWork: entries + cold entries + the run-accumulation term + major_cost (2 for the operand by
+    rows, 6 for the transposed one); a long major: major_cost alone."""
     lens = np.asarray(lens, dtype=np.int64)
-    return np.where(lens > long_limit, major_cost, lens + (lens * np.minimum(lens, 64)) // 32 + major_cost)
+    return np.where(lens > long_limit, major_cost, lens + cold + (lens * np.minimum(lens, 64)) // 32 + major_cost)
 
 
-def _slab_partition_restated(beg, n_major, n_minor, long_limit, major_cost=2):
+def _cold_counts(beg, idx, n_minor, long_limit):
+    """pdlp_host.cpp slabColdCounts: entries 2^17 or more minors away from the major's middle entry, in a minor that at
+    most 64 majors touch."""
+    beg = np.asarray(beg, dtype=np.int64)
+    idx = np.asarray(idx, dtype=np.int64)
+    lens = np.diff(beg)
+    count = np.bincount(idx, minlength=max(n_minor, 1))
+    rows = np.repeat(np.arange(len(lens)), lens)
+    mid = idx[np.minimum(beg[:-1] + lens // 2, max(len(idx) - 1, 0))] if len(idx) else np.zeros(len(lens), np.int64)
+    is_cold = (np.abs(idx - mid[rows]) >= (1 << 17)) & (count[idx] <= 64) & ((lens >= 2) & (lens <= long_limit))[rows]
+    return np.bincount(rows[is_cold], minlength=len(lens)).astype(np.int64)
+
+
+def _slab_partition_restated(beg, n_major, n_minor, long_limit, major_cost=2, cold=0):
     """pdlp_host.cpp slabPartition, restated: blocks, then the 16 waves of every block, filled one after the other by
     work = _slab_work."""
     lens = np.diff(beg)
-    cost = _slab_work(lens, long_limit, major_cost)
+    cost = _slab_work(lens, long_limit, major_cost, cold)
     mb = max(int(np.ceil(np.log2(max(n_minor, 1)))), 4)
     wave_cap = min(1 << (32 - mb), 16384)
     block_cap = min(16384, wave_cap * 16)
@@ -223,9 +236,10 @@ def test_slab_layout_is_a_permutation_of_the_csr(which, long_limit):
     blk = wb[::16]
     assert np.all(np.diff(blk) >= 1) and np.max(np.diff(blk)) == sl["rows_per_block"] <= 16384
     # the partition is the restated rule, and it balances work: no block above the mean by more than one major's worth
-    nb, mb, wb2 = _slab_partition_restated(beg, n_major, P.n if which == 0 else P.m, long_limit, 6 if which else 2)
+    cold = _cold_counts(beg, idx, P.n if which == 0 else P.m, long_limit)
+    nb, mb, wb2 = _slab_partition_restated(beg, n_major, P.n if which == 0 else P.m, long_limit, 6 if which else 2, cold)
     assert nb == sl["n_blocks"] and mb == sl["minor_bits"] and np.array_equal(wb2, wb)
-    cost = _slab_work(lens, long_limit, 6 if which else 2)
+    cost = _slab_work(lens, long_limit, 6 if which else 2, cold)
     work = np.add.reduceat(cost, blk[:-1])
     assert work.max() <= work.mean() + cost.max()
     # a wave's entries are those of its majors
@@ -234,6 +248,41 @@ def test_slab_layout_is_a_permutation_of_the_csr(which, long_limit):
     # inside a wave the key (slab, local major, minor) ascends
     key = (wave << 52) | ((mnr >> W) << 40) | ((maj - wb[wave]) << 28) | (mnr & ((1 << W) - 1))
     assert np.all(np.diff(key) > 0)
+
+
+def test_slab_partition_counts_cold_entries_twice():
+    """Rows of random columns at the end of a banded matrix (the tail of bench.py --config c in small): their entries are
+    2^17 or more columns away from the row's middle entry, in columns almost nobody else touches — cold gathers — and count
+    twice; entries just as far away but in columns that many rows touch (a dense column) do not.  The product's partition is
+    the restated rule's, on both operands."""
+    rng = np.random.default_rng(5)
+    n, m_band, m_tail = 600000, 6000, 300
+    rows, cols = [], []
+    for i in range(m_band):
+        c0 = int(i * (n - 64) / m_band)
+        cc = sorted(rng.choice(np.arange(c0 + 1, c0 + 64), size=6, replace=False))
+        if i % 10 == 0:
+            cc = sorted(set(cc) | {0 if c0 > n // 2 else n - 1})  # a far entry in one of two DENSE columns: hot
+        cols += cc; rows += [i] * len(cc)
+    for i in range(m_band, m_band + m_tail):
+        cols += sorted(rng.choice(n, size=10, replace=False)); rows += [i] * 10
+    m = m_band + m_tail
+    r_start = np.searchsorted(np.array(rows), np.arange(m + 1))
+    inf = float("inf")
+    lp = L.HighsLp.from_rowwise(n, m, r_start, cols, rng.standard_normal(len(cols)), col_cost=np.ones(n), col_lower=np.zeros(n),
+                                col_upper=np.ones(n), row_lower=np.full(m, -inf), row_upper=np.ones(m))
+    P = solver.Prepared(lp, pdlp_features_off=1)
+    for which in (0, 1):
+        beg, idx = (P.csr_beg, P.csr_idx) if which == 0 else (P.csc_beg, P.csc_idx)
+        n_major, n_minor = (P.m, P.n) if which == 0 else (P.n, P.m)
+        sl = P.slab_layout(which)
+        cold = _cold_counts(beg, idx, n_minor, 256)
+        if which == 0:
+            assert cold[:m_band].sum() == 0 and 1000 < cold[m_band:].sum() <= 3000  # the tail's entries, not the dense columns'
+        nb, mb, wb = _slab_partition_restated(beg, n_major, n_minor, 256, 6 if which else 2, cold)
+        assert nb == sl["n_blocks"] and np.array_equal(wb, sl["wave_beg"])
+        if which == 0:
+            assert not np.array_equal(_slab_partition_restated(beg, n_major, n_minor, 256, 2, 0)[2], wb)  # the rule moved boundaries
 
 
 def test_slab_partition_balances_skewed_majors():
