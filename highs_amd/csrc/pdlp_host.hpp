@@ -132,25 +132,28 @@ constexpr int32_t kSlabMinRowsPerBlock = 256;
 // ~10, most of them behind the grid barrier) differ: with one value for both, config d lost 3 us on one launch or the other
 constexpr int32_t kSlabMajorCostRows = 2, kSlabMajorCostCols = 6;
 
-// The partition of the majors over blocks and waves.  Work of a major of len entries = len + (its cold entries) +
-// len * min(len, 64) / 32 + majorCost (the epilogue: kSlabMajorCostRows / Cols), majorCost alone for a long major: the entries of a run of equal majors inside a 64-entry
-// group are added by ONE lane, so a group made of one run of 64 costs about three times a group of eight runs of
-// eight (config d, blocks of equal ENTRY counts: the block with the longest rows still streamed 1.66x the mean time).
+// The partition of the majors over blocks and waves.  Work of a major of len entries =
+//     len + cold + len * min(len, 64) / 32 + majorCost            (majorCost alone for a long major)
+//   * len * min(len, 64) / 32: the entries of a run of equal majors inside a 64-entry group are added by ONE lane, so a
+//     group made of one run of 64 costs about three times a group of eight runs of eight (config d, blocks of equal ENTRY
+//     counts: the block with the longest rows still streamed 1.66x the mean time);
+//   * cold: its COLD entries count twice.  Cold = kSlabFar or more minors away from the major's middle entry AND in a
+//     minor that at most kSlabHotCount majors touch: the gather leaves the part of the gathered vector the block works in
+//     and meets nobody else's (config c: the block that owns 512 rows of 12 random columns ended 7 us after the others).
+//     Far entries in minors that many majors touch — the dense columns of config d, the dense rows of config c seen from
+//     its columns — are the hottest lines of the vector and cost nothing extra (a span-only rule measured worse there:
+//     profiles/r05_development_measurements.md section 4);
+//   * majorCost: the epilogue, kSlabMajorCostRows / Cols above.
 // nBlocks = ceil(nMajor / 256) capped at 256 (more only when 256 blocks of 16384 majors do not hold the operand).
 // Blocks are filled one after the other: block b takes majors while it is closer to ceil(work left / blocks left)
 // with the next major than without, but at least one, at most kSlabBlockRowCap, and never so few / many that the
 // blocks behind it could not hold / would not get the rest; the 16 waves of a block are filled the same way from the
 // block's majors (cap: 2^(32 - minorBits) majors, the local-major field of an entry).  Sequential and exact in
-// integers: the device-side set-up (pdlp_setup.hip) calls this same function on the downloaded major starts,
-// oracle/gpu_order.h restates it.
-// + nCold: the major's COLD entries count twice.  Cold = kSlabFar or more minors away from the major's middle entry AND
-// in a minor that at most kSlabHotCount majors touch: its gather leaves the part of the gathered vector the block works
-// in and meets nobody else's (config c: the block that owns 512 rows of 12 random columns ended 7 us after the others).
-// Far entries in minors that many majors touch — the dense columns of config d, the dense rows of config c seen from its
-// columns — are the hottest lines of the vector and cost nothing extra (a span-only rule measured worse there, r05 section 4).
+// integers: the device-side set-up (pdlp_setup.hip) counts the cold entries with two small kernels, downloads them
+// with the major starts (8 bytes per major) and calls this same function; oracle/gpu_order.h restates it.
 int64_t slabMajorWork(int32_t len, int32_t nCold, int32_t longLimit, int32_t majorCost);
 constexpr int32_t kSlabFar = 1 << 17, kSlabHotCount = 64;
-// cold[r] for every major (minorCount: scratch of nMinor entries, filled here)
+// cold[r] for every major r (0 for long and single-entry majors)
 void slabColdCounts(const int32_t* beg, const int32_t* idx, int32_t nMajor, int32_t nMinor, int32_t longLimit, int32_t* cold);
 struct SlabPartition {
   int32_t nBlocks = 0, minorBits = 0, maxRowsPerBlock = 0;
