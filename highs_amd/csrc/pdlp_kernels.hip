@@ -668,6 +668,17 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
   }
   epi.template finish<kSlabThreads>(blk, scratch);
   profStamp(1);
+  if (EPI == kAtyFused && !kFixEarly) {
+    // (the 64-register variant: the stream's pipeline registers are free now — the operands of the next primal step are
+    // fetched here, in flight across the grid barrier and the decision instead of behind them)
+#pragma unroll
+    for (int k = 0; k < kSlabPre; ++k) {
+      const int r0_ = rBase + tid + k * kSlabThreads;
+      const int r = r0_ < rEnd ? r0_ : rEnd - 1;
+      fix[k].a = ldStream(a.v.cost + r); fix[k].b = ldStream(a.v.lower + r); fix[k].c = ldStream(a.v.upper + r);
+      fix[k].d = ldStream(a.v.xSum + r); fix[k].e = a.v.qdiag ? ldStream(a.v.qdiag + r) : 0.0;
+    }
+  }
   if (EPI == kAtyFused && !TWO && a.inlineTasks) {  // (the 64-register variant carries task workgroups instead)
     // Long columns in the fused trial: their segment tasks cannot be extra workgroups (those would have to be resident
     // next to the waiting blocks), so the streaming blocks take them — task group tb goes to block tb % nBlocks, one
@@ -733,15 +744,6 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
       t = t > l ? t : l;
       xOut[r] = t;  // gathered by the A x+ kernel: ordinary store
     };
-    if (!kFixEarly) {
-#pragma unroll
-      for (int k = 0; k < kSlabPre; ++k) {
-        const int r0_ = rBase + tid + k * kSlabThreads;
-        const int r = r0_ < rEnd ? r0_ : rEnd - 1;
-        fix[k].a = ldStream(a.v.cost + r); fix[k].b = ldStream(a.v.lower + r); fix[k].c = ldStream(a.v.upper + r);
-        fix[k].d = ldStream(a.v.xSum + r); fix[k].e = a.v.qdiag ? ldStream(a.v.qdiag + r) : 0.0;
-      }
-    }
     // (a long column's A'y+ was computed by a segment task, maybe in another block: taken from memory, agent scope)
     auto isLong = [&](int lr) { return (a.inlineTasks || a.coTaskBlocks) && longMajor(rBase + lr); };
 #pragma unroll
