@@ -732,20 +732,25 @@ def test_concurrent_solver_contexts_on_two_threads():
 
 def test_fused_trial_keeps_long_columns(monkeypatch):
     """Dense columns in a slab-layout operand: the 2-launch fused trial used to be switched off by a single long column
-    (its segment tasks ran in extra workgroups that took no part in the grid barrier); now the streaming blocks run the
-    tasks themselves (SpmvArgs::inlineTasks).  Same lanes and sums: the bits of the 3-launch trial, and of the oracle."""
+    (its segment tasks ran in extra workgroups that took no part in the grid barrier).  Round 5: the 64-register variant
+    of the fused kernel carries them as co-resident task workgroups that arrive at its barrier; where two blocks per CU do
+    not fit (or with PDLP_MI355X_FUSED_COTASKS=0) the streaming blocks run the task passes themselves behind their stream
+    (round 4's form).  Same lanes and sums either way: the bits of the 3-launch trial, and of the oracle."""
     from lpgen import dense_column_lp
     lp = dense_column_lp(5, periods=40, rows_per=512, cols_per=448, dense_cols=16, dense_nnz=5000, tail_rows=128, tail_max=700)
     monkeypatch.setenv("PDLP_MI355X_SLAB", "1")
     monkeypatch.setenv("PDLP_MI355X_PERSISTENT", "0")
     out = {}
-    for fused in ("0", "1"):
+    for name, fused, cotasks in (("three", "0", "1"), ("inline", "1", "0"), ("cotasks", "1", "1")):
         monkeypatch.setenv("PDLP_MI355X_FUSED", fused)
-        out[fused] = _iterate_state(dict(lp=lp), 240)
-    assert out["0"][5] == 3 and out["1"][5] == 2, (out["0"][5], out["1"][5])
-    for a, b in zip(out["0"][:3], out["1"][:3]):
-        assert np.array_equal(a, b)
-    assert out["0"][3:5] == out["1"][3:5]
+        monkeypatch.setenv("PDLP_MI355X_FUSED_COTASKS", cotasks)
+        out[name] = _iterate_state(dict(lp=lp), 240)
+    assert out["three"][5] == 3 and out["inline"][5] == 2 and out["cotasks"][5] == 2, [o[5] for o in out.values()]
+    for name in ("inline", "cotasks"):
+        assert out[name][6] == 0, (name, "a barrier launch gave up")
+        for a, b in zip(out["three"][:3], out[name][:3]):
+            assert np.array_equal(a, b), name
+        assert out["three"][3:5] == out[name][3:5], name
 
 
 def _iterate_state(kw, iters):
