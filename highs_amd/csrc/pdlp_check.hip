@@ -89,6 +89,22 @@ __global__ __launch_bounds__(kVecThreads) void k_restart_vec(const IterVecs v, c
   restartVecBlock<false>(v, st->cur, kind, r, (int)blockIdx.x, partX, nbX, partY, nbY, scratch);
 }
 
+__global__ __launch_bounds__(kVecThreads) void k_restart_copy_full(const DevState* st, const CheckCtl* cc, double* x0, double* x1,
+                                                                   double* aty0, double* aty1, double* y0, double* y1,
+                                                                   const double* __restrict__ xAvg, const double* __restrict__ atyAvg,
+                                                                   const double* __restrict__ yAvg, int n, int yLen) {
+  if (!checkDue(st, cc)) return;
+  if (cc->restartKind != 2) return;
+  const int c = st->cur;
+  double* __restrict__ x = c ? x1 : x0;
+  double* __restrict__ aty = c ? aty1 : aty0;
+  double* __restrict__ y = c ? y1 : y0;
+  const int stride = gridDim.x * blockDim.x;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) { x[j] = xAvg[j]; aty[j] = atyAvg[j]; }
+  if (y)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < yLen; i += stride) y[i] = yAvg[i];
+}
+
 __global__ __launch_bounds__(kVecThreads) void k_restart_finish(DevState* st, CheckCtl* cc, const double* __restrict__ partX, int nbX,
                                                                 const double* __restrict__ partY, int nbY, CheckRecord* rec) {
   if (!checkDue(st, cc)) return;
@@ -397,6 +413,12 @@ void launchCheckDecide(DevState* st, CheckCtl* cc, const double* stat, CheckReco
 void launchRestartVec(const IterVecs& v, const DevState* st, const CheckCtl* cc, const RestartVecs& r, double* partX, int32_t nbX,
                       double* partY, int32_t nbY, hipStream_t s) {
   hipLaunchKernelGGL(k_restart_vec, dim3(nbX + nbY), dim3(kVecThreads), 0, s, v, st, cc, r, partX, nbX, partY, nbY);
+}
+void launchRestartCopyFull(const DevState* st, const CheckCtl* cc, double* const x[2], double* const aty[2], double* const yFull[2],
+                           const double* xAvg, const double* atyAvg, const double* yAvgFull, int32_t n, int32_t yLen, hipStream_t s) {
+  const int32_t len = n > yLen ? n : yLen;
+  hipLaunchKernelGGL(k_restart_copy_full, dim3(vecBlocks(len > 0 ? len : 1)), dim3(kVecThreads), 0, s, st, cc, x[0], x[1], aty[0], aty[1],
+                     yFull ? yFull[0] : (double*)nullptr, yFull ? yFull[1] : (double*)nullptr, xAvg, atyAvg, yAvgFull, n, yLen);
 }
 void launchRestartFinish(DevState* st, CheckCtl* cc, const double* partX, int32_t nbX, const double* partY, int32_t nbY,
                          CheckRecord* rec, hipStream_t s) {

@@ -378,6 +378,12 @@ struct RestartVecs {
 };
 void launchRestartVec(const IterVecs& v, const DevState* st, const CheckCtl* cc, const RestartVecs& r, double* partX, int32_t nbX,
                       double* partY, int32_t nbY, hipStream_t s);
+// Row-block sharded solve, restart to the average: launchRestartVec above works on a rank's own columns and rows; the
+// REPLICATED vectors (x and A'y full length on every rank; y too in the two-all-gathers layout) are copied whole here —
+// xAvg / atyAvg / yAvg are full length on every rank after the check's all-gathers.  No-op unless the check is due and
+// decided restartKind 2.
+void launchRestartCopyFull(const DevState* st, const CheckCtl* cc, double* const x[2], double* const aty[2], double* const yFull[2],
+                           const double* xAvg, const double* atyAvg, const double* yAvgFull, int32_t n, int32_t yLen, hipStream_t s);
 // Primal-weight update after a restart (PDHG_Compute_Step_Size_Ratio, cupdlp_step.c:147-176) from the two partial
 // arrays, then — restart or not — the next halt iteration of the reference's check schedule and the device runs on.
 void launchRestartFinish(DevState* st, CheckCtl* cc, const double* partX, int32_t nbX, const double* partY, int32_t nbY,

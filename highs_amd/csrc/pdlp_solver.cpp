@@ -554,7 +554,9 @@ void Solver::construct(const pdlp_problem_t& P, const void* id128) {
     if (checkSmall_) checkBar_.alloc((size_t)smallGrid_ + 8);
   }
   // check iterations on the device (single GPU; the sharded paths issue their check collectives from the host)
-  devCheck_ = !sharded_ && sw_.deviceCheck != 0;
+  // check iterations on the device: single GPU, and (round 5) the row-block sharded solve in the two-all-gathers layout of the
+  // mesh exchange — its check collectives are enqueued with the check's kernels instead of being driven from the host
+  devCheck_ = (!sharded_ || (meshMode_ && colblock_)) && sw_.deviceCheck != 0;
   reset();
   // the trial-batch graph is part of the setup, not of the first iterations
   if (useGraph_ && !persistent_ && (!sharded_ || meshMode_)) captureGraph();
@@ -1398,6 +1400,49 @@ void Solver::enqueueCheckDevice() {
     needPrimal_ = true;
     return;
   }
+  if (sharded_) {
+    // Row-block sharded (mesh exchange, two-all-gathers layout): the kernels of the host-driven check (computeAverage,
+    // computeResiduals, restartIterate) on this rank's rows and columns, gated like the single-GPU ones, with the SAME
+    // collectives in between — enqueued, not waited for.  The collectives themselves are never gated (their epochs are
+    // counted by the host on every rank alike): a check that is not due exchanges buffers nobody reads.  Every rank
+    // holds the same all-reduced statistics and norms, so every rank takes the same decisions (bit-identical state, as
+    // in the hot loop).
+    const int32_t nbM = vecBlocks(std::max(mLoc_, 1)), nbN = vecBlocks(std::max(nLoc_, 1));
+    const size_t co = (size_t)c0_;
+    const int sc = F_.scaled ? 1 : 0;
+    double* part = statPart_.get();
+    launchFlushScale(vecsCol_, g, 0, 0.0, 0.0, 1.0, 1.0, xAvg_.get() + co, yAvgl(), stream_);
+    mesh_->allGather(xAvg_.get(), false, stream_);
+    launchSpmvPlain(dA_.view(), xAvg_.get(), axAvg_.get(), stream_, g);
+    mesh_->allGather(yAvg_.get(), true, stream_);  // (yAvgl() = this rank's rows inside the full-length vector)
+    launchSpmvPlain(dAt_.view(), yAvg_.get(), atyAvg_.get() + co, stream_, g);
+    mesh_->allGather(atyAvg_.get(), false, stream_);
+    launchRowStats2(vecs_, g, 0, axAvg_.get(), yAvgl(), rowScale_.get(), sc, part + (size_t)kStatRowCur * statStride_, statStride_, nbM,
+                    stream_);
+    launchColStats2(vecsCol_, g, 0, atyAvg_.get() + co, xAvg_.get() + co, colScale_.get() + co, nullptr, sc, slackPos_.get() + co,
+                    slackNeg_.get() + co, slackPosAvg_.get() + co, slackNegAvg_.get() + co, part + (size_t)kStatColCur * statStride_,
+                    statStride_, nbN, stream_);
+    launchFinalReduce2(part, statStride_, 2 * kRowStats, nbM, 2 * kColStats, nbN, statOut_.get(), g, stream_);
+    mesh_->allReduceScalars(statOut_.get(), kStatTotal, stream_);
+    CheckRecord* rec = hostRing_ + (checkSeq_ % kRingSlots);
+    rec->ran = 0;
+    ++checkSeq_;
+    launchCheckDecide(st, dCtl_.get(), statOut_.get(), rec, stream_);
+    double* xs[2] = {x_[0].get(), x_[1].get()};
+    double* as[2] = {aty_[0].get(), aty_[1].get()};
+    double* ys[2] = {y_[0].get(), y_[1].get()};
+    launchRestartCopyFull(st, dCtl_.get(), xs, as, ys, xAvg_.get(), atyAvg_.get(), yAvg_.get(), F_.n, yLen_, stream_);
+    const RestartVecs rv{xAvg_.get() + co, yAvgl(), axAvg_.get(), atyAvg_.get() + co, nullptr, xLast_.get() + co, yLast_.get()};
+    launchRestartVec(vecsCol_, st, dCtl_.get(), rv, partDX_.get(), nbN, partRestartY_.get(), nbM, stream_);
+    // the two norms of the primal-weight update: this rank's partials -> one scalar each (reduceScalar's kernel) -> summed
+    // over the ranks in rank order -> k_restart_finish takes them as partial arrays of length one
+    double* norms = statOut_.get() + kStatTotal + 2;
+    launchFinalReduce(partDX_.get(), nbN, nbN, 1, norms, stream_);
+    launchFinalReduce(partRestartY_.get(), nbM, nbM, 1, norms + 1, stream_);
+    mesh_->allReduceScalars(norms, 2, stream_);
+    launchRestartFinish(st, dCtl_.get(), norms, 1, norms + 1, 1, rec, stream_);
+    return;
+  }
   if (!persistent_ && !fused_)  // 3-launch loop: the decision of the last trial may still be pending
     launchDecide(st, partDY_.get(), dA_.nPartials(), partDX_.get(), partInter_.get(), dAt_.nPartials(), nullptr, stream_, true,
                  hasQoff_ ? partQ_.get() : nullptr, hasQoff_ ? dQ_.nPartials() : 0);
@@ -1497,6 +1542,11 @@ void Solver::doSolveDevice(bool terminate, int32_t target) {
     }
     endBarrierRound(gate);
     syncState();
+    if (meshMode_) {  // (sharded: the exchange's error flag and the checksum guard of the replicated iterates, once per round)
+      mesh_->checkError(stream_);
+      mesh_->verifyReplicated(x_[s.cur].get(), F_.n, stream_);
+      if (colblock_) mesh_->verifyReplicated(y_[s.cur].get(), F_.m, stream_);
+    }
     processRecords(terminate, iterLim, logSinceHeader);
     bool over = false;  // a check of this round has ended the solve (everything queued behind it was a no-op)
     for (int64_t q = seq0; q < checkSeq_; ++q) over = over || (hostRing_[q % kRingSlots].ran && hostRing_[q % kRingSlots].terminated);
@@ -1516,7 +1566,10 @@ void Solver::doSolveDevice(bool terminate, int32_t target) {
     if (s.powRed && s.nTrials + 4096 >= s.powBase + s.powCount) pushState(false);
     // queue depth: ~25 ms of work, at most 16 units
     const double roundMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - roundBeg).count();
-    if (units > 0 && roundMs > 0.0) aheadMax = std::max(1, std::min(16, (int32_t)(25.0 * units / roundMs)));
+    // (sharded: every rank must queue the same units per round — the rounds end in collectives — so the depth does not
+    // follow this rank's clock there: 1, 2, 4, 4, ...)
+    if (sharded_) aheadMax = 4;
+    else if (units > 0 && roundMs > 0.0) aheadMax = std::max(1, std::min(16, (int32_t)(25.0 * units / roundMs)));
     ahead = std::min(ahead * 2, aheadMax);
   }
   downloadCtl();
