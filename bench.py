@@ -402,6 +402,8 @@ def main():
                    "options": "presolve=off, kkt_tolerance=1e-4, adaptive step + restarts (reference defaults)"},
         "trial_steps": int(st.trials), "rejected_trials": int(st.trials - st.iters), "checks": int(st.checks),
         "trial_launches": int(S.stage("trial_launches")[0]) if args.solver == "pdlp" else 2,
+        # launches of one check iteration queued behind the trial batches (0: the host drives the checks and waits for them)
+        "check_launches": int(S.stage("check_launches")[0]) if args.solver == "pdlp" else None,
         "restarts": int(st.restarts), "setup_seconds": t_setup, "ranks_bit_identical": rank_consistent,
         "exchange_fallback": exchange_fallback, "exchange": exchange if world > 1 else None, "exchange_waits": exchange_waits,
         "startup_ms_first_40": startup_ms,

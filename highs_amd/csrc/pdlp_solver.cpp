@@ -1850,8 +1850,9 @@ void Solver::stage(const std::string& name, double* out, int32_t cap) {
     put(0, meshMode_ ? (colblock_ ? 10.0 - 2.0 * fw : 9.0 - fw) : sharded_ ? 7.0 : persistent_ ? 0.0 : fused_ ? 2.0 : 3.0);  // 0: one persistent launch per batch
   } else if (name == "trial_barriers") {  // grid barriers per trial of the persistent loop (0: no persistent loop)
     put(0, !persistent_ ? 0.0 : primalInA_ ? 2.0 : 3.0);
-  } else if (name == "check_launches") {  // kernels of one device-driven check iteration (1: the one-launch form of small LPs)
-    put(0, !devCheck_ ? 0.0 : persistent_ && checkSmall_ ? 1.0 : 10.0);
+  } else if (name == "check_launches") {  // kernels of one device-driven check iteration (1: the one-launch form of small LPs;
+    // sharded: 12 gated kernels + three all-gathers of 4 launches + two scalar all-reduces; 0: the host drives the checks)
+    put(0, !devCheck_ ? 0.0 : sharded_ ? 26.0 : persistent_ && checkSmall_ ? 1.0 : 10.0);
   } else if (name == "barrier_fallbacks") {  // times a launch with grid barriers gave up and the loop went on with plain launches
     put(0, (double)barrierFallbacks_);
   } else if (name == "exchange") {  // 0 = not sharded, 1 = RCCL all-reduce, 2 = direct xGMI mesh (partials), 3 = mesh, two all-gathers

@@ -36,6 +36,7 @@ def test_bench_two_ranks_one_device(world, solver_name):
     assert w["waits"][0] > 0 and w["waits"][1] > 0 and w["X_allgather_x"] > 0 and w["P_reduce_scatter_aty"] > 0
     if solver_name == "pdlp":
         assert w["waits"][2] > 0 and w["S_scalars"] > 0
+        assert d["check_launches"] == 26  # the checks of the sharded solve run on the device, collectives enqueued with them
 
 
 def test_bench_rccl_exchange_when_two_devices_are_visible():
