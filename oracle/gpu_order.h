@@ -23,7 +23,7 @@ static inline int g_chunk_for(long nnz) { return nnz < (1L << 18) ? G_CHUNK_SMAL
  * operand); block b takes majors while it is closer to ceil(work left / blocks left) with the next major than without,
  * at least one and at most 16384, and never so few / many that the blocks behind it could not hold / would not get the
  * rest. */
-enum { G_SLAB_T = 1024, G_SLAB_WAVES = 16, G_SLAB_BLOCKS = 256, G_SLAB_BLOCK_CAP = 16384, G_SLAB_MIN_ROWS = 256, G_SLAB_MAJOR_COST_ROWS = 2, G_SLAB_MAJOR_COST_COLS = 6 };
+enum { G_SLAB_T = 1024, G_SLAB_WAVES = 16, G_SLAB_BLOCKS = 256, G_SLAB_BLOCK_CAP = 16384, G_SLAB_MIN_ROWS = 256, G_SLAB_MAJOR_COST_ROWS = 2, G_SLAB_MAJOR_COST_COLS = 10 };
 static inline int g_slab_fits(int nMajor, int nMinor) { /* the minor index must fit 28 bits of an entry */
   (void)nMajor;
   return (long)nMinor <= (1L << 28);

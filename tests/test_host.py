@@ -237,9 +237,9 @@ def test_slab_layout_is_a_permutation_of_the_csr(which, long_limit):
     assert np.all(np.diff(blk) >= 1) and np.max(np.diff(blk)) == sl["rows_per_block"] <= 16384
     # the partition is the restated rule, and it balances work: no block above the mean by more than one major's worth
     cold = _cold_counts(beg, idx, P.n if which == 0 else P.m, long_limit)
-    nb, mb, wb2 = _slab_partition_restated(beg, n_major, P.n if which == 0 else P.m, long_limit, 6 if which else 2, cold)
+    nb, mb, wb2 = _slab_partition_restated(beg, n_major, P.n if which == 0 else P.m, long_limit, 10 if which else 2, cold)
     assert nb == sl["n_blocks"] and mb == sl["minor_bits"] and np.array_equal(wb2, wb)
-    cost = _slab_work(lens, long_limit, 6 if which else 2, cold)
+    cost = _slab_work(lens, long_limit, 10 if which else 2, cold)
     work = np.add.reduceat(cost, blk[:-1])
     assert work.max() <= work.mean() + cost.max()
     # a wave's entries are those of its majors
@@ -279,7 +279,7 @@ def test_slab_partition_counts_cold_entries_twice():
         cold = _cold_counts(beg, idx, n_minor, 256)
         if which == 0:
             assert cold[:m_band].sum() == 0 and 1000 < cold[m_band:].sum() <= 3000  # the tail's entries, not the dense columns'
-        nb, mb, wb = _slab_partition_restated(beg, n_major, n_minor, 256, 6 if which else 2, cold)
+        nb, mb, wb = _slab_partition_restated(beg, n_major, n_minor, 256, 10 if which else 2, cold)
         assert nb == sl["n_blocks"] and np.array_equal(wb, sl["wave_beg"])
         if which == 0:
             assert not np.array_equal(_slab_partition_restated(beg, n_major, n_minor, 256, 2, 0)[2], wb)  # the rule moved boundaries
