@@ -129,7 +129,8 @@ constexpr int32_t kSlabBlockRowCap = 16384; // majors per block: 128 KB of LDS a
 constexpr int32_t kSlabMinRowsPerBlock = 256;
 // work of a major besides its entries, in entries: its epilogue.  The operand by rows (A x+: dual step, ~7 vector
 // loads and stores per row) and the transposed one (A'y+ with the interaction sums AND the next primal step of the column:
-// ~10, most of them behind the grid barrier) differ: with one value for both, config d lost 3 us on one launch or the other
+// ~10, most of them behind the grid barrier) differ: with one value for both, config d lost 3 us on one launch or the
+// other; 6 / 10 / 16 for the transposed operand: config d 72.3 / 70.6-71.0 / 71.4 us per iteration, config c unchanged
 constexpr int32_t kSlabMajorCostRows = 2, kSlabMajorCostCols = 10;
 
 // The partition of the majors over blocks and waves.  Work of a major of len entries =
