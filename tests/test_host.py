@@ -285,6 +285,34 @@ def test_slab_partition_counts_cold_entries_twice():
             assert not np.array_equal(_slab_partition_restated(beg, n_major, n_minor, 256, 2, 0)[2], wb)  # the rule moved boundaries
 
 
+@pytest.mark.parametrize("shape", [(40, 300, 900, 1), (300, 40, 900, 2), (5000, 70000, 30000, 3), (70000, 5000, 140000, 4),
+                                   (1200, 1200, 200000, 5)])
+def test_slab_partition_edge_shapes(shape):
+    """Few majors (one or two blocks, empty waves), far more majors than entries (empty majors, blocks at their minimum
+    size), dense-ish operands (every major long enough for the run term to matter): the product's partition is the restated
+    rule's on both operands, covers every major exactly once, and no wave exceeds the local-major field of an entry."""
+    m, n, nnz, seed = shape
+    sp_ = solver.SyntheticProblem(m, n, nnz, seed)
+    P = solver.Prepared(problem_struct=sp_.struct)
+    for which in (0, 1):
+        beg, idx = (P.csr_beg, P.csr_idx) if which == 0 else (P.csc_beg, P.csc_idx)
+        n_major, n_minor = (P.m, P.n) if which == 0 else (P.n, P.m)
+        sl = P.slab_layout(which)
+        wb = sl["wave_beg"]
+        cold = _cold_counts(beg, idx, n_minor, 256)
+        nb, mb, wb2 = _slab_partition_restated(beg, n_major, n_minor, 256, 10 if which else 2, cold)
+        assert nb == sl["n_blocks"] == max(1, min(256, -(-n_major // 256))) and mb == sl["minor_bits"]
+        assert np.array_equal(wb, wb2)
+        assert wb[0] == 0 and wb[-1] == n_major and np.all(np.diff(wb) >= 0) and np.all(np.diff(wb[::16]) >= 1)
+        assert np.max(np.diff(wb)) <= 1 << (32 - mb) and np.max(np.diff(wb[::16])) == sl["rows_per_block"]
+        # the entries of every wave's list are those of its majors (long majors left out)
+        lens = np.diff(beg)
+        short = lens <= 256
+        per_wave = np.array([lens[wb[w]:wb[w + 1]][short[wb[w]:wb[w + 1]]].sum() for w in range(len(wb) - 1)])
+        assert np.array_equal(per_wave, np.diff(sl["wave_ptr"]))
+    sp_.close()
+
+
 def test_slab_partition_balances_skewed_majors():
     """Power-law major lengths (the staircase LP of bench.py --config d): blocks of equal major COUNT would differ by 2x
     in entries; blocks cut by work do not."""
