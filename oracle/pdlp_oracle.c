@@ -1306,6 +1306,18 @@ void pdlp_oracle_spmv_csr(int m, const int* beg, const int* idx, const double* v
   }
 }
 
+/* The block boundaries of the slab layout as the device-order mode models them (gpu_order.h g_slab_cold + g_slab_blocks),
+ * for the CPU test that compares them with the product's partition: blockBeg[0 .. nBlocks], returns nBlocks.
+ * which = 0: the operand by rows (majorCost 2), 1: the transposed one (10). */
+int pdlp_oracle_slab_blocks(int nMajor, int nMinor, const int* beg, const int* idx, int longLimit, int which, int* blockBeg) {
+  int* cold = ialloc((long)nMajor + 1);
+  int* count = ialloc((long)nMinor + 1);
+  g_slab_cold(beg, idx, nMajor, nMinor, longLimit, cold, count);
+  const int nB = g_slab_blocks(beg, cold, nMajor, nMinor, longLimit, which ? G_SLAB_MAJOR_COST_COLS : G_SLAB_MAJOR_COST_ROWS, blockBeg);
+  free(cold); free(count);
+  return nB;
+}
+
 /* exp and log of the oracle's device-order mode (det_math.h), for the accuracy test against libm and the comparison
  * with the product's functions (pdlp_mi355x_det_exp_log) */
 void pdlp_oracle_det_exp_log(int n, const double* x, double* expOut, double* logOut) {

@@ -58,6 +58,8 @@ def oracle():
         lib.pdlp_oracle_spmv_csr.argtypes = [C.c_int, abi.c_i32p, abi.c_i32p, abi.c_f64p, abi.c_f64p, abi.c_f64p]
         lib.pdlp_oracle_spmv_csr_device_order.argtypes = lib.pdlp_oracle_spmv_csr.argtypes + [C.c_int]
         lib.pdlp_oracle_det_exp_log.argtypes = [C.c_int, abi.c_f64p, abi.c_f64p, abi.c_f64p]
+        lib.pdlp_oracle_slab_blocks.argtypes = [C.c_int, C.c_int, abi.c_i32p, abi.c_i32p, C.c_int, C.c_int, abi.c_i32p]
+        lib.pdlp_oracle_slab_blocks.restype = C.c_int
         lib.pdlp_oracle_trial_step.argtypes = [C.POINTER(Formulated), C.c_double, C.c_double] + [abi.c_f64p] * 9
         _oracle = lib
     return _oracle

@@ -169,6 +169,16 @@ def _cold_counts(beg, idx, n_minor, long_limit):
     return np.bincount(rows[is_cold], minlength=len(lens)).astype(np.int64)
 
 
+def _oracle_blocks(beg, idx, n_major, n_minor, which, long_limit=256):
+    """The slab block boundaries as the oracle's device-order mode models them (oracle/gpu_order.h, in C)."""
+    ob = np.zeros(256 + n_major // 16384 + 3, dtype=np.int32)
+    b32 = np.ascontiguousarray(beg, dtype=np.int32)
+    i32 = np.ascontiguousarray(idx if len(idx) else [0], dtype=np.int32)
+    nb = O.oracle().pdlp_oracle_slab_blocks(n_major, n_minor, b32.ctypes.data_as(abi.c_i32p), i32.ctypes.data_as(abi.c_i32p), long_limit,
+                                            which, ob.ctypes.data_as(abi.c_i32p))
+    return ob[:nb + 1].astype(np.int64)
+
+
 def _slab_partition_restated(beg, n_major, n_minor, long_limit, major_cost=2, cold=0):
     """pdlp_host.cpp slabPartition, restated: blocks, then the 16 waves of every block, filled one after the other by
     work = _slab_work."""
@@ -239,6 +249,7 @@ def test_slab_layout_is_a_permutation_of_the_csr(which, long_limit):
     cold = _cold_counts(beg, idx, P.n if which == 0 else P.m, long_limit)
     nb, mb, wb2 = _slab_partition_restated(beg, n_major, P.n if which == 0 else P.m, long_limit, 10 if which else 2, cold)
     assert nb == sl["n_blocks"] and mb == sl["minor_bits"] and np.array_equal(wb2, wb)
+    assert np.array_equal(_oracle_blocks(beg, idx, n_major, P.n if which == 0 else P.m, which, long_limit), blk)  # the oracle's C restatement too
     cost = _slab_work(lens, long_limit, 10 if which else 2, cold)
     work = np.add.reduceat(cost, blk[:-1])
     assert work.max() <= work.mean() + cost.max()
@@ -281,6 +292,7 @@ def test_slab_partition_counts_cold_entries_twice():
             assert cold[:m_band].sum() == 0 and 1000 < cold[m_band:].sum() <= 3000  # the tail's entries, not the dense columns'
         nb, mb, wb = _slab_partition_restated(beg, n_major, n_minor, 256, 10 if which else 2, cold)
         assert nb == sl["n_blocks"] and np.array_equal(wb, sl["wave_beg"])
+        assert np.array_equal(_oracle_blocks(beg, idx, n_major, n_minor, which), wb[::16])
         if which == 0:
             assert not np.array_equal(_slab_partition_restated(beg, n_major, n_minor, 256, 2, 0)[2], wb)  # the rule moved boundaries
 
@@ -305,6 +317,8 @@ def test_slab_partition_edge_shapes(shape):
         assert np.array_equal(wb, wb2)
         assert wb[0] == 0 and wb[-1] == n_major and np.all(np.diff(wb) >= 0) and np.all(np.diff(wb[::16]) >= 1)
         assert np.max(np.diff(wb)) <= 1 << (32 - mb) and np.max(np.diff(wb[::16])) == sl["rows_per_block"]
+        # ... and the ORACLE's restatement in C (oracle/gpu_order.h, what its device-order mode sums by) gives the same blocks
+        assert np.array_equal(_oracle_blocks(beg, idx, n_major, n_minor, which), wb[::16])
         # the entries of every wave's list are those of its majors (long majors left out)
         lens = np.diff(beg)
         short = lens <= 256
