@@ -142,6 +142,15 @@ class PdlpSlabLayout(C.Structure):
     ]
 
 
+class PdlpTaskPlan(C.Structure):
+    """pdlp_task_plan_t (include/pdlp_mi355x.h): the segment tasks of a slab operand's long majors, for the CPU tests."""
+    _fields_ = [
+        ("n_tasks", C.c_int32), ("task_group", C.c_int32), ("n_seg_slots", C.c_int32), ("n_long", C.c_int32),
+        ("n_blocks", C.c_int32), ("tile_log2", C.c_int32), ("n_tiles", C.c_int32), ("reserved", C.c_int32),
+        ("tasks", c_i32p), ("tile_owner", C.POINTER(C.c_int8)), ("long_beg", c_i32p), ("long_idx", c_i32p),
+    ]
+
+
 class PdlpMpsModel(C.Structure):
     """pdlp_mps_model_t (include/pdlp_mi355x.h): what pdlp_mi355x_read_mps fills."""
     _fields_ = [

@@ -319,6 +319,46 @@ void pdlp_mi355x_free_slab_layout(pdlp_slab_layout_t* o) {
   memset(o, 0, sizeof(*o));
 }
 
+int pdlp_mi355x_host_task_plan(const pdlp_prepared_t* prep, int32_t which, int32_t long_limit, int32_t balance,
+                               pdlp_task_plan_t* out) {
+  return guarded([&] {
+    if (!prep || !out) throw std::runtime_error("null argument");
+    memset(out, 0, sizeof(*out));
+    const int32_t nMajor = which ? prep->n : prep->m, nMinor = which ? prep->m : prep->n;
+    pdlp::Compressed c;
+    const int32_t* beg = which ? prep->csc_beg : prep->csr_beg;
+    c.beg.assign(beg, beg + nMajor + 1);
+    c.idx.assign(which ? prep->csc_idx : prep->csr_idx, (which ? prep->csc_idx : prep->csr_idx) + prep->nnz);
+    c.val.assign(which ? prep->csc_val : prep->csr_val, (which ? prep->csc_val : prep->csr_val) + prep->nnz);
+    const int32_t majorCost = which ? pdlp::kSlabMajorCostCols : pdlp::kSlabMajorCostRows;
+    // the same calls, in the same order, as DeviceMatrix::upload (pdlp_solver.cpp)
+    std::vector<int32_t> cold((size_t)std::max(nMajor, 1));
+    pdlp::slabColdCounts(c.beg.data(), c.idx.data(), nMajor, nMinor, long_limit, cold.data());
+    const pdlp::SlabPartition part = pdlp::slabPartition(c.beg.data(), cold.data(), nMajor, nMinor, long_limit, majorCost);
+    std::vector<int32_t> lo, hi, cnt;
+    const int32_t tileLog2 = pdlp::xcdTileLog2(nMinor), nTiles = pdlp::xcdTileCount(nMinor, tileLog2);
+    const std::vector<int32_t> hist = pdlp::slabTileHistogram(c.beg.data(), c.idx.data(), part, long_limit, tileLog2, nTiles, lo, hi, cnt);
+    const std::vector<int8_t> owner = pdlp::xcdTileOwners(hist, nTiles);
+    pdlp::SlabLayout L;
+    pdlp::buildSlabLayout(c, nMajor, nMinor, long_limit, pdlp::kSlabWidthLog2, majorCost, L);
+    int32_t taskGroup = 0;
+    const int32_t nLong = (int32_t)L.longMap.size();
+    const pdlp::LongPlan P = pdlp::planSlabTasks(L.longCsr.beg, L.longCsr.idx.data(), nLong, L.longMap.data(), balance != 0, &owner, tileLog2,
+                                                 L.nBlocks, taskGroup);
+    out->n_tasks = P.nTasks; out->task_group = taskGroup; out->n_seg_slots = P.nSegSlots; out->n_long = nLong;
+    out->n_blocks = L.nBlocks; out->tile_log2 = tileLog2; out->n_tiles = nTiles;
+    std::vector<int32_t> flat((size_t)8 * P.nTasks);
+    if (P.nTasks > 0) memcpy(flat.data(), P.tasks.data(), flat.size() * sizeof(int32_t));
+    out->tasks = dupVec(flat); out->tile_owner = dupVec(owner); out->long_beg = dupVec(L.longCsr.beg); out->long_idx = dupVec(L.longCsr.idx);
+  });
+}
+
+void pdlp_mi355x_free_task_plan(pdlp_task_plan_t* o) {
+  if (!o) return;
+  free(o->tasks); free(o->tile_owner); free(o->long_beg); free(o->long_idx);
+  memset(o, 0, sizeof(*o));
+}
+
 void pdlp_mi355x_det_exp_log(int32_t n, const double* x, double* exp_out, double* log_out) {
   for (int32_t i = 0; i < n; ++i) { exp_out[i] = pdlp_det_exp(x[i]); log_out[i] = pdlp_det_log(x[i]); }
 }
@@ -332,6 +372,7 @@ int64_t pdlp_mi355x_sizeof(int32_t which) {
     case 4: return sizeof(pdlp_prepared_t);
     case 5: return sizeof(pdlp_slab_layout_t);
     case 6: return sizeof(pdlp_mps_model_t);
+    case 7: return sizeof(pdlp_task_plan_t);
     default: return -1;
   }
 }

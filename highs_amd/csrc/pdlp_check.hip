@@ -195,14 +195,14 @@ __device__ __forceinline__ void plainLongBlock(const LongMat& L, int tb, const d
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x / kWave);
   const int t = tb * W + wave;
   LongTask T;
-  T.c = -1; T.pBeg = T.pEnd = 0; T.first = t; T.nSeg = 1; T.major = 0; T.contained = 1; T.pad_ = 0;
+  T.c = -1; T.pBeg = T.pEnd = 0; T.first = t; T.nSeg = 1; T.major = 0; T.contained = 1; T.seg = 0;
   if (t < L.nTasks) {
     const int32_t* q = reinterpret_cast<const int32_t*>(L.tasks + t);
     T.pBeg = ldUniform(q); T.pEnd = ldUniform(q + 1); T.c = ldUniform(q + 2); T.first = ldUniform(q + 3);
-    T.nSeg = ldUniform(q + 4); T.major = ldUniform(q + 5); T.contained = ldUniform(q + 6);
+    T.nSeg = ldUniform(q + 4); T.major = ldUniform(q + 5); T.contained = ldUniform(q + 6); T.seg = ldUniform(q + 7);
   }
   const bool active = T.c >= 0;
-  const int seg = t - T.first;
+  const int seg = T.seg;
   constexpr int kPer = kLongSegment / kWave;
   double s = 0.0;
   for (int base = T.pBeg; base < T.pEnd; base += kLongSegment) {
@@ -226,7 +226,7 @@ __device__ __forceinline__ void plainLongBlock(const LongMat& L, int tb, const d
   if (lane == 0) {
     lds[wave] = s;
     if (active && !T.contained) {
-      __hip_atomic_store(reinterpret_cast<unsigned long long*>(L.segSum + t), (unsigned long long)__double_as_longlong(s),
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(L.segSum + T.first + seg), (unsigned long long)__double_as_longlong(s),
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const unsigned old = __hip_atomic_fetch_add(L.ticket + T.c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <functional>
 #include <cmath>
 #include <limits>
 #include <stdexcept>
@@ -403,27 +404,101 @@ StreamPlan planStream(const std::vector<int32_t>& beg, int32_t nMajor, int32_t c
 }
 
 LongPlan planLong(const std::vector<int32_t>& beg, const std::vector<int32_t>& longMajors, const int32_t* vecIndex,
-                  int32_t W) {
+                  int32_t W, const std::function<int(int32_t, int32_t)>* homeOf, int32_t firstXcd) {
   constexpr int32_t kSeg = 512, kMaxSeg = 64;  // pdlp_kernels.hpp kLongSegment, kLongMaxSegments
   LongPlan L;
   L.nLong = (int32_t)longMajors.size();
+  std::vector<LongTaskHost> real;  // XCD-affine order: the tasks in (major, segment) order first
+  int32_t slot = 0;                // first segment-sum slot of the major
   for (int32_t c = 0; c < L.nLong; ++c) {
     const int32_t r = longMajors[c];
     const int32_t p0 = beg[r], len = beg[r + 1] - beg[r];
     int64_t seg = kSeg;
     while ((len + seg - 1) / seg > kMaxSeg) seg *= 2;
     const int32_t nSeg = (int32_t)((len + seg - 1) / seg);
-    const bool contained = nSeg <= W;
-    if (contained)
+    const bool contained = homeOf ? nSeg == 1 : nSeg <= W;
+    if (contained && !homeOf)
       while ((int32_t)(L.tasks.size() % W) + nSeg > W) L.tasks.push_back(LongTaskHost{0, 0, -1, (int32_t)L.tasks.size(), 1, 0, 1, 0});
-    const int32_t first = (int32_t)L.tasks.size();
+    const int32_t first = homeOf ? slot : (int32_t)L.tasks.size();
     for (int32_t k = 0; k < nSeg; ++k) {
       const int64_t a = p0 + (int64_t)k * seg, b = std::min<int64_t>(p0 + len, a + seg);
-      L.tasks.push_back(LongTaskHost{(int32_t)a, (int32_t)b, c, first, nSeg, vecIndex ? vecIndex[c] : r, contained ? 1 : 0, 0});
+      (homeOf ? real : L.tasks).push_back(LongTaskHost{(int32_t)a, (int32_t)b, c, first, nSeg, vecIndex ? vecIndex[c] : r, contained ? 1 : 0, k});
     }
+    slot += nSeg;
+  }
+  if (homeOf) {
+    // XCD-affine deal (slab layout).  Task workgroup lb is workgroup nStreamingBlocks + lb of its launch and runs on XCD
+    // (firstXcd + lb) % 8 (dispatch order; a speed assumption only).  A task goes to a workgroup of the XCD whose streaming
+    // blocks gather from the same stretch of the vector (homeOf), so that its gathers hit lines that L2 holds anyway instead
+    // of pulling a second copy of them into another XCD's L2 (bench.py --config c, A x+: 2.18x the needed HBM bytes before).
+    // No XCD takes more than its share of the workgroups: what does not fit goes to the XCD with the most room.  Which
+    // workgroup runs a task changes no sum: a major's segment sums meet in HBM slots (first + seg) and are added left to right.
+    constexpr int kXcds = 8;
+    const int32_t nReal = (int32_t)real.size();
+    const int32_t G = (nReal + W - 1) / W;
+    int32_t cap[kXcds] = {0};
+    for (int32_t lb = 0; lb < G; ++lb) cap[(firstXcd + lb) % kXcds] += W;
+    std::vector<int32_t> list[kXcds], spill;
+    for (int32_t i = 0; i < nReal; ++i) {
+      int h = (*homeOf)(real[i].pBeg, real[i].pEnd);
+      h = ((h % kXcds) + kXcds) % kXcds;
+      if ((int32_t)list[h].size() < cap[h]) list[h].push_back(i); else spill.push_back(i);
+    }
+    for (int32_t i : spill) {
+      int best = 0;
+      for (int x = 1; x < kXcds; ++x)
+        if (cap[x] - (int32_t)list[x].size() > cap[best] - (int32_t)list[best].size()) best = x;
+      list[best].push_back(i);
+    }
+    size_t next[kXcds] = {0};
+    L.tasks.reserve((size_t)G * W);
+    for (int32_t lb = 0; lb < G; ++lb) {
+      const int x = (firstXcd + lb) % kXcds;
+      for (int32_t w = 0; w < W; ++w) {
+        if (next[x] < list[x].size()) L.tasks.push_back(real[(size_t)list[x][next[x]++]]);
+        else L.tasks.push_back(LongTaskHost{0, 0, -1, 0, 1, 0, 1, 0});  // idle
+      }
+    }
+    L.nSegSlots = slot;
   }
   L.nTasks = (int32_t)L.tasks.size();
+  if (!homeOf) L.nSegSlots = L.nTasks;
   return L;
+}
+
+int32_t xcdTileLog2(int32_t nMinor) {
+  int b = 0;
+  while (((int64_t)1 << b) < (int64_t)nMinor) ++b;
+  return std::max(14, b - 12);  // at most 4096 tiles (an LDS histogram of 16 KB in the device build)
+}
+std::vector<int8_t> xcdTileOwners(const std::vector<int32_t>& hist, int32_t nTiles) {
+  std::vector<int8_t> owner((size_t)std::max(nTiles, 1), -1);
+  for (int32_t t = 0; t < nTiles; ++t) {
+    int32_t best = 0;
+    for (int x = 0; x < 8; ++x)
+      if (hist[(size_t)x * nTiles + t] > best) { best = hist[(size_t)x * nTiles + t]; owner[t] = (int8_t)x; }
+  }
+  // tiles nobody gathers from: the nearest owned tile to the left, else to the right, else proportional
+  int8_t last = -1;
+  for (int32_t t = 0; t < nTiles; ++t) { if (owner[t] >= 0) last = owner[t]; else owner[t] = last; }
+  last = -1;
+  for (int32_t t = nTiles - 1; t >= 0; --t) { if (owner[t] >= 0) last = owner[t]; else owner[t] = last; }
+  for (int32_t t = 0; t < nTiles; ++t) if (owner[t] < 0) owner[t] = (int8_t)(((int64_t)t * 8) / nTiles);
+  return owner;
+}
+int xcdHomeOf(const int32_t* idx, int32_t pBeg, int32_t pEnd, const std::vector<int8_t>& owner, int32_t tileLog2) {
+  const int64_t len = (int64_t)pEnd - pBeg;
+  if (len <= 0 || owner.empty()) return 0;
+  int votes[8] = {0};
+  for (int k = 0; k < 8; ++k) {
+    const int64_t p = pBeg + ((2 * k + 1) * len) / 16;
+    size_t t = (size_t)(idx[p] >> tileLog2);
+    if (t >= owner.size()) t = owner.size() - 1;
+    ++votes[owner[t] & 7];
+  }
+  int best = 0;
+  for (int x = 1; x < 8; ++x) if (votes[x] > votes[best]) best = x;
+  return best;
 }
 
 namespace {
@@ -497,10 +572,14 @@ SlabPartition slabPartition(const int32_t* beg, const int32_t* cold, int32_t nMa
   nB = std::min<int64_t>(nB, kSlabTargetBlocks);
   nB = std::max<int64_t>(nB, ((int64_t)nMajor + blockCap - 1) / blockCap);
   P.nBlocks = (int32_t)nB;
+  // the transposed operand: no block owns more than 5/4 of the mean number of majors (see kSlabColsCapNum)
+  int64_t fillCap = blockCap;
+  if (majorCost == kSlabMajorCostCols && nB > 0)
+    fillCap = std::min<int64_t>(blockCap, std::max<int64_t>(((int64_t)kSlabColsCapNum * nMajor + kSlabColsCapDen * nB - 1) / (kSlabColsCapDen * nB), kSlabMinRowsPerBlock));
   P.waveBeg.assign((size_t)nB * kSlabWavesPerBlock + 1, 0);
   if (nB == 0) return P;
   std::vector<int32_t> blockBeg((size_t)nB + 1);
-  fillByWork(beg, cold, longLimit, majorCost, 0, nMajor, (int32_t)nB, blockCap, true, blockBeg.data());
+  fillByWork(beg, cold, longLimit, majorCost, 0, nMajor, (int32_t)nB, fillCap, true, blockBeg.data());
   for (int32_t b = 0; b < (int32_t)nB; ++b) {
     fillByWork(beg, cold, longLimit, majorCost, blockBeg[b], blockBeg[b + 1], kSlabWavesPerBlock, waveCap, false,
                P.waveBeg.data() + (size_t)b * kSlabWavesPerBlock);
@@ -568,6 +647,49 @@ void buildSlabLayout(const Compressed& csr, int32_t nMajor, int32_t nMinor, int3
         out.val[q] = csr.val[p];
       }
     }
+}
+
+
+std::vector<int32_t> slabTileHistogram(const int32_t* beg, const int32_t* idx, const SlabPartition& part, int32_t longLimit,
+                                       int32_t tileLog2, int32_t nTiles, std::vector<int32_t>& lo, std::vector<int32_t>& hi,
+                                       std::vector<int32_t>& cnt) {
+  const int32_t nB = part.nBlocks;
+  lo.assign((size_t)nB, std::numeric_limits<int32_t>::max());
+  hi.assign((size_t)nB, -1);
+  cnt.assign((size_t)nB, 0);
+  std::vector<int32_t> hist((size_t)8 * nTiles, 0);
+  for (int32_t b = 0; b < nB; ++b) {
+    int32_t* hx = hist.data() + (size_t)xcdOfLogicalBlock(b, nB) * nTiles;
+    for (int32_t r = part.blockBeg(b); r < part.blockBeg(b + 1); ++r) {
+      const int32_t p0 = beg[r], p1 = beg[r + 1];
+      if (p1 <= p0 || p1 - p0 > longLimit) continue;
+      lo[b] = std::min(lo[b], idx[p0]); hi[b] = std::max(hi[b], idx[p1 - 1]); cnt[b] += p1 - p0;
+      for (int32_t p = p0; p < p1; ++p) ++hx[idx[p] >> tileLog2];
+    }
+  }
+  return hist;
+}
+
+LongPlan planSlabTasks(const std::vector<int32_t>& longBeg, const int32_t* longIdx, int32_t nLong, const int32_t* longMap, bool balance,
+                       const std::vector<int8_t>* tileOwner, int32_t tileLog2, int32_t nSlabBlocks, int32_t& taskGroup) {
+  constexpr int32_t kSeg = 512, kMaxSeg = 64;  // pdlp_kernels.hpp kLongSegment, kLongMaxSegments
+  taskGroup = kSlabWavesPerBlock;
+  if (balance) {
+    int64_t segs = 0;
+    for (int32_t c = 0; c < nLong; ++c) {
+      const int64_t len = longBeg[c + 1] - longBeg[c];
+      int64_t seg = kSeg;
+      while ((len + seg - 1) / seg > kMaxSeg) seg *= 2;
+      segs += (len + seg - 1) / seg;
+    }
+    while (taskGroup > 1 && segs / taskGroup < kSlabTargetBlocks) taskGroup /= 2;
+  }
+  std::vector<int32_t> all((size_t)nLong);
+  for (int32_t c = 0; c < nLong; ++c) all[c] = c;
+  std::function<int(int32_t, int32_t)> homeOf;
+  if (tileOwner && longIdx)
+    homeOf = [&](int32_t pBeg, int32_t pEnd) { return xcdHomeOf(longIdx, pBeg, pEnd, *tileOwner, tileLog2); };
+  return planLong(longBeg, all, longMap, taskGroup, homeOf ? &homeOf : nullptr, nSlabBlocks % 8);
 }
 
 }  // namespace pdlp

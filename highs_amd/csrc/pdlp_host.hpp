@@ -10,6 +10,7 @@
 #pragma once
 #include <cstdarg>
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -97,16 +98,37 @@ StreamPlan planStream(const std::vector<int32_t>& beg, int32_t nMajor, int32_t c
 
 // Segment tasks of the long majors of one operand (the device view is pdlp_kernels.hpp LongMat / LongTask).  A long
 // major is cut into segments of 512 * 2^k nonzeros (smallest k with at most 64 segments), one task each; tasks are
-// handed to workgroups of wavesPerBlock waves, W consecutive tasks each, and a major with at most W segments never
-// straddles two workgroups (idle tasks pad the list).
-struct LongTaskHost { int32_t pBeg, pEnd, c, first, nSeg, major, contained, pad_; };  // = LongTask
+// handed to workgroups of wavesPerBlock waves, W consecutive tasks each.
+//   Stream layout (homeOf == nullptr): tasks in (major, segment) order; a major with at most W segments never straddles
+// two workgroups (idle tasks pad the list) and its segment sums meet in LDS.
+//   Slab layout (homeOf given): the XCD-affine deal.  homeOf(pBeg, pEnd) = the XCD (0..7) whose streaming blocks gather
+// from the stretch of the vector the segment's entries [pBeg, pEnd) lie in; task workgroup lb runs on XCD
+// (firstXcd + lb) % 8 and takes tasks of that home (see planLong).  Segment sums of majors with more than one segment
+// meet in HBM slots (LongTask::first + seg); nSegSlots of them.
+struct LongTaskHost { int32_t pBeg, pEnd, c, first, nSeg, major, contained, seg; };  // = LongTask
 struct LongPlan {
   std::vector<LongTaskHost> tasks;
-  int32_t nLong = 0, nTasks = 0;
+  int32_t nLong = 0, nTasks = 0, nSegSlots = 0;
 };
 // longMajors: indices into beg; vecIndex: result-vector index of each of them (nullptr: the index itself)
 LongPlan planLong(const std::vector<int32_t>& beg, const std::vector<int32_t>& longMajors, const int32_t* vecIndex,
-                  int32_t wavesPerBlock);
+                  int32_t wavesPerBlock, const std::function<int(int32_t, int32_t)>* homeOf = nullptr, int32_t firstXcd = 0);
+
+// XCD of logical slab block b under the contiguous block -> XCD map (the inverse of pdlp_devfn.hpp xcdContiguousBlock:
+// XCD x runs the logical blocks [x*nB/8, (x+1)*nB/8), the first nB % 8 XCDs one more)
+inline int32_t xcdOfLogicalBlock(int32_t b, int32_t nB) {
+  const int32_t qlo = nB / 8, r = nB % 8;
+  if (b < r * (qlo + 1)) return b / (qlo + 1);
+  return qlo > 0 ? r + (b - r * (qlo + 1)) / qlo : 0;
+}
+// Which XCD's streaming blocks gather from which stretch of the vector: tile t = minors [t << tileLog2, (t+1) << tileLog2);
+// owner[t] = the XCD (contiguous map) whose blocks hold the most short-major entries in it, the nearest owned tile's
+// owner where nobody gathers.  hist: [8 * nTiles] entry counts per (XCD, tile).
+int32_t xcdTileLog2(int32_t nMinor);
+inline int32_t xcdTileCount(int32_t nMinor, int32_t tileLog2) { return (int32_t)((((int64_t)(nMinor > 1 ? nMinor : 1) - 1) >> tileLog2) + 1); }
+std::vector<int8_t> xcdTileOwners(const std::vector<int32_t>& hist, int32_t nTiles);
+// home XCD of the entries idx[pBeg, pEnd) (ascending minors): the most frequent owner among 8 sample entries
+int xcdHomeOf(const int32_t* idx, int32_t pBeg, int32_t pEnd, const std::vector<int8_t>& owner, int32_t tileLog2);
 
 // Slab layout (the layout of k_spmv_slab).  The gathered vector of a random sparse LP (8 MB at
 // n = 1M) does not fit one XCD's 4 MB L2, so a plain CSR stream pays one fabric request per 8-byte
@@ -132,6 +154,12 @@ constexpr int32_t kSlabMinRowsPerBlock = 256;
 // ~10, most of them behind the grid barrier) differ: with one value for both, config d lost 3 us on one launch or the
 // other; 6 / 10 / 16 for the transposed operand: config d 72.3 / 70.6-71.0 / 71.4 us per iteration, config c unchanged
 constexpr int32_t kSlabMajorCostRows = 2, kSlabMajorCostCols = 10;
+// The transposed operand's launch does the next primal step of every column of the block BEHIND its grid barrier, where
+// nothing overlaps it: a block of many one-entry columns is at the mean WORK and still the launch's straggler (config d,
+// round 5: one block owned 4 690 columns, 2.1x the mean, and ended 3 us after the others).  So on that operand (majorCost =
+// kSlabMajorCostCols) no block takes more than 5/4 of the mean number of majors per block (never fewer than
+// kSlabMinRowsPerBlock); the blocks behind it share what it leaves, by work as before.
+constexpr int32_t kSlabColsCapNum = 5, kSlabColsCapDen = 4;
 
 // The partition of the majors over blocks and waves.  Work of a major of len entries =
 //     len + cold + len * min(len, 64) / 32 + majorCost            (majorCost alone for a long major)
@@ -147,8 +175,8 @@ constexpr int32_t kSlabMajorCostRows = 2, kSlabMajorCostCols = 10;
 //   * majorCost: the epilogue, kSlabMajorCostRows / Cols above.
 // nBlocks = ceil(nMajor / 256) capped at 256 (more only when 256 blocks of 16384 majors do not hold the operand).
 // Blocks are filled one after the other: block b takes majors while it is closer to ceil(work left / blocks left)
-// with the next major than without, but at least one, at most kSlabBlockRowCap, and never so few / many that the
-// blocks behind it could not hold / would not get the rest; the 16 waves of a block are filled the same way from the
+// with the next major than without, but at least one, at most kSlabBlockRowCap (the transposed operand: at most 5/4 of
+// the mean, kSlabColsCapNum), and never so few / many that the blocks behind it could not hold / would not get the rest; the 16 waves of a block are filled the same way from the
 // block's majors (cap: 2^(32 - minorBits) majors, the local-major field of an entry).  Sequential and exact in
 // integers: the device-side set-up (pdlp_setup.hip) counts the cold entries with two small kernels, downloads them
 // with the major starts (8 bytes per major) and calls this same function; oracle/gpu_order.h restates it.
@@ -180,5 +208,18 @@ struct SlabLayout {
 };
 void buildSlabLayout(const Compressed& csr, int32_t nMajor, int32_t nMinor, int32_t longLimit, int32_t slabWidthLog2,
                      int32_t majorCost, SlabLayout& out);
+// Host build of what pdlp_kernels.hip k_block_span computes on the device: per block of the partition the span (lo, hi) and
+// entry count of its short majors, and the histogram [8 * nTiles] of their entries per (XCD of the contiguous map, tile).
+std::vector<int32_t> slabTileHistogram(const int32_t* beg, const int32_t* idx, const SlabPartition& part, int32_t longLimit,
+                                       int32_t tileLog2, int32_t nTiles, std::vector<int32_t>& lo, std::vector<int32_t>& hi,
+                                       std::vector<int32_t>& cnt);
+// The segment tasks of a slab operand's long majors.  longBeg / longIdx: the compact CSR of the long majors (nLong of
+// them), longMap: compact index -> major.  Tasks per workgroup (taskGroup, out): 16 — or, `balance`, halved until there
+// are at least as many task workgroups as CUs: they run NEXT to the streaming blocks (two per CU), and 128 of them on 256
+// CUs slow down half of the streaming blocks (bench.py --config c, A x+: blocks sharing their CU 37 us, the others 26.5).
+// tileOwner (nullptr: tasks in (major, segment) order): the XCD-affine deal of planLong, nSlabBlocks streaming blocks in
+// front of the task workgroups.
+LongPlan planSlabTasks(const std::vector<int32_t>& longBeg, const int32_t* longIdx, int32_t nLong, const int32_t* longMap, bool balance,
+                       const std::vector<int8_t>* tileOwner, int32_t tileLog2, int32_t nSlabBlocks, int32_t& taskGroup);
 
 }  // namespace pdlp

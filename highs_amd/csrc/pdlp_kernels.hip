@@ -13,6 +13,7 @@
 // reductions (tree order here, left-to-right there) differ in the last bits.
 #include "pdlp_kernels.hpp"
 
+#include <climits>
 #include <cmath>
 #include <cstddef>
 
@@ -185,14 +186,14 @@ __device__ __forceinline__ void longBlock(const SpmvArgs& a, Epi<EPI>& epi, int 
   const bool mine = many || sub == 0;
   const int t = mine ? grp * g + (wave - sub * g) : L.nTasks;
   LongTask T;
-  T.c = -1; T.pBeg = T.pEnd = 0; T.first = t; T.nSeg = 1; T.major = 0; T.contained = 1; T.pad_ = 0;
+  T.c = -1; T.pBeg = T.pEnd = 0; T.first = t; T.nSeg = 1; T.major = 0; T.contained = 1; T.seg = 0;
   if (t < L.nTasks) {  // (one 32-byte scalar load)
     const int32_t* q = reinterpret_cast<const int32_t*>(L.tasks + t);
     T.pBeg = ldUniform(q); T.pEnd = ldUniform(q + 1); T.c = ldUniform(q + 2); T.first = ldUniform(q + 3);
-    T.nSeg = ldUniform(q + 4); T.major = ldUniform(q + 5); T.contained = ldUniform(q + 6);
+    T.nSeg = ldUniform(q + 4); T.major = ldUniform(q + 5); T.contained = ldUniform(q + 6); T.seg = ldUniform(q + 7);
   }
   const bool active = T.c >= 0;
-  const int seg = t - T.first;
+  const int seg = T.seg;
   Pre pre{0.0, 0.0, 0.0, 0.0, 0.0};
   if (active && (seg == 0 || !T.contained)) pre = epi.prefetch(T.major);
   const int32_t* __restrict__ idx = L.idx;
@@ -221,7 +222,7 @@ __device__ __forceinline__ void longBlock(const SpmvArgs& a, Epi<EPI>& epi, int 
   if (lane == 0) {
     lds[wave] = s;
     if (active && !T.contained) {
-      __hip_atomic_store(reinterpret_cast<unsigned long long*>(L.segSum + t), (unsigned long long)__double_as_longlong(s),
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(L.segSum + T.first + seg), (unsigned long long)__double_as_longlong(s),
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the segment sum has landed before the ticket is taken
       const unsigned old = __hip_atomic_fetch_add(L.ticket + T.c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1350,30 +1351,56 @@ void launchDiffNorm2(const double* a, const double* b, int32_t len, double* part
   hipLaunchKernelGGL(k_diff_norm2, dim3(nBlocks), dim3(kVecThreads), 0, s, a, b, len, partials);
 }
 namespace {
-// Per slab block (majors [waveBeg[16 b], waveBeg[16 b + 16])): smallest and largest minor index over its majors of at most
-// `longLimit` entries (CSR with ascending minors: the first and the last entry of a major) and their entry count.
-__global__ __launch_bounds__(kVecThreads) void k_block_span(const int32_t* __restrict__ beg, const int32_t* __restrict__ idx, int nMajor,
+// Per slab block b (majors [waveBeg[16 b], waveBeg[16 b + 16])), ONE workgroup each: smallest and largest minor index over
+// its majors of at most `longLimit` entries (CSR with ascending minors: the first and the last entry of a major), their
+// entry count, and — hist != nullptr — the entries per tile of 2^tileLog2 minors, added to the histogram row of the XCD
+// that runs the block under the contiguous map (pdlp_host.hpp xcdOfLogicalBlock / xcdTileOwners).  Thread-local
+// min / max / count, block reduction, one store per block (round 5 took three contended global atomics per major:
+// 3.4 ms per call at 1M majors); the histogram is counted in LDS and flushed with one integer atomic per non-empty tile.
+constexpr int kSpanMaxTiles = 4096;
+__global__ __launch_bounds__(kVecThreads) void k_block_span(const int32_t* __restrict__ beg, const int32_t* __restrict__ idx,
                                                             const int32_t* __restrict__ waveBeg, int nBlocks, int longLimit, int32_t* lo,
-                                                            int32_t* hi, int32_t* cnt) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= nMajor) return;
-  const int p0 = beg[r], p1 = beg[r + 1];
-  if (p1 <= p0 || p1 - p0 > longLimit) return;
-  int b = 0, e = nBlocks;  // last block whose first major is <= r
-  while (e - b > 1) {
-    const int mid = (b + e) >> 1;
-    if (waveBeg[mid * 16] <= r) b = mid; else e = mid;
+                                                            int32_t* hi, int32_t* cnt, int tileLog2, int nTiles, int32_t* hist) {
+  __shared__ int32_t tile[kSpanMaxTiles];
+  __shared__ int32_t red[3][kVecThreads / kWave];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int r0 = waveBeg[b * 16], r1 = waveBeg[b * 16 + 16];
+  if (hist) for (int t = tid; t < nTiles; t += kVecThreads) tile[t] = 0;
+  __syncthreads();
+  int32_t l = INT_MAX, h = -1, c = 0;
+  for (int r = r0 + tid; r < r1; r += kVecThreads) {
+    const int p0 = beg[r], p1 = beg[r + 1];
+    if (p1 <= p0 || p1 - p0 > longLimit) continue;
+    const int32_t a = idx[p0], z = idx[p1 - 1];
+    l = a < l ? a : l; h = z > h ? z : h; c += p1 - p0;
+    if (hist) for (int p = p0; p < p1; ++p) atomicAdd(&tile[idx[p] >> tileLog2], 1);
   }
-  atomicMin(lo + b, idx[p0]);
-  atomicMax(hi + b, idx[p1 - 1]);
-  atomicAdd(cnt + b, p1 - p0);
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+    const int32_t l2 = __shfl_down(l, off, kWave), h2 = __shfl_down(h, off, kWave), c2 = __shfl_down(c, off, kWave);
+    l = l2 < l ? l2 : l; h = h2 > h ? h2 : h; c += c2;
+  }
+  if ((tid & (kWave - 1)) == 0) { red[0][tid / kWave] = l; red[1][tid / kWave] = h; red[2][tid / kWave] = c; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < kVecThreads / kWave; ++w) {
+      l = red[0][w] < l ? red[0][w] : l; h = red[1][w] > h ? red[1][w] : h; c += red[2][w];
+    }
+    lo[b] = l; hi[b] = h; cnt[b] = c;
+  }
+  if (hist) {
+    const int qlo = nBlocks / 8, rr = nBlocks % 8;  // = pdlp_host.hpp xcdOfLogicalBlock
+    const int x = b < rr * (qlo + 1) ? b / (qlo + 1) : (qlo > 0 ? rr + (b - rr * (qlo + 1)) / qlo : 0);
+    for (int t = tid; t < nTiles; t += kVecThreads)
+      if (tile[t]) atomicAdd(hist + (size_t)x * nTiles + t, tile[t]);
+  }
 }
 }  // namespace
-void launchBlockSpan(const int32_t* beg, const int32_t* idx, int32_t nMajor, const int32_t* waveBeg, int32_t nBlocks, int32_t longLimit,
-                     int32_t* lo, int32_t* hi, int32_t* cnt, hipStream_t s) {
-  if (nMajor <= 0) return;
-  hipLaunchKernelGGL(k_block_span, dim3((nMajor + kVecThreads - 1) / kVecThreads), dim3(kVecThreads), 0, s, beg, idx, nMajor, waveBeg,
-                     nBlocks, longLimit, lo, hi, cnt);
+void launchBlockSpan(const int32_t* beg, const int32_t* idx, const int32_t* waveBeg, int32_t nBlocks, int32_t longLimit, int32_t* lo,
+                     int32_t* hi, int32_t* cnt, int32_t tileLog2, int32_t nTiles, int32_t* hist, hipStream_t s) {
+  if (nBlocks <= 0) return;
+  if (nTiles > kSpanMaxTiles) hist = nullptr;  // (xcdTileLog2 never asks for more)
+  hipLaunchKernelGGL(k_block_span, dim3(nBlocks), dim3(kVecThreads), 0, s, beg, idx, waveBeg, nBlocks, longLimit, lo, hi, cnt, tileLog2,
+                     nTiles, hist);
 }
 void launchDot(const double* a, const double* b, int32_t len, double* partials, int32_t nBlocks, hipStream_t s) {
   hipLaunchKernelGGL(k_dot, dim3(nBlocks), dim3(kVecThreads), 0, s, a, b, len, partials);

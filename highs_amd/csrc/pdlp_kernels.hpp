@@ -123,17 +123,17 @@ constexpr int kLongSlotCap = 2048;  // more long majors than this: contributions
 struct LongTask {      // 32 bytes: one scalar load per wave
   int32_t pBeg, pEnd;  // entries of the segment
   int32_t c;           // long-major index (-1: idle task, padding)
-  int32_t first;       // first task of the major (segment = task - first)
+  int32_t first;       // first segment-sum slot of the major (stream layout: = its first task)
   int32_t nSeg;        // segments of the major
   int32_t major;       // index of the major in the result vector
-  int32_t contained;   // 1: all segments in this workgroup (LDS), 0: spanning (tickets)
-  int32_t pad_;
+  int32_t contained;   // 1: all segments in this workgroup, consecutive waves (LDS), 0: spanning (HBM slots + tickets)
+  int32_t seg;         // this task's segment of the major; its sum goes to slot first + seg
 };
 struct LongMat {
   const int32_t* idx;        // the CSR arrays the long majors live in (the operand's, or the slab layout's side copy)
   const double* val;
   const LongTask* tasks;     // [nTasks]
-  double* segSum;            // [nTasks] (spanning majors)
+  double* segSum;            // [segment slots] (spanning majors)
   uint32_t* ticket;          // [nLong] zero between launches
   double* contrib;           // [2*nLong] when nLong > kLongSlotCap (then k_long_groups fills the slots), else nullptr
   int32_t nLong, nTasks;
@@ -392,8 +392,10 @@ void launchRestartFinish(DevState* st, CheckCtl* cc, const double* partX, int32_
 int32_t vecBlocks(int32_t len);  // grid size used by the vector/statistics kernels
 
 // ---- set-up: which slab width suits an operand ----
-// lo/hi/cnt [ceil(nMajor/R)], pre-set to INT_MAX / -1 / 0: column span and entry count of each block's short majors
-void launchBlockSpan(const int32_t* beg, const int32_t* idx, int32_t nMajor, const int32_t* waveBeg, int32_t nBlocks, int32_t longLimit,
-                     int32_t* lo, int32_t* hi, int32_t* cnt, hipStream_t s);
+// lo/hi/cnt [nBlocks]: column span and entry count of each slab block's short majors (INT_MAX / -1 / 0 for a block without
+// any); hist (nullptr: none) [8 * nTiles], zeroed by the caller: entries per (XCD of the contiguous map, tile of 2^tileLog2
+// minors) — which XCD's streaming blocks gather from which stretch of the vector (pdlp_host.hpp xcdTileOwners)
+void launchBlockSpan(const int32_t* beg, const int32_t* idx, const int32_t* waveBeg, int32_t nBlocks, int32_t longLimit, int32_t* lo,
+                     int32_t* hi, int32_t* cnt, int32_t tileLog2, int32_t nTiles, int32_t* hist, hipStream_t s);
 
 }  // namespace pdlp

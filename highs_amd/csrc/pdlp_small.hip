@@ -228,14 +228,14 @@ __device__ __forceinline__ void smallLongBlock(const SmallArgs& a, const LongMat
   const int nxt = cur ^ 1;
   const int t = tb * W + wave;
   LongTask T;
-  T.c = -1; T.pBeg = T.pEnd = 0; T.first = t; T.nSeg = 1; T.major = 0; T.contained = 1; T.pad_ = 0;
+  T.c = -1; T.pBeg = T.pEnd = 0; T.first = t; T.nSeg = 1; T.major = 0; T.contained = 1; T.seg = 0;
   if (t < L.nTasks) {
     const int32_t* q = reinterpret_cast<const int32_t*>(L.tasks + t);
     T.pBeg = ldUniform(q); T.pEnd = ldUniform(q + 1); T.c = ldUniform(q + 2); T.first = ldUniform(q + 3);
-    T.nSeg = ldUniform(q + 4); T.major = ldUniform(q + 5); T.contained = ldUniform(q + 6);
+    T.nSeg = ldUniform(q + 4); T.major = ldUniform(q + 5); T.contained = ldUniform(q + 6); T.seg = ldUniform(q + 7);
   }
   const bool active = T.c >= 0;
-  const int seg = t - T.first;
+  const int seg = T.seg;
   const int r = T.major;
   double pa = 0.0, pb = 0.0, pc = 0.0, pd = 0.0;
   if (active && (seg == 0 || !T.contained)) {
@@ -271,7 +271,7 @@ __device__ __forceinline__ void smallLongBlock(const SmallArgs& a, const LongMat
   if (lane == 0) {
     lds[wave] = s;
     if (active && !T.contained) {
-      __hip_atomic_store(reinterpret_cast<unsigned long long*>(L.segSum + t), (unsigned long long)__double_as_longlong(s),
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(L.segSum + T.first + seg), (unsigned long long)__double_as_longlong(s),
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the segment sum has landed before the ticket is taken
       const unsigned old = __hip_atomic_fetch_add(L.ticket + T.c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

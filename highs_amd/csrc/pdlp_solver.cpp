@@ -53,7 +53,7 @@ bool chooseSlab(int mode, int32_t nMajor, int32_t nMinor) {
 // Slab layout: those arrays hold only the majors longer than kSlabLongLimit, so chunk = that limit and every one
 // of them becomes segment tasks (longVecIndex = compact index -> major).
 void DeviceMatrix::uploadPlans(const std::vector<int32_t>& hostBeg, int32_t nCsrMajor, const int32_t* longVecIndex,
-                               hipStream_t s) {
+                               hipStream_t s, const int32_t* hostLongIdx, const std::vector<int8_t>* tileOwner, int32_t tileLog2) {
   const int64_t nnzCsr = nCsrMajor > 0 ? (int64_t)hostBeg[nCsrMajor] : 0;
   chunk = spmvChunkFor(nnzCsr);
   StreamPlan plan = planStream(hostBeg, nCsrMajor, useSlab ? kSlabLongLimit : chunk, kMaxMajorsPerBlock);
@@ -65,29 +65,23 @@ void DeviceMatrix::uploadPlans(const std::vector<int32_t>& hostBeg, int32_t nCsr
   if (longVecIndex)
     for (int32_t c : plan.longMajors) vecIdx.push_back(longVecIndex[c]);
   static_assert(sizeof(LongTask) == sizeof(LongTaskHost) && sizeof(LongTask) == 32, "task record layout");
-  // tasks per workgroup.  Stream layout: the 4 waves of a workgroup.  Slab layout: task workgroups run NEXT to the
-  // streaming blocks (two per CU), and 128 of them on 256 CUs slow down half of the streaming blocks (bench.py --config c,
-  // A x+: blocks sharing their CU 37 us, the others 26.5 — the launch takes the 37); the group is halved until there are
-  // at least as many task workgroups as CUs, so every CU carries the same extra load
-  taskGroup = (useSlab ? kSlabThreads : kSpmvThreads) / 64;
-  if (useSlab && balanceTaskBlocks) {
-    int64_t segs = 0;
-    for (int32_t c : plan.longMajors) {
-      const int64_t len = hostBeg[c + 1] - hostBeg[c];
-      int64_t seg = kLongSegment;
-      while ((len + seg - 1) / seg > kLongMaxSegments) seg *= 2;
-      segs += (len + seg - 1) / seg;
-    }
-    while (taskGroup > 1 && segs / taskGroup < kSlabTargetBlocks) taskGroup /= 2;
+  // tasks per workgroup.  Stream layout: the 4 waves of a workgroup, tasks in (major, segment) order.  Slab layout:
+  // pdlp_host.hpp planSlabTasks (group size by the number of CUs, XCD-affine deal)
+  LongPlan L;
+  if (useSlab) {
+    L = planSlabTasks(hostBeg, hostLongIdx, (int32_t)plan.longMajors.size(), longVecIndex, balanceTaskBlocks,
+                      affineTasks && hostLongIdx && tileOwner ? tileOwner : nullptr, tileLog2, slab.nBlocks, taskGroup);
+  } else {
+    taskGroup = kSpmvThreads / 64;
+    L = planLong(hostBeg, plan.longMajors, longVecIndex ? vecIdx.data() : nullptr, taskGroup);
   }
-  LongPlan L = planLong(hostBeg, plan.longMajors, longVecIndex ? vecIdx.data() : nullptr, taskGroup);
   nLong = L.nLong;
   nTasks = L.nTasks;
   longGroup = nLong > kLongSlotCap ? (nLong + kLongSlotCap - 1) / kLongSlotCap : 1;
   longSlots = (nLong + longGroup - 1) / longGroup;
   lTasks.alloc((size_t)nTasks);
   lTasks.upload(reinterpret_cast<const LongTask*>(L.tasks.data()), (size_t)nTasks, s);
-  lSegSum.alloc((size_t)nTasks);
+  lSegSum.alloc((size_t)std::max(L.nSegSlots, 1));
   lSegSum.zero(s);
   lTicket.alloc((size_t)nLong);
   lTicket.zero(s);
@@ -117,20 +111,20 @@ void DeviceMatrix::upload(const Compressed& cIn, int32_t nMajor_, int32_t nMinor
   nMajor = nMajor_;
   nnz = cIn.beg.empty() ? 0 : cIn.beg[nMajor_];
   useSlab = chooseSlab(sw.slab, nMajor_, nMinor_);
+  affineTasks = sw.affineTasks != 0;
   const Compressed* c = &cIn;
   SlabLayout L;
+  std::vector<int8_t> tileOwner;
+  int32_t tileLog2 = 0;
   if (useSlab) {
     std::vector<int32_t> cold((size_t)std::max(nMajor_, 1));
     slabColdCounts(cIn.beg.data(), cIn.idx.data(), nMajor_, nMinor_, kSlabLongLimit, cold.data());
     const SlabPartition part = slabPartition(cIn.beg.data(), cold.data(), nMajor_, nMinor_, kSlabLongLimit, majorCost);
-    const int32_t nB = part.nBlocks;
-    std::vector<int32_t> lo((size_t)nB, INT_MAX), hi((size_t)nB, -1), cnt((size_t)nB, 0);
-    for (int32_t b = 0; b < nB; ++b)
-      for (int32_t r = part.blockBeg(b); r < part.blockBeg(b + 1); ++r) {
-        const int32_t p0 = cIn.beg[r], p1 = cIn.beg[r + 1];
-        if (p1 <= p0 || p1 - p0 > kSlabLongLimit) continue;
-        lo[b] = std::min(lo[b], cIn.idx[p0]); hi[b] = std::max(hi[b], cIn.idx[p1 - 1]); cnt[b] += p1 - p0;
-      }
+    std::vector<int32_t> lo, hi, cnt;
+    tileLog2 = xcdTileLog2(nMinor_);
+    const int32_t nTiles = xcdTileCount(nMinor_, tileLog2);
+    const std::vector<int32_t> hist = slabTileHistogram(cIn.beg.data(), cIn.idx.data(), part, kSlabLongLimit, tileLog2, nTiles, lo, hi, cnt);
+    tileOwner = xcdTileOwners(hist, nTiles);
     buildSlabLayout(cIn, nMajor_, nMinor_, kSlabLongLimit, slabWidthFor(sw, touchesFewTiles(lo, hi, cnt)), majorCost, L);
     if (L.rowsPerBlock > kSlabMaxRows) throw std::runtime_error("slab layout: too many majors per block");
     wavePtr.alloc(L.wavePtr.size());
@@ -158,7 +152,7 @@ void DeviceMatrix::upload(const Compressed& cIn, int32_t nMajor_, int32_t nMinor
   beg.upload(c->beg.data(), c->beg.size(), s);
   idx.upload(c->idx.data(), (size_t)nnzCsr, s);
   val.upload(c->val.data(), (size_t)nnzCsr, s);
-  uploadPlans(c->beg, nCsrMajor, useSlab ? L.longMap.data() : nullptr, s);
+  uploadPlans(c->beg, nCsrMajor, useSlab ? L.longMap.data() : nullptr, s, c->idx.data(), useSlab ? &tileOwner : nullptr, tileLog2);
   PDLP_HIP(hipStreamSynchronize(s));  // host vectors may go out of scope
 }
 
@@ -166,7 +160,10 @@ void DeviceMatrix::buildFromDevice(DeviceCsrData& M, const DevSwitches& sw, hipS
   nMajor = M.nMajor;
   nnz = M.nnz;
   useSlab = chooseSlab(sw.slab, M.nMajor, M.nMinor);
-  std::vector<int32_t> hostBeg, hostLongMap;
+  affineTasks = sw.affineTasks != 0;
+  std::vector<int32_t> hostBeg, hostLongMap, hostLongIdx;
+  std::vector<int8_t> tileOwner;
+  int32_t tileLog2 = 0;
   int32_t nCsrMajor = nMajor;
   bool localM = false;
   if (useSlab) {
@@ -174,14 +171,21 @@ void DeviceMatrix::buildFromDevice(DeviceCsrData& M, const DevSwitches& sw, hipS
     gpuSlabPartition(M, kSlabLongLimit, majorCost, s, L);
     const int32_t nB = L.nBlocks;
     {  // per-block span of the short majors, from the CSR that is already in HBM
+      // ... and which XCD's blocks gather from which stretch of the vector (the home of the long majors' segment tasks)
       std::vector<int32_t> lo((size_t)nB, INT_MAX), hi((size_t)nB, -1), cnt((size_t)nB, 0);
-      DeviceArray<int32_t> dLo, dHi, dCn;
-      dLo.alloc(nB); dHi.alloc(nB); dCn.alloc(nB);
-      dLo.upload(lo.data(), nB, s); dHi.upload(hi.data(), nB, s); dCn.upload(cnt.data(), nB, s);
-      launchBlockSpan(M.beg.get(), M.idx.get(), M.nMajor, L.waveBeg.get(), nB, kSlabLongLimit, dLo.get(), dHi.get(), dCn.get(), s);
+      tileLog2 = xcdTileLog2(M.nMinor);
+      const int32_t nTiles = xcdTileCount(M.nMinor, tileLog2);
+      std::vector<int32_t> hist((size_t)8 * nTiles, 0);
+      DeviceArray<int32_t> dLo, dHi, dCn, dHist;
+      dLo.alloc(nB); dHi.alloc(nB); dCn.alloc(nB); dHist.alloc(hist.size());
+      dHist.zero(s);
+      launchBlockSpan(M.beg.get(), M.idx.get(), L.waveBeg.get(), nB, kSlabLongLimit, dLo.get(), dHi.get(), dCn.get(), tileLog2, nTiles,
+                      dHist.get(), s);
       dLo.download(lo.data(), nB, s); dHi.download(hi.data(), nB, s); dCn.download(cnt.data(), nB, s);
+      dHist.download(hist.data(), hist.size(), s);
       PDLP_HIP(hipStreamSynchronize(s));
       localM = touchesFewTiles(lo, hi, cnt);
+      tileOwner = xcdTileOwners(hist, nTiles);
     }
     // (an operand whose blocks touch few 16384-entry tiles of the gathered vector densely gets slabs of that width: its
     // runs of equal majors are shorter, more lanes add in parallel — bench.py --config c, A x: 44.0 -> 41.1 us)
@@ -200,6 +204,8 @@ void DeviceMatrix::buildFromDevice(DeviceCsrData& M, const DevSwitches& sw, hipS
     nCsrMajor = L.nLong;
     hostLongMap.resize((size_t)L.nLong);
     L.longMap.download(hostLongMap.data(), (size_t)L.nLong, s);
+    hostLongIdx.resize((size_t)hostBeg[L.nLong] + 1);  // (the minors of the long majors: where their segments gather from)
+    if (L.nLong > 0) idx.download(hostLongIdx.data(), (size_t)hostBeg[L.nLong], s);
     PDLP_HIP(hipStreamSynchronize(s));
   } else {
     beg = std::move(M.beg);
@@ -209,7 +215,8 @@ void DeviceMatrix::buildFromDevice(DeviceCsrData& M, const DevSwitches& sw, hipS
     beg.download(hostBeg.data(), hostBeg.size(), s);
     PDLP_HIP(hipStreamSynchronize(s));
   }
-  uploadPlans(hostBeg, nCsrMajor, useSlab ? hostLongMap.data() : nullptr, s);
+  uploadPlans(hostBeg, nCsrMajor, useSlab ? hostLongMap.data() : nullptr, s, useSlab ? hostLongIdx.data() : nullptr,
+              useSlab ? &tileOwner : nullptr, tileLog2);
 }
 
 MatView DeviceMatrix::view() const {
@@ -282,6 +289,7 @@ DevSwitches DevSwitches::fromEnv() {
   w.slabW = num("PDLP_MI355X_SLAB_W", 0);
   w.xcdMap = num("PDLP_MI355X_XCD_MAP", -1);
   w.slabPace = num("PDLP_MI355X_SLAB_PACE", -1);
+  w.affineTasks = num("PDLP_MI355X_AFFINE_TASKS", 1);
   w.fused = num("PDLP_MI355X_FUSED", -1);
   w.fusedStream = num("PDLP_MI355X_FUSED_STREAM", 0);
   w.fusedCoTasks = num("PDLP_MI355X_FUSED_COTASKS", -1);

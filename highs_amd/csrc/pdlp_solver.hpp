@@ -25,6 +25,7 @@ struct DevSwitches {
   int slab = -1;          // PDLP_MI355X_SLAB: 0 CSR stream only, 1 slab layout, -1 automatic by the gathered vector's size
   int slabW = 0;          // PDLP_MI355X_SLAB_W: log2 of the slab width (development)
   int xcdMap = -1, slabPace = -1;
+  int affineTasks = 1;  // XCD-affine deal of the slab layout's segment tasks (0: (major, segment) order; A/B measurements)
   int fusedCoTasks = -1;  // PDLP_MI355X_FUSED_COTASKS: 0 = the fused trial's streaming blocks run the long columns' task passes themselves
   int fused = -1, fusedStream = 0, persistent = -1, xcdLocal = -1, hierBarrier = -1, deviceCheck = -1, checkSmall = -1;
   int primalInA = -1;     // PDLP_MI355X_PRIMAL_IN_A: the persistent loop without its P phase (pdlp_small.hip PINA); -1 = where measured faster
@@ -49,6 +50,7 @@ struct DeviceMatrix {
   // slab layout: size the task workgroups so that every CU gets one (uploadPlans).  Off for the operand whose tasks the
   // fused trial runs inside its streaming blocks (already spread evenly; full groups of 16 keep long columns in LDS)
   bool balanceTaskBlocks = true;
+  bool affineTasks = true;  // slab layout: XCD-affine deal of the segment tasks (PDLP_MI355X_DEV_AFFINE_TASKS=0: (major, segment) order)
   int32_t majorCost = kSlabMajorCostRows;  // slab partition: work of a major besides its entries (the owner sets kSlabMajorCostCols on its transposed operand)
   int32_t fusedCoTasks = 0;  // MatView::coTaskBlocks (the fused trial's task workgroups), decided by the solver at set-up
   int32_t nMajor = 0, nBlocks = 0;  // nBlocks = CSR stream blocks
@@ -66,7 +68,10 @@ struct DeviceMatrix {
   int32_t nPartials() const { return (useSlab ? slab.nBlocks : 0) + nBlocks + longSlots; }
 
  private:
-  void uploadPlans(const std::vector<int32_t>& hostBeg, int32_t nCsrMajor, const int32_t* longVecIndex, hipStream_t s);
+  // hostLongIdx / tileOwner / tileLog2 (slab layout): the minors of the long majors on the host and the XCD that owns each
+  // tile of the gathered vector — the segment tasks are dealt to workgroups of the XCD their entries live in (planLong)
+  void uploadPlans(const std::vector<int32_t>& hostBeg, int32_t nCsrMajor, const int32_t* longVecIndex, hipStream_t s,
+                   const int32_t* hostLongIdx = nullptr, const std::vector<int8_t>* tileOwner = nullptr, int32_t tileLog2 = 0);
   // per-block column span / entry count of the short majors -> do the blocks touch few stretches of the gathered vector densely?
   static bool touchesFewTiles(const std::vector<int32_t>& lo, const std::vector<int32_t>& hi, const std::vector<int32_t>& cnt);
 };

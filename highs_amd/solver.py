@@ -40,6 +40,7 @@ EXPORTS = [
     "pdlp_mi355x_free_problem", "pdlp_mi355x_last_error", "pdlp_mi355x_abi_version",
     "pdlp_mi355x_host_prepare", "pdlp_mi355x_free_prepared", "pdlp_mi355x_row_partition", "pdlp_mi355x_sizeof",
     "pdlp_mi355x_host_slab_layout", "pdlp_mi355x_free_slab_layout", "pdlp_mi355x_det_exp_log",
+    "pdlp_mi355x_host_task_plan", "pdlp_mi355x_free_task_plan",
     "pdlp_mi355x_read_mps", "pdlp_mi355x_read_mps_timed", "pdlp_mi355x_free_mps_model",
 ]
 
@@ -89,6 +90,10 @@ def lib():
         L.pdlp_mi355x_host_slab_layout.argtypes = [pPrep, C.c_int32, C.c_int32, pSlab]
         L.pdlp_mi355x_free_slab_layout.argtypes = [pSlab]
         L.pdlp_mi355x_free_slab_layout.restype = None
+        pTask = C.POINTER(abi.PdlpTaskPlan)
+        L.pdlp_mi355x_host_task_plan.argtypes = [pPrep, C.c_int32, C.c_int32, C.c_int32, pTask]
+        L.pdlp_mi355x_free_task_plan.argtypes = [pTask]
+        L.pdlp_mi355x_free_task_plan.restype = None
         pMps = C.POINTER(abi.PdlpMpsModel)
         L.pdlp_mi355x_read_mps.argtypes = [C.c_char_p, C.c_int32, pMps]
         L.pdlp_mi355x_read_mps_timed.argtypes = [C.c_char_p, C.c_int32, C.c_double, pMps]
@@ -383,6 +388,18 @@ class Prepared:
                 ent=g(SL.ent, SL.nnz_short, np.uint32), val=g(SL.val, SL.nnz_short, np.float64),
                 long_mask=g(SL.long_mask, (n if which else m) // 32 + 1, np.uint32), long_map=g(SL.long_map, SL.n_long, np.int32))
             lib().pdlp_mi355x_free_slab_layout(C.byref(SL))
+        self._tasks = {}
+        for which in (0, 1):
+            for balance in (0, 1):
+                TP = abi.PdlpTaskPlan()
+                _check(lib().pdlp_mi355x_host_task_plan(C.byref(F), which, slab_long_limit, balance, C.byref(TP)), "task_plan")
+                nl = TP.n_long
+                lb = g(TP.long_beg, nl + 1, np.int64)
+                self._tasks[which, balance] = dict(
+                    n_tasks=TP.n_tasks, task_group=TP.task_group, n_seg_slots=TP.n_seg_slots, n_long=nl, n_blocks=TP.n_blocks,
+                    tile_log2=TP.tile_log2, tasks=g(TP.tasks, 8 * TP.n_tasks, np.int64).reshape(-1, 8),
+                    tile_owner=g(TP.tile_owner, TP.n_tiles, np.int64), long_beg=lb, long_idx=g(TP.long_idx, int(lb[-1]) if nl else 0, np.int64))
+                lib().pdlp_mi355x_free_task_plan(C.byref(TP))
         self._parts = {}
         for w in (1, 2, 3, 4, 8):
             off = np.zeros(w + 1, dtype=np.int32)
@@ -392,6 +409,10 @@ class Prepared:
 
     def row_partition(self, world):
         return self._parts[world]
+
+    def task_plan(self, which, balance=1):
+        """Segment tasks of the long majors of operand `which` as the slab launches run them (pdlp_task_plan_t)."""
+        return self._tasks[which, balance]
 
     def slab_layout(self, which):
         """which = 0: A by rows, 1: A' by columns."""

@@ -303,12 +303,29 @@ typedef struct pdlp_slab_layout {
   double* val;        /* [nnz_short] */
   uint32_t* long_mask;/* [n_major/32 + 1] bit r: major r is a long one */
   int32_t* long_map;  /* [n_long] */
-  int32_t* wave_beg;  /* [16*n_blocks+1] first major of every wave: blocks and waves are cut by work
-                         (entries of the short majors + 2 per major), not by major count */
+  int32_t* wave_beg;  /* [16*n_blocks+1] first major of every wave: blocks and waves are cut by work, not by major
+                         count (csrc/pdlp_host.hpp slabPartition holds the rule) */
 } pdlp_slab_layout_t;
 int pdlp_mi355x_host_slab_layout(const pdlp_prepared_t* prep, int32_t which,
                                  int32_t long_limit, pdlp_slab_layout_t* out);
 void pdlp_mi355x_free_slab_layout(pdlp_slab_layout_t* out);
+/* The segment tasks of that operand's long majors (more than long_limit entries) as the slab SpMV launches run them
+ * (csrc/pdlp_host.hpp planSlabTasks): task t belongs to task workgroup t / task_group, which is workgroup
+ * n_blocks + t / task_group of its launch and runs on XCD (n_blocks + t / task_group) % 8; a task is dealt to a workgroup
+ * of the XCD whose streaming blocks gather from the stretch of the vector its entries lie in (tile_owner).  For the CPU
+ * tests; balance = 1: at least one task workgroup per CU.  Free with pdlp_mi355x_free_task_plan. */
+typedef struct pdlp_task_plan {
+  int32_t n_tasks, task_group, n_seg_slots, n_long, n_blocks, tile_log2, n_tiles, reserved;
+  int32_t* tasks;     /* [8*n_tasks] entry range [p_beg, p_end) in long_idx, long-major index c (-1: idle), first
+                         segment-sum slot of the major, its segment count, its index in the result vector, contained,
+                         segment number */
+  int8_t* tile_owner; /* [n_tiles] XCD (contiguous block -> XCD map) that gathers most from minors [t << tile_log2, ...) */
+  int32_t* long_beg;  /* [n_long+1] compact CSR of the long majors */
+  int32_t* long_idx;  /* [long_beg[n_long]] */
+} pdlp_task_plan_t;
+int pdlp_mi355x_host_task_plan(const pdlp_prepared_t* prep, int32_t which, int32_t long_limit, int32_t balance,
+                               pdlp_task_plan_t* out);
+void pdlp_mi355x_free_task_plan(pdlp_task_plan_t* out);
 /* exp(x[i]) and log(x[i]) as the solver computes them in the restart's primal-weight update (plain IEEE arithmetic,
  * csrc/pdlp_detmath.h: the same bits on host and device) — for the CPU tests, which compare them with long-double libm
  * and with the oracle's separately written restatement.  Reference arithmetic: cupdlp_step.c:165-170 (libm). */

@@ -490,12 +490,12 @@ static void g_setup(Work* w, int layoutMode) {
   int* gCount = ialloc((long)(n > m ? n : m) + 1);
   if (w->slabA) {
     g_slab_cold(w->csrBeg, w->csrIdx, m, n, w->chunkA, gCold, gCount);
-    w->planA = ialloc(G_SLAB_BLOCKS + m / G_SLAB_BLOCK_CAP + 3); w->nPlanA = -g_slab_blocks(w->csrBeg, gCold, m, n, w->chunkA, G_SLAB_MAJOR_COST_ROWS, w->planA);
+    w->planA = ialloc(g_slab_blocks_room(m)); w->nPlanA = -g_slab_blocks(w->csrBeg, gCold, m, n, w->chunkA, G_SLAB_MAJOR_COST_ROWS, w->planA);
   }
   else w->planA = g_plan(w->csrBeg, m, w->chunkA, &w->nPlanA);
   if (w->slabAt) {
     g_slab_cold(w->cssBeg, w->cssIdx, n, m, w->chunkAt, gCold, gCount);
-    w->planAt = ialloc(G_SLAB_BLOCKS + n / G_SLAB_BLOCK_CAP + 3); w->nPlanAt = -g_slab_blocks(w->cssBeg, gCold, n, m, w->chunkAt, G_SLAB_MAJOR_COST_COLS, w->planAt);
+    w->planAt = ialloc(g_slab_blocks_room(n)); w->nPlanAt = -g_slab_blocks(w->cssBeg, gCold, n, m, w->chunkAt, G_SLAB_MAJOR_COST_COLS, w->planAt);
   }
   else w->planAt = g_plan(w->cssBeg, n, w->chunkAt, &w->nPlanAt);
   if (w->qnBeg) { /* N gathers x (n), majors = n */
@@ -504,7 +504,7 @@ static void g_setup(Work* w, int layoutMode) {
     w->chunkQ = w->slabQ ? G_SLAB_LONG : g_chunk_for(w->qnBeg[n]);
     if (w->slabQ) {
       g_slab_cold(w->qnBeg, w->qnIdx, n, n, w->chunkQ, gCold, gCount);
-      w->planQ = ialloc(G_SLAB_BLOCKS + n / G_SLAB_BLOCK_CAP + 3); w->nPlanQ = -g_slab_blocks(w->qnBeg, gCold, n, n, w->chunkQ, G_SLAB_MAJOR_COST_ROWS, w->planQ);
+      w->planQ = ialloc(g_slab_blocks_room(n)); w->nPlanQ = -g_slab_blocks(w->qnBeg, gCold, n, n, w->chunkQ, G_SLAB_MAJOR_COST_ROWS, w->planQ);
     }
     else w->planQ = g_plan(w->qnBeg, n, w->chunkQ, &w->nPlanQ);
   }

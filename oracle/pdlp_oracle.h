@@ -28,7 +28,7 @@ int pdlp_oracle_solve(const pdlp_problem_t* P, const pdlp_params_t* opt, pdlp_re
 int pdlp_oracle_solve_traced(const pdlp_problem_t* P, const pdlp_params_t* opt, pdlp_result_t* R,
                              pdlp_oracle_trace_fn trace, void* trace_ctx);
 
-/* block boundaries of the slab layout as the device-order mode models them; blockBeg needs 256 + nMajor / 16384 + 3 ints */
+/* block boundaries of the slab layout as the device-order mode models them; blockBeg needs 256 + nMajor / 16 + 3 ints */
 int pdlp_oracle_slab_blocks(int nMajor, int nMinor, const int* beg, const int* idx, int longLimit, int which, int* blockBeg);
 /* exp(x[i]) and log(x[i]) of the oracle's own plain-arithmetic functions (det_math.h) */
 void pdlp_oracle_det_exp_log(int n, const double* x, double* expOut, double* logOut);

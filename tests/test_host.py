@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_sizes_match_ctypes_mirror():
     lib = solver.lib()
     for which, ty in enumerate([abi.PdlpProblem, abi.PdlpParams, abi.PdlpResult, abi.PdlpIterStats, abi.PdlpPrepared,
-                              abi.PdlpSlabLayout, abi.PdlpMpsModel]):
+                              abi.PdlpSlabLayout, abi.PdlpMpsModel, abi.PdlpTaskPlan]):
         assert lib.pdlp_mi355x_sizeof(which) == C.sizeof(ty), ty.__name__
 
 
@@ -151,7 +151,7 @@ def _slab_to_coo(sl, n_major):
 
 def _slab_work(lens, long_limit, major_cost=2, cold=0):
     """pdlp_host.cpp slabMajorWork: entries + cold entries + the run-accumulation term + major_cost (2 for the operand by
-    rows, 6 for the transposed one); a long major: major_cost alone."""
+    rows, 10 for the transposed one); a long major: major_cost alone."""
     lens = np.asarray(lens, dtype=np.int64)
     return np.where(lens > long_limit, major_cost, lens + cold + (lens * np.minimum(lens, 64)) // 32 + major_cost)
 
@@ -171,7 +171,7 @@ def _cold_counts(beg, idx, n_minor, long_limit):
 
 def _oracle_blocks(beg, idx, n_major, n_minor, which, long_limit=256):
     """The slab block boundaries as the oracle's device-order mode models them (oracle/gpu_order.h, in C)."""
-    ob = np.zeros(256 + n_major // 16384 + 3, dtype=np.int32)
+    ob = np.zeros(256 + n_major // 16 + 3, dtype=np.int32)
     b32 = np.ascontiguousarray(beg, dtype=np.int32)
     i32 = np.ascontiguousarray(idx if len(idx) else [0], dtype=np.int32)
     nb = O.oracle().pdlp_oracle_slab_blocks(n_major, n_minor, b32.ctypes.data_as(abi.c_i32p), i32.ctypes.data_as(abi.c_i32p), long_limit,
@@ -188,6 +188,9 @@ def _slab_partition_restated(beg, n_major, n_minor, long_limit, major_cost=2, co
     wave_cap = min(1 << (32 - mb), 16384)
     block_cap = min(16384, wave_cap * 16)
     nb = max(min(-(-n_major // 256), 256), -(-n_major // block_cap))
+    fill_cap = block_cap
+    if major_cost == 10 and nb > 0:  # the transposed operand: no block above 5/4 of the mean number of majors (never below 256)
+        fill_cap = min(block_cap, max(-(-5 * n_major // (4 * nb)), 256))
 
     def fill(r0, r1, units, cap, non_empty):
         out, r, rem = [r0], r0, int(cost[r0:r1].sum())
@@ -205,7 +208,7 @@ def _slab_partition_restated(beg, n_major, n_minor, long_limit, major_cost=2, co
             rem -= acc
             out.append(r)
         return out
-    bb = fill(0, n_major, nb, block_cap, True)
+    bb = fill(0, n_major, nb, fill_cap, True)
     wb = [0]
     for b in range(nb):
         wb += fill(bb[b], bb[b + 1], 16, wave_cap, False)[1:]
@@ -346,6 +349,76 @@ def test_slab_partition_balances_skewed_majors():
         w = wb[16 * b:16 * b + 17]
         ww = np.array([cost[w[k]:w[k + 1]].sum() for k in range(16)])
         assert ww.max() <= ww.mean() + cost.max()
+
+
+def test_slab_partition_caps_the_major_count_of_the_transposed_operand():
+    """A stretch of one-entry columns (the block of config d that owned 2.1x the mean number of columns and ended the fused
+    launch 3 us late): on the transposed operand no block owns more than 5/4 of the mean number of majors — the operand by
+    rows is cut by work alone — and product, restated rule and the oracle's C restatement agree on both."""
+    rng = np.random.default_rng(11)
+    n, m = 150000, 80000
+    lens = np.minimum((rng.pareto(1.3, n) * 3 + 2).astype(np.int64), 200)
+    lens[40000:75000] = 1
+    a_start = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    a_index = np.concatenate([np.sort(rng.choice(m, size=k, replace=False)) for k in lens]).astype(np.int32)
+    inf = float("inf")
+    lp = L.HighsLp(num_col=n, num_row=m, a_start=a_start, a_index=a_index, a_value=rng.standard_normal(len(a_index)),
+                   col_cost=np.ones(n), col_lower=np.zeros(n), col_upper=np.ones(n), row_lower=np.full(m, -inf),
+                   row_upper=np.ones(m)).normalise()
+    P = solver.Prepared(lp, pdlp_features_off=1)
+    assert P.n == n
+    for which in (0, 1):
+        beg, idx = (P.csr_beg, P.csr_idx) if which == 0 else (P.csc_beg, P.csc_idx)
+        n_major, n_minor = (P.m, P.n) if which == 0 else (P.n, P.m)
+        sl = P.slab_layout(which)
+        cold = _cold_counts(beg, idx, n_minor, 256)
+        nb, mb, wb = _slab_partition_restated(beg, n_major, n_minor, 256, 10 if which else 2, cold)
+        assert nb == sl["n_blocks"] == 256 and np.array_equal(wb, sl["wave_beg"])
+        assert np.array_equal(_oracle_blocks(beg, idx, n_major, n_minor, which), wb[::16])
+        per_block = np.diff(wb[::16])
+        if which == 1:
+            cap = -(-5 * n_major // (4 * 256))
+            assert per_block.max() == cap  # the cap binds on the one-entry stretch ...
+            uncapped = np.diff(_slab_partition_restated(beg, n_major, n_minor, 256, 9, cold)[2][::16])
+            assert uncapped.max() > 1.5 * n_major / 256  # ... where work alone would hand one block far more columns
+        assert wb[0] == 0 and wb[-1] == n_major and per_block.min() >= 1
+
+
+def test_segment_tasks_are_dealt_to_the_xcd_their_entries_live_in():
+    """The segment tasks of a slab operand's long majors (block-angular LP with dense linking rows — bench.py --config c in
+    small): every segment of every long major exactly once, segment sums in slots of their own, whole task workgroups,
+    and — the point of the deal — a task sits in a workgroup of the XCD whose streaming blocks gather from the stretch of
+    the vector its entries lie in, no XCD carrying more than its share of the workgroups."""
+    from lpgen import structured_lp
+    lp = structured_lp(3, commodities=32, nodes=512, arcs=4096, link_rows=48, link_nnz=4096, extra_rows=64)  # 8 segments per linking row
+    P = solver.Prepared(lp)
+    for balance in (1, 0):
+        T = P.task_plan(0, balance)
+        tk, g, nb = T["tasks"], T["task_group"], T["n_blocks"]
+        lb, li = T["long_beg"], T["long_idx"]
+        assert T["n_long"] == 48 and T["n_tasks"] % g == 0 and g in (1, 2, 4, 8, 16)
+        real = tk[tk[:, 2] >= 0]
+        assert len(real) > T["n_tasks"] - g  # one workgroup is not full at most
+        slots = real[:, 3] + real[:, 7]
+        assert len(set(slots.tolist())) == len(slots) and slots.max() < T["n_seg_slots"] == len(real)
+        for c in range(T["n_long"]):
+            mine = real[real[:, 2] == c]
+            mine = mine[np.argsort(mine[:, 7])]
+            n_seg = -(-(lb[c + 1] - lb[c]) // 512)
+            assert len(mine) == n_seg and np.array_equal(mine[:, 7], np.arange(n_seg)) and np.all(mine[:, 4] == n_seg)
+            assert mine[0, 0] == lb[c] and mine[-1, 1] == lb[c + 1] and np.array_equal(mine[1:, 0], mine[:-1, 1])
+            assert np.all(mine[:, 6] == (1 if n_seg == 1 else 0)) and len(set(mine[:, 3].tolist())) == 1
+        # XCD of a task's workgroup vs the owner of the tile its middle entry lies in
+        grp = np.nonzero(tk[:, 2] >= 0)[0] // g
+        xcd = (nb + grp) % 8
+        mid = li[(real[:, 0] + real[:, 1]) // 2]
+        home = T["tile_owner"][np.minimum(mid >> T["tile_log2"], len(T["tile_owner"]) - 1)]
+        assert (home == xcd).mean() > 0.9
+        per_xcd = np.bincount(xcd, minlength=8)
+        assert per_xcd.max() <= g * -(-(T["n_tasks"] // g) // 8)
+    # the tile owners follow the contiguous block -> XCD map: network block k's columns belong to the XCD that runs its rows
+    own = P.task_plan(0)["tile_owner"]
+    assert np.all(np.diff(own[:-1]) >= 0) and set(own.tolist()) == set(range(8))
 
 
 @pytest.mark.parametrize("corrupt", ["start0", "decreasing", "row_index", "overrun"])
