@@ -682,7 +682,8 @@ LongPlan planSlabTasks(const std::vector<int32_t>& longBeg, const int32_t* longI
       while ((len + seg - 1) / seg > kMaxSeg) seg *= 2;
       segs += (len + seg - 1) / seg;
     }
-    while (taskGroup > 1 && segs / taskGroup < kSlabTargetBlocks) taskGroup /= 2;
+    // one task workgroup per CU where there are that many tasks: ceil(segments / 256) tasks each, 1 .. 16
+    taskGroup = (int32_t)std::min<int64_t>(kSlabWavesPerBlock, std::max<int64_t>(1, (segs + kSlabTargetBlocks - 1) / kSlabTargetBlocks));
   }
   std::vector<int32_t> all((size_t)nLong);
   for (int32_t c = 0; c < nLong; ++c) all[c] = c;

@@ -214,9 +214,11 @@ std::vector<int32_t> slabTileHistogram(const int32_t* beg, const int32_t* idx, c
                                        int32_t tileLog2, int32_t nTiles, std::vector<int32_t>& lo, std::vector<int32_t>& hi,
                                        std::vector<int32_t>& cnt);
 // The segment tasks of a slab operand's long majors.  longBeg / longIdx: the compact CSR of the long majors (nLong of
-// them), longMap: compact index -> major.  Tasks per workgroup (taskGroup, out): 16 — or, `balance`, halved until there
-// are at least as many task workgroups as CUs: they run NEXT to the streaming blocks (two per CU), and 128 of them on 256
-// CUs slow down half of the streaming blocks (bench.py --config c, A x+: blocks sharing their CU 37 us, the others 26.5).
+// them), longMap: compact index -> major.  Tasks per workgroup (taskGroup, out): 16 — or, `balance`, ceil(segments / 256),
+// at most 16: ONE task workgroup per CU.  They run NEXT to the streaming blocks (two blocks per CU), and 128 of them on 256
+// CUs slow down half of the streaming blocks (bench.py --config c, A x+: blocks sharing their CU 37 us, the others 26.5);
+// the fused A'y+ launch can only carry them as co-resident workgroups when there is at most one per CU (config d: 2 304
+// segments -> 256 workgroups of 9; round 5 ran 144 of 16 there and the launch waited for the 144 blocks that shared a CU).
 // tileOwner (nullptr: tasks in (major, segment) order): the XCD-affine deal of planLong, nSlabBlocks streaming blocks in
 // front of the task workgroups.
 LongPlan planSlabTasks(const std::vector<int32_t>& longBeg, const int32_t* longIdx, int32_t nLong, const int32_t* longMap, bool balance,

@@ -182,8 +182,9 @@ __device__ __forceinline__ void longBlock(const SpmvArgs& a, Epi<EPI>& epi, int 
   // (more, lighter task workgroups: every CU gets one next to its streaming block)
   const int g = L.taskGroup;
   const int sub = wave / g;
-  const int grp = many ? lb * (W / g) + sub : lb;
-  const bool mine = many || sub == 0;
+  const int per = W / g;  // whole groups per pass of W waves (`many`)
+  const int grp = many ? lb * per + sub : lb;
+  const bool mine = many ? sub < per : sub == 0;
   const int t = mine ? grp * g + (wave - sub * g) : L.nTasks;
   LongTask T;
   T.c = -1; T.pBeg = T.pEnd = 0; T.first = t; T.nSeg = 1; T.major = 0; T.contained = 1; T.seg = 0;
@@ -472,9 +473,10 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
   if (EPI == kPlain && !gateOpen(a.gate)) return;
   static_assert(GD >= 1 && NB >= GD + 2, "entry loads need two steps, gathers GD steps");
   const unsigned long long tProf0 = a.prof ? wall_clock64() : 0ull;
+  int profBlk = (int)blockIdx.x;  // (the LOGICAL block once it is known: the table is indexed like the partition)
   auto profStamp = [&](int k) {
     if (a.prof && threadIdx.x == 0 && (int)blockIdx.x < a.S.nBlocks) {
-      unsigned long long* q = a.prof + ((EPI == kAtyFused ? 1024 : 0) + (int)blockIdx.x) * 8;
+      unsigned long long* q = a.prof + ((EPI == kAtyFused ? 1024 : 0) + profBlk) * 8;
       if (k == 0) q[0] += 1;
       q[1 + k] += wall_clock64() - tProf0;
     }
@@ -504,6 +506,7 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
   const int blk = a.xcdMap ? xcdContiguousBlock(blockIdx.x, a.S.nBlocks) : (int)blockIdx.x;
+  profBlk = blk;
   const int mb = a.S.minorBits;
   const uint32_t mmask = (1u << mb) - 1u;
   const int gw = blk * kWaves + wave;
@@ -684,7 +687,8 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
     // Long columns in the fused trial: their segment tasks cannot be extra workgroups (those would have to be resident
     // next to the waiting blocks), so the streaming blocks take them — task group tb goes to block tb % nBlocks, one
     // task per wave, same lanes and sums as in the extra blocks of the other launches (longBlock).
-    const int nTB = (a.L.nTasks + kWaves - 1) / kWaves;  // passes of kWaves tasks (kWaves / taskGroup groups each)
+    const int perPass = kWaves / a.L.taskGroup;  // whole task groups per pass of the block's waves
+    const int nTB = ((a.L.nTasks + a.L.taskGroup - 1) / a.L.taskGroup + perPass - 1) / perPass;
     for (int tb = (int)blockIdx.x; tb < nTB; tb += a.S.nBlocks) {
       longBlock<EPI, kWaves>(a, epi, tb, &scratch[0][0], true);
       __syncthreads();

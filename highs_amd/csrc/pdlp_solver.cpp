@@ -517,6 +517,11 @@ void Solver::construct(const pdlp_problem_t& P, const void* id128) {
   tuneXcdMap(dA_, sw_, x_[0].get(), ax_[0].get(), stream_);
   tuneXcdMap(dAt_, sw_, y_[0].get(), sharded_ ? commBuf_.get() : aty_[0].get(), stream_);
   if (hasQoff_) tuneXcdMap(dQ_, sw_, x_[0].get(), nx_[0].get(), stream_);
+  if (getenv("PDLP_MI355X_SLAB_PROF") && rank_ == 0)  // (development: what the set-up chose, next to the per-block phase profile)
+    for (const DeviceMatrix* M : {&dA_, &dAt_})
+      fprintf(stderr, "slab operand %s: slab %d, blocks %d, XCD map %s, %s, long majors %d, tasks %d in workgroups of %d\n", M == &dA_ ? "A" : "A'",
+              (int)M->useSlab, M->useSlab ? M->slab.nBlocks : M->nBlocks, M->xcdMap ? "contiguous" : "round robin", M->noPace ? "free-running waves" : "paced",
+              M->nLong, M->nTasks, M->taskGroup);
   // 2-launch trial where the A' y grid is resident all at once (grid barrier inside the kernel); PDLP_MI355X_FUSED=0 forces
   // 3 launches.  Slab layout (one block per CU): on by default, 140.0 -> 135.0 us per iteration at 1M x 1M.  Stream
   // layout: off by default — measured in round 3 the barrier + decision tail costs what the separate launch did
@@ -593,8 +598,6 @@ void Solver::uploadProblem() {
   const int32_t n = F_.n;
   dAt_.majorCost = kSlabMajorCostCols;
   if (!sharded_) {
-    // (the fused trial runs the long columns' tasks inside its streaming blocks — but it is not used with an off-diagonal Hessian)
-    dAt_.balanceTaskBlocks = sw_.fused == 0 || hasQoff_;
     dA_.upload(F_.csr, F_.m, n, sw_, stream_);
     dAt_.upload(F_.cscSorted, n, F_.m, sw_, stream_);
   } else {
@@ -671,7 +674,6 @@ void Solver::downloadForm(DeviceProblem& D, StandardForm& F, hipStream_t s) {
 
 void Solver::uploadProblemFromDevice(DeviceProblem& D) {
   dAt_.majorCost = kSlabMajorCostCols;
-  dAt_.balanceTaskBlocks = sharded_ || sw_.fused == 0 || hasQoff_;  // (the fused trial runs the long columns' tasks inside its streaming blocks)
   dA_.buildFromDevice(D.A, sw_, stream_);
   dAt_.buildFromDevice(D.At, sw_, stream_);
   cost_ = std::move(D.cost); rhs_ = std::move(D.rhs); lower_ = std::move(D.lower); upper_ = std::move(D.upper);

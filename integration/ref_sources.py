@@ -15,11 +15,14 @@ WANT = ["basiclu_sources", "ipx_sources", "cupdlp_sources", "hipo_sources", "fac
         "highs_sources"]
 # what the drop-in replaces: the cuPDLP-C wrapper + vendored C, the HiPDLP wrapper + hipdlp/*, the MPS reader TU
 DROP = re.compile(r"^(pdlp/CupdlpWrapper\.cpp|pdlp/cupdlp/|pdlp/HiPdlpWrapper\.cpp|pdlp/hipdlp/|io/FilereaderMps\.cpp)")
+# --dropped: exactly those TUs instead — what the UNMODIFIED reference library (integration/Makefile libhighs_reference.so.1:
+# the goldens' generator and the CPU baseline of Highs::run()) adds to the common object list
+only_dropped = len(sys.argv) > 2 and sys.argv[2] == "--dropped"
 out = []
 for name in WANT:
     m = re.search(r"set\(%s\s+(.*?)\)" % name, txt, re.S)
     for tok in m.group(1).split():
-        if re.search(r"\.(c|cc|cpp)$", tok) and not DROP.search(tok) and tok not in out:
+        if re.search(r"\.(c|cc|cpp)$", tok) and bool(DROP.search(tok)) == only_dropped and tok not in out:
             out.append(tok)
 keep_reader = len(sys.argv) > 2 and sys.argv[2] == "--with-reader"
 if keep_reader:

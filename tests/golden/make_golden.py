@@ -8,7 +8,8 @@ Outputs : tests/golden/instances/<name>.npz   the LP as HighsLp arrays (CSC)
              - "highs": what the reference BINARY prints for
                `highs --solver=pdlp --presolve=off <mps>` (model status, PDLP
                iterations, objective, P-D objective error), if a reference build
-               exists at $HIGHS_REF_BIN (default /tmp/ref_build/bin/highs);
+               exists at $HIGHS_REF_BIN (default integration/_build/highs_reference_cli:
+               `make -C integration reference`);
              - "cupdlp": full-precision outputs of the real cuPDLP-C core
                compiled from the reference sources (oracle/_ref), default
                tolerances 1e-7: iterations, trials, term code, cuPDLP primal /
@@ -31,7 +32,8 @@ import oraclelib as O  # noqa: E402
 from highs_amd import lp as L  # noqa: E402
 
 REF = "/root/reference"
-HIGHS = os.environ.get("HIGHS_REF_BIN", "/tmp/ref_build/bin/highs")
+# the UNMODIFIED reference binary, built from /root/reference by this repository's own recipe: make -C integration reference
+HIGHS = os.environ.get("HIGHS_REF_BIN", os.path.join(ROOT, "integration", "_build", "highs_reference_cli"))
 NAMES = ["25fv47", "adlittle", "afiro", "avgas", "blending", "chip", "e226", "scrs8", "sctest", "shell", "stair",
          "standata", "standgub"]
 # largest LP bundled with the reference (BASELINE.json config 3 stand-in: pds-100 is not in the tree);

@@ -16,8 +16,10 @@ import sys
 import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
-HIGHS = os.environ.get("HIGHS_REF_BIN", "/tmp/ref_build/bin/highs")
+# the UNMODIFIED reference binary, built from /root/reference by this repository's own recipe: make -C integration reference
+HIGHS = os.environ.get("HIGHS_REF_BIN", os.path.join(ROOT, "integration", "_build", "highs_reference_cli"))
 NAMES = ["afiro", "adlittle", "avgas", "blending", "chip", "sctest", "shell", "standata", "standgub", "scrs8",
          "stair", "e226", "25fv47"]
 BUDGET = float(os.environ.get("HIPDLP_GOLDEN_BUDGET", "400"))

@@ -3,7 +3,7 @@
 gates solver="pdlp" to LPs), so parity of the QP prox path is pinned on the OPTIMAL OBJECTIVES of the
 reference's own QP solver: random convex QPs with a diagonal Hessian (tests/lpgen.py::random_diag_qp) are written
 as .mps with a QUADOBJ section and solved by the reference binary ($HIGHS_REF_BIN, default
-/tmp/ref_build/bin/highs; its default QP solver is the active-set `qpasm`).  Output: tests/golden/qp/qp<seed>.npz
+integration/_build/highs_reference_cli = `make -C integration reference`; its default QP solver is the active-set `qpasm`).  Output: tests/golden/qp/qp<seed>.npz
 (the model incl. the Hessian) and tests/golden/reference_qp.json (objective, model status).
 
 Round 3: Hessians with OFF-DIAGONAL entries — random sparse PSD Q = G'G + diag(d) on the same LPs
@@ -26,7 +26,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from highs_amd import lp as L  # noqa: E402
 from lpgen import random_diag_qp, random_sparse_qp  # noqa: E402
 
-HIGHS = os.environ.get("HIGHS_REF_BIN", "/tmp/ref_build/bin/highs")
+# the UNMODIFIED reference binary, built from /root/reference by this repository's own recipe: make -C integration reference
+HIGHS = os.environ.get("HIGHS_REF_BIN", os.path.join(ROOT, "integration", "_build", "highs_reference_cli"))
 
 
 def main():
