@@ -9,8 +9,8 @@ Goldens, from the REFERENCE's own code:
   "cupdlp":  the real cuPDLP-C core compiled from the reference sources (oracle/_ref) at the default tolerance with a
              time budget of REF_TIME_LIMIT seconds per instance: where it converges, iteration count and objectives; where
              it does not, the record says so (term_code) with the iterations it got through.
-The reference CLI here is integration/_build/highs_ref_cli (the reference's app/ + every reference TU except the two PDLP
-wrappers and the MPS reader front end; the simplex and QP solvers are the reference's).
+The reference CLI here is integration/_build/highs_reference_cli: the UNMODIFIED reference (app/RunHighs.cpp on
+libhighs_reference.so.1, `make -C integration reference` — nothing of this repository in it).
 
     python tests/golden/make_golden_hard.py   -> tests/golden/reference_hard.json, tests/golden/instances/*.npz
 """
@@ -30,14 +30,13 @@ sys.path.insert(0, HERE)
 import make_golden as MG  # noqa: E402
 from highs_amd import solver  # noqa: E402
 
-CLI = os.path.join(ROOT, "integration", "_build", "highs_ref_cli")
+CLI = os.environ.get("HIGHS_REF_BIN", os.path.join(ROOT, "integration", "_build", "highs_reference_cli"))
 NAMES = ["perold", "gas11", "primal1", "greenbea"]
 REF_TIME_LIMIT = float(os.environ.get("REF_TIME_LIMIT", "3000"))
 
 
 def simplex_record(mps):
-    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "integration", "_build") + ":" + os.path.join(ROOT, "highs_amd", "lib"))
-    out = subprocess.run([CLI, "--solver=simplex", mps], capture_output=True, text=True, env=env).stdout
+    out = subprocess.run([CLI, "--solver=simplex", mps], capture_output=True, text=True).stdout
     g = lambda pat: (re.search(pat, out) or [None, None])[1]
     return {"model_status": g(r"Model status\s*:\s*(.+)"), "objective_value": float(g(r"Objective value\s*:\s*(\S+)") or "nan"),
             "is_qp": bool(re.search(r"^QP ", out, re.M))}

@@ -2,9 +2,8 @@
 """Golden digests of what the REFERENCE's MPS reader builds (run in the build container only).
 
 Reads every MPS file of the reference's check/instances and of tests/golden/mps_cases/ (hand-written edge cases of
-this repository) with the reference itself — Highs_readModel of the C API in integration/_build/libhighs_ref_reader.so, a
-libhighs linked from the reference's own object files (integration/build_dropin.sh; file reading is untouched
-reference code: io/FilereaderMps.cpp -> io/HMpsFF.cpp, fixed-format fallback io/HMPSIO.cpp) — and stores
+this repository) with the reference itself — Highs_readModel of the C API in integration/_build/libhighs_reference.so.1, the
+UNMODIFIED reference library (`make -C integration reference`: every TU compiled from /root/reference; file reading: io/FilereaderMps.cpp -> io/HMpsFF.cpp, fixed-format fallback io/HMPSIO.cpp) — and stores
 dimensions, sense, offset and sha256 digests of every array of the incumbent model in
 tests/golden/reference_mps.json.  tests/test_mps_reader.py compares the library's multi-threaded reader
 (pdlp_mi355x_read_mps) with these records after applying the two normalisations Highs::passModel performs on
@@ -24,7 +23,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF_INSTANCES = "/root/reference/check/instances"
-LIBHIGHS = os.path.join(ROOT, "integration", "_build", "libhighs_ref_reader.so")
+LIBHIGHS = os.path.join(ROOT, "integration", "_build", "libhighs_reference.so.1")  # the unmodified reference: make -C integration reference
 OUT = os.path.join(HERE, "reference_mps.json")
 
 
