@@ -117,7 +117,7 @@ void solveSharded(const pdlp_problem_t& P, const pdlp_params_t& opt, int G, pdlp
   if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0)
     throw std::runtime_error("pdlp_mi355x: no HIP device available (this library has no CPU fallback)");
   // PDLP_MI355X_FOLD_DEVICES=1 (tests on a 1-GPU box): several ranks share a physical device
-  const char* f = getenv("PDLP_MI355X_FOLD_DEVICES");
+  const char* f = pdlp::devEnv("PDLP_MI355X_FOLD_DEVICES");
   const bool fold = f && atoi(f) != 0;
   if (!fold && opt.device + G > nDev)
     throw std::runtime_error("pdlp_mi355x: num_devices = " + std::to_string(G) + " starting at device " +
@@ -131,7 +131,7 @@ void solveSharded(const pdlp_problem_t& P, const pdlp_params_t& opt, int G, pdlp
   std::vector<std::string> errors((size_t)G);
   std::vector<pdlp_result_t> scratch((size_t)G);
   // PDLP_MI355X_VERIFY_RANKS=1 (tests): every rank returns its full solution, compared bit for bit below
-  const char* vr = getenv("PDLP_MI355X_VERIFY_RANKS");
+  const char* vr = pdlp::devEnv("PDLP_MI355X_VERIFY_RANKS");
   const bool verify = vr && atoi(vr) != 0;
   std::vector<std::vector<double>> keep;
   if (verify) keep.resize((size_t)G * 4);

@@ -257,9 +257,21 @@ __device__ __forceinline__ double ldAgent(const double* p) {
 // launches (Solver::syncState).
 constexpr unsigned long long kBarPoison = 1ull << 62;
 enum : int { kBarOk = 0, kBarFailed = 1, kBarBroken = 2 };
+// gridArrive + gridWait = gridBarrier.  Apart: a block that has loads in flight which nobody else needs (operands it
+// prefetches for the phase behind the barrier) arrives FIRST and issues them afterwards — the arrival waits for vmcnt(0),
+// and with the prefetches in front of it that wait was a whole HBM round trip under load (round 6: the fused trial released
+// its barrier 2-5 us after the last block's epilogue).
 template <bool LOCAL = false>
-__device__ __forceinline__ int gridBarrier(unsigned long long* bar, int blk, int nBlocks, unsigned long long epoch, int lane,
-                                            unsigned long long limitTicks) {
+__device__ __forceinline__ void gridArrive(unsigned long long* bar, int blk, unsigned long long epoch, int lane) {
+  if (lane == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this block's published words have landed
+    if (LOCAL) *reinterpret_cast<volatile unsigned long long*>(bar + blk) = epoch;
+    else __hip_atomic_store(bar + blk, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+template <bool LOCAL = false>
+__device__ __forceinline__ int gridWait(unsigned long long* bar, int blk, int nBlocks, unsigned long long epoch, int lane,
+                                         unsigned long long limitTicks) {
   auto ld = [&](const unsigned long long* p) -> unsigned long long {
     if (!LOCAL) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned long long v;
@@ -270,18 +282,30 @@ __device__ __forceinline__ int gridBarrier(unsigned long long* bar, int blk, int
     if (LOCAL) *reinterpret_cast<volatile unsigned long long*>(p) = v;
     else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
-  if (lane == 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this block's published words have landed
-    st(bar + blk, epoch);
-  }
   const unsigned long long t0 = wall_clock64();
+  // The words of a lane (up to kSweepPer, i.e. 512 blocks) are loaded back to back and looked at afterwards: one memory
+  // round trip per sweep whatever the number of words (measured the same as the plain loop at 256 and 512 words, round 6 —
+  // what the release waited for was the arrival, see gridArrive).
+  constexpr int kSweepPer = 8;
   for (uint32_t spins = 0;; ++spins) {
     bool ok = true, bad = false, stale = false;
-    for (int i = lane; i < nBlocks; i += kWave) {
-      const unsigned long long v = ld(bar + i);
+    auto look = [&](unsigned long long v) {
       ok = ok && v >= epoch;
       bad = bad || (v & kBarPoison) != 0;
       stale = stale || ((v & kBarPoison) != 0 && (v & ~kBarPoison) < epoch);
+    };
+    const int nB = __builtin_amdgcn_readfirstlane(nBlocks);
+    if (!LOCAL && nB <= kSweepPer * kWave) {
+      unsigned long long v[kSweepPer];
+#pragma unroll
+      for (int k = 0; k < kSweepPer; ++k) {  // clamped; the condition is wave-uniform (scalar branch): all loads in flight together
+        const int i = lane + k * kWave;
+        v[k] = (k * kWave < nB) ? ld(bar + (i < nB ? i : nB - 1)) : epoch;
+      }
+#pragma unroll
+      for (int k = 0; k < kSweepPer; ++k) look(v[k]);
+    } else {
+      for (int i = lane; i < nBlocks; i += kWave) look(ld(bar + i));
     }
     if (__any(stale)) return kBarBroken;
     if (__any(bad)) return kBarFailed;
@@ -295,6 +319,13 @@ __device__ __forceinline__ int gridBarrier(unsigned long long* bar, int blk, int
       return kBarFailed;
     }
   }
+}
+
+template <bool LOCAL = false>
+__device__ __forceinline__ int gridBarrier(unsigned long long* bar, int blk, int nBlocks, unsigned long long epoch, int lane,
+                                            unsigned long long limitTicks) {
+  gridArrive<LOCAL>(bar, blk, epoch, lane);
+  return gridWait<LOCAL>(bar, blk, nBlocks, epoch, lane, limitTicks);
 }
 
 // Roll call at the START of a launch whose workgroups will meet at grid barriers: before it has written anything,

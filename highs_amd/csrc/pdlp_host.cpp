@@ -6,10 +6,26 @@
 #include <functional>
 #include <cmath>
 #include <limits>
+#include <mutex>
+#include <set>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 
 namespace pdlp {
+
+const char* devEnv(const char* name) {
+  const char* v = getenv(name);
+  if (!v) return nullptr;
+  const char* d = getenv("PDLP_MI355X_DEV");
+  if (d && atoi(d) != 0) return v;
+  static std::mutex mu;
+  static std::set<std::string> told;
+  std::lock_guard<std::mutex> g(mu);
+  if (told.insert(name).second)
+    fprintf(stderr, "pdlp_mi355x: %s is a development switch and is ignored (set PDLP_MI355X_DEV=1 to enable development switches)\n", name);
+  return nullptr;
+}
 
 void logLineV(const pdlp_params_t& opt, int level, const char* fmt, va_list ap) {
   if (!opt.log_callback) {
@@ -535,7 +551,7 @@ void fillByWork(const int32_t* beg, const int32_t* cold, int32_t longLimit, int3
 
 int64_t slabMajorWork(int32_t len, int32_t nCold, int32_t longLimit, int32_t majorCost) {
   if (len > longLimit) return majorCost;  // (its segment tasks run elsewhere)
-  return (int64_t)len + nCold + ((int64_t)len * std::min(len, 64)) / 32 + majorCost;
+  return (int64_t)len + (int64_t)nCold * (kSlabColdWeight - 1) + ((int64_t)len * std::min(len, 64)) / 32 + majorCost;
 }
 
 void slabColdCounts(const int32_t* beg, const int32_t* idx, int32_t nMajor, int32_t nMinor, int32_t longLimit, int32_t* cold) {
@@ -572,14 +588,10 @@ SlabPartition slabPartition(const int32_t* beg, const int32_t* cold, int32_t nMa
   nB = std::min<int64_t>(nB, kSlabTargetBlocks);
   nB = std::max<int64_t>(nB, ((int64_t)nMajor + blockCap - 1) / blockCap);
   P.nBlocks = (int32_t)nB;
-  // the transposed operand: no block owns more than 5/4 of the mean number of majors (see kSlabColsCapNum)
-  int64_t fillCap = blockCap;
-  if (majorCost == kSlabMajorCostCols && nB > 0)
-    fillCap = std::min<int64_t>(blockCap, std::max<int64_t>(((int64_t)kSlabColsCapNum * nMajor + kSlabColsCapDen * nB - 1) / (kSlabColsCapDen * nB), kSlabMinRowsPerBlock));
   P.waveBeg.assign((size_t)nB * kSlabWavesPerBlock + 1, 0);
   if (nB == 0) return P;
   std::vector<int32_t> blockBeg((size_t)nB + 1);
-  fillByWork(beg, cold, longLimit, majorCost, 0, nMajor, (int32_t)nB, fillCap, true, blockBeg.data());
+  fillByWork(beg, cold, longLimit, majorCost, 0, nMajor, (int32_t)nB, blockCap, true, blockBeg.data());
   for (int32_t b = 0; b < (int32_t)nB; ++b) {
     fillByWork(beg, cold, longLimit, majorCost, blockBeg[b], blockBeg[b + 1], kSlabWavesPerBlock, waveCap, false,
                P.waveBeg.data() + (size_t)b * kSlabWavesPerBlock);

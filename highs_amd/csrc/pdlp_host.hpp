@@ -15,8 +15,10 @@
 #include <vector>
 
 #include "../../include/pdlp_mi355x.h"
+#include "pdlp_env.hpp"
 
 namespace pdlp {
+
 
 // One formatted log line to the caller's sink (pdlp_params_t::log_callback, e.g. highsLogUser) or, without
 // one, to stdout like the reference's cuPDLP-C.
@@ -154,34 +156,32 @@ constexpr int32_t kSlabMinRowsPerBlock = 256;
 // ~10, most of them behind the grid barrier) differ: with one value for both, config d lost 3 us on one launch or the
 // other; 6 / 10 / 16 for the transposed operand: config d 72.3 / 70.6-71.0 / 71.4 us per iteration, config c unchanged
 constexpr int32_t kSlabMajorCostRows = 2, kSlabMajorCostCols = 10;
-// The transposed operand's launch does the next primal step of every column of the block BEHIND its grid barrier, where
-// nothing overlaps it: a block of many one-entry columns is at the mean WORK and still the launch's straggler (config d,
-// round 5: one block owned 4 690 columns, 2.1x the mean, and ended 3 us after the others).  So on that operand (majorCost =
-// kSlabMajorCostCols) no block takes more than 5/4 of the mean number of majors per block (never fewer than
-// kSlabMinRowsPerBlock); the blocks behind it share what it leaves, by work as before.
-constexpr int32_t kSlabColsCapNum = 5, kSlabColsCapDen = 4;
 
 // The partition of the majors over blocks and waves.  Work of a major of len entries =
-//     len + cold + len * min(len, 64) / 32 + majorCost            (majorCost alone for a long major)
+//     len + 3 cold + len * min(len, 64) / 32 + majorCost          (majorCost alone for a long major)
 //   * len * min(len, 64) / 32: the entries of a run of equal majors inside a 64-entry group are added by ONE lane, so a
 //     group made of one run of 64 costs about three times a group of eight runs of eight (config d, blocks of equal ENTRY
 //     counts: the block with the longest rows still streamed 1.66x the mean time);
-//   * cold: its COLD entries count twice.  Cold = kSlabFar or more minors away from the major's middle entry AND in a
-//     minor that at most kSlabHotCount majors touch: the gather leaves the part of the gathered vector the block works in
-//     and meets nobody else's (config c: the block that owns 512 rows of 12 random columns ended 7 us after the others).
+//   * cold: its COLD entries count kSlabColdWeight = 4 times.  Cold = kSlabFar or more minors away from the major's middle
+//     entry AND in a minor that at most kSlabHotCount majors touch: the gather leaves the part of the gathered vector the
+//     block works in and meets nobody else's — a miss all the way to HBM, and a wave has ONE group of gathers in flight, so
+//     a group of cold entries is a memory round trip of its own (config c: the block that owns 512 rows of 12 random
+//     columns ended 7 us after the others in round 5; at weight 2, once the XCD-affine tasks had taken the wasted traffic
+//     out of the launch, still 4 us — 34.1 against a mean of 29.8; weight 3 / 4 on one box: 32.3 / 32.6, launch 35.0 ->
+//     33.5 / 33.6 us, round 6).
 //     Far entries in minors that many majors touch — the dense columns of config d, the dense rows of config c seen from
 //     its columns — are the hottest lines of the vector and cost nothing extra (a span-only rule measured worse there:
 //     profiles/r05_development_measurements.md section 4);
 //   * majorCost: the epilogue, kSlabMajorCostRows / Cols above.
 // nBlocks = ceil(nMajor / 256) capped at 256 (more only when 256 blocks of 16384 majors do not hold the operand).
 // Blocks are filled one after the other: block b takes majors while it is closer to ceil(work left / blocks left)
-// with the next major than without, but at least one, at most kSlabBlockRowCap (the transposed operand: at most 5/4 of
-// the mean, kSlabColsCapNum), and never so few / many that the blocks behind it could not hold / would not get the rest; the 16 waves of a block are filled the same way from the
+// with the next major than without, but at least one, at most kSlabBlockRowCap, and never so few / many that the
+// blocks behind it could not hold / would not get the rest; the 16 waves of a block are filled the same way from the
 // block's majors (cap: 2^(32 - minorBits) majors, the local-major field of an entry).  Sequential and exact in
 // integers: the device-side set-up (pdlp_setup.hip) counts the cold entries with two small kernels, downloads them
 // with the major starts (8 bytes per major) and calls this same function; oracle/gpu_order.h restates it.
 int64_t slabMajorWork(int32_t len, int32_t nCold, int32_t longLimit, int32_t majorCost);
-constexpr int32_t kSlabFar = 1 << 17, kSlabHotCount = 64;
+constexpr int32_t kSlabFar = 1 << 17, kSlabHotCount = 64, kSlabColdWeight = 4;
 // cold[r] for every major r (0 for long and single-entry majors)
 void slabColdCounts(const int32_t* beg, const int32_t* idx, int32_t nMajor, int32_t nMinor, int32_t longLimit, int32_t* cold);
 struct SlabPartition {

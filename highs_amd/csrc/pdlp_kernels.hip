@@ -487,6 +487,10 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
   if ((int)blockIdx.x >= a.S.nBlocks) {  // the extra blocks: one segment task of a long major per wave
     Epi<EPI> epiL(a);
     longBlock<EPI, kWaves>(a, epiL, (int)blockIdx.x - a.S.nBlocks, reinterpret_cast<double*>(smem));
+    if (a.prof && threadIdx.x == 0 && (int)blockIdx.x - a.S.nBlocks < 512) {  // (development: when the task workgroups are done, rows 512.. of the table)
+      unsigned long long* q = a.prof + ((EPI == kAtyFused ? 1024 : 0) + 512 + (int)blockIdx.x - a.S.nBlocks) * 8;
+      q[0] += 1; q[1] += wall_clock64() - tProf0;
+    }
     if (EPI == kAtyFused) {
       // a task workgroup of the fused launch: what it published (A'y+ of its long columns, their contributions) has landed;
       // it arrives at the grid barrier the streaming blocks wait at — and leaves (it needs nothing from behind the barrier)
@@ -663,26 +667,8 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
       if (rBase + lr < rEnd && !longMajor(rBase + lr)) epi.apply(rBase + lr, acc[lr], more[k]);
     }
   }
-  if (EPI == kAtyFused && kFixEarly) {  // xSum of the own columns: in flight across the barrier and the decision
-#pragma unroll
-    for (int k = 0; k < kSlabPre; ++k) {
-      const int r0_ = rBase + tid + k * kSlabThreads;
-      fix[k].d = ldStream(a.v.xSum + (r0_ < rEnd ? r0_ : rEnd - 1));
-    }
-  }
   epi.template finish<kSlabThreads>(blk, scratch);
   profStamp(1);
-  if (EPI == kAtyFused && !kFixEarly) {
-    // (the 64-register variant: the stream's pipeline registers are free now — the operands of the next primal step are
-    // fetched here, in flight across the grid barrier and the decision instead of behind them)
-#pragma unroll
-    for (int k = 0; k < kSlabPre; ++k) {
-      const int r0_ = rBase + tid + k * kSlabThreads;
-      const int r = r0_ < rEnd ? r0_ : rEnd - 1;
-      fix[k].a = ldStream(a.v.cost + r); fix[k].b = ldStream(a.v.lower + r); fix[k].c = ldStream(a.v.upper + r);
-      fix[k].d = ldStream(a.v.xSum + r); fix[k].e = a.v.qdiag ? ldStream(a.v.qdiag + r) : 0.0;
-    }
-  }
   if (EPI == kAtyFused && !TWO && a.inlineTasks) {  // (the 64-register variant carries task workgroups instead)
     // Long columns in the fused trial: their segment tasks cannot be extra workgroups (those would have to be resident
     // next to the waiting blocks), so the streaming blocks take them — task group tb goes to block tb % nBlocks, one
@@ -696,14 +682,38 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave's published words have landed before the block arrives
     __syncthreads();
   }
+  // ---- every block's partials in HBM -> decision (identical in every block) -> the next trial's primal step ----
+  // The block ARRIVES at the grid barrier before it prefetches anything for the phase behind it: the arrival waits for this
+  // wave's memory operations (vmcnt(0)), and with the operand loads of the next primal step issued in front of it that wait
+  // was an HBM round trip under load — every block's, so the release came 2.7 us (config b) to 5 us (config d, ten loads
+  // per thread) after the last epilogue (round 6).
+  if (EPI == kAtyFused && wave == 0)
+    gridArrive(a.bar, (int)blockIdx.x, (unsigned long long)a.st->nTrials + 1ull, lane);
+  if (EPI == kAtyFused && kFixEarly) {  // xSum of the own columns: in flight across the barrier and the decision
+#pragma unroll
+    for (int k = 0; k < kSlabPre; ++k) {
+      const int r0_ = rBase + tid + k * kSlabThreads;
+      fix[k].d = ldStream(a.v.xSum + (r0_ < rEnd ? r0_ : rEnd - 1));
+    }
+  }
+  if (EPI == kAtyFused && !kFixEarly) {
+    // (the 64-register variant: the stream's pipeline registers are free now — the operands of the next primal step are
+    // fetched here, in flight across the grid barrier and the decision instead of behind them)
+#pragma unroll
+    for (int k = 0; k < kSlabPre; ++k) {
+      const int r0_ = rBase + tid + k * kSlabThreads;
+      const int r = r0_ < rEnd ? r0_ : rEnd - 1;
+      fix[k].a = ldStream(a.v.cost + r); fix[k].b = ldStream(a.v.lower + r); fix[k].c = ldStream(a.v.upper + r);
+      fix[k].d = ldStream(a.v.xSum + r); fix[k].e = a.v.qdiag ? ldStream(a.v.qdiag + r) : 0.0;
+    }
+  }
   if (EPI == kAtyFused) {
-    // ---- every block's partials in HBM -> decision (identical in every block) -> the next trial's primal step ----
     double(*tscr)[kVecThreads / kWave] = reinterpret_cast<double(*)[kVecThreads / kWave]>(&scratch[2][0]);
     DevState* sh = reinterpret_cast<DevState*>(&tscr[4][0]);
     int* barVerdict = reinterpret_cast<int*>(reinterpret_cast<char*>(sh) + ((sizeof(DevState) + 7) / 8) * 8);
     if (wave == 0) {
       const int nExp = a.S.nBlocks + a.coTaskBlocks + (a.st->nTrials + 1 == a.faultTrial ? 1 : 0);
-      const int verdict = gridBarrier(a.bar, (int)blockIdx.x, nExp, (unsigned long long)a.st->nTrials + 1ull, lane, a.barLimit);
+      const int verdict = gridWait(a.bar, (int)blockIdx.x, nExp, (unsigned long long)a.st->nTrials + 1ull, lane, a.barLimit);
       if (lane == 0) *barVerdict = verdict;
     }
     {  // the state record -> LDS, one word per thread (no register copy of the 50-word record)
@@ -1121,13 +1131,13 @@ unsigned long long* slabProf() {
   static unsigned long long* prof = [] {
     unsigned long long* p = nullptr;
     constexpr size_t kWords = 2 * 1024 * 8;
-    if (getenv("PDLP_MI355X_SLAB_PROF") && hipMalloc((void**)&p, kWords * 8) == hipSuccess) {
+    if (devEnv("PDLP_MI355X_SLAB_PROF") && hipMalloc((void**)&p, kWords * 8) == hipSuccess) {
       (void)hipMemset(p, 0, kWords * 8);
       static unsigned long long* keep = p;
       atexit([] {
         std::vector<unsigned long long> h(kWords);
         if (hipMemcpy(h.data(), keep, kWords * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
-        if (const char* path = getenv("PDLP_MI355X_SLAB_PROF"); path && path[0] != '1') {  // a path: the raw table too
+        if (const char* path = devEnv("PDLP_MI355X_SLAB_PROF"); path && path[0] != '1') {  // a path: the raw table too
           if (FILE* f = fopen(path, "wb")) { fwrite(h.data(), 8, kWords, f); fclose(f); }
         }
         for (int half = 0; half < 2; ++half) {

@@ -11,6 +11,8 @@
 
 #include <cstdint>
 
+#include "pdlp_env.hpp"
+
 namespace pdlp {
 
 // Nonzeros staged through LDS per work block of the CSR-adaptive SpMV: 2048 for big operands (8 loads in

@@ -613,7 +613,7 @@ int32_t capped(int64_t len, int cap) {
 }
 int32_t meshBlocks(int64_t len) {  // producers
   static const int cap = [] {
-    const char* e = getenv("PDLP_MI355X_MESH_BLOCKS");
+    const char* e = devEnv("PDLP_MI355X_MESH_BLOCKS");
     const int v = e ? atoi(e) : 0;
     return v > 0 ? v : 128;
   }();
@@ -762,7 +762,7 @@ void Mesh::construct(int32_t rank, int32_t world, const void* id128, int32_t n, 
 
   // memory that is coherent between agents inside a kernel (PDLP_MI355X_MESH_MEM=finegrained|coarse are
   // diagnostic switches; coarse only for single-GPU protocol tests)
-  const char* mm = getenv("PDLP_MI355X_MESH_MEM");
+  const char* mm = devEnv("PDLP_MI355X_MESH_MEM");
   if (mm && !strcmp(mm, "coarse")) {
     PDLP_HIP(hipMalloc(&arena_, arenaBytes_));
   } else if (mm && !strcmp(mm, "finegrained")) {
@@ -810,7 +810,7 @@ void Mesh::construct(int32_t rank, int32_t world, const void* id128, int32_t n, 
   bool ok = true;
   int myDevice = 0;
   (void)hipGetDevice(&myDevice);
-  const char* forceIpc = getenv("PDLP_MI355X_MESH_FORCE_IPC");  // diagnostic: IPC also inside one process
+  const char* forceIpc = devEnv("PDLP_MI355X_MESH_FORCE_IPC");  // diagnostic: IPC also inside one process
   const bool allLocal = !(forceIpc && atoi(forceIpc) != 0);
   const bool exported = hipIpcGetMemHandle(&mine.handle, arena_) == hipSuccess;
   if (!exported) {
@@ -869,7 +869,7 @@ void Mesh::construct(int32_t rank, int32_t world, const void* id128, int32_t n, 
     for (int b = a + 1; b < world; ++b)
       if (seg->slot[a].busHash == 0ull || seg->slot[a].busHash == seg->slot[b].busHash) own = false;
   int fusedWait = own ? 1 : 0;
-  if (const char* e = getenv("PDLP_MI355X_MESH_FUSED_WAIT")) fusedWait = atoi(e) != 0 ? 1 : 0;
+  if (const char* e = devEnv("PDLP_MI355X_MESH_FUSED_WAIT")) fusedWait = atoi(e) != 0 ? 1 : 0;
   args_ = MeshArgs{dView_, state_, v_.G, v_.g, v_.waitTicks, meshFences(), fusedWait};
   hostBarrier(1, 60.0);
 }

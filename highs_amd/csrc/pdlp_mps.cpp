@@ -1,5 +1,6 @@
 // pdlp_mps.cpp — see pdlp_mps.hpp.  Reference behaviour followed: io/HMpsFF.cpp (free-format MPS parser).
 #include "pdlp_mps.hpp"
+#include "pdlp_env.hpp"
 
 #include <dlfcn.h>
 #include <fcntl.h>
@@ -682,7 +683,7 @@ ReadStatus Reader::open(const std::string& path) {
 
 ReadStatus Reader::run(const std::string& path) {
   t0 = lastT = std::chrono::steady_clock::now();
-  timing = std::getenv("PDLP_MI355X_MPS_TIMING") != nullptr;
+  timing = pdlp::devEnv("PDLP_MI355X_MPS_TIMING") != nullptr;
   M = Model();
   ReadStatus status = open(path);
   if (status == kReadOk) {

@@ -622,7 +622,7 @@ void launchSmallTrials(const MatView& A, const MatView& At, const IterVecs& v, D
   a.xcdA = A.xcdMap; a.xcdAt = At.xcdMap; a.maxTrials = maxTrials;
   static unsigned long long* prof = [] {  // PDLP_MI355X_SMALL_PROF=1: per-phase ticks, printed at exit (development)
     unsigned long long* p = nullptr;
-    if (getenv("PDLP_MI355X_SMALL_PROF") && hipMalloc((void**)&p, 64) == hipSuccess) {
+    if (devEnv("PDLP_MI355X_SMALL_PROF") && hipMalloc((void**)&p, 64) == hipSuccess) {
       (void)hipMemset(p, 0, 64);
       static unsigned long long* keep = p;
       atexit([] {

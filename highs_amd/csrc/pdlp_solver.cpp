@@ -274,37 +274,46 @@ void tuneXcdMap(DeviceMatrix& M, const DevSwitches& sw, const double* in, double
 // the rest are development and test switches.
 DevSwitches DevSwitches::fromEnv() {
   DevSwitches w;
+  // user switches: always read
   auto num = [](const char* name, int dflt) {
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
   };
-  auto str = [](const char* name) {
-    const char* e = getenv(name);
+  // development / test switches: only with PDLP_MI355X_DEV=1 (pdlp_host.hpp devEnv)
+  auto dev = [](const char* name, int dflt) {
+    const char* e = devEnv(name);
+    return e ? atoi(e) : dflt;
+  };
+  auto devStr = [](const char* name) {
+    const char* e = devEnv(name);
     return std::string(e ? e : "");
   };
-  w.graph = num("PDLP_MI355X_GRAPH", -1);
-  w.forceComm = num("PDLP_MI355X_FORCE_COMM", 0);
   w.gpuSetup = num("PDLP_MI355X_GPU_SETUP", -1);
-  w.slab = num("PDLP_MI355X_SLAB", -1);
-  w.slabW = num("PDLP_MI355X_SLAB_W", 0);
-  w.xcdMap = num("PDLP_MI355X_XCD_MAP", -1);
-  w.slabPace = num("PDLP_MI355X_SLAB_PACE", -1);
-  w.affineTasks = num("PDLP_MI355X_AFFINE_TASKS", 1);
   w.fused = num("PDLP_MI355X_FUSED", -1);
-  w.fusedStream = num("PDLP_MI355X_FUSED_STREAM", 0);
-  w.fusedCoTasks = num("PDLP_MI355X_FUSED_COTASKS", -1);
   w.persistent = num("PDLP_MI355X_PERSISTENT", -1);
-  w.xcdLocal = num("PDLP_MI355X_XCD_LOCAL", -1);
-  w.hierBarrier = num("PDLP_MI355X_HIER_BARRIER", -1);
-  w.deviceCheck = num("PDLP_MI355X_DEVICE_CHECK", -1);
-  w.checkSmall = num("PDLP_MI355X_CHECK_SMALL", -1);
-  w.primalInA = num("PDLP_MI355X_PRIMAL_IN_A", -1);
   w.barrierTimeoutMs = num("PDLP_MI355X_BARRIER_TIMEOUT_MS", 1000);
-  w.fault = num("PDLP_MI355X_FAULT", 0);
+  {
+    const char* e = getenv("PDLP_MI355X_EXCHANGE");
+    w.exchange = e ? e : "";
+  }
+  w.graph = dev("PDLP_MI355X_GRAPH", -1);
+  w.forceComm = dev("PDLP_MI355X_FORCE_COMM", 0);
+  w.slab = dev("PDLP_MI355X_SLAB", -1);
+  w.slabW = dev("PDLP_MI355X_SLAB_W", 0);
+  w.xcdMap = dev("PDLP_MI355X_XCD_MAP", -1);
+  w.slabPace = dev("PDLP_MI355X_SLAB_PACE", -1);
+  w.affineTasks = dev("PDLP_MI355X_AFFINE_TASKS", 1);
+  w.fusedStream = dev("PDLP_MI355X_FUSED_STREAM", 0);
+  w.fusedCoTasks = dev("PDLP_MI355X_FUSED_COTASKS", -1);
+  w.xcdLocal = dev("PDLP_MI355X_XCD_LOCAL", -1);
+  w.hierBarrier = dev("PDLP_MI355X_HIER_BARRIER", -1);
+  w.deviceCheck = dev("PDLP_MI355X_DEVICE_CHECK", -1);
+  w.checkSmall = dev("PDLP_MI355X_CHECK_SMALL", -1);
+  w.primalInA = dev("PDLP_MI355X_PRIMAL_IN_A", -1);
+  w.fault = dev("PDLP_MI355X_FAULT", 0);
   if (w.fault) fprintf(stderr, "pdlp_mi355x: PDLP_MI355X_FAULT=%d is set — a TEST hook that makes a barrier launch time out on purpose; "
                                "this solve will stall for the barrier timeout and continue on the slower plain-launch path\n", w.fault);
-  w.exchange = str("PDLP_MI355X_EXCHANGE");
-  w.meshLayout = str("PDLP_MI355X_MESH_LAYOUT");
+  w.meshLayout = devStr("PDLP_MI355X_MESH_LAYOUT");
   return w;
 }
 
@@ -517,7 +526,7 @@ void Solver::construct(const pdlp_problem_t& P, const void* id128) {
   tuneXcdMap(dA_, sw_, x_[0].get(), ax_[0].get(), stream_);
   tuneXcdMap(dAt_, sw_, y_[0].get(), sharded_ ? commBuf_.get() : aty_[0].get(), stream_);
   if (hasQoff_) tuneXcdMap(dQ_, sw_, x_[0].get(), nx_[0].get(), stream_);
-  if (getenv("PDLP_MI355X_SLAB_PROF") && rank_ == 0)  // (development: what the set-up chose, next to the per-block phase profile)
+  if (devEnv("PDLP_MI355X_SLAB_PROF") && rank_ == 0)  // (development: what the set-up chose, next to the per-block phase profile)
     for (const DeviceMatrix* M : {&dA_, &dAt_})
       fprintf(stderr, "slab operand %s: slab %d, blocks %d, XCD map %s, %s, long majors %d, tasks %d in workgroups of %d\n", M == &dA_ ? "A" : "A'",
               (int)M->useSlab, M->useSlab ? M->slab.nBlocks : M->nBlocks, M->xcdMap ? "contiguous" : "round robin", M->noPace ? "free-running waves" : "paced",

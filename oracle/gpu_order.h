@@ -17,12 +17,12 @@ enum { G_T = 256, G_WAVE = 64, G_CHUNK = 2048, G_CHUNK_SMALL = 512, G_MAXMAJ = 2
 static inline int g_chunk_for(long nnz) { return nnz < (1L << 18) ? G_CHUNK_SMALL : G_CHUNK; }
 /* slab SpMV (k_spmv_slab): 1024-thread blocks of 16 waves.  The majors are dealt to blocks (and, inside a block, to its
  * waves — which does not matter for any sum) by WORK: pdlp_host.cpp slabPartition, restated here.  Work of a major of len
- * entries = len + its cold entries (g_slab_cold) + len * min(len, 64) / 32 + majorCost (integer division; majorCost alone for a long major, whose segment
+ * entries = len + 3 x its cold entries (g_slab_cold: they count four times) + len * min(len, 64) / 32 + majorCost (integer division; majorCost alone for a long major, whose segment
  * tasks run elsewhere; majorCost = 2 for the operand by rows, 10 for the transposed one, whose launch also carries the
  * next primal step of every column).  nBlocks = ceil(nMajor / 256) capped at 256 (more only when 256 blocks of 16384 majors do not hold the
  * operand); block b takes majors while it is closer to ceil(work left / blocks left) with the next major than without,
- * at least one and at most 16384 — on the transposed operand at most 5/4 of the mean number of majors per block (never
- * below 256) — and never so few / many that the blocks behind it could not hold / would not get the rest. */
+ * at least one and at most 16384, and never so few / many that the blocks behind it could not hold / would not get the
+ * rest. */
 enum { G_SLAB_T = 1024, G_SLAB_WAVES = 16, G_SLAB_BLOCKS = 256, G_SLAB_BLOCK_CAP = 16384, G_SLAB_MIN_ROWS = 256, G_SLAB_MAJOR_COST_ROWS = 2, G_SLAB_MAJOR_COST_COLS = 10 };
 static inline int g_slab_fits(int nMajor, int nMinor) { /* the minor index must fit 28 bits of an entry */
   (void)nMajor;
@@ -31,7 +31,7 @@ static inline int g_slab_fits(int nMajor, int nMinor) { /* the minor index must 
 /* blockBeg[0..nBlocks] (caller provides room for g_slab_blocks_room(nMajor) ints); returns nBlocks */
 static inline long g_slab_blocks_room(long nMajor) { return G_SLAB_BLOCKS + nMajor / 16 + 3; } /* (a wave holds >= 16 majors: g_slab_fits) */
 /* cold entries of every major (pdlp_host.cpp slabColdCounts): 2^17 or more minors away from the major's middle entry, in a
- * minor that at most 64 majors touch; they count twice.  cold: caller's scratch of nMajor ints, count: of nMinor ints */
+ * minor that at most 64 majors touch; they count four times.  cold: caller's scratch of nMajor ints, count: of nMinor ints */
 static inline void g_slab_cold(const int* beg, const int* idx, int nMajor, int nMinor, int longLimit, int* cold, int* count) {
   for (int j = 0; j < nMinor; ++j) count[j] = 0;
   for (long p = 0; p < (nMajor > 0 ? beg[nMajor] : 0); ++p) count[idx[p]]++;
@@ -59,12 +59,7 @@ static inline int g_slab_blocks(const int* beg, const int* cold, int nMajor, int
   long nB = ((long)nMajor + G_SLAB_MIN_ROWS - 1) / G_SLAB_MIN_ROWS;
   if (nB > G_SLAB_BLOCKS) nB = G_SLAB_BLOCKS;
   if (nB < ((long)nMajor + cap - 1) / cap) nB = ((long)nMajor + cap - 1) / cap;
-  if (majorCost == G_SLAB_MAJOR_COST_COLS && nB > 0) { /* the transposed operand: at most 5/4 of the mean per block */
-    long c54 = (5L * nMajor + 4 * nB - 1) / (4 * nB);
-    if (c54 < G_SLAB_MIN_ROWS) c54 = G_SLAB_MIN_ROWS;
-    if (c54 < cap) cap = c54;
-  }
-#define G_WORK(r, len) ((len) > longLimit ? (long)majorCost : (long)(len) + cold[r] + ((long)(len) * ((len) < 64 ? (len) : 64)) / 32 + majorCost)
+#define G_WORK(r, len) ((len) > longLimit ? (long)majorCost : (long)(len) + 3L * cold[r] + ((long)(len) * ((len) < 64 ? (len) : 64)) / 32 + majorCost)
   long rem = 0;
   for (int r = 0; r < nMajor; ++r) { const int len = beg[r + 1] - beg[r]; rem += G_WORK(r, len); }
   int r = 0;

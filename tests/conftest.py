@@ -6,6 +6,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+# the tests drive layout / variant / fault switches of the library: those are development switches, read only with the
+# master switch set (highs_amd/csrc/pdlp_env.hpp); child processes (mesh workers, the reference CLI) inherit it
+os.environ.setdefault("PDLP_MI355X_DEV", "1")
 
 
 def pytest_configure(config):

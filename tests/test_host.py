@@ -28,6 +28,25 @@ def test_library_exports_every_declared_symbol():
     assert lib.pdlp_mi355x_abi_version() == int(re.search(r"#define PDLP_MI355X_ABI_VERSION (\d+)", hdr).group(1)) == 6
 
 
+def test_development_switches_need_the_master_switch():
+    """A development variable in the environment changes nothing unless PDLP_MI355X_DEV=1 (highs_amd/csrc/pdlp_env.hpp): the
+    library says once that it ignores it.  Checked on a switch that needs no GPU (the per-phase timing of the MPS reader)."""
+    import subprocess
+    import sys
+    mps = os.path.join(ROOT, "tests", "golden", "mps_cases", "ranges.mps")
+    if not os.path.exists(mps):
+        mps = sorted(__import__("glob").glob(os.path.join(ROOT, "tests", "golden", "mps_cases", "*.mps")))[0]
+    code = ("import sys; sys.path.insert(0, %r); from highs_amd import solver; solver.read_mps(%r)" % (ROOT, mps))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("PDLP_MI355X_")}
+    env["PDLP_MI355X_MPS_TIMING"] = "1"
+    off = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert off.returncode == 0, off.stderr
+    assert "PDLP_MI355X_MPS_TIMING is a development switch and is ignored" in off.stderr
+    on = subprocess.run([sys.executable, "-c", code], env=dict(env, PDLP_MI355X_DEV="1"), capture_output=True, text=True, timeout=120)
+    assert on.returncode == 0, on.stderr
+    assert "development switch" not in on.stderr and on.stderr.strip() != ""  # the timing lines instead
+
+
 def test_struct_sizes_match_ctypes_mirror():
     lib = solver.lib()
     for which, ty in enumerate([abi.PdlpProblem, abi.PdlpParams, abi.PdlpResult, abi.PdlpIterStats, abi.PdlpPrepared,
@@ -150,10 +169,10 @@ def _slab_to_coo(sl, n_major):
 
 
 def _slab_work(lens, long_limit, major_cost=2, cold=0):
-    """pdlp_host.cpp slabMajorWork: entries + cold entries + the run-accumulation term + major_cost (2 for the operand by
+    """pdlp_host.cpp slabMajorWork: entries + 3 x cold entries (they count four times) + the run-accumulation term + major_cost (2 for the operand by
     rows, 10 for the transposed one); a long major: major_cost alone."""
     lens = np.asarray(lens, dtype=np.int64)
-    return np.where(lens > long_limit, major_cost, lens + cold + (lens * np.minimum(lens, 64)) // 32 + major_cost)
+    return np.where(lens > long_limit, major_cost, lens + 3 * cold + (lens * np.minimum(lens, 64)) // 32 + major_cost)
 
 
 def _cold_counts(beg, idx, n_minor, long_limit):
@@ -188,9 +207,6 @@ def _slab_partition_restated(beg, n_major, n_minor, long_limit, major_cost=2, co
     wave_cap = min(1 << (32 - mb), 16384)
     block_cap = min(16384, wave_cap * 16)
     nb = max(min(-(-n_major // 256), 256), -(-n_major // block_cap))
-    fill_cap = block_cap
-    if major_cost == 10 and nb > 0:  # the transposed operand: no block above 5/4 of the mean number of majors (never below 256)
-        fill_cap = min(block_cap, max(-(-5 * n_major // (4 * nb)), 256))
 
     def fill(r0, r1, units, cap, non_empty):
         out, r, rem = [r0], r0, int(cost[r0:r1].sum())
@@ -208,7 +224,7 @@ def _slab_partition_restated(beg, n_major, n_minor, long_limit, major_cost=2, co
             rem -= acc
             out.append(r)
         return out
-    bb = fill(0, n_major, nb, fill_cap, True)
+    bb = fill(0, n_major, nb, block_cap, True)
     wb = [0]
     for b in range(nb):
         wb += fill(bb[b], bb[b + 1], 16, wave_cap, False)[1:]
@@ -264,10 +280,10 @@ def test_slab_layout_is_a_permutation_of_the_csr(which, long_limit):
     assert np.all(np.diff(key) > 0)
 
 
-def test_slab_partition_counts_cold_entries_twice():
+def test_slab_partition_counts_cold_entries_four_times():
     """Rows of random columns at the end of a banded matrix (the tail of bench.py --config c in small): their entries are
     2^17 or more columns away from the row's middle entry, in columns almost nobody else touches — cold gathers — and count
-    twice; entries just as far away but in columns that many rows touch (a dense column) do not.  The product's partition is
+    four times; entries just as far away but in columns that many rows touch (a dense column) do not.  The product's partition is
     the restated rule's, on both operands."""
     rng = np.random.default_rng(5)
     n, m_band, m_tail = 600000, 6000, 300
@@ -349,39 +365,6 @@ def test_slab_partition_balances_skewed_majors():
         w = wb[16 * b:16 * b + 17]
         ww = np.array([cost[w[k]:w[k + 1]].sum() for k in range(16)])
         assert ww.max() <= ww.mean() + cost.max()
-
-
-def test_slab_partition_caps_the_major_count_of_the_transposed_operand():
-    """A stretch of one-entry columns (the block of config d that owned 2.1x the mean number of columns and ended the fused
-    launch 3 us late): on the transposed operand no block owns more than 5/4 of the mean number of majors — the operand by
-    rows is cut by work alone — and product, restated rule and the oracle's C restatement agree on both."""
-    rng = np.random.default_rng(11)
-    n, m = 150000, 80000
-    lens = np.minimum((rng.pareto(1.3, n) * 3 + 2).astype(np.int64), 200)
-    lens[40000:75000] = 1
-    a_start = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
-    a_index = np.concatenate([np.sort(rng.choice(m, size=k, replace=False)) for k in lens]).astype(np.int32)
-    inf = float("inf")
-    lp = L.HighsLp(num_col=n, num_row=m, a_start=a_start, a_index=a_index, a_value=rng.standard_normal(len(a_index)),
-                   col_cost=np.ones(n), col_lower=np.zeros(n), col_upper=np.ones(n), row_lower=np.full(m, -inf),
-                   row_upper=np.ones(m)).normalise()
-    P = solver.Prepared(lp, pdlp_features_off=1)
-    assert P.n == n
-    for which in (0, 1):
-        beg, idx = (P.csr_beg, P.csr_idx) if which == 0 else (P.csc_beg, P.csc_idx)
-        n_major, n_minor = (P.m, P.n) if which == 0 else (P.n, P.m)
-        sl = P.slab_layout(which)
-        cold = _cold_counts(beg, idx, n_minor, 256)
-        nb, mb, wb = _slab_partition_restated(beg, n_major, n_minor, 256, 10 if which else 2, cold)
-        assert nb == sl["n_blocks"] == 256 and np.array_equal(wb, sl["wave_beg"])
-        assert np.array_equal(_oracle_blocks(beg, idx, n_major, n_minor, which), wb[::16])
-        per_block = np.diff(wb[::16])
-        if which == 1:
-            cap = -(-5 * n_major // (4 * 256))
-            assert per_block.max() == cap  # the cap binds on the one-entry stretch ...
-            uncapped = np.diff(_slab_partition_restated(beg, n_major, n_minor, 256, 9, cold)[2][::16])
-            assert uncapped.max() > 1.5 * n_major / 256  # ... where work alone would hand one block far more columns
-        assert wb[0] == 0 and wb[-1] == n_major and per_block.min() >= 1
 
 
 def test_segment_tasks_are_dealt_to_the_xcd_their_entries_live_in():

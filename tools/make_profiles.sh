@@ -9,6 +9,7 @@
 #                     trace domains), corrected as MI355X_MICROARCH.md prescribes: bytes = (2*FETCH + WRITE) * 1024
 #   ingest / e2e    : tools/mps_bench.py on this box's host cores, tools/e2e_cli.sh (reference CLI on the drop-in, MPS -> solution)
 #   test logs       : pytest -m gpu (includes the drop-in tests: reference CLI, Catch2 cases, C API client)
+export PDLP_MI355X_DEV=1  # the switches below are development switches (highs_amd/csrc/pdlp_env.hpp)
 set -u
 R=$(cd "$(dirname "$0")/.." && pwd)
 RND=${1:-r05}

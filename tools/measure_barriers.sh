@@ -1,5 +1,6 @@
 #!/bin/bash
 # hierarchical barrier: 80bau3b (48 workgroups) both ways, 100k x 100k, parity
+export PDLP_MI355X_DEV=1  # the switches below are development switches (highs_amd/csrc/pdlp_env.hpp)
 cd "$(dirname "$0")/.."
 O=gpurun_out/r03h; mkdir -p $O
 echo "80bau3b sweep barrier:"; PDLP_MI355X_HIER_BARRIER=0 python tools/small_loop.py 80bau3b 2>&1 | grep -v amdgpu.ids

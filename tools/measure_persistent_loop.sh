@@ -1,5 +1,6 @@
 #!/bin/bash
 # persistent trial loop: phases and loop times on 25fv47 / 80bau3b, 100k x 100k; the 1M headline; bit-identity of the loop variants
+export PDLP_MI355X_DEV=1  # the switches below are development switches (highs_amd/csrc/pdlp_env.hpp)
 cd "$(dirname "$0")/.."
 O=gpurun_out/persistent; mkdir -p $O
 PDLP_MI355X_SMALL_PROF=1 python tools/small_loop.py 25fv47 2>&1 | grep -v amdgpu.ids

@@ -1,5 +1,6 @@
 #!/bin/bash
 # structured LP (config c): stream layout for both operands against the slab layout
+export PDLP_MI355X_DEV=1  # the switches below are development switches (highs_amd/csrc/pdlp_env.hpp)
 cd "$(dirname "$0")/.."
 O=gpurun_out/r03i; mkdir -p $O
 for mode in auto 0; do

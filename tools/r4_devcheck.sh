@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 4, device-driven checks: parity subset + A/B of the host-driven and the device-driven loop on the same box
+export PDLP_MI355X_DEV=1  # the switches below are development switches (highs_amd/csrc/pdlp_env.hpp)
 cd "$(dirname "$0")/.."
 O=gpurun_out/r4_devcheck; mkdir -p $O
 timeout 600 python -m pytest tests/test_gpu_bitexact.py tests/test_gpu_parity.py -q -x -m gpu \

@@ -1,5 +1,6 @@
 #!/bin/bash
 # tools/r4_graph_ab.sh — A/B on one box: the 42-trial hipGraph vs eager launches queued ahead (PDLP_MI355X_GRAPH=0), configs b and c
+export PDLP_MI355X_DEV=1  # the switches below are development switches (highs_amd/csrc/pdlp_env.hpp)
 R=$(cd "$(dirname "$0")/.." && pwd); O=$R/gpurun_out/r4_graph_ab.log; : > $O
 cd $R
 for rep in 1 2; do

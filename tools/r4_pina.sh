@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 4: the persistent loop without its P phase (PDLP_MI355X_PRIMAL_IN_A) — parity subset, then A/B on the same box
+export PDLP_MI355X_DEV=1  # the switches below are development switches (highs_amd/csrc/pdlp_env.hpp)
 cd "$(dirname "$0")/.."
 O=gpurun_out/r4_pina; mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_bitexact.py tests/test_gpu_parity.py -q -x -m gpu \

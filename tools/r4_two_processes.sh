@@ -1,6 +1,7 @@
 #!/bin/bash
 # two PROCESSES with grid-barrier launches on one device at the same time (the in-process gate does not reach across
 # processes: the roll call / the all-or-none barrier and the fall-back have to carry this case)
+export PDLP_MI355X_DEV=1  # the switches below are development switches (highs_amd/csrc/pdlp_env.hpp)
 cd "$(dirname "$0")/.."
 O=gpurun_out/r4_two_processes; mkdir -p $O
 for cfg in a b; do

@@ -1,6 +1,7 @@
 #!/bin/bash
 # tools/r5_balance.sh TAG — round 5: the work-balanced slab partition on the GPU box.  GPU tests first (log kept), then the
 # bench lines of configs b / c / d / a / qp and the per-block phase profile of the slab launches.
+export PDLP_MI355X_DEV=1  # the switches below are development switches (highs_amd/csrc/pdlp_env.hpp)
 cd "$(dirname "$0")/.."
 TAG=${1:-r05}
 OUT=gpurun_out/$TAG

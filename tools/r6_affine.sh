@@ -3,6 +3,7 @@
 # operand.  The GPU tests that see the slab layout / long majors first (log kept), then A/B bench lines of configs c, d, b
 # (PDLP_MI355X_AFFINE_TASKS=0: tasks in (major, segment) order as in round 5), the per-block phase profile, and the PMC
 # traffic of configs c and d (separate --pmc passes, tools/pmc_traffic.sh).
+export PDLP_MI355X_DEV=1  # the switches below are development switches (highs_amd/csrc/pdlp_env.hpp)
 cd "$(dirname "$0")/.."
 TAG=${1:-r06_affine}
 OUT=gpurun_out/$TAG

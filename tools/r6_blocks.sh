@@ -1,5 +1,6 @@
 #!/bin/bash
 # tools/r6_blocks.sh TAG [configs] — per-block phase tables of the two slab launches (raw + JSON) and the bench lines
+export PDLP_MI355X_DEV=1  # the switches below are development switches (highs_amd/csrc/pdlp_env.hpp)
 cd "$(dirname "$0")/.."
 TAG=${1:-r06_blocks}; shift
 OUT=gpurun_out/$TAG

@@ -10,6 +10,7 @@ import argparse
 import hashlib
 import json
 import os
+os.environ.setdefault("PDLP_MI355X_DEV", "1")  # development switches below
 import sys
 import time
 
