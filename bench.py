@@ -40,6 +40,11 @@ CONFIGS = {
     # second structured family (round 4): tests/lpgen.py::dense_column_lp — staircase LP with 192 DENSE COLUMNS of ~6000
     # nonzeros (segment tasks in the A'y launch), power-law row lengths: 459k columns, 526k rows, 4.4M nonzeros
     "d": dict(staircase=True, name="structured staircase LP with dense columns, 526k x 459k, 4.4M nnz, 192 dense columns (seed 1)"),
+    # HELD-OUT structured families (round 6): written after the slab partition's constants were chosen on c and d, never tuned
+    # on.  tests/lpgen.py::tall_lp — 1.2M rows x 160k columns, 5.5M nnz, 96 dense coupling rows (A x: CSR stream + segment
+    # tasks, A'y: slab layout); powerlaw_band_lp — 650k x 700k, 6.3M nnz, power-law row AND column lengths, hub columns
+    "e": dict(family="tall", name="held-out tall LP, 1.2M x 160k, 5.5M nnz, 96 dense rows (seed 1)"),
+    "f": dict(family="plband", name="held-out power-law banded LP, 650k x 700k, 6.3M nnz, hub columns up to 93k entries (seed 1)"),
     "qp": dict(m=500_000, n=500_000, nnz=4_000_000, qp=True,
                name="synthetic random sparse QP 500kx500k, 4M nnz, diagonal Q ~ U(0,1) (seed 1)"),
     # the same with a NON-diagonal Hessian (the Q x SpMV of the general-Q path, a fourth launch per trial): tridiagonal,
@@ -75,10 +80,12 @@ def build_workload(config):
     stay alive next to it.  Shared with tools/kbench.py (the command the rocprofv3 passes run)."""
     from highs_amd import abi, solver
     cfg = CONFIGS[config]
-    if cfg.get("structured") or cfg.get("staircase"):
+    if cfg.get("structured") or cfg.get("staircase") or cfg.get("family"):
         sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from lpgen import dense_column_lp, structured_lp
-        sp_ = abi.ProblemHandle(dense_column_lp(1) if cfg.get("staircase") else structured_lp(1))  # same attribute (.struct) as the library-generated problem
+        from lpgen import dense_column_lp, powerlaw_band_lp, structured_lp, tall_lp
+        gen = tall_lp if cfg.get("family") == "tall" else powerlaw_band_lp if cfg.get("family") == "plband" else \
+            dense_column_lp if cfg.get("staircase") else structured_lp
+        sp_ = abi.ProblemHandle(gen(1))  # same attribute (.struct) as the library-generated problem
     else:
         sp_ = solver.SyntheticProblem(cfg["m"], cfg["n"], cfg["nnz"], 1)
     qkeep = None
@@ -380,7 +387,7 @@ def main():
     if args.solver == "pdlp" and world == 1:
         # measured device-copy ceiling: 2 x 512 MiB hipMemcpyDtoD, beyond the Infinity Cache
         copy_gbs = 2 * 512 * 2**20 / (S.time_kernel("copy", 10) * 1e-3) / 1e9
-    traffic = None
+    traffic = traffic_miss = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if args.solver == "hipdlp":  # same SpMV kernels with the Halpern epilogues
         dom_name = {"spmv_ax_dual": "spmv_ax_halpern_dual", "spmv_aty_interact": "spmv_aty_halpern_primal"}.get(dom_name, dom_name)
@@ -389,9 +396,14 @@ def main():
         try:
             # (counters exist per configuration; the HiPDLP path was profiled on the headline LP only — another config: none)
             cfg_key = args.config if (args.solver == "pdlp" or args.config == "b") else None
-            traffic = json.load(open(tpath)).get(cfg_key, {}).get(traffic_key) if cfg_key else None
+            tj = json.load(open(tpath))
+            traffic = tj.get(cfg_key, {}).get(traffic_key) if cfg_key else None
+            # the cross-check of the guide's x2 on FETCH_SIZE: L2 misses of the same launches x 128 B lines
+            raw = tj.get("raw_per_launch", {}).get(cfg_key if args.solver == "pdlp" else "hipdlp_b", {}).get(traffic_key, {})
+            traffic_miss = raw.get("TCC_MISS_sum", {}).get("mean_working")
+            traffic_miss = traffic_miss * 128.0 if traffic_miss is not None and not persistent else None
         except Exception:
-            traffic = None
+            traffic = traffic_miss = None
     out = {
         "metric": "PDHG iterations/sec" if args.solver == "pdlp" else "PDHG iterations/sec (HiPDLP path)",
         "value": st.iters / elapsed, "unit": "it/s", "n_gpus": world,
@@ -416,7 +428,7 @@ def main():
         "iter_hbm_gbs": b_iter / (ms_step * 1e-3) / 1e9,
         "iter_hbm_frac_of_peak": b_iter / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS / world,
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_tcc_miss_x_128B": traffic_miss,
                      "traffic_source": "profiles/pmc_traffic.json (static: rocprofv3 --pmc passes of tools/make_profiles.sh, not "
                                        "measured in this run)" if traffic is not None else None,
                      "algorithmic_bytes_per_launch": dom_bytes,
@@ -472,7 +484,7 @@ def main():
         out["kernels_ms"] = ks
     if rank == 0 and world == 1:
         # two iteration limits (whole check periods + 1: the reference stops at limit - 1), about 10-30 s of one core
-        budget = args.cpu_iters if args.cpu_iters is not None else {"b": 201, "qp": 361, "c": 361, "d": 361, "qpn": 361}.get(args.config, 3001)
+        budget = args.cpu_iters if args.cpu_iters is not None else {"b": 201, "qp": 361, "c": 361, "d": 361, "e": 361, "f": 361, "qpn": 361}.get(args.config, 3001)
         if budget > 0:
             lo = max(41, (budget - 1) * 2 // 5 // 40 * 40 + 1)
             hi = max(budget, lo + 40)

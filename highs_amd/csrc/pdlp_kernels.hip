@@ -1141,21 +1141,30 @@ unsigned long long* slabProf() {
           if (FILE* f = fopen(path, "wb")) { fwrite(h.data(), 8, kWords, f); fclose(f); }
         }
         for (int half = 0; half < 2; ++half) {
-          const int base = half * 1024, nBlocks = 1024;
-          for (int k = 0; k < 4; ++k) {
-            double mean = 0, lo = 1e300, hi = 0;
+          const int base = half * 1024;
+          auto stat = [&](int b0, int b1, int k, double& mean, double& lo, double& hi) {
+            mean = 0; lo = 1e300; hi = 0;
             int cnt = 0;
-            for (int b = 0; b < nBlocks; ++b) {
+            for (int b = b0; b < b1; ++b) {
               const unsigned long long n = h[(size_t)(base + b) * 8];
               if (!n) continue;
               const double us = (double)h[(size_t)(base + b) * 8 + 1 + k] * 0.01 / (double)n;
               mean += us; lo = us < lo ? us : lo; hi = us > hi ? us : hi; ++cnt;
             }
+            if (cnt) mean /= cnt;
+            return cnt;
+          };
+          for (int k = 0; k < 4; ++k) {  // rows 0..511: the streaming blocks (logical block index)
+            double mean, lo, hi;
+            const int cnt = stat(0, 512, k, mean, lo, hi);
             if (cnt && hi > 0)
               fprintf(stderr, "slab launch %s, %d blocks, to the end of %s: mean %.2f us, fastest block %.2f, slowest %.2f\n",
                       half ? "A'y+ (fused)" : "A x+", cnt, k == 0 ? "the stream" : k == 1 ? "the epilogue" : k == 2 ? "the grid barrier" : "the kernel",
-                      mean / cnt, lo, hi);
+                      mean, lo, hi);
           }
+          double mean, lo, hi;  // rows 512..: the task workgroups (segment tasks of the long majors), when each was done
+          const int cnt = stat(512, 1024, 0, mean, lo, hi);
+          if (cnt) fprintf(stderr, "slab launch %s, %d task workgroups done: mean %.2f us, first %.2f, last %.2f\n", half ? "A'y+ (fused)" : "A x+", cnt, mean, lo, hi);
         }
       });
     }
@@ -1167,7 +1176,7 @@ unsigned long long* slabProf() {
 template <int EPI>
 void launchSpmv(const MatView& M, SpmvArgs a, hipStream_t s) {
   a.xcdMap = M.xcdMap;
-  if (EPI == kDualStep && M.useSlab && M.slab.nBlocks <= 1024) a.prof = slabProf();
+  if (EPI == kDualStep && M.useSlab && M.slab.nBlocks <= 512) a.prof = slabProf();
   a.L = M.lng;
   a.A = M.csr;
   const int nTasks = M.lng.nTasks;
@@ -1255,7 +1264,7 @@ void launchSpmvAtyFusedPrimal(const MatView& At, const IterVecs& v, const DevSta
   a.inlineTasks = At.useSlab && At.lng.nTasks > 0 && a.coTaskBlocks == 0 ? 1 : 0;
   a.st = stIn; a.v = v; a.part0 = partDX; a.part1 = partInter;
   a.stOut = stOut; a.partDY = partDY; a.nDY = nDY; a.nDX = At.nPartials; a.bar = bar;
-  if (At.useSlab && At.slab.nBlocks <= 1024) a.prof = slabProf();
+  if (At.useSlab && At.slab.nBlocks <= 512) a.prof = slabProf();
   a.xcdMap = At.xcdMap; a.L = At.lng; a.A = At.csr; a.S = At.slab;
   if (At.useSlab && a.coTaskBlocks > 0)
     hipLaunchKernelGGL((k_spmv_slab<kAtyFused, true, kSlabSlots, 1>), dim3(At.slab.nBlocks + a.coTaskBlocks), dim3(kSlabThreads), fusedLds(At), s, a);

@@ -343,11 +343,23 @@ void Solver::endBarrierRound(std::unique_lock<std::mutex>& gate) {
   if (!gate.owns_lock()) return;
   DeviceGate& G = deviceGate(opt_.device);
   const int nxt = G.cur ^ 1;
-  if (!G.ev[nxt]) PDLP_HIP(hipEventCreateWithFlags(&G.ev[nxt], hipEventDisableTiming));
+  if (!G.ev[nxt]) {
+    PDLP_HIP(hipSetDevice(opt_.device));  // (the event belongs to the device of the gate, whichever thread gets here first)
+    PDLP_HIP(hipEventCreateWithFlags(&G.ev[nxt], hipEventDisableTiming));
+  }
   PDLP_HIP(hipEventRecord(G.ev[nxt], stream_));
   G.cur = nxt;
   G.recorded = true;
   gate.unlock();
+}
+// The end of a round is recorded on EVERY way out of it: if enqueueing throws (a failed launch or graph capture), the
+// barrier kernels that are already queued on this stream must still be ordered in front of the next context's round.
+Solver::BarrierRound::~BarrierRound() {
+  if (!gate.owns_lock()) return;
+  try {
+    self.endBarrierRound(gate);
+  } catch (...) {  // (recording failed too: the gate is released by the lock's destructor; the next round may time out and fall back)
+  }
 }
 
 double Solver::elapsed() const {
@@ -1151,7 +1163,8 @@ void Solver::runUntilHalt() {
     if (remaining > 4 * kCheckInterval) remaining = 4 * kCheckInterval;
     int32_t todo = (int32_t)remaining;
     const int32_t trialsBefore = hostState_->nTrials;
-    std::unique_lock<std::mutex> gate = beginBarrierRound();
+    BarrierRound round{*this, beginBarrierRound()};
+    std::unique_lock<std::mutex>& gate = round.gate;
     enqueueBatch(todo);
     const int32_t iterBefore = hostState_->nIter;
     endBarrierRound(gate);
@@ -1537,7 +1550,8 @@ void Solver::doSolveDevice(bool terminate, int32_t target) {
     const auto roundBeg = std::chrono::steady_clock::now();
     const int32_t iterBefore = s.nIter, trialsBefore = s.nTrials;
     const int64_t seq0 = checkSeq_;
-    std::unique_lock<std::mutex> gate = beginBarrierRound();
+    BarrierRound round{*this, beginBarrierRound()};
+    std::unique_lock<std::mutex>& gate = round.gate;
     int64_t itExp = s.nIter, haltExp = s.haltIter;
     if (s.halted) {  // (entry only: every batch below is followed by its check)
       enqueueCheckDevice();
@@ -1597,11 +1611,16 @@ void Solver::doSolveDevice(bool terminate, int32_t target) {
     // a check (fresh residuals) unless a period was cut short by rejected trials — then one host-driven check.  The
     // same when that last check went on to RESTART: its records describe the iterate before the restart, the vectors
     // that post-solve returns are the restarted ones (the host-driven loop stops in front of the restart).
+    const bool behindRestart = s.nIter == hostCtl_->lastCheckIter && hostCtl_->restartKind != 0;
     if (s.nIter != hostCtl_->lastCheckIter || hostCtl_->restartKind != 0) {
       computeAverage();
       computeResiduals();
       ++nChecks_;
     }
+    // (right behind a restart the running sums are zero: the "average" would be the zero vector.  The reference never looks
+    // at it there — it stops in front of the restart — so the current iterate stands in for both in the log line and in the
+    // termination tests.)
+    if (behindRestart) avg_ = cur_;
     logCheckLine(s.nIter, cur_, avg_, elapsed(), logSinceHeader);
     if (terminate) {
       if (checkTermination(cur_)) { termIterate_ = 0; termCode_ = PDLP_TERM_OPTIMAL; }

@@ -222,6 +222,11 @@ class Solver : public SolverBase {
   static DeviceGate& deviceGate(int device);
   std::unique_lock<std::mutex> beginBarrierRound();          // locked (and the stream ordered behind the last round) iff this solver launches grid barriers
   void endBarrierRound(std::unique_lock<std::mutex>& gate);  // marks the end of this round on the stream, releases the gate
+  struct BarrierRound {  // a round in scope: ended (event recorded, gate released) on every way out, also by an exception
+    Solver& self;
+    std::unique_lock<std::mutex> gate;
+    ~BarrierRound();
+  };
   int32_t stalledRounds_ = 0, stalledSince_ = 0;  // consecutive device stops without an accepted trial
   // Device-driven check iterations (pdlp_kernels.hpp CheckCtl; PDLP_MI355X_DEVICE_CHECK=0 gives the host-driven loop back)
   bool devCheck_ = true;

@@ -13,6 +13,7 @@ os.environ.setdefault("PDLP_MI355X_DEV", "1")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: a multi-million-iteration solve (a minute on the device); deselect with -m 'gpu and not slow'")
 
 
 def _gpu_unavailable_reason():

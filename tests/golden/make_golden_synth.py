@@ -7,7 +7,7 @@ Runs the REAL cuPDLP-C core compiled from the reference sources (oracle/_ref/lib
 north_star parity criterion compares: objective, cuPDLP primal / dual objective, residual norms,
 HiGHS-style KKT measures and the iteration count.
 
-    python tests/golden/make_golden_synth.py [a] [b] [c_small] [c] [d_small] [d]   (default: a b; "b" takes ~1-2 h of one core)
+    python tests/golden/make_golden_synth.py [a] [b] [c_small] [c] [d_small] [d] [e_small] [e] [f_small] [f]   (default: a b; "b" takes ~1-2 h of one core)
 
 Output: tests/golden/reference_synth.json (one record per config; existing records of configs that are
 not re-run are kept).  The LP itself is regenerated on the GPU box by the library's seeded generator
@@ -36,15 +36,22 @@ CONFIGS = {"a": (100_000, 100_000, 1_000_000), "b": (1_000_000, 1_000_000, 8_000
            # power-law row lengths; "d" = the bench size (~4.4M nnz), "d_small" ~ 1/8
            "d_small": dict(family="dense_column", periods=64, rows_per=1024, cols_per=896, dense_cols=48, dense_nnz=4000,
                            tail_rows=512, tail_max=2500),
-           "d": dict(family="dense_column")}
+           "d": dict(family="dense_column"),
+           # HELD-OUT families (round 6; the slab partition's constants were not tuned on them): tests/lpgen.py::tall_lp
+           # (m >> n, dense coupling rows) and powerlaw_band_lp (power-law lengths in both orientations, hub columns)
+           "e_small": dict(family="tall", n=20_000, m=150_000, window=1024, dense_rows=24, dense_nnz=3000),
+           "e": dict(family="tall"),
+           "f_small": dict(family="plband", n=90_000, m=80_000, band=2048, hubs=400),
+           "f": dict(family="plband")}
 OUT = os.path.join(HERE, "reference_synth.json")
 
 
 def record(key, tol):
     if isinstance(CONFIGS[key], dict):
-        from lpgen import dense_column_lp, structured_lp
+        from lpgen import dense_column_lp, powerlaw_band_lp, structured_lp, tall_lp
         kw = dict(CONFIGS[key])
-        lp = dense_column_lp(1, **kw) if kw.pop("family", None) == "dense_column" else structured_lp(1, **kw)
+        fam = kw.pop("family", None)
+        lp = {"dense_column": dense_column_lp, "tall": tall_lp, "plband": powerlaw_band_lp, None: structured_lp}[fam](1, **kw)
         m, n, nnz = lp.num_row, lp.num_col, lp.num_nz
     else:
         m, n, nnz = CONFIGS[key]

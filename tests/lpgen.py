@@ -273,3 +273,86 @@ def bench_qp_at_scale(n, banded, seed=1):
     else:
         lp.hessian = (np.arange(n + 1, dtype=np.int32), np.arange(n, dtype=np.int32), rng.uniform(0.0, 1.0, n))
     return lp
+
+
+def _finish_lp(rng, rows, cols, vals, m, n, name, sense=1, offset=0.0):
+    """Triplets -> a feasible, bounded HighsLp: one entry per (row, column), column-major storage, a primal point strictly
+    inside mixed column bounds, rows of every kind around its activity, costs = A'y0 + reduced costs of admissible sign."""
+    inf = float("inf")
+    order = np.lexsort((rows, cols))
+    rows, cols, vals = rows[order], cols[order], vals[order]
+    first = np.ones(rows.size, dtype=bool)
+    first[1:] = (rows[1:] != rows[:-1]) | (cols[1:] != cols[:-1])
+    rows, cols, vals = rows[first], cols[first], vals[first]
+    a_start = np.zeros(n + 1, np.int64)
+    a_start[1:] = np.cumsum(np.bincount(cols, minlength=n))
+    xs = rng.uniform(-1.0, 1.0, n)
+    cl = xs - rng.uniform(0.1, 1.0, n)
+    cu = xs + rng.uniform(0.1, 1.0, n)
+    kind = rng.random(n)
+    cl[kind < 0.1] = -inf
+    cu[(kind >= 0.1) & (kind < 0.3)] = inf
+    fixed = (kind >= 0.3) & (kind < 0.31)
+    cl[fixed] = cu[fixed] = xs[fixed]
+    ax = np.zeros(m)
+    np.add.at(ax, rows, vals * xs[cols])
+    rk = rng.random(m)
+    rl, ru = ax.copy(), ax.copy()
+    le = (rk >= 0.35) & (rk < 0.6)
+    rl[le], ru[le] = -inf, ax[le] + rng.uniform(0.0, 1.0, int(le.sum()))
+    ge = (rk >= 0.6) & (rk < 0.85)
+    rl[ge], ru[ge] = ax[ge] - rng.uniform(0.0, 1.0, int(ge.sum())), inf
+    rg = rk >= 0.85
+    rl[rg], ru[rg] = ax[rg] - rng.uniform(0.1, 1.0, int(rg.sum())), ax[rg] + rng.uniform(0.1, 1.0, int(rg.sum()))
+    y0 = rng.standard_normal(m)
+    y0[le] = -np.abs(y0[le])
+    y0[ge] = np.abs(y0[ge])
+    z = rng.standard_normal(n)
+    z = np.where(np.isinf(cl) & ~np.isinf(cu), -np.abs(z), z)
+    z = np.where(np.isinf(cu) & ~np.isinf(cl), np.abs(z), z)
+    c = z.copy()
+    np.add.at(c, cols, vals * y0[rows])
+    return L.HighsLp(n, m, sense * c, cl, cu, rl, ru, a_start.astype(np.int32), rows.astype(np.int32), vals, sense, offset,
+                     name).normalise()
+
+
+def tall_lp(seed=1, n=160_000, m=1_200_000, row_nnz=4, window=2048, dense_rows=96, dense_nnz=8000):
+    """HELD-OUT family 1 (round 6: the slab partition's constants were chosen on structured_lp and dense_column_lp; this
+    one and powerlaw_band_lp were written afterwards and the constants were NOT re-tuned on them): a TALL LP, m >> n —
+    scenario / sample-average models: every row has `row_nnz` entries inside a window of `window` columns that slides
+    with the row index, so every COLUMN is touched by ~m * row_nnz / n = 30 rows spread over a stretch of rows; plus
+    `dense_rows` coupling rows of ~`dense_nnz` entries anywhere (segment tasks of A x; seen from the columns they are
+    the rows that EVERY block of the transposed operand gathers from).  The gathered vector of A x (n doubles = 1.3 MB)
+    fits an XCD's L2: that operand runs the CSR stream layout, the transposed one (y: 9.6 MB) the slab layout — a mix
+    the two fitted families do not have.  Defaults: 1.2 M rows, 160 k columns, ~5.5 M nonzeros."""
+    rng = np.random.default_rng(seed)
+    m_reg = m - dense_rows
+    r = np.repeat(np.arange(m_reg, dtype=np.int64), row_nnz)
+    base = (np.arange(m_reg, dtype=np.int64) * (n - window)) // max(m_reg - 1, 1)
+    c = np.repeat(base, row_nnz) + rng.integers(0, window, size=r.size)
+    r_d = m_reg + np.repeat(np.arange(dense_rows, dtype=np.int64), dense_nnz)
+    c_d = rng.integers(0, n, size=r_d.size)
+    rows, cols = np.concatenate([r, r_d]), np.concatenate([c, c_d])
+    vals = rng.uniform(0.2, 2.0, size=rows.size) * np.where(rng.random(rows.size) < 0.4, -1.0, 1.0)
+    return _finish_lp(rng, rows, cols, vals, m, n, f"tall{seed}", 1, 1.5)
+
+
+def powerlaw_band_lp(seed=1, n=700_000, m=650_000, band=4096, hubs=3000, hub_share=0.12, max_len=240):
+    """HELD-OUT family 2 (see tall_lp): POWER-LAW lengths in BOTH orientations with banded locality.  Row lengths follow
+    a Pareto law (most below 10 entries, capped at `max_len`, so no row is a segment task); a row's entries lie in a band
+    of `band` columns around its own position — except a `hub_share` of them, which go to one of `hubs` hub columns
+    chosen by a Zipf law, so that column lengths are power-law too: the heaviest hubs have thousands of entries (segment
+    tasks of A'y), hundreds of them lie between the slab layout's 256-entry limit and a segment.  Both gathered vectors
+    exceed an L2 (5.6 / 5.2 MB): both operands run the slab layout.  Defaults: ~5.4 M nonzeros."""
+    rng = np.random.default_rng(seed)
+    lens = np.minimum(max_len, (3.0 * (1.0 + rng.pareto(1.3, size=m))).astype(np.int64))
+    r = np.repeat(np.arange(m, dtype=np.int64), lens)
+    centre = (np.repeat(np.arange(m, dtype=np.int64), lens) * (n - 1)) // max(m - 1, 1)
+    c = np.clip(centre + rng.integers(-band // 2, band // 2, size=r.size), 0, n - 1)
+    to_hub = rng.random(r.size) < hub_share
+    hub_cols = rng.choice(n, size=hubs, replace=False)
+    zipf = 1.0 / np.arange(1, hubs + 1) ** 1.1
+    pick = rng.choice(hubs, size=int(to_hub.sum()), p=zipf / zipf.sum())
+    c[to_hub] = hub_cols[pick]
+    vals = rng.uniform(0.2, 2.0, size=r.size) * np.where(rng.random(r.size) < 0.4, -1.0, 1.0)
+    return _finish_lp(rng, r, c, vals, m, n, f"plband{seed}", -1, -2.0)

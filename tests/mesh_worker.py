@@ -2,7 +2,7 @@
 1-GPU test box every rank uses the same device — the xGMI mesh exchange only needs HIP IPC).
 
 usage: mesh_worker.py RANK WORLD IDHEX CASE OUTFILE
-  CASE = solve:<instance>[:features_off]  -> full solve through create_sharded / run
+  CASE = solve:<instance>[:features_off[:iteration_limit]]  -> full solve through create_sharded / run
          iterate:<instance|synth>:<k>     -> k fixed iterations, dumps x and the step sizes
 """
 import ctypes as C
@@ -60,6 +60,8 @@ def main():
         return
     if kind == "solve":
         foff = int(rest[0]) if rest else 0
+        if len(rest) > 1:  # a fixed amount of work on an LP that takes millions of iterations: tolerance out of reach
+            kw.update(pdlp_iteration_limit=int(rest[1]), kkt_tolerance=1e-12)
         S = solver.DeviceSolver(rank=rank, world=world, unique_id=uid, time_limit=1000.0, pdlp_features_off=foff, **kw)
         ex = S.stage("exchange")[0]
         R = S.run(nc, nr)

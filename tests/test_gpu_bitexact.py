@@ -97,6 +97,31 @@ def test_dense_column_lp_bit_exact(layout, monkeypatch):
     assert _check(lp, layout=layout, kkt_tolerance=1e-5, pdlp_iteration_limit=30000) > 0
 
 
+@pytest.mark.parametrize("family", ["tall", "plband"])
+@pytest.mark.parametrize("layout", ["csr", "slab"])
+def test_held_out_families_bit_exact(family, layout, monkeypatch):
+    """The two HELD-OUT structured families of round 6 in small (tests/lpgen.py tall_lp: m >> n with dense coupling rows;
+    powerlaw_band_lp: power-law row and column lengths, hub columns that are segment tasks of A'y): whole solves bit for
+    bit in both layouts — the XCD-affine task deal, the work-balanced partition and the co-resident task workgroups see
+    shapes they were not developed on."""
+    from lpgen import powerlaw_band_lp, tall_lp
+    monkeypatch.setenv("PDLP_MI355X_SLAB", "1" if layout == "slab" else "0")
+    lp = tall_lp(2, n=3000, m=20000, window=256, dense_rows=6, dense_nnz=1500) if family == "tall" else \
+        powerlaw_band_lp(2, n=12000, m=10000, band=512, hubs=60)
+    assert _check(lp, layout=layout, kkt_tolerance=1e-5, pdlp_iteration_limit=4000) > 0
+
+
+@pytest.mark.parametrize("family", ["tall", "plband"])
+def test_held_out_families_at_bench_size_first_iterations(family, monkeypatch):
+    """... and at the size bench.py --config e / f runs them (device-side set-up, automatic layouts: tall = CSR stream for
+    A x with 96 long rows + slab for A'y; plband = slab for both with hub columns up to 93k entries): the first 60
+    iterations, checks included, bit for bit against the oracle's device-order mode."""
+    from lpgen import powerlaw_band_lp, tall_lp
+    monkeypatch.delenv("PDLP_MI355X_SLAB", raising=False)
+    lp = tall_lp(1) if family == "tall" else powerlaw_band_lp(1)
+    assert _check(lp, layout="auto", kkt_tolerance=1e-4, pdlp_iteration_limit=60) == 59
+
+
 def test_bench_workload_bit_exact_first_iterations(monkeypatch):
     """The bench workload itself (1M x 1M, 8M nnz; automatic layout = slab, device-side setup): the first
     60 iterations — checks, restarts and rejected trials included — reproduced bit for bit."""

@@ -78,6 +78,19 @@ def test_sharded_device_driven_checks_give_the_bits_of_host_driven_checks(name, 
     assert int(dev[0]["term"]) == 0 and int(dev[0]["num_iter"]) > 100
 
 
+def test_sharded_hard_instance_device_driven_checks(tmp_path):
+    """perold — the LP of check/instances that takes the method millions of iterations and hundreds of restarts — on two
+    ranks (folded on this device), 4 000 iterations with the checks, restarts and primal-weight updates on the device: both
+    ranks hold the same bits, and they are the bits of the host-driven checks (round 6)."""
+    dev = _run_ranks(2, "solve:perold:0:4000", tmp_path)
+    (tmp_path / "host").mkdir()
+    host = _run_ranks(2, "solve:perold:0:4000", tmp_path / "host", extra_env={"PDLP_MI355X_DEVICE_CHECK": "0"})
+    for k in ("col_value", "col_dual", "row_value", "row_dual", "num_iter", "num_trials", "primal_obj", "dual_obj", "term"):
+        assert np.array_equal(dev[0][k], dev[1][k]), k
+        assert np.array_equal(dev[0][k], host[0][k]), k
+    assert int(dev[0]["num_iter"]) == 3999 and int(dev[0]["num_trials"]) > 3999
+
+
 @pytest.mark.parametrize("case,world", [("iterate:25fv47:40", 4), ("iterate:synth:120", 2), ("iterate:synth:120", 8),
                                         ("iterate:synthbig:80", 4)])  # the bench workload (1M x 1M, slab layout, 2 MB slices)
 def test_mesh_fixed_iterations_match_single_gpu(case, world, tmp_path):
