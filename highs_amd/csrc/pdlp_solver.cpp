@@ -1883,6 +1883,25 @@ void Solver::stage(const std::string& name, double* out, int32_t cap) {
     double us[3] = {0, 0, 0}, cnt[3] = {0, 0, 0};
     if (meshMode_) mesh_->phaseStats(us, cnt, stream_);
     for (int k = 0; k < 3; ++k) { put(k, us[k]); put(3 + k, cnt[k]); }
+  } else if (name == "mesh_hop_us") {  // bring-up: microseconds per scalar all-reduce over the mesh (one flag hop out + one back), 200 rounds
+    if (meshMode_) {
+      hipEvent_t e0, e1;
+      PDLP_HIP(hipEventCreate(&e0));
+      PDLP_HIP(hipEventCreate(&e1));
+      for (int k = 0; k < 8; ++k) mesh_->allReduceScalars(statOut_.get(), 4, stream_);
+      PDLP_HIP(hipEventRecord(e0, stream_));
+      for (int k = 0; k < 200; ++k) mesh_->allReduceScalars(statOut_.get(), 4, stream_);
+      PDLP_HIP(hipEventRecord(e1, stream_));
+      PDLP_HIP(hipEventSynchronize(e1));
+      float ms = 0.f;
+      PDLP_HIP(hipEventElapsedTime(&ms, e0, e1));
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+      mesh_->checkError(stream_);
+      put(0, (double)ms * 1e3 / 200.0);
+    } else {
+      put(0, -1.0);
+    }
   } else if (name == "trial_launches") {  // kernels per trial step of the hot loop (2 = fused decision + primal step)
     const double fw = meshMode_ && mesh_->args().fusedWait ? 1.0 : 0.0;  // (all-gather consumers wait themselves: two / one launches less)
     put(0, meshMode_ ? (colblock_ ? 10.0 - 2.0 * fw : 9.0 - fw) : sharded_ ? 7.0 : persistent_ ? 0.0 : fused_ ? 2.0 : 3.0);  // 0: one persistent launch per batch
