@@ -23,7 +23,10 @@ __device__ __forceinline__ bool checkDue(const DevState* st, const CheckCtl* cc)
   if (!cc->terminate && it >= cc->iterLimit) return false;
   return it < 10 || it % cc->interval == 0 || (cc->terminate && it == cc->optIterLimit - 1);
 }
-__device__ __forceinline__ bool gateOpen(const CheckGate& g) { return g.st == nullptr || checkDue(g.st, g.cc); }
+__device__ __forceinline__ bool gateOpen(const CheckGate& g) {
+  if (g.flag && *g.flag == 0) return false;
+  return g.st == nullptr || checkDue(g.st, g.cc);
+}
 
 // Streamed vector traffic (iterates, costs, bounds, sums: everything that is touched once per kernel)
 // is loaded and stored NON-TEMPORALLY: it then does not displace the two matrix copies (192 MB at the

@@ -1,6 +1,7 @@
 // pdlp_halpern.cpp — see pdlp_halpern.hpp.  Host control flow of PDLPSolver::solve
 // (hipdlp/pdhg.cc:494-707); every vector lives in HBM.
 #include "pdlp_halpern.hpp"
+#include "pdlp_halpernfn.hpp"
 
 #include <algorithm>
 #include <climits>
@@ -17,8 +18,8 @@ namespace {
 constexpr int kCheckInterval = 40;  // PDHG_CHECK_INTERVAL, pdhg.cc:32
 constexpr int kStatSlots = 8;       // rows of the partial-sum table
 // statOut_/hostStats_ slots of one block's ONE download (doSolve): [fpe 3 | check 6 | fpe after the block's first step 3]
-constexpr int kSlotFpe = 0, kSlotCheck = 3, kSlotFpe0 = kSlotCheck + kHRowStats + kHColStats, kStatOut = 16;
-static_assert(kSlotFpe0 + 3 <= kStatOut, "stat slots");
+constexpr int kSlotFpe = kHSlotFpe, kSlotCheck = kHSlotCheck, kSlotFpe0 = kHSlotFpe0, kSlotDiff = kHSlotDiff, kStatOut = kHStatOut;
+static_assert(kSlotFpe0 == kSlotCheck + kHRowStats + kHColStats && kSlotDiff == kSlotFpe0 + 3 && kSlotDiff + 2 <= kStatOut, "stat slots");
 }  // namespace
 
 double HalpernSolver::elapsed() const {
@@ -57,6 +58,9 @@ void HalpernSolver::construct(const pdlp_problem_t& P, const void* id128) {
   if (sw.graph >= 0) useGraph_ = sw.graph != 0;
   if (world_ < 1 || rank_ < 0 || rank_ >= world_) throw std::runtime_error("bad rank/world");
   sharded_ = world_ > 1 || sw.forceComm != 0;
+  // check iterations, restarts and the PID weight on the device (one GPU): whole blocks are queued ahead, the host reads
+  // the checks' lines from a pinned ring.  PDLP_MI355X_DEVICE_CHECK=0 (development) / a sharded solve: the host decides.
+  devLoop_ = !sharded_ && sw.deviceCheck != 0;
   if (rank_ == 0) log(1, "Solving with HiPDLP (restarted Halpern PDHG) on MI355X (gfx950, HIP)\n");
   if ((opt_.features_off & PDLP_FEATURE_RESTART_OFF) != 0)
     log(1, "HiPDLP uses Halpern restart only; ignoring the restart-off feature flag.\n");  // pdhg.cc:1846-1852
@@ -150,7 +154,9 @@ void HalpernSolver::construct(const pdlp_problem_t& P, const void* id128) {
   dState_.alloc(1);
   PDLP_HIP(hipHostMalloc((void**)&hostState_, sizeof(HalpernState), hipHostMallocDefault));
   PDLP_HIP(hipHostMalloc((void**)&hostStats_, sizeof(double) * kStatOut, hipHostMallocDefault));
+  PDLP_HIP(hipHostMalloc((void**)&hostRing_, sizeof(HalpernRecord) * kHalpernRing, hipHostMallocDefault));
   memset(hostState_, 0, sizeof(HalpernState));
+  memset(hostRing_, 0, sizeof(HalpernRecord) * kHalpernRing);
   PDLP_HIP(hipStreamSynchronize(stream_));
   F_.csc = Compressed(); F_.csr = Compressed(); F_.cscSorted = Compressed();
   // block -> XCD assignment of the two operands (scratch vectors: any input will do)
@@ -162,6 +168,9 @@ void HalpernSolver::construct(const pdlp_problem_t& P, const void* id128) {
 
 void HalpernSolver::release() noexcept {
   if (graphExec_) (void)hipGraphExecDestroy(graphExec_);
+  if (unitGraph_) (void)hipGraphExecDestroy(unitGraph_);
+  if (hostRing_) (void)hipHostFree(hostRing_);
+  unitGraph_ = nullptr; hostRing_ = nullptr;
   for (hipEvent_t e : profEvents_) (void)hipEventDestroy(e);
   profEvents_.clear();
   if (hostState_) (void)hipHostFree(hostState_);
@@ -195,9 +204,11 @@ void HalpernSolver::sumOverRanks(double* devBuf, int32_t count) {
 
 // A' y for row-local y: the full vector on one GPU; when sharded, the rank-ordered sum of the ranks'
 // partials on the OWN column slice of `aty` (a full-length buffer)
-void HalpernSolver::spmvAt(const double* yLocal, double* aty) {
+void HalpernSolver::spmvAt(const double* yLocal, double* aty, const int32_t* gate) {
   if (!sharded_) {
-    launchSpmvPlain(dAt_.view(), yLocal, aty, stream_);
+    CheckGate g;
+    g.flag = gate;
+    launchSpmvPlain(dAt_.view(), yLocal, aty, stream_, g);
   } else {
     launchSpmvPlain(dAt_.view(), yLocal, commBuf_.get(), stream_);
     mesh_->reduceScatterCols(commBuf_.get(), aty, stream_);
@@ -246,44 +257,55 @@ double HalpernSolver::powerMethod() {
 
 // initializeStepSizes, pdhg.cc:1944-1977
 void HalpernSolver::initStepSizes() {
-  omega_ = (F_.normCost + 1.0) / (F_.normRhs + 1.0);
-  primalWeight_ = omega_;
-  bestPrimalWeight_ = primalWeight_;
-  beta_ = primalWeight_ * primalWeight_;
+  HalpernState& H = *hostState_;
+  H.omega = (F_.normCost + 1.0) / (F_.normRhs + 1.0);
+  H.primalWeight = H.omega;
+  H.bestPrimalWeight = H.primalWeight;
   lambda_ = powerMethod();
   const double base = 0.998 / std::sqrt(lambda_);
-  eta_ = base;
-  hostState_->tau = base / omega_;
-  hostState_->sigma = base * omega_;
-  hostState_->rho = 1.0;  // halpern_gamma, pdhg.cc:1913
+  H.eta = base;
+  H.tau = base / H.omega;
+  H.sigma = base * H.omega;
+  H.rho = 1.0;  // halpern_gamma, pdhg.cc:1913
   log(2, "Initial step sizes from power method lambda = %g: primal step = %g; dual step = %g, eta = %g, omega = %g\n",
-      lambda_, hostState_->tau, hostState_->sigma, eta_, omega_);
+      lambda_, H.tau, H.sigma, H.eta, H.omega);
 }
 
 void HalpernSolver::pushState() {
-  hostState_->hIter = halpernIter_;
   PDLP_HIP(hipMemcpyAsync(dState_.get(), hostState_, sizeof(HalpernState), hipMemcpyHostToDevice, stream_));
   PDLP_HIP(hipStreamSynchronize(stream_));
+}
+void HalpernSolver::pullState() {
+  PDLP_HIP(hipMemcpyAsync(hostState_, dState_.get(), sizeof(HalpernState), hipMemcpyDeviceToHost, stream_));
+  PDLP_HIP(hipStreamSynchronize(stream_));
+  PDLP_HIP(hipGetLastError());  // a failed kernel launch since the last stop surfaces here
+}
+// the loop may run: the gate words of the block's kernels follow the state (stage / timing entry points, start of a solve)
+void HalpernSolver::armState() {
+  HalpernState& H = *hostState_;
+  H.halted = 0; H.run = 1; H.runFpe0 = H.fpe0Pending; H.doRestart = 0;
 }
 
 // initializeStepSizes + initialize + the start of solve() (pdhg.cc:499-553)
 void HalpernSolver::reset() {
   const int32_t n = F_.n, m = mLoc_;
+  HalpernState& H = *hostState_;
+  memset(&H, 0, sizeof(H));
   initStepSizes();
-  bestGap_ = std::numeric_limits<double>::infinity();
-  errSum_ = lastErr_ = 0.0;
+  H.bestGap = std::numeric_limits<double>::infinity();
+  H.lastTrialFpe = std::numeric_limits<double>::infinity();
+  H.normRhs = F_.normRhs; H.normCost = F_.normCost; H.offset = F_.offset; H.tol = opt_.gap_tol;  // params_.tolerance
+  H.pid = pid_ ? 1 : 0;
+  H.termStatus = -1;
+  H.iterLimit = 0;
+  armState();
   for (DeviceArray<double>* d : {&xc_, &xn_, &rx_, &xa_, &slack_, &sp_, &sn_, &outX_}) d->zero(stream_);
   for (DeviceArray<double>* d : {&yc_, &yn_, &ry_, &ya_, &outY_}) d->zero(stream_);
   launchProjectBounds(xc_.get(), lower_.get(), upper_.get(), n, stream_);  // linalg::projectBounds of x = 0
   PDLP_HIP(hipMemcpyAsync(xa_.get(), xc_.get(), sizeof(double) * n, hipMemcpyDeviceToDevice, stream_));
   PDLP_HIP(hipMemcpyAsync(ya_.get(), yc_.get(), sizeof(double) * m, hipMemcpyDeviceToDevice, stream_));
-  halpernIter_ = 0;
   iters_ = 0;
   nRestarts_ = nChecks_ = 0;
-  doRestart_ = false;
-  slackValid_ = false;
-  fpe_ = initialFpe_ = 0.0;
-  lastTrialFpe_ = std::numeric_limits<double>::infinity();
   termStatus_ = -1;
   haveOutput_ = false;
   res_ = Res();
@@ -345,52 +367,46 @@ void HalpernSolver::profCollect() {
   profQueued_ = 0;
 }
 
-// One block of the main loop (pdhg.cc:578-641): major step 1, [fixed-point error if a restart
-// just happened], minor steps 2..39, major step 40.
+// The steps 2..40 of a block (the hipGraph of the host-driven loop; part of the unit graph of the device-driven one)
+void HalpernSolver::enqueueMinorSteps() {
+  for (int i = 2; i <= kCheckInterval - 1; ++i) enqueueStep(false, i);
+  enqueueStep(true, kCheckInterval);
+}
+
+// One block of the main loop (pdhg.cc:578-641) in the HOST-driven loop: major step 1, [fixed-point error if a restart
+// just happened], minor steps 2..39, major step 40.  The state on the device is the host's (pushed by the caller).
 void HalpernSolver::runBlock(bool fpeAfterFirst) {
-  pushState();
   enqueueStep(true, 1);
-  slackValid_ = true;
-  if (fpeAfterFirst) enqueueFpe(kSlotFpe0);  // read with the block's other statistics (fetchStats)
+  if (fpeAfterFirst) enqueueFpe(kSlotFpe0, nullptr);  // read with the block's other statistics (fetchStats)
   if (profile_ && !sharded_) {
-    for (int i = 2; i <= kCheckInterval - 1; ++i) enqueueStep(false, i);
-    enqueueStep(true, kCheckInterval);
+    enqueueMinorSteps();
     profCollect();
   } else if (useGraph_) {
     if (!graphExec_) {
       hipGraph_t graph = nullptr;
       PDLP_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
-      for (int i = 2; i <= kCheckInterval - 1; ++i) enqueueStep(false, i);
-      enqueueStep(true, kCheckInterval);
+      enqueueMinorSteps();
       PDLP_HIP(hipStreamEndCapture(stream_, &graph));
       PDLP_HIP(hipGraphInstantiate(&graphExec_, graph, nullptr, nullptr, 0));
       (void)hipGraphDestroy(graph);
     }
     PDLP_HIP(hipGraphLaunch(graphExec_, stream_));
   } else {
-    for (int i = 2; i <= kCheckInterval - 1; ++i) enqueueStep(false, i);
-    enqueueStep(true, kCheckInterval);
+    enqueueMinorSteps();
   }
 }
 
 // computeFixedPointError, pdhg.cc:709-739: the three sums into statOut_[slot..slot+2]
-void HalpernSolver::enqueueFpe(int slot) {
+void HalpernSolver::enqueueFpe(int slot, const int32_t* gate) {
   const int32_t m = mLoc_;
   const int32_t nbM = vecBlocks(std::max(m, 1)), nbN = vecBlocks(std::max(nLoc_, 1));
   double* part = part_.get();
-  launchHalpernFpeRows(yn_.get(), ry_.get(), tmpM_.get(), m, part, nbM, stream_);
-  spmvAt(tmpM_.get(), tmpN_.get());
+  launchHalpernFpeRows(yn_.get(), ry_.get(), tmpM_.get(), m, part, nbM, stream_, gate);
+  spmvAt(tmpM_.get(), tmpN_.get(), gate);
   launchHalpernFpeCols(xn_.get() + c0_, rx_.get() + c0_, tmpN_.get() + c0_, nLoc_, part + stride_,
-                       part + 2 * (size_t)stride_, nbN, stream_);
-  launchFinalReduce(part, stride_, nbM, 1, statOut_.get() + slot, stream_);
-  launchFinalReduce(part + stride_, stride_, nbN, 2, statOut_.get() + slot + 1, stream_);
-}
-
-double HalpernSolver::fpeFrom(const double* h) const {
-  const double dn = h[0], pn = h[1], cross = h[2];
-  const double movement = pn * omega_ + dn / omega_;
-  const double interaction = 2.0 * eta_ * cross;
-  return std::sqrt(std::max(0.0, movement + interaction));
+                       part + 2 * (size_t)stride_, nbN, stream_, gate);
+  launchFinalReduce(part, stride_, nbM, 1, statOut_.get() + slot, stream_, gate);
+  launchFinalReduce(part + stride_, stride_, nbN, 2, statOut_.get() + slot + 1, stream_, gate);
 }
 
 // The first `count` statistics slots: summed over the ranks, brought to the host, ONE stream synchronisation.
@@ -404,160 +420,176 @@ void HalpernSolver::fetchStats(int count) {
 
 // runConvergenceCheck's "current" leg (pdhg.cc:820-833): A x, A'y and the six sums into statOut_[kSlotCheck..].
 // x: full-length buffer whose own column slice is valid (all of it on one GPU); y: local rows.
-void HalpernSolver::enqueueCheck(double* x, const double* y, bool cachedSlack) {
+void HalpernSolver::enqueueCheck(double* x, const double* y, bool cachedSlack, const int32_t* gate) {
   const int32_t m = mLoc_;
   const int32_t nbM = vecBlocks(std::max(m, 1)), nbN = vecBlocks(std::max(nLoc_, 1));
   const int sc = F_.scaled ? 1 : 0;
   const size_t co = (size_t)c0_;
   double* part = part_.get();
   double* out = statOut_.get() + kSlotCheck;
+  CheckGate g;
+  g.flag = gate;
   if (sharded_) mesh_->allGather(x, false, stream_);  // A x needs every column slice
-  launchSpmvPlain(dA_.view(), x, tmpM_.get(), stream_);
-  spmvAt(y, tmpN_.get());
-  launchHalpernRowStats(tmpM_.get(), y, rl_.get(), rowScale_.get(), isEq_.get(), m, sc, part, stride_, nbM, stream_);
+  launchSpmvPlain(dA_.view(), x, tmpM_.get(), stream_, g);
+  spmvAt(y, tmpN_.get(), gate);
+  launchHalpernRowStats(tmpM_.get(), y, rl_.get(), rowScale_.get(), isEq_.get(), m, sc, part, stride_, nbM, stream_, gate);
   launchHalpernColStats(tmpN_.get() + co, x + co, cost_.get() + co, lower_.get() + co, upper_.get() + co,
                         colScale_.get() + co, cachedSlack ? slack_.get() + co : nullptr, nLoc_, sc, sp_.get() + co,
-                        sn_.get() + co, part + (size_t)kHRowStats * stride_, stride_, nbN, stream_);
-  launchFinalReduce(part, stride_, nbM, kHRowStats, out, stream_);
-  launchFinalReduce(part + (size_t)kHRowStats * stride_, stride_, nbN, kHColStats, out + kHRowStats, stream_);
+                        sn_.get() + co, part + (size_t)kHRowStats * stride_, stride_, nbN, stream_, gate);
+  launchFinalReduce(part, stride_, nbM, kHRowStats, out, stream_, gate);
+  launchFinalReduce(part + (size_t)kHRowStats * stride_, stride_, nbN, kHColStats, out + kHRowStats, stream_, gate);
 }
 
-// checkConvergence (pdhg.cc:1474-1527) on the fetched sums
-bool HalpernSolver::evalCheck(Res& r) {
-  if (mesh_) mesh_->verifyReplicated(rx_.get(), F_.n, stream_);  // the reflected x is the vector every rank holds in full
-  ++nChecks_;
-  const double* rs = hostStats_ + kSlotCheck;
-  const double* cs = rs + kHRowStats;
-  r.pFeas = std::sqrt(rs[0]);
-  r.dFeas = std::sqrt(cs[0]);
-  r.pObj = F_.offset + cs[1];
-  r.dObj = ((F_.offset + rs[1]) + cs[2]) - cs[3];
-  const double gap = r.pObj - r.dObj;
-  r.gap = std::fabs(gap);
-  r.relGap = std::fabs(gap) / (1.0 + std::fabs(r.pObj) + std::fabs(r.dObj));
-  const double eps = opt_.gap_tol;  // params_.tolerance
-  return r.pFeas < eps * (1.0 + F_.normRhs) && r.dFeas < eps * (1.0 + F_.normCost) && r.relGap < eps;
-}
-
-// checkRestartCriteria, pdhg.cc:901-927 (factors restart.hpp:91-93)
-bool HalpernSolver::restartCriteria() const {
-  if (iters_ == kCheckInterval) return true;
-  if (iters_ > kCheckInterval) {
-    if (fpe_ <= 0.2 * initialFpe_) return true;
-    if (fpe_ <= 0.8 * initialFpe_ && fpe_ > lastTrialFpe_) return true;
-    if ((double)halpernIter_ >= 0.36 * (double)iters_) return true;
-  }
-  return false;
-}
-
-// updatePrimalWeightAtRestart, pdhg.cc:1979-2049
-void HalpernSolver::updatePrimalWeight(const Res& r) {
+// The two distances of updatePrimalWeightAtRestart (pdhg.cc:1979-2049), |x_next - x_anchor|^2 and |y_next - y_anchor|^2,
+// into statOut_[kSlotDiff..]: part of every check (two vector passes), so that the decision needs no second round trip.
+void HalpernSolver::enqueueDiff(const int32_t* gate) {
   const int32_t m = mLoc_;
   const int32_t nbM = vecBlocks(std::max(m, 1)), nbN = vecBlocks(std::max(nLoc_, 1));
-  launchDiffNorm2(xn_.get() + c0_, xa_.get() + c0_, nLoc_, part_.get(), nbN, stream_);
-  launchDiffNorm2(yn_.get(), ya_.get(), m, part_.get() + stride_, nbM, stream_);
-  launchFinalReduce(part_.get(), stride_, nbN, 1, statOut_.get(), stream_);
-  launchFinalReduce(part_.get() + stride_, stride_, nbM, 1, statOut_.get() + 1, stream_);
-  if (sharded_) sumOverRanks(statOut_.get(), 2);
-  PDLP_HIP(hipMemcpyAsync(hostStats_, statOut_.get(), sizeof(double) * 2, hipMemcpyDeviceToHost, stream_));
-  PDLP_HIP(hipStreamSynchronize(stream_));
-  const double primalDist = std::sqrt(hostStats_[0]), dualDist = std::sqrt(hostStats_[1]);
-  const double relP = r.pFeas / (1.0 + F_.normRhs), relD = r.dFeas / (1.0 + F_.normCost);
-  const double ratio = relP > 0.0 ? relD / relP : 1e300;
-  if (primalDist > 1e-16 && dualDist > 1e-16 && primalDist < 1e12 && dualDist < 1e12 && ratio > 1e-8 && ratio < 1e8) {
-    const double err = std::log(dualDist) - std::log(primalDist) - std::log(primalWeight_);
-    errSum_ = 0.3 * errSum_ + err;                // i_smooth
-    const double dErr = err - lastErr_;
-    primalWeight_ *= std::exp(0.99 * err + 0.01 * errSum_ + 0.0 * dErr);  // k_p, k_i, k_d
-    lastErr_ = err;
-  } else {
-    primalWeight_ = bestPrimalWeight_;
-    errSum_ = 0.0;
-    lastErr_ = 0.0;
-  }
-  const double gap = (relP > 0.0 && relD > 0.0) ? std::fabs(std::log10(relD / relP)) : bestGap_;
-  if (gap < bestGap_) { bestGap_ = gap; bestPrimalWeight_ = primalWeight_; }
-  const double eta = std::sqrt(hostState_->tau * hostState_->sigma);
-  beta_ = primalWeight_ * primalWeight_;
-  hostState_->tau = eta / primalWeight_;
-  hostState_->sigma = eta * primalWeight_;
-  omega_ = std::sqrt(beta_);  // params_.omega = primal_weight_, then RestartScheme::updateBeta
+  launchDiffNorm2(xn_.get() + c0_, xa_.get() + c0_, nLoc_, part_.get(), nbN, stream_, gate);
+  launchDiffNorm2(yn_.get(), ya_.get(), m, part_.get() + stride_, nbM, stream_, gate);
+  launchFinalReduce(part_.get(), stride_, nbN, 1, statOut_.get() + kSlotDiff, stream_, gate);
+  launchFinalReduce(part_.get() + stride_, stride_, nbM, 1, statOut_.get() + kSlotDiff + 1, stream_, gate);
 }
 
-// pdhg.cc:663-692: anchor and current iterate <- pdhg iterate of the last major step
-void HalpernSolver::restart() {
+// pdhg.cc:663-692: anchor and current iterate <- pdhg iterate of the last major step (the host-driven loop; the primal
+// weight has been updated by halpernDecide)
+void HalpernSolver::restartCopies() {
   const int32_t n = F_.n, m = mLoc_;
-  if (pid_) updatePrimalWeight(res_);
   PDLP_HIP(hipMemcpyAsync(xa_.get(), xn_.get(), sizeof(double) * n, hipMemcpyDeviceToDevice, stream_));
   PDLP_HIP(hipMemcpyAsync(ya_.get(), yn_.get(), sizeof(double) * m, hipMemcpyDeviceToDevice, stream_));
   PDLP_HIP(hipMemcpyAsync(xc_.get(), xn_.get(), sizeof(double) * n, hipMemcpyDeviceToDevice, stream_));
   PDLP_HIP(hipMemcpyAsync(yc_.get(), yn_.get(), sizeof(double) * m, hipMemcpyDeviceToDevice, stream_));
-  halpernIter_ = 0;
-  lastTrialFpe_ = std::numeric_limits<double>::infinity();
-  ++nRestarts_;
+}
+
+void HalpernSolver::noteRecord(const HalpernRecord& r) {
+  res_.pObj = r.pObj; res_.dObj = r.dObj; res_.gap = r.gap; res_.relGap = r.relGap; res_.pFeas = r.pFeas; res_.dFeas = r.dFeas;
+  if (opt_.log_level > 1 && rank_ == 0)
+    logLine(opt_, 2, "%9lld  %+15.8e  %+15.8e  %8.2e  %10.2e  %8.2e  fpe %8.2e  w %8.2e\n", (long long)r.iters, r.pObj, r.dObj,
+            r.relGap, r.pFeas / (1.0 + F_.normRhs), r.dFeas / (1.0 + F_.normCost), r.fpe, r.primalWeight);
+}
+
+// One unit of the DEVICE-driven loop: a block of 40 steps, the initial fixed-point error behind its first step when a
+// restart came before (gated), the check's statistics, the decision kernel and what it switches on (restart copies,
+// output copy).  Every kernel is a no-op once the loop has halted; the whole unit replays from ONE hipGraph.
+void HalpernSolver::enqueueUnit() {
+  HalpernState* ds = dState_.get();
+  const int32_t n = F_.n, m = mLoc_;
+  enqueueStep(true, 1);
+  enqueueFpe(kSlotFpe0, &ds->runFpe0);
+  enqueueMinorSteps();
+  enqueueFpe(kSlotFpe, &ds->run);
+  enqueueCheck(xn_.get(), yn_.get(), true, &ds->run);
+  enqueueDiff(&ds->run);
+  launchHalpernDecide(ds, statOut_.get(), hostRing_, stream_);
+  launchHalpernRestartCopy(ds, xa_.get(), xc_.get(), xn_.get(), n, ya_.get(), yc_.get(), yn_.get(), m, stream_);
+  launchHalpernKeepOutput(ds, outX_.get(), xn_.get(), n, outY_.get(), yn_.get(), m, stream_);
 }
 
 // PDLPSolver::solve, pdhg.cc:494-707.  terminate = false: fixed-work loop for timing (same
 // kernels, checks and restarts; convergence is ignored).
 void HalpernSolver::doSolve(bool terminate, int64_t iterTarget) {
   const int32_t n = F_.n, m = mLoc_;
+  HalpernState& H = *hostState_;
   auto keepOutput = [&](const double* x, const double* y) {
     PDLP_HIP(hipMemcpyAsync(outX_.get(), x, sizeof(double) * n, hipMemcpyDeviceToDevice, stream_));
     PDLP_HIP(hipMemcpyAsync(outY_.get(), y, sizeof(double) * m, hipMemcpyDeviceToDevice, stream_));
     haveOutput_ = true;
   };
-  if (iters_ == 0 && terminate) {  // initial convergence check, pdhg.cc:563-570
-    Res r;
-    enqueueCheck(xc_.get(), yc_.get(), false);
+  auto mirror = [&]() { iters_ = H.iters; nRestarts_ = H.nRestarts; nChecks_ = H.nChecks; };
+  auto timeUp = [&]() {  // every rank must take the same branch: the ranks' clocks are OR-ed
+    bool up = elapsed() > opt_.time_limit;
+    if (sharded_ && std::isfinite(opt_.time_limit)) {
+      hostStats_[0] = up ? 1.0 : 0.0;
+      PDLP_HIP(hipMemcpyAsync(statOut_.get(), hostStats_, sizeof(double), hipMemcpyHostToDevice, stream_));
+      sumOverRanks(statOut_.get(), 1);
+      PDLP_HIP(hipMemcpyAsync(hostStats_, statOut_.get(), sizeof(double), hipMemcpyDeviceToHost, stream_));
+      PDLP_HIP(hipStreamSynchronize(stream_));
+      up = hostStats_[0] > 0.0;
+    }
+    return up;
+  };
+  const int64_t limit = terminate ? (int64_t)opt_.iter_limit : iterTarget;
+  H.terminate = terminate ? 1 : 0;
+  H.iterLimit = limit;
+  H.converged = 0;
+  armState();
+  if (H.iters == 0 && terminate) {  // initial convergence check, pdhg.cc:563-570
+    pushState();
+    enqueueCheck(xc_.get(), yc_.get(), false, nullptr);
     fetchStats(kSlotFpe0);
-    if (evalCheck(r)) {
+    if (mesh_) mesh_->verifyReplicated(rx_.get(), F_.n, stream_);
+    HalpernRecord r{};
+    const bool conv = halpernResiduals(H, hostStats_, r);
+    H.nChecks += 1;
+    res_.pObj = r.pObj; res_.dObj = r.dObj; res_.gap = r.gap; res_.relGap = r.relGap; res_.pFeas = r.pFeas; res_.dFeas = r.dFeas;
+    mirror();
+    if (conv) {
       keepOutput(xc_.get(), yc_.get());
-      res_ = r;
       termStatus_ = 0;
       return;
     }
-    res_ = r;
   }
-  const int64_t limit = terminate ? (int64_t)opt_.iter_limit : iterTarget;
-  while (iters_ < limit) {
-    if (terminate) {  // every rank must take the same branch: the ranks' clocks are OR-ed
-      bool up = elapsed() > opt_.time_limit;
-      if (sharded_ && std::isfinite(opt_.time_limit)) {
-        hostStats_[0] = up ? 1.0 : 0.0;
-        PDLP_HIP(hipMemcpyAsync(statOut_.get(), hostStats_, sizeof(double), hipMemcpyHostToDevice, stream_));
-        sumOverRanks(statOut_.get(), 1);
-        PDLP_HIP(hipMemcpyAsync(hostStats_, statOut_.get(), sizeof(double), hipMemcpyDeviceToHost, stream_));
-        PDLP_HIP(hipStreamSynchronize(stream_));
-        up = hostStats_[0] > 0.0;
-      }
-      if (up) { termStatus_ = 2; return; }
+  if (H.iters >= limit) { if (terminate) termStatus_ = 1; return; }
+  const bool device = devLoop_ && !profile_;
+  if (device) {
+    // ---- the device decides: whole units are queued ahead, the host reads the checks' lines ----
+    pushState();
+    if (!unitGraph_ && useGraph_) {
+      hipGraph_t graph = nullptr;
+      PDLP_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+      enqueueUnit();
+      PDLP_HIP(hipStreamEndCapture(stream_, &graph));
+      PDLP_HIP(hipGraphInstantiate(&unitGraph_, graph, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(graph);
     }
-    // One block, its fixed-point error(s) and its convergence statistics are queued back to back and read with ONE
-    // download: the host only decides (converged / restart) between blocks.
-    const bool fpeAfterFirst = doRestart_;
+    int ahead = 1;
+    for (;;) {
+      if (terminate && timeUp()) { termStatus_ = 2; break; }
+      const int32_t checksBefore = H.nChecks;
+      const auto t0 = std::chrono::steady_clock::now();
+      const int64_t unitsLeft = (limit - H.iters + kCheckInterval - 1) / kCheckInterval;
+      const int units = (int)std::max<int64_t>(1, std::min<int64_t>(ahead, unitsLeft));
+      for (int u = 0; u < units; ++u) {
+        if (unitGraph_) PDLP_HIP(hipGraphLaunch(unitGraph_, stream_));
+        else enqueueUnit();
+      }
+      pullState();
+      for (int32_t c = checksBefore; c < H.nChecks; ++c) noteRecord(hostRing_[c % kHalpernRing]);
+      mirror();
+      if (H.halted) {
+        if (H.converged) { haveOutput_ = true; termStatus_ = 0; }
+        else if (terminate) termStatus_ = 1;
+        break;
+      }
+      // queue depth: ~25 ms of work, at most half the ring
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      const int cap = ms > 0.0 ? std::max(1, std::min(kHalpernRing / 2, (int)(25.0 * units / ms))) : 1;
+      ahead = std::min(ahead * 2, cap);
+    }
+    return;
+  }
+  // ---- the host decides (sharded solves, profile mode, PDLP_MI355X_DEVICE_CHECK=0): same kernels, same decision function ----
+  while (H.iters < limit) {
+    if (terminate && timeUp()) { termStatus_ = 2; return; }
+    // One block, its fixed-point error(s), its convergence statistics and the restart distances are queued back to back
+    // and read with ONE download: the host only decides (converged / restart) between blocks.
+    const bool fpeAfterFirst = H.fpe0Pending != 0;
+    pushState();
     runBlock(fpeAfterFirst);
-    doRestart_ = false;
-    enqueueFpe(kSlotFpe);
-    enqueueCheck(xn_.get(), yn_.get(), slackValid_);
-    fetchStats(fpeAfterFirst ? kSlotFpe0 + 3 : kSlotFpe0);
-    if (fpeAfterFirst) initialFpe_ = fpeFrom(hostStats_ + kSlotFpe0);
-    fpe_ = fpeFrom(hostStats_ + kSlotFpe);
-    halpernIter_ += kCheckInterval;
-    iters_ += kCheckInterval;
-    Res r;
-    const bool converged = evalCheck(r);
-    res_ = r;
-    if (opt_.log_level > 1 && rank_ == 0)
-      logLine(opt_, 2, "%9lld  %+15.8e  %+15.8e  %8.2e  %10.2e  %8.2e  fpe %8.2e  w %8.2e\n", (long long)iters_, r.pObj, r.dObj,
-             r.relGap, r.pFeas / (1.0 + F_.normRhs), r.dFeas / (1.0 + F_.normCost), fpe_, primalWeight_);
-    if (converged && terminate) {
+    enqueueFpe(kSlotFpe, nullptr);
+    enqueueCheck(xn_.get(), yn_.get(), true, nullptr);
+    enqueueDiff(nullptr);
+    fetchStats(kStatOut);
+    if (mesh_) mesh_->verifyReplicated(rx_.get(), F_.n, stream_);  // the reflected x is the vector every rank holds in full
+    const HalpernRecord r = halpernDecide(H, hostStats_);
+    noteRecord(r);
+    mirror();
+    if (H.converged) {
       keepOutput(xn_.get(), yn_.get());
       termStatus_ = 0;
       return;
     }
-    doRestart_ = restartCriteria();
-    lastTrialFpe_ = fpe_;
-    if (doRestart_) restart();
+    if (H.doRestart) restartCopies();
   }
   if (terminate) termStatus_ = 1;
 }
@@ -688,7 +720,8 @@ std::pair<double*, int64_t> HalpernSolver::lookup(const std::string& name) {
 
 void HalpernSolver::getVector(const std::string& name, double* host, int64_t len) {
   if (name == "steps") {  // {tau, sigma, omega, eta, lambda, primal weight, fpe, initial fpe}
-    const double v[8] = {hostState_->tau, hostState_->sigma, omega_, eta_, lambda_, primalWeight_, fpe_, initialFpe_};
+    const HalpernState& H = *hostState_;
+    const double v[8] = {H.tau, H.sigma, H.omega, H.eta, lambda_, H.primalWeight, H.fpe, H.initialFpe};
     for (int64_t i = 0; i < len && i < 8; ++i) host[i] = v[i];
     return;
   }
@@ -715,14 +748,17 @@ void HalpernSolver::setVector(const std::string& name, const double* host, int64
 void HalpernSolver::stage(const std::string& name, double* out, int32_t cap) {
   auto put = [&](int i, double v) { if (out && i < cap) out[i] = v; };
   if (name == "block") {  // one block of 40 steps from the current state, then the fixed-point error
+    armState();
+    pushState();
     runBlock(false);
-    enqueueFpe(kSlotFpe);
+    enqueueFpe(kSlotFpe, nullptr);
     fetchStats(3);
-    fpe_ = fpeFrom(hostStats_ + kSlotFpe);
-    put(0, fpe_);
+    hostState_->fpe = halpernFpe(*hostState_, hostStats_ + kSlotFpe);
+    put(0, hostState_->fpe);
   } else if (name == "steps") {  // out[0] = number of steps (1..40), the last one major: returns nothing
     const int k = out && cap > 0 ? (int)out[0] : kCheckInterval;
     if (k < 1 || k > kCheckInterval) throw std::runtime_error("steps: 1..40");
+    armState();
     pushState();
     for (int i = 1; i <= k; ++i) enqueueStep(i == 1 || i == k, i);
   } else if (name == "mesh_phases") {  // {X, P, -} average wait in us, then the wait counts (since the last call)
@@ -741,6 +777,7 @@ void HalpernSolver::stage(const std::string& name, double* out, int32_t cap) {
 
 double HalpernSolver::timeKernel(const std::string& name, int32_t reps) {
   if (reps < 1) reps = 1;
+  armState();
   pushState();
   const HalpernVecs h = stepVecs(false, 2);
   auto once = [&]() {

@@ -4,9 +4,11 @@
 // final reduce (deterministic, no atomics).
 #include "pdlp_halpern.hpp"
 
+#include <algorithm>
 #include <cmath>
 
 #include "pdlp_devfn.hpp"
+#include "pdlp_halpernfn.hpp"
 
 namespace pdlp {
 
@@ -14,7 +16,8 @@ namespace {
 
 // computeFixedPointError, pdhg.cc:709-739: delta_y = y_next - reflected_y and its squared norm
 __global__ __launch_bounds__(kVecThreads) void k_h_fpe_rows(const double* __restrict__ yn, const double* __restrict__ ry,
-                                                            double* __restrict__ dy, int m, double* part) {
+                                                            double* __restrict__ dy, int m, double* part, const int32_t* gate) {
+  if (gate && *gate == 0) return;
   __shared__ double scratch[kVecThreads / kWave];
   double s = 0.0;
   const int stride = gridDim.x * blockDim.x;
@@ -29,7 +32,8 @@ __global__ __launch_bounds__(kVecThreads) void k_h_fpe_rows(const double* __rest
 // ... delta_x = x_next - reflected_x: squared norm and <delta_x, A' delta_y>
 __global__ __launch_bounds__(kVecThreads) void k_h_fpe_cols(const double* __restrict__ xn, const double* __restrict__ rx,
                                                             const double* __restrict__ atd, int n, double* partDx2,
-                                                            double* partCross) {
+                                                            double* partCross, const int32_t* gate) {
+  if (gate && *gate == 0) return;
   __shared__ double scratch[2][kVecThreads / kWave];
   double s0 = 0.0, s1 = 0.0;
   const int stride = gridDim.x * blockDim.x;
@@ -48,7 +52,8 @@ __global__ __launch_bounds__(kVecThreads) void k_h_row_stats(const double* __res
                                                              const double* __restrict__ rl,
                                                              const double* __restrict__ rowScale,
                                                              const uint8_t* __restrict__ isEq, int m, int scaled,
-                                                             double* part, int pstride) {
+                                                             double* part, int pstride, const int32_t* gate) {
+  if (gate && *gate == 0) return;
   __shared__ double scratch[kVecThreads / kWave];
   double a0 = 0.0, a1 = 0.0;
   const int stride = gridDim.x * blockDim.x;
@@ -75,7 +80,8 @@ __global__ __launch_bounds__(kVecThreads) void k_h_col_stats(const double* __res
                                                              const double* __restrict__ colScale,
                                                              const double* __restrict__ cachedSlack, int n, int scaled,
                                                              double* __restrict__ sp, double* __restrict__ sn,
-                                                             double* part, int pstride) {
+                                                             double* part, int pstride, const int32_t* gate) {
+  if (gate && *gate == 0) return;
   __shared__ double scratch[kVecThreads / kWave];
   double a[kHColStats] = {0.0, 0.0, 0.0, 0.0};
   const int stride = gridDim.x * blockDim.x;
@@ -111,28 +117,71 @@ __global__ __launch_bounds__(kVecThreads) void k_div_scalar(double* v, double de
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += stride) v[i] /= denom;
 }
 
+// The end of a block in the device-driven loop: one thread takes the decision of pdlp_halpernfn.hpp halpernDecide on the
+// check's statistics, in place on the state record, and writes the check's line into the pinned ring.
+__global__ void k_h_decide(HalpernState* st, const double* __restrict__ stat, HalpernRecord* ring) {
+  if (st->halted) return;
+  HalpernState s = *st;
+  const HalpernRecord r = halpernDecide(s, stat);
+  *st = s;
+  ring[(s.nChecks - 1) % kHalpernRing] = r;
+}
+// restart (pdhg.cc:663-692): anchor and current iterate <- pdhg iterate of the last major step; gated by doRestart
+__global__ __launch_bounds__(kVecThreads) void k_h_restart_copy(const HalpernState* st, double* __restrict__ xa, double* __restrict__ xc,
+                                                                const double* __restrict__ xn, int n, double* __restrict__ ya,
+                                                                double* __restrict__ yc, const double* __restrict__ yn, int m) {
+  if (!st->doRestart) return;
+  const int stride = gridDim.x * blockDim.x, tot = n + m;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += stride) {
+    if (i < n) { const double v = xn[i]; xa[i] = v; xc[i] = v; }
+    else { const double v = yn[i - n]; ya[i - n] = v; yc[i - n] = v; }
+  }
+}
+// a converged check keeps its iterate (pdhg.cc:866-877); gated by converged
+__global__ __launch_bounds__(kVecThreads) void k_h_keep_output(const HalpernState* st, double* __restrict__ outX, const double* __restrict__ xn,
+                                                               int n, double* __restrict__ outY, const double* __restrict__ yn, int m) {
+  if (!st->converged) return;
+  const int stride = gridDim.x * blockDim.x, tot = n + m;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += stride) {
+    if (i < n) outX[i] = xn[i];
+    else outY[i - n] = yn[i - n];
+  }
+}
+
 }  // namespace
 
+void launchHalpernDecide(HalpernState* st, const double* stat, HalpernRecord* ring, hipStream_t s) {
+  hipLaunchKernelGGL(k_h_decide, dim3(1), dim3(1), 0, s, st, stat, ring);
+}
+void launchHalpernRestartCopy(const HalpernState* st, double* xa, double* xc, const double* xn, int32_t n, double* ya, double* yc,
+                              const double* yn, int32_t m, hipStream_t s) {
+  hipLaunchKernelGGL(k_h_restart_copy, dim3(vecBlocks(std::max(n + m, 1))), dim3(kVecThreads), 0, s, st, xa, xc, xn, n, ya, yc, yn, m);
+}
+void launchHalpernKeepOutput(const HalpernState* st, double* outX, const double* xn, int32_t n, double* outY, const double* yn, int32_t m,
+                             hipStream_t s) {
+  hipLaunchKernelGGL(k_h_keep_output, dim3(vecBlocks(std::max(n + m, 1))), dim3(kVecThreads), 0, s, st, outX, xn, n, outY, yn, m);
+}
+
 void launchHalpernFpeRows(const double* yn, const double* ry, double* dy, int32_t m, double* part, int32_t nBlocks,
-                          hipStream_t s) {
-  hipLaunchKernelGGL(k_h_fpe_rows, dim3(nBlocks), dim3(kVecThreads), 0, s, yn, ry, dy, m, part);
+                          hipStream_t s, const int32_t* gate) {
+  hipLaunchKernelGGL(k_h_fpe_rows, dim3(nBlocks), dim3(kVecThreads), 0, s, yn, ry, dy, m, part, gate);
 }
 void launchHalpernFpeCols(const double* xn, const double* rx, const double* atd, int32_t n, double* partDx2,
-                          double* partCross, int32_t nBlocks, hipStream_t s) {
-  hipLaunchKernelGGL(k_h_fpe_cols, dim3(nBlocks), dim3(kVecThreads), 0, s, xn, rx, atd, n, partDx2, partCross);
+                          double* partCross, int32_t nBlocks, hipStream_t s, const int32_t* gate) {
+  hipLaunchKernelGGL(k_h_fpe_cols, dim3(nBlocks), dim3(kVecThreads), 0, s, xn, rx, atd, n, partDx2, partCross, gate);
 }
 void launchHalpernRowStats(const double* ax, const double* y, const double* rl, const double* rowScale,
                            const uint8_t* isEq, int32_t m, int scaled, double* part, int32_t stride, int32_t nBlocks,
-                           hipStream_t s) {
+                           hipStream_t s, const int32_t* gate) {
   hipLaunchKernelGGL(k_h_row_stats, dim3(nBlocks), dim3(kVecThreads), 0, s, ax, y, rl, rowScale, isEq, m, scaled, part,
-                     stride);
+                     stride, gate);
 }
 void launchHalpernColStats(const double* aty, const double* x, const double* cost, const double* lower,
                            const double* upper, const double* colScale, const double* cachedSlack, int32_t n,
                            int scaled, double* sp, double* sn, double* part, int32_t stride, int32_t nBlocks,
-                           hipStream_t s) {
+                           hipStream_t s, const int32_t* gate) {
   hipLaunchKernelGGL(k_h_col_stats, dim3(nBlocks), dim3(kVecThreads), 0, s, aty, x, cost, lower, upper, colScale,
-                     cachedSlack, n, scaled, sp, sn, part, stride);
+                     cachedSlack, n, scaled, sp, sn, part, stride, gate);
 }
 void launchDivScalar(double* v, double denom, int32_t len, hipStream_t s) {
   if (len <= 0) return;

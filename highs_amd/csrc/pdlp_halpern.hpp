@@ -17,19 +17,27 @@
 namespace pdlp {
 
 // vector kernels of the check iterations (pdlp_halpern.hip); partial layouts as in pdlp_kernels.hpp
+// gate (every launcher below): the kernel runs only while that device word is non-zero (nullptr: always) — the
+// device-driven loop queues whole blocks ahead and lets the decision kernel switch them off
 void launchHalpernFpeRows(const double* yn, const double* ry, double* dy, int32_t m, double* part, int32_t nBlocks,
-                          hipStream_t s);
+                          hipStream_t s, const int32_t* gate = nullptr);
 void launchHalpernFpeCols(const double* xn, const double* rx, const double* atd, int32_t n, double* partDx2,
-                          double* partCross, int32_t nBlocks, hipStream_t s);
+                          double* partCross, int32_t nBlocks, hipStream_t s, const int32_t* gate = nullptr);
 constexpr int kHRowStats = 2;  // 0: sum (((ax - rl) [min 0 on inequality rows]) * rowScale)^2   1: sum rl*y
 void launchHalpernRowStats(const double* ax, const double* y, const double* rl, const double* rowScale,
                            const uint8_t* isEq, int32_t m, int scaled, double* part, int32_t stride, int32_t nBlocks,
-                           hipStream_t s);
+                           hipStream_t s, const int32_t* gate = nullptr);
 constexpr int kHColStats = 4;  // 0: sum ((c - A'y - s+ + s-) * colScale)^2  1: sum c*x  2: sum l*s+  3: sum u*s-
 void launchHalpernColStats(const double* aty, const double* x, const double* cost, const double* lower,
                            const double* upper, const double* colScale, const double* cachedSlack, int32_t n,
                            int scaled, double* sp, double* sn, double* part, int32_t stride, int32_t nBlocks,
-                           hipStream_t s);
+                           hipStream_t s, const int32_t* gate = nullptr);
+// the device-driven loop (pdlp_halpernfn.hpp halpernDecide on the device, and what it gates)
+void launchHalpernDecide(HalpernState* st, const double* stat, HalpernRecord* ring, hipStream_t s);
+void launchHalpernRestartCopy(const HalpernState* st, double* xa, double* xc, const double* xn, int32_t n, double* ya, double* yc,
+                              const double* yn, int32_t m, hipStream_t s);
+void launchHalpernKeepOutput(const HalpernState* st, double* outX, const double* xn, int32_t n, double* outY, const double* yn, int32_t m,
+                             hipStream_t s);
 void launchDivScalar(double* v, double denom, int32_t len, hipStream_t s);  // v[i] /= denom
 
 class HalpernSolver : public SolverBase {
@@ -52,22 +60,25 @@ class HalpernSolver : public SolverBase {
   HalpernVecs stepVecs(bool major, int32_t kOff) const;
   void sumOverRanks(double* devBuf, int32_t count);
   void gatherToHost(const double* devLocal, int32_t lo, int32_t hi, bool byRows, std::vector<double>& full);
-  void spmvAt(const double* yLocal, double* atySliceInFull);  // A'y: full vector, or own column slice when sharded
+  void spmvAt(const double* yLocal, double* atySliceInFull, const int32_t* gate = nullptr);  // A'y: full vector, or own column slice when sharded
   void release() noexcept;
   struct Res { double pObj = 0, dObj = 0, gap = 0, relGap = 0, pFeas = 0, dFeas = 0; };
   double powerMethod();
   void initStepSizes();
-  void pushState();
+  void pushState();                            // the host's copy of the state record -> device
+  void pullState();                            // ... and back (device-driven loop)
+  void armState();                             // host copy: the loop may run (gate words follow the state)
   void enqueueStep(bool major, int32_t kOff);
-  void runBlock(bool fpeAfterFirst);           // steps 1..40 of one block
-  void enqueueFpe(int slot);                   // computeFixedPointError's three sums -> statOut_[slot..]
-  double fpeFrom(const double* h) const;
-  void enqueueCheck(double* x, const double* y, bool cachedSlack);  // A x, A'y + the sums of checkConvergence
-  bool evalCheck(Res& r);
+  void enqueueMinorSteps();                    // steps 2..40
+  void runBlock(bool fpeAfterFirst);           // steps 1..40 of one block (host-driven loop)
+  void enqueueUnit();                          // block + check + decision + gated copies (device-driven loop)
+  // gate (device word, nullptr = always): see pdlp_halpern.hpp launchHalpern*
+  void enqueueFpe(int slot, const int32_t* gate);   // computeFixedPointError's three sums -> statOut_[slot..]
+  void enqueueCheck(double* x, const double* y, bool cachedSlack, const int32_t* gate);  // A x, A'y + the sums of checkConvergence
+  void enqueueDiff(const int32_t* gate);       // the two restart distances -> statOut_[kHSlotDiff..]
   void fetchStats(int count);                  // all queued statistics: one all-reduce, one download, one sync
-  void updatePrimalWeight(const Res& r);
-  void restart();
-  bool restartCriteria() const;
+  void restartCopies();
+  void noteRecord(const HalpernRecord& r);     // a check's line: residuals for the result, log
   void doSolve(bool terminate, int64_t iterTarget);
   void postsolve(pdlp_result_t* R);
   double sum(const double* partials, int32_t nBlocks);
@@ -95,13 +106,15 @@ class HalpernSolver : public SolverBase {
   HalpernState* hostState_ = nullptr;  // pinned
   double* hostStats_ = nullptr;        // pinned
   int32_t stride_ = 0;
-  // host scalars of PDLPSolver (pdhg.hpp)
-  double eta_ = 0, omega_ = 0, beta_ = 0, primalWeight_ = 0, bestPrimalWeight_ = 0, bestGap_ = 0;
-  double errSum_ = 0, lastErr_ = 0, lambda_ = 0;
-  double fpe_ = 0, initialFpe_ = 0, lastTrialFpe_ = 0;
-  bool doRestart_ = false, slackValid_ = false, pid_ = true;
-  int32_t halpernIter_ = 0, nRestarts_ = 0, nChecks_ = 0;
+  // the scalars of PDLPSolver (pdhg.hpp) live in the state record (pdlp_kernels.hpp HalpernState: hostState_ is the host's
+  // copy, dState_ the device's); mirrors of its counters for the result
+  double lambda_ = 0;
+  bool pid_ = true;
+  bool devLoop_ = false;  // check iterations, restarts and the PID weight on the device (one GPU)
+  int32_t nRestarts_ = 0, nChecks_ = 0;
   int64_t iters_ = 0;
+  HalpernRecord* hostRing_ = nullptr;  // pinned: the checks' lines, written by the decision kernel
+  hipGraphExec_t unitGraph_ = nullptr; // one unit of the device-driven loop
   int termStatus_ = -1;  // -1 not set, 0 optimal, 1 iteration limit, 2 time limit
   bool haveOutput_ = false;
   Res res_;

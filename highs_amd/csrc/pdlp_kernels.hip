@@ -306,6 +306,7 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
     return;
   }
   if (usesDevState(EPI) && a.st->halted) return;
+  if ((EPI == kHalpernPrimal || EPI == kHalpernDual) && a.h.hs->halted) return;  // (HiPDLP's device-driven loop has ended)
   if (EPI == kPlain && !gateOpen(a.gate)) return;
   __shared__ double prod[CHUNK + CHUNK / 8 + 8];
   __shared__ double scratch[2][kSpmvThreads / kWave];
@@ -470,6 +471,7 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
     return;
   }
   if (usesDevState(EPI) && a.st->halted) return;
+  if ((EPI == kHalpernPrimal || EPI == kHalpernDual) && a.h.hs->halted) return;  // (HiPDLP's device-driven loop has ended)
   if (EPI == kPlain && !gateOpen(a.gate)) return;
   static_assert(GD >= 1 && NB >= GD + 2, "entry loads need two steps, gathers GD steps");
   const unsigned long long tProf0 = a.prof ? wall_clock64() : 0ull;
@@ -1081,14 +1083,16 @@ __global__ __launch_bounds__(kVecThreads) void k_final_reduce2(const double* par
 }
 
 __global__ __launch_bounds__(kVecThreads) void k_final_reduce(const double* partials, int pstride, int nBlocks,
-                                                              double* out) {
+                                                              double* out, const int32_t* gate) {
+  if (gate && *gate == 0) return;
   __shared__ double scratch[kVecThreads / kWave];
   const double s = reducePartials(partials + (size_t)blockIdx.x * pstride, nBlocks, scratch);
   if (threadIdx.x == 0) out[blockIdx.x] = s;
 }
 
 __global__ __launch_bounds__(kVecThreads) void k_diff_norm2(const double* __restrict__ a, const double* __restrict__ b,
-                                                            int len, double* partials) {
+                                                            int len, double* partials, const int32_t* gate) {
+  if (gate && *gate == 0) return;
   __shared__ double scratch[kVecThreads / kWave];
   double s = 0.0;
   const int stride = gridDim.x * blockDim.x;
@@ -1366,12 +1370,12 @@ void launchDivInPlace(double* x, const double* y, int32_t len, hipStream_t s) {
   hipLaunchKernelGGL(k_div, dim3(vecBlocks(len)), dim3(kVecThreads), 0, s, x, y, len);
 }
 void launchFinalReduce(const double* partials, int32_t stride, int32_t nBlocks, int32_t nQ, double* out,
-                       hipStream_t s) {
-  hipLaunchKernelGGL(k_final_reduce, dim3(nQ), dim3(kVecThreads), 0, s, partials, stride, nBlocks, out);
+                       hipStream_t s, const int32_t* gate) {
+  hipLaunchKernelGGL(k_final_reduce, dim3(nQ), dim3(kVecThreads), 0, s, partials, stride, nBlocks, out, gate);
 }
 void launchDiffNorm2(const double* a, const double* b, int32_t len, double* partials, int32_t nBlocks,
-                     hipStream_t s) {
-  hipLaunchKernelGGL(k_diff_norm2, dim3(nBlocks), dim3(kVecThreads), 0, s, a, b, len, partials);
+                     hipStream_t s, const int32_t* gate) {
+  hipLaunchKernelGGL(k_diff_norm2, dim3(nBlocks), dim3(kVecThreads), 0, s, a, b, len, partials, gate);
 }
 namespace {
 // Per slab block b (majors [waveBeg[16 b], waveBeg[16 b + 16])), ONE workgroup each: smallest and largest minor index over

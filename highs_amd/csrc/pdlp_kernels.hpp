@@ -215,8 +215,32 @@ struct HalpernState {
   double tau, sigma;  // stepsize_.primal_step / dual_step
   double rho;         // params_.halpern_gamma (1 = full reflection)
   int32_t hIter;      // halpern_iteration_ at the start of the block
-  int32_t pad_;
+  int32_t halted;     // the device-driven loop has ended (converged, iteration limit): every kernel queued behind is a no-op
+  // ---- the scalars of PDLPSolver (pdhg.hpp) that the check iteration reads and writes: on the device the block's
+  // decision kernel updates them (pdlp_halpernfn.hpp halpernDecide), in the host-driven loop (sharded, profile mode) the
+  // same function runs on the host's copy ----
+  double eta, omega, primalWeight, bestPrimalWeight, bestGap, errSum, lastErr;
+  double fpe, initialFpe, lastTrialFpe;
+  double normRhs, normCost, offset, tol;
+  long long iters, iterLimit;
+  int32_t run;        // gate word of the block's kernels: 1 while the loop runs (= !halted)
+  int32_t runFpe0;    // gate word of the initial fixed-point error behind the block's first step: a restart came before
+  int32_t doRestart;  // gate word of the restart copies (anchor and current iterate <- pdhg iterate of the last major step)
+  int32_t converged;  // gate word of the output copy
+  int32_t pid, terminate, nRestarts, nChecks;
+  int32_t termStatus;
+  int32_t fpe0Pending;  // the next block starts behind a restart (runFpe0 is this word while the loop runs, 0 once it has halted)
 };
+// One line of the check, written by the device into pinned host memory (a ring): what the host logs and returns.
+struct HalpernRecord {
+  long long iters;
+  double pObj, dObj, gap, relGap, pFeas, dFeas, fpe, primalWeight;
+  int32_t restarted, converged;
+};
+constexpr int kHalpernRing = 32;
+// slots of the statistics vector of one check (pdlp_halpern.cpp): three sums of the fixed-point error, the six sums of
+// checkConvergence, the three sums of the initial fixed-point error, the two restart distances
+constexpr int kHSlotFpe = 0, kHSlotCheck = 3, kHSlotFpe0 = 9, kHSlotDiff = 12, kHStatOut = 16;
 struct HalpernVecs {
   double* xc; double* yc;          // x_current_, y_current_
   double* xn; double* yn;          // x_next_, y_next_ (pdhg iterate of the last MAJOR step)
@@ -314,6 +338,7 @@ inline __host__ __device__ size_t smallBarWords(int grid) { return ((2 * (size_t
 struct CheckGate {
   const DevState* st = nullptr;
   const CheckCtl* cc = nullptr;
+  const int32_t* flag = nullptr;  // HiPDLP's device-driven loop: the kernel runs only while this word is non-zero
 };
 void launchFlushAverage(const IterVecs& v, DevState* st, hipStream_t s);
 void launchClearAvgW(DevState* st, hipStream_t s);  // the pending average weights of *st have been consumed
@@ -348,10 +373,10 @@ void launchMulInPlace(double* x, const double* y, int32_t len, hipStream_t s);  
 void launchDivInPlace(double* x, const double* y, int32_t len, hipStream_t s);   // x /= y
 // out[q] = sum_{b<nBlocks} partials[q*stride+b], q < nQ (deterministic)
 void launchFinalReduce(const double* partials, int32_t stride, int32_t nBlocks, int32_t nQ, double* out,
-                       hipStream_t s);
+                       hipStream_t s, const int32_t* gate = nullptr);  // gate: the kernel runs only while this device word is non-zero
 // partials of ||a-b||^2
 void launchDiffNorm2(const double* a, const double* b, int32_t len, double* partials, int32_t nBlocks,
-                     hipStream_t s);
+                     hipStream_t s, const int32_t* gate = nullptr);
 // partials of a.b
 void launchDot(const double* a, const double* b, int32_t len, double* partials, int32_t nBlocks, hipStream_t s);
 

@@ -48,6 +48,7 @@
 #include <string.h>
 #include <time.h>
 
+#include "det_math.h"
 #include "gpu_order.h"
 #include "pdlp_oracle.h"
 
@@ -496,15 +497,20 @@ static void h_update_weight(HState* S, const HRes* res) {
   const double relP = res->pFeas / (1.0 + L->bNorm), relD = res->dFeas / (1.0 + L->cNorm);
   const double ratio = relP > 0.0 ? relD / relP : 1e300;
   if (pd > 1e-16 && dd > 1e-16 && pd < 1e12 && dd < 1e12 && ratio > 1e-8 && ratio < 1e8) {
-    const double err = log(dd) - log(pd) - log(S->pw);
+    /* device-order mode: the product's check iteration runs on the device and computes log / exp in plain arithmetic
+     * (det_math.h is this oracle's own restatement of those functions); the reference, and the serial mode, call libm */
+    const double err = S->dev ? o_det_log(dd) - o_det_log(pd) - o_det_log(S->pw) : log(dd) - log(pd) - log(S->pw);
     S->errSum = 0.3 * S->errSum + err;
     const double dErr = err - S->lastErr;
-    S->pw *= exp(0.99 * err + 0.01 * S->errSum + 0.0 * dErr);
+    const double arg = 0.99 * err + 0.01 * S->errSum + 0.0 * dErr;
+    S->pw *= S->dev ? o_det_exp(arg) : exp(arg);
     S->lastErr = err;
   } else {
     S->pw = S->bestPw; S->errSum = 0.0; S->lastErr = 0.0;
   }
-  const double gap = (relP > 0.0 && relD > 0.0) ? fabs(log10(relD / relP)) : S->bestGap;
+  const double gap = (relP > 0.0 && relD > 0.0)
+                         ? (S->dev ? fabs(o_det_log(relD / relP) * 0.4342944819032518 /* 1 / ln 10 */) : fabs(log10(relD / relP)))
+                         : S->bestGap;
   if (gap < S->bestGap) { S->bestGap = gap; S->bestPw = S->pw; }
   const double eta = sqrt(S->tau * S->sigma);
   S->beta = S->pw * S->pw;
