@@ -12,7 +12,7 @@
 export PDLP_MI355X_DEV=1  # the switches below are development switches (highs_amd/csrc/pdlp_env.hpp)
 set -u
 R=$(cd "$(dirname "$0")/.." && pwd)
-RND=${1:-r05}
+RND=${1:-r06}
 if [ "${2:-}" = "collect" ]; then
   S=$R/gpurun_out/profiles_$RND
   cp $S/r*.json $S/r*.csv $S/r*.log $R/profiles/ 2>/dev/null
@@ -25,17 +25,19 @@ mkdir -p $OUT
 cd $R
 # PMC traffic of the dominant kernels of every configuration first (separate --pmc passes): the bench lines below then
 # carry THIS tree's counters in roofline.traffic (bench.py reads profiles/pmc_traffic.json)
-bash tools/pmc_traffic.sh $RND > $OUT/pmc_traffic.log 2>&1
+bash tools/pmc_traffic.sh $RND b a c d e f qp qpn > $OUT/pmc_traffic.log 2>&1
 cp $OUT/pmc_traffic.json $R/profiles/pmc_traffic.json
 python bench.py > $OUT/${RND}_bench_1M.json 2> $OUT/bench_1M.err
 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${RND}_bench_1M_driver_flags.json 2>> $OUT/bench_1M.err
 python bench.py --config a > $OUT/${RND}_bench_100k.json 2>> $OUT/bench_1M.err
 python bench.py --config c > $OUT/${RND}_bench_structured.json 2>> $OUT/bench_1M.err
 python bench.py --config d > $OUT/${RND}_bench_staircase_dense_columns.json 2>> $OUT/bench_1M.err
+python bench.py --config e > $OUT/${RND}_bench_heldout_tall.json 2>> $OUT/bench_1M.err
+python bench.py --config f > $OUT/${RND}_bench_heldout_powerlaw_band.json 2>> $OUT/bench_1M.err
 python bench.py --config qp > $OUT/${RND}_bench_qp.json 2>> $OUT/bench_1M.err
 python bench.py --config qpn > $OUT/${RND}_bench_qp_sparse_hessian.json 2>> $OUT/bench_1M.err
 python bench.py --solver hipdlp > $OUT/${RND}_bench_hipdlp_1M.json 2>> $OUT/bench_1M.err
-for cfg in b c d qp; do  # per-block phase profile of the two slab launches of a trial (development buffer, 100 MHz wall clock)
+for cfg in b c d e f qp; do  # per-block phase profile of the two slab launches of a trial (development buffer, 100 MHz wall clock)
   echo "== bench.py --config $cfg (PDLP_MI355X_SLAB_PROF=1)"
   PDLP_MI355X_SLAB_PROF=1 python bench.py --config $cfg --cpu-iters 0 2>&1 >/dev/null | grep "slab launch"
 done > $OUT/${RND}_slab_phase_profile.log
@@ -74,6 +76,10 @@ PY
 if [ -e $R/integration/_build/libhighs.so.1 ]; then
   python tools/mps_bench.py --config c --threads 1,8,16,32,64,0 --reps 2 > $OUT/${RND}_mps_ingest_gpu_box_host.json 2> $OUT/mps_bench.err
   bash tools/e2e_cli.sh b > $OUT/${RND}_e2e_reference_cli_1M.log 2>&1
+  # Highs::run()-level time to solution, reference CLI (CPU) vs drop-in CLI (GPU), same .mps, same options
+  timeout 3000 python tools/time_to_solution.py a b > $OUT/${RND}_time_to_solution.json 2> $OUT/time_to_solution.err
 fi
+bash tools/bringup_multi_gpu.sh 4 $OUT/bringup > $OUT/${RND}_bringup_multi_gpu.log 2>&1
+cp $OUT/bringup/bringup.jsonl $OUT/${RND}_bringup_multi_gpu.jsonl 2>/dev/null
 PYTEST_TIMEOUT=2400 bash tools/gpu_pytest.sh profiles_$RND/${RND}_pytest_gpu tests -m gpu -q
 echo done
