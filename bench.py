@@ -146,6 +146,48 @@ def scaling_model(n, m, nnz, G, ax_us_1gpu, aty_us_1gpu, vec_us_1gpu):
                            % (link_gbs, hop_us, floor_us, boundary_us)}
 
 
+def _reference_highs_fn(lib_path, solver_name):
+    """A solve function with the signature of the oracle's (problem, params, result) that runs the reference itself:
+    highs_c_api.h of libhighs_reference.so.1 (interfaces/highs_c_api.h: Highs_passLp, Highs_setStringOptionValue, Highs_run)."""
+    H = C.CDLL(lib_path)
+    H.Highs_create.restype = C.c_void_p
+    vp, i32, f64 = C.c_void_p, C.c_int32, C.c_double
+    pd, pi = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    H.Highs_passLp.argtypes = [vp, i32, i32, i32, i32, i32, f64, pd, pd, pd, pd, pd, pi, pi, pd]
+    H.Highs_setStringOptionValue.argtypes = [vp, C.c_char_p, C.c_char_p]
+    H.Highs_setBoolOptionValue.argtypes = [vp, C.c_char_p, i32]
+    H.Highs_setIntOptionValue.argtypes = [vp, C.c_char_p, i32]
+    H.Highs_setDoubleOptionValue.argtypes = [vp, C.c_char_p, f64]
+    H.Highs_getIntInfoValue.argtypes = [vp, C.c_char_p, pi]
+    H.Highs_run.argtypes = [vp]
+    H.Highs_destroy.argtypes = [vp]
+
+    def fn(p_ref, o_ref, r_ref):
+        P, o, R = p_ref._obj, o_ref._obj, r_ref._obj
+        h = H.Highs_create()
+        H.Highs_setBoolOptionValue(h, b"output_flag", 0)
+        H.Highs_setStringOptionValue(h, b"solver", solver_name.encode())
+        H.Highs_setStringOptionValue(h, b"presolve", b"off")
+        H.Highs_setDoubleOptionValue(h, b"kkt_tolerance", o.gap_tol)
+        H.Highs_setIntOptionValue(h, b"pdlp_iteration_limit", int(o.iter_limit))
+        cast = lambda q, t: C.cast(q, t)
+        rc = H.Highs_passLp(h, P.num_col, P.num_row, int(P.a_start[P.num_col]), 1, int(P.sense), float(P.offset), cast(P.col_cost, pd),
+                            cast(P.col_lower, pd), cast(P.col_upper, pd), cast(P.row_lower, pd), cast(P.row_upper, pd),
+                            cast(P.a_start, pi), cast(P.a_index, pi), cast(P.a_value, pd))
+        if rc not in (0, 1):
+            H.Highs_destroy(h)
+            return 1
+        t0 = time.perf_counter()
+        H.Highs_run(h)
+        R.solve_seconds = time.perf_counter() - t0
+        it = C.c_int32(0)
+        H.Highs_getIntInfoValue(h, b"pdlp_iteration_count", C.byref(it))
+        R.num_iter = it.value
+        H.Highs_destroy(h)
+        return 0
+    return fn
+
+
 def cpu_baseline(sp_struct, cfg, limits, solver_name="pdlp"):
     """Reference CPU pdlp (single thread) on a bounded sample of the same LP, as SURVEY §8(d) prescribes: the same
     solve at TWO iteration limits, iterations/s = the slope between them — set-up and the start-up phase (a check at
@@ -153,7 +195,12 @@ def cpu_baseline(sp_struct, cfg, limits, solver_name="pdlp"):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oraclelib as O
     from highs_amd import abi
-    if solver_name == "hipdlp":  # no compiled reference for this path: the oracle restatement
+    ref_lib = os.path.join(ROOT, "integration", "_build", "libhighs_reference.so.1")
+    if solver_name == "hipdlp" and os.path.exists(ref_lib):
+        # the UNMODIFIED reference library (integration/Makefile `reference`: every TU compiled from the reference tree, travels
+        # with the snapshot) through its own C API: Highs_passLp + solver=hipdlp + Highs_run
+        kind, fn = "reference", _reference_highs_fn(ref_lib, "hipdlp")
+    elif solver_name == "hipdlp":  # no reference build on this box: the oracle restatement
         kind, fn = "port", O.hipdlp_solve_fn()
     elif sp_struct.q_dim > 0:  # no PDLP-QP in the reference: this repository's own CPU restatement
         kind, fn = "port", O.oracle().pdlp_oracle_solve

@@ -286,29 +286,16 @@ __device__ __forceinline__ int gridWait(unsigned long long* bar, int blk, int nB
     else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   const unsigned long long t0 = wall_clock64();
-  // The words of a lane (up to kSweepPer, i.e. 512 blocks) are loaded back to back and looked at afterwards: one memory
-  // round trip per sweep whatever the number of words (measured the same as the plain loop at 256 and 512 words, round 6 —
-  // what the release waited for was the arrival, see gridArrive).
-  constexpr int kSweepPer = 8;
+  // (Round 6 also tried loading all words of a sweep back to back — eight at 512 blocks — instead of this loop: the release
+  // came no earlier, and the sixteen registers of the word array spilled in the fused kernel.  What the release waits for
+  // is the arrival, see gridArrive.)
   for (uint32_t spins = 0;; ++spins) {
     bool ok = true, bad = false, stale = false;
-    auto look = [&](unsigned long long v) {
+    for (int i = lane; i < nBlocks; i += kWave) {
+      const unsigned long long v = ld(bar + i);
       ok = ok && v >= epoch;
       bad = bad || (v & kBarPoison) != 0;
       stale = stale || ((v & kBarPoison) != 0 && (v & ~kBarPoison) < epoch);
-    };
-    const int nB = __builtin_amdgcn_readfirstlane(nBlocks);
-    if (!LOCAL && nB <= kSweepPer * kWave) {
-      unsigned long long v[kSweepPer];
-#pragma unroll
-      for (int k = 0; k < kSweepPer; ++k) {  // clamped; the condition is wave-uniform (scalar branch): all loads in flight together
-        const int i = lane + k * kWave;
-        v[k] = (k * kWave < nB) ? ld(bar + (i < nB ? i : nB - 1)) : epoch;
-      }
-#pragma unroll
-      for (int k = 0; k < kSweepPer; ++k) look(v[k]);
-    } else {
-      for (int i = lane; i < nBlocks; i += kWave) look(ld(bar + i));
     }
     if (__any(stale)) return kBarBroken;
     if (__any(bad)) return kBarFailed;

@@ -13,6 +13,7 @@
 // reductions (tree order here, left-to-right there) differ in the last bits.
 #include "pdlp_kernels.hpp"
 
+#include <algorithm>
 #include <climits>
 #include <cmath>
 #include <cstddef>
@@ -463,7 +464,12 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
 constexpr int kSlabSlots = 3;  // register pipeline depth (groups of 64 entries per wave)
 // TWO: register budget for two resident blocks per CU (8 waves per SIMD) — the extra blocks with the segment
 // tasks of the long majors then run NEXT to the streaming blocks instead of after them.
-template <int EPI, bool TWO, int NB, int GD>
+// LATE (kAtyFused): the operands of the next primal step that no decision can change (c, l, u, xSum, q) are fetched behind
+// the block's ARRIVAL at the grid barrier instead of travelling with the stream, and for TWICE as many columns per thread
+// (the stream's registers are free by then): 8192 columns per block (4096 in the 64-register variant) are stepped from
+// registers behind the barrier, nothing but the stores left there (round 6: config c spent 13 us behind its barrier on
+// 8200 columns per block, half of them fetched there).
+template <int EPI, bool TWO, int NB, int GD, bool LATE = false>
 __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabThreads / 256) void k_spmv_slab(const SpmvArgs a) {
   if (EPI == kAtyFused && a.st->halted) {  // keep the two state slots identical while the queue drains
     if (blockIdx.x == 0 && threadIdx.x < sizeof(DevState) / 4)
@@ -536,8 +542,10 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
   }
   // kAtyFused: the operands of the NEXT primal step that no decision can change (c, l, u, xSum) travel with the stream
   // (not in the 64-register variant that leaves room for the task workgroups: there they are fetched behind the barrier)
-  constexpr bool kFixEarly = !TWO;
-  Pre fix[EPI == kAtyFused ? kSlabPre : 1];
+  constexpr bool kFixEarly = !TWO && !LATE;
+  constexpr int kFixN = EPI == kAtyFused ? (LATE ? 2 * kSlabPre : kSlabPre) : 1;  // columns per thread stepped from registers
+  Pre fix[kFixN];
+  double xbLate[LATE ? kSlabPre : 1];  // x+ of the second kSlabPre columns (the first ones': pre[k].b)
   if (EPI == kAtyFused && kFixEarly) {
 #pragma unroll
     for (int k = 0; k < kSlabPre; ++k) {
@@ -699,14 +707,17 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
     }
   }
   if (EPI == kAtyFused && !kFixEarly) {
-    // (the 64-register variant: the stream's pipeline registers are free now — the operands of the next primal step are
-    // fetched here, in flight across the grid barrier and the decision instead of behind them)
+    // (the stream's pipeline registers are free now — the operands of the next primal step are fetched here, in flight
+    // across the grid barrier and the decision instead of behind them)
 #pragma unroll
-    for (int k = 0; k < kSlabPre; ++k) {
+    for (int k = 0; k < kFixN; ++k) {
       const int r0_ = rBase + tid + k * kSlabThreads;
       const int r = r0_ < rEnd ? r0_ : rEnd - 1;
       fix[k].a = ldStream(a.v.cost + r); fix[k].b = ldStream(a.v.lower + r); fix[k].c = ldStream(a.v.upper + r);
-      fix[k].d = ldStream(a.v.xSum + r); fix[k].e = a.v.qdiag ? ldStream(a.v.qdiag + r) : 0.0;
+      fix[k].d = ldStream(a.v.xSum + r);
+      // (the diagonal of Q of a QP's prox step: in a register for the first kSlabPre columns, fetched behind the barrier for the others)
+      fix[k].e = (k < kSlabPre && a.v.qdiag) ? ldStream(a.v.qdiag + r) : 0.0;
+      if (LATE && k >= kSlabPre) xbLate[k - kSlabPre] = ldStream(a.v.x[epi.nxt] + r);  // (x+ of the trial: what the step starts from when it is accepted)
     }
   }
   if (EPI == kAtyFused) {
@@ -772,10 +783,25 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
         step(r, accepted ? pre[k].b : ldStream(xBase + r), ab, fix[k].a, fix[k].b, fix[k].c, fix[k].d, fix[k].e);
       }
     }
-    for (int lr0 = tid + kSlabPre * kSlabThreads; rBase + lr0 < rEnd; lr0 += kSlabPre * kSlabThreads) {  // (more than 4096 majors per block:
-      double xb[kSlabPre], ab[kSlabPre], cc[kSlabPre], ll[kSlabPre], uu[kSlabPre], xs[kSlabPre], qq[kSlabPre];  //  kSlabPre columns' operands per round trip)
+    if (LATE) {  // the second kSlabPre columns per thread: from registers too
 #pragma unroll
-      for (int k = 0; k < kSlabPre; ++k) {
+      for (int k = kSlabPre; k < kFixN; ++k) {
+        const int lr = tid + k * kSlabThreads;
+        if (rBase + lr < rEnd) {
+          const int r = rBase + lr;
+          const double ab = isLong(lr) ? ldAgent(atyBase + r) : accepted ? acc[lr] : ldStream(atyBase + r);
+          step(r, accepted ? xbLate[k - kSlabPre] : ldStream(xBase + r), ab, fix[k].a, fix[k].b, fix[k].c, fix[k].d,
+               a.v.qdiag ? ldStream(a.v.qdiag + r) : 0.0);
+        }
+      }
+    }
+    // (more columns per block than that: kTail columns' operands per round trip — two in the LATE variants, where this
+    // loop only sees blocks beyond 8192 / 4096 columns and the registers hold twice as many columns across the barrier)
+    constexpr int kTail = LATE ? 2 : kSlabPre;
+    for (int lr0 = tid + kFixN * kSlabThreads; rBase + lr0 < rEnd; lr0 += kTail * kSlabThreads) {
+      double xb[kTail], ab[kTail], cc[kTail], ll[kTail], uu[kTail], xs[kTail], qq[kTail];
+#pragma unroll
+      for (int k = 0; k < kTail; ++k) {
         const int lr1 = lr0 + k * kSlabThreads;
         const int lr = rBase + lr1 < rEnd ? lr1 : rEnd - 1 - rBase;
         const int r = rBase + lr;
@@ -785,7 +811,7 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
         qq[k] = a.v.qdiag ? ldStream(a.v.qdiag + r) : 0.0;
       }
 #pragma unroll
-      for (int k = 0; k < kSlabPre; ++k) {
+      for (int k = 0; k < kTail; ++k) {
         const int lr = lr0 + k * kSlabThreads;
         if (rBase + lr < rEnd) step(rBase + lr, xb[k], ab[k], cc[k], ll[k], uu[k], xs[k], qq[k]);
       }
@@ -1247,7 +1273,7 @@ int fusedAtyBlocksResident(const MatView& At, int device) {
     if (At.slab.nBlocks <= 0) return 0;
     e = At.coTaskBlocks > 0
             ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_spmv_slab<kAtyFused, true, kSlabSlots, 1>, kSlabThreads, fusedLds(At))
-            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_spmv_slab<kAtyFused, false, kSlabSlots, 1>, kSlabThreads, fusedLds(At));
+            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_spmv_slab<kAtyFused, false, kSlabSlots, 1, true>, kSlabThreads, fusedLds(At));
   } else {
     if (At.csr.nBlocks <= 0) return 0;
     e = At.csr.chunk == kChunkSmall ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_spmv<kAtyFused, kChunkSmall>, kSpmvThreads, 0)
@@ -1270,10 +1296,12 @@ void launchSpmvAtyFusedPrimal(const MatView& At, const IterVecs& v, const DevSta
   a.stOut = stOut; a.partDY = partDY; a.nDY = nDY; a.nDX = At.nPartials; a.bar = bar;
   if (At.useSlab && At.slab.nBlocks <= 512) a.prof = slabProf();
   a.xcdMap = At.xcdMap; a.L = At.lng; a.A = At.csr; a.S = At.slab;
+  // (LATE — twice as many columns stepped from registers behind the barrier — in the 128-register variant only: in the
+  // 64-register one, which carries the task workgroups, it spills and measured slower: config d 36.5 -> 41.2 us, round 6)
   if (At.useSlab && a.coTaskBlocks > 0)
-    hipLaunchKernelGGL((k_spmv_slab<kAtyFused, true, kSlabSlots, 1>), dim3(At.slab.nBlocks + a.coTaskBlocks), dim3(kSlabThreads), fusedLds(At), s, a);
+    hipLaunchKernelGGL((k_spmv_slab<kAtyFused, true, kSlabSlots, 1, false>), dim3(At.slab.nBlocks + a.coTaskBlocks), dim3(kSlabThreads), fusedLds(At), s, a);
   else if (At.useSlab)
-    hipLaunchKernelGGL((k_spmv_slab<kAtyFused, false, kSlabSlots, 1>), dim3(At.slab.nBlocks), dim3(kSlabThreads), fusedLds(At), s, a);
+    hipLaunchKernelGGL((k_spmv_slab<kAtyFused, false, kSlabSlots, 1, true>), dim3(At.slab.nBlocks), dim3(kSlabThreads), fusedLds(At), s, a);
   else if (At.csr.chunk == kChunkSmall)
     hipLaunchKernelGGL((k_spmv<kAtyFused, kChunkSmall>), dim3(At.csr.nBlocks), dim3(kSpmvThreads), 0, s, a);
   else
@@ -1428,6 +1456,16 @@ void launchBlockSpan(const int32_t* beg, const int32_t* idx, const int32_t* wave
   if (nTiles > kSpanMaxTiles) hist = nullptr;  // (xcdTileLog2 never asks for more)
   hipLaunchKernelGGL(k_block_span, dim3(nBlocks), dim3(kVecThreads), 0, s, beg, idx, waveBeg, nBlocks, longLimit, lo, hi, cnt, tileLog2,
                      nTiles, hist);
+}
+namespace {
+__global__ __launch_bounds__(kVecThreads) void k_add_int(int32_t* v, int32_t d, long long len) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += stride) v[i] += d;
+}
+}  // namespace
+void launchAddInt(int32_t* v, int32_t d, int64_t len, hipStream_t s) {
+  if (len <= 0) return;
+  hipLaunchKernelGGL(k_add_int, dim3(vecBlocks((int32_t)std::min<int64_t>(len, 1 << 30))), dim3(kVecThreads), 0, s, v, d, (long long)len);
 }
 void launchDot(const double* a, const double* b, int32_t len, double* partials, int32_t nBlocks, hipStream_t s) {
   hipLaunchKernelGGL(k_dot, dim3(nBlocks), dim3(kVecThreads), 0, s, a, b, len, partials);

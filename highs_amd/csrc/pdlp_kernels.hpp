@@ -417,6 +417,7 @@ void launchRestartFinish(DevState* st, CheckCtl* cc, const double* partX, int32_
                          CheckRecord* rec, hipStream_t s);
 
 int32_t vecBlocks(int32_t len);  // grid size used by the vector/statistics kernels
+void launchAddInt(int32_t* v, int32_t d, int64_t len, hipStream_t s);  // v[i] += d (set-up: rebasing index arrays of a shard)
 
 // ---- set-up: which slab width suits an operand ----
 // lo/hi/cnt [nBlocks]: column span and entry count of each slab block's short majors (INT_MAX / -1 / 0 for a block without

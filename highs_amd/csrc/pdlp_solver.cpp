@@ -448,10 +448,30 @@ void Solver::construct(const pdlp_problem_t& P, const void* id128) {
     sumRhs2_ = devProb.sumRhs2;
   } else if (shardedGpuSetup) {
     gpuPrepare(P, doScale, stream_, devProb);
-    downloadForm(devProb, F_, stream_);
     sumCost2_ = devProb.sumCost2;
     sumRhs2_ = devProb.sumRhs2;
-    devProb = DeviceProblem();  // released before any exchange kernel of another rank can run on this device
+    // A rank keeps only its shard (round 6): in the two-all-gathers layout of the mesh exchange both operands of a rank
+    // are CONTIGUOUS pieces of the two orientations that the device-side set-up has just built (rows [r0, r1) of A by rows,
+    // columns [c0, c1) of A by columns), so they are cut on the device (uploadShardFromDevice below) and nothing but the
+    // row starts (4 bytes per row, for the row partition) and the scale vectors crosses PCIe.  The RCCL exchange and the
+    // round-1 mesh layout need the transpose of the row slab: the whole form comes to the host as before.
+    shardOnDevice_ = sw_.exchange != "rccl" && sw_.meshLayout != "partial";
+    if (shardOnDevice_) {
+      F_ = StandardForm();
+      F_.n = devProb.n; F_.m = devProb.m; F_.n0 = devProb.n0; F_.nEqs = devProb.nEqs; F_.nnz = devProb.nnz;
+      F_.scaled = devProb.scaled; F_.offset = devProb.offset; F_.sense = devProb.sense;
+      F_.normCost = devProb.normCost; F_.normRhs = devProb.normRhs; F_.matNormInf = devProb.matNormInf;
+      F_.rowKind = std::move(devProb.rowKind);
+      F_.rowNewIdx = std::move(devProb.rowNewIdx);
+      F_.colScale = std::move(devProb.hColScale);
+      F_.rowScale = std::move(devProb.hRowScale);
+      F_.csr.beg.resize((size_t)F_.m + 1);
+      devProb.A.beg.download(F_.csr.beg.data(), F_.csr.beg.size(), stream_);
+      PDLP_HIP(hipStreamSynchronize(stream_));
+    } else {
+      downloadForm(devProb, F_, stream_);
+      devProb = DeviceProblem();  // released before any exchange kernel of another rank can run on this device
+    }
   } else {
     formulate(P, F_);
     if (doScale) scale(F_);
@@ -494,6 +514,18 @@ void Solver::construct(const pdlp_problem_t& P, const void* id128) {
     std::vector<int32_t> off = rowPartition(F_.csr, F_.m, world_);
     r0_ = off[rank_];
     r1_ = off[rank_ + 1];
+    if (shardOnDevice_) {
+      // (the mesh's column slices, pdlp_mesh.hip: n * h / world) — the shard is cut, and every temporary of the cut is
+      // released, BEFORE the exchange exists: a hipFree synchronises the device, and with several ranks folded onto one
+      // device it would wait for a peer's kernel that is waiting for this rank
+      c0_ = (int32_t)((int64_t)F_.n * rank_ / world_);
+      c1_ = (int32_t)((int64_t)F_.n * (rank_ + 1) / world_);
+      nLoc_ = c1_ - c0_;
+      mLoc_ = r1_ - r0_;
+      uploadShardFromDevice(devProb);
+      devProb = DeviceProblem();
+      PDLP_HIP(hipStreamSynchronize(stream_));
+    }
     // Exchange: the direct xGMI mesh unless PDLP_MI355X_EXCHANGE=rccl, or the mesh cannot be
     // set up / fails its known-answer test on some rank (then EVERY rank uses RCCL).
     bool wantMesh = sw_.exchange != "rccl";
@@ -511,8 +543,17 @@ void Solver::construct(const pdlp_problem_t& P, const void* id128) {
       }
     }
     meshMode_ = mesh_ != nullptr;
+    if (shardOnDevice_ && !meshMode_) {
+      // the direct exchange is not available after all: the RCCL path needs the transpose of the row slab — prepare
+      // again and bring the whole form to the host (every rank takes this branch together: allAgree above)
+      DeviceProblem again;
+      gpuPrepare(P, doScale, stream_, again);
+      downloadForm(again, F_, stream_);
+      shardOnDevice_ = false;
+    }
     if (meshMode_) {
       colblock_ = sw_.meshLayout != "partial";
+      if (shardOnDevice_ && (c0_ != mesh_->c0() || c1_ != mesh_->c1())) throw std::runtime_error("pdlp_mi355x: column slices of the shard cut and of the exchange differ");
       c0_ = mesh_->c0();
       c1_ = mesh_->c1();
       nLoc_ = c1_ - c0_;
@@ -533,6 +574,7 @@ void Solver::construct(const pdlp_problem_t& P, const void* id128) {
   }
   mLoc_ = r1_ - r0_;
   if (gpuSetup_) uploadProblemFromDevice(devProb);
+  else if (shardOnDevice_) allocIterates();  // (the operands and vectors of the shard are in place: uploadShardFromDevice)
   else uploadProblem();
   // block -> XCD assignment of the two operands (x_ / y_ are zero here: any input will do)
   tuneXcdMap(dA_, sw_, x_[0].get(), ax_[0].get(), stream_);
@@ -704,6 +746,61 @@ void Solver::uploadProblemFromDevice(DeviceProblem& D) {
     log(1, "Quadratic objective (diagonal Hessian): proximal primal step\n");
   }
   allocIterates();
+}
+
+// rows / columns [lo, hi) of a device CSR as a matrix of its own (contiguous piece: two device-to-device copies, the
+// major starts rebased on the host — 4 bytes per major of the piece)
+static void sliceDeviceCsr(const DeviceCsrData& M, int32_t lo, int32_t hi, hipStream_t s, DeviceCsrData& out) {
+  const int32_t nMaj = hi - lo;
+  std::vector<int32_t> hb((size_t)nMaj + 1);
+  PDLP_HIP(hipMemcpyAsync(hb.data(), M.beg.get() + lo, sizeof(int32_t) * hb.size(), hipMemcpyDeviceToHost, s));
+  PDLP_HIP(hipStreamSynchronize(s));
+  const int32_t p0 = hb[0];
+  const int64_t nnz = (int64_t)hb[nMaj] - p0;
+  for (int32_t& v : hb) v -= p0;
+  out.nMajor = nMaj; out.nMinor = M.nMinor; out.nnz = nnz;
+  out.beg.alloc(hb.size());
+  out.beg.upload(hb.data(), hb.size(), s);
+  out.idx.alloc((size_t)nnz + 1);  // one pad element: the kernels clamp, never predicate, their loads
+  out.val.alloc((size_t)nnz + 1);
+  out.major.alloc((size_t)std::max<int64_t>(nnz, 1));
+  out.idx.zero(s);
+  out.val.zero(s);
+  if (nnz > 0) {
+    PDLP_HIP(hipMemcpyAsync(out.idx.get(), M.idx.get() + p0, sizeof(int32_t) * nnz, hipMemcpyDeviceToDevice, s));
+    PDLP_HIP(hipMemcpyAsync(out.val.get(), M.val.get() + p0, sizeof(double) * nnz, hipMemcpyDeviceToDevice, s));
+    PDLP_HIP(hipMemcpyAsync(out.major.get(), M.major.get() + p0, sizeof(int32_t) * nnz, hipMemcpyDeviceToDevice, s));
+    launchAddInt(out.major.get(), -lo, nnz, s);  // entry -> LOCAL major
+  }
+  PDLP_HIP(hipStreamSynchronize(s));  // hb goes out of scope
+}
+
+// The shard of this rank from the device-prepared problem (two-all-gathers layout): A x operand = rows [r0, r1) of A by
+// rows, A'y operand = columns [c0, c1) of A by columns (over ALL rows: every column is summed in the single-GPU order),
+// column vectors whole (x is replicated), row vectors cut to the own rows.  Same bits as the host cut (uploadProblem).
+void Solver::uploadShardFromDevice(DeviceProblem& D) {
+  dAt_.majorCost = kSlabMajorCostCols;
+  {
+    DeviceCsrData As, Ats;
+    sliceDeviceCsr(D.A, r0_, r1_, stream_, As);
+    sliceDeviceCsr(D.At, c0_, c1_, stream_, Ats);
+    D.A = DeviceCsrData();
+    D.At = DeviceCsrData();
+    dA_.buildFromDevice(As, sw_, stream_);
+    dAt_.buildFromDevice(Ats, sw_, stream_);
+  }
+  cost_ = std::move(D.cost); lower_ = std::move(D.lower); upper_ = std::move(D.upper); colScale_ = std::move(D.colScale);
+  rhs_.alloc((size_t)std::max(mLoc_, 1));
+  rowScale_.alloc((size_t)std::max(mLoc_, 1));
+  if (mLoc_ > 0) {
+    PDLP_HIP(hipMemcpyAsync(rhs_.get(), D.rhs.get() + r0_, sizeof(double) * mLoc_, hipMemcpyDeviceToDevice, stream_));
+    PDLP_HIP(hipMemcpyAsync(rowScale_.get(), D.rowScale.get() + r0_, sizeof(double) * mLoc_, hipMemcpyDeviceToDevice, stream_));
+  }
+  if (D.qdiag.size()) {
+    qdiag_ = std::move(D.qdiag);
+    log(1, "Quadratic objective (diagonal Hessian): proximal primal step\n");
+  }
+  PDLP_HIP(hipStreamSynchronize(stream_));
 }
 
 void Solver::allocIterates() {

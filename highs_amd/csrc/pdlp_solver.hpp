@@ -124,6 +124,7 @@ class Solver : public SolverBase {
   void release() noexcept;
   void uploadProblem();
   void uploadProblemFromDevice(DeviceProblem& D);
+  void uploadShardFromDevice(DeviceProblem& D);  // sharded, two-all-gathers layout: the rank's shard cut on the device
   static void downloadForm(DeviceProblem& D, StandardForm& F, hipStream_t s);
   void allocIterates();
   void initStepSizes();
@@ -173,6 +174,7 @@ class Solver : public SolverBase {
   bool gpuSetup_ = true;   // formulate/scale/transpose/slab layout on the device (pdlp_setup.hip)
   double sumCost2_ = 0, sumRhs2_ = 0;  // left-to-right sums of the scaled c, b
   bool sharded_ = false;  // row-block sharded kernel sequence (world > 1, or forced for testing)
+  bool shardOnDevice_ = false;  // sharded + device-side set-up: the rank's shard is cut on the device (uploadShardFromDevice)
   // exchange of the sharded path: direct xGMI mesh (pdlp_mesh.hpp; columns are then sliced as
   // well, [c0_, c1_)) or, as the fallback, RCCL all-reduce with replicated column work
   Mesh* mesh_ = nullptr;
