@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/r6_xp.sh TAG — round 6 experiments on one box (EXPERIMENT switches)
+# tools/r6_xp.sh TAG — round 6 experiments on one box (A/B of development switches)
 export PDLP_MI355X_DEV=1
 cd "$(dirname "$0")/.."
 TAG=${1:-r06_xp}; OUT=gpurun_out/$TAG; mkdir -p $OUT
@@ -7,10 +7,10 @@ line() { python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); pr
 run() { # name cfg env...
   local name=$1 cfg=$2; shift 2
   env "$@" python bench.py --config $cfg --cpu-iters 0 2>/dev/null | line $name
-  env "$@" PDLP_MI355X_SLAB_PROF=1 python bench.py --config $cfg --cpu-iters 0 2>&1 >/dev/null | grep "slab launch" | grep -E "fused" | grep -E "barrier|kernel"
+  env "$@" PDLP_MI355X_SLAB_PROF=1 python bench.py --config $cfg --cpu-iters 0 2>&1 >/dev/null | grep "slab launch" | grep -E "fused" | grep -E "epilogue|barrier|kernel"
 }
-for cfg in b c e d f qp; do
-  run ${cfg}_late $cfg PDLP_MI355X_XP_LATE_FIX=1
-  run ${cfg}_early $cfg PDLP_MI355X_XP_LATE_FIX=0
+for cfg in b c e qp; do
+  run ${cfg}_tagged $cfg PDLP_MI355X_TAGGED_SLOTS=1
+  run ${cfg}_words $cfg PDLP_MI355X_TAGGED_SLOTS=0
 done
-bash tools/gpu_pytest.sh $TAG/pytest tests -m gpu -q -x --timeout 600 -k "fused or bit_exact or mesh or multirank or sharded"
+bash tools/gpu_pytest.sh $TAG/pytest tests -m gpu -q -x --timeout 600 -k "fused or bit_exact or two_large or fault or barrier or bench"
