@@ -98,8 +98,8 @@ void HalpernSolver::construct(const pdlp_problem_t& P, const void* id128) {
     F_.rowKind = std::move(D.rowKind); F_.rowNewIdx = std::move(D.rowNewIdx);
     F_.colScale = std::move(D.hColScale); F_.rowScale = std::move(D.hRowScale);
     dAt_.majorCost = kSlabMajorCostCols;
-    dA_.buildFromDevice(D.A, sw, stream_);
-    dAt_.buildFromDevice(D.At, sw, stream_);
+    buildSlabTuned(dA_, D.A, sw, stream_);
+    buildSlabTuned(dAt_, D.At, sw, stream_);
     cost_ = std::move(D.cost); lower_ = std::move(D.lower); upper_ = std::move(D.upper); rl_ = std::move(D.rhs);
     ru_ = std::move(D.rowUpper); colScale_ = std::move(D.colScale); rowScale_ = std::move(D.rowScale);
     isEq_ = std::move(D.rowIsEq);

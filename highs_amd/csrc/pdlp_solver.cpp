@@ -186,10 +186,24 @@ void DeviceMatrix::buildFromDevice(DeviceCsrData& M, const DevSwitches& sw, hipS
       PDLP_HIP(hipStreamSynchronize(s));
       localM = touchesFewTiles(lo, hi, cnt);
       tileOwner = xcdTileOwners(hist, nTiles);
+      // how long the runs of equal majors are at the rule's widest slabs (2^17): entries per short major of a block, over
+      // the number of slabs the block's span crosses — 1 on a random operand (every entry of a row in another slab), the
+      // major's whole length where a block is local.  Below 2 no narrower slab can help (buildSlabTuned skips its candidates).
+      double num = 0.0, den = 0.0;
+      for (int32_t b = 0; b < nB; ++b) {
+        if (cnt[b] <= 0) continue;
+        const double majors = std::max(1, L.hostWaveBeg[(size_t)(b + 1) * kSlabWavesPerBlock] - L.hostWaveBeg[(size_t)b * kSlabWavesPerBlock]);
+        const double meanLen = (double)cnt[b] / majors;
+        const double slabs = (double)((hi[b] >> kSlabWidthLog2) - (lo[b] >> kSlabWidthLog2) + 1);
+        num += (double)cnt[b] * (meanLen / std::min(std::max(meanLen, 1.0), slabs));
+        den += (double)cnt[b];
+      }
+      estRunLen = den > 0.0 ? num / den : 1.0;
     }
     // (an operand whose blocks touch few 16384-entry tiles of the gathered vector densely gets slabs of that width: its
     // runs of equal majors are shorter, more lanes add in parallel — bench.py --config c, A x: 44.0 -> 41.1 us)
-    gpuBuildSlabLayout(M, kSlabLongLimit, slabWidthFor(sw, localM), majorCost, s, L);
+    slabWidthLog2 = slabWidthFor(sw, localM);
+    gpuBuildSlabLayout(M, kSlabLongLimit, slabWidthLog2, majorCost, s, L);
     if (L.rowsPerBlock > kSlabMaxRows) throw std::runtime_error("slab layout: too many majors per block");
     wavePtr = std::move(L.wavePtr);
     waveBeg = std::move(L.waveBeg);
@@ -234,16 +248,16 @@ MatView DeviceMatrix::view() const {
   return v;
 }
 
-void tuneXcdMap(DeviceMatrix& M, const DevSwitches& sw, const double* in, double* out, hipStream_t s) {
+float tuneXcdMap(DeviceMatrix& M, const DevSwitches& sw, const double* in, double* out, hipStream_t s) {
   const bool em = sw.xcdMap >= 0;
   const bool ep = sw.slabPace >= 0;  // 1 = barrier per group (random operands), 0 = free-running waves
   if (em) M.xcdMap = sw.xcdMap != 0;
   if (ep) M.noPace = sw.slabPace == 0;
   if (M.nnz < 200000) {  // small operands live in every L2 anyway
     if (!em) M.xcdMap = 1;
-    return;
+    return 0.f;
   }
-  if (em && (ep || !M.useSlab)) return;
+  if (M.mapTuned) return 0.f;  // (chosen together with the slab width: buildSlabTuned)
   hipEvent_t e0, e1;
   PDLP_HIP(hipEventCreate(&e0));
   PDLP_HIP(hipEventCreate(&e1));
@@ -268,6 +282,45 @@ void tuneXcdMap(DeviceMatrix& M, const DevSwitches& sw, const double* in, double
   M.noPace = bestFree;
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
+  return best / 3.f;
+}
+
+// The slab WIDTH of an operand, by timing (round 6).  The width decides how long the runs of equal majors inside a
+// 64-entry group are — a run is added by ONE lane — and which stretch of the gathered vector a CU's waves sweep together;
+// it changes no sum (a major's runs are added in ascending minor order whatever the width).  The rule of round 3 (2^14 for
+// operands whose blocks touch few stretches densely, else 2^17) is right for the random LP and misses structured operands
+// whose majors are long AND local: the tall held-out LP's columns (35 entries within a few thousand rows) stream 20 %
+// faster at 2^11, config c's rows (16 entries) 6 % faster at 2^13 — while config d's and the power-law LP's operands lose
+// up to 35 % there.  So: the rule's layout first, then 2^13 and 2^11, each with its own XCD map / pacing (tuneXcdMap), the
+// fastest plain SpMV stays.  Only for operands of at least 2^20 nonzeros built on the device (a candidate costs one more
+// slab build, ~10 ms at 5 M nonzeros); PDLP_MI355X_SLAB_W (development) forces a width.
+void buildSlabTuned(DeviceMatrix& out, DeviceCsrData& M, const DevSwitches& sw, hipStream_t s) {
+  out.buildFromDevice(M, sw, s);
+  if (!out.useSlab || sw.slabW > 0 || sw.slabTune == 0 || M.nnz < ((int64_t)1 << 20)) return;  // (the stream layout has consumed M's arrays)
+  if (out.estRunLen < 2.0) return;  // runs of one entry (random operands): nothing a narrower slab could shorten
+  DeviceArray<double> in, res;
+  in.alloc((size_t)std::max(M.nMinor, 1));
+  res.alloc((size_t)std::max(M.nMajor, 1));
+  in.zero(s);
+  float best = tuneXcdMap(out, sw, in.get(), res.get(), s);
+  out.mapTuned = true;
+  const int32_t autoW = out.slabWidthLog2;
+  for (int32_t W : {13, 11}) {
+    if (W == autoW || ((int64_t)1 << W) >= (int64_t)M.nMinor) continue;
+    DevSwitches sw2 = sw;
+    sw2.slabW = W;
+    DeviceMatrix cand;
+    cand.majorCost = out.majorCost;
+    cand.balanceTaskBlocks = out.balanceTaskBlocks;
+    cand.buildFromDevice(M, sw2, s);
+    const float t = tuneXcdMap(cand, sw, in.get(), res.get(), s);
+    cand.mapTuned = true;
+    if (t < 0.97f * best) {  // a change only when clearly faster
+      best = t;
+      out = std::move(cand);
+    }
+    PDLP_HIP(hipStreamSynchronize(s));  // (the loser's arrays are released with no launch on them in flight)
+  }
 }
 
 // The environment, read ONCE per solver (never per launch).  What a user may need is listed in INTEGRATION.md section 4;
@@ -302,6 +355,7 @@ DevSwitches DevSwitches::fromEnv() {
   w.slabW = dev("PDLP_MI355X_SLAB_W", 0);
   w.xcdMap = dev("PDLP_MI355X_XCD_MAP", -1);
   w.slabPace = dev("PDLP_MI355X_SLAB_PACE", -1);
+  w.slabTune = dev("PDLP_MI355X_SLAB_TUNE", 1);
   w.affineTasks = dev("PDLP_MI355X_AFFINE_TASKS", 1);
   w.fusedStream = dev("PDLP_MI355X_FUSED_STREAM", 0);
   w.fusedCoTasks = dev("PDLP_MI355X_FUSED_COTASKS", -1);
@@ -582,8 +636,8 @@ void Solver::construct(const pdlp_problem_t& P, const void* id128) {
   if (hasQoff_) tuneXcdMap(dQ_, sw_, x_[0].get(), nx_[0].get(), stream_);
   if (devEnv("PDLP_MI355X_SLAB_PROF") && rank_ == 0)  // (development: what the set-up chose, next to the per-block phase profile)
     for (const DeviceMatrix* M : {&dA_, &dAt_})
-      fprintf(stderr, "slab operand %s: slab %d, blocks %d, XCD map %s, %s, long majors %d, tasks %d in workgroups of %d\n", M == &dA_ ? "A" : "A'",
-              (int)M->useSlab, M->useSlab ? M->slab.nBlocks : M->nBlocks, M->xcdMap ? "contiguous" : "round robin", M->noPace ? "free-running waves" : "paced",
+      fprintf(stderr, "slab operand %s: slab %d (width 2^%d, estimated run length %.1f), blocks %d, XCD map %s, %s, long majors %d, tasks %d in workgroups of %d\n", M == &dA_ ? "A" : "A'",
+              (int)M->useSlab, M->slabWidthLog2, M->estRunLen, M->useSlab ? M->slab.nBlocks : M->nBlocks, M->xcdMap ? "contiguous" : "round robin", M->noPace ? "free-running waves" : "paced",
               M->nLong, M->nTasks, M->taskGroup);
   // 2-launch trial where the A' y grid is resident all at once (grid barrier inside the kernel); PDLP_MI355X_FUSED=0 forces
   // 3 launches.  Slab layout (one block per CU): on by default, 140.0 -> 135.0 us per iteration at 1M x 1M.  Stream
@@ -737,8 +791,8 @@ void Solver::downloadForm(DeviceProblem& D, StandardForm& F, hipStream_t s) {
 
 void Solver::uploadProblemFromDevice(DeviceProblem& D) {
   dAt_.majorCost = kSlabMajorCostCols;
-  dA_.buildFromDevice(D.A, sw_, stream_);
-  dAt_.buildFromDevice(D.At, sw_, stream_);
+  buildSlabTuned(dA_, D.A, sw_, stream_);
+  buildSlabTuned(dAt_, D.At, sw_, stream_);
   cost_ = std::move(D.cost); rhs_ = std::move(D.rhs); lower_ = std::move(D.lower); upper_ = std::move(D.upper);
   colScale_ = std::move(D.colScale); rowScale_ = std::move(D.rowScale);
   if (D.qdiag.size()) {

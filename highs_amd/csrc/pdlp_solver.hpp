@@ -25,6 +25,7 @@ struct DevSwitches {
   int slab = -1;          // PDLP_MI355X_SLAB: 0 CSR stream only, 1 slab layout, -1 automatic by the gathered vector's size
   int slabW = 0;          // PDLP_MI355X_SLAB_W: log2 of the slab width (development)
   int xcdMap = -1, slabPace = -1;
+  int slabTune = 1;       // PDLP_MI355X_SLAB_TUNE=0 (development): the slab width by rule only, no timing of narrower slabs
   int affineTasks = 1;  // XCD-affine deal of the slab layout's segment tasks (0: (major, segment) order; A/B measurements)
   int fusedCoTasks = -1;  // PDLP_MI355X_FUSED_COTASKS: 0 = the fused trial's streaming blocks run the long columns' task passes themselves
   int fused = -1, fusedStream = 0, persistent = -1, xcdLocal = -1, hierBarrier = -1, deviceCheck = -1, checkSmall = -1;
@@ -58,6 +59,9 @@ struct DeviceMatrix {
   int64_t nnz = 0;
   bool useSlab = false;
   int32_t noPace = 0;  // slab kernel without the per-group block barrier (SlabMat::noPace), see tuneXcdMap
+  int32_t slabWidthLog2 = 0;  // log2 of the slab width the layout was built with (device build; see buildSlabTuned)
+  double estRunLen = 1.0;     // estimated run length of equal majors at the widest slabs (device build)
+  bool mapTuned = false;      // XCD map / pacing already chosen by timing (with the slab width)
   int32_t xcdMap = 1;  // block -> XCD assignment of the SpMV kernels (pdlp_kernels.hip xcdContiguousBlock), see tuneXcdMap
   SlabMat slab{};
   // sw.slab: 0 = CSR stream only, 1 = slab layout, -1 = auto by nMinor
@@ -78,7 +82,11 @@ struct DeviceMatrix {
 
 // Picks M.xcdMap by timing the plain SpMV out = M * in with both block -> XCD assignments (a few launches; the
 // result vector is scratch).  PDLP_MI355X_XCD_MAP=0|1 forces one.
-void tuneXcdMap(DeviceMatrix& M, const DevSwitches& sw, const double* in, double* out, hipStream_t s);
+// Returns the time of one plain SpMV with the choice made (ms; 0 for operands too small to time).
+float tuneXcdMap(DeviceMatrix& M, const DevSwitches& sw, const double* in, double* out, hipStream_t s);
+// M -> `out` like DeviceMatrix::buildFromDevice, plus (slab layout, >= 2^20 nonzeros) the slab width chosen by timing
+// the plain SpMV at the rule's width, 2^13 and 2^11 (pdlp_solver.cpp buildSlabTuned holds the measurements behind it).
+void buildSlabTuned(DeviceMatrix& out, DeviceCsrData& M, const DevSwitches& sw, hipStream_t s);
 
 class Comm;  // RCCL wrapper (pdlp_comm.cpp)
 
