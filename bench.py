@@ -129,16 +129,17 @@ def scaling_model(n, m, nnz, G, ax_us_1gpu, aty_us_1gpu, vec_us_1gpu):
     """Predicted microseconds per phase of one trial on G GPUs with the two-all-gathers layout, from
     the single-GPU kernel times and the node's link figures: xGMI 76.8 GB/s per direction and link (153.6 GB/s
     bidirectional, 7 links per GPU: MI355X_MICROARCH.md / the task statement), every rank sends its slice to the G-1
-    peers over G-1 separate links, a flag hop ~3 us, a kernel ~3 us at least, a kernel boundary ~1.7 us; eight launches
-    per trial with every rank on a GPU of its own (the consumers of the two all-gathers wait for the flags themselves:
-    MeshArgs::fusedWait), i.e. seven boundaries.  The measured `exchange_waits` of an N > 1 run are printed next to it."""
+    peers over G-1 separate links, a flag hop ~3 us, a kernel ~3 us at least, a kernel boundary ~1.7 us; FIVE launches
+    per trial with every rank on a GPU of its own (round 6, MeshArgs::fusedWait == 2: an exchange is one kernel — push,
+    epoch, wait, copy), i.e. four boundaries (round 5: seven).  The measured `exchange_waits` of an N > 1 run are
+    printed next to it."""
     link_gbs, hop_us, floor_us, boundary_us = 76.8, 3.0, 3.0, 1.7
     x_us = 8.0 * n / G / (link_gbs * 1e3) + hop_us   # the own slice to each peer, one link per peer
     y_us = 8.0 * m / G / (link_gbs * 1e3) + hop_us
     phases = {"primal_step_own_columns": max(floor_us, vec_us_1gpu / G), "X_allgather_x": x_us,
               "spmv_ax_dual_own_rows": max(floor_us, ax_us_1gpu / G), "Y_allgather_y": y_us,
               "spmv_aty_interact_own_columns": max(floor_us, aty_us_1gpu / G), "S_scalars_and_decision": hop_us + 1.0,
-              "kernel_boundaries": 7 * boundary_us}
+              "kernel_boundaries": 4 * boundary_us}
     total = sum(phases.values())
     return {"ranks": G, "us_per_phase": phases, "us_per_trial": total,
             "bytes_sent_per_rank_and_trial": 8 * (n + m) * (G - 1) // G,

@@ -171,11 +171,8 @@ __global__ __launch_bounds__(kWave) void k_mesh_wait(DevState* st, const MeshArg
 // ---- hot loop ------------------------------------------------------------------------
 // x+ = clamp(x - tau (c - A'y), l, u) on the own column slice (cupdlp_step.c:16-40), stored
 // locally and pushed into every peer's recvX.
-__global__ __launch_bounds__(kVecThreads) void k_mesh_primal_step(const IterVecs v, const DevState* st,
-                                                                  const MeshArgs ma) {
+__device__ __forceinline__ void primalStepAndPush(const IterVecs& v, const DevState* st, const MeshArgs& ma) {
   const MeshView* __restrict__ mv = ma.v; (void)mv;
-  if (st->halted || dead(ma)) return;
-  const long long e = ma.ms->seq + 1;
   const int cur = st->cur, nxt = cur ^ 1;
   const double tau = st->tau, avgW = st->avgWx;
   const double* __restrict__ x = v.x[cur];
@@ -211,30 +208,20 @@ __global__ __launch_bounds__(kVecThreads) void k_mesh_primal_step(const IterVecs
         if (peer.p[h]) sysStore(peer.p[h] + c0 + j, t);
     }
   }
-  lastBlockSignal(ma, kFlagX, e, 0);
 }
 
-// x+ of the other column slices: recvX -> x[nxt] (ordinary memory, so that the SpMV gathers hit L2).
-__global__ __launch_bounds__(kVecThreads) void k_mesh_wait_copy_x(const IterVecs v, DevState* st,
-                                                                  const MeshArgs ma) {
-  const MeshView* __restrict__ mv = ma.v; (void)mv;
-  if (st->halted || dead(ma)) return;  // (k_mesh_wait ran before: flag X has arrived, or the exchange is dead)
-  if (ma.fusedWait && !waitPeers(ma, kFlagX, ma.ms->seq + 1)) { fail(ma, st); return; }  // ... or every block waits itself
-  const int nxt = st->cur ^ 1;
-  const int c0 = mv->colOff[ma.g], c1 = mv->colOff[ma.g + 1];
-  const double* __restrict__ src = recvX(ma, ma.g);
-  double* __restrict__ dst = v.x[nxt];
+// The other ranks' pieces of an all-gathered vector: receive area (uncached) -> dst (ordinary memory, so that the
+// SpMV gathers hit L2).  [lo, hi) is the own piece, already in place.
+__device__ __forceinline__ void copyOthers(const double* __restrict__ src, double* __restrict__ dst, int lo, int hi, int len) {
   const int stride = gridDim.x * blockDim.x;
-  // [0, c0) and [c1, n): the own slice is already in place
-  const int other = v.n - (c1 - c0);
-  const int lastQ = other - 1;
+  const int other = len - (hi - lo), lastQ = other - 1;
   for (int q0 = blockIdx.x * blockDim.x + threadIdx.x; q0 < other; q0 += 4 * stride) {
     double t[4];
     int jj[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {  // four independent system-scope loads in flight
       const int q = min(q0 + u * stride, lastQ);
-      jj[u] = q < c0 ? q : q + (c1 - c0);
+      jj[u] = q < lo ? q : q + (hi - lo);
       t[u] = sysLoad(src + jj[u]);
     }
 #pragma unroll
@@ -243,14 +230,44 @@ __global__ __launch_bounds__(kVecThreads) void k_mesh_wait_copy_x(const IterVecs
   }
 }
 
-// ---- "two all-gathers" layout: all-gather of y+ (rows) --------------------------------------------------
-// y+[r0:r1) (just written by the dual-step epilogue of A_g x+) -> every peer's recvY; flag P.
-__global__ __launch_bounds__(kVecThreads) void k_mesh_push_y(const double* __restrict__ y0, const double* __restrict__ y1,
-                                                             const DevState* st, const MeshArgs ma) {
+__global__ __launch_bounds__(kVecThreads) void k_mesh_primal_step(const IterVecs v, const DevState* st,
+                                                                  const MeshArgs ma) {
+  if (st->halted || dead(ma)) return;
+  const long long e = ma.ms->seq + 1;
+  primalStepAndPush(v, st, ma);
+  lastBlockSignal(ma, kFlagX, e, 0);
+}
+
+// x+ of the other column slices: recvX -> x[nxt].
+__global__ __launch_bounds__(kVecThreads) void k_mesh_wait_copy_x(const IterVecs v, DevState* st,
+                                                                  const MeshArgs ma) {
+  const MeshView* __restrict__ mv = ma.v; (void)mv;
+  if (st->halted || dead(ma)) return;  // (k_mesh_wait ran before: flag X has arrived, or the exchange is dead)
+  if (ma.fusedWait && !waitPeers(ma, kFlagX, ma.ms->seq + 1)) { fail(ma, st); return; }  // ... or every block waits itself
+  copyOthers(recvX(ma, ma.g), v.x[st->cur ^ 1], mv->colOff[ma.g], mv->colOff[ma.g + 1], v.n);
+}
+
+// Round 6, every rank on a GPU of its own (MeshArgs::fusedWait == 2): the whole X exchange in ONE launch — primal step
+// on the own slice pushed to the peers, the block that drains last publishes the epoch, then every block waits for the
+// peers' epochs and copies its share of their slices.  vc = the own column slice, xFull = the two full-length iterates.
+// No block waits for anything before ITS pushes are out and a grid of at most 256 workgroups of 256 threads is resident
+// at once on a device of its own, so the waits cannot keep a producer off the CUs.
+__global__ __launch_bounds__(kVecThreads) void k_mesh_primal_x(const IterVecs vc, double* __restrict__ x0Full,
+                                                               double* __restrict__ x1Full, int nFull, DevState* st,
+                                                               const MeshArgs ma) {
   const MeshView* __restrict__ mv = ma.v; (void)mv;
   if (st->halted || dead(ma)) return;
   const long long e = ma.ms->seq + 1;
-  const double* __restrict__ yn = (st->cur ^ 1) ? y1 : y0;
+  primalStepAndPush(vc, st, ma);
+  lastBlockSignal(ma, kFlagX, e, 0);
+  if (!waitPeers(ma, kFlagX, e)) { fail(ma, st); return; }
+  copyOthers(recvX(ma, ma.g), (st->cur ^ 1) ? x1Full : x0Full, mv->colOff[ma.g], mv->colOff[ma.g + 1], nFull);
+}
+
+// ---- "two all-gathers" layout: all-gather of y+ (rows) --------------------------------------------------
+// y+[r0:r1) (just written by the dual-step epilogue of A_g x+) -> every peer's recvY; flag P.
+__device__ __forceinline__ void pushRows(const double* __restrict__ yn, const MeshArgs& ma) {
+  const MeshView* __restrict__ mv = ma.v; (void)mv;
   const int r0 = mv->rowOff[ma.g], r1 = mv->rowOff[ma.g + 1];
   const int G = ma.G, g = ma.g;
   PeerPtrs peer;
@@ -270,6 +287,12 @@ __global__ __launch_bounds__(kVecThreads) void k_mesh_push_y(const double* __res
         if (peer.p[h]) sysStore(peer.p[h] + r0 + i, t[u]);
     }
   }
+}
+__global__ __launch_bounds__(kVecThreads) void k_mesh_push_y(const double* __restrict__ y0, const double* __restrict__ y1,
+                                                             const DevState* st, const MeshArgs ma) {
+  if (st->halted || dead(ma)) return;
+  const long long e = ma.ms->seq + 1;
+  pushRows((st->cur ^ 1) ? y1 : y0, ma);
   lastBlockSignal(ma, kFlagP, e, 1);
 }
 // y+ of the other row blocks: recvY -> y[nxt] (ordinary memory, so that the A'y gathers hit L2).
@@ -278,24 +301,19 @@ __global__ __launch_bounds__(kVecThreads) void k_mesh_wait_copy_y(double* __rest
   const MeshView* __restrict__ mv = ma.v; (void)mv;
   if (st->halted || dead(ma)) return;  // (k_mesh_wait ran before: flag P has arrived, or the exchange is dead)
   if (ma.fusedWait && !waitPeers(ma, kFlagP, ma.ms->seq + 1)) { fail(ma, const_cast<DevState*>(st)); return; }
-  double* __restrict__ dst = (st->cur ^ 1) ? y1 : y0;
-  const int r0 = mv->rowOff[ma.g], r1 = mv->rowOff[ma.g + 1];
-  const double* __restrict__ src = recvY(ma, ma.g);
-  const int stride = gridDim.x * blockDim.x;
-  const int other = m - (r1 - r0), lastQ = other - 1;
-  for (int q0 = blockIdx.x * blockDim.x + threadIdx.x; q0 < other; q0 += 4 * stride) {
-    double t[4];
-    int jj[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {  // four independent system-scope loads in flight
-      const int q = min(q0 + u * stride, lastQ);
-      jj[u] = q < r0 ? q : q + (r1 - r0);
-      t[u] = sysLoad(src + jj[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (q0 + u * stride <= lastQ) dst[jj[u]] = t[u];
-  }
+  copyOthers(recvY(ma, ma.g), (st->cur ^ 1) ? y1 : y0, mv->rowOff[ma.g], mv->rowOff[ma.g + 1], m);
+}
+// The whole Y exchange in one launch (fusedWait == 2, see k_mesh_primal_x).
+__global__ __launch_bounds__(kVecThreads) void k_mesh_y(double* __restrict__ y0, double* __restrict__ y1, int m, DevState* st,
+                                                        const MeshArgs ma) {
+  const MeshView* __restrict__ mv = ma.v; (void)mv;
+  if (st->halted || dead(ma)) return;
+  const long long e = ma.ms->seq + 1;
+  double* __restrict__ yn = (st->cur ^ 1) ? y1 : y0;
+  pushRows(yn, ma);
+  lastBlockSignal(ma, kFlagP, e, 1);
+  if (!waitPeers(ma, kFlagP, e)) { fail(ma, st); return; }
+  copyOthers(recvY(ma, ma.g), yn, mv->rowOff[ma.g], mv->rowOff[ma.g + 1], m);
 }
 
 // partial[slice of owner h] -> h's recvP[g], one short coalesced loop per peer.  st != nullptr:
@@ -467,23 +485,7 @@ __global__ __launch_bounds__(kVecThreads) void k_mesh_h_reduce_primal(const Halp
 __global__ __launch_bounds__(kVecThreads) void k_mesh_h_copy_x(double* __restrict__ rx, int n, const MeshArgs ma) {
   const MeshView* __restrict__ mv = ma.v; (void)mv;
   if (dead(ma)) return;
-  const int c0 = mv->colOff[ma.g], c1 = mv->colOff[ma.g + 1];
-  const double* __restrict__ src = recvX(ma, ma.g);
-  const int stride = gridDim.x * blockDim.x;
-  const int other = n - (c1 - c0), lastQ = other - 1;
-  for (int q0 = blockIdx.x * blockDim.x + threadIdx.x; q0 < other; q0 += 4 * stride) {
-    double t[4];
-    int jj[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int q = min(q0 + u * stride, lastQ);
-      jj[u] = q < c0 ? q : q + (c1 - c0);
-      t[u] = sysLoad(src + jj[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (q0 + u * stride <= lastQ) rx[jj[u]] = t[u];
-  }
+  copyOthers(recvX(ma, ma.g), rx, mv->colOff[ma.g], mv->colOff[ma.g + 1], n);
 }
 __global__ void k_mesh_bump(const MeshArgs ma) {
   if (dead(ma)) return;
@@ -491,11 +493,7 @@ __global__ void k_mesh_bump(const MeshArgs ma) {
 }
 
 // ---- generic collectives (host-counted epochs, off the hot path) ---------------------------
-__global__ __launch_bounds__(kVecThreads) void k_mesh_push_slice(const double* __restrict__ vec, int lo, int hi,
-                                                                 const MeshArgs ma, long long e) {
-  const MeshView* __restrict__ mv = ma.v; (void)mv;
-
-  if (dead(ma)) return;
+__device__ __forceinline__ void pushSlice(const double* __restrict__ vec, int lo, int hi, const MeshArgs& ma) {
   PeerPtrs peer;
   peerRecvX(ma, peer);
   const int stride = gridDim.x * blockDim.x;
@@ -505,30 +503,46 @@ __global__ __launch_bounds__(kVecThreads) void k_mesh_push_slice(const double* _
     for (int h = 0; h < kMeshMaxRanks; ++h)
       if (peer.p[h]) sysStore(peer.p[h] + j, t);
   }
+}
+__global__ __launch_bounds__(kVecThreads) void k_mesh_push_slice(const double* __restrict__ vec, int lo, int hi,
+                                                                 const MeshArgs ma, long long e) {
+  if (dead(ma)) return;
+  pushSlice(vec, lo, hi, ma);
   lastBlockSignal(ma, kFlagGen, e, 2);
 }
 
 __global__ __launch_bounds__(kVecThreads) void k_mesh_wait_copy(double* __restrict__ vec, int lo, int hi, int len,
                                                                 const MeshArgs ma, long long e) {
-  const MeshView* __restrict__ mv = ma.v; (void)mv;
-
   if (dead(ma)) return;
-  const double* __restrict__ src = recvX(ma, ma.g);
-  const int stride = gridDim.x * blockDim.x;
-  const int other = len - (hi - lo), lastQ = other - 1;
-  for (int q0 = blockIdx.x * blockDim.x + threadIdx.x; q0 < other; q0 += 4 * stride) {
-    double t[4];
-    int jj[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int q = min(q0 + u * stride, lastQ);
-      jj[u] = q < lo ? q : q + (hi - lo);
-      t[u] = sysLoad(src + jj[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (q0 + u * stride <= lastQ) vec[jj[u]] = t[u];
+  copyOthers(recvX(ma, ma.g), vec, lo, hi, len);
+}
+
+// Whole block: true in the block that arrives last at `ticket` (every block of the grid must call it once).
+__device__ bool lastBlockHere(const MeshArgs& ma, int ticket) {
+  __shared__ int lastOne;
+  __syncthreads();  // every wave of the block has finished what came before
+  if (threadIdx.x == 0) {
+    const unsigned prev = __hip_atomic_fetch_add(&ma.ms->counter[ticket], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    lastOne = prev == gridDim.x - 1;
+    if (lastOne) __hip_atomic_store(&ma.ms->counter[ticket], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  __syncthreads();
+  return lastOne != 0;
+}
+
+// Round 6 (fusedWait == 2): a generic all-gather in ONE launch instead of four — push, epoch by the block that drains
+// last, every block waits and copies its share, and the block that finishes copying last holds the rendezvous that
+// k_mesh_barrier held (the receive area may be overwritten by the next collective only after every rank has read it).
+__global__ __launch_bounds__(kVecThreads) void k_mesh_allgather(double* __restrict__ vec, int lo, int hi, int len,
+                                                                const MeshArgs ma, long long e) {
+  if (dead(ma)) return;
+  pushSlice(vec, lo, hi, ma);
+  lastBlockSignal(ma, kFlagGen, e, 2);
+  if (!waitPeers(ma, kFlagGen, e)) { fail(ma, nullptr); return; }
+  copyOthers(recvX(ma, ma.g), vec, lo, hi, len);  // (a thread's loads have returned before it reaches the ticket: their values were stored)
+  if (!lastBlockHere(ma, 3)) return;
+  if (threadIdx.x == 0) signalPeers(ma, kFlagBar, e);
+  if (!waitPeers(ma, kFlagBar, e)) fail(ma, nullptr);
 }
 
 __global__ __launch_bounds__(kVecThreads) void k_mesh_wait_reduce(const double* __restrict__ partial,
@@ -577,13 +591,11 @@ __global__ void k_mesh_checksum_pack(const unsigned long long* acc, double* buf,
   }
 }
 
-__global__ __launch_bounds__(kVecThreads) void k_mesh_allreduce_scalars(double* buf, int k, const MeshArgs ma,
-                                                                        long long e) {
-  const MeshView* __restrict__ mv = ma.v; (void)mv;
-  if (dead(ma)) return;
+// buf[0:k) summed over the ranks in rank order by ONE block (the body of k_mesh_allreduce_scalars).
+__device__ void allReduceBlock(double* buf, int k, const MeshArgs& ma, long long e, bool agentLoads) {
   const int tid = threadIdx.x;
   if (tid < k) {
-    const double t = buf[tid];
+    const double t = agentLoads ? __hip_atomic_load(buf + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : buf[tid];
     for (int h = 0; h < ma.G; ++h) sysStore(mailAt(ma, h, false, ma.g) + tid, t);
   }
   drainStores();
@@ -599,6 +611,42 @@ __global__ __launch_bounds__(kVecThreads) void k_mesh_allreduce_scalars(double* 
   // the mailboxes may be overwritten by the next all-reduce only after every rank has read them
   if (tid == 0) signalPeers(ma, kFlagBar, e);
   if (!waitPeers(ma, kFlagBar, e)) fail(ma, nullptr);
+}
+
+__global__ __launch_bounds__(kVecThreads) void k_mesh_allreduce_scalars(double* buf, int k, const MeshArgs ma,
+                                                                        long long e) {
+  if (dead(ma)) return;
+  allReduceBlock(buf, k, ma, e, false);
+}
+
+// Round 6: the statistics of a sharded check — k_final_reduce2 (one block per quantity, fixed-order sum of its per-block
+// partials, gated like every kernel of a check) and the all-reduce over the ranks in ONE launch: the block that finishes
+// last runs the exchange.  The exchange is never gated (its epochs are counted by the host on every rank alike).
+__global__ __launch_bounds__(kVecThreads) void k_mesh_reduce2_allreduce(const double* partials, int pstride, int nQ0, int nBlocks0,
+                                                                        int nBlocks1, double* out, const CheckGate g,
+                                                                        const MeshArgs ma, long long e) {
+  if (dead(ma)) return;
+  __shared__ double scratch[kVecThreads / kWave];
+  if (gateOpen(g)) {
+    const double s = reducePartials(partials + (size_t)blockIdx.x * pstride, (int)blockIdx.x < nQ0 ? nBlocks0 : nBlocks1, scratch);
+    if (threadIdx.x == 0) __hip_atomic_store(out + blockIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  drainStores();  // the sum is in memory before this block's ticket
+  if (!lastBlockHere(ma, 3)) return;
+  allReduceBlock(out, (int)gridDim.x, ma, e, true);
+}
+
+// The two norms of the primal-weight update (k_restart_vec's partials): each summed in fixed order by the one block,
+// then added over the ranks — two k_final_reduce launches and the all-reduce in one.
+__global__ __launch_bounds__(kVecThreads) void k_mesh_norms_allreduce(const double* partX, int nX, const double* partY, int nY,
+                                                                      double* norms, const MeshArgs ma, long long e) {
+  if (dead(ma)) return;
+  __shared__ double scratch[2][kVecThreads / kWave];
+  const double sx = reducePartials(partX, nX, scratch[0]);
+  const double sy = reducePartials(partY, nY, scratch[1]);
+  if (threadIdx.x == 0) { norms[0] = sx; norms[1] = sy; }
+  __syncthreads();
+  allReduceBlock(norms, 2, ma, e, false);
 }
 
 // Grids of the mesh kernels.  Producers end with one ticket atomic per block on a single counter
@@ -656,6 +704,15 @@ void launchMeshWaitCopyY(double* const yFull[2], int32_t m, const DevState* st, 
   if (!dmv.fusedWait) hipLaunchKernelGGL(k_mesh_wait, dim3(1), dim3(kWave), 0, s, const_cast<DevState*>(st), dmv, (int)kFlagP, 0LL);
   hipLaunchKernelGGL(k_mesh_wait_copy_y, dim3(dmv.fusedWait ? capped((std::max(m, 1) + 3) / 4, 256) : meshConsumerBlocks(std::max(m, 1))),
                      dim3(kVecThreads), 0, s, yFull[0], yFull[1], m, st, dmv);
+}
+
+// fusedWait == 2: the X / Y exchange of a trial in one launch each (see k_mesh_primal_x)
+void launchMeshPrimalX(const IterVecs& vc, double* const xFull[2], int32_t nFull, DevState* st, const MeshArgs& dmv, hipStream_t s) {
+  hipLaunchKernelGGL(k_mesh_primal_x, dim3(capped((std::max(nFull, 1) + 3) / 4, 256)), dim3(kVecThreads), 0, s, vc, xFull[0], xFull[1], nFull,
+                     st, dmv);
+}
+void launchMeshY(double* const yFull[2], int32_t m, DevState* st, const MeshArgs& dmv, hipStream_t s) {
+  hipLaunchKernelGGL(k_mesh_y, dim3(capped((std::max(m, 1) + 3) / 4, 256)), dim3(kVecThreads), 0, s, yFull[0], yFull[1], m, st, dmv);
 }
 
 void launchMeshHalpernStep(const MatView& A, const MatView& At, const HalpernVecs& hFull, const HalpernVecs& hCol,
@@ -868,8 +925,8 @@ void Mesh::construct(int32_t rank, int32_t world, const void* id128, int32_t n, 
   for (int a = 0; a < world; ++a)
     for (int b = a + 1; b < world; ++b)
       if (seg->slot[a].busHash == 0ull || seg->slot[a].busHash == seg->slot[b].busHash) own = false;
-  int fusedWait = own ? 1 : 0;
-  if (const char* e = devEnv("PDLP_MI355X_MESH_FUSED_WAIT")) fusedWait = atoi(e) != 0 ? 1 : 0;
+  int fusedWait = own ? 2 : 0;
+  if (const char* e = devEnv("PDLP_MI355X_MESH_FUSED_WAIT")) fusedWait = std::min(std::max(atoi(e), 0), 2);
   args_ = MeshArgs{dView_, state_, v_.G, v_.g, v_.waitTicks, meshFences(), fusedWait};
   hostBarrier(1, 60.0);
 }
@@ -902,6 +959,10 @@ void Mesh::allGather(double* vec, bool byRows, hipStream_t s) {
   const int32_t* off = byRows ? v_.rowOff : v_.colOff;
   const int32_t lo = off[v_.g], hi = off[v_.g + 1], len = off[v_.G];
   const long long e = ++epoch_;
+  if (args_.fusedWait == 2) {  // every rank on a GPU of its own: one launch
+    hipLaunchKernelGGL(k_mesh_allgather, dim3(capped((len + 3) / 4, 256)), dim3(kVecThreads), 0, s, vec, lo, hi, len, args_, e);
+    return;
+  }
   hipLaunchKernelGGL(k_mesh_push_slice, dim3(meshBlocks(hi - lo)), dim3(kVecThreads), 0, s, vec, lo, hi, args_, e);
   hipLaunchKernelGGL(k_mesh_wait, dim3(1), dim3(kWave), 0, s, (DevState*)nullptr, args_, (int)kFlagGen, e);
   hipLaunchKernelGGL(k_mesh_wait_copy, dim3(meshConsumerBlocks(len)), dim3(kVecThreads), 0, s, vec, lo, hi, len, args_, e);
@@ -923,6 +984,30 @@ void Mesh::allReduceScalars(double* buf, int32_t k, hipStream_t s) {
   if (v_.G == 1) return;
   const long long e = ++epoch_;
   hipLaunchKernelGGL(k_mesh_allreduce_scalars, dim3(1), dim3(kVecThreads), 0, s, buf, k, args_, e);
+}
+
+void Mesh::reduce2AllReduce(const double* partials, int32_t stride, int32_t nQ0, int32_t nBlocks0, int32_t nQ1, int32_t nBlocks1,
+                            double* out, CheckGate g, hipStream_t s) {
+  if (nQ0 + nQ1 > kMeshMailDoubles) throw std::runtime_error("pdlp_mi355x mesh: too many scalars in one all-reduce");
+  if (v_.G == 1 || args_.fusedWait != 2) {
+    launchFinalReduce2(partials, stride, nQ0, nBlocks0, nQ1, nBlocks1, out, g, s);
+    allReduceScalars(out, nQ0 + nQ1, s);
+    return;
+  }
+  const long long e = ++epoch_;
+  hipLaunchKernelGGL(k_mesh_reduce2_allreduce, dim3(nQ0 + nQ1), dim3(kVecThreads), 0, s, partials, stride, nQ0, nBlocks0, nBlocks1, out, g,
+                     args_, e);
+}
+
+void Mesh::normsAllReduce(const double* partX, int32_t nX, const double* partY, int32_t nY, double* norms, hipStream_t s) {
+  if (v_.G == 1 || args_.fusedWait != 2) {
+    launchFinalReduce(partX, nX, nX, 1, norms, s);
+    launchFinalReduce(partY, nY, nY, 1, norms + 1, s);
+    allReduceScalars(norms, 2, s);
+    return;
+  }
+  const long long e = ++epoch_;
+  hipLaunchKernelGGL(k_mesh_norms_allreduce, dim3(1), dim3(kVecThreads), 0, s, partX, nX, partY, nY, norms, args_, e);
 }
 
 // Every rank must hold the same bits in a replicated vector (x of the cuPDLP path, the reflected x of the

@@ -74,9 +74,11 @@ struct MeshArgs {
   int64_t waitTicks;
   int32_t fences;  // PDLP_MI355X_MESH_FENCES=1: system-scope release before every flag store, acquire after every wait
   // 1: the kernels that consume an all-gather wait for the peers' flags themselves (every block polls; two launches
-  // less per trial).  Taken when every rank has a GPU of its own — with ranks folded onto one device (the tests of
-  // this repository's one-GPU box) a spinning grid per rank could keep the producers it waits for off the CUs, so
-  // there the wait stays a single-block kernel of its own.  PDLP_MI355X_MESH_FUSED_WAIT=0|1 forces either.
+  // less per trial).  2 (round 6): producer and consumer of an exchange are ONE kernel — push, epoch, wait, copy: five
+  // launches per trial, one per all-gather of a check, the statistics' reduction with its all-reduce.  2 is taken when
+  // every rank has a GPU of its own — with ranks folded onto one device (the tests of this repository's one-GPU box) a
+  // spinning grid per rank could keep the producers it waits for off the CUs, so there the wait stays a single-block
+  // kernel of its own (0).  PDLP_MI355X_MESH_FUSED_WAIT=0|1|2 forces one.
   int32_t fusedWait;
 };
 
@@ -102,6 +104,12 @@ class Mesh {
   void reduceScatterCols(const double* partial, double* dst, hipStream_t s);
   // buf[0:k) = sum over ranks (rank order), k <= kMeshMailDoubles; identical bits on every rank
   void allReduceScalars(double* buf, int32_t k, hipStream_t s);
+  // the statistics of a sharded check: out[q] = fixed-order sum of quantity q's per-block partials (launchFinalReduce2,
+  // gated by g), then summed over the ranks — one launch with fusedWait == 2, else the two steps one after the other
+  void reduce2AllReduce(const double* partials, int32_t stride, int32_t nQ0, int32_t nBlocks0, int32_t nQ1, int32_t nBlocks1, double* out,
+                        CheckGate g, hipStream_t s);
+  // norms[0], norms[1] = fixed-order sums of the two partial arrays, then summed over the ranks
+  void normsAllReduce(const double* partX, int32_t nX, const double* partY, int32_t nY, double* norms, hipStream_t s);
   // throws unless every rank holds bit-identical copies of vec[0:len) (collective; syncs the stream)
   void verifyReplicated(const double* vec, int64_t len, hipStream_t s);
   // average microseconds a hot-loop wait for the peers took since the last call, per exchange {X, P, S}, and
@@ -153,6 +161,10 @@ void launchMeshDecide(DevState* st, const MeshArgs& dmv, const double* partDY, i
 // full-length y of the next parity on this rank.
 void launchMeshPushY(const IterVecs& vf, const double* const yFull[2], const DevState* st, const MeshArgs& dmv, hipStream_t s);
 void launchMeshWaitCopyY(double* const yFull[2], int32_t m, const DevState* st, const MeshArgs& dmv, hipStream_t s);
+// MeshArgs::fusedWait == 2 (round 6): the X exchange (primal step on the own slice + push + epoch + wait + copy of the
+// peers' slices) and the Y exchange (push of the own rows + epoch + wait + copy) as ONE launch each
+void launchMeshPrimalX(const IterVecs& vc, double* const xFull[2], int32_t nFull, DevState* st, const MeshArgs& dmv, hipStream_t s);
+void launchMeshY(double* const yFull[2], int32_t m, DevState* st, const MeshArgs& dmv, hipStream_t s);
 
 // One sharded HiPDLP step (pdhg.cc:961-1018 over row-block shards): hFull = full-length / local-row
 // pointers, hCol = the same with the column vectors offset to the own slice (rx stays full-length).

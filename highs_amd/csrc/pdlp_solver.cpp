@@ -1165,15 +1165,25 @@ void Solver::enqueueTrial() {
     const MeshArgs& mv = mesh_->args();
     double* buf = commBuf_.get();
     const int32_t nb = meshGrid(std::max(nLoc_, 1));  // consumer grid: ~4 slice elements per thread
-    launchMeshPrimalStep(vecsCol_, dst(), mv, stream_);
-    launchMeshWaitCopyX(vecs_, dst(), mv, stream_);
+    const bool oneLaunch = mv.fusedWait == 2;  // every rank on a GPU of its own: an exchange is one kernel (five launches per trial)
+    if (oneLaunch) {
+      double* xFull[2] = {x_[0].get(), x_[1].get()};
+      launchMeshPrimalX(vecsCol_, xFull, F_.n, dst(), mv, stream_);
+    } else {
+      launchMeshPrimalStep(vecsCol_, dst(), mv, stream_);
+      launchMeshWaitCopyX(vecs_, dst(), mv, stream_);
+    }
     launchSpmvAxDual(dA_.view(), vecs_, dst(), partDY_.get(), stream_);
     if (colblock_) {
       // Y all-gather of the dual step's rows, then A'y+ on the own COLUMNS from the column block: every column is
       // summed over all rows in the single-GPU order; no n-length partial is written, pushed and re-reduced
       double* yFull[2] = {y_[0].get(), y_[1].get()};
-      launchMeshPushY(vecs_, yFull, dst(), mv, stream_);
-      launchMeshWaitCopyY(yFull, F_.m, dst(), mv, stream_);
+      if (oneLaunch) {
+        launchMeshY(yFull, F_.m, dst(), mv, stream_);
+      } else {
+        launchMeshPushY(vecs_, yFull, dst(), mv, stream_);
+        launchMeshWaitCopyY(yFull, F_.m, dst(), mv, stream_);
+      }
       launchSpmvAtyInteract(dAt_.view(), vecsAty_, dst(), partDX_.get(), partInter_.get(), stream_);
       launchMeshDecide(dst(), mv, partDY_.get(), dA_.nPartials(), partDX_.get(), partInter_.get(), dAt_.nPartials(), stream_);
       return;
@@ -1605,8 +1615,7 @@ void Solver::enqueueCheckDevice() {
     launchColStats2(vecsCol_, g, 0, atyAvg_.get() + co, xAvg_.get() + co, colScale_.get() + co, nullptr, sc, slackPos_.get() + co,
                     slackNeg_.get() + co, slackPosAvg_.get() + co, slackNegAvg_.get() + co, part + (size_t)kStatColCur * statStride_,
                     statStride_, nbN, stream_);
-    launchFinalReduce2(part, statStride_, 2 * kRowStats, nbM, 2 * kColStats, nbN, statOut_.get(), g, stream_);
-    mesh_->allReduceScalars(statOut_.get(), kStatTotal, stream_);
+    mesh_->reduce2AllReduce(part, statStride_, 2 * kRowStats, nbM, 2 * kColStats, nbN, statOut_.get(), g, stream_);
     CheckRecord* rec = hostRing_ + (checkSeq_ % kRingSlots);
     rec->ran = 0;
     ++checkSeq_;
@@ -1620,9 +1629,7 @@ void Solver::enqueueCheckDevice() {
     // the two norms of the primal-weight update: this rank's partials -> one scalar each (reduceScalar's kernel) -> summed
     // over the ranks in rank order -> k_restart_finish takes them as partial arrays of length one
     double* norms = statOut_.get() + kStatTotal + 2;
-    launchFinalReduce(partDX_.get(), nbN, nbN, 1, norms, stream_);
-    launchFinalReduce(partRestartY_.get(), nbM, nbM, 1, norms + 1, stream_);
-    mesh_->allReduceScalars(norms, 2, stream_);
+    mesh_->normsAllReduce(partDX_.get(), nbN, partRestartY_.get(), nbM, norms, stream_);
     launchRestartFinish(st, dCtl_.get(), norms, 1, norms + 1, 1, rec, stream_);
     return;
   }
@@ -2054,13 +2061,17 @@ void Solver::stage(const std::string& name, double* out, int32_t cap) {
       put(0, -1.0);
     }
   } else if (name == "trial_launches") {  // kernels per trial step of the hot loop (2 = fused decision + primal step)
-    const double fw = meshMode_ && mesh_->args().fusedWait ? 1.0 : 0.0;  // (all-gather consumers wait themselves: two / one launches less)
-    put(0, meshMode_ ? (colblock_ ? 10.0 - 2.0 * fw : 9.0 - fw) : sharded_ ? 7.0 : persistent_ ? 0.0 : fused_ ? 2.0 : 3.0);  // 0: one persistent launch per batch
+    // mesh, two all-gathers: 9 with single-block wait kernels, 7 with consumers that wait themselves, 5 with an exchange
+    // per launch (fusedWait 0 / 1 / 2); round-1 layout: 9 / 8
+    const int fw = meshMode_ ? mesh_->args().fusedWait : 0;
+    put(0, meshMode_ ? (colblock_ ? 9.0 - 2.0 * fw : 9.0 - (fw ? 1.0 : 0.0)) : sharded_ ? 7.0 : persistent_ ? 0.0 : fused_ ? 2.0 : 3.0);  // 0: one persistent launch per batch
   } else if (name == "trial_barriers") {  // grid barriers per trial of the persistent loop (0: no persistent loop)
     put(0, !persistent_ ? 0.0 : primalInA_ ? 2.0 : 3.0);
   } else if (name == "check_launches") {  // kernels of one device-driven check iteration (1: the one-launch form of small LPs;
-    // sharded: 12 gated kernels + three all-gathers of 4 launches + two scalar all-reduces; 0: the host drives the checks)
-    put(0, !devCheck_ ? 0.0 : sharded_ ? 26.0 : persistent_ && checkSmall_ ? 1.0 : 10.0);
+    // sharded: 12 gated kernels + three all-gathers of 4 launches + two scalar all-reduces = 26, with an exchange per
+    // launch (fusedWait 2) 9 gated kernels + three all-gathers + the two reductions with their all-reduces = 14;
+    // 0: the host drives the checks)
+    put(0, !devCheck_ ? 0.0 : sharded_ ? (mesh_ && mesh_->args().fusedWait == 2 ? 14.0 : 26.0) : persistent_ && checkSmall_ ? 1.0 : 10.0);
   } else if (name == "barrier_fallbacks") {  // times a launch with grid barriers gave up and the loop went on with plain launches
     put(0, (double)barrierFallbacks_);
   } else if (name == "exchange") {  // 0 = not sharded, 1 = RCCL all-reduce, 2 = direct xGMI mesh (partials), 3 = mesh, two all-gathers
