@@ -299,9 +299,12 @@ def main():
     # iterate at every check): if it reports an inconsistency on this machine, every rank starts over with the
     # RCCL all-reduce exchange and the line says so.
     exchange_fallback = None
-    for attempt in ([None, "fences", "rccl"] if world > 1 and args.solver == "pdlp" else [None, "fences"] if world > 1 else [None]):
+    chain = [None, "fences", "fences, a kernel per step"]
+    for attempt in (chain + ["rccl"] if world > 1 and args.solver == "pdlp" else chain if world > 1 else [None]):
         if attempt == "fences":  # the direct exchange with system-scope release / acquire fences around the flags
             os.environ["PDLP_MI355X_MESH_FENCES"] = "1"
+        elif attempt == chain[2]:  # ... and every step of an exchange a kernel of its own (round 5's folded form)
+            os.environ["PDLP_MI355X_MESH_FENCES"] = "2"
         elif attempt:
             os.environ["PDLP_MI355X_EXCHANGE"] = attempt
         err, S = None, None
@@ -326,11 +329,13 @@ def main():
             failed = err is not None
         if not failed:
             break
-        if attempt == "rccl" or world == 1 or (attempt == "fences" and args.solver != "pdlp"):
+        if attempt == "rccl" or world == 1 or (attempt == chain[2] and args.solver != "pdlp"):
             raise SystemExit("bench.py: the solver failed: %s" % err)
-        exchange_fallback = ("direct xGMI exchange%s rejected on this machine (%s); next: %s"
-                             % (" with fences" if attempt == "fences" else "", err or "error on another rank",
-                                "the same with release/acquire fences" if attempt is None else "RCCL all-reduce"))
+        exchange_fallback = ("%sdirect xGMI exchange%s rejected on this machine (%s); next: %s"
+                             % (exchange_fallback + " | " if exchange_fallback else "", " with " + attempt if attempt else "",
+                                err or "error on another rank",
+                                "the same with release/acquire fences" if attempt is None else
+                                "the same with a kernel per exchange step" if attempt == "fences" else "RCCL all-reduce"))
         if S is not None:
             try:
                 S.close()

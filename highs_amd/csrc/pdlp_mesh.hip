@@ -760,10 +760,13 @@ uint64_t fnv64(const void* p, size_t len) {
 
 size_t alignUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-int32_t meshFences() {
+// PDLP_MI355X_MESH_FENCES: 1 = release / acquire fences around the flags; 2 = the same AND every step of an exchange a
+// kernel of its own (single-block wait kernels: the most conservative form, the last stop in front of RCCL)
+int32_t meshFenceLevel() {
   const char* e = getenv("PDLP_MI355X_MESH_FENCES");
-  return e && atoi(e) != 0 ? 1 : 0;
+  return e ? std::min(std::max(atoi(e), 0), 2) : 0;
 }
+int32_t meshFences() { return meshFenceLevel() != 0 ? 1 : 0; }
 
 }  // namespace
 
@@ -926,6 +929,7 @@ void Mesh::construct(int32_t rank, int32_t world, const void* id128, int32_t n, 
     for (int b = a + 1; b < world; ++b)
       if (seg->slot[a].busHash == 0ull || seg->slot[a].busHash == seg->slot[b].busHash) own = false;
   int fusedWait = own ? 2 : 0;
+  if (meshFenceLevel() == 2) fusedWait = 0;
   if (const char* e = devEnv("PDLP_MI355X_MESH_FUSED_WAIT")) fusedWait = std::min(std::max(atoi(e), 0), 2);
   args_ = MeshArgs{dView_, state_, v_.G, v_.g, v_.waitTicks, meshFences(), fusedWait};
   hostBarrier(1, 60.0);

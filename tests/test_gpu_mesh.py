@@ -205,10 +205,11 @@ def test_mesh_with_release_acquire_fences_gives_the_same_bits(tmp_path):
     """PDLP_MI355X_MESH_FENCES=1 (the belt-and-braces form of the exchange that bench.py tries before falling
     back to RCCL) changes ordering instructions only: same iterates, bit for bit."""
     a = _run_ranks(2, "solve:e226", tmp_path)
-    b = _run_ranks(2, "solve:e226", tmp_path, extra_env={"PDLP_MI355X_MESH_FENCES": "1"})
-    for k in ("col_value", "row_dual", "num_iter", "num_trials", "primal_obj"):
-        assert np.array_equal(a[0][k], b[0][k]) and np.array_equal(b[0][k], b[1][k]), k
-    assert b[0]["exchange"] in (2.0, 3.0)
+    for level in ("1", "2"):  # (2: fences and a kernel per exchange step, bench.py's last stop in front of RCCL)
+        b = _run_ranks(2, "solve:e226", tmp_path, extra_env={"PDLP_MI355X_MESH_FENCES": level})
+        for k in ("col_value", "row_dual", "num_iter", "num_trials", "primal_obj"):
+            assert np.array_equal(a[0][k], b[0][k]) and np.array_equal(b[0][k], b[1][k]), (level, k)
+        assert b[0]["exchange"] in (2.0, 3.0)
 
 
 @pytest.mark.parametrize("case,world", [("solve:e226", 2), ("iterate:synth:120", 2), ("iterate:synthbig:40", 2)])

@@ -1,5 +1,6 @@
 #!/bin/bash
-# tools/r6_xp.sh TAG — round 6 experiments on one box (A/B of development switches)
+# tools/r6_xp.sh [TAG] — round-6 A/B of the fused trial's barrier with task workgroups (configs d, f): streaming blocks
+# vouch for "their" task workgroups' arrival (PDLP_MI355X_PAIRED_TASKS=1, default) vs every word swept by everybody (0)
 export PDLP_MI355X_DEV=1
 cd "$(dirname "$0")/.."
 TAG=${1:-r06_xp}; OUT=gpurun_out/$TAG; mkdir -p $OUT
@@ -7,11 +8,12 @@ line() { python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); pr
 run() { # name cfg env...
   local name=$1 cfg=$2; shift 2
   env "$@" python bench.py --config $cfg --cpu-iters 0 2>$OUT/$name.err | line $name
-  grep "slab operand" $OUT/$name.err
+  env "$@" PDLP_MI355X_SLAB_PROF=1 python bench.py --config $cfg --cpu-iters 0 2>&1 >/dev/null | grep "slab launch" | grep -E "fused" | grep -E "epilogue|barrier|kernel"
 }
-for cfg in b d e c f; do
-  run ${cfg}_tuned $cfg PDLP_MI355X_SLAB_PROF=1
-  run ${cfg}_rule $cfg PDLP_MI355X_SLAB_TUNE=0
+for cfg in d f; do
+  for rep in 1 2; do
+    run ${cfg}_paired_$rep $cfg PDLP_MI355X_PAIRED_TASKS=1
+    run ${cfg}_swept_$rep $cfg PDLP_MI355X_PAIRED_TASKS=0
+  done
 done
-python bench.py --solver hipdlp --cpu-iters 0 2>/dev/null | line hipdlp_tuned
-bash tools/gpu_pytest.sh $TAG/pytest tests -m gpu -q -x --timeout 600 -k "bit_exact or setup or held_out"
+bash tools/gpu_pytest.sh $TAG/pytest tests -m gpu -q -x --timeout 600 -k "fused or bit_exact or two_large or fault or barrier or held_out"
