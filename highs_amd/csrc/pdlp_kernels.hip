@@ -56,7 +56,6 @@ struct SpmvArgs {
   unsigned long long barLimit;  // 100 MHz ticks the grid barrier may wait for a missing block
   int32_t faultTrial;           // tests: the barrier of the trial that raises the trial counter to this value expects one block too many
   int32_t inlineTasks;          // kAtyFused: the streaming blocks run the segment tasks of the long majors themselves (no extra blocks)
-  int32_t pairedTasks;          // kAtyFused with task workgroups: a streaming block vouches for "its" task workgroups' arrival (k_spmv_slab)
   int32_t coTaskBlocks;         // kAtyFused: ... or that many extra workgroups run them, resident next to the streaming blocks, and arrive at the barrier
   CheckGate gate;  // kPlain inside a device-driven check: the launch is a no-op unless the check is due
   // development (PDLP_MI355X_SLAB_PROF=1): per block {launches, ticks to the end of the stream, to the end of the epilogue, to
@@ -698,31 +697,8 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
   // wave's memory operations (vmcnt(0)), and with the operand loads of the next primal step issued in front of it that wait
   // was an HBM round trip under load — every block's, so the release came 2.7 us (config b) to 5 us (config d, ten loads
   // per thread) after the last epilogue (round 6).
-  if (EPI == kAtyFused && wave == 0) {
-    const unsigned long long epochB = (unsigned long long)a.st->nTrials + 1ull;
-    bool pairOk = true;
-    if (TWO && a.pairedTasks) {
-      // (round 6) the task workgroups' arrival words are not swept by everybody: streaming block b looks at the words of task
-      // workgroups b, b + nBlocks, ... BEFORE it arrives, so its own arrival stands for theirs and a sweep covers the
-      // streaming blocks' words only — half the polled words on config d (256 + 256).  The task workgroups are done
-      // microseconds before the slowest epilogue, so the look costs one uncached round trip.  Bounded like the sweep: on a
-      // time-out the block poisons its own word instead of arriving and every sweep fails (gridWait).
-      const unsigned long long t0 = wall_clock64();
-      for (int w = (int)blockIdx.x; w < a.coTaskBlocks && pairOk; w += a.S.nBlocks) {
-        for (uint32_t spins = 0;; ++spins) {
-          const unsigned long long v = __hip_atomic_load(a.bar + a.S.nBlocks + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (v >= epochB) break;
-          __builtin_amdgcn_s_sleep(1);
-          if ((spins & 31u) == 31u && wall_clock64() - t0 > a.barLimit) { pairOk = false; break; }
-        }
-      }
-    }
-    if (pairOk) gridArrive(a.bar, (int)blockIdx.x, epochB, lane);
-    else if (lane == 0) {
-      __hip_atomic_store(a.bar + blockIdx.x, epochB | kBarPoison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(a.bar + a.S.nBlocks + a.coTaskBlocks, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
+  if (EPI == kAtyFused && wave == 0)
+    gridArrive(a.bar, (int)blockIdx.x, (unsigned long long)a.st->nTrials + 1ull, lane);
   if (EPI == kAtyFused && kFixEarly) {  // xSum of the own columns: in flight across the barrier and the decision
 #pragma unroll
     for (int k = 0; k < kSlabPre; ++k) {
@@ -749,7 +725,7 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
     DevState* sh = reinterpret_cast<DevState*>(&tscr[4][0]);
     int* barVerdict = reinterpret_cast<int*>(reinterpret_cast<char*>(sh) + ((sizeof(DevState) + 7) / 8) * 8);
     if (wave == 0) {
-      const int nExp = a.S.nBlocks + (TWO && a.pairedTasks ? 0 : a.coTaskBlocks) + (a.st->nTrials + 1 == a.faultTrial ? 1 : 0);
+      const int nExp = a.S.nBlocks + a.coTaskBlocks + (a.st->nTrials + 1 == a.faultTrial ? 1 : 0);
       const int verdict = gridWait(a.bar, (int)blockIdx.x, nExp, (unsigned long long)a.st->nTrials + 1ull, lane, a.barLimit);
       if (lane == 0) *barVerdict = verdict;
     }
@@ -1316,7 +1292,6 @@ void launchSpmvAtyFusedPrimal(const MatView& At, const IterVecs& v, const DevSta
   a.faultTrial = faultTrial;
   a.coTaskBlocks = At.useSlab && At.lng.nTasks > 0 ? At.coTaskBlocks : 0;
   a.inlineTasks = At.useSlab && At.lng.nTasks > 0 && a.coTaskBlocks == 0 ? 1 : 0;
-  a.pairedTasks = a.coTaskBlocks > 0 ? At.pairedTasks : 0;
   a.st = stIn; a.v = v; a.part0 = partDX; a.part1 = partInter;
   a.stOut = stOut; a.partDY = partDY; a.nDY = nDY; a.nDX = At.nPartials; a.bar = bar;
   if (At.useSlab && At.slab.nBlocks <= 512) a.prof = slabProf();

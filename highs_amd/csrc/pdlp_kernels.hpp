@@ -187,7 +187,6 @@ struct MatView {
   // barrier; 0 = the streaming blocks run the task passes themselves behind their stream (where two blocks per CU do
   // not fit).  Set by the solver from fusedCoTaskBlocks().
   int32_t coTaskBlocks;
-  int32_t pairedTasks;   // the fused trial's streaming blocks vouch for the task workgroups' arrival (round 6; 0: every word swept by everybody)
 };
 
 // Vectors of the iteration (device pointers). Pairs are double-buffered by parity.
