@@ -56,6 +56,7 @@ struct SpmvArgs {
   unsigned long long barLimit;  // 100 MHz ticks the grid barrier may wait for a missing block
   int32_t faultTrial;           // tests: the barrier of the trial that raises the trial counter to this value expects one block too many
   int32_t inlineTasks;          // kAtyFused: the streaming blocks run the segment tasks of the long majors themselves (no extra blocks)
+  int32_t touchTail;            // kAtyFused: columns beyond the register-held ones are touched before the barrier (k_spmv_slab)
   int32_t coTaskBlocks;         // kAtyFused: ... or that many extra workgroups run them, resident next to the streaming blocks, and arrive at the barrier
   CheckGate gate;  // kPlain inside a device-driven check: the launch is a no-op unless the check is due
   // development (PDLP_MI355X_SLAB_PROF=1): per block {launches, ticks to the end of the stream, to the end of the epilogue, to
@@ -720,6 +721,23 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
       if (LATE && k >= kSlabPre) xbLate[k - kSlabPre] = ldStream(a.v.x[epi.nxt] + r);  // (x+ of the trial: what the step starts from when it is accepted)
     }
   }
+  // (round 6) Columns beyond the ones stepped from registers — the blocks that own thousands of one-entry slack columns —
+  // used to fetch their operands behind the barrier, kTail columns per HBM round trip under load: those blocks ended
+  // 4.5 us (config d) / 7 us (f) after the others.  Their lines are TOUCHED here instead (one dword per lane and operand,
+  // result unused, all into one register), so that the loads behind the barrier hit the L2.
+  uint32_t touched = 0u;
+  if (EPI == kAtyFused && TWO && a.touchTail) {  // (the 128-register variant steps 8192 columns per block from registers: nothing to gain there, config c lost 2 us)
+    const double* __restrict__ xNxt = a.v.x[epi.nxt];
+    int n = 0;
+    for (int lr0 = tid + kFixN * kSlabThreads; rBase + lr0 < rEnd && n < 8; lr0 += kSlabThreads, ++n) {
+      const int r = rBase + lr0;
+      asm volatile("global_load_dword %0, %1, off" : "+v"(touched) : "v"(a.v.cost + r) : "memory");
+      asm volatile("global_load_dword %0, %1, off" : "+v"(touched) : "v"(a.v.lower + r) : "memory");
+      asm volatile("global_load_dword %0, %1, off" : "+v"(touched) : "v"(a.v.upper + r) : "memory");
+      asm volatile("global_load_dword %0, %1, off" : "+v"(touched) : "v"(a.v.xSum + r) : "memory");
+      asm volatile("global_load_dword %0, %1, off" : "+v"(touched) : "v"(xNxt + r) : "memory");
+    }
+  }
   if (EPI == kAtyFused) {
     double(*tscr)[kVecThreads / kWave] = reinterpret_cast<double(*)[kVecThreads / kWave]>(&scratch[2][0]);
     DevState* sh = reinterpret_cast<DevState*>(&tscr[4][0]);
@@ -736,6 +754,7 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
     }
     __syncthreads();
     profStamp(2);
+    if (TWO && a.touchTail) asm volatile("s_waitcnt vmcnt(0)" : "+v"(touched) : : "memory");  // (the register of the touches is free again)
     if (*barVerdict != kBarOk) {  // not every block of this launch was resident in time: the trial stays undecided (fusedBarrierFailed)
       fusedBarrierFailed(a.stOut, reinterpret_cast<const uint32_t*>(sh), *barVerdict, blockIdx.x == 0, tid);
       return;
@@ -797,7 +816,7 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
     }
     // (more columns per block than that: kTail columns' operands per round trip — two in the LATE variants, where this
     // loop only sees blocks beyond 8192 / 4096 columns and the registers hold twice as many columns across the barrier)
-    constexpr int kTail = LATE ? 2 : kSlabPre;
+    constexpr int kTail = LATE ? 2 : TWO ? 3 : kSlabPre;
     for (int lr0 = tid + kFixN * kSlabThreads; rBase + lr0 < rEnd; lr0 += kTail * kSlabThreads) {
       double xb[kTail], ab[kTail], cc[kTail], ll[kTail], uu[kTail], xs[kTail], qq[kTail];
 #pragma unroll
@@ -1292,6 +1311,7 @@ void launchSpmvAtyFusedPrimal(const MatView& At, const IterVecs& v, const DevSta
   a.faultTrial = faultTrial;
   a.coTaskBlocks = At.useSlab && At.lng.nTasks > 0 ? At.coTaskBlocks : 0;
   a.inlineTasks = At.useSlab && At.lng.nTasks > 0 && a.coTaskBlocks == 0 ? 1 : 0;
+  a.touchTail = At.touchTail;
   a.st = stIn; a.v = v; a.part0 = partDX; a.part1 = partInter;
   a.stOut = stOut; a.partDY = partDY; a.nDY = nDY; a.nDX = At.nPartials; a.bar = bar;
   if (At.useSlab && At.slab.nBlocks <= 512) a.prof = slabProf();

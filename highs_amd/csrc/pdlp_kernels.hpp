@@ -187,6 +187,7 @@ struct MatView {
   // barrier; 0 = the streaming blocks run the task passes themselves behind their stream (where two blocks per CU do
   // not fit).  Set by the solver from fusedCoTaskBlocks().
   int32_t coTaskBlocks;
+  int32_t touchTail;     // the fused trial touches the operands of a block's columns beyond the register-held ones before its barrier
 };
 
 // Vectors of the iteration (device pointers). Pairs are double-buffered by parity.

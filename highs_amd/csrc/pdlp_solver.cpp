@@ -244,6 +244,7 @@ MatView DeviceMatrix::view() const {
   v.useSlab = useSlab ? 1 : 0;
   v.xcdMap = xcdMap;
   v.coTaskBlocks = fusedCoTasks;
+  v.touchTail = touchTail;
   v.nPartials = nPartials();
   return v;
 }
@@ -359,6 +360,7 @@ DevSwitches DevSwitches::fromEnv() {
   w.affineTasks = dev("PDLP_MI355X_AFFINE_TASKS", 1);
   w.fusedStream = dev("PDLP_MI355X_FUSED_STREAM", 0);
   w.fusedCoTasks = dev("PDLP_MI355X_FUSED_COTASKS", -1);
+  w.touchTail = dev("PDLP_MI355X_TOUCH_TAIL", 1);
   w.xcdLocal = dev("PDLP_MI355X_XCD_LOCAL", -1);
   w.hierBarrier = dev("PDLP_MI355X_HIER_BARRIER", -1);
   w.deviceCheck = dev("PDLP_MI355X_DEVICE_CHECK", -1);
@@ -647,6 +649,7 @@ void Solver::construct(const pdlp_problem_t& P, const void* id128) {
     // (long columns: their segment tasks as workgroups of the fused launch, resident next to its streaming blocks, where
     // two 1024-thread blocks per CU fit — PDLP_MI355X_FUSED_COTASKS=0 keeps the task passes inside the streaming blocks)
     dAt_.fusedCoTasks = sw_.fusedCoTasks != 0 ? fusedCoTaskBlocks(dAt_.view(), opt_.device) : 0;
+    dAt_.touchTail = sw_.touchTail != 0 ? 1 : 0;
     const MatView at = dAt_.view();
     const bool allowed = at.useSlab ? sw_.fused != 0 : sw_.fusedStream != 0;
     fused_ = allowed && !hasQoff_ && fusedAtyBlocks(at) > 0 && fusedAtyBlocksResident(at, opt_.device) >= fusedAtyBlocks(at);

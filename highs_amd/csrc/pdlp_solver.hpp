@@ -28,6 +28,7 @@ struct DevSwitches {
   int slabTune = 1;       // PDLP_MI355X_SLAB_TUNE=0 (development): the slab width by rule only, no timing of narrower slabs
   int affineTasks = 1;  // XCD-affine deal of the slab layout's segment tasks (0: (major, segment) order; A/B measurements)
   int fusedCoTasks = -1;  // PDLP_MI355X_FUSED_COTASKS: 0 = the fused trial's streaming blocks run the long columns' task passes themselves
+  int touchTail = 1;      // PDLP_MI355X_TOUCH_TAIL=0 (development): no touching of the tail columns' operands in front of the fused trial's barrier
   int fused = -1, fusedStream = 0, persistent = -1, xcdLocal = -1, hierBarrier = -1, deviceCheck = -1, checkSmall = -1;
   int primalInA = -1;     // PDLP_MI355X_PRIMAL_IN_A: the persistent loop without its P phase (pdlp_small.hip PINA); -1 = where measured faster
   int barrierTimeoutMs = 1000;  // PDLP_MI355X_BARRIER_TIMEOUT_MS: how long a grid barrier / roll call waits for missing workgroups
@@ -54,6 +55,7 @@ struct DeviceMatrix {
   bool affineTasks = true;  // slab layout: XCD-affine deal of the segment tasks (PDLP_MI355X_DEV_AFFINE_TASKS=0: (major, segment) order)
   int32_t majorCost = kSlabMajorCostRows;  // slab partition: work of a major besides its entries (the owner sets kSlabMajorCostCols on its transposed operand)
   int32_t fusedCoTasks = 0;  // MatView::coTaskBlocks (the fused trial's task workgroups), decided by the solver at set-up
+  int32_t touchTail = 1;     // MatView::touchTail
   int32_t nMajor = 0, nBlocks = 0;  // nBlocks = CSR stream blocks
   int32_t chunk = kChunk;           // work-plan block size of the CSR stream (spmvChunkFor)
   int64_t nnz = 0;
