@@ -470,6 +470,9 @@ constexpr int kSlabSlots = 3;  // register pipeline depth (groups of 64 entries 
 // (the stream's registers are free by then): 8192 columns per block (4096 in the 64-register variant) are stepped from
 // registers behind the barrier, nothing but the stores left there (round 6: config c spent 13 us behind its barrier on
 // 8200 columns per block, half of them fetched there).
+#ifndef PDLP_TWO_EXTRA
+#define PDLP_TWO_EXTRA 0
+#endif
 template <int EPI, bool TWO, int NB, int GD, bool LATE = false>
 __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabThreads / 256) void k_spmv_slab(const SpmvArgs a) {
   if (EPI == kAtyFused && a.st->halted) {  // keep the two state slots identical while the queue drains
@@ -544,9 +547,12 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
   // kAtyFused: the operands of the NEXT primal step that no decision can change (c, l, u, xSum) travel with the stream
   // (not in the 64-register variant that leaves room for the task workgroups: there they are fetched behind the barrier)
   constexpr bool kFixEarly = !TWO && !LATE;
-  constexpr int kFixN = EPI == kAtyFused ? (LATE ? 2 * kSlabPre : kSlabPre) : 1;  // columns per thread stepped from registers
+  // columns per thread stepped from registers: the kSlabPre whose epilogue operands travel with the stream, plus kExtra whose
+  // operands are fetched behind the arrival (LATE: as many again; the 64-register variant: PDLP_TWO_EXTRA, measured)
+  constexpr int kExtra = EPI != kAtyFused ? 0 : LATE ? kSlabPre : TWO ? PDLP_TWO_EXTRA : 0;
+  constexpr int kFixN = EPI == kAtyFused ? kSlabPre + kExtra : 1;
   Pre fix[kFixN];
-  double xbLate[LATE ? kSlabPre : 1];  // x+ of the second kSlabPre columns (the first ones': pre[k].b)
+  double xbLate[kExtra > 0 ? kExtra : 1];  // x+ of the extra columns (the first ones': pre[k].b)
   if (EPI == kAtyFused && kFixEarly) {
 #pragma unroll
     for (int k = 0; k < kSlabPre; ++k) {
@@ -718,7 +724,7 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
       fix[k].d = ldStream(a.v.xSum + r);
       // (the diagonal of Q of a QP's prox step: in a register for the first kSlabPre columns, fetched behind the barrier for the others)
       fix[k].e = (k < kSlabPre && a.v.qdiag) ? ldStream(a.v.qdiag + r) : 0.0;
-      if (LATE && k >= kSlabPre) xbLate[k - kSlabPre] = ldStream(a.v.x[epi.nxt] + r);  // (x+ of the trial: what the step starts from when it is accepted)
+      if (kExtra > 0 && k >= kSlabPre) xbLate[k - kSlabPre] = ldStream(a.v.x[epi.nxt] + r);  // (x+ of the trial: what the step starts from when it is accepted)
     }
   }
   // (round 6) Columns beyond the ones stepped from registers — the blocks that own thousands of one-entry slack columns —
@@ -802,7 +808,7 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
         step(r, accepted ? pre[k].b : ldStream(xBase + r), ab, fix[k].a, fix[k].b, fix[k].c, fix[k].d, fix[k].e);
       }
     }
-    if (LATE) {  // the second kSlabPre columns per thread: from registers too
+    if (kExtra > 0) {  // the extra columns per thread: from registers too
 #pragma unroll
       for (int k = kSlabPre; k < kFixN; ++k) {
         const int lr = tid + k * kSlabThreads;

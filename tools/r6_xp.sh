@@ -12,8 +12,8 @@ run() { # name cfg env...
 }
 for cfg in d f; do
   for rep in 1 2; do
-    run ${cfg}_k3_$rep $cfg PDLP_X=0
-    run ${cfg}_k2_$rep $cfg PDLP_MI355X_LIB=$PWD/highs_amd/lib/alt/lib_k2.so
+    run ${cfg}_x0_$rep $cfg PDLP_X=0
+    run ${cfg}_x1_$rep $cfg PDLP_MI355X_LIB=$PWD/highs_amd/lib/alt/lib_x1.so
   done
 done
 bash tools/gpu_pytest.sh $TAG/pytest tests -m gpu -q -x --timeout 600 -k "fused or bit_exact or two_large or fault or barrier or held_out"
