@@ -6,7 +6,8 @@
 #   1 peers     device count, peer-access matrix                                  (tools/bringup_multi_gpu.py peers)
 #   2 mesh      HIP IPC arena mapping + the exchange's known-answer self-test + flag-hop latency + 200 sharded iterations
 #   3 rccl      ncclAllReduce with N ranks (torch.distributed, backend nccl = RCCL)
-#   4 bench     python bench.py --gpus 2 / 4 / .. / N (mesh -> mesh with fences -> RCCL fall-back chain inside bench.py):
+#   4 bench     python bench.py --gpus 2 / 4 / .. / N (mesh -> mesh with fences -> the same with a kernel per exchange step -> RCCL
+#               fall-back chain inside bench.py):
 #               the N > 1 line carries ranks_bit_identical, exchange, exchange_fallback, exchange_waits per phase next to scaling_model
 # Nothing here needs the reference tree or the network.
 cd "$(dirname "$0")/.."
@@ -23,6 +24,9 @@ stage() { # name timeout cmd...
 stage peers 60 python tools/bringup_multi_gpu.py peers
 ID=$(python -c "import os; print(os.urandom(128).hex())")
 for W in $(seq 2 $N | awk '$1==2||$1==4||$1==8||$1=='$N); do
+  # (eight or more ranks FOLDED onto fewer devices: one hardware queue per rank process, or the device's queues are
+  # oversubscribed and a rank spins on a peer that is switched out — profiles/r06_development_measurements.md section 9)
+  if [ "$W" -ge 8 ] && [ "$NDEV" -lt "$W" ]; then export GPU_MAX_HW_QUEUES=1; fi
   pids=(); for r in $(seq 0 $((W-1))); do
     ( timeout 300 python tools/bringup_multi_gpu.py mesh $r $W $ID > $OUT/mesh_w${W}_r$r.json 2> $OUT/mesh_w${W}_r$r.err ) & pids+=($!)
   done
