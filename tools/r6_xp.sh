@@ -1,6 +1,6 @@
 #!/bin/bash
-# tools/r6_xp.sh [TAG] — round-6 A/B of the fused trial's tail behind the barrier (configs d, f: the 64-register variant):
-# three columns' operands per round trip (the build) vs two (highs_amd/lib/alt/lib_k2.so), both with the tail touched
+# tools/r6_xp.sh [TAG] — round-6 A/B of the fused trial: the sweeping wave fetches its operands behind the release (the
+# build) vs in front of the barrier like the other waves (highs_amd/lib/alt/lib_s0.so)
 export PDLP_MI355X_DEV=1
 cd "$(dirname "$0")/.."
 TAG=${1:-r06_xp}; OUT=gpurun_out/$TAG; mkdir -p $OUT
@@ -8,12 +8,10 @@ line() { python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); pr
 run() { # name cfg env...
   local name=$1 cfg=$2; shift 2
   env "$@" python bench.py --config $cfg --cpu-iters 0 2>$OUT/$name.err | line $name
-  env "$@" PDLP_MI355X_SLAB_PROF=1 python bench.py --config $cfg --cpu-iters 0 2>&1 >/dev/null | grep "slab launch" | grep -E "fused" | grep -E "kernel"
+  env "$@" PDLP_MI355X_SLAB_PROF=1 python bench.py --config $cfg --cpu-iters 0 2>&1 >/dev/null | grep "slab launch" | grep -E "fused" | grep -E "barrier|kernel"
 }
-for cfg in d f; do
-  for rep in 1 2; do
-    run ${cfg}_x0_$rep $cfg PDLP_X=0
-    run ${cfg}_x1_$rep $cfg PDLP_MI355X_LIB=$PWD/highs_amd/lib/alt/lib_x1.so
-  done
+for cfg in b c d e f qp; do
+  run ${cfg}_late $cfg PDLP_X=0
+  run ${cfg}_early $cfg PDLP_MI355X_LIB=$PWD/highs_amd/lib/alt/lib_s0.so
 done
 bash tools/gpu_pytest.sh $TAG/pytest tests -m gpu -q -x --timeout 600 -k "fused or bit_exact or two_large or fault or barrier or held_out"
