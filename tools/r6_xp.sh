@@ -1,6 +1,6 @@
 #!/bin/bash
-# tools/r6_xp.sh [TAG] — round-6 A/B of the fused trial: the sweeping wave fetches its operands behind the release (the
-# build) vs in front of the barrier like the other waves (highs_amd/lib/alt/lib_s0.so)
+# tools/r6_xp.sh [TAG] — round-6 A/B of the fused trial's barrier: arrival words 8 bytes apart (the build) vs 128 B / 256 B /
+# 4 KB apart (highs_amd/lib/alt/lib_st{16,32,512}.so): do the sweeps of 256 blocks queue on one memory channel?
 export PDLP_MI355X_DEV=1
 cd "$(dirname "$0")/.."
 TAG=${1:-r06_xp}; OUT=gpurun_out/$TAG; mkdir -p $OUT
@@ -10,8 +10,8 @@ run() { # name cfg env...
   env "$@" python bench.py --config $cfg --cpu-iters 0 2>$OUT/$name.err | line $name
   env "$@" PDLP_MI355X_SLAB_PROF=1 python bench.py --config $cfg --cpu-iters 0 2>&1 >/dev/null | grep "slab launch" | grep -E "fused" | grep -E "barrier|kernel"
 }
-for cfg in b c d e f qp; do
-  run ${cfg}_late $cfg PDLP_X=0
-  run ${cfg}_early $cfg PDLP_MI355X_LIB=$PWD/highs_amd/lib/alt/lib_s0.so
+for cfg in b c d qp; do
+  run ${cfg}_st1 $cfg PDLP_X=0
+  for st in 16 32 512; do run ${cfg}_st$st $cfg PDLP_MI355X_LIB=$PWD/highs_amd/lib/alt/lib_st$st.so; done
 done
 bash tools/gpu_pytest.sh $TAG/pytest tests -m gpu -q -x --timeout 600 -k "fused or bit_exact or two_large or fault or barrier or held_out"
