@@ -15,7 +15,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 RND=${1:-r06}
 if [ "${2:-}" = "collect" ]; then
   S=$R/gpurun_out/profiles_$RND
-  cp $S/r*.json $S/r*.csv $S/r*.log $R/profiles/ 2>/dev/null
+  cp $S/r*.json $S/r*.jsonl $S/r*.csv $S/r*.log $R/profiles/ 2>/dev/null
   cp $S/pmc_traffic.json $R/profiles/pmc_traffic.json
   ls -la $R/profiles
   exit 0
