@@ -258,6 +258,9 @@ __device__ __forceinline__ double ldAgent(const double* p) {
 // NEXT barrier of any block then meets a poisoned word of an older epoch and reports kBarBroken: an error, never a
 // silently wrong iterate).  On kBarFailed the caller leaves the trial undecided and the host falls back to plain
 // launches (Solver::syncState).
+#ifndef PDLP_BAR_SLEEP
+#define PDLP_BAR_SLEEP 1
+#endif
 constexpr unsigned long long kBarPoison = 1ull << 62;
 enum : int { kBarOk = 0, kBarFailed = 1, kBarBroken = 2 };
 // gridArrive + gridWait = gridBarrier.  Apart: a block that has loads in flight which nobody else needs (operands it
@@ -300,7 +303,7 @@ __device__ __forceinline__ int gridWait(unsigned long long* bar, int blk, int nB
     if (__any(stale)) return kBarBroken;
     if (__any(bad)) return kBarFailed;
     if (__all(ok)) return kBarOk;
-    __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_s_sleep(PDLP_BAR_SLEEP);
     if ((spins & 31u) == 31u && wall_clock64() - t0 > limitTicks) {
       if (lane == 0) {
         st(bar + blk, epoch | kBarPoison);

@@ -68,6 +68,16 @@ struct SpmvArgs {
 //   kDualStep     y+ = proj(y + sigma (b - 2 A x+ + A x)), sum (dy)^2        cupdlp_step.c:43-69
 //   kAtyInteract  sum (dx)^2, sum dx . d(A'y)                                cupdlp_linalg.c:772-801
 //   kHalpern*     the Halpern PDHG step of the HiPDLP path                   hipdlp/pdhg.cc:961-1018
+// The problem's CONSTANT vectors of the primal step (c, l, u: 24 bytes per column and iteration) are read with ordinary
+// loads: next to the two matrix copies (192 MB at 1M x 1M) they stay in the 256 MB Infinity Cache, and the tail of the
+// fused trial behind its stream — operand loads and stores of every column at once, bandwidth-bound — moves that much
+// less through HBM (round 6: config c fused launch 55.2 -> 49.8 us, b 64.6 -> 63.3, qp 40.4 -> 39.8; d, e unchanged).  The
+// iterates and running sums, read AND written once per iteration, stay non-temporal (xSum as ordinary traffic: no gain), and
+// so do the constants of the epilogues that travel with the stream (rhs; HiPDLP's c, l, u, row bounds: 40 more bytes per
+// row / column pushed the matrices out of the cache — HiPDLP 120 -> 130-135 us per iteration).
+template <class T>
+__device__ __forceinline__ T ldConst(const T* p) { return *p; }
+
 template <int EPI>
 struct Epi {
   const SpmvArgs& a;
@@ -347,7 +357,7 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
     // kAtyFused: what the NEXT primal step needs of this lane's first major and no decision can change (c, l, u)
     Pre fix{0.0, 0.0, 0.0, 0.0, 0.0};
     double keepX = 0.0, keepS = 0.0;  // x+ and (A'y+) of that major, for the step after an accepted trial
-    if (EPI == kAtyFused) { fix.a = ldStream(a.v.cost + rr); fix.b = ldStream(a.v.lower + rr); fix.c = ldStream(a.v.upper + rr); }
+    if (EPI == kAtyFused) { fix.a = ldConst(a.v.cost + rr); fix.b = ldConst(a.v.lower + rr); fix.c = ldConst(a.v.upper + rr); }
     // phase 1: kPer unit-stride loads of idx/val per lane, all issued before the
     // dependent gathers, so a wave keeps 3*kPer memory operations in flight
     const int last = cnt > 0 ? cnt - 1 : 0;  // idx/val carry one pad element
@@ -423,7 +433,7 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
           c = fix.a; l = fix.b; u = fix.c; xs = fix.d;
         } else {            // (more than 256 majors in the block: short columns)
           xb = ldStream(xBase + r); ab = ldStream(atyBase + r);
-          c = ldStream(a.v.cost + r); l = ldStream(a.v.lower + r); u = ldStream(a.v.upper + r); xs = ldStream(a.v.xSum + r);
+          c = ldConst(a.v.cost + r); l = ldConst(a.v.lower + r); u = ldConst(a.v.upper + r); xs = ldStream(a.v.xSum + r);
         }
         if (avgWx != 0.0) stStream(a.v.xSum + r, xs + avgWx * xb);  // deferred PDHG_Update_Average (step.c:437)
         double t = xb;
@@ -704,8 +714,10 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
   // wave's memory operations (vmcnt(0)), and with the operand loads of the next primal step issued in front of it that wait
   // was an HBM round trip under load — every block's, so the release came 2.7 us (config b) to 5 us (config d, ten loads
   // per thread) after the last epilogue (round 6).
-  if (EPI == kAtyFused && wave == 0)
+  if (EPI == kAtyFused && wave == 0) {
     gridArrive(a.bar, (int)blockIdx.x, (unsigned long long)a.st->nTrials + 1ull, lane);
+    profStamp(4);  // (the block's published words have landed, its arrival word is on its way)
+  }
   if (EPI == kAtyFused && kFixEarly) {  // xSum of the own columns: in flight across the barrier and the decision
 #pragma unroll
     for (int k = 0; k < kSlabPre; ++k) {
@@ -720,7 +732,7 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
     for (int k = 0; k < kFixN; ++k) {
       const int r0_ = rBase + tid + k * kSlabThreads;
       const int r = r0_ < rEnd ? r0_ : rEnd - 1;
-      fix[k].a = ldStream(a.v.cost + r); fix[k].b = ldStream(a.v.lower + r); fix[k].c = ldStream(a.v.upper + r);
+      fix[k].a = ldConst(a.v.cost + r); fix[k].b = ldConst(a.v.lower + r); fix[k].c = ldConst(a.v.upper + r);
       fix[k].d = ldStream(a.v.xSum + r);
       // (the diagonal of Q of a QP's prox step: in a register for the first kSlabPre columns, fetched behind the barrier for the others)
       fix[k].e = (k < kSlabPre && a.v.qdiag) ? ldStream(a.v.qdiag + r) : 0.0;
@@ -832,7 +844,7 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
         const int r = rBase + lr;
         xb[k] = ldStream(xBase + r);
         ab[k] = isLong(lr) ? ldAgent(atyBase + r) : accepted ? acc[lr] : ldStream(atyBase + r);
-        cc[k] = ldStream(a.v.cost + r); ll[k] = ldStream(a.v.lower + r); uu[k] = ldStream(a.v.upper + r); xs[k] = ldStream(a.v.xSum + r);
+        cc[k] = ldConst(a.v.cost + r); ll[k] = ldConst(a.v.lower + r); uu[k] = ldConst(a.v.upper + r); xs[k] = ldStream(a.v.xSum + r);
         qq[k] = a.v.qdiag ? ldStream(a.v.qdiag + r) : 0.0;
       }
 #pragma unroll
@@ -948,7 +960,7 @@ __global__ __launch_bounds__(kVecThreads) void k_decide_primal(const IterVecs v,
     for (int k = 0; k < kPer; ++k) {
       const int j = base + k * stride;
       const int jj = j < v.n ? j : (v.n > 0 ? v.n - 1 : 0);  // clamped, unconditional (every vector has >= 1 element)
-      cv[k] = ldStream(v.cost + jj); lv[k] = ldStream(v.lower + jj); uv[k] = ldStream(v.upper + jj);
+      cv[k] = ldConst(v.cost + jj); lv[k] = ldConst(v.lower + jj); uv[k] = ldConst(v.upper + jj);
       sv[k] = ldStream(v.xSum + jj);
       qv[k] = v.qdiag ? ldStream(v.qdiag + jj) : 0.0;
     }
@@ -1209,12 +1221,12 @@ unsigned long long* slabProf() {
             if (cnt) mean /= cnt;
             return cnt;
           };
-          for (int k = 0; k < 4; ++k) {  // rows 0..511: the streaming blocks (logical block index)
+          for (int k : {0, 1, 4, 2, 3}) {  // rows 0..511: the streaming blocks (logical block index)
             double mean, lo, hi;
             const int cnt = stat(0, 512, k, mean, lo, hi);
             if (cnt && hi > 0)
               fprintf(stderr, "slab launch %s, %d blocks, to the end of %s: mean %.2f us, fastest block %.2f, slowest %.2f\n",
-                      half ? "A'y+ (fused)" : "A x+", cnt, k == 0 ? "the stream" : k == 1 ? "the epilogue" : k == 2 ? "the grid barrier" : "the kernel",
+                      half ? "A'y+ (fused)" : "A x+", cnt, k == 0 ? "the stream" : k == 1 ? "the epilogue" : k == 4 ? "the arrival" : k == 2 ? "the grid barrier" : "the kernel",
                       mean, lo, hi);
           }
           double mean, lo, hi;  // rows 512..: the task workgroups (segment tasks of the long majors), when each was done
