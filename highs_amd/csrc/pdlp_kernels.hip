@@ -71,12 +71,15 @@ struct SpmvArgs {
 // The problem's CONSTANT vectors of the primal step (c, l, u: 24 bytes per column and iteration) are read with ordinary
 // loads: next to the two matrix copies (192 MB at 1M x 1M) they stay in the 256 MB Infinity Cache, and the tail of the
 // fused trial behind its stream — operand loads and stores of every column at once, bandwidth-bound — moves that much
-// less through HBM (round 6: config c fused launch 55.2 -> 49.8 us, b 64.6 -> 63.3, qp 40.4 -> 39.8; d, e unchanged).  The
+// less through HBM (round 6: config c fused launch 55.2 -> 49.8 us, qp 40.4 -> 39.8; d, e unchanged) — where the cache has
+// room to spare (IterVecs::constCached, pdlp_kernels.hpp constCached(): not at 1M x 1M / 8M nonzeros).  The
 // iterates and running sums, read AND written once per iteration, stay non-temporal (xSum as ordinary traffic: no gain), and
 // so do the constants of the epilogues that travel with the stream (rhs; HiPDLP's c, l, u, row bounds: 40 more bytes per
 // row / column pushed the matrices out of the cache — HiPDLP 120 -> 130-135 us per iteration).
-template <class T>
-__device__ __forceinline__ T ldConst(const T* p) { return *p; }
+// (A compile-time choice: a run-time select between the two loads of one address is merged into ONE ordinary load by the
+// compiler — the non-temporal hint is metadata — so the policy is a template parameter of the fused slab kernel.)
+template <bool CACHED, class T>
+__device__ __forceinline__ T ldConst(const T* p) { return CACHED ? *p : ldStream(p); }
 
 template <int EPI>
 struct Epi {
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
     // kAtyFused: what the NEXT primal step needs of this lane's first major and no decision can change (c, l, u)
     Pre fix{0.0, 0.0, 0.0, 0.0, 0.0};
     double keepX = 0.0, keepS = 0.0;  // x+ and (A'y+) of that major, for the step after an accepted trial
-    if (EPI == kAtyFused) { fix.a = ldConst(a.v.cost + rr); fix.b = ldConst(a.v.lower + rr); fix.c = ldConst(a.v.upper + rr); }
+    if (EPI == kAtyFused) { fix.a = ldStream(a.v.cost + rr); fix.b = ldStream(a.v.lower + rr); fix.c = ldStream(a.v.upper + rr); }
     // phase 1: kPer unit-stride loads of idx/val per lane, all issued before the
     // dependent gathers, so a wave keeps 3*kPer memory operations in flight
     const int last = cnt > 0 ? cnt - 1 : 0;  // idx/val carry one pad element
@@ -433,7 +436,7 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv(const SpmvArgs a) {
           c = fix.a; l = fix.b; u = fix.c; xs = fix.d;
         } else {            // (more than 256 majors in the block: short columns)
           xb = ldStream(xBase + r); ab = ldStream(atyBase + r);
-          c = ldConst(a.v.cost + r); l = ldConst(a.v.lower + r); u = ldConst(a.v.upper + r); xs = ldStream(a.v.xSum + r);
+          c = ldStream(a.v.cost + r); l = ldStream(a.v.lower + r); u = ldStream(a.v.upper + r); xs = ldStream(a.v.xSum + r);
         }
         if (avgWx != 0.0) stStream(a.v.xSum + r, xs + avgWx * xb);  // deferred PDHG_Update_Average (step.c:437)
         double t = xb;
@@ -483,7 +486,7 @@ constexpr int kSlabSlots = 3;  // register pipeline depth (groups of 64 entries 
 #ifndef PDLP_TWO_EXTRA
 #define PDLP_TWO_EXTRA 0
 #endif
-template <int EPI, bool TWO, int NB, int GD, bool LATE = false>
+template <int EPI, bool TWO, int NB, int GD, bool LATE = false, bool CC = false>
 __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabThreads / 256) void k_spmv_slab(const SpmvArgs a) {
   if (EPI == kAtyFused && a.st->halted) {  // keep the two state slots identical while the queue drains
     if (blockIdx.x == 0 && threadIdx.x < sizeof(DevState) / 4)
@@ -732,7 +735,7 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
     for (int k = 0; k < kFixN; ++k) {
       const int r0_ = rBase + tid + k * kSlabThreads;
       const int r = r0_ < rEnd ? r0_ : rEnd - 1;
-      fix[k].a = ldConst(a.v.cost + r); fix[k].b = ldConst(a.v.lower + r); fix[k].c = ldConst(a.v.upper + r);
+      fix[k].a = ldConst<CC>(a.v.cost + r); fix[k].b = ldConst<CC>(a.v.lower + r); fix[k].c = ldConst<CC>(a.v.upper + r);
       fix[k].d = ldStream(a.v.xSum + r);
       // (the diagonal of Q of a QP's prox step: in a register for the first kSlabPre columns, fetched behind the barrier for the others)
       fix[k].e = (k < kSlabPre && a.v.qdiag) ? ldStream(a.v.qdiag + r) : 0.0;
@@ -844,7 +847,7 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
         const int r = rBase + lr;
         xb[k] = ldStream(xBase + r);
         ab[k] = isLong(lr) ? ldAgent(atyBase + r) : accepted ? acc[lr] : ldStream(atyBase + r);
-        cc[k] = ldConst(a.v.cost + r); ll[k] = ldConst(a.v.lower + r); uu[k] = ldConst(a.v.upper + r); xs[k] = ldStream(a.v.xSum + r);
+        cc[k] = ldConst<CC>(a.v.cost + r); ll[k] = ldConst<CC>(a.v.lower + r); uu[k] = ldConst<CC>(a.v.upper + r); xs[k] = ldStream(a.v.xSum + r);
         qq[k] = a.v.qdiag ? ldStream(a.v.qdiag + r) : 0.0;
       }
 #pragma unroll
@@ -960,7 +963,7 @@ __global__ __launch_bounds__(kVecThreads) void k_decide_primal(const IterVecs v,
     for (int k = 0; k < kPer; ++k) {
       const int j = base + k * stride;
       const int jj = j < v.n ? j : (v.n > 0 ? v.n - 1 : 0);  // clamped, unconditional (every vector has >= 1 element)
-      cv[k] = ldConst(v.cost + jj); lv[k] = ldConst(v.lower + jj); uv[k] = ldConst(v.upper + jj);
+      cv[k] = ldStream(v.cost + jj); lv[k] = ldStream(v.lower + jj); uv[k] = ldStream(v.upper + jj);
       sv[k] = ldStream(v.xSum + jj);
       qv[k] = v.qdiag ? ldStream(v.qdiag + jj) : 0.0;
     }
@@ -1336,10 +1339,15 @@ void launchSpmvAtyFusedPrimal(const MatView& At, const IterVecs& v, const DevSta
   a.xcdMap = At.xcdMap; a.L = At.lng; a.A = At.csr; a.S = At.slab;
   // (LATE — twice as many columns stepped from registers behind the barrier — in the 128-register variant only: in the
   // 64-register one, which carries the task workgroups, it spills and measured slower: config d 36.5 -> 41.2 us, round 6)
-  if (At.useSlab && a.coTaskBlocks > 0)
-    hipLaunchKernelGGL((k_spmv_slab<kAtyFused, true, kSlabSlots, 1, false>), dim3(At.slab.nBlocks + a.coTaskBlocks), dim3(kSlabThreads), fusedLds(At), s, a);
-  else if (At.useSlab)
-    hipLaunchKernelGGL((k_spmv_slab<kAtyFused, false, kSlabSlots, 1, true>), dim3(At.slab.nBlocks), dim3(kSlabThreads), fusedLds(At), s, a);
+  // (CC — c, l, u of the primal step as ordinary loads — where IterVecs::constCached says the Infinity Cache has room)
+  const dim3 gridTwo(At.slab.nBlocks + a.coTaskBlocks), gridOne(At.slab.nBlocks), block(kSlabThreads);
+  if (At.useSlab && a.coTaskBlocks > 0) {
+    if (v.constCached) hipLaunchKernelGGL((k_spmv_slab<kAtyFused, true, kSlabSlots, 1, false, true>), gridTwo, block, fusedLds(At), s, a);
+    else hipLaunchKernelGGL((k_spmv_slab<kAtyFused, true, kSlabSlots, 1, false, false>), gridTwo, block, fusedLds(At), s, a);
+  } else if (At.useSlab) {
+    if (v.constCached) hipLaunchKernelGGL((k_spmv_slab<kAtyFused, false, kSlabSlots, 1, true, true>), gridOne, block, fusedLds(At), s, a);
+    else hipLaunchKernelGGL((k_spmv_slab<kAtyFused, false, kSlabSlots, 1, true, false>), gridOne, block, fusedLds(At), s, a);
+  }
   else if (At.csr.chunk == kChunkSmall)
     hipLaunchKernelGGL((k_spmv<kAtyFused, kChunkSmall>), dim3(At.csr.nBlocks), dim3(kSpmvThreads), 0, s, a);
   else

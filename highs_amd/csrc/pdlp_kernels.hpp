@@ -207,7 +207,15 @@ struct IterVecs {
   int32_t n, m;
   int32_t nEqs;       // GLOBAL count of equality rows
   int32_t rowOffset;  // global index of local row 0 (0 unless sharded)
+  // 1: c, l, u of the primal step are read with ordinary loads (they stay in the Infinity Cache next to the matrices);
+  // 0: non-temporal like every vector touched once per kernel.  Set by the solver from the operands' sizes (constCached).
+  int32_t constCached;
 };
+// The 256 MB Infinity Cache holds the two matrix copies (24 bytes per nonzero) for the whole solve; the constant vectors of
+// the primal step (24 bytes per column) join them only where that leaves room to spare: at 216 MB (1M x 1M / 8M nonzeros)
+// the fused launch gained 1.3 us and the other launch lost as much, with outliers of +7 us (round 6, measurements
+// section 14); at 176 MB (config c) the fused launch gained 5.5 us.
+inline int32_t constCached(int64_t nnz, int64_t n) { return 24 * nnz + 24 * n <= (int64_t)200 * 1000 * 1000 ? 1 : 0; }
 
 // ---- HiPDLP path (solver="hipdlp"): restarted Halpern PDHG, hipdlp/pdhg.cc:961-1018 ----------
 // Step sizes and the Halpern counter live in HBM so that a block of 40 steps replays from a

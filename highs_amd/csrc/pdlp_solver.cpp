@@ -360,6 +360,7 @@ DevSwitches DevSwitches::fromEnv() {
   w.affineTasks = dev("PDLP_MI355X_AFFINE_TASKS", 1);
   w.fusedStream = dev("PDLP_MI355X_FUSED_STREAM", 0);
   w.fusedCoTasks = dev("PDLP_MI355X_FUSED_COTASKS", -1);
+  w.constCached = dev("PDLP_MI355X_CONST_CACHED", -1);
   w.touchTail = dev("PDLP_MI355X_TOUCH_TAIL", 1);
   w.xcdLocal = dev("PDLP_MI355X_XCD_LOCAL", -1);
   w.hierBarrier = dev("PDLP_MI355X_HIER_BARRIER", -1);
@@ -912,6 +913,7 @@ void Solver::allocIterates() {
   vecs_.qdiag = qdiag_.size() ? qdiag_.get() : nullptr;
   if (hasQoff_) { vecs_.nx[0] = nx_[0].get(); vecs_.nx[1] = nx_[1].get(); }
   vecs_.n = n; vecs_.m = mLoc_; vecs_.nEqs = F_.nEqs; vecs_.rowOffset = r0_;
+  vecs_.constCached = sw_.constCached >= 0 ? (sw_.constCached != 0) : constCached(dA_.nnz, n);
   vecsCol_ = vecs_;
   for (int k = 0; k < 2; ++k) { vecsCol_.x[k] += c0_; vecsCol_.aty[k] += c0_; }
   vecsCol_.xSum += c0_; vecsCol_.cost += c0_; vecsCol_.lower += c0_; vecsCol_.upper += c0_;

@@ -29,6 +29,7 @@ struct DevSwitches {
   int affineTasks = 1;  // XCD-affine deal of the slab layout's segment tasks (0: (major, segment) order; A/B measurements)
   int fusedCoTasks = -1;  // PDLP_MI355X_FUSED_COTASKS: 0 = the fused trial's streaming blocks run the long columns' task passes themselves
   int touchTail = 1;      // PDLP_MI355X_TOUCH_TAIL=0 (development): no touching of the tail columns' operands in front of the fused trial's barrier
+  int constCached = -1;   // PDLP_MI355X_CONST_CACHED=0|1 (development): c, l, u of the primal step non-temporal / ordinary loads (default: by size)
   int fused = -1, fusedStream = 0, persistent = -1, xcdLocal = -1, hierBarrier = -1, deviceCheck = -1, checkSmall = -1;
   int primalInA = -1;     // PDLP_MI355X_PRIMAL_IN_A: the persistent loop without its P phase (pdlp_small.hip PINA); -1 = where measured faster
   int barrierTimeoutMs = 1000;  // PDLP_MI355X_BARRIER_TIMEOUT_MS: how long a grid barrier / roll call waits for missing workgroups

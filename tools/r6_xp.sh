@@ -10,14 +10,11 @@ run() { # name cfg env...
   env "$@" python bench.py --config $cfg --cpu-iters 0 2>$OUT/$name.err | line $name
   env "$@" PDLP_MI355X_SLAB_PROF=1 python bench.py --config $cfg --cpu-iters 0 2>&1 >/dev/null | grep "slab launch" | grep -E "fused" | grep -E "barrier|kernel"
 }
-for cfg in b c d e; do
-  for rep in 1 2; do
-    run ${cfg}_nt_$rep $cfg PDLP_X=0
-    run ${cfg}_plain_$rep $cfg PDLP_MI355X_LIB=$PWD/highs_amd/lib/alt/lib_ec1.so
+for cfg in b c; do
+  for rep in 1 2 3; do
+    run ${cfg}_default_$rep $cfg PDLP_X=0
+    run ${cfg}_nt_$rep $cfg PDLP_MI355X_CONST_CACHED=0
+    run ${cfg}_cached_$rep $cfg PDLP_MI355X_CONST_CACHED=1
   done
-done
-for rep in 1 2; do
-  python bench.py --solver hipdlp --cpu-iters 0 2>/dev/null | line hipdlp_nt_$rep
-  PDLP_MI355X_LIB=$PWD/highs_amd/lib/alt/lib_ec1.so python bench.py --solver hipdlp --cpu-iters 0 2>/dev/null | line hipdlp_plain_$rep
 done
 bash tools/gpu_pytest.sh $TAG/pytest tests -m gpu -q -x --timeout 600 -k "fused or bit_exact or two_large or fault or barrier or held_out"
