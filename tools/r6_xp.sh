@@ -10,11 +10,9 @@ run() { # name cfg env...
   env "$@" python bench.py --config $cfg --cpu-iters 0 2>$OUT/$name.err | line $name
   env "$@" PDLP_MI355X_SLAB_PROF=1 python bench.py --config $cfg --cpu-iters 0 2>&1 >/dev/null | grep "slab launch" | grep -E "fused" | grep -E "barrier|kernel"
 }
-for cfg in b c; do
-  for rep in 1 2 3; do
-    run ${cfg}_default_$rep $cfg PDLP_X=0
-    run ${cfg}_nt_$rep $cfg PDLP_MI355X_CONST_CACHED=0
-    run ${cfg}_cached_$rep $cfg PDLP_MI355X_CONST_CACHED=1
-  done
+for cfg in qp d e c f; do
+  run ${cfg}_nt $cfg PDLP_X=0
+  run ${cfg}_ld $cfg PDLP_MI355X_LIB=$PWD/highs_amd/lib/alt/lib_nont1.so
+  run ${cfg}_ldst $cfg PDLP_MI355X_LIB=$PWD/highs_amd/lib/alt/lib_nont2.so
 done
 bash tools/gpu_pytest.sh $TAG/pytest tests -m gpu -q -x --timeout 600 -k "fused or bit_exact or two_large or fault or barrier or held_out"
