@@ -13,6 +13,8 @@
 // reductions (tree order here, left-to-right there) differ in the last bits.
 #include "pdlp_kernels.hpp"
 
+#include <type_traits>
+
 #include <algorithm>
 #include <climits>
 #include <cmath>
@@ -486,7 +488,7 @@ constexpr int kSlabSlots = 3;  // register pipeline depth (groups of 64 entries 
 #ifndef PDLP_TWO_EXTRA
 #define PDLP_TWO_EXTRA 0
 #endif
-template <int EPI, bool TWO, int NB, int GD, bool LATE = false, bool CC = false>
+template <int EPI, bool TWO, int NB, int GD, bool LATE = false, bool CC = false, bool ULO = false>
 __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabThreads / 256) void k_spmv_slab(const SpmvArgs a) {
   if (EPI == kAtyFused && a.st->halted) {  // keep the two state slots identical while the queue drains
     if (blockIdx.x == 0 && threadIdx.x < sizeof(DevState) / 4)
@@ -566,6 +568,9 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
   constexpr int kFixN = EPI == kAtyFused ? kSlabPre + kExtra : 1;
   Pre fix[kFixN];
   double xbLate[kExtra > 0 ? kExtra : 1];  // x+ of the extra columns (the first ones': pre[k].b)
+  // bounds that ALL columns of this block share (IterVecs::colBlockUni): taken from two scalars instead of 8 / 16 bytes per column
+  const int uniB = (EPI == kAtyFused && a.v.colBlockUni) ? ldUniform(a.v.colBlockUni + blk) : 0;
+  const double lo0 = uniB ? ldUniform(a.v.colBlockBounds + 2 * blk) : 0.0, up0 = uniB ? ldUniform(a.v.colBlockBounds + 2 * blk + 1) : 0.0;  // (scalar registers)
   if (EPI == kAtyFused && kFixEarly) {
 #pragma unroll
     for (int k = 0; k < kSlabPre; ++k) {
@@ -735,7 +740,11 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
     for (int k = 0; k < kFixN; ++k) {
       const int r0_ = rBase + tid + k * kSlabThreads;
       const int r = r0_ < rEnd ? r0_ : rEnd - 1;
-      fix[k].a = ldConst<CC>(a.v.cost + r); fix[k].b = ldConst<CC>(a.v.lower + r); fix[k].c = ldConst<CC>(a.v.upper + r);
+      fix[k].a = ldConst<CC>(a.v.cost + r);
+      // (a bound that all columns of the block share: no load; ULO — ALL columns of the operand share the lower bound, the
+      // rule in LPs: no register either, the step takes the scalar)
+      if (!ULO) fix[k].b = (uniB & 1) ? lo0 : ldConst<CC>(a.v.lower + r);
+      fix[k].c = (uniB & 2) ? up0 : ldConst<CC>(a.v.upper + r);
       fix[k].d = ldStream(a.v.xSum + r);
       // (the diagonal of Q of a QP's prox step: in a register for the first kSlabPre columns, fetched behind the barrier for the others)
       fix[k].e = (k < kSlabPre && a.v.qdiag) ? ldStream(a.v.qdiag + r) : 0.0;
@@ -753,8 +762,8 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
     for (int lr0 = tid + kFixN * kSlabThreads; rBase + lr0 < rEnd && n < 8; lr0 += kSlabThreads, ++n) {
       const int r = rBase + lr0;
       asm volatile("global_load_dword %0, %1, off" : "+v"(touched) : "v"(a.v.cost + r) : "memory");
-      asm volatile("global_load_dword %0, %1, off" : "+v"(touched) : "v"(a.v.lower + r) : "memory");
-      asm volatile("global_load_dword %0, %1, off" : "+v"(touched) : "v"(a.v.upper + r) : "memory");
+      if (!(uniB & 1)) asm volatile("global_load_dword %0, %1, off" : "+v"(touched) : "v"(a.v.lower + r) : "memory");
+      if (!(uniB & 2)) asm volatile("global_load_dword %0, %1, off" : "+v"(touched) : "v"(a.v.upper + r) : "memory");
       asm volatile("global_load_dword %0, %1, off" : "+v"(touched) : "v"(a.v.xSum + r) : "memory");
       asm volatile("global_load_dword %0, %1, off" : "+v"(touched) : "v"(xNxt + r) : "memory");
     }
@@ -820,7 +829,7 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
       if (rBase + lr < rEnd) {  // (a rejected trial, 3 %, fetches x and A'y again)
         const int r = rBase + lr;
         const double ab = isLong(lr) ? ldAgent(atyBase + r) : accepted ? acc[lr] : ldStream(atyBase + r);
-        step(r, accepted ? pre[k].b : ldStream(xBase + r), ab, fix[k].a, fix[k].b, fix[k].c, fix[k].d, fix[k].e);
+        step(r, accepted ? pre[k].b : ldStream(xBase + r), ab, fix[k].a, ULO ? lo0 : fix[k].b, fix[k].c, fix[k].d, fix[k].e);
       }
     }
     if (kExtra > 0) {  // the extra columns per thread: from registers too
@@ -830,7 +839,7 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
         if (rBase + lr < rEnd) {
           const int r = rBase + lr;
           const double ab = isLong(lr) ? ldAgent(atyBase + r) : accepted ? acc[lr] : ldStream(atyBase + r);
-          step(r, accepted ? xbLate[k - kSlabPre] : ldStream(xBase + r), ab, fix[k].a, fix[k].b, fix[k].c, fix[k].d,
+          step(r, accepted ? xbLate[k - kSlabPre] : ldStream(xBase + r), ab, fix[k].a, ULO ? lo0 : fix[k].b, fix[k].c, fix[k].d,
                a.v.qdiag ? ldStream(a.v.qdiag + r) : 0.0);
         }
       }
@@ -847,7 +856,8 @@ __global__ __launch_bounds__(kSlabThreads, TWO ? 2 * kSlabThreads / 256 : kSlabT
         const int r = rBase + lr;
         xb[k] = ldStream(xBase + r);
         ab[k] = isLong(lr) ? ldAgent(atyBase + r) : accepted ? acc[lr] : ldStream(atyBase + r);
-        cc[k] = ldConst<CC>(a.v.cost + r); ll[k] = ldConst<CC>(a.v.lower + r); uu[k] = ldConst<CC>(a.v.upper + r); xs[k] = ldStream(a.v.xSum + r);
+        cc[k] = ldConst<CC>(a.v.cost + r); ll[k] = (uniB & 1) ? lo0 : ldConst<CC>(a.v.lower + r); uu[k] = (uniB & 2) ? up0 : ldConst<CC>(a.v.upper + r);
+        xs[k] = ldStream(a.v.xSum + r);
         qq[k] = a.v.qdiag ? ldStream(a.v.qdiag + r) : 0.0;
       }
 #pragma unroll
@@ -1339,15 +1349,23 @@ void launchSpmvAtyFusedPrimal(const MatView& At, const IterVecs& v, const DevSta
   a.xcdMap = At.xcdMap; a.L = At.lng; a.A = At.csr; a.S = At.slab;
   // (LATE — twice as many columns stepped from registers behind the barrier — in the 128-register variant only: in the
   // 64-register one, which carries the task workgroups, it spills and measured slower: config d 36.5 -> 41.2 us, round 6)
-  // (CC — c, l, u of the primal step as ordinary loads — where IterVecs::constCached says the Infinity Cache has room)
+  // (CC — c, l, u of the primal step as ordinary loads where IterVecs::constCached says the Infinity Cache has room; ULO —
+  // every column shares one lower bound, IterVecs::lowerUniform)
   const dim3 gridTwo(At.slab.nBlocks + a.coTaskBlocks), gridOne(At.slab.nBlocks), block(kSlabThreads);
-  if (At.useSlab && a.coTaskBlocks > 0) {
-    if (v.constCached) hipLaunchKernelGGL((k_spmv_slab<kAtyFused, true, kSlabSlots, 1, false, true>), gridTwo, block, fusedLds(At), s, a);
-    else hipLaunchKernelGGL((k_spmv_slab<kAtyFused, true, kSlabSlots, 1, false, false>), gridTwo, block, fusedLds(At), s, a);
-  } else if (At.useSlab) {
-    if (v.constCached) hipLaunchKernelGGL((k_spmv_slab<kAtyFused, false, kSlabSlots, 1, true, true>), gridOne, block, fusedLds(At), s, a);
-    else hipLaunchKernelGGL((k_spmv_slab<kAtyFused, false, kSlabSlots, 1, true, false>), gridOne, block, fusedLds(At), s, a);
-  }
+  const size_t lds = At.useSlab ? fusedLds(At) : 0;
+  auto launchTwo = [&](auto cc, auto ulo) {
+    hipLaunchKernelGGL((k_spmv_slab<kAtyFused, true, kSlabSlots, 1, false, decltype(cc)::value, decltype(ulo)::value>), gridTwo, block, lds, s, a);
+  };
+  auto launchOne = [&](auto cc, auto ulo) {
+    hipLaunchKernelGGL((k_spmv_slab<kAtyFused, false, kSlabSlots, 1, true, decltype(cc)::value, decltype(ulo)::value>), gridOne, block, lds, s, a);
+  };
+  auto pick = [&](auto&& launch) {
+    using T = std::true_type; using F = std::false_type;
+    if (v.constCached) { if (v.lowerUniform) launch(T{}, T{}); else launch(T{}, F{}); }
+    else { if (v.lowerUniform) launch(F{}, T{}); else launch(F{}, F{}); }
+  };
+  if (At.useSlab && a.coTaskBlocks > 0) pick(launchTwo);
+  else if (At.useSlab) pick(launchOne);
   else if (At.csr.chunk == kChunkSmall)
     hipLaunchKernelGGL((k_spmv<kAtyFused, kChunkSmall>), dim3(At.csr.nBlocks), dim3(kSpmvThreads), 0, s, a);
   else
@@ -1502,6 +1520,35 @@ void launchBlockSpan(const int32_t* beg, const int32_t* idx, const int32_t* wave
   if (nTiles > kSpanMaxTiles) hist = nullptr;  // (xcdTileLog2 never asks for more)
   hipLaunchKernelGGL(k_block_span, dim3(nBlocks), dim3(kVecThreads), 0, s, beg, idx, waveBeg, nBlocks, longLimit, lo, hi, cnt, tileLog2,
                      nTiles, hist);
+}
+namespace {
+__global__ __launch_bounds__(kVecThreads) void k_block_bounds(const double* __restrict__ lower, const double* __restrict__ upper,
+                                                              const int32_t* __restrict__ waveBeg, int32_t* uni, double* bounds) {
+  __shared__ int diff[2];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int r0 = waveBeg[b * 16], r1 = waveBeg[b * 16 + 16];  // (never empty)
+  if (tid < 2) diff[tid] = 0;
+  __syncthreads();
+  const long long l0 = __double_as_longlong(lower[r0]), u0 = __double_as_longlong(upper[r0]);
+  bool dl = false, du = false;
+  for (int r = r0 + tid; r < r1; r += kVecThreads) {
+    dl = dl || __double_as_longlong(lower[r]) != l0;
+    du = du || __double_as_longlong(upper[r]) != u0;
+  }
+  if (dl) diff[0] = 1;
+  if (du) diff[1] = 1;
+  __syncthreads();
+  if (tid == 0) {
+    uni[b] = (diff[0] ? 0 : 1) | (diff[1] ? 0 : 2);
+    bounds[2 * b] = lower[r0];
+    bounds[2 * b + 1] = upper[r0];
+  }
+}
+}  // namespace
+void launchBlockBounds(const double* lower, const double* upper, const int32_t* waveBeg, int32_t nBlocks, int32_t* uni, double* bounds,
+                       hipStream_t s) {
+  if (nBlocks <= 0) return;
+  hipLaunchKernelGGL(k_block_bounds, dim3(nBlocks), dim3(kVecThreads), 0, s, lower, upper, waveBeg, uni, bounds);
 }
 namespace {
 __global__ __launch_bounds__(kVecThreads) void k_add_int(int32_t* v, int32_t d, long long len) {

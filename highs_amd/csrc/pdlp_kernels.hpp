@@ -210,6 +210,13 @@ struct IterVecs {
   // 1: c, l, u of the primal step are read with ordinary loads (they stay in the Infinity Cache next to the matrices);
   // 0: non-temporal like every vector touched once per kernel.  Set by the solver from the operands' sizes (constCached).
   int32_t constCached;
+  // Round 6: where ALL columns of a block of the transposed operand's slab partition share one lower (upper) bound —
+  // x >= 0 without an upper bound is the rule in LPs, and an infinite bound stays infinite under column scaling — the
+  // fused trial's tail takes the value from here instead of loading it per column: colBlockUni[b] bit 0 = lower, bit 1 =
+  // upper uniform in logical block b, colBlockBounds[2 b], [2 b + 1] the values (launchBlockBounds; nullptr: none).
+  const int32_t* colBlockUni;
+  const double* colBlockBounds;
+  int32_t lowerUniform;  // every block's bit 0 is set and the values agree: the fused slab kernel's ULO instantiation
 };
 // The 256 MB Infinity Cache holds the two matrix copies (24 bytes per nonzero) for the whole solve; the constant vectors of
 // the primal step (24 bytes per column) join them only where that leaves room to spare: at 216 MB (1M x 1M / 8M nonzeros)
@@ -432,6 +439,10 @@ void launchAddInt(int32_t* v, int32_t d, int64_t len, hipStream_t s);  // v[i] +
 // lo/hi/cnt [nBlocks]: column span and entry count of each slab block's short majors (INT_MAX / -1 / 0 for a block without
 // any); hist (nullptr: none) [8 * nTiles], zeroed by the caller: entries per (XCD of the contiguous map, tile of 2^tileLog2
 // minors) — which XCD's streaming blocks gather from which stretch of the vector (pdlp_host.hpp xcdTileOwners)
+// uni[b] / bounds[2 b .. 2 b + 1] of IterVecs::colBlockUni / colBlockBounds for the nBlocks logical blocks of a slab
+// partition (waveBeg: its prefix array of majors, 16 waves per block): equality of the bit patterns, so -0.0 != 0.0
+void launchBlockBounds(const double* lower, const double* upper, const int32_t* waveBeg, int32_t nBlocks, int32_t* uni, double* bounds,
+                       hipStream_t s);
 void launchBlockSpan(const int32_t* beg, const int32_t* idx, const int32_t* waveBeg, int32_t nBlocks, int32_t longLimit, int32_t* lo,
                      int32_t* hi, int32_t* cnt, int32_t tileLog2, int32_t nTiles, int32_t* hist, hipStream_t s);
 

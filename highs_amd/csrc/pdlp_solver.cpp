@@ -360,6 +360,7 @@ DevSwitches DevSwitches::fromEnv() {
   w.affineTasks = dev("PDLP_MI355X_AFFINE_TASKS", 1);
   w.fusedStream = dev("PDLP_MI355X_FUSED_STREAM", 0);
   w.fusedCoTasks = dev("PDLP_MI355X_FUSED_COTASKS", -1);
+  w.uniformBounds = dev("PDLP_MI355X_UNIFORM_BOUNDS", 1);
   w.constCached = dev("PDLP_MI355X_CONST_CACHED", -1);
   w.touchTail = dev("PDLP_MI355X_TOUCH_TAIL", 1);
   w.xcdLocal = dev("PDLP_MI355X_XCD_LOCAL", -1);
@@ -682,6 +683,23 @@ void Solver::construct(const pdlp_problem_t& P, const void* id128) {
       hierBar_ = !smallChunks || (sw_.hierBarrier >= 0 ? sw_.hierBarrier != 0 : g > 64);
     }
     if (fused_) gridBar_.alloc(gridBarWords(fusedAtyBlocks(at)));
+    if (fused_ && at.useSlab && sw_.uniformBounds != 0) {
+      // bounds that all columns of a block of the fused launch share (x >= 0 without an upper bound is the rule): two scalars
+      // per block instead of 8 / 16 bytes per column in the launch's bandwidth-bound tail (IterVecs::colBlockUni)
+      colBlockUni_.alloc((size_t)at.slab.nBlocks);
+      colBlockBounds_.alloc((size_t)at.slab.nBlocks * 2);
+      launchBlockBounds(lower_.get(), upper_.get(), at.slab.waveBeg, at.slab.nBlocks, colBlockUni_.get(), colBlockBounds_.get(), stream_);
+      std::vector<int32_t> uni((size_t)at.slab.nBlocks);
+      std::vector<double> bnd((size_t)at.slab.nBlocks * 2);
+      colBlockUni_.download(uni.data(), uni.size(), stream_);
+      colBlockBounds_.download(bnd.data(), bnd.size(), stream_);
+      PDLP_HIP(hipStreamSynchronize(stream_));
+      bool allLower = true;  // (bit patterns: the kernel's ULO instantiation takes ONE scalar for all columns)
+      for (size_t b = 0; b < uni.size(); ++b) allLower = allLower && (uni[b] & 1) && memcmp(&bnd[2 * b], &bnd[0], sizeof(double)) == 0;
+      for (IterVecs* v : {&vecs_, &vecsCol_, &vecsAty_}) {
+        v->colBlockUni = colBlockUni_.get(); v->colBlockBounds = colBlockBounds_.get(); v->lowerUniform = allLower ? 1 : 0;
+      }
+    }
     if (persistent_) gridBar_.alloc(smallBarWords(smallGrid_));
     // Netlib-class LPs (at most 64 workgroups): the check iteration as one launch too (PDLP_MI355X_CHECK_SMALL=0: ten launches)
     checkSmall_ = persistent_ && smallGrid_ <= 64 && sw_.checkSmall != 0 && checkSmallResident(dA_.view(), at, opt_.device) >= smallGrid_;

@@ -29,6 +29,7 @@ struct DevSwitches {
   int affineTasks = 1;  // XCD-affine deal of the slab layout's segment tasks (0: (major, segment) order; A/B measurements)
   int fusedCoTasks = -1;  // PDLP_MI355X_FUSED_COTASKS: 0 = the fused trial's streaming blocks run the long columns' task passes themselves
   int touchTail = 1;      // PDLP_MI355X_TOUCH_TAIL=0 (development): no touching of the tail columns' operands in front of the fused trial's barrier
+  int uniformBounds = 1;  // PDLP_MI355X_UNIFORM_BOUNDS=0 (development): the fused trial loads l and u of every column even where a block's columns share them
   int constCached = -1;   // PDLP_MI355X_CONST_CACHED=0|1 (development): c, l, u of the primal step non-temporal / ordinary loads (default: by size)
   int fused = -1, fusedStream = 0, persistent = -1, xcdLocal = -1, hierBarrier = -1, deviceCheck = -1, checkSmall = -1;
   int primalInA = -1;     // PDLP_MI355X_PRIMAL_IN_A: the persistent loop without its P phase (pdlp_small.hip PINA); -1 = where measured faster
@@ -228,6 +229,8 @@ class Solver : public SolverBase {
   int smallMode() const { return xcdLocal_ ? 1 : hierBar_ ? 2 : 0; }
   int32_t smallGrid_ = 0;
   DeviceArray<unsigned long long> gridBar_;
+  DeviceArray<int32_t> colBlockUni_;     // IterVecs::colBlockUni / colBlockBounds (fused slab launch)
+  DeviceArray<double> colBlockBounds_;
   int32_t barrierFallbacks_ = 0, smallLaunches_ = 0;
   unsigned long long smallSeq_ = 0;  // persistent launches since gridBar_ was zeroed (their roll call counts cumulatively)
   // (barrier rounds of the contexts of one device: ordered on the DEVICE by an event chain, see pdlp_solver.cpp)
