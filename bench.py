@@ -429,6 +429,9 @@ def main():
         dom_name, dom_ms, dom_bytes = "trials_persistent(per trial)", ms_step * st.iters / max(int(st.trials), 1), b_iter
     # what the two launches really have to move (needed_bytes) next to SURVEY's per-operation formula
     nb_ax, nb_aty = needed_bytes(n, m, nnz, fused, bool(cfg.get("qp")))
+    if fused:  # bounds that all columns of a block share are not loaded per column (round 6): 8 bytes less for each of them
+        ub = S.stage("uniform_bound_columns")
+        nb_aty -= 8 * int(ub[0] + ub[1])
     if args.solver != "pdlp":  # (the Halpern launches: their formula already counts what the fused kernels move)
         nb_ax, nb_aty = b_ax, b_aty
     dom_needed = b_iter if persistent else nb_ax if dom_name == "spmv_ax_dual" else nb_aty

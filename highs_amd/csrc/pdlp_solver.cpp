@@ -696,6 +696,17 @@ void Solver::construct(const pdlp_problem_t& P, const void* id128) {
       PDLP_HIP(hipStreamSynchronize(stream_));
       bool allLower = true;  // (bit patterns: the kernel's ULO instantiation takes ONE scalar for all columns)
       for (size_t b = 0; b < uni.size(); ++b) allLower = allLower && (uni[b] & 1) && memcmp(&bnd[2 * b], &bnd[0], sizeof(double)) == 0;
+      {  // (for bench.py's needed bytes: how many columns' lower / upper bounds the fused launch does not load)
+        std::vector<int32_t> wb((size_t)at.slab.nBlocks * kSlabWavesPerBlock + 1);
+        PDLP_HIP(hipMemcpyAsync(wb.data(), at.slab.waveBeg, wb.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+        PDLP_HIP(hipStreamSynchronize(stream_));
+        uniLowerCols_ = uniUpperCols_ = 0;
+        for (size_t b = 0; b < uni.size(); ++b) {
+          const int64_t cols = wb[(b + 1) * kSlabWavesPerBlock] - wb[b * kSlabWavesPerBlock];
+          if (uni[b] & 1) uniLowerCols_ += cols;
+          if (uni[b] & 2) uniUpperCols_ += cols;
+        }
+      }
       for (IterVecs* v : {&vecs_, &vecsCol_, &vecsAty_}) {
         v->colBlockUni = colBlockUni_.get(); v->colBlockBounds = colBlockBounds_.get(); v->lowerUniform = allLower ? 1 : 0;
       }
@@ -2097,6 +2108,8 @@ void Solver::stage(const std::string& name, double* out, int32_t cap) {
     put(0, !devCheck_ ? 0.0 : sharded_ ? (mesh_ && mesh_->args().fusedWait == 2 ? 14.0 : 26.0) : persistent_ && checkSmall_ ? 1.0 : 10.0);
   } else if (name == "barrier_fallbacks") {  // times a launch with grid barriers gave up and the loop went on with plain launches
     put(0, (double)barrierFallbacks_);
+  } else if (name == "uniform_bound_columns") {  // columns whose lower / upper bound the fused launch takes from a scalar of their block
+    put(0, (double)uniLowerCols_); put(1, (double)uniUpperCols_);
   } else if (name == "exchange") {  // 0 = not sharded, 1 = RCCL all-reduce, 2 = direct xGMI mesh (partials), 3 = mesh, two all-gathers
     put(0, !sharded_ ? 0.0 : !meshMode_ ? 1.0 : colblock_ ? 3.0 : 2.0);
   } else if (name == "residuals") {

@@ -231,6 +231,7 @@ class Solver : public SolverBase {
   DeviceArray<unsigned long long> gridBar_;
   DeviceArray<int32_t> colBlockUni_;     // IterVecs::colBlockUni / colBlockBounds (fused slab launch)
   DeviceArray<double> colBlockBounds_;
+  int64_t uniLowerCols_ = 0, uniUpperCols_ = 0;  // columns covered by a block-wide lower / upper bound (stage "uniform_bound_columns")
   int32_t barrierFallbacks_ = 0, smallLaunches_ = 0;
   unsigned long long smallSeq_ = 0;  // persistent launches since gridBar_ was zeroed (their roll call counts cumulatively)
   // (barrier rounds of the contexts of one device: ordered on the DEVICE by an event chain, see pdlp_solver.cpp)
